@@ -1,0 +1,75 @@
+#!/usr/bin/env python3
+"""Regenerate tests/golden/ from the reference checkout.
+
+The reference (sourmash @ /root/reference) cannot be imported or built in this
+image (Rust core, no cargo; no cffi/screed wheels -- SURVEY.md section 8c), so
+the golden vectors are the reference's OWN committed fixtures: input FASTA files
+together with the signatures the reference produced from them, and the
+signature collections its tests assert exact results on.  This script copies
+those data files verbatim (no source code) and records where each came from in
+MANIFEST.json.  Run from the repo root inside the build container:
+
+    python tests/golden/make_golden.py
+
+/root/reference does not exist on the GPU box; tests only read tests/golden/.
+"""
+import hashlib
+import json
+import os
+import shutil
+import sys
+
+REF = os.environ.get("SOURMASH_REFERENCE", "/root/reference")
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+# (source path under REF, destination under tests/golden, why / which reference test pins it)
+FILES = [
+    ("data/GCF_000005845.2_ASM584v2_genomic.fna.gz", "ecoli/GCF_000005845.2_ASM584v2_genomic.fna.gz",
+     "BASELINE config C1 input (E. coli K-12)"),
+    ("tests/test-data/GCF_000005845.2_ASM584v2_genomic.fna.gz.sig", "ecoli/GCF_000005845.2_ASM584v2_genomic.fna.gz.sig",
+     "reference sketch of the above: k=21/31/51 scaled=1000 (k=31: 4476 hashes, md5 0a8632c6...)"),
+    ("data/GCF_000006945.1_ASM694v1_genomic.fna.gz", "scaled100/GCF_000006945.1_ASM694v1_genomic.fna.gz",
+     "second genome, input"),
+    ("tests/test-data/scaled100/GCF_000006945.1_ASM694v1_genomic.fna.gz.sig.gz",
+     "scaled100/GCF_000006945.1_ASM694v1_genomic.fna.gz.sig.gz", "reference sketch k=21 scaled=100 (48504 hashes)"),
+    ("tests/test-data/scaled100/GCF_000005845.2_ASM584v2_genomic.fna.gz.sig.gz",
+     "scaled100/GCF_000005845.2_ASM584v2_genomic.fna.gz.sig.gz",
+     "reference sketch of the E. coli genome k=21 scaled=100 (45577 hashes); tests/test_jaccard.py:207-232"),
+    ("tests/test-data/genome-s10.fa.gz", "num/genome-s10.fa.gz", "input for the num (bottom-k) sketch"),
+    ("tests/test-data/genome-s10.fa.gz.sig", "num/genome-s10.fa.gz.sig", "reference sketch k=21/30 num=500 (+protein)"),
+    ("tests/test-data/ecoli.genes.fna", "genes/ecoli.genes.fna", "tests/test_sourmash_compute.py:858-897 input"),
+    ("tests/test-data/benchmark.dna.sig", "genes/benchmark.dna.sig",
+     "independent mmh3 restatement output (utils/compute-dna-mh-another-way.py)"),
+    ("tests/test-data/47.fa.sig", "pairs/47.fa.sig", "tests/test_jaccard.py:175-232"),
+    ("tests/test-data/63.fa.sig", "pairs/63.fa.sig", "tests/test_jaccard.py:175-232"),
+    ("tests/test-data/track_abund/47.fa.sig", "pairs/track_abund_47.fa.sig", "abundance sketches (angular similarity)"),
+    ("tests/test-data/track_abund/63.fa.sig", "pairs/track_abund_63.fa.sig", "abundance sketches (angular similarity)"),
+]
+for name in ["SRR2060939_1", "SRR2060939_2", "SRR2241509_1", "SRR2255622_1", "SRR453566_1", "SRR453569_1", "SRR453570_1"]:
+    FILES.append((f"tests/test-data/demo/{name}.sig", f"demo/{name}.sig", "tests/test_compare.py:48-63 7x7 matrix"))
+for name in ["GCF_000006945.2_ASM694v2", "GCF_000007545.1_ASM754v1", "GCF_000008105.1_ASM810v1",
+             "GCF_000008545.1_ASM854v1", "GCF_000009085.1_ASM908v1", "GCF_000009505.1_ASM950v1",
+             "GCF_000009525.1_ASM952v1", "GCF_000011885.1_ASM1188v1", "GCF_000016045.1_ASM1604v1",
+             "GCF_000016785.1_ASM1678v1", "GCF_000018945.1_ASM1894v1", "GCF_000195995.1_ASM19599v1"]:
+    FILES.append((f"tests/test-data/gather/{name}_genomic.fna.gz.sig", f"gather/{name}_genomic.fna.gz.sig",
+                  "tests/test_index_protocol.py:1057-1097 golden gather"))
+FILES.append(("tests/test-data/gather/combined.sig", "gather/combined.sig", "golden gather query"))
+
+
+def main():
+    manifest = []
+    for src, dst, why in FILES:
+        s = os.path.join(REF, src)
+        d = os.path.join(HERE, dst)
+        os.makedirs(os.path.dirname(d), exist_ok=True)
+        shutil.copyfile(s, d)
+        with open(d, "rb") as fh:
+            sha = hashlib.sha256(fh.read()).hexdigest()
+        manifest.append({"file": dst, "reference_path": src, "sha256": sha, "pins": why})
+    with open(os.path.join(HERE, "MANIFEST.json"), "w") as fh:
+        json.dump(manifest, fh, indent=1)
+    print(f"copied {len(manifest)} fixtures", file=sys.stderr)
+
+
+if __name__ == "__main__":
+    main()
