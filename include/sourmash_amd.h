@@ -1,0 +1,273 @@
+/*
+ * sourmash_amd.h -- C-ABI of libsourmash_amd.so, the MI355X-native FracMinHash engine.
+ *
+ * PART 1 is a drop-in for the hot-path subset of the reference's cffi boundary
+ * (reference header: include/sourmash.h, generated from the Rust shims under src/core/src/ffi/).
+ * Every declaration has the reference's name, argument order, ownership rule
+ * and error convention; the comment on each group cites the reference lines it
+ * replaces.  A maintainer switches the path over by loading this library where
+ * `sourmash._lowlevel.lib` is loaded today.
+ *
+ * PART 2 are additive batch entry points (prefix smgpu_) that collapse the
+ * reference's per-record / per-pair / per-round Python loops into single calls
+ * on device-resident data.  Plain pointers and sizes only -- no torch types.
+ *
+ * Error convention (src/core/src/ffi/utils.rs:17-19,58-83,195-207;
+ * src/sourmash/utils.py:65-78): a fallible function stores its error in
+ * thread-local state and returns an all-zero value; callers bracket calls with
+ * sourmash_err_clear() / sourmash_err_get_last_code().  There is NO CPU
+ * fallback: k-mer hashing and sketch intersection run on the GPU or fail with
+ * SOURMASH_ERROR_CODE_INTERNAL.
+ */
+#ifndef SOURMASH_AMD_H_INCLUDED
+#define SOURMASH_AMD_H_INCLUDED
+
+#include <stdarg.h>
+#include <stdbool.h>
+#include <stdint.h>
+#include <stdlib.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ======================= PART 1: reference-compatible ABI ======================= */
+
+/* include/sourmash.h:11-17 (src/core/src/ffi/mod.rs:33-68) */
+/* (anonymous enum + integer typedef: identical ABI to the reference's `enum X {..}; typedef uint32_t X;`,
+ * and also valid C++) */
+enum {
+  HASH_FUNCTIONS_MURMUR64_DNA = 1,
+  HASH_FUNCTIONS_MURMUR64_PROTEIN = 2,
+  HASH_FUNCTIONS_MURMUR64_DAYHOFF = 3,
+  HASH_FUNCTIONS_MURMUR64_HP = 4,
+};
+typedef uint32_t HashFunctions;
+
+/* include/sourmash.h:19-53 (src/core/src/errors.rs:101-143) -- values are ABI */
+enum {
+  SOURMASH_ERROR_CODE_NO_ERROR = 0,
+  SOURMASH_ERROR_CODE_PANIC = 1,
+  SOURMASH_ERROR_CODE_INTERNAL = 2,
+  SOURMASH_ERROR_CODE_MSG = 3,
+  SOURMASH_ERROR_CODE_UNKNOWN = 4,
+  SOURMASH_ERROR_CODE_MISMATCH_K_SIZES = 101,
+  SOURMASH_ERROR_CODE_MISMATCH_DNA_PROT = 102,
+  SOURMASH_ERROR_CODE_MISMATCH_SCALED = 103,
+  SOURMASH_ERROR_CODE_MISMATCH_SEED = 104,
+  SOURMASH_ERROR_CODE_MISMATCH_SIGNATURE_TYPE = 105,
+  SOURMASH_ERROR_CODE_NON_EMPTY_MIN_HASH = 106,
+  SOURMASH_ERROR_CODE_MISMATCH_NUM = 107,
+  SOURMASH_ERROR_CODE_NEEDS_ABUNDANCE_TRACKING = 108,
+  SOURMASH_ERROR_CODE_CANNOT_UPSAMPLE_SCALED = 109,
+  SOURMASH_ERROR_CODE_NO_MIN_HASH_FOUND = 110,
+  SOURMASH_ERROR_CODE_EMPTY_SIGNATURE = 111,
+  SOURMASH_ERROR_CODE_MULTIPLE_SKETCHES_FOUND = 112,
+  SOURMASH_ERROR_CODE_INVALID_DNA = 1101,
+  SOURMASH_ERROR_CODE_INVALID_PROT = 1102,
+  SOURMASH_ERROR_CODE_INVALID_CODON_LENGTH = 1103,
+  SOURMASH_ERROR_CODE_INVALID_HASH_FUNCTION = 1104,
+  SOURMASH_ERROR_CODE_READ_DATA = 1201,
+  SOURMASH_ERROR_CODE_STORAGE = 1202,
+  SOURMASH_ERROR_CODE_HLL_PRECISION_BOUNDS = 1301,
+  SOURMASH_ERROR_CODE_ANI_ESTIMATION_ERROR = 1401,
+  SOURMASH_ERROR_CODE_IO = 100001,
+  SOURMASH_ERROR_CODE_UTF8_ERROR = 100002,
+  SOURMASH_ERROR_CODE_PARSE_INT = 100003,
+  SOURMASH_ERROR_CODE_SERDE_ERROR = 100004,
+  SOURMASH_ERROR_CODE_NIFFLER_ERROR = 100005,
+  SOURMASH_ERROR_CODE_CSV_ERROR = 100006,
+  SOURMASH_ERROR_CODE_ROCKS_DB_ERROR = 100007,
+};
+typedef uint32_t SourmashErrorCode;
+
+/* opaque handles, include/sourmash.h:55-69: created by *_new / *_from_params,
+ * owned by the caller, released by *_free (NULL tolerated, ffi/utils.rs:50-55) */
+typedef struct SourmashComputeParameters SourmashComputeParameters;
+typedef struct SourmashKmerMinHash SourmashKmerMinHash;
+typedef struct SourmashSignature SourmashSignature;
+
+/* include/sourmash.h:74-87 (ffi/utils.rs:209-316) */
+typedef struct {
+  char *data;
+  uintptr_t len;
+  bool owned;
+} SourmashStr;
+
+/* ---- library / errors: include/sourmash.h:416-467 (ffi/utils.rs:85-193) ---- */
+void sourmash_init(void);
+void sourmash_err_clear(void);
+SourmashErrorCode sourmash_err_get_last_code(void);
+SourmashStr sourmash_err_get_last_message(void);
+SourmashStr sourmash_err_get_backtrace(void);
+void sourmash_str_free(SourmashStr *s);
+SourmashStr sourmash_str_from_cstr(const char *s);
+
+/* ---- include/sourmash.h:133 (ffi/mod.rs:22-31; lib.rs:57-59): MurmurHash3_x64_128 h1 ---- */
+uint64_t hash_murmur(const char *kmer, uint64_t seed);
+
+/* ---- compute parameters: include/sourmash.h:89-131 (ffi/cmd/compute.rs:1-170) ---- */
+SourmashComputeParameters *computeparams_new(void);
+void computeparams_free(SourmashComputeParameters *ptr);
+bool computeparams_dayhoff(const SourmashComputeParameters *ptr);
+bool computeparams_dna(const SourmashComputeParameters *ptr);
+bool computeparams_hp(const SourmashComputeParameters *ptr);
+bool computeparams_protein(const SourmashComputeParameters *ptr);
+bool computeparams_track_abundance(const SourmashComputeParameters *ptr);
+const uint32_t *computeparams_ksizes(const SourmashComputeParameters *ptr, uintptr_t *size);
+void computeparams_ksizes_free(uint32_t *ptr, uintptr_t insize);
+uint32_t computeparams_num_hashes(const SourmashComputeParameters *ptr);
+uint64_t computeparams_scaled(const SourmashComputeParameters *ptr);
+uint64_t computeparams_seed(const SourmashComputeParameters *ptr);
+void computeparams_set_dayhoff(SourmashComputeParameters *ptr, bool v);
+void computeparams_set_dna(SourmashComputeParameters *ptr, bool v);
+void computeparams_set_hp(SourmashComputeParameters *ptr, bool v);
+void computeparams_set_protein(SourmashComputeParameters *ptr, bool v);
+void computeparams_set_track_abundance(SourmashComputeParameters *ptr, bool v);
+void computeparams_set_ksizes(SourmashComputeParameters *ptr, const uint32_t *ksizes_ptr, uintptr_t insize);
+void computeparams_set_num_hashes(SourmashComputeParameters *ptr, uint32_t num);
+void computeparams_set_scaled(SourmashComputeParameters *ptr, uint64_t scaled);
+void computeparams_set_seed(SourmashComputeParameters *ptr, uint64_t new_seed);
+
+/* ---- sketch object: include/sourmash.h:169-273 (ffi/minhash.rs:1-483) ---- */
+SourmashKmerMinHash *kmerminhash_new(uint64_t scaled, uint32_t k, HashFunctions hash_function, uint64_t seed,
+                                     bool track_abundance, uint32_t n);
+void kmerminhash_free(SourmashKmerMinHash *ptr);
+void kmerminhash_slice_free(uint64_t *ptr, uintptr_t insize);
+/* HOT: sequence -> k-mers -> canonical -> murmur -> keep (signature.rs:38-58,246-306). NUL-terminated. */
+void kmerminhash_add_sequence(SourmashKmerMinHash *ptr, const char *sequence, bool force);
+const uint64_t *kmerminhash_seq_to_hashes(SourmashKmerMinHash *ptr, const char *sequence, uintptr_t insize,
+                                          bool force, bool bad_kmers_as_zeroes, bool is_protein, uintptr_t *size);
+void kmerminhash_add_hash(SourmashKmerMinHash *ptr, uint64_t h);
+void kmerminhash_add_hash_with_abundance(SourmashKmerMinHash *ptr, uint64_t h, uint64_t abundance);
+void kmerminhash_add_many(SourmashKmerMinHash *ptr, const uint64_t *hashes_ptr, uintptr_t insize);
+void kmerminhash_add_from(SourmashKmerMinHash *ptr, const SourmashKmerMinHash *other);
+void kmerminhash_add_word(SourmashKmerMinHash *ptr, const char *word);
+void kmerminhash_add_protein(SourmashKmerMinHash *ptr, const char *sequence);   /* out of scope: raises */
+void kmerminhash_remove_hash(SourmashKmerMinHash *ptr, uint64_t h);
+void kmerminhash_remove_many(SourmashKmerMinHash *ptr, const uint64_t *hashes_ptr, uintptr_t insize);
+void kmerminhash_remove_from(SourmashKmerMinHash *ptr, const SourmashKmerMinHash *other);
+void kmerminhash_clear(SourmashKmerMinHash *ptr);
+const uint64_t *kmerminhash_get_mins(const SourmashKmerMinHash *ptr, uintptr_t *size);
+uintptr_t kmerminhash_get_mins_size(const SourmashKmerMinHash *ptr);
+const uint64_t *kmerminhash_get_abunds(SourmashKmerMinHash *ptr, uintptr_t *size);
+void kmerminhash_set_abundances(SourmashKmerMinHash *ptr, const uint64_t *hashes_ptr, const uint64_t *abunds_ptr,
+                                uintptr_t insize, bool clear);
+SourmashStr kmerminhash_md5sum(const SourmashKmerMinHash *ptr);
+void kmerminhash_merge(SourmashKmerMinHash *ptr, const SourmashKmerMinHash *other);
+bool kmerminhash_is_compatible(const SourmashKmerMinHash *ptr, const SourmashKmerMinHash *other);
+/* HOT: sorted-u64 merge intersections (minhash.rs:539-631,635-702,915-953,1721-1807) */
+uint64_t kmerminhash_count_common(const SourmashKmerMinHash *ptr, const SourmashKmerMinHash *other, bool downsample);
+SourmashKmerMinHash *kmerminhash_intersection(const SourmashKmerMinHash *ptr, const SourmashKmerMinHash *other);
+uint64_t kmerminhash_intersection_union_size(const SourmashKmerMinHash *ptr, const SourmashKmerMinHash *other,
+                                             uint64_t *union_size);
+double kmerminhash_jaccard(const SourmashKmerMinHash *ptr, const SourmashKmerMinHash *other);
+double kmerminhash_similarity(const SourmashKmerMinHash *ptr, const SourmashKmerMinHash *other,
+                              bool ignore_abundance, bool downsample);
+double kmerminhash_angular_similarity(const SourmashKmerMinHash *ptr, const SourmashKmerMinHash *other);
+uint32_t kmerminhash_num(const SourmashKmerMinHash *ptr);
+uint32_t kmerminhash_ksize(const SourmashKmerMinHash *ptr);
+uint64_t kmerminhash_seed(const SourmashKmerMinHash *ptr);
+uint64_t kmerminhash_max_hash(const SourmashKmerMinHash *ptr);
+HashFunctions kmerminhash_hash_function(const SourmashKmerMinHash *ptr);
+void kmerminhash_hash_function_set(SourmashKmerMinHash *ptr, HashFunctions hash_function);
+bool kmerminhash_is_protein(const SourmashKmerMinHash *ptr);
+bool kmerminhash_dayhoff(const SourmashKmerMinHash *ptr);
+bool kmerminhash_hp(const SourmashKmerMinHash *ptr);
+bool kmerminhash_track_abundance(const SourmashKmerMinHash *ptr);
+void kmerminhash_enable_abundance(SourmashKmerMinHash *ptr);
+void kmerminhash_disable_abundance(SourmashKmerMinHash *ptr);
+
+/* ---- signature container: include/sourmash.h:364-414 (ffi/signature.rs:1-344) ---- */
+SourmashSignature *signature_new(void);
+void signature_free(SourmashSignature *ptr);
+SourmashSignature *signature_from_params(const SourmashComputeParameters *ptr);
+uintptr_t signature_len(const SourmashSignature *ptr);
+/* HOT: fans the record out over every sketch of the signature (signature.rs:661-677) */
+void signature_add_sequence(SourmashSignature *ptr, const char *sequence, bool force);
+void signature_add_protein(SourmashSignature *ptr, const char *sequence);       /* out of scope: raises */
+void signature_set_name(SourmashSignature *ptr, const char *name);
+void signature_set_filename(SourmashSignature *ptr, const char *name);
+SourmashStr signature_get_name(const SourmashSignature *ptr);
+SourmashStr signature_get_filename(const SourmashSignature *ptr);
+SourmashStr signature_get_license(const SourmashSignature *ptr);
+SourmashKmerMinHash *signature_first_mh(const SourmashSignature *ptr);
+SourmashKmerMinHash **signature_get_mhs(const SourmashSignature *ptr, uintptr_t *size);
+void signature_set_mh(SourmashSignature *ptr, const SourmashKmerMinHash *other);
+void signature_push_mh(SourmashSignature *ptr, const SourmashKmerMinHash *other);
+bool signature_eq(const SourmashSignature *ptr, const SourmashSignature *other);
+SourmashStr signature_save_json(const SourmashSignature *ptr);
+SourmashSignature **signatures_load_buffer(const char *ptr, uintptr_t insize, bool _ignore_md5sum, uintptr_t ksize,
+                                           const char *select_moltype, uintptr_t *size);
+SourmashSignature **signatures_load_path(const char *ptr, bool _ignore_md5sum, uintptr_t ksize,
+                                         const char *select_moltype, uintptr_t *size);
+const uint8_t *signatures_save_buffer(const SourmashSignature *const *ptr, uintptr_t size, uint8_t compression,
+                                      uintptr_t *osize);
+/* generic byte-buffer free (src/sourmash/signature.py:514 frees signatures_save_buffer output with it) */
+void nodegraph_buffer_free(uint8_t *ptr, uintptr_t insize);
+
+/* ============================ PART 2: batch extensions ============================ */
+/* Same conventions (TLS error, zero on failure).  "d_" pointers are device
+ * pointers valid on the current HIP device; `stream` is a hipStream_t passed as
+ * void* (NULL = the null stream).  None of the *_raw functions allocates or
+ * synchronises unless stated. */
+
+/* number of visible HIP devices (0 when none / no driver); never fails */
+int32_t smgpu_device_count(void);
+/* 1 if the k-mer / intersection kernels can run in this process */
+bool smgpu_available(void);
+
+/* Collapses the per-record loop of src/sourmash/command_sketch.py:746-768 +
+ * src/core/src/signature.rs:38-58: sketch a whole buffer (records separated by any
+ * byte outside ACGTacgt, e.g. '\n'; no NUL needed) into `ptr`. */
+void smgpu_minhash_add_buffer(SourmashKmerMinHash *ptr, const char *buf, uintptr_t len, bool force);
+
+/* Scratch size needed by smgpu_sketch_dna_raw for an output capacity. */
+uint64_t smgpu_sketch_workspace_bytes(uint64_t out_capacity);
+/* Device-resident sketching: d_seq[0,len) ASCII (16-byte aligned) -> sorted unique
+ * kept hashes (1 <= h <= max_hash; max_hash 0 = keep all) in d_out[0, n).
+ * d_result (device, 2 x u64): [0] kept k-mer occurrences, [1] unique hashes n.
+ * Synchronises the stream once (the sort needs the kept count).  Returns n, or
+ * UINT64_MAX with an error set; if kept > out_capacity the error says so and the
+ * caller retries with a larger buffer. */
+uint64_t smgpu_sketch_dna_raw(const uint8_t *d_seq, uint64_t len, uint32_t ksize, uint64_t seed, uint64_t max_hash,
+                              uint64_t *d_out, uint64_t out_capacity, uint64_t *d_result, void *d_workspace,
+                              uint64_t workspace_bytes, void *stream);
+/* Only the k-mer kernel (no sort): appends kept hashes unordered to d_out, adds the
+ * count to *d_count (device u64, caller zeroes).  Fully asynchronous. */
+void smgpu_sketch_dna_kernel_raw(const uint8_t *d_seq, uint64_t len, uint32_t ksize, uint64_t seed, uint64_t max_hash,
+                                 uint64_t *d_out, uint64_t out_capacity, uint64_t *d_count, void *stream);
+/* Synthetic random DNA written straight into HBM (BASELINE config C2 generator). */
+void smgpu_synth_dna_raw(uint8_t *d_out, uint64_t start, uint64_t n, uint64_t seed, uint64_t record_len, void *stream);
+
+/* Collapses compare_all_pairs (src/sourmash/compare.py:14-64,328-358): CSR of n
+ * sorted sketches on device -> u32 common[(row_hi-row_lo)][n] and/or f64
+ * jaccard[(row_hi-row_lo)][n] for rows [row_lo,row_hi).  Either output may be NULL
+ * (d_common is required as scratch if d_jaccard is given).  Asynchronous. */
+void smgpu_compare_raw(const uint64_t *d_hashes, const uint64_t *d_offsets, uint32_t n, uint32_t row_lo,
+                       uint32_t row_hi, uint32_t *d_common, double *d_jaccard, void *stream);
+/* Host convenience: n sketch handles -> n x n matrices on the host (either may be NULL). */
+void smgpu_compare_all_pairs(const SourmashKmerMinHash *const *mhs, uintptr_t n, uint32_t *common_out,
+                             double *jaccard_out);
+
+/* Gather primitives (src/sourmash/index/__init__.py:735-909):
+ *   overlap:  d_overlap[d] = |Q ∩ D_d| (op 0, CounterGather.add) or
+ *             d_overlap[d] -= |Q ∩ D_d| saturating (op 1, CounterGather.consume)
+ *   argmax:   *d_best = max(*d_best, (count << 32) | ~(index_base + d)): highest count,
+ *             ties to the lowest index (Counter.most_common order) -- one u64 MAX
+ *             all-reduce across GPUs picks the global winner.
+ *   intersect: sorted list Q ∩ R into d_out, size into *d_n (device u64). */
+void smgpu_overlap_raw(const uint64_t *d_query, uint64_t nq, const uint64_t *d_hashes, const uint64_t *d_offsets,
+                       uint64_t ndb, uint64_t *d_overlap, int32_t op, void *stream);
+void smgpu_argmax_raw(const uint64_t *d_overlap, uint64_t ndb, uint64_t index_base, uint64_t *d_best, void *stream);
+uint64_t smgpu_intersect_workspace_bytes(uint64_t n);
+void smgpu_intersect_raw(const uint64_t *d_a, uint64_t na, const uint64_t *d_b, uint64_t nb, uint64_t *d_out,
+                         uint64_t *d_n, void *d_workspace, uint64_t workspace_bytes, void *stream);
+/* query <- query minus match (src/sourmash/search.py:915-919): sorted set difference */
+void smgpu_subtract_raw(const uint64_t *d_a, uint64_t na, const uint64_t *d_b, uint64_t nb, uint64_t *d_out,
+                        uint64_t *d_n, void *d_workspace, uint64_t workspace_bytes, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SOURMASH_AMD_H_INCLUDED */

@@ -1,0 +1,661 @@
+// capi.cpp -- the extern "C" surface of libsourmash_amd.so (include/sourmash_amd.h).
+//
+// Part 1 re-implements the hot-path subset of the reference's FFI shims
+// (src/core/src/ffi/{utils,mod,minhash,signature,cmd/compute}.rs) on top of the
+// host containers (minhash_host.hpp, signature_host.hpp) and the HIP kernels
+// (DeviceCtx / device_api.hpp).  Part 2 are the smgpu_* batch extensions.
+#include <hip/hip_runtime_api.h>
+#include <stdio.h>
+#include <string.h>
+#include <cmath>
+#include <fstream>
+#include <sstream>
+#include "../../include/sourmash_amd.h"
+#include "device_ctx.hpp"
+#include "murmur3.hpp"
+#include "signature_host.hpp"
+
+using namespace smg;
+
+// ---------------------------------------------------------------------------------------------
+// thread-local last error + landing pad (ffi/utils.rs:17-19,58-83,195-207)
+// ---------------------------------------------------------------------------------------------
+namespace {
+
+thread_local uint32_t g_err_code = 0;
+thread_local std::string g_err_msg;
+
+void set_error(uint32_t code, const std::string& msg) { g_err_code = code; g_err_msg = msg; }
+
+template <class R, class F>
+R landing(F&& f) {
+    try {
+        return f();
+    } catch (const Error& e) {
+        set_error(e.code, e.what());
+    } catch (const std::bad_alloc&) {
+        set_error(E_PANIC, "sourmash panicked: out of memory");
+    } catch (const std::exception& e) {
+        set_error(E_PANIC, std::string("sourmash panicked: ") + e.what());
+    } catch (...) {
+        set_error(E_PANIC, "sourmash panicked: unknown exception");
+    }
+    return R{};
+}
+template <class F>
+void landing_void(F&& f) {
+    landing<int>([&]() { f(); return 0; });
+}
+
+SourmashStr make_str(const std::string& s) {
+    SourmashStr out;
+    out.data = (char*)malloc(s.size() + 1);
+    memcpy(out.data, s.data(), s.size());
+    out.data[s.size()] = 0;
+    out.len = s.size();
+    out.owned = true;
+    return out;
+}
+
+inline KmerMinHash* MH(SourmashKmerMinHash* p) { return reinterpret_cast<KmerMinHash*>(p); }
+inline const KmerMinHash* MH(const SourmashKmerMinHash* p) { return reinterpret_cast<const KmerMinHash*>(p); }
+inline Signature* SIG(SourmashSignature* p) { return reinterpret_cast<Signature*>(p); }
+inline const Signature* SIG(const SourmashSignature* p) { return reinterpret_cast<const Signature*>(p); }
+inline ComputeParameters* CP(SourmashComputeParameters* p) { return reinterpret_cast<ComputeParameters*>(p); }
+inline const ComputeParameters* CP(const SourmashComputeParameters* p) { return reinterpret_cast<const ComputeParameters*>(p); }
+
+uint64_t* slice_out(const std::vector<uint64_t>& v, uintptr_t* size) {
+    *size = v.size();
+    uint64_t* p = (uint64_t*)malloc((v.size() ? v.size() : 1) * sizeof(uint64_t));
+    if (v.size()) memcpy(p, v.data(), v.size() * sizeof(uint64_t));
+    return p;
+}
+
+std::string upper_ascii(const uint8_t* p, size_t n) {
+    std::string s((const char*)p, n);
+    for (auto& c : s) if (c >= 'a' && c <= 'z') c = (char)(c - 32);
+    return s;
+}
+
+inline uint64_t keep_threshold(const KmerMinHash& mh) { return mh.max_hash ? mh.max_hash : ~0ull; }
+
+// The DNA add_sequence path (signature.rs:38-58 + :246-306) on the GPU.
+// force == false: the walk is streaming in the reference, so the hashes of every
+// k-mer before the first offending one are added before InvalidDNA is raised.
+void add_sequence_dna(KmerMinHash& mh, const uint8_t* seq, size_t len, bool force) {
+    if (!mh.is_dna())
+        throw err_internal("sourmash_amd accelerates DNA sketches only; protein/dayhoff/hp sketching is out of scope "
+                           "(SURVEY.md section 8f)");
+    const uint32_t k = mh.ksize;
+    if (len < k || k == 0) return;                                  // signature.rs:206-210
+    if (mh.num == 0 && mh.max_hash == 0) return;                    // sketch that can never hold anything
+    DeviceCtx& ctx = DeviceCtx::get();
+    std::lock_guard<std::mutex> g(ctx.mutex());
+    size_t use_len = len;
+    bool raise = false;
+    size_t bad_kmer = 0;
+    if (!force) {
+        const size_t p = ctx.first_invalid_host(seq, len);
+        if (p != SIZE_MAX) {
+            bad_kmer = p + 1 >= k ? p + 1 - k : 0;                  // first k-mer whose window covers byte p
+            if (bad_kmer < len - k + 1) {
+                raise = true;
+                use_len = bad_kmer + k - 1;                         // k-mers 0 .. bad_kmer-1 only
+            }
+        }
+    }
+    if (use_len >= k) {
+        std::vector<uint64_t> hs, cs;
+        ctx.sketch_host(seq, use_len, k, mh.seed, keep_threshold(mh), mh.track_abundance, mh.num, hs, cs);
+        mh.add_sorted_batch(hs.data(), mh.track_abundance ? cs.data() : nullptr, hs.size());
+    }
+    if (raise) throw err_invalid_dna(upper_ascii(seq + bad_kmer, k));   // errors.rs:49-50
+}
+
+struct Downsampled {
+    const KmerMinHash* a;
+    const KmerMinHash* b;
+    KmerMinHash tmp;
+};
+// minhash.rs:540-548 / 688-696: the finer sketch is downsampled to the coarser scaled
+void align_scaled(const KmerMinHash& x, const KmerMinHash& y, bool downsample, Downsampled& d) {
+    d.a = &x; d.b = &y;
+    if (downsample && x.scaled() != y.scaled()) {
+        if (x.scaled() > y.scaled()) { d.tmp = y.downsample_scaled(x.scaled()); d.b = &d.tmp; }
+        else { d.tmp = x.downsample_scaled(y.scaled()); d.a = &d.tmp; }
+    }
+}
+
+PairStats device_pair(const KmerMinHash& a, const KmerMinHash& b, bool want_abund, bool want_list, uint64_t num,
+                      std::vector<uint64_t>* list) {
+    DeviceCtx& ctx = DeviceCtx::get();
+    std::lock_guard<std::mutex> g(ctx.mutex());
+    return ctx.pair(a, b, want_abund, want_list, num, list);
+}
+
+// minhash.rs:593-621 -> (common, union)
+std::pair<uint64_t, uint64_t> intersection_size(const KmerMinHash& a, const KmerMinHash& b) {
+    a.check_compatible(b);
+    if (a.num != 0) {
+        const PairStats st = device_pair(a, b, false, false, a.num, nullptr);
+        const uint64_t uni_all = a.size() + b.size() - st.common;
+        return {st.common_num, uni_all < a.num ? uni_all : a.num};
+    }
+    const PairStats st = device_pair(a, b, false, false, 0, nullptr);
+    return {st.common, a.size() + b.size() - st.common};
+}
+
+double jaccard(const KmerMinHash& a, const KmerMinHash& b) {      // minhash.rs:624-631
+    const auto cu = intersection_size(a, b);
+    return (double)cu.first / (double)(cu.second > 1 ? cu.second : 1);
+}
+
+double angular(const KmerMinHash& a, const KmerMinHash& b) {      // minhash.rs:635-680
+    a.check_compatible(b);
+    if (!a.track_abundance || !b.track_abundance) throw err_needs_abundance();
+    const PairStats st = device_pair(a, b, true, false, 0, nullptr);
+    const double na = std::sqrt((double)st.a_sq), nb = std::sqrt((double)st.b_sq);
+    if (na == 0.0 || nb == 0.0) return 0.0;
+    double p = (double)st.prod / (na * nb);
+    if (p > 1.0) p = 1.0;
+    return 1.0 - 2.0 * std::acos(p) / 3.14159265358979323846264338327950288;
+}
+
+}  // namespace
+
+extern "C" {
+
+// ---------------------------------------------------------------------------------------------
+// library / errors
+// ---------------------------------------------------------------------------------------------
+void sourmash_init(void) {}
+void sourmash_err_clear(void) { g_err_code = 0; g_err_msg.clear(); }
+SourmashErrorCode sourmash_err_get_last_code(void) { return g_err_code; }
+SourmashStr sourmash_err_get_last_message(void) {
+    if (g_err_code == 0) { SourmashStr s = {nullptr, 0, false}; return s; }
+    return make_str(g_err_msg);
+}
+SourmashStr sourmash_err_get_backtrace(void) { SourmashStr s = {nullptr, 0, false}; return s; }
+void sourmash_str_free(SourmashStr* s) {
+    if (s && s->owned && s->data) { free(s->data); s->data = nullptr; s->len = 0; s->owned = false; }
+}
+SourmashStr sourmash_str_from_cstr(const char* s) { return make_str(s ? s : ""); }
+
+uint64_t hash_murmur(const char* kmer, uint64_t seed) {           // ffi/mod.rs:22-31
+    if (!kmer) return 0;
+    return mmh3_h1_bytes((const uint8_t*)kmer, strlen(kmer), seed);
+}
+
+// ---------------------------------------------------------------------------------------------
+// compute parameters (ffi/cmd/compute.rs)
+// ---------------------------------------------------------------------------------------------
+SourmashComputeParameters* computeparams_new(void) { return reinterpret_cast<SourmashComputeParameters*>(new ComputeParameters()); }
+void computeparams_free(SourmashComputeParameters* p) { delete CP(p); }
+bool computeparams_dayhoff(const SourmashComputeParameters* p) { return CP(p)->dayhoff; }
+bool computeparams_dna(const SourmashComputeParameters* p) { return CP(p)->dna; }
+bool computeparams_hp(const SourmashComputeParameters* p) { return CP(p)->hp; }
+bool computeparams_protein(const SourmashComputeParameters* p) { return CP(p)->protein; }
+bool computeparams_track_abundance(const SourmashComputeParameters* p) { return CP(p)->track_abundance; }
+const uint32_t* computeparams_ksizes(const SourmashComputeParameters* p, uintptr_t* size) {
+    const auto& k = CP(p)->ksizes;
+    *size = k.size();
+    uint32_t* out = (uint32_t*)malloc((k.size() ? k.size() : 1) * sizeof(uint32_t));
+    if (k.size()) memcpy(out, k.data(), k.size() * sizeof(uint32_t));
+    return out;
+}
+void computeparams_ksizes_free(uint32_t* ptr, uintptr_t) { free(ptr); }
+uint32_t computeparams_num_hashes(const SourmashComputeParameters* p) { return CP(p)->num_hashes; }
+uint64_t computeparams_scaled(const SourmashComputeParameters* p) { return CP(p)->scaled; }
+uint64_t computeparams_seed(const SourmashComputeParameters* p) { return CP(p)->seed; }
+void computeparams_set_dayhoff(SourmashComputeParameters* p, bool v) { CP(p)->dayhoff = v; }
+void computeparams_set_dna(SourmashComputeParameters* p, bool v) { CP(p)->dna = v; }
+void computeparams_set_hp(SourmashComputeParameters* p, bool v) { CP(p)->hp = v; }
+void computeparams_set_protein(SourmashComputeParameters* p, bool v) { CP(p)->protein = v; }
+void computeparams_set_track_abundance(SourmashComputeParameters* p, bool v) { CP(p)->track_abundance = v; }
+void computeparams_set_ksizes(SourmashComputeParameters* p, const uint32_t* ks, uintptr_t n) {
+    CP(p)->ksizes.assign(ks, ks + n);
+}
+void computeparams_set_num_hashes(SourmashComputeParameters* p, uint32_t n) { CP(p)->num_hashes = n; }
+void computeparams_set_scaled(SourmashComputeParameters* p, uint64_t s) { CP(p)->scaled = s; }
+void computeparams_set_seed(SourmashComputeParameters* p, uint64_t s) { CP(p)->seed = s; }
+
+// ---------------------------------------------------------------------------------------------
+// sketch object (ffi/minhash.rs)
+// ---------------------------------------------------------------------------------------------
+SourmashKmerMinHash* kmerminhash_new(uint64_t scaled, uint32_t k, HashFunctions hf, uint64_t seed, bool track,
+                                     uint32_t n) {
+    return reinterpret_cast<SourmashKmerMinHash*>(new KmerMinHash(scaled, k, hf, seed, track, n));
+}
+void kmerminhash_free(SourmashKmerMinHash* p) { delete MH(p); }
+void kmerminhash_slice_free(uint64_t* ptr, uintptr_t) { free(ptr); }
+
+void kmerminhash_add_sequence(SourmashKmerMinHash* p, const char* sequence, bool force) {
+    landing_void([&] {
+        if (!sequence) throw err_internal("null sequence");
+        add_sequence_dna(*MH(p), (const uint8_t*)sequence, strlen(sequence), force);   // CStr: stops at NUL (ffi/minhash.rs:53-59)
+    });
+}
+
+const uint64_t* kmerminhash_seq_to_hashes(SourmashKmerMinHash* p, const char* sequence, uintptr_t insize, bool force,
+                                          bool bad_kmers_as_zeroes, bool is_protein, uintptr_t* size) {
+    return landing<const uint64_t*>([&]() -> const uint64_t* {
+        KmerMinHash& mh = *MH(p);
+        if (is_protein || !mh.is_dna())
+            throw err_internal("sourmash_amd accelerates DNA sketches only; protein k-mers are out of scope");
+        const uint8_t* seq = (const uint8_t*)sequence;
+        std::vector<uint64_t> out;
+        const uint32_t k = mh.ksize;
+        if (insize >= k && k != 0) {
+            DeviceCtx& ctx = DeviceCtx::get();
+            std::lock_guard<std::mutex> g(ctx.mutex());
+            ctx.kmer_hashes_host(seq, insize, k, mh.seed, out);       // 0 where a k-mer covers an invalid byte
+            if (!force) {
+                // ffi/minhash.rs:76-96: the first bad k-mer aborts with InvalidDNA
+                const size_t pos = ctx.first_invalid_host(seq, insize);
+                if (pos != SIZE_MAX) {
+                    const size_t bad = pos + 1 >= k ? pos + 1 - k : 0;
+                    if (bad < out.size()) throw err_invalid_dna(upper_ascii(seq + bad, k));
+                }
+            }
+            if (!(force && bad_kmers_as_zeroes)) {
+                size_t w = 0;
+                for (uint64_t h : out) if (h != 0) out[w++] = h;
+                out.resize(w);
+            }
+        }
+        return slice_out(out, size);
+    });
+}
+
+void kmerminhash_add_hash(SourmashKmerMinHash* p, uint64_t h) { MH(p)->add_hash(h); }
+void kmerminhash_add_hash_with_abundance(SourmashKmerMinHash* p, uint64_t h, uint64_t a) { MH(p)->add_hash_with_abundance(h, a); }
+void kmerminhash_add_many(SourmashKmerMinHash* p, const uint64_t* hs, uintptr_t n) {
+    landing_void([&] {
+        if (!hs && n) throw err_internal("null hashes pointer");
+        for (uintptr_t i = 0; i < n; ++i) MH(p)->add_hash(hs[i]);
+    });
+}
+void kmerminhash_add_from(SourmashKmerMinHash* p, const SourmashKmerMinHash* o) {
+    landing_void([&] { for (uint64_t h : MH(o)->mins) MH(p)->add_hash(h); });   // minhash.rs:518-523
+}
+void kmerminhash_add_word(SourmashKmerMinHash* p, const char* word) {           // minhash.rs:401-404
+    if (!word) return;
+    MH(p)->add_hash(mmh3_h1_bytes((const uint8_t*)word, strlen(word), MH(p)->seed));
+}
+void kmerminhash_add_protein(SourmashKmerMinHash*, const char*) {
+    landing_void([&] { throw err_internal("protein sketching is out of scope of sourmash_amd (SURVEY.md section 8f)"); });
+}
+void kmerminhash_remove_hash(SourmashKmerMinHash* p, uint64_t h) { MH(p)->remove_hash(h); }
+void kmerminhash_remove_many(SourmashKmerMinHash* p, const uint64_t* hs, uintptr_t n) {
+    for (uintptr_t i = 0; i < n; ++i) MH(p)->remove_hash(hs[i]);
+}
+void kmerminhash_remove_from(SourmashKmerMinHash* p, const SourmashKmerMinHash* o) {
+    landing_void([&] { for (uint64_t h : MH(o)->mins) MH(p)->remove_hash(h); });
+}
+void kmerminhash_clear(SourmashKmerMinHash* p) { MH(p)->clear(); }
+
+const uint64_t* kmerminhash_get_mins(const SourmashKmerMinHash* p, uintptr_t* size) {
+    return landing<const uint64_t*>([&]() -> const uint64_t* { return slice_out(MH(p)->mins, size); });
+}
+uintptr_t kmerminhash_get_mins_size(const SourmashKmerMinHash* p) { return MH(p)->size(); }
+const uint64_t* kmerminhash_get_abunds(SourmashKmerMinHash* p, uintptr_t* size) {
+    return landing<const uint64_t*>([&]() -> const uint64_t* {
+        if (!MH(p)->track_abundance) throw Error(E_PANIC, "sourmash panicked: not implemented");   // ffi/minhash.rs:248-260
+        return slice_out(MH(p)->abunds, size);
+    });
+}
+void kmerminhash_set_abundances(SourmashKmerMinHash* p, const uint64_t* hs, const uint64_t* as, uintptr_t n, bool clear) {
+    landing_void([&] {                                                          // ffi/minhash.rs:269-300
+        if ((!hs || !as) && n) throw err_internal("null pointer");
+        std::vector<std::pair<uint64_t, uint64_t>> pairs(n);
+        for (uintptr_t i = 0; i < n; ++i) pairs[i] = {hs[i], as[i]};
+        std::sort(pairs.begin(), pairs.end());
+        if (clear) MH(p)->clear();
+        for (auto& pr : pairs) MH(p)->add_hash_with_abundance(pr.first, pr.second);
+    });
+}
+SourmashStr kmerminhash_md5sum(const SourmashKmerMinHash* p) {
+    return landing<SourmashStr>([&] { return make_str(MH(p)->md5sum()); });
+}
+void kmerminhash_merge(SourmashKmerMinHash* p, const SourmashKmerMinHash* o) {
+    landing_void([&] { MH(p)->merge(*MH(o)); });
+}
+bool kmerminhash_is_compatible(const SourmashKmerMinHash* p, const SourmashKmerMinHash* o) {
+    try { MH(p)->check_compatible(*MH(o)); return true; } catch (const Error&) { return false; }
+}
+
+uint64_t kmerminhash_count_common(const SourmashKmerMinHash* p, const SourmashKmerMinHash* o, bool downsample) {
+    return landing<uint64_t>([&]() -> uint64_t {                                // minhash.rs:539-558
+        Downsampled d;
+        align_scaled(*MH(p), *MH(o), downsample, d);
+        d.a->check_compatible(*d.b);
+        return device_pair(*d.a, *d.b, false, false, 0, nullptr).common;
+    });
+}
+
+SourmashKmerMinHash* kmerminhash_intersection(const SourmashKmerMinHash* p, const SourmashKmerMinHash* o) {
+    return landing<SourmashKmerMinHash*>([&]() -> SourmashKmerMinHash* {        // ffi/minhash.rs:428-441, minhash.rs:560-589
+        const KmerMinHash& a = *MH(p);
+        const KmerMinHash& b = *MH(o);
+        a.check_compatible(b);
+        std::vector<uint64_t> list;
+        device_pair(a, b, false, true, 0, &list);
+        if (a.num != 0) {
+            // bottom-k: keep only hashes that survive the merged-and-truncated union (minhash.rs:563-585)
+            const uint64_t uni = a.size() + b.size() - list.size();
+            if (uni > a.num) {
+                // the num-th smallest of the union bounds the kept intersection
+                KmerMinHash u = a;
+                u.track_abundance = false; u.abunds.clear();
+                KmerMinHash bb = b; bb.track_abundance = false; bb.abunds.clear();
+                u.merge(bb);
+                const uint64_t cutoff = u.mins.empty() ? 0 : u.mins.back();
+                while (!list.empty() && list.back() > cutoff) list.pop_back();
+            }
+        }
+        KmerMinHash* out = new KmerMinHash(a);
+        out->clear();
+        for (uint64_t h : list) out->add_hash(h);
+        return reinterpret_cast<SourmashKmerMinHash*>(out);
+    });
+}
+
+uint64_t kmerminhash_intersection_union_size(const SourmashKmerMinHash* p, const SourmashKmerMinHash* o, uint64_t* usize) {
+    return landing<uint64_t>([&]() -> uint64_t {                                // ffi/minhash.rs:443-457
+        try {
+            const auto cu = intersection_size(*MH(p), *MH(o));
+            *usize = cu.second;
+            return cu.first;
+        } catch (const Error& e) {
+            if (e.code >= 101 && e.code <= 104) { *usize = 0; return 0; }      // incompatible -> (0, 0), no error
+            throw;
+        }
+    });
+}
+
+double kmerminhash_jaccard(const SourmashKmerMinHash* p, const SourmashKmerMinHash* o) {
+    return landing<double>([&] { return jaccard(*MH(p), *MH(o)); });
+}
+
+double kmerminhash_similarity(const SourmashKmerMinHash* p, const SourmashKmerMinHash* o, bool ignore_abundance,
+                              bool downsample) {
+    return landing<double>([&]() -> double {                                    // minhash.rs:682-702
+        Downsampled d;
+        align_scaled(*MH(p), *MH(o), downsample, d);
+        if (ignore_abundance || !d.a->track_abundance || !d.b->track_abundance) return jaccard(*d.a, *d.b);
+        return angular(*d.a, *d.b);
+    });
+}
+
+double kmerminhash_angular_similarity(const SourmashKmerMinHash* p, const SourmashKmerMinHash* o) {
+    return landing<double>([&] { return angular(*MH(p), *MH(o)); });
+}
+
+uint32_t kmerminhash_num(const SourmashKmerMinHash* p) { return MH(p)->num; }
+uint32_t kmerminhash_ksize(const SourmashKmerMinHash* p) { return MH(p)->ksize; }
+uint64_t kmerminhash_seed(const SourmashKmerMinHash* p) { return MH(p)->seed; }
+uint64_t kmerminhash_max_hash(const SourmashKmerMinHash* p) { return MH(p)->max_hash; }
+HashFunctions kmerminhash_hash_function(const SourmashKmerMinHash* p) { return MH(p)->hash_function; }
+void kmerminhash_hash_function_set(SourmashKmerMinHash* p, HashFunctions hf) {
+    landing_void([&] {
+        if (hf < 1 || hf > 4) throw Error(E_INVALID_HASH_FUNCTION, "Invalid hash function: \"" + std::to_string(hf) + "\"");
+        MH(p)->set_hash_function(hf);
+    });
+}
+bool kmerminhash_is_protein(const SourmashKmerMinHash* p) { return MH(p)->hash_function == HF_PROTEIN; }
+bool kmerminhash_dayhoff(const SourmashKmerMinHash* p) { return MH(p)->hash_function == HF_DAYHOFF; }
+bool kmerminhash_hp(const SourmashKmerMinHash* p) { return MH(p)->hash_function == HF_HP; }
+bool kmerminhash_track_abundance(const SourmashKmerMinHash* p) { return MH(p)->track_abundance; }
+void kmerminhash_enable_abundance(SourmashKmerMinHash* p) { landing_void([&] { MH(p)->enable_abundance(); }); }
+void kmerminhash_disable_abundance(SourmashKmerMinHash* p) { MH(p)->disable_abundance(); }
+
+// ---------------------------------------------------------------------------------------------
+// signature container (ffi/signature.rs)
+// ---------------------------------------------------------------------------------------------
+SourmashSignature* signature_new(void) { return reinterpret_cast<SourmashSignature*>(new Signature()); }
+void signature_free(SourmashSignature* p) { delete SIG(p); }
+SourmashSignature* signature_from_params(const SourmashComputeParameters* p) {
+    return reinterpret_cast<SourmashSignature*>(new Signature(Signature::from_params(*CP(p))));
+}
+uintptr_t signature_len(const SourmashSignature* p) { return SIG(p)->sketches.size(); }
+
+void signature_add_sequence(SourmashSignature* p, const char* sequence, bool force) {
+    landing_void([&] {                                                          // signature.rs:661-677
+        if (!sequence) throw err_internal("null sequence");
+        const size_t len = strlen(sequence);
+        for (auto& mh : SIG(p)->sketches) add_sequence_dna(mh, (const uint8_t*)sequence, len, force);
+    });
+}
+void signature_add_protein(SourmashSignature*, const char*) {
+    landing_void([&] { throw err_internal("protein sketching is out of scope of sourmash_amd (SURVEY.md section 8f)"); });
+}
+void signature_set_name(SourmashSignature* p, const char* name) { landing_void([&] { if (name) SIG(p)->name = std::string(name); }); }
+void signature_set_filename(SourmashSignature* p, const char* name) { landing_void([&] { if (name) SIG(p)->filename = std::string(name); }); }
+SourmashStr signature_get_name(const SourmashSignature* p) {
+    return landing<SourmashStr>([&] { return make_str(SIG(p)->name ? *SIG(p)->name : std::string()); });
+}
+SourmashStr signature_get_filename(const SourmashSignature* p) {
+    return landing<SourmashStr>([&] { return make_str(SIG(p)->filename ? *SIG(p)->filename : std::string()); });
+}
+SourmashStr signature_get_license(const SourmashSignature* p) {
+    return landing<SourmashStr>([&] { return make_str(SIG(p)->license); });
+}
+SourmashKmerMinHash* signature_first_mh(const SourmashSignature* p) {
+    return landing<SourmashKmerMinHash*>([&]() -> SourmashKmerMinHash* {        // ffi/signature.rs:167-182: a fresh clone
+        if (SIG(p)->sketches.empty()) throw err_internal("found unsupported sketch type");
+        return reinterpret_cast<SourmashKmerMinHash*>(new KmerMinHash(SIG(p)->sketches[0]));
+    });
+}
+SourmashKmerMinHash** signature_get_mhs(const SourmashSignature* p, uintptr_t* size) {
+    return landing<SourmashKmerMinHash**>([&]() -> SourmashKmerMinHash** {
+        const auto& sk = SIG(p)->sketches;
+        *size = sk.size();
+        SourmashKmerMinHash** out = (SourmashKmerMinHash**)malloc((sk.size() ? sk.size() : 1) * sizeof(void*));
+        for (size_t i = 0; i < sk.size(); ++i) out[i] = reinterpret_cast<SourmashKmerMinHash*>(new KmerMinHash(sk[i]));
+        return out;
+    });
+}
+void signature_set_mh(SourmashSignature* p, const SourmashKmerMinHash* o) {
+    landing_void([&] { SIG(p)->sketches.clear(); SIG(p)->sketches.push_back(*MH(o)); });
+}
+void signature_push_mh(SourmashSignature* p, const SourmashKmerMinHash* o) {
+    landing_void([&] { SIG(p)->sketches.push_back(*MH(o)); });
+}
+bool signature_eq(const SourmashSignature* p, const SourmashSignature* o) {
+    return landing<bool>([&] { return SIG(p)->equals(*SIG(o)); });
+}
+SourmashStr signature_save_json(const SourmashSignature* p) {
+    return landing<SourmashStr>([&] { std::string s; SIG(p)->to_json(s); return make_str(s); });
+}
+
+static SourmashSignature** sigs_out(std::vector<Signature>&& sigs, uintptr_t* size) {
+    *size = sigs.size();
+    SourmashSignature** out = (SourmashSignature**)malloc((sigs.size() ? sigs.size() : 1) * sizeof(void*));
+    for (size_t i = 0; i < sigs.size(); ++i) out[i] = reinterpret_cast<SourmashSignature*>(new Signature(std::move(sigs[i])));
+    return out;
+}
+
+SourmashSignature** signatures_load_buffer(const char* ptr, uintptr_t insize, bool, uintptr_t ksize,
+                                           const char* select_moltype, uintptr_t* size) {
+    return landing<SourmashSignature**>([&]() -> SourmashSignature** {
+        if (!ptr) throw err_internal("null buffer");
+        uint32_t mol = 0;
+        if (select_moltype) mol = molecule_from_name(select_moltype);
+        return sigs_out(load_signatures(ptr, insize, ksize, select_moltype ? &mol : nullptr), size);
+    });
+}
+SourmashSignature** signatures_load_path(const char* path, bool, uintptr_t ksize, const char* select_moltype,
+                                         uintptr_t* size) {
+    return landing<SourmashSignature**>([&]() -> SourmashSignature** {
+        if (!path) throw err_internal("null path");
+        std::ifstream in(path, std::ios::binary);
+        if (!in) throw Error(E_IO, std::string("No such file or directory: ") + path);
+        std::stringstream ss;
+        ss << in.rdbuf();
+        const std::string data = ss.str();
+        uint32_t mol = 0;
+        if (select_moltype) mol = molecule_from_name(select_moltype);
+        return sigs_out(load_signatures(data.data(), data.size(), ksize, select_moltype ? &mol : nullptr), size);
+    });
+}
+const uint8_t* signatures_save_buffer(const SourmashSignature* const* ptr, uintptr_t n, uint8_t compression,
+                                      uintptr_t* osize) {
+    return landing<const uint8_t*>([&]() -> const uint8_t* {                    // ffi/signature.rs:220-259
+        if (!ptr && n) throw err_internal("null pointer");
+        std::string s = "[";
+        for (uintptr_t i = 0; i < n; ++i) { if (i) s += ','; SIG(ptr[i])->to_json(s); }
+        s += ']';
+        if (compression > 0) s = gzip_bytes(s, compression > 9 ? 9 : compression);
+        *osize = s.size();
+        uint8_t* out = (uint8_t*)malloc(s.size() ? s.size() : 1);
+        memcpy(out, s.data(), s.size());
+        return out;
+    });
+}
+void nodegraph_buffer_free(uint8_t* ptr, uintptr_t) { free(ptr); }
+
+// =============================================================================================
+// PART 2: batch extensions
+// =============================================================================================
+int32_t smgpu_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+bool smgpu_available(void) { return smgpu_device_count() > 0; }
+
+void smgpu_minhash_add_buffer(SourmashKmerMinHash* p, const char* buf, uintptr_t len, bool force) {
+    landing_void([&] {
+        if (!buf && len) throw err_internal("null buffer");
+        add_sequence_dna(*MH(p), (const uint8_t*)buf, len, force);
+    });
+}
+
+uint64_t smgpu_sketch_workspace_bytes(uint64_t out_capacity) {
+    return (uint64_t)out_capacity * 8 + sort_unique_temp_bytes(out_capacity) + 512;
+}
+
+uint64_t smgpu_sketch_dna_raw(const uint8_t* d_seq, uint64_t len, uint32_t ksize, uint64_t seed, uint64_t max_hash,
+                              uint64_t* d_out, uint64_t cap, uint64_t* d_result, void* d_ws, uint64_t ws_bytes,
+                              void* stream) {
+    uint64_t ret = ~0ull;
+    landing_void([&] {
+        hipStream_t st = (hipStream_t)stream;
+        if (ws_bytes < smgpu_sketch_workspace_bytes(cap)) throw err_internal("workspace too small (smgpu_sketch_workspace_bytes)");
+        if (((uintptr_t)d_seq & 15) != 0) throw err_internal("d_seq must be 16-byte aligned");
+        uint64_t* d_raw = (uint64_t*)d_ws;                                   // unordered kept hashes
+        void* d_tmp = (char*)d_ws + ((cap * 8 + 255) / 256) * 256;
+        const size_t tmp_bytes = (size_t)(ws_bytes - ((cap * 8 + 255) / 256) * 256);
+        const uint64_t thr = max_hash ? max_hash : ~0ull;
+        hip_check(hipMemsetAsync(d_result, 0, 16, st), "memset");
+        hip_check(sketch_dna_launch(d_seq, len, ksize, seed, thr, d_raw, (unsigned long long*)d_result, cap, st), "sketch_dna");
+        unsigned long long kept = 0;
+        hip_check(hipMemcpyAsync(&kept, d_result, 8, hipMemcpyDeviceToHost, st), "D2H");
+        hip_check(hipStreamSynchronize(st), "sync");
+        if (kept > cap)
+            throw err_internal("output capacity too small: " + std::to_string(kept) + " kept hashes > capacity " + std::to_string(cap));
+        int bits = 64;
+        if (thr != ~0ull) { bits = 1; while (bits < 64 && (thr >> bits)) ++bits; }
+        hip_check(sort_unique(d_raw, kept, d_out, nullptr, d_result + 1, d_tmp, tmp_bytes, bits, st), "sort_unique");
+        unsigned long long nu = 0;
+        hip_check(hipMemcpyAsync(&nu, d_result + 1, 8, hipMemcpyDeviceToHost, st), "D2H");
+        hip_check(hipStreamSynchronize(st), "sync");
+        ret = nu;
+    });
+    return ret;
+}
+
+void smgpu_sketch_dna_kernel_raw(const uint8_t* d_seq, uint64_t len, uint32_t ksize, uint64_t seed, uint64_t max_hash,
+                                 uint64_t* d_out, uint64_t cap, uint64_t* d_count, void* stream) {
+    landing_void([&] {
+        if (((uintptr_t)d_seq & 15) != 0) throw err_internal("d_seq must be 16-byte aligned");
+        hip_check(sketch_dna_launch(d_seq, len, ksize, seed, max_hash ? max_hash : ~0ull, d_out,
+                                    (unsigned long long*)d_count, cap, (hipStream_t)stream), "sketch_dna");
+    });
+}
+
+void smgpu_synth_dna_raw(uint8_t* d_out, uint64_t start, uint64_t n, uint64_t seed, uint64_t record_len, void* stream) {
+    landing_void([&] { hip_check(synth_dna_launch(d_out, start, n, seed, record_len, (hipStream_t)stream), "synth_dna"); });
+}
+
+void smgpu_compare_raw(const uint64_t* d_hashes, const uint64_t* d_offsets, uint32_t n, uint32_t row_lo, uint32_t row_hi,
+                       uint32_t* d_common, double* d_jaccard, void* stream) {
+    landing_void([&] {
+        if (!d_common) throw err_internal("d_common is required");
+        hip_check(compare_counts_launch(d_hashes, d_offsets, n, row_lo, row_hi, d_common, (hipStream_t)stream), "compare");
+        if (d_jaccard)
+            hip_check(jaccard_from_counts_launch(d_common, d_offsets, n, row_lo, row_hi, d_jaccard, (hipStream_t)stream), "jaccard");
+    });
+}
+
+void smgpu_compare_all_pairs(const SourmashKmerMinHash* const* mhs, uintptr_t n, uint32_t* common_out, double* jaccard_out) {
+    landing_void([&] {
+        if (n == 0) return;
+        if (n > 0xffffffffu) throw err_internal("too many sketches");
+        for (uintptr_t i = 1; i < n; ++i) MH(mhs[0])->check_compatible(*MH(mhs[i]));
+        if (MH(mhs[0])->num != 0)
+            throw err_internal("smgpu_compare_all_pairs handles scaled sketches; use kmerminhash_similarity for num sketches");
+        std::vector<uint64_t> offsets(n + 1, 0);
+        for (uintptr_t i = 0; i < n; ++i) offsets[i + 1] = offsets[i] + MH(mhs[i])->size();
+        const uint64_t total = offsets[n];
+        DeviceCtx& ctx = DeviceCtx::get();
+        std::lock_guard<std::mutex> g(ctx.mutex());
+        hipStream_t st = ctx.stream();
+        DevBuf dh, doff, dc, dj;
+        struct Free { DevBuf& b; ~Free() { if (b.p) (void)hipFree(b.p); } } f1{dh}, f2{doff}, f3{dc}, f4{dj};
+        dh.reserve(total * 8 + 16);
+        doff.reserve((n + 1) * 8);
+        dc.reserve((size_t)n * n * 4);
+        for (uintptr_t i = 0; i < n; ++i)
+            if (MH(mhs[i])->size())
+                hip_check(hipMemcpyAsync(dh.as<uint64_t>() + offsets[i], MH(mhs[i])->mins.data(), MH(mhs[i])->size() * 8,
+                                         hipMemcpyHostToDevice, st), "H2D");
+        hip_check(hipMemcpyAsync(doff.p, offsets.data(), (n + 1) * 8, hipMemcpyHostToDevice, st), "H2D");
+        hip_check(compare_counts_launch(dh.as<uint64_t>(), doff.as<uint64_t>(), (uint32_t)n, 0, (uint32_t)n, dc.as<uint32_t>(), st), "compare");
+        if (jaccard_out) {
+            dj.reserve((size_t)n * n * 8);
+            hip_check(jaccard_from_counts_launch(dc.as<uint32_t>(), doff.as<uint64_t>(), (uint32_t)n, 0, (uint32_t)n, dj.as<double>(), st), "jaccard");
+            hip_check(hipMemcpyAsync(jaccard_out, dj.p, (size_t)n * n * 8, hipMemcpyDeviceToHost, st), "D2H");
+        }
+        if (common_out) hip_check(hipMemcpyAsync(common_out, dc.p, (size_t)n * n * 4, hipMemcpyDeviceToHost, st), "D2H");
+        hip_check(hipStreamSynchronize(st), "sync");
+    });
+}
+
+void smgpu_overlap_raw(const uint64_t* d_query, uint64_t nq, const uint64_t* d_hashes, const uint64_t* d_offsets,
+                       uint64_t ndb, uint64_t* d_overlap, int32_t op, void* stream) {
+    landing_void([&] {
+        hip_check(overlap_vector_launch(d_query, nq, d_hashes, d_offsets, ndb, (unsigned long long*)d_overlap, op,
+                                        (hipStream_t)stream), "overlap");
+    });
+}
+void smgpu_argmax_raw(const uint64_t* d_overlap, uint64_t ndb, uint64_t index_base, uint64_t* d_best, void* stream) {
+    landing_void([&] {
+        hip_check(argmax_launch((const unsigned long long*)d_overlap, ndb, index_base, (unsigned long long*)d_best,
+                                (hipStream_t)stream), "argmax");
+    });
+}
+uint64_t smgpu_intersect_workspace_bytes(uint64_t n) { return (uint64_t)select_temp_bytes(n) + ((n + 255) / 256) * 256 + 256; }
+
+static void select_pair(const uint64_t* d_a, uint64_t na, const uint64_t* d_b, uint64_t nb, uint64_t* d_out, uint64_t* d_n,
+                        void* d_ws, uint64_t ws_bytes, int invert, void* stream) {
+    landing_void([&] {
+        if (ws_bytes < smgpu_intersect_workspace_bytes(na)) throw err_internal("workspace too small (smgpu_intersect_workspace_bytes)");
+        uint8_t* flags = (uint8_t*)d_ws;
+        void* tmp = (char*)d_ws + ((na + 255) / 256) * 256;
+        const size_t tmp_bytes = (size_t)(ws_bytes - ((na + 255) / 256) * 256);
+        hipStream_t st = (hipStream_t)stream;
+        hip_check(pair_match_launch(d_a, na, d_b, nb, nullptr, nullptr, flags, nullptr, invert, st), "pair_match");
+        hip_check(select_flagged(d_a, flags, na, d_out, d_n, tmp, tmp_bytes, st), "select");
+    });
+}
+void smgpu_intersect_raw(const uint64_t* d_a, uint64_t na, const uint64_t* d_b, uint64_t nb, uint64_t* d_out, uint64_t* d_n,
+                         void* d_ws, uint64_t ws_bytes, void* stream) {
+    select_pair(d_a, na, d_b, nb, d_out, d_n, d_ws, ws_bytes, 0, stream);
+}
+void smgpu_subtract_raw(const uint64_t* d_a, uint64_t na, const uint64_t* d_b, uint64_t nb, uint64_t* d_out, uint64_t* d_n,
+                        void* d_ws, uint64_t ws_bytes, void* stream) {
+    select_pair(d_a, na, d_b, nb, d_out, d_n, d_ws, ws_bytes, 1, stream);
+}
+
+}  // extern "C"

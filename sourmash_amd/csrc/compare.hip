@@ -1,0 +1,177 @@
+// compare.hip -- all-vs-all sorted-u64 merge-intersection, tiled in LDS (gfx950).
+//
+// GPU counterpart of
+//   src/sourmash/compare.py:14-64      compare_serial (the N(N-1)/2 Python loop)
+//   src/core/src/sketch/minhash.rs:539-558  count_common
+//   src/core/src/sketch/minhash.rs:915-953  Intersection (two-pointer walk)
+//   src/core/src/sketch/minhash.rs:1765-1807 intersection_size (common, union)
+//   src/core/src/sketch/minhash.rs:624-631  jaccard = common / max(1, union)
+//
+// Layout: CSR -- d_hashes holds every sketch's sorted unique u64 hashes back to
+// back, d_offsets[n+1] the row starts.
+//
+// Kernel: one workgroup owns a 16 x 16 tile of (row sketch, column sketch)
+// pairs, one lane per pair.  The 32 sketches of the tile are streamed through
+// LDS in lock-step "slabs": every round each sketch contributes its next
+// <= SEG hashes (coalesced 16-byte loads, one wave per sketch segment), the
+// slab's upper bound `hi` is the smallest last-loaded hash among sketches that
+// still have more to come, and every lane two-pointer-merges the parts of its
+// row and column segments that are <= hi.  Sketches then advance by exactly
+// what was consumed.  This is the reference's merge walk, cut at common hash
+// boundaries so that 256 walks share each byte fetched: HBM/L2 sees every
+// hash of a tile once per round instead of 16 times.  Works for any length
+// mix (empty, 1-hash, 50k-hash rows) because the cut points are data driven.
+//
+// union = n_i + n_j - common (scaled sketches; equals the walk's union count),
+// so Jaccard needs only the u32 common matrix and the row lengths.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "device_api.hpp"
+
+namespace smg {
+
+constexpr int CT = 16;            // tile edge (sketches)
+constexpr int SEG = 128;          // hashes per sketch per round
+constexpr int SEG_STRIDE = SEG + 1;  // +1 u64 pad: spreads the 16 column segments over distinct LDS banks
+constexpr int CMP_BLOCK = CT * CT;
+
+__global__ __launch_bounds__(CMP_BLOCK) void compare_tile_kernel(
+    const uint64_t* __restrict__ hashes, const uint64_t* __restrict__ offsets, uint32_t n,
+    uint32_t row_lo, uint32_t row_hi, uint32_t* __restrict__ common, int symmetric) {
+    __shared__ uint64_t s_seg[2 * CT][SEG_STRIDE];
+    __shared__ uint64_t s_pos[2 * CT], s_end[2 * CT];
+    __shared__ uint32_t s_take[2 * CT];
+    __shared__ unsigned long long s_hi;
+    __shared__ uint32_t s_live[2];   // [0] rows with data left, [1] columns with data left
+
+    const uint32_t rb = blockIdx.y, cb = blockIdx.x;
+    const uint32_t row0 = row_lo + rb * CT, col0 = cb * CT;
+    if (symmetric && col0 + CT <= row0) return;   // tile strictly below the diagonal: mirrored from above
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = tid / CT, c = tid % CT;
+
+    if (tid < 2 * CT) {
+        const uint32_t s = tid < CT ? row0 + tid : col0 + (tid - CT);
+        const bool ok = tid < CT ? (s < row_hi) : (s < n);
+        s_pos[tid] = ok ? offsets[s] : 0;
+        s_end[tid] = ok ? offsets[s + 1] : 0;
+    }
+    uint32_t cnt = 0;
+    __syncthreads();
+
+    for (;;) {
+        if (tid == 0) { s_hi = ~0ull; s_live[0] = 0; s_live[1] = 0; }
+        __syncthreads();
+        // ---- stage the next <= SEG hashes of each of the 32 sketches: wave w takes sketches 8w..8w+7,
+        //      lane l the hashes 2l, 2l+1 (one 16-byte load when aligned) ----
+        uint64_t e0[8], e1[8];
+        uint32_t have[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int s = wave * 8 + i;
+            const uint64_t pos = s_pos[s], end = s_end[s];
+            const uint64_t left = end - pos;
+            const uint32_t len = left < (uint64_t)SEG ? (uint32_t)left : (uint32_t)SEG;
+            have[i] = len;
+            const uint64_t* p = hashes + pos + 2 * lane;
+            uint64_t v0 = ~0ull, v1 = ~0ull;
+            if ((uint32_t)(2 * lane + 1) < len) {
+                if ((pos & 1) == 0) {
+                    const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(p);
+                    v0 = v.x; v1 = v.y;
+                } else { v0 = p[0]; v1 = p[1]; }
+            } else if ((uint32_t)(2 * lane) < len) {
+                v0 = p[0];
+            }
+            e0[i] = v0; e1[i] = v1;
+            s_seg[s][2 * lane] = v0;
+            s_seg[s][2 * lane + 1] = v1;
+            if (lane == 0) {
+                if (left > (uint64_t)SEG) atomicMin(&s_hi, (unsigned long long)hashes[pos + SEG - 1]);
+                if (len) atomicOr(&s_live[s < CT ? 0 : 1], 1u);
+            }
+        }
+        __syncthreads();
+        if (s_live[0] == 0 || s_live[1] == 0) break;   // every row or every column exhausted
+        const uint64_t hi = s_hi;
+        // ---- how many staged hashes of each sketch are <= hi ----
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int s = wave * 8 + i;
+            const bool in0 = (uint32_t)(2 * lane) < have[i] && e0[i] <= hi;
+            const bool in1 = (uint32_t)(2 * lane + 1) < have[i] && e1[i] <= hi;
+            const uint32_t take = (uint32_t)__popcll(__ballot(in0)) + (uint32_t)__popcll(__ballot(in1));
+            if (lane == 0) { s_take[s] = take; s_pos[s] += take; }
+        }
+        __syncthreads();
+        // ---- the merge walk of minhash.rs:915-953 on the LDS-resident parts ----
+        {
+            const uint32_t na = s_take[r], nb = s_take[CT + c];
+            const uint64_t* A = s_seg[r];
+            const uint64_t* B = s_seg[CT + c];
+            uint32_t ia = 0, ib = 0;
+            while (ia < na && ib < nb) {
+                const uint64_t a = A[ia], b = B[ib];
+                cnt += (a == b);
+                ia += (a <= b);
+                ib += (b <= a);
+            }
+        }
+        // next round's staging overwrites s_seg: the barrier at the top of the loop orders it
+    }
+
+    const uint32_t row = row0 + r, col = col0 + c;
+    if (row < row_hi && col < n) {
+        const uint64_t idx = (uint64_t)(row - row_lo) * n + col;
+        if (!symmetric) {
+            common[idx] = cnt;
+        } else if (col >= row) {
+            common[idx] = cnt;
+            if (col < row_hi && col >= row_lo) common[(uint64_t)(col - row_lo) * n + row] = cnt;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void jaccard_from_counts_kernel(const uint32_t* __restrict__ common,
+                                                                  const uint64_t* __restrict__ offsets, uint32_t n,
+                                                                  uint32_t row_lo, uint32_t row_hi,
+                                                                  double* __restrict__ out) {
+    const uint64_t total = (uint64_t)(row_hi - row_lo) * n;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t row = row_lo + (uint32_t)(i / n), col = (uint32_t)(i % n);
+        double v;
+        if (row == col) {
+            v = 1.0;                                              // compare.py:33 np.ones diagonal
+        } else {
+            const uint64_t ni = offsets[row + 1] - offsets[row], nj = offsets[col + 1] - offsets[col];
+            const uint64_t cm = common[i];
+            const uint64_t uni = ni + nj - cm;
+            v = (double)cm / (double)(uni > 1 ? uni : 1);         // minhash.rs:624-631
+        }
+        out[i] = v;
+    }
+}
+
+hipError_t compare_counts_launch(const uint64_t* d_hashes, const uint64_t* d_offsets, uint32_t n, uint32_t row_lo,
+                                 uint32_t row_hi, uint32_t* d_common, hipStream_t stream) {
+    if (row_hi <= row_lo || n == 0) return hipSuccess;
+    const int symmetric = (row_lo == 0 && row_hi == n) ? 1 : 0;
+    dim3 grid((n + CT - 1) / CT, (row_hi - row_lo + CT - 1) / CT);
+    hipLaunchKernelGGL(compare_tile_kernel, grid, dim3(CMP_BLOCK), 0, stream, d_hashes, d_offsets, n, row_lo, row_hi,
+                       d_common, symmetric);
+    return hipGetLastError();
+}
+
+hipError_t jaccard_from_counts_launch(const uint32_t* d_common, const uint64_t* d_offsets, uint32_t n,
+                                      uint32_t row_lo, uint32_t row_hi, double* d_out, hipStream_t stream) {
+    if (row_hi <= row_lo || n == 0) return hipSuccess;
+    const uint64_t total = (uint64_t)(row_hi - row_lo) * n;
+    const uint64_t nb = (total + 255) / 256;
+    hipLaunchKernelGGL(jaccard_from_counts_kernel, dim3((unsigned)(nb < 4096 ? nb : 4096)), dim3(256), 0, stream,
+                       d_common, d_offsets, n, row_lo, row_hi, d_out);
+    return hipGetLastError();
+}
+
+}  // namespace smg

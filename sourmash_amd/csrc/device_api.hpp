@@ -1,0 +1,43 @@
+// Internal C++ interface between the HIP translation units and the C-ABI layer.
+// Everything here takes raw device pointers and a stream and never allocates.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+namespace smg {
+
+// ---- sketch.hip ---------------------------------------------------------------
+// Append every hash h of a canonical DNA k-mer of d_seq[0,len) with 1 <= h <= thr
+// to d_out (unordered, duplicates kept); *d_count += number appended (keeps
+// counting past `cap`, entries past cap are dropped).  d_seq must be 16-byte
+// aligned.  Any byte outside ACGTacgt kills the k-mers covering it.
+hipError_t sketch_dna_launch(const uint8_t* d_seq, uint64_t len, uint32_t k, uint64_t seed, uint64_t thr,
+                             uint64_t* d_out, unsigned long long* d_count, uint64_t cap, hipStream_t stream);
+// d_out[i] = hash of the canonical k-mer starting at i for i in [0, n_kmers) (0 for k-mers
+// covering a byte outside ACGTacgt).  d_out must be zeroed by the caller.
+hipError_t kmer_hashes_launch(const uint8_t* d_seq, uint64_t len, uint32_t k, uint64_t seed, uint64_t* d_out,
+                              uint64_t n_kmers, hipStream_t stream);
+// *d_first = min(*d_first, position of the first byte outside ACGTacgt)
+hipError_t first_invalid_launch(const uint8_t* d_seq, uint64_t len, unsigned long long* d_first, hipStream_t stream);
+
+// ---- device_sort.hip ------------------------------------------------------------
+size_t sort_unique_temp_bytes(uint64_t n);
+// keys[0,n) -> sorted unique in out[0,*d_n_out); if d_counts != nullptr also the
+// multiplicity of every unique key.  keys is clobbered.  `bits` = significant key bits.
+hipError_t sort_unique(uint64_t* d_keys, uint64_t n, uint64_t* d_out, uint64_t* d_counts, uint64_t* d_n_out,
+                       void* d_temp, size_t temp_bytes, int bits, hipStream_t stream);
+
+// ---- synth.hip --------------------------------------------------------------------
+hipError_t synth_dna_launch(uint8_t* d_out, uint64_t start, uint64_t n, uint64_t seed, uint64_t record_len,
+                            hipStream_t stream);
+
+// ---- compare.hip ------------------------------------------------------------------
+// CSR of sorted unique u64 rows on device -> common[i][j] for i in [row_lo,row_hi), all j.
+hipError_t compare_counts_launch(const uint64_t* d_hashes, const uint64_t* d_offsets, uint32_t n,
+                                 uint32_t row_lo, uint32_t row_hi, uint32_t* d_common /*[(row_hi-row_lo)][n]*/,
+                                 hipStream_t stream);
+hipError_t jaccard_from_counts_launch(const uint32_t* d_common, const uint64_t* d_offsets, uint32_t n,
+                                      uint32_t row_lo, uint32_t row_hi, double* d_out, hipStream_t stream);
+
+}  // namespace smg

@@ -1,0 +1,243 @@
+// DeviceCtx -- owns the HIP stream and grow-only device scratch buffers used by
+// the host-pointer entry points of the C-ABI (kmerminhash_add_sequence, ...).
+// The raw device-pointer entry points (smgpu_*_raw) bypass it entirely.
+//
+// There is deliberately NO CPU fallback: if no HIP device can be opened every
+// k-mer / intersection operation raises SOURMASH_ERROR_CODE_INTERNAL.
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <stdint.h>
+#include <string.h>
+#include <cmath>
+#include <mutex>
+#include <string>
+#include <vector>
+#include "device_api.hpp"
+#include "minhash_host.hpp"
+#include "pair_api.hpp"
+#include "smg_errors.hpp"
+
+namespace smg {
+
+inline void hip_check(hipError_t e, const char* what) {
+    if (e != hipSuccess)
+        throw err_internal(std::string("HIP failure in ") + what + ": " + hipGetErrorString(e));
+}
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    void reserve(size_t bytes) {
+        if (bytes <= cap) return;
+        if (p) hip_check(hipFree(p), "hipFree");
+        p = nullptr; cap = 0;
+        size_t want = bytes + bytes / 4 + 4096;
+        hip_check(hipMalloc(&p, want), "hipMalloc");
+        cap = want;
+    }
+    template <class T> T* as() { return static_cast<T*>(p); }
+};
+
+struct PairStats {
+    uint64_t common = 0;       // |A ∩ B|
+    uint64_t prod = 0;         // sum abundA*abundB over the intersection
+    uint64_t a_sq = 0, b_sq = 0;
+    uint64_t common_num = 0;   // num rule: intersection hashes that survive merge-and-truncate
+};
+
+class DeviceCtx {
+  public:
+    // One context per process (leaked on purpose: HIP may already be torn down at exit).
+    static DeviceCtx& get() {
+        static DeviceCtx* ctx = nullptr;
+        static std::mutex mu;
+        std::lock_guard<std::mutex> g(mu);
+        if (!ctx) {
+            int n = 0;
+            hipError_t e = hipGetDeviceCount(&n);
+            if (e != hipSuccess || n <= 0)
+                throw err_internal("no HIP device available: sourmash_amd has no CPU fallback for k-mer hashing "
+                                   "or sketch intersection (hipGetDeviceCount: " +
+                                   std::string(e == hipSuccess ? "0 devices" : hipGetErrorString(e)) + ")");
+            ctx = new DeviceCtx();
+            hip_check(hipStreamCreate(&ctx->stream_), "hipStreamCreate");
+            ctx->scalars_.reserve(256);
+        }
+        return *ctx;
+    }
+
+    std::mutex& mutex() { return mu_; }
+    hipStream_t stream() const { return stream_; }
+
+    // ---- sketch a host buffer: sorted unique kept hashes (+ multiplicities) -------------------
+    // thr: keep 1 <= h <= thr.  limit: only the `limit` smallest are needed (num sketches; 0 = all).
+    void sketch_host(const uint8_t* seq, size_t len, uint32_t k, uint64_t seed, uint64_t thr, bool want_counts,
+                     size_t limit, std::vector<uint64_t>& hashes, std::vector<uint64_t>& counts) {
+        hashes.clear(); counts.clear();
+        if (len < k || k == 0) return;
+        // bounded chunks (k-1 overlap) so scratch stays modest whatever the record length
+        const size_t CHUNK = (size_t)256 << 20;
+        KmerMinHash acc;                       // merges chunk results (plain sorted-set union with counts)
+        acc.max_hash = 0; acc.num = limit ? (uint32_t)limit : 0; acc.track_abundance = want_counts;
+        bool multi = len > CHUNK;
+        std::vector<uint64_t> hs, cs;
+        for (size_t off = 0; off < len - (k - 1); off += CHUNK) {
+            const size_t n = std::min(len - off, CHUNK + (size_t)(k - 1));
+            sketch_chunk(seq + off, n, k, seed, thr, want_counts, limit, hs, cs);
+            if (!multi) { hashes.swap(hs); counts.swap(cs); return; }
+            if (acc.num == 0 && acc.max_hash == 0) acc.max_hash = UINT64_MAX;   // make the accumulator accept everything
+            acc.add_sorted_batch(hs.data(), want_counts ? cs.data() : nullptr, hs.size());
+        }
+        hashes.swap(acc.mins);
+        if (want_counts) counts.swap(acc.abunds);
+    }
+
+    // ---- per-k-mer hashes of a host buffer (0 for bad k-mers) ----------------------------------
+    void kmer_hashes_host(const uint8_t* seq, size_t len, uint32_t k, uint64_t seed, std::vector<uint64_t>& out) {
+        out.clear();
+        if (len < k || k == 0) return;
+        const size_t nk = len - k + 1;
+        upload_seq(seq, len);
+        out_.reserve(nk * 8);
+        hip_check(hipMemsetAsync(out_.p, 0, nk * 8, stream_), "memset");
+        hip_check(kmer_hashes_launch(seq_.as<uint8_t>(), len, k, seed, out_.as<uint64_t>(), nk, stream_), "kmer_hashes");
+        out.resize(nk);
+        hip_check(hipMemcpyAsync(out.data(), out_.p, nk * 8, hipMemcpyDeviceToHost, stream_), "D2H");
+        hip_check(hipStreamSynchronize(stream_), "sync");
+    }
+
+    // ---- position of the first byte outside ACGTacgt, or SIZE_MAX ------------------------------
+    size_t first_invalid_host(const uint8_t* seq, size_t len) {
+        if (len == 0) return SIZE_MAX;
+        upload_seq(seq, len);
+        unsigned long long* d = scalars_.as<unsigned long long>();
+        hip_check(hipMemsetAsync(d, 0xff, 8, stream_), "memset");
+        hip_check(first_invalid_launch(seq_.as<uint8_t>(), len, d, stream_), "first_invalid");
+        unsigned long long h = 0;
+        hip_check(hipMemcpyAsync(&h, d, 8, hipMemcpyDeviceToHost, stream_), "D2H");
+        hip_check(hipStreamSynchronize(stream_), "sync");
+        return h == ~0ull ? SIZE_MAX : (size_t)h;
+    }
+
+    // ---- pair statistics of two sorted sketches -------------------------------------------------
+    // want_list: also return the sorted intersection.  num != 0: apply the bottom-k rule.
+    PairStats pair(const KmerMinHash& a, const KmerMinHash& b, bool want_abund, bool want_list, uint64_t num,
+                   std::vector<uint64_t>* list) {
+        PairStats st;
+        if (list) list->clear();
+        // search the shorter list's hashes in the longer one (minhash.rs:550-554 swaps likewise)
+        const KmerMinHash& A = a.size() <= b.size() ? a : b;
+        const KmerMinHash& B = a.size() <= b.size() ? b : a;
+        const size_t na = A.size(), nb = B.size();
+        const bool ab = want_abund && a.track_abundance && b.track_abundance;
+        // device layout: [A mins][B mins][A abunds][B abunds][I list]
+        const size_t words = 2 * (na + nb) + na + 16;
+        pair_.reserve(words * 8);
+        uint64_t* dA = pair_.as<uint64_t>();
+        uint64_t* dB = dA + na;
+        uint64_t* dAa = dB + nb;
+        uint64_t* dBa = dAa + na;
+        uint64_t* dI = dBa + nb;
+        flags_.reserve(na + 16);
+        unsigned long long* sums = scalars_.as<unsigned long long>();   // [0..3] sums, [4] list size, [5] num count
+        hip_check(hipMemsetAsync(sums, 0, 64, stream_), "memset");
+        if (na) hip_check(hipMemcpyAsync(dA, A.mins.data(), na * 8, hipMemcpyHostToDevice, stream_), "H2D");
+        if (nb) hip_check(hipMemcpyAsync(dB, B.mins.data(), nb * 8, hipMemcpyHostToDevice, stream_), "H2D");
+        if (ab) {
+            if (na) hip_check(hipMemcpyAsync(dAa, A.abunds.data(), na * 8, hipMemcpyHostToDevice, stream_), "H2D");
+            if (nb) hip_check(hipMemcpyAsync(dBa, B.abunds.data(), nb * 8, hipMemcpyHostToDevice, stream_), "H2D");
+        }
+        const bool need_list = want_list || num != 0;
+        hip_check(pair_match_launch(dA, na, dB, nb, ab ? dAa : nullptr, ab ? dBa : nullptr,
+                                    need_list ? flags_.as<uint8_t>() : nullptr, sums, 0, stream_), "pair_match");
+        if (ab) {
+            hip_check(sumsq_launch(dAa, na, sums + 2, stream_), "sumsq");
+            hip_check(sumsq_launch(dBa, nb, sums + 3, stream_), "sumsq");
+        }
+        if (need_list && na && nb) {
+            const size_t tb = select_temp_bytes(na);
+            temp_.reserve(tb);
+            hip_check(select_flagged(dA, flags_.as<uint8_t>(), na, dI, (uint64_t*)(sums + 4), temp_.p, tb, stream_), "select");
+        }
+        unsigned long long h[8] = {0};
+        hip_check(hipMemcpyAsync(h, sums, 64, hipMemcpyDeviceToHost, stream_), "D2H");
+        hip_check(hipStreamSynchronize(stream_), "sync");
+        st.common = h[0]; st.prod = h[1];
+        // sums[2]/[3] belong to the (possibly swapped) A/B
+        const bool swapped = &A != &a;
+        st.a_sq = swapped ? h[3] : h[2];
+        st.b_sq = swapped ? h[2] : h[3];
+        const uint64_t ni = need_list ? h[4] : 0;
+        if (num != 0 && ni) {
+            hip_check(num_rank_launch(dI, ni, dA, na, dB, nb, num, sums + 5, stream_), "num_rank");
+            hip_check(hipMemcpyAsync(h, sums, 64, hipMemcpyDeviceToHost, stream_), "D2H");
+            hip_check(hipStreamSynchronize(stream_), "sync");
+            st.common_num = h[5];
+        }
+        if (want_list && list && ni) {
+            list->resize(ni);
+            hip_check(hipMemcpyAsync(list->data(), dI, ni * 8, hipMemcpyDeviceToHost, stream_), "D2H");
+            hip_check(hipStreamSynchronize(stream_), "sync");
+        }
+        return st;
+    }
+
+  private:
+    DeviceCtx() = default;
+
+    void upload_seq(const uint8_t* seq, size_t len) {
+        seq_.reserve(len + 64);
+        hip_check(hipMemcpyAsync(seq_.p, seq, len, hipMemcpyHostToDevice, stream_), "H2D");
+    }
+
+    void sketch_chunk(const uint8_t* seq, size_t len, uint32_t k, uint64_t seed, uint64_t thr, bool want_counts,
+                      size_t limit, std::vector<uint64_t>& hashes, std::vector<uint64_t>& counts) {
+        hashes.clear(); counts.clear();
+        const size_t nk = len - k + 1;
+        upload_seq(seq, len);
+        const double frac = (double)thr / 18446744073709551616.0;
+        const double expect = (double)nk * frac;
+        size_t cap = (size_t)(expect * 1.5 + 8.0 * std::sqrt(expect + 1.0)) + 4096;
+        if (cap > nk) cap = nk;
+        unsigned long long* d_cnt = scalars_.as<unsigned long long>();
+        unsigned long long kept = 0;
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            out_.reserve(cap * 8);
+            hip_check(hipMemsetAsync(d_cnt, 0, 16, stream_), "memset");
+            hip_check(sketch_dna_launch(seq_.as<uint8_t>(), len, k, seed, thr, out_.as<uint64_t>(), d_cnt, cap, stream_),
+                      "sketch_dna");
+            hip_check(hipMemcpyAsync(&kept, d_cnt, 8, hipMemcpyDeviceToHost, stream_), "D2H");
+            hip_check(hipStreamSynchronize(stream_), "sync");
+            if (kept <= cap) break;
+            cap = (size_t)kept;                 // repetitive input beat the estimate: rerun with the exact size
+        }
+        if (kept == 0) return;
+        const size_t tb = sort_unique_temp_bytes(kept);
+        temp_.reserve(tb);
+        uniq_.reserve((size_t)kept * 16 + 64);
+        uint64_t* d_u = uniq_.as<uint64_t>();
+        uint64_t* d_c = d_u + kept;
+        int bits = 64;
+        if (thr != ~0ull) { bits = 1; while (bits < 64 && (thr >> bits)) ++bits; }
+        hip_check(sort_unique(out_.as<uint64_t>(), kept, d_u, d_c, (uint64_t*)(d_cnt + 1), temp_.p, tb, bits, stream_),
+                  "sort_unique");
+        unsigned long long nu = 0;
+        hip_check(hipMemcpyAsync(&nu, d_cnt + 1, 8, hipMemcpyDeviceToHost, stream_), "D2H");
+        hip_check(hipStreamSynchronize(stream_), "sync");
+        size_t take = (size_t)nu;
+        if (limit && take > limit) take = limit;        // bottom-k: only the smallest `num` can ever be kept
+        hashes.resize(take);
+        hip_check(hipMemcpyAsync(hashes.data(), d_u, take * 8, hipMemcpyDeviceToHost, stream_), "D2H");
+        if (want_counts) {
+            counts.resize(take);
+            hip_check(hipMemcpyAsync(counts.data(), d_c, take * 8, hipMemcpyDeviceToHost, stream_), "D2H");
+        }
+        hip_check(hipStreamSynchronize(stream_), "sync");
+    }
+
+    hipStream_t stream_ = nullptr;
+    std::mutex mu_;
+    DevBuf seq_, out_, uniq_, temp_, scalars_, pair_, flags_;
+};
+
+}  // namespace smg

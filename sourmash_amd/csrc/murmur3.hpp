@@ -1,0 +1,109 @@
+// MurmurHash3_x64_128 (low 64 bits), host + gfx950 device.
+//
+// Replaces: src/core/src/lib.rs:57-59 `_hash_murmur(kmer, seed) =
+// murmurhash3_x64_128(kmer, seed).0` (crate murmurhash3 0.0.5, un-vendored; the
+// algorithm is Appleby's public-domain MurmurHash3_x64_128 with the u64 seed
+// loaded into both h1 and h2) and its C export `hash_murmur`
+// (src/core/src/ffi/mod.rs:22-31, include/sourmash.h:133).
+//
+// Two forms:
+//   * mmh3_h1_bytes(ptr, len, seed)      -- any length, host and device.
+//   * mmh3_h1_words<K>(w[], seed)        -- K known at compile time, the key
+//     already assembled as little-endian 32-bit words, zero padded.  This is
+//     what the sketch kernel calls once per k-mer: 12 64-bit multiplies for
+//     K = 31 (4 in the 16-byte block, 4 in the 15-byte tail, 4 in fmix64 x2).
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define SMG_HD __host__ __device__ __forceinline__
+#else
+#define SMG_HD inline
+#endif
+
+namespace smg {
+
+constexpr uint64_t MMH3_C1 = 0x87c37b91114253d5ULL;
+constexpr uint64_t MMH3_C2 = 0x4cf5ad432745937fULL;
+
+SMG_HD uint64_t rotl64(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
+
+SMG_HD uint64_t fmix64(uint64_t k) {
+    k ^= k >> 33;
+    k *= 0xff51afd7ed558ccdULL;
+    k ^= k >> 33;
+    k *= 0xc4ceb9fe1a85ec53ULL;
+    k ^= k >> 33;
+    return k;
+}
+
+SMG_HD void mmh3_block(uint64_t& h1, uint64_t& h2, uint64_t k1, uint64_t k2) {
+    k1 *= MMH3_C1; k1 = rotl64(k1, 31); k1 *= MMH3_C2; h1 ^= k1;
+    h1 = rotl64(h1, 27); h1 += h2; h1 = h1 * 5 + 0x52dce729;
+    k2 *= MMH3_C2; k2 = rotl64(k2, 33); k2 *= MMH3_C1; h2 ^= k2;
+    h2 = rotl64(h2, 31); h2 += h1; h2 = h2 * 5 + 0x38495ab5;
+}
+
+SMG_HD uint64_t mmh3_finish(uint64_t h1, uint64_t h2, uint64_t len) {
+    h1 ^= len; h2 ^= len;
+    h1 += h2; h2 += h1;
+    h1 = fmix64(h1); h2 = fmix64(h2);
+    return h1 + h2;
+}
+
+// Key given as zero-padded little-endian dwords w[0 .. ceil(K/4)-1].
+template <int K>
+SMG_HD uint64_t mmh3_h1_words(const uint32_t* w, uint64_t seed) {
+    constexpr int NB = K / 16;     // full 16-byte blocks
+    constexpr int T = K % 16;      // tail bytes
+    constexpr int NW = (K + 3) / 4;
+    uint64_t h1 = seed, h2 = seed;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        uint64_t k1 = (uint64_t)w[4 * b] | ((uint64_t)w[4 * b + 1] << 32);
+        uint64_t k2 = (uint64_t)w[4 * b + 2] | ((uint64_t)w[4 * b + 3] << 32);
+        mmh3_block(h1, h2, k1, k2);
+    }
+    constexpr int tb = 4 * NB;
+    if (T > 8) {
+        uint64_t k2 = (uint64_t)w[tb + 2];
+        if (tb + 3 < NW) k2 |= (uint64_t)w[tb + 3] << 32;
+        k2 *= MMH3_C2; k2 = rotl64(k2, 33); k2 *= MMH3_C1; h2 ^= k2;
+    }
+    if (T > 0) {
+        uint64_t k1 = (uint64_t)w[tb];
+        if (tb + 1 < NW) k1 |= (uint64_t)w[tb + 1] << 32;
+        k1 *= MMH3_C1; k1 = rotl64(k1, 31); k1 *= MMH3_C2; h1 ^= k1;
+    }
+    return mmh3_finish(h1, h2, (uint64_t)K);
+}
+
+// Any length, byte pointer (host `hash_murmur`, `add_word`; generic-k kernel).
+SMG_HD uint64_t mmh3_h1_bytes(const uint8_t* data, uint64_t len, uint64_t seed) {
+    uint64_t h1 = seed, h2 = seed;
+    const uint64_t nblocks = len / 16;
+    for (uint64_t i = 0; i < nblocks; ++i) {
+        uint64_t k1 = 0, k2 = 0;
+        for (int j = 7; j >= 0; --j) {
+            k1 = (k1 << 8) | data[16 * i + j];
+            k2 = (k2 << 8) | data[16 * i + 8 + j];
+        }
+        mmh3_block(h1, h2, k1, k2);
+    }
+    const uint8_t* tail = data + 16 * nblocks;
+    const int t = (int)(len & 15);
+    if (t > 8) {
+        uint64_t k2 = 0;
+        for (int j = t - 1; j >= 8; --j) k2 = (k2 << 8) | tail[j];
+        k2 *= MMH3_C2; k2 = rotl64(k2, 33); k2 *= MMH3_C1; h2 ^= k2;
+    }
+    if (t > 0) {
+        uint64_t k1 = 0;
+        for (int j = (t > 8 ? 8 : t) - 1; j >= 0; --j) k1 = (k1 << 8) | tail[j];
+        k1 *= MMH3_C1; k1 = rotl64(k1, 31); k1 *= MMH3_C2; h1 ^= k1;
+    }
+    return mmh3_finish(h1, h2, len);
+}
+
+}  // namespace smg

@@ -1,0 +1,27 @@
+// Internal launchers of pair_ops.hip (raw device pointers, no allocation).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+namespace smg {
+
+// sums layout (device, 4 x u64, zeroed by the caller):
+//   [0] |A ∩ B|   [1] sum abundA*abundB over matches   [2] sum abundA^2   [3] sum abundB^2
+hipError_t pair_match_launch(const uint64_t* A, uint64_t na, const uint64_t* B, uint64_t nb, const uint64_t* abA,
+                             const uint64_t* abB, uint8_t* flags, unsigned long long* sums, int invert,
+                             hipStream_t stream);  // invert: flag hashes of A NOT in B
+hipError_t sumsq_launch(const uint64_t* a, uint64_t n, unsigned long long* dst, hipStream_t stream);
+hipError_t num_rank_launch(const uint64_t* I, uint64_t ni, const uint64_t* A, uint64_t na, const uint64_t* B,
+                           uint64_t nb, uint64_t num, unsigned long long* dst, hipStream_t stream);
+size_t select_temp_bytes(uint64_t n);
+hipError_t select_flagged(const uint64_t* in, const uint8_t* flags, uint64_t n, uint64_t* out, uint64_t* d_n_out,
+                          void* temp, size_t temp_bytes, hipStream_t stream);
+// op 0: overlap[d] = |Q ∩ D_d| ; op 1: overlap[d] -= |Q ∩ D_d| (saturating, rows at 0 skipped)
+hipError_t overlap_vector_launch(const uint64_t* Q, uint64_t nq, const uint64_t* hashes, const uint64_t* offsets,
+                                 uint64_t ndb, unsigned long long* overlap, int op, hipStream_t stream);
+// *best = max(*best, (count << 32) | ~(index_base + d)) over rows with count > 0
+hipError_t argmax_launch(const unsigned long long* overlap, uint64_t ndb, uint64_t index_base,
+                         unsigned long long* best, hipStream_t stream);
+
+}  // namespace smg

@@ -1,0 +1,130 @@
+"""Device-resident batch API: torch tensors in, torch tensors out.
+
+PyTorch is plumbing here -- it owns the HBM allocations, the current HIP stream
+and (in parallel.py) the RCCL process group; every computation is one of the
+raw C-ABI entry points of include/sourmash_amd.h (smgpu_*_raw), i.e. the
+hand-written HIP kernels.  Nothing in this module runs on the CPU: without a GPU
+every function raises.
+"""
+import ctypes as C
+
+from ._lowlevel import lib
+from .minhash import _get_max_hash_for_scaled
+from .exceptions import SourmashError, exceptions_by_code
+from .utils import decode_str, rustcall
+
+
+def _torch():
+    import torch
+    if not torch.cuda.is_available():
+        raise RuntimeError("sourmash_amd.device needs a HIP device (no CPU fallback)")
+    return torch
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr())
+
+
+def _stream(torch):
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _u64(torch, n, device):
+    # torch has no uint64 arithmetic but int64 storage is all we need (bit patterns)
+    return torch.empty(int(n), dtype=torch.int64, device=device)
+
+
+def synth_dna(n, seed=42, record_len=0, start=0, device="cuda", out=None):
+    "n bytes of the BASELINE C2 random-DNA stream generated in HBM (uint8 tensor)."
+    torch = _torch()
+    if out is None:
+        out = torch.empty(int(n), dtype=torch.uint8, device=device)
+    rustcall(lib.smgpu_synth_dna_raw, _ptr(out), int(start), int(n), int(seed), int(record_len), _stream(torch))
+    return out
+
+
+class DeviceSketcher:
+    """Reusable scratch for sketching device-resident sequence buffers.
+
+    sketch(seq) -> int64 tensor viewing the sorted unique kept hashes (u64 bit patterns).
+    Capacity is sized from scaled (expected kept = len/scaled) with slack; on
+    overflow the buffers grow and the call is repeated.
+    """
+
+    def __init__(self, ksize=31, scaled=1000, seed=42, device="cuda"):
+        self.torch = _torch()
+        self.ksize, self.scaled, self.seed, self.device = int(ksize), int(scaled), int(seed), device
+        self.max_hash = _get_max_hash_for_scaled(scaled)
+        self.cap = 0
+        self.out = self.ws = None
+        self.result = self.torch.zeros(2, dtype=self.torch.int64, device=device)
+
+    def _reserve(self, cap):
+        if cap <= self.cap:
+            return
+        torch = self.torch
+        self.cap = int(cap)
+        self.out = _u64(torch, self.cap, self.device)
+        nbytes = lib.smgpu_sketch_workspace_bytes(self.cap)
+        self.ws = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+
+    def capacity_for(self, n_bases):
+        expect = n_bases / max(self.scaled, 1)
+        return int(expect * 1.25 + 8 * expect ** 0.5 + 4096)
+
+    def sketch(self, seq):
+        torch = self.torch
+        assert seq.dtype == torch.uint8 and seq.is_cuda and seq.is_contiguous()
+        n = seq.numel()
+        self._reserve(self.capacity_for(n))
+        for attempt in range(2):
+            lib.sourmash_err_clear()
+            got = lib.smgpu_sketch_dna_raw(_ptr(seq), n, self.ksize, self.seed, self.max_hash, _ptr(self.out),
+                                           self.cap, _ptr(self.result), _ptr(self.ws), self.ws.numel(),
+                                           _stream(torch))
+            code = lib.sourmash_err_get_last_code()
+            if code == 0:
+                return self.out[:got]
+            message = decode_str(lib.sourmash_err_get_last_message())
+            kept = int(self.result[0].item())
+            if attempt == 0 and kept > self.cap:   # repetitive input beat the estimate: grow and retry once
+                self._reserve(kept + 1024)
+                continue
+            raise exceptions_by_code.get(code, SourmashError)(message)
+
+    def kernel_only(self, seq, out, count):
+        "Just the k-mer kernel (no sort): appends to `out`, adds to `count` (int64[1], caller zeroes)."
+        torch = self.torch
+        rustcall(lib.smgpu_sketch_dna_kernel_raw, _ptr(seq), seq.numel(), self.ksize, self.seed, self.max_hash,
+                 _ptr(out), out.numel(), _ptr(count), _stream(torch))
+
+
+def pack_csr(sketches, device="cuda"):
+    "list of sorted u64 numpy arrays -> (hashes int64 tensor, offsets int64 tensor) on device."
+    import numpy as np
+    torch = _torch()
+    offsets = np.zeros(len(sketches) + 1, dtype=np.int64)
+    for i, s in enumerate(sketches):
+        offsets[i + 1] = offsets[i] + len(s)
+    flat = np.concatenate([np.asarray(s, dtype=np.uint64) for s in sketches]) if len(sketches) and offsets[-1] \
+        else np.zeros(0, dtype=np.uint64)
+    hashes = torch.from_numpy(flat.view(np.int64).copy()).to(device)
+    if hashes.numel() == 0:
+        hashes = torch.zeros(2, dtype=torch.int64, device=device)
+    return hashes, torch.from_numpy(offsets).to(device)
+
+
+def compare_rows(hashes, offsets, row_lo=0, row_hi=None, want_jaccard=True, common=None, jaccard=None):
+    """common[(row_hi-row_lo), n] (int32 view of u32) and jaccard (float64) for a row block of the
+    all-pairs matrix of a device CSR.  Asynchronous on the current stream."""
+    torch = _torch()
+    n = offsets.numel() - 1
+    row_hi = n if row_hi is None else row_hi
+    rows = row_hi - row_lo
+    if common is None:
+        common = torch.empty((rows, n), dtype=torch.int32, device=hashes.device)
+    if want_jaccard and jaccard is None:
+        jaccard = torch.empty((rows, n), dtype=torch.float64, device=hashes.device)
+    rustcall(lib.smgpu_compare_raw, _ptr(hashes), _ptr(offsets), n, row_lo, row_hi, _ptr(common),
+             _ptr(jaccard) if want_jaccard else None, _stream(torch))
+    return common, (jaccard if want_jaccard else None)

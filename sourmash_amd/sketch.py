@@ -1,0 +1,244 @@
+"""`sourmash sketch dna` driver: parameter strings, FASTA/FASTQ ingest, sketching.
+
+Thin host layer around the GPU path:
+  src/sourmash/command_sketch.py:33-87    parameter-string grammar ("k=31,scaled=1000,abund")
+  src/sourmash/command_sketch.py:90-186   one signature template per parameter string
+  src/sourmash/command_sketch.py:662-832  per-file driver: every record of a file accumulates
+                                          into the same signatures (unless singleton)
+  src/sourmash/command_sketch.py:864-1085 ComputeParameters over computeparams_*
+Where the reference crosses the FFI once per FASTA record, `sketch_file` joins the
+records of a file with a separator byte and crosses it once per file: a byte
+outside ACGT kills exactly the k-mers that would span two records, which is what
+one add_sequence call per record achieves (force=True semantics, the CLI default).
+"""
+import ctypes as C
+import gzip
+import io
+
+from ._lowlevel import ffi, lib
+from .minhash import MINHASH_DEFAULT_SEED
+from .signature import SourmashSignature
+from .utils import RustObject, rustcall
+
+DEFAULTS = dict(dna="k=31,scaled=1000,noabund")   # command_sketch.py:25-30 (DNA row; other moltypes are out of scope)
+MIN_SCALED, MAX_SCALED = 100, 1e6                 # advisory bounds of sourmash_args.py:61-82 (warnings there, not errors)
+
+
+def parse_params_str(params_str):
+    "-> (moltype or None, dict(ksize=[...], num=, scaled=, seed=, track_abundance=)); command_sketch.py:33-87"
+    moltype, params = None, {"ksize": []}
+    for item in params_str.split(","):
+        if item == "abund":
+            params["track_abundance"] = True
+        elif item == "noabund":
+            params["track_abundance"] = False
+        elif item in ("protein", "dayhoff", "hp", "dna"):
+            moltype = item
+        elif item.startswith("scaled"):
+            if len(item) < 8 or item[6] != "=":
+                raise ValueError("scaled takes a parameter, e.g. 'scaled=1000'")
+            if params.get("num"):
+                raise ValueError("cannot set both num and scaled in a single minhash")
+            try:
+                scaled = int(item[7:])
+            except ValueError:
+                raise ValueError(f"cannot parse scaled='{item[7:]}' as an integer")
+            if scaled < 0:
+                raise ValueError("ERROR: scaled value must be positive")
+            params["scaled"], params["num"] = scaled, 0
+        elif item.startswith("seed"):
+            if len(item) < 6 or item[4] != "=":
+                raise ValueError("seed takes a parameter, e.g. 'seed=42'")
+            params["seed"] = int(item[5:])
+        elif item.startswith("num"):
+            if len(item) < 5 or item[3] != "=":
+                raise ValueError("num takes a parameter, e.g. 'num=500'")
+            if params.get("scaled"):
+                raise ValueError("cannot set both num and scaled in a single minhash")
+            try:
+                num = int(item[4:])
+            except ValueError:
+                raise ValueError(f"cannot parse num='{item[4:]}' as a number")
+            if num < 0:
+                raise ValueError("ERROR: num value must be positive")
+            params["num"], params["scaled"] = num, 0
+        elif item.startswith("k"):
+            if len(item) < 3 or item[1] != "=":
+                raise ValueError("k takes a parameter, e.g. 'k=31'")
+            params["ksize"].append(int(item[2:]))
+        else:
+            raise ValueError(f"unknown component '{item}' in params string")
+    return moltype, params
+
+
+class ComputeParameters(RustObject):
+    "Parameter block that crosses the ABI (command_sketch.py:864-1085 over ffi/cmd/compute.rs)."
+    __dealloc_func__ = lib.computeparams_free
+
+    def __init__(self, *, ksizes=(21, 31, 51), seed=42, protein=False, dayhoff=False, hp=False, dna=True,
+                 num_hashes=500, track_abundance=False, scaled=0):
+        self._objptr = lib.computeparams_new()
+        self.seed = seed
+        self.ksizes = ksizes
+        self.protein, self.dayhoff, self.hp, self.dna = protein, dayhoff, hp, dna
+        self.num_hashes = num_hashes
+        self.track_abundance = track_abundance
+        self.scaled = scaled
+
+    @classmethod
+    def from_param_str(cls, params_str, default_moltype="dna"):
+        "One parameter string layered over the moltype defaults (command_sketch.py:90-186)."
+        moltype, params = parse_params_str(params_str)
+        moltype = moltype or default_moltype
+        if moltype != "dna":
+            raise ValueError("sourmash_amd sketches DNA only (protein/dayhoff/hp are out of scope, SURVEY.md 8f)")
+        _, merged = parse_params_str(DEFAULTS["dna"])
+        if params["ksize"]:
+            merged["ksize"] = params["ksize"]
+        for key in ("seed", "track_abundance"):
+            if key in params:
+                merged[key] = params[key]
+        if "num" in params or "scaled" in params:
+            merged["num"], merged["scaled"] = params.get("num", 0), params.get("scaled", 0)
+        return cls(ksizes=merged["ksize"], seed=merged.get("seed", MINHASH_DEFAULT_SEED), dna=True,
+                   num_hashes=merged.get("num", 0), track_abundance=merged.get("track_abundance", False),
+                   scaled=merged.get("scaled", 0))
+
+    def _flag(name):   # noqa: N805
+        getter, setter = getattr(lib, "computeparams_" + name), getattr(lib, "computeparams_set_" + name)
+        return property(lambda self: self._methodcall(getter), lambda self, v: self._methodcall(setter, v))
+
+    seed = _flag("seed")
+    protein = _flag("protein")
+    dayhoff = _flag("dayhoff")
+    hp = _flag("hp")
+    dna = _flag("dna")
+    num_hashes = _flag("num_hashes")
+    track_abundance = _flag("track_abundance")
+    scaled = _flag("scaled")
+    del _flag
+
+    @property
+    def ksizes(self):
+        size = ffi.new_size()
+        ptr = self._methodcall(lib.computeparams_ksizes, C.byref(size))
+        try:
+            return [ptr[i] for i in range(size.value)]
+        finally:
+            lib.computeparams_ksizes_free(ptr, size.value)
+
+    @ksizes.setter
+    def ksizes(self, v):
+        v = list(v)
+        self._methodcall(lib.computeparams_set_ksizes, (C.c_uint32 * max(len(v), 1))(*v), len(v))
+
+    @property
+    def moltype(self):
+        return "DNA" if self.dna else "protein" if self.protein else "dayhoff" if self.dayhoff else "hp"
+
+    def to_param_str(self):
+        parts = ["dna" if self.dna else "protein" if self.protein else "hp" if self.hp else "dayhoff"]
+        parts += [f"k={k}" for k in self.ksizes]
+        parts.append(f"scaled={self.scaled}" if self.scaled else f"num={self.num_hashes}")
+        if self.seed != MINHASH_DEFAULT_SEED:
+            parts.append(f"seed={self.seed}")
+        parts.append("abund" if self.track_abundance else "noabund")
+        return ",".join(parts)
+
+
+# ---- FASTA / FASTQ ingest (screed replacement) --------------------
+def _open_maybe_gzip(path):
+    fh = open(path, "rb")
+    magic = fh.read(2)
+    fh.seek(0)
+    return gzip.open(fh, "rb") if magic == b"\x1f\x8b" else fh
+
+
+def read_records(path):
+    "Yield (name, sequence-bytes) from FASTA or FASTQ (optionally gzip); newlines stripped."
+    with _open_maybe_gzip(path) as fh:
+        data = io.BufferedReader(fh) if not isinstance(fh, io.BufferedReader) else fh
+        first = data.peek(1)[:1]
+        if first == b"@":                                    # FASTQ: 4-line records
+            while True:
+                head = data.readline()
+                if not head:
+                    return
+                seq = data.readline().rstrip(b"\r\n")
+                data.readline()
+                data.readline()
+                yield head[1:].rstrip(b"\r\n").decode("utf-8", "replace"), seq
+        name, chunks = None, []
+        for line in data:
+            if line.startswith(b">"):
+                if name is not None:
+                    yield name, b"".join(chunks)
+                name, chunks = line[1:].rstrip(b"\r\n").decode("utf-8", "replace"), []
+            elif name is not None:
+                chunks.append(line.rstrip(b"\r\n"))
+        if name is not None:
+            yield name, b"".join(chunks)
+
+
+def sketch_records(records, param_str=DEFAULTS["dna"], *, name="", filename="", check_sequence=False,
+                   singleton=False):
+    """Sketch an iterable of (name, sequence) records.
+
+    singleton=False: one SourmashSignature (all ksizes) for the whole input
+    (command_sketch.py:741-768); singleton=True: one per record (:712-739).
+    check_sequence=True maps to force=False (cli/sketch/dna.py:42-46)."""
+    params = ComputeParameters.from_param_str(param_str)
+    force = not check_sequence
+    if singleton:
+        out = []
+        for rec_name, seq in records:
+            sig = SourmashSignature.from_params(params)
+            sig.add_sequence(seq, force)
+            sig.name = rec_name
+            if filename:
+                sig.filename = filename
+            out.append(sig)
+        return out
+    sig = SourmashSignature.from_params(params)
+    if force:
+        # one FFI crossing per file: records joined by a byte that no k-mer may span
+        joined = b"\n".join(seq for _, seq in records)
+        for mh_sig in [sig]:
+            _add_buffer_to_signature(mh_sig, joined)
+    else:
+        for _, seq in records:
+            sig.add_sequence(seq, False)
+    if name:
+        sig.name = name
+    if filename:
+        sig.filename = filename
+    return [sig]
+
+
+def _add_buffer_to_signature(sig, buf):
+    "Feed one buffer to every sketch of a signature through the batch entry point."
+    mhs = sig.minhashes()
+    if len(mhs) == 1:
+        mh = mhs[0].to_mutable()
+        mh.add_sequence_buffer(buf, force=True)
+        sig.minhash = mh
+        return
+    # several sketches: rebuild the signature sketch by sketch
+    first = True
+    for fmh in mhs:
+        mh = fmh.to_mutable()
+        mh.add_sequence_buffer(buf, force=True)
+        if first:
+            rustcall(lib.signature_set_mh, sig._get_objptr(), mh._get_objptr())
+            first = False
+        else:
+            rustcall(lib.signature_push_mh, sig._get_objptr(), mh._get_objptr())
+
+
+def sketch_file(path, param_str=DEFAULTS["dna"], *, name=None, check_sequence=False, singleton=False):
+    "`sourmash sketch dna -p <param_str> <path>` -> list of SourmashSignature."
+    recs = list(read_records(path))
+    if name is None and not singleton and recs:
+        name = ""
+    return sketch_records(recs, param_str, name=name or "", filename=str(path), check_sequence=check_sequence,
+                          singleton=singleton)

@@ -1,0 +1,56 @@
+"""Synthetic sketch collections for the compare / gather configurations
+(BASELINE.json configs C3-C5; generators of SURVEY.md section 8d).  Pure numpy,
+deterministic, identical on every host -- inputs only, no product logic.
+"""
+import numpy as np
+
+MASK = np.uint64(0xFFFFFFFFFFFFFFFF)
+MAX_HASH_1000 = 18446744073709552
+
+
+def splitmix64(x):
+    "vectorised splitmix64 finaliser over uint64 arrays (wrapping arithmetic)."
+    x = np.asarray(x, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        x = x + np.uint64(0x9E3779B97F4A7C15)
+        x = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        return x ^ (x >> np.uint64(31))
+
+
+def synth_sketches(n, seed=1234, pool_size=50_000, keep_one_in=10, max_hash=MAX_HASH_1000, planted=True):
+    """n sorted unique u64 sketches of ~pool_size/keep_one_in hashes drawn from a shared pool
+    (E|A ∩ B| ~ pool_size/keep_one_in^2), plus planted edge rows at the end when planted:
+    a duplicate of row 0, a sketch disjoint from the pool, a 1-hash sketch, the whole pool."""
+    j = np.arange(pool_size, dtype=np.uint64)
+    pool = np.unique(splitmix64(np.uint64(seed) + j) % np.uint64(max_hash + 1))
+    pool = pool[pool > 0]
+    n_plain = n - 4 if planted and n >= 8 else n
+    out = []
+    jj = np.arange(len(pool), dtype=np.uint64)
+    for i in range(n_plain):
+        key = (np.uint64(i) << np.uint64(32)) ^ jj ^ np.uint64(0x9E3779B97F4A7C15) ^ np.uint64(seed)
+        sel = splitmix64(key) % np.uint64(keep_one_in) == 0
+        out.append(pool[sel])
+    if n_plain != n:
+        out.append(out[0].copy())                                        # identical pair -> jaccard 1.0
+        priv = np.unique(splitmix64((np.uint64(1) << np.uint64(61)) + np.uint64(seed) + np.arange(5000, dtype=np.uint64)) % np.uint64(max_hash + 1))
+        out.append(np.setdiff1d(priv[priv > 0], pool))                   # no overlap with anything
+        out.append(pool[:1].copy())                                      # 1-hash sketch
+        out.append(pool.copy())                                          # 50k-hash sketch (superset of all)
+    return out
+
+
+def synth_gather(n_query=1_000_000, n_db=100_000, db_size=5000, seed=777, max_hash=MAX_HASH_1000):
+    """(query, [db sketches]): query = n_query distinct hashes; every db sketch draws half of its
+    ~db_size hashes from the query and half from a private stream (config C5)."""
+    q = np.unique(splitmix64(np.uint64(seed) + np.arange(int(n_query * 1.01), dtype=np.uint64)) % np.uint64(max_hash + 1))
+    q = q[q > 0][:n_query]
+    half = db_size // 2
+    db = []
+    for d in range(n_db):
+        idx = splitmix64((np.uint64(d) << np.uint64(32)) ^ np.arange(half, dtype=np.uint64) ^ np.uint64(seed)) % np.uint64(len(q))
+        shared = q[np.unique(idx)]
+        priv = splitmix64((np.uint64(1) << np.uint64(62)) + (np.uint64(d) << np.uint64(33)) + np.arange(half, dtype=np.uint64) + np.uint64(seed)) % np.uint64(max_hash + 1)
+        db.append(np.unique(np.concatenate([shared, priv[priv > 0]])))
+    return q, db

@@ -1,0 +1,52 @@
+"""Handle ownership and the call protocol of the C-ABI.
+
+``rustcall`` keeps the reference's name (src/sourmash/utils.py:65-78) because the
+protocol is the same: clear the thread-local error, call, poll the error code,
+raise the mapped exception.  ``RustObject`` is the base of every Python class
+that owns an opaque library handle (released through ``__dealloc_func__``).
+"""
+from ._lowlevel import lib, decode_str
+from .exceptions import SourmashError, exceptions_by_code
+
+__all__ = ["RustObject", "rustcall", "decode_str"]
+
+
+def rustcall(func, *args):
+    lib.sourmash_err_clear()
+    result = func(*args)
+    code = lib.sourmash_err_get_last_code()
+    if code == 0:
+        return result
+    message = decode_str(lib.sourmash_err_get_last_message())
+    raise exceptions_by_code.get(code, SourmashError)(message)
+
+
+class RustObject:
+    __dealloc_func__ = None
+    _objptr = None
+    _shared = False
+
+    def __init__(self):
+        raise TypeError(f"Cannot instanciate {type(self).__name__!r} objects")
+
+    @classmethod
+    def _from_objptr(cls, ptr, shared=False):
+        obj = object.__new__(cls)
+        obj._objptr = ptr
+        obj._shared = shared
+        return obj
+
+    def _get_objptr(self):
+        if not self._objptr:
+            raise RuntimeError("Object is closed")
+        return self._objptr
+
+    def _methodcall(self, func, *args):
+        return rustcall(func, self._get_objptr(), *args)
+
+    def __del__(self):
+        ptr, self._objptr = self._objptr, None
+        if ptr and not self._shared:
+            free = type(self).__dealloc_func__
+            if free is not None:
+                free(ptr)

@@ -1,0 +1,181 @@
+"""GPU parity: merge-intersection kernels (pair ops + the LDS-tiled all-pairs
+compare) through the C-ABI, against the oracle and the reference's golden
+compare values.  Run with -m gpu."""
+import glob
+
+import numpy as np
+import pytest
+
+import oracle
+from conftest import golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def sm():
+    import torch  # noqa: F401
+    import sourmash_amd
+    assert sourmash_amd.gpu_available()
+    return sourmash_amd
+
+
+def _load(sm, path, ksize=None):
+    return list(sm.load_signatures_from_json(path, ksize=ksize))
+
+
+def _omh(d):
+    scaled = oracle.scaled_for_max_hash(d["max_hash"]) if d["max_hash"] else 0
+    num = 0 if d["max_hash"] else d["num"]
+    ab = "abundances" in d
+    mh = oracle.OracleMinHash(num, d["ksize"], scaled=scaled, seed=d["seed"], track_abundance=ab)
+    if ab:
+        for h, a in sorted(zip(d["mins"].tolist(), d["abundances"].tolist())):
+            mh.add_hash_with_abundance(h, a)
+    else:
+        mh.add_many(np.sort(d["mins"]))
+    return mh
+
+
+def test_demo_matrix_num_sketches(sm):
+    # tests/test_compare.py:48-63 -- num=500 sketches: bottom-k rule on the GPU pair path
+    from sourmash_amd.compare import compare_all_pairs
+    sigs = [s for f in sorted(glob.glob(golden("demo", "*.sig"))) for s in _load(sm, f)]
+    got = compare_all_pairs(sigs, ignore_abundance=True)
+    want = np.array([
+        [1.0, 0.356, 0.078, 0.086, 0.0, 0.0, 0.0],
+        [0.356, 1.0, 0.072, 0.078, 0.0, 0.0, 0.0],
+        [0.078, 0.072, 1.0, 0.074, 0.0, 0.0, 0.0],
+        [0.086, 0.078, 0.074, 1.0, 0.0, 0.0, 0.0],
+        [0.0, 0.0, 0.0, 0.0, 1.0, 0.382, 0.364],
+        [0.0, 0.0, 0.0, 0.0, 0.382, 1.0, 0.386],
+        [0.0, 0.0, 0.0, 0.0, 0.364, 0.386, 1.0]])
+    np.testing.assert_array_equal(got, want)
+
+
+def test_scaled_on_real_data(sm):
+    # tests/test_jaccard.py:207-232
+    a = _load(sm, golden("scaled100", "GCF_000005845.2_ASM584v2_genomic.fna.gz.sig.gz"))[0].minhash
+    b = _load(sm, golden("scaled100", "GCF_000006945.1_ASM694v1_genomic.fna.gz.sig.gz"))[0].minhash
+    assert round(a.similarity(b), 5) == 0.01644 == round(b.similarity(a), 5)
+    a2, b2 = a.downsample(scaled=1000), b.downsample(scaled=1000)
+    assert round(a2.similarity(b2), 5) == 0.01874
+    a3, b3 = a2.downsample(scaled=10000), b2.downsample(scaled=10000)
+    assert a3.similarity(b3) == 0.01
+    assert round(a.similarity(b2, downsample=True), 5) == 0.01874   # minhash.rs:688-696
+    with pytest.raises(ValueError) as e:                              # MismatchScaled -> ValueError
+        a.similarity(b2)
+    assert "mismatch in scaled" in str(e.value)
+    assert a.count_common(b2, downsample=True) == a2.count_common(b2)
+    with pytest.raises(ValueError):
+        a.count_common(b2)
+
+
+def test_pair_ops_vs_oracle(sm):
+    da = oracle.read_sig_json(golden("pairs", "47.fa.sig"))[0]
+    db = oracle.read_sig_json(golden("pairs", "63.fa.sig"))[0]
+    a, b = _load(sm, golden("pairs", "47.fa.sig"))[0].minhash, _load(sm, golden("pairs", "63.fa.sig"))[0].minhash
+    oa, ob = _omh(da), _omh(db)
+    assert a.count_common(b) == oa.count_common(ob) == b.count_common(a)
+    assert a.intersection_and_union_size(b) == oa.intersection_and_union_size(ob)
+    assert a.jaccard(b) == oa.jaccard(ob) and a.similarity(b) == oa.similarity(ob)
+    inter = a & b
+    want = np.intersect1d(oa.mins, ob.mins)
+    assert np.array_equal(inter._mins_array(), want) and inter.scaled == a.scaled
+    assert a.contained_by(b) == pytest.approx(len(want) / len(a), rel=1e-3)
+    e = sm.MinHash(0, 31, scaled=1000)
+    assert a.count_common(e) == 0 and a.jaccard(e) == 0.0 and e.jaccard(e) == 0.0   # tests/test_minhash.py:115-132
+    assert e.contained_by(a) == 0.0
+    # incompatible sketches: check order ksize -> moltype -> scaled -> seed (minhash.rs:886-912)
+    for other, msg in ((sm.MinHash(0, 21, scaled=1000), "different ksizes"),
+                       (sm.MinHash(0, 31, scaled=1000, seed=43), "mismatch in seed")):
+        with pytest.raises(ValueError) as err:
+            a.count_common(other)
+        assert msg in str(err.value)
+    with pytest.raises(TypeError):
+        a.intersection_and_union_size(sm.MinHash(0, 21, scaled=1000))
+
+
+def test_angular_similarity(sm):
+    da = oracle.read_sig_json(golden("pairs", "track_abund_47.fa.sig"))[0]
+    db = oracle.read_sig_json(golden("pairs", "track_abund_63.fa.sig"))[0]
+    a = _load(sm, golden("pairs", "track_abund_47.fa.sig"))[0].minhash
+    b = _load(sm, golden("pairs", "track_abund_63.fa.sig"))[0].minhash
+    oa, ob = _omh(da), _omh(db)
+    assert a.track_abundance and b.track_abundance
+    # integer sums on the GPU, sqrt/acos on the host with the same libm as the oracle: bit-identical
+    assert a.similarity(b) == oa.similarity(ob) == a.angular_similarity(b)
+    assert a.similarity(a) == 1.0
+    assert a.similarity(b, ignore_abundance=True) == oa.jaccard(ob)
+    with pytest.raises(TypeError):
+        a.angular_similarity(b.flatten())
+
+
+def _check_csr(sm, sketches):
+    mhs = []
+    for s in sketches:
+        mh = sm.MinHash(0, 31, scaled=1000)
+        mh.add_many(s)
+        mhs.append(mh)
+    from sourmash_amd.compare import common_matrix
+    common, jac = common_matrix(mhs)
+    hashes, offsets = oracle.make_csr(sketches)
+    wc, wj = oracle.compare_all_pairs(hashes, offsets, nthreads=8)
+    assert np.array_equal(common, wc)
+    assert np.array_equal(jac.view(np.uint64), wj.view(np.uint64))       # bit-identical f64
+    return common, jac
+
+
+def test_compare_small_and_ragged(sm):
+    from sourmash_amd.synth import synth_sketches
+    rng = np.random.default_rng(1)
+    sk = synth_sketches(40, pool_size=3000)
+    sk.append(np.zeros(0, dtype=np.uint64))                              # empty row
+    sk.append(np.sort(rng.choice(sk[-2], size=1234, replace=False)))     # subset of the big row
+    sk.append(np.arange(1, 700, dtype=np.uint64))                        # dense small values
+    sk.append(np.array([2**64 - 1], dtype=np.uint64))                    # max u64 (only fits scaled=1 in practice)
+    sk[-1] = np.array([18446744073709552], dtype=np.uint64)              # exactly max_hash
+    common, jac = _check_csr(sm, sk)
+    n = len(sk)
+    assert np.array_equal(common, common.T) and np.all(np.diag(jac) == 1.0)
+    assert common[0, 36] == len(sk[0]) and jac[0, 36] == 1.0            # planted duplicate of row 0
+    _check_csr(sm, [sk[3]])                                              # 1 x 1
+    _check_csr(sm, sk[:17])                                              # one tile + 1
+
+
+def test_compare_c3_full(sm):
+    """BASELINE config C3: 1,000 sketches x ~5,000 hashes (+ planted rows), full matrix vs oracle."""
+    from sourmash_amd.synth import synth_sketches
+    common, jac = _check_csr(sm, synth_sketches(1000, seed=1234))
+    assert common.shape == (1000, 1000)
+
+
+def test_compare_device_rows(sm):
+    import torch
+    from sourmash_amd import device as smd
+    from sourmash_amd.synth import synth_sketches
+    sk = synth_sketches(150, pool_size=8000)
+    h, off = smd.pack_csr(sk)
+    full_c, full_j = smd.compare_rows(h, off)
+    torch.cuda.synchronize()
+    hashes, offsets = oracle.make_csr(sk)
+    wc, wj = oracle.compare_all_pairs(hashes, offsets, nthreads=8)
+    assert np.array_equal(full_c.cpu().numpy().view(np.uint32), wc)
+    # row-block shards (the multi-GPU partition) reproduce the same rows
+    for lo, hi in ((0, 37), (37, 101), (101, 150)):
+        c, j = smd.compare_rows(h, off, lo, hi)
+        torch.cuda.synchronize()
+        assert np.array_equal(c.cpu().numpy().view(np.uint32), wc[lo:hi])
+        assert np.array_equal(j.cpu().numpy().view(np.uint64), wj[lo:hi].view(np.uint64))
+
+
+def test_containment_matrices(sm):
+    from sourmash_amd.compare import (compare_serial_containment, compare_serial_max_containment,
+                                      compare_serial_avg_containment)
+    sigs = [_load(sm, golden("pairs", f))[0] for f in ("47.fa.sig", "63.fa.sig")]
+    c = compare_serial_containment(sigs)
+    assert c[0, 1] == sigs[1].contained_by(sigs[0]) and c[1, 0] == sigs[0].contained_by(sigs[1])
+    m = compare_serial_max_containment(sigs)
+    assert m[0, 1] == m[1, 0] == sigs[0].max_containment(sigs[1])
+    a = compare_serial_avg_containment(sigs)
+    assert a[0, 1] == sigs[0].avg_containment(sigs[1])
