@@ -224,7 +224,7 @@ void smgpu_minhash_add_buffer(SourmashKmerMinHash *ptr, const char *buf, uintptr
 
 /* Scratch size needed by smgpu_sketch_dna_raw for an output capacity. */
 uint64_t smgpu_sketch_workspace_bytes(uint64_t out_capacity);
-/* Device-resident sketching: d_seq[0,len) ASCII (16-byte aligned) -> sorted unique
+/* Device-resident sketching: d_seq[0,len) ASCII (any alignment) -> sorted unique
  * kept hashes (1 <= h <= max_hash; max_hash 0 = keep all) in d_out[0, n).
  * d_result (device, 2 x u64): [0] kept k-mer occurrences, [1] unique hashes n.
  * Synchronises the stream once (the sort needs the kept count).  Returns n, or

@@ -35,11 +35,14 @@ _SCALARS = {
 _OPAQUE = {"SourmashKmerMinHash", "SourmashSignature", "SourmashComputeParameters"}
 
 
-def _ctype(decl):
-    """C type text (without the parameter name) -> ctypes type."""
+def _ctype(decl, is_arg=False):
+    """C type text (without the parameter name) -> ctypes type.  Data-pointer ARGUMENTS become
+    c_void_p so that numpy buffers, ctypes arrays, byref() and raw device addresses all pass."""
     t = decl.replace("const", " ").strip()
     stars = t.count("*")
     base = t.replace("*", " ").split()[0]
+    if is_arg and stars and not (base == "char" and stars == 1):
+        return C.c_void_p
     if base in _OPAQUE:
         return C.c_void_p if stars == 1 else C.POINTER(C.c_void_p)
     if stars == 0:
@@ -110,7 +113,7 @@ class _Lib:
             for name, (ret, args) in self.functions.items():
                 fn = getattr(self._cdll, name)       # AttributeError here == missing export
                 fn.restype = _ctype(ret)
-                fn.argtypes = [_ctype(a) for a in args]
+                fn.argtypes = [_ctype(a, is_arg=True) for a in args]
             self._cdll.sourmash_init()
         return self._cdll
 

@@ -542,7 +542,6 @@ uint64_t smgpu_sketch_dna_raw(const uint8_t* d_seq, uint64_t len, uint32_t ksize
     landing_void([&] {
         hipStream_t st = (hipStream_t)stream;
         if (ws_bytes < smgpu_sketch_workspace_bytes(cap)) throw err_internal("workspace too small (smgpu_sketch_workspace_bytes)");
-        if (((uintptr_t)d_seq & 15) != 0) throw err_internal("d_seq must be 16-byte aligned");
         uint64_t* d_raw = (uint64_t*)d_ws;                                   // unordered kept hashes
         void* d_tmp = (char*)d_ws + ((cap * 8 + 255) / 256) * 256;
         const size_t tmp_bytes = (size_t)(ws_bytes - ((cap * 8 + 255) / 256) * 256);
@@ -568,7 +567,6 @@ uint64_t smgpu_sketch_dna_raw(const uint8_t* d_seq, uint64_t len, uint32_t ksize
 void smgpu_sketch_dna_kernel_raw(const uint8_t* d_seq, uint64_t len, uint32_t ksize, uint64_t seed, uint64_t max_hash,
                                  uint64_t* d_out, uint64_t cap, uint64_t* d_count, void* stream) {
     landing_void([&] {
-        if (((uintptr_t)d_seq & 15) != 0) throw err_internal("d_seq must be 16-byte aligned");
         hip_check(sketch_dna_launch(d_seq, len, ksize, seed, max_hash ? max_hash : ~0ull, d_out,
                                     (unsigned long long*)d_count, cap, (hipStream_t)stream), "sketch_dna");
     });

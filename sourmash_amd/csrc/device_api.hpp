@@ -10,8 +10,8 @@ namespace smg {
 // ---- sketch.hip ---------------------------------------------------------------
 // Append every hash h of a canonical DNA k-mer of d_seq[0,len) with 1 <= h <= thr
 // to d_out (unordered, duplicates kept); *d_count += number appended (keeps
-// counting past `cap`, entries past cap are dropped).  d_seq must be 16-byte
-// aligned.  Any byte outside ACGTacgt kills the k-mers covering it.
+// counting past `cap`, entries past cap are dropped).  d_seq may have any alignment
+// (an unaligned start costs nothing: the kernel realigns and blanks the prefix).  Any byte outside ACGTacgt kills the k-mers covering it.
 hipError_t sketch_dna_launch(const uint8_t* d_seq, uint64_t len, uint32_t k, uint64_t seed, uint64_t thr,
                              uint64_t* d_out, unsigned long long* d_count, uint64_t cap, hipStream_t stream);
 // d_out[i] = hash of the canonical k-mer starting at i for i in [0, n_kmers) (0 for k-mers

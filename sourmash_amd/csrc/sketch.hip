@@ -32,7 +32,9 @@ template <int K, int P, bool DENSE>
 __global__ __launch_bounds__(SK_BLOCK) void sketch_dna_kernel(
     const uint8_t* __restrict__ seq, uint64_t len, uint64_t seed, uint64_t thr,
     uint64_t* __restrict__ out, unsigned long long* __restrict__ out_count, uint64_t out_cap,
-    uint64_t n_tiles) {
+    uint64_t n_tiles, uint32_t skip) {
+    // seq is 16-byte aligned; its first `skip` (< 16) bytes precede the caller's buffer and are
+    // treated as invalid.  len includes them.  DENSE positions are reported relative to seq + skip.
     using G = LaneGeom<K, P>;
     constexpr int TILE = SK_BLOCK * P;                       // start positions per tile
     constexpr int LANE_RD = ((G::NW + 3) / 4) * 4;           // dwords each lane reads (whole b128s)
@@ -62,6 +64,11 @@ __global__ __launch_bounds__(SK_BLOCK) void sketch_dna_kernel(
                 for (uint64_t b = off; b < len; ++b) w[(b - off) >> 2] |= (uint32_t)seq[b] << (8 * ((b - off) & 3));
                 v = make_uint4(w[0], w[1], w[2], w[3]);
             }
+            if (off == 0 && skip) {                      // blank the alignment prefix
+                uint32_t w[4] = {v.x, v.y, v.z, v.w};
+                for (uint32_t b = 0; b < skip; ++b) w[b >> 2] &= ~(0xffu << (8 * (b & 3)));
+                v = make_uint4(w[0], w[1], w[2], w[3]);
+            }
             *reinterpret_cast<uint4*>(&s_in[c * 4]) = v;
         }
         __syncthreads();
@@ -81,7 +88,7 @@ __global__ __launch_bounds__(SK_BLOCK) void sketch_dna_kernel(
         }
         process_lane<K, P>(raw, seed, thr, [&](int o, uint64_t h) {
             if constexpr (DENSE) {
-                const uint64_t pos = base + (uint64_t)tid * P + (uint64_t)o;
+                const uint64_t pos = base + (uint64_t)tid * P + (uint64_t)o - skip;   // valid k-mers never start in the prefix
                 if (pos < out_cap) out[pos] = h;
                 return;
             }
@@ -186,16 +193,19 @@ template <int K, int P>
 static hipError_t launch_k(const uint8_t* d_seq, uint64_t len, uint64_t seed, uint64_t thr, uint64_t* d_out,
                            unsigned long long* d_count, uint64_t cap, bool dense, hipStream_t stream) {
     constexpr uint64_t TILE = (uint64_t)SK_BLOCK * P;
+    const uint32_t skip = (uint32_t)((uintptr_t)d_seq & 15);     // realign: 16-byte loads need an aligned base
+    d_seq -= skip;
+    len += skip;
     const uint64_t n_tiles = (len + TILE - 1) / TILE;
     if (n_tiles == 0) return hipSuccess;
     const uint64_t max_blocks = 256ull * 8;   // 256 CUs x 8 resident workgroups
     const unsigned grid = (unsigned)(n_tiles < max_blocks ? n_tiles : max_blocks);
     if (dense)
         hipLaunchKernelGGL((sketch_dna_kernel<K, P, true>), dim3(grid), dim3(SK_BLOCK), 0, stream, d_seq, len, seed,
-                           thr, d_out, d_count, cap, n_tiles);
+                           thr, d_out, d_count, cap, n_tiles, skip);
     else
         hipLaunchKernelGGL((sketch_dna_kernel<K, P, false>), dim3(grid), dim3(SK_BLOCK), 0, stream, d_seq, len, seed,
-                           thr, d_out, d_count, cap, n_tiles);
+                           thr, d_out, d_count, cap, n_tiles, skip);
     return hipGetLastError();
 }
 
