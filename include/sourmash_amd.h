@@ -250,6 +250,23 @@ void smgpu_compare_raw(const uint64_t *d_hashes, const uint64_t *d_offsets, uint
 void smgpu_compare_all_pairs(const SourmashKmerMinHash *const *mhs, uintptr_t n, uint32_t *common_out,
                              double *jaccard_out);
 
+/* Device-resident sketch collection + gather counters: the batched form of CounterGather
+ * (src/sourmash/index/__init__.py:735-909).  A SketchSet is a CSR of n sorted sketches in HBM;
+ * a Counter holds c[d] = |Q ∩ D_d| for every member d (CounterGather.add, :783-789), finds the
+ * best match with the reference tie-break (highest count, then first inserted = lowest index;
+ * :856-857) and applies consume (c[d] -= |I ∩ D_d| for every live d; :897-909) in one kernel. */
+typedef struct SmgpuSketchSet SmgpuSketchSet;
+typedef struct SmgpuCounter SmgpuCounter;
+SmgpuSketchSet *smgpu_sketchset_new(const SourmashKmerMinHash *const *mhs, uintptr_t n);
+void smgpu_sketchset_free(SmgpuSketchSet *ptr);
+uintptr_t smgpu_sketchset_len(const SmgpuSketchSet *ptr);
+SmgpuCounter *smgpu_counter_new(const SmgpuSketchSet *set, const SourmashKmerMinHash *query);
+void smgpu_counter_free(SmgpuCounter *ptr);
+void smgpu_counter_get(const SmgpuCounter *ptr, uint64_t *counts_out);
+void smgpu_counter_set(SmgpuCounter *ptr, uint64_t index, uint64_t value);
+bool smgpu_counter_best(const SmgpuCounter *ptr, uint64_t *index, uint64_t *count);
+void smgpu_counter_consume(SmgpuCounter *ptr, const SourmashKmerMinHash *intersect);
+
 /* Gather primitives (src/sourmash/index/__init__.py:735-909):
  *   overlap:  d_overlap[d] = |Q ∩ D_d| (op 0, CounterGather.add) or
  *             d_overlap[d] -= |Q ∩ D_d| saturating (op 1, CounterGather.consume)

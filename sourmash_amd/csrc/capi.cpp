@@ -9,6 +9,7 @@
 #include <string.h>
 #include <cmath>
 #include <fstream>
+#include <memory>
 #include <sstream>
 #include "../../include/sourmash_amd.h"
 #include "device_ctx.hpp"
@@ -287,10 +288,15 @@ void kmerminhash_add_protein(SourmashKmerMinHash*, const char*) {
 }
 void kmerminhash_remove_hash(SourmashKmerMinHash* p, uint64_t h) { MH(p)->remove_hash(h); }
 void kmerminhash_remove_many(SourmashKmerMinHash* p, const uint64_t* hs, uintptr_t n) {
-    for (uintptr_t i = 0; i < n; ++i) MH(p)->remove_hash(hs[i]);
+    landing_void([&] {
+        if (n < 16) { for (uintptr_t i = 0; i < n; ++i) MH(p)->remove_hash(hs[i]); return; }
+        std::vector<uint64_t> sorted(hs, hs + n);
+        std::sort(sorted.begin(), sorted.end());
+        MH(p)->remove_sorted(sorted.data(), sorted.size());
+    });
 }
 void kmerminhash_remove_from(SourmashKmerMinHash* p, const SourmashKmerMinHash* o) {
-    landing_void([&] { for (uint64_t h : MH(o)->mins) MH(p)->remove_hash(h); });
+    landing_void([&] { MH(p)->remove_sorted(MH(o)->mins.data(), MH(o)->mins.size()); });
 }
 void kmerminhash_clear(SourmashKmerMinHash* p) { MH(p)->clear(); }
 
@@ -616,6 +622,120 @@ void smgpu_compare_all_pairs(const SourmashKmerMinHash* const* mhs, uintptr_t n,
             hip_check(hipMemcpyAsync(jaccard_out, dj.p, (size_t)n * n * 8, hipMemcpyDeviceToHost, st), "D2H");
         }
         if (common_out) hip_check(hipMemcpyAsync(common_out, dc.p, (size_t)n * n * 4, hipMemcpyDeviceToHost, st), "D2H");
+        hip_check(hipStreamSynchronize(st), "sync");
+    });
+}
+
+// ---- device-resident sketch collections and gather counters ------------------------------------
+struct SketchSet {
+    DevBuf hashes, offsets;
+    uint64_t n = 0, total = 0;
+    ~SketchSet() { if (hashes.p) (void)hipFree(hashes.p); if (offsets.p) (void)hipFree(offsets.p); }
+};
+struct GatherCounter {
+    const SketchSet* set = nullptr;
+    DevBuf counters, q, scal;
+    ~GatherCounter() {
+        if (counters.p) (void)hipFree(counters.p);
+        if (q.p) (void)hipFree(q.p);
+        if (scal.p) (void)hipFree(scal.p);
+    }
+    void upload(const KmerMinHash& mh, hipStream_t st) {
+        q.reserve(mh.size() * 8 + 16);
+        if (mh.size()) hip_check(hipMemcpyAsync(q.p, mh.mins.data(), mh.size() * 8, hipMemcpyHostToDevice, st), "H2D");
+    }
+};
+
+SmgpuSketchSet* smgpu_sketchset_new(const SourmashKmerMinHash* const* mhs, uintptr_t n) {
+    return landing<SmgpuSketchSet*>([&]() -> SmgpuSketchSet* {
+        DeviceCtx& ctx = DeviceCtx::get();
+        std::lock_guard<std::mutex> g(ctx.mutex());
+        std::unique_ptr<SketchSet> s(new SketchSet());
+        std::vector<uint64_t> off(n + 1, 0);
+        for (uintptr_t i = 0; i < n; ++i) off[i + 1] = off[i] + MH(mhs[i])->size();
+        s->n = n; s->total = off[n];
+        s->hashes.reserve(s->total * 8 + 16);
+        s->offsets.reserve((n + 1) * 8);
+        hipStream_t st = ctx.stream();
+        // stage through one host vector: one large H2D copy instead of n small ones
+        std::vector<uint64_t> flat(s->total);
+        for (uintptr_t i = 0; i < n; ++i)
+            if (MH(mhs[i])->size()) memcpy(flat.data() + off[i], MH(mhs[i])->mins.data(), MH(mhs[i])->size() * 8);
+        if (s->total) hip_check(hipMemcpyAsync(s->hashes.p, flat.data(), s->total * 8, hipMemcpyHostToDevice, st), "H2D");
+        hip_check(hipMemcpyAsync(s->offsets.p, off.data(), (n + 1) * 8, hipMemcpyHostToDevice, st), "H2D");
+        hip_check(hipStreamSynchronize(st), "sync");
+        return reinterpret_cast<SmgpuSketchSet*>(s.release());
+    });
+}
+void smgpu_sketchset_free(SmgpuSketchSet* p) { delete reinterpret_cast<SketchSet*>(p); }
+uintptr_t smgpu_sketchset_len(const SmgpuSketchSet* p) { return reinterpret_cast<const SketchSet*>(p)->n; }
+
+SmgpuCounter* smgpu_counter_new(const SmgpuSketchSet* set, const SourmashKmerMinHash* query) {
+    return landing<SmgpuCounter*>([&]() -> SmgpuCounter* {
+        const SketchSet* s = reinterpret_cast<const SketchSet*>(set);
+        DeviceCtx& ctx = DeviceCtx::get();
+        std::lock_guard<std::mutex> g(ctx.mutex());
+        hipStream_t st = ctx.stream();
+        std::unique_ptr<GatherCounter> c(new GatherCounter());
+        c->set = s;
+        c->counters.reserve(s->n * 8 + 16);
+        c->scal.reserve(64);
+        c->upload(*MH(query), st);
+        hip_check(hipMemsetAsync(c->counters.p, 0, s->n * 8 + 16, st), "memset");
+        hip_check(overlap_vector_launch(c->q.as<uint64_t>(), MH(query)->size(), s->hashes.as<uint64_t>(),
+                                        s->offsets.as<uint64_t>(), s->n, c->counters.as<unsigned long long>(), 0, st), "overlap");
+        hip_check(hipStreamSynchronize(st), "sync");
+        return reinterpret_cast<SmgpuCounter*>(c.release());
+    });
+}
+void smgpu_counter_free(SmgpuCounter* p) { delete reinterpret_cast<GatherCounter*>(p); }
+void smgpu_counter_get(const SmgpuCounter* p, uint64_t* out) {
+    landing_void([&] {
+        const GatherCounter* c = reinterpret_cast<const GatherCounter*>(p);
+        DeviceCtx& ctx = DeviceCtx::get();
+        std::lock_guard<std::mutex> g(ctx.mutex());
+        if (c->set->n) hip_check(hipMemcpyAsync(out, c->counters.p, c->set->n * 8, hipMemcpyDeviceToHost, ctx.stream()), "D2H");
+        hip_check(hipStreamSynchronize(ctx.stream()), "sync");
+    });
+}
+void smgpu_counter_set(SmgpuCounter* p, uint64_t index, uint64_t value) {
+    landing_void([&] {
+        GatherCounter* c = reinterpret_cast<GatherCounter*>(p);
+        if (index >= c->set->n) throw err_internal("counter index out of range");
+        DeviceCtx& ctx = DeviceCtx::get();
+        std::lock_guard<std::mutex> g(ctx.mutex());
+        hip_check(hipMemcpyAsync(c->counters.as<uint64_t>() + index, &value, 8, hipMemcpyHostToDevice, ctx.stream()), "H2D");
+        hip_check(hipStreamSynchronize(ctx.stream()), "sync");
+    });
+}
+bool smgpu_counter_best(const SmgpuCounter* p, uint64_t* index, uint64_t* count) {
+    return landing<bool>([&]() -> bool {
+        const GatherCounter* c = reinterpret_cast<const GatherCounter*>(p);
+        DeviceCtx& ctx = DeviceCtx::get();
+        std::lock_guard<std::mutex> g(ctx.mutex());
+        hipStream_t st = ctx.stream();
+        unsigned long long* d_best = const_cast<GatherCounter*>(c)->scal.as<unsigned long long>();
+        hip_check(hipMemsetAsync(d_best, 0, 8, st), "memset");
+        hip_check(argmax_launch(c->counters.as<unsigned long long>(), c->set->n, 0, d_best, st), "argmax");
+        unsigned long long key = 0;
+        hip_check(hipMemcpyAsync(&key, d_best, 8, hipMemcpyDeviceToHost, st), "D2H");
+        hip_check(hipStreamSynchronize(st), "sync");
+        if (key == 0) return false;
+        *count = key >> 32;
+        *index = (uint64_t)(0xffffffffull & ~key);
+        return true;
+    });
+}
+void smgpu_counter_consume(SmgpuCounter* p, const SourmashKmerMinHash* intersect) {
+    landing_void([&] {
+        GatherCounter* c = reinterpret_cast<GatherCounter*>(p);
+        if (MH(intersect)->size() == 0) return;
+        DeviceCtx& ctx = DeviceCtx::get();
+        std::lock_guard<std::mutex> g(ctx.mutex());
+        hipStream_t st = ctx.stream();
+        c->upload(*MH(intersect), st);
+        hip_check(overlap_vector_launch(c->q.as<uint64_t>(), MH(intersect)->size(), c->set->hashes.as<uint64_t>(),
+                                        c->set->offsets.as<uint64_t>(), c->set->n, c->counters.as<unsigned long long>(), 1, st), "consume");
         hip_check(hipStreamSynchronize(st), "sync");
     });
 }

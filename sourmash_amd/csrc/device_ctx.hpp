@@ -35,7 +35,7 @@ struct DevBuf {
         hip_check(hipMalloc(&p, want), "hipMalloc");
         cap = want;
     }
-    template <class T> T* as() { return static_cast<T*>(p); }
+    template <class T> T* as() const { return static_cast<T*>(p); }
 };
 
 struct PairStats {

@@ -67,6 +67,21 @@ struct KmerMinHash {
         }
     }
 
+    // minhash.rs:418-430 remove_many / remove_from: same result as remove_hash per element, done as
+    // one sorted set difference (the reference's Vec::remove per hash is quadratic on big queries).
+    void remove_sorted(const uint64_t* hs, size_t n) {
+        size_t i = 0, j = 0, w = 0;
+        while (i < mins.size()) {
+            while (j < n && hs[j] < mins[i]) ++j;
+            if (j < n && hs[j] == mins[i]) { ++i; continue; }
+            mins[w] = mins[i];
+            if (track_abundance) abunds[w] = abunds[i];
+            ++w; ++i;
+        }
+        mins.resize(w);
+        if (track_abundance) abunds.resize(w);
+    }
+
     // minhash.rs:313-383
     void add_hash_with_abundance(uint64_t h, uint64_t abundance) {
         const uint64_t current_max = mins.empty() ? UINT64_MAX : mins.back();

@@ -1,0 +1,374 @@
+"""Index / CounterGather -- search, prefetch and gather over collections of signatures.
+
+API of src/sourmash/index/__init__.py: IndexSearchResult (:55), Index.find (:115-170),
+search (:202-239), prefetch (:241-256), best_containment (:258-270), counter_gather
+(:302-320), LinearIndex (:397-453) and CounterGather (:735-909).
+
+What changes underneath: the collection lives in HBM as one CSR (`SketchSet`), so
+  * find() scores the query against EVERY signature with one overlap kernel
+    (the reference loops over signatures, two FFI clones + one merge each);
+  * CounterGather keeps its counters on the GPU: add-time overlaps, the arg-max with
+    the reference tie-break, and consume() are single kernel launches.
+Results (which signatures, which order, which numbers) are those of the reference.
+"""
+import ctypes as C
+from collections import namedtuple
+
+import numpy as np
+
+from ._lowlevel import lib
+from .minhash import flatten_and_downsample_num, flatten_and_downsample_scaled, flatten_and_intersect_scaled
+from .search import calc_threshold_from_bp, make_containment_query, make_jaccard_search_query
+from .signature import SourmashSignature
+from .utils import RustObject, rustcall
+
+__all__ = ["IndexSearchResult", "SketchSet", "LinearIndex", "CounterGather"]
+
+IndexSearchResult = namedtuple("Result", "score, signature, location")
+
+
+class SketchSet(RustObject):
+    "n flat sketches packed as one device-resident CSR (smgpu_sketchset_*)."
+    __dealloc_func__ = lib.smgpu_sketchset_free
+
+    def __init__(self, minhashes):
+        self._keep = list(minhashes)
+        ptrs = (C.c_void_p * max(len(self._keep), 1))(*[mh._get_objptr() for mh in self._keep])
+        self._objptr = rustcall(lib.smgpu_sketchset_new, ptrs, len(self._keep))
+
+    def __len__(self):
+        return self._methodcall(lib.smgpu_sketchset_len)
+
+
+class _DeviceCounter(RustObject):
+    "c[d] = |query ∩ D_d| on the GPU (smgpu_counter_*)."
+    __dealloc_func__ = lib.smgpu_counter_free
+
+    def __init__(self, sketchset, query_mh):
+        self._set = sketchset
+        self._objptr = rustcall(lib.smgpu_counter_new, sketchset._get_objptr(), query_mh._get_objptr())
+
+    def values(self):
+        out = np.zeros(max(len(self._set), 1), dtype=np.uint64)
+        self._methodcall(lib.smgpu_counter_get, out.ctypes.data_as(C.c_void_p))
+        return out[:len(self._set)]
+
+    def best(self):
+        "-> (index, count) of the largest counter (ties: lowest index) or None"
+        idx, cnt = C.c_uint64(0), C.c_uint64(0)
+        ok = self._methodcall(lib.smgpu_counter_best, C.byref(idx), C.byref(cnt))
+        return (idx.value, cnt.value) if ok else None
+
+    def consume(self, intersect_mh):
+        self._methodcall(lib.smgpu_counter_consume, intersect_mh._get_objptr())
+
+    def set(self, index, value):
+        self._methodcall(lib.smgpu_counter_set, index, value)
+
+
+class LinearIndex:
+    "An in-memory list of signatures searched exhaustively -- on the GPU, all at once."
+    is_database = False
+
+    def __init__(self, _signatures=None, filename=None):
+        self._signatures = list(_signatures) if _signatures else []
+        self.filename = filename
+        self._packed = None          # (key, SketchSet, prepared minhashes)
+
+    @property
+    def location(self):
+        return self.filename
+
+    def signatures(self):
+        yield from self._signatures
+
+    def signatures_with_location(self):
+        for ss in self._signatures:
+            yield ss, self.location
+
+    def __bool__(self):
+        return bool(self._signatures)
+
+    def __len__(self):
+        return len(self._signatures)
+
+    def insert(self, node):
+        self._signatures.append(node)
+        self._packed = None
+
+    def select(self, ksize=None, moltype=None, scaled=None, num=None, abund=None, containment=None, **kw):
+        "Filter by sketch parameters (index/__init__.py:333-394 semantics for the common keys)."
+        def ok(ss):
+            mh = ss.minhash
+            if ksize is not None and mh.ksize != ksize:
+                return False
+            if moltype is not None and mh.moltype != moltype:
+                return False
+            if containment and not mh.scaled:
+                raise ValueError("Containment requires scaled signatures.")
+            if scaled is not None and scaled and (not mh.scaled or mh.scaled > scaled):
+                return False
+            if num is not None and num and mh.num != num:
+                return False
+            if abund and not mh.track_abundance:
+                return False
+            return True
+        return LinearIndex([ss for ss in self._signatures if ok(ss)], self.filename)
+
+    # ---- batched scoring --------------------------------------------------------------------------
+    def _scaled_counts(self, query_mh):
+        """shared sizes of a scaled query against every scaled signature, one kernel.
+        Subject sketches are flattened and downsampled to the query's scaled when finer (find :125-131)."""
+        qs = query_mh.scaled
+        key = ("scaled", qs)
+        if self._packed is None or self._packed[0] != key:
+            subj = [flatten_and_downsample_scaled(ss.minhash, qs) for ss in self._signatures]
+            self._packed = (key, SketchSet(subj), subj)
+        _, sset, subj = self._packed
+        counter = _DeviceCounter(sset, query_mh)
+        return counter.values(), subj
+
+    def find(self, search_fn, query, **kwargs):
+        search_fn.check_is_compatible(query)
+        query_mh = query.minhash
+        assert not query_mh.track_abundance
+        if query_mh.scaled and all(ss.minhash.scaled for ss in self._signatures):
+            shared, subj = self._scaled_counts(query_mh)
+            for i, (ss, subj_mh) in enumerate(zip(self._signatures, subj)):
+                # the query is downsampled to the subject's scaled when the subject is coarser (:129-131)
+                q_mh = query_mh if subj_mh.scaled <= query_mh.scaled else flatten_and_downsample_scaled(query_mh, subj_mh.scaled)
+                q_size, s_size = len(q_mh), len(subj_mh)
+                # plain |Q ∩ D| is unchanged by downsampling either side to the coarser scaled
+                n_shared = int(shared[i])
+                total = q_size + s_size - n_shared
+                score = search_fn.score_fn(q_size, n_shared, s_size, total)
+                if search_fn.passes(score) and search_fn.collect(score, ss):
+                    yield IndexSearchResult(score, ss, self.location)
+            return
+        # num sketches (or mixed): per-pair GPU intersections, like the reference loop
+        for ss in self._signatures:
+            if query_mh.scaled:
+                subj_mh = flatten_and_downsample_scaled(ss.minhash, query_mh.scaled)
+                q_mh = flatten_and_downsample_scaled(query_mh, subj_mh.scaled)
+            else:
+                subj_mh = flatten_and_downsample_num(ss.minhash, query_mh.num)
+                q_mh = flatten_and_downsample_num(query_mh, subj_mh.num)
+            n_shared, total = q_mh.intersection_and_union_size(subj_mh)
+            score = search_fn.score_fn(len(q_mh), n_shared, len(subj_mh), total)
+            if search_fn.passes(score) and search_fn.collect(score, ss):
+                yield IndexSearchResult(score, ss, self.location)
+
+    def search(self, query, *, threshold=None, do_containment=False, do_max_containment=False, best_only=False, **kw):
+        if threshold is None:
+            raise TypeError("'search' requires 'threshold'")
+        search_obj = make_jaccard_search_query(do_containment=do_containment, do_max_containment=do_max_containment,
+                                               best_only=best_only, threshold=float(threshold))
+        matches = list(self.find(search_obj, query, **kw))
+        matches.sort(key=lambda x: -x.score)
+        return matches
+
+    def search_abund(self, query, *, threshold=None, **kw):
+        if not query.minhash.track_abundance:
+            raise TypeError("'search_abund' requires query signature with abundance information")
+        if threshold is None:
+            raise TypeError("'search_abund' requires 'threshold'")
+        out = []
+        for ss, loc in self.signatures_with_location():
+            if not ss.minhash.track_abundance:
+                raise TypeError("'search_abund' requires subject signatures with abundance information")
+            score = query.similarity(ss, downsample=True)
+            if score >= float(threshold):
+                out.append(IndexSearchResult(score, ss, loc))
+        out.sort(key=lambda x: -x.score)
+        return out
+
+    def prefetch(self, query, threshold_bp, **kwargs):
+        if not self:
+            raise ValueError("no signatures to search")
+        search_fn = make_containment_query(query.minhash, threshold_bp, best_only=kwargs.get("best_only", False))
+        yield from self.find(search_fn, query, **kwargs)
+
+    def best_containment(self, query, threshold_bp=None, **kwargs):
+        results = sorted(self.prefetch(query, threshold_bp, best_only=True, **kwargs),
+                         key=lambda x: (-x.score, x.signature.md5sum()))
+        return results[0] if results else None
+
+    def peek(self, query_mh, *, threshold_bp=0):
+        try:
+            result = self.best_containment(SourmashSignature(query_mh), threshold_bp=threshold_bp)
+        except ValueError:
+            result = None
+        if not result:
+            return []
+        return [result, flatten_and_intersect_scaled(result.signature.minhash, query_mh)]
+
+    def consume(self, intersect_mh):
+        pass
+
+    def counter_gather(self, query, threshold_bp, **kwargs):
+        "Prefetch, then hand every match to a CounterGather in ONE batched add (index/__init__.py:302-320)."
+        prefetch_query = query.to_mutable()
+        prefetch_query.minhash = prefetch_query.minhash.flatten()
+        counter = CounterGather(prefetch_query)
+        matches = list(self.prefetch(prefetch_query, threshold_bp, **kwargs))
+        counter.add_many([m.signature for m in matches], locations=[m.location for m in matches])
+        return counter
+
+    def gather(self, query, threshold_bp=None, **kwargs):
+        "Best containment match only (index/__init__.py:272-300)."
+        if not query.minhash.scaled:
+            raise ValueError("gather requires scaled signatures")
+        res = self.best_containment(query, threshold_bp=threshold_bp, **kwargs)
+        return [res] if res else []
+
+
+class CounterGather:
+    """Track overlaps between a query and candidate matches for min-set-cover gather.
+
+    Same protocol as the reference class (add / peek / consume, keyed by md5 with
+    first-inserted winning ties); the counters live on the GPU.  `add_many` is the
+    batch extension: all overlaps in one kernel.
+    """
+
+    def __init__(self, query):
+        query_mh = query.minhash
+        if not query_mh.scaled:
+            raise ValueError("gather requires scaled signatures")
+        self.orig_query_mh = query_mh.copy().flatten()
+        self.scaled = query_mh.scaled
+        self.siglist = {}            # md5 -> signature, insertion ordered
+        self.locations = {}
+        self.query_started = 0
+        self._pending = []           # signatures added since the device state was last built
+        self._host_counts = {}       # md5 -> overlap, until the device counter exists
+        self._dev = None             # (_DeviceCounter, [md5 in CSR order])
+
+    # ---- loading ---------------------------------------------------------------------------------
+    def add(self, ss, *, location=None, require_overlap=True):
+        "Add one potential match (overlap counted against the original query on the GPU)."
+        if self.query_started:
+            raise ValueError("cannot add more signatures to counter after peek/consume")
+        overlap = self.orig_query_mh.count_common(ss.minhash, True)
+        if overlap:
+            self._register(ss, overlap, location)
+        elif require_overlap:
+            raise ValueError("no overlap between query and signature!?")
+
+    def add_many(self, siglist, *, locations=None, require_overlap=False):
+        "Batch extension: overlaps of every candidate in one kernel launch."
+        if self.query_started:
+            raise ValueError("cannot add more signatures to counter after peek/consume")
+        siglist = list(siglist)
+        if not siglist:
+            return
+        mhs = [ss.minhash.flatten() for ss in siglist]
+        for mh in mhs:                                   # compatibility as count_common(downsample=True) would check
+            if mh.ksize != self.orig_query_mh.ksize or mh.moltype != self.orig_query_mh.moltype \
+                    or mh.seed != self.orig_query_mh.seed:
+                self.orig_query_mh.count_common(mh, True)   # raises the reference's error
+        overlaps = _DeviceCounter(SketchSet(mhs), self.orig_query_mh).values()
+        for i, ss in enumerate(siglist):
+            if overlaps[i]:
+                self._register(ss, int(overlaps[i]), locations[i] if locations else None)
+            elif require_overlap:
+                raise ValueError("no overlap between query and signature!?")
+
+    def _register(self, ss, overlap, location):
+        md5 = ss.md5sum()
+        if md5 not in self.siglist:
+            self._pending.append(md5)
+        self._host_counts[md5] = overlap
+        self.siglist[md5] = ss
+        self.locations[md5] = location
+        self.downsample(ss.minhash.scaled)
+
+    def downsample(self, scaled):
+        if scaled > self.scaled:
+            self.scaled = scaled
+        return self.scaled
+
+    def signatures(self):
+        yield from self.siglist.values()
+
+    @property
+    def union_found(self):
+        found_mh = self.orig_query_mh.copy_and_clear()
+        for ss in self.siglist.values():
+            found_mh.add_many(flatten_and_intersect_scaled(ss.minhash, self.orig_query_mh))
+        return found_mh
+
+    # ---- device state ---------------------------------------------------------------------------------
+    def _device(self):
+        if self._dev is None:
+            order = list(self.siglist)
+            mhs = [self.siglist[m].minhash.flatten() for m in order]
+            dev = _DeviceCounter(SketchSet(mhs), self.orig_query_mh)
+            # |Q ∩ D| computed in one launch equals the add-time overlaps (plain set intersections)
+            self._dev = (dev, order)
+        return self._dev
+
+    @property
+    def counter(self):
+        "md5 -> remaining overlap (a dict view of the device counters; zero entries dropped)."
+        if not self.siglist:
+            return {}
+        dev, order = self._device()
+        vals = dev.values()
+        return {m: int(v) for m, v in zip(order, vals) if v}
+
+    # ---- gather protocol ---------------------------------------------------------------------------------
+    def peek(self, cur_query_mh, *, threshold_bp=0):
+        "Best remaining match for the current query, without changing the counters."
+        self.query_started = 1
+        if not self.siglist:
+            return []
+        dev, order = self._device()
+        scaled = self.downsample(cur_query_mh.scaled)
+        cur_query_mh = cur_query_mh.downsample(scaled=scaled)
+        if not cur_query_mh:
+            return []
+        if cur_query_mh.contained_by(self.orig_query_mh, downsample=True) < 1:
+            raise ValueError("current query not a subset of original query")
+        try:
+            threshold, n_threshold_hashes = calc_threshold_from_bp(threshold_bp, scaled, len(cur_query_mh))
+        except ValueError:
+            return []
+        best = dev.best()                               # highest count, ties to the first inserted
+        if best is None:
+            return []
+        idx, match_size = best
+        if match_size < n_threshold_hashes:
+            return []
+        md5 = order[idx]
+        match = self.siglist[md5]
+        cont = cur_query_mh.contained_by(match.minhash, downsample=True)
+        assert cont and cont >= threshold
+        match_mh = match.minhash.downsample(scaled=scaled).flatten()
+        intersect_mh = cur_query_mh & match_mh
+        return (IndexSearchResult(cont, match, self.locations[md5]), intersect_mh)
+
+    def consume(self, intersect_mh):
+        "Subtract |intersect ∩ D_d| from every live counter (one kernel)."
+        self.query_started = 1
+        if not intersect_mh or not self.siglist:
+            return
+        dev, _ = self._device()
+        dev.consume(intersect_mh)
+
+    # ---- batch extension: the whole min-set-cover loop ---------------------------------------------------
+    def gather_all(self, threshold_bp=0):
+        """Run gather to exhaustion; -> list of (md5, |intersect|) in rank order.  Same decisions as
+        GatherDatabases over this single counter, without building result objects."""
+        out = []
+        query_mh = self.orig_query_mh.to_mutable()
+        while query_mh:
+            res = self.peek(query_mh, threshold_bp=threshold_bp)
+            if not res:
+                break
+            sr, intersect_mh = res
+            self.consume(intersect_mh)
+            out.append((sr.signature.md5sum(), len(intersect_mh)))
+            scaled = max(query_mh.scaled, sr.signature.minhash.scaled)
+            query_mh = query_mh.downsample(scaled=scaled).to_mutable() if scaled != query_mh.scaled else query_mh
+            query_mh.remove_many(sr.signature.minhash.downsample(scaled=scaled).flatten())
+        return out

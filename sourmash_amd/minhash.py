@@ -644,8 +644,8 @@ class FrozenMinHash(MinHash):
         return MinHash.flatten(self).to_frozen()
 
     def to_mutable(self):
-        mut = MinHash.__new__(MinHash)
-        mut.__setstate__(self.__getstate__())
+        mut = self._like()                 # same parameters, empty; then one C-level sorted merge
+        MinHash.merge(mut, self)
         return mut
 
     def to_frozen(self):

@@ -1,0 +1,160 @@
+"""GPU parity: search / prefetch / gather (CounterGather on device counters) against the
+oracle and the reference's golden gather results.  Run with -m gpu."""
+import glob
+
+import numpy as np
+import pytest
+
+import oracle
+from conftest import golden
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN_GATHER = [("NC_003198.1", 487), ("NC_000853.1", 192), ("NC_011978.1", 169), ("NC_002163.1", 157),
+                 ("NC_003197.2", 152), ("NC_009486.1", 92), ("NC_006905.1", 76), ("NC_011080.1", 59),
+                 ("NC_011274.1", 42), ("NC_006511.1", 31), ("NC_011294.1", 7), ("NC_004631.1", 2)]
+
+
+@pytest.fixture(scope="module")
+def sm():
+    import torch  # noqa: F401
+    import sourmash_amd
+    assert sourmash_amd.gpu_available()
+    return sourmash_amd
+
+
+def _sig(sm, hashes, name, scaled=1, ksize=21):
+    mh = sm.MinHash(0, ksize, scaled=scaled)
+    mh.add_many(hashes)
+    return sm.SourmashSignature(mh, name=name)
+
+
+def _gather_db(sm):
+    files = sorted(glob.glob(golden("gather", "GCF_*.sig")))
+    return [sm.load_one_signature_from_json(f, ksize=21) for f in files]
+
+
+def test_golden_gather_counter_protocol(sm):
+    # tests/test_index_protocol.py:1057-1097: CounterGather over the 12 genomes, (name, |intersect|) per round
+    from sourmash_amd.index import CounterGather
+    query = sm.load_one_signature_from_json(golden("gather", "combined.sig"), ksize=21)
+    counter = CounterGather(query)
+    for ss in _gather_db(sm):
+        counter.add(ss)
+    got = []
+    query_mh = query.minhash.to_mutable()
+    while True:
+        res = counter.peek(query_mh)
+        if not res:
+            break
+        sr, isect = res
+        got.append((sr.signature.name.split()[0], len(isect)))
+        counter.consume(isect)
+        query_mh.remove_many(sr.signature.minhash)
+    assert got == GOLDEN_GATHER
+
+
+def test_golden_gather_databases_and_stats(sm):
+    from sourmash_amd.index import LinearIndex
+    from sourmash_amd.search import GatherDatabases
+    query = sm.load_one_signature_from_json(golden("gather", "combined.sig"), ksize=21)
+    db = LinearIndex(_gather_db(sm))
+    counter = db.counter_gather(query, 0)
+    results = list(GatherDatabases(query, [counter], threshold_bp=0))
+    assert [(r.name.split()[0], r.n_intersect) for r in results] == GOLDEN_GATHER
+    assert [r.gather_result_rank for r in results] == list(range(12))
+    # tests/test_sourmash.py:4546-4614 (three Thermotoga genomes)
+    names = ("GCF_000016785.1_ASM1678v1", "GCF_000018945.1_ASM1894v1", "GCF_000008545.1_ASM854v1")
+    three = LinearIndex([sm.load_one_signature_from_json(golden("gather", n + "_genomic.fna.gz.sig"), ksize=21)
+                         for n in names])
+    rows = list(GatherDatabases(query, [three.counter_gather(query, 0)], threshold_bp=0))
+    assert [r.name.split()[0] for r in rows] == ["NC_000853.1", "NC_011978.1", "NC_009486.1"]
+    assert rows[0].f_match == 1.0 and round(rows[0].f_unique_to_query, 5) == round(0.13096862, 5)
+    assert (rows[0].unique_intersect_bp, rows[0].remaining_bp) == (1920000, 12740000)
+    assert round(rows[1].f_match, 5) == round(0.898936170212766, 5) and round(rows[1].f_unique_to_query, 5) == round(0.115279, 5)
+    assert (rows[1].unique_intersect_bp, rows[1].remaining_bp) == (1690000, 11050000)
+    assert round(rows[2].f_match, 5) == round(0.4842105, 5) and round(rows[2].f_unique_to_query, 5) == round(0.0627557, 5)
+    assert (rows[2].unique_intersect_bp, rows[2].remaining_bp) == (920000, 10130000)
+
+
+def test_counter_trace_ties_and_threshold(sm):
+    # tests/test_index.py:1581-1679: query 0..19; matches 0-9 / 7-14 / 13-16 -> counters 10,8,4 -> 5,4 -> 2
+    from sourmash_amd.index import CounterGather
+    query = _sig(sm, range(0, 20), "q")
+    m = [_sig(sm, range(0, 10), "a"), _sig(sm, range(7, 15), "b"), _sig(sm, range(13, 17), "c")]
+    cg = CounterGather(query)
+    for ss in m:
+        cg.add(ss)
+    assert sorted(cg.counter.values(), reverse=True) == [10, 8, 4]
+    qmh = query.minhash.to_mutable()
+    sr, isect = cg.peek(qmh)
+    assert sr.signature.name == "a" and len(isect) == 10 and sr.score == 0.5
+    cg.consume(isect)
+    assert sorted(cg.counter.values(), reverse=True) == [5, 4]
+    qmh.remove_many(sr.signature.minhash)
+    sr, isect = cg.peek(qmh)
+    assert sr.signature.name == "b" and len(isect) == 5
+    cg.consume(isect)
+    qmh.remove_many(sr.signature.minhash)
+    assert list(cg.counter.values()) == [2]
+    sr, isect = cg.peek(qmh)
+    assert sr.signature.name == "c" and len(isect) == 2
+    cg.consume(isect)
+    assert cg.counter == {}
+    with pytest.raises(ValueError):
+        cg.add(m[0])                                   # no adds after peek/consume (:778-779)
+    # ties go to the first inserted (Counter.most_common is stable)
+    cg = CounterGather(query)
+    cg.add_many([_sig(sm, range(10, 15), "x"), _sig(sm, range(0, 5), "y"), _sig(sm, range(0, 3), "z")])
+    assert cg.gather_all() == [(_sig(sm, range(10, 15), "x").md5sum(), 5), (_sig(sm, range(0, 5), "y").md5sum(), 5)]
+    # threshold_bp / scaled = minimum hashes (search.py:15-37); unattainable -> no result
+    for thr, want in ((5, 2), (6, 1), (11, 0), (21, 0)):
+        cg = CounterGather(query)
+        cg.add_many(m)
+        assert len(cg.gather_all(threshold_bp=thr)) == want, thr
+    with pytest.raises(ValueError):
+        CounterGather(query).add(_sig(sm, range(100, 110), "nope"))   # require_overlap
+    with pytest.raises(ValueError):
+        cg2 = CounterGather(query)
+        cg2.add(m[0])
+        cg2.peek(_sig(sm, range(15, 30), "not-subset").minhash)
+
+
+def test_search_and_prefetch_vs_oracle(sm):
+    from sourmash_amd.index import LinearIndex
+    from sourmash_amd.synth import synth_sketches
+    sk = synth_sketches(120, pool_size=6000)
+    sigs = [_sig(sm, s, f"s{i}", scaled=1000, ksize=31) for i, s in enumerate(sk)]
+    db = LinearIndex(sigs)
+    q = sigs[5]
+    hashes, offsets = oracle.make_csr(sk)
+    wc, wj = oracle.compare_all_pairs(hashes, offsets, nthreads=4)
+    res = db.search(q, threshold=0.06)
+    want = sorted([(wj[5, j], j) for j in range(len(sk)) if wj[5, j] >= 0.06 and wj[5, j] > 0], key=lambda t: -t[0])
+    assert [r.score for r in res] == [w[0] for w in want]
+    assert {r.signature.name for r in res} == {f"s{j}" for _, j in want}
+    cres = db.search(q, threshold=0.1, do_containment=True)
+    wantc = {j for j in range(len(sk)) if len(sk[5]) and wc[5, j] / len(sk[5]) >= 0.1}
+    assert {r.signature.name for r in cres} == {f"s{j}" for j in wantc}
+    pre = list(db.prefetch(q, threshold_bp=60 * 1000))
+    assert {r.signature.name for r in pre} == {f"s{j}" for j in range(len(sk)) if wc[5, j] >= 60}
+    with pytest.raises(ValueError):
+        list(LinearIndex([]).prefetch(q, 0))
+    assert db.best_containment(q).signature.name in ("s5", "s116")          # itself or its planted duplicate
+
+
+def test_synthetic_gather_vs_oracle(sm):
+    from sourmash_amd.index import CounterGather
+    from sourmash_amd.synth import synth_gather
+    qh, dbh = synth_gather(n_query=60_000, n_db=1500, db_size=600)
+    query = _sig(sm, qh, "q", scaled=1000, ksize=31)
+    sigs = [_sig(sm, h, f"d{i}", scaled=1000, ksize=31) for i, h in enumerate(dbh)]
+    hashes, offsets = oracle.make_csr(dbh)
+    for thr_bp in (0, 50_000, 200_000):
+        want = oracle.gather(qh, hashes, offsets, threshold_bp=thr_bp, scaled=1000)
+        cg = CounterGather(query)
+        cg.add_many(sigs)
+        got = cg.gather_all(threshold_bp=thr_bp)
+        md5_to_idx = {s.md5sum(): i for i, s in enumerate(sigs)}
+        assert [(md5_to_idx[m], n) for m, n in got] == want, thr_bp
+        assert len(want) > 10 or thr_bp == 200_000
