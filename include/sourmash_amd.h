@@ -246,6 +246,17 @@ void smgpu_synth_dna_raw(uint8_t *d_out, uint64_t start, uint64_t n, uint64_t se
  * (d_common is required as scratch if d_jaccard is given).  Asynchronous. */
 void smgpu_compare_raw(const uint64_t *d_hashes, const uint64_t *d_offsets, uint32_t n, uint32_t row_lo,
                        uint32_t row_hi, uint32_t *d_common, double *d_jaccard, void *stream);
+/* Multi-GPU form of the same kernel (BASELINE config C4: row-block shard per GPU): this launch owns
+ * the 16-row tiles rb_first, rb_first + rb_stride, ... (rb_count tiles) of the n x n problem and
+ * computes their tiles on/above the diagonal into d_common[rb_count*16][n] (zero-initialised by the
+ * caller).  After one all-gather of the shards, smgpu_symmetrize_raw mirrors the upper triangle of the
+ * full matrix and smgpu_jaccard_raw converts counts (rows [row_lo,row_hi) of a full matrix slice that
+ * starts at row_lo) to f64 Jaccard. */
+void smgpu_compare_blocks_raw(const uint64_t *d_hashes, const uint64_t *d_offsets, uint32_t n, uint32_t rb_first,
+                              uint32_t rb_stride, uint32_t rb_count, uint32_t *d_common, void *stream);
+void smgpu_symmetrize_raw(uint32_t *d_common, uint32_t n, void *stream);
+void smgpu_jaccard_raw(const uint32_t *d_common, const uint64_t *d_offsets, uint32_t n, uint32_t row_lo,
+                       uint32_t row_hi, double *d_jaccard, void *stream);
 /* Host convenience: n sketch handles -> n x n matrices on the host (either may be NULL). */
 void smgpu_compare_all_pairs(const SourmashKmerMinHash *const *mhs, uintptr_t n, uint32_t *common_out,
                              double *jaccard_out);

@@ -592,6 +592,23 @@ void smgpu_compare_raw(const uint64_t* d_hashes, const uint64_t* d_offsets, uint
     });
 }
 
+void smgpu_compare_blocks_raw(const uint64_t* d_hashes, const uint64_t* d_offsets, uint32_t n, uint32_t rb_first,
+                              uint32_t rb_stride, uint32_t rb_count, uint32_t* d_common, void* stream) {
+    landing_void([&] {
+        hip_check(compare_blocks_launch(d_hashes, d_offsets, n, rb_first, rb_stride, rb_count, d_common, (hipStream_t)stream),
+                  "compare_blocks");
+    });
+}
+void smgpu_symmetrize_raw(uint32_t* d_common, uint32_t n, void* stream) {
+    landing_void([&] { hip_check(symmetrize_launch(d_common, n, (hipStream_t)stream), "symmetrize"); });
+}
+void smgpu_jaccard_raw(const uint32_t* d_common, const uint64_t* d_offsets, uint32_t n, uint32_t row_lo, uint32_t row_hi,
+                       double* d_jaccard, void* stream) {
+    landing_void([&] {
+        hip_check(jaccard_from_counts_launch(d_common, d_offsets, n, row_lo, row_hi, d_jaccard, (hipStream_t)stream), "jaccard");
+    });
+}
+
 void smgpu_compare_all_pairs(const SourmashKmerMinHash* const* mhs, uintptr_t n, uint32_t* common_out, double* jaccard_out) {
     landing_void([&] {
         if (n == 0) return;

@@ -37,14 +37,19 @@ constexpr int CMP_BLOCK = CT * CT;
 
 __global__ __launch_bounds__(CMP_BLOCK) void compare_tile_kernel(
     const uint64_t* __restrict__ hashes, const uint64_t* __restrict__ offsets, uint32_t n,
-    uint32_t row_lo, uint32_t row_hi, uint32_t* __restrict__ common, int symmetric) {
+    uint32_t row_lo, uint32_t row_hi, uint32_t* __restrict__ common, int symmetric,
+    uint32_t rb_first, uint32_t rb_stride) {
+    // Row tiles: blockIdx.y-th tile covers global rows row_lo + (rb_first + blockIdx.y * rb_stride) * CT ...;
+    // the output holds the tiles this launch owns back to back (local row = blockIdx.y * CT + r).
+    // symmetric: 0 = every tile; 1 = all rows local: skip tiles below the diagonal and mirror on
+    // write; 2 = upper tiles only, no mirror (sharded launch; smg::symmetrize fills the rest).
     __shared__ uint64_t s_seg[2 * CT][SEG_STRIDE];
     __shared__ uint64_t s_pos[2 * CT], s_end[2 * CT];
     __shared__ uint32_t s_take[2 * CT];
     __shared__ unsigned long long s_hi;
     __shared__ uint32_t s_live[2];   // [0] rows with data left, [1] columns with data left
 
-    const uint32_t rb = blockIdx.y, cb = blockIdx.x;
+    const uint32_t rb = rb_first + blockIdx.y * rb_stride, cb = blockIdx.x;
     const uint32_t row0 = row_lo + rb * CT, col0 = cb * CT;
     if (symmetric && col0 + CT <= row0) return;   // tile strictly below the diagonal: mirrored from above
 
@@ -123,12 +128,12 @@ __global__ __launch_bounds__(CMP_BLOCK) void compare_tile_kernel(
 
     const uint32_t row = row0 + r, col = col0 + c;
     if (row < row_hi && col < n) {
-        const uint64_t idx = (uint64_t)(row - row_lo) * n + col;
+        const uint64_t idx = (uint64_t)(blockIdx.y * CT + r) * n + col;
         if (!symmetric) {
             common[idx] = cnt;
         } else if (col >= row) {
             common[idx] = cnt;
-            if (col < row_hi && col >= row_lo) common[(uint64_t)(col - row_lo) * n + row] = cnt;
+            if (symmetric == 1) common[(uint64_t)(col - row_lo) * n + row] = cnt;   // all rows local, rb_stride == 1
         }
     }
 }
@@ -160,7 +165,42 @@ hipError_t compare_counts_launch(const uint64_t* d_hashes, const uint64_t* d_off
     const int symmetric = (row_lo == 0 && row_hi == n) ? 1 : 0;
     dim3 grid((n + CT - 1) / CT, (row_hi - row_lo + CT - 1) / CT);
     hipLaunchKernelGGL(compare_tile_kernel, grid, dim3(CMP_BLOCK), 0, stream, d_hashes, d_offsets, n, row_lo, row_hi,
-                       d_common, symmetric);
+                       d_common, symmetric, 0u, 1u);
+    return hipGetLastError();
+}
+
+// Sharded form: this launch owns the row tiles rb_first, rb_first + rb_stride, ... (rb_count of them)
+// of the full n x n problem and computes only their tiles on or above the diagonal.
+hipError_t compare_blocks_launch(const uint64_t* d_hashes, const uint64_t* d_offsets, uint32_t n, uint32_t rb_first,
+                                 uint32_t rb_stride, uint32_t rb_count, uint32_t* d_common, hipStream_t stream) {
+    if (rb_count == 0 || n == 0) return hipSuccess;
+    dim3 grid((n + CT - 1) / CT, rb_count);
+    hipLaunchKernelGGL(compare_tile_kernel, grid, dim3(CMP_BLOCK), 0, stream, d_hashes, d_offsets, n, 0u, n, d_common,
+                       2, rb_first, rb_stride);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void symmetrize_kernel(uint32_t* __restrict__ m, uint32_t n) {
+    // m[j][i] = m[i][j] for i < j.  32 x 32 tiles through LDS so both the read and the write are coalesced.
+    __shared__ uint32_t t[32][33];
+    const uint32_t bi = blockIdx.y, bj = blockIdx.x;
+    if (bj < bi) return;
+    const uint32_t tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (uint32_t r = ty; r < 32; r += 8) {
+        const uint32_t i = bi * 32 + r, j = bj * 32 + tx;
+        t[r][tx] = (i < n && j < n) ? m[(uint64_t)i * n + j] : 0;
+    }
+    __syncthreads();
+    for (uint32_t r = ty; r < 32; r += 8) {
+        const uint32_t j = bj * 32 + r, i = bi * 32 + tx;        // writing element (j, i), j is the row
+        if (i < n && j < n && i < j) m[(uint64_t)j * n + i] = t[tx][r];
+    }
+}
+
+hipError_t symmetrize_launch(uint32_t* d_common, uint32_t n, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    dim3 grid((n + 31) / 32, (n + 31) / 32);
+    hipLaunchKernelGGL(symmetrize_kernel, grid, dim3(256), 0, stream, d_common, n);
     return hipGetLastError();
 }
 

@@ -37,6 +37,12 @@ hipError_t synth_dna_launch(uint8_t* d_out, uint64_t start, uint64_t n, uint64_t
 hipError_t compare_counts_launch(const uint64_t* d_hashes, const uint64_t* d_offsets, uint32_t n,
                                  uint32_t row_lo, uint32_t row_hi, uint32_t* d_common /*[(row_hi-row_lo)][n]*/,
                                  hipStream_t stream);
+// Sharded all-pairs: row tiles (16 rows each) rb_first, rb_first + rb_stride, ... of the n x n problem,
+// upper-triangle tiles only; d_common holds the owned tiles back to back ([rb_count * 16][n]).
+hipError_t compare_blocks_launch(const uint64_t* d_hashes, const uint64_t* d_offsets, uint32_t n, uint32_t rb_first,
+                                 uint32_t rb_stride, uint32_t rb_count, uint32_t* d_common, hipStream_t stream);
+// m[j][i] = m[i][j] for i < j on a full n x n matrix
+hipError_t symmetrize_launch(uint32_t* d_common, uint32_t n, hipStream_t stream);
 hipError_t jaccard_from_counts_launch(const uint32_t* d_common, const uint64_t* d_offsets, uint32_t n,
                                       uint32_t row_lo, uint32_t row_hi, double* d_out, hipStream_t stream);
 
