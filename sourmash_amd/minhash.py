@@ -615,10 +615,12 @@ class MinHash(RustObject):
 
     def size_is_accurate(self, relative_error=0.20, confidence=0.95):
         "Is the sketch large enough for len*scaled to estimate the k-mer count well?"
-        from .distance_utils import set_size_chernoff
+        from .distance_utils import set_size_exact_prob
+        if not self.scaled:
+            raise TypeError("Error: can only estimate dataset size for scaled MinHashes")
         if any(not 0 <= v <= 1 for v in (relative_error, confidence)):
             raise ValueError("Error: relative error and confidence values must be between 0 and 1.")
-        probability = set_size_chernoff(self.unique_dataset_hashes, self.scaled, relative_error=relative_error)
+        probability = set_size_exact_prob(self.unique_dataset_hashes, self.scaled, relative_error=relative_error)
         return probability >= confidence
 
 
