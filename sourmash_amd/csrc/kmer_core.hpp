@@ -72,6 +72,23 @@ SMG_HD bool any_lane(bool p) {
 #endif
 }
 
+// bitwise select: mask ? b : c  (v_bitop3_b32 is full rate on gfx950, v_cndmask_b32 is not)
+SMG_HD uint32_t bitselect(uint32_t mask, uint32_t b, uint32_t c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_bitop3_b32(mask, b, c, 0xCA);
+#else
+    return (mask & b) | (~mask & c);
+#endif
+}
+
+// Make a value opaque to the optimiser at this point (keeps rare-path work inside its branch).
+SMG_HD uint32_t opaque(uint32_t x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(x));
+#endif
+    return x;
+}
+
 SMG_HD uint32_t bswap32(uint32_t x) { return perm_b32(0u, x, 0x00010203u); }
 
 // LUTs indexed by code = (ascii >> 1) & 3 :  A -> 0, C -> 1, T -> 2, G -> 3
@@ -137,9 +154,18 @@ struct PosOps {
     }
 
     template <int CH>
+    static SMG_HD uint64_t be_chunk_opaque(const uint32_t* W) {
+        uint64_t v = (uint64_t)bswap32(opaque(W[2 * CH])) << 32;
+        if constexpr (2 * CH + 1 < G::NWK) v |= bswap32(opaque(W[2 * CH + 1]));
+        return v;
+    }
+
+    // Rare path (some lane's first 8 bytes tie): the operands are laundered through `opaque` so
+    // the compiler cannot hoist these byte swaps out of the branch and run them for every k-mer.
+    template <int CH>
     static SMG_HD void tie_break(const uint32_t* F, const uint32_t* R, bool& tie, bool& gt) {
         if constexpr (CH < G::NCH) {
-            const uint64_t bf = be_chunk<CH>(F), br = be_chunk<CH>(R);
+            const uint64_t bf = be_chunk_opaque<CH>(F), br = be_chunk_opaque<CH>(R);
             gt = gt || (tie && bf > br);
             tie = tie && (bf == br);
             tie_break<CH + 1>(F, R, tie, gt);
@@ -162,8 +188,9 @@ struct PosOps {
         bool tie = bf == br;
         if (G::NCH > 1 && any_lane(tie)) tie_break<1>(F, R, tie, gt);
         uint32_t W[G::NWK];
+        const uint32_t m = gt ? 0xffffffffu : 0u;
 #pragma unroll
-        for (int d = 0; d < G::NWK; ++d) W[d] = gt ? R[d] : F[d];
+        for (int d = 0; d < G::NWK; ++d) W[d] = bitselect(m, R[d], F[d]);
         return mmh3_h1_words<K>(W, seed);
     }
 };
