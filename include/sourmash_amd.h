@@ -257,6 +257,17 @@ void smgpu_compare_blocks_raw(const uint64_t *d_hashes, const uint64_t *d_offset
 void smgpu_symmetrize_raw(uint32_t *d_common, uint32_t n, void *stream);
 void smgpu_jaccard_raw(const uint32_t *d_common, const uint64_t *d_offsets, uint32_t n, uint32_t row_lo,
                        uint32_t row_hi, double *d_jaccard, void *stream);
+/* Dense path of the same comparison: when the collection's U distinct hashes are at most ~512 x the mean
+ * sketch size, sketches become U-bit rows over the collection's own dictionary and |A ∩ B| =
+ * popcount(A & B).  smgpu_bitindex_new sorts/uniques all hashes (synchronises the stream), measures U
+ * and returns NULL -- with no error set -- when the collection is too sparse (use smgpu_compare_*_raw).
+ * smgpu_bitindex_compare_raw fills d_common[rb_count*16][n] for the owned 16-row tiles, ALL columns. */
+typedef struct SmgpuBitIndex SmgpuBitIndex;
+SmgpuBitIndex *smgpu_bitindex_new(const uint64_t *d_hashes, const uint64_t *d_offsets, uint32_t n, void *stream);
+void smgpu_bitindex_free(SmgpuBitIndex *ptr);
+uint64_t smgpu_bitindex_universe(const SmgpuBitIndex *ptr);
+void smgpu_bitindex_compare_raw(const SmgpuBitIndex *ptr, uint32_t rb_first, uint32_t rb_stride, uint32_t rb_count,
+                                uint32_t *d_common, void *stream);
 /* Host convenience: n sketch handles -> n x n matrices on the host (either may be NULL). */
 void smgpu_compare_all_pairs(const SourmashKmerMinHash *const *mhs, uintptr_t n, uint32_t *common_out,
                              double *jaccard_out);

@@ -1,0 +1,140 @@
+// bitindex.hip -- dense path of the all-pairs compare: sketches as bit rows over the collection's
+// own hash dictionary, intersections as popcount(AND).
+//
+// Same results as compare.hip (u32 |A ∩ B| for every pair; reference: minhash.rs:539-558 count_common),
+// different cost model.  The merge walk costs ~(n_i + n_j) steps per pair whatever the data; when the
+// collection is "dense" -- its U distinct hashes are at most a few hundred times the mean sketch size,
+// as for related genomes or any collection drawn from a common pool (BASELINE configs C3/C4: U = 50,000,
+// n = 5,000) -- a sketch is better stored as U bits, and a 64 x 64 tile of pairs costs U/32 x 4096
+// (AND + popcount) in registers with every bitmap word fetched once per tile.  smgpu_bitindex_new
+// decides from the measured U (dictionary = device radix sort + run-length encode of all hashes) and
+// returns NULL for sparse collections, for which the merge kernel stays the right tool.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "device_api.hpp"
+
+namespace smg {
+
+constexpr int BT = 64;            // tile edge (sketches)
+constexpr int BKC = 32;           // bitmap words staged per k-step
+constexpr int BSTRIDE = BKC + 4;  // LDS row stride in words: 36*t mod 64 is a distinct multiple of 4 for t = 0..15
+
+__device__ __forceinline__ uint64_t lower_bound_u64(const uint64_t* __restrict__ a, uint64_t n, uint64_t x) {
+    uint64_t lo = 0, hi = n;
+    while (lo < hi) {
+        const uint64_t mid = (lo + hi) >> 1;
+        if (a[mid] < x) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// one wave per sketch: set bit rank(h) for every hash h of the row
+__global__ __launch_bounds__(256) void bitmap_build_kernel(const uint64_t* __restrict__ hashes,
+                                                           const uint64_t* __restrict__ offsets, uint32_t n,
+                                                           const uint64_t* __restrict__ dict, uint64_t U,
+                                                           uint32_t* __restrict__ bits, uint32_t words_per_row) {
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    for (uint64_t row = wave; row < n; row += n_waves) {
+        const uint64_t lo = offsets[row], hi = offsets[row + 1];
+        uint32_t* out = bits + row * (uint64_t)words_per_row;
+        for (uint64_t i = lo + lane; i < hi; i += 64) {
+            const uint64_t rank = lower_bound_u64(dict, U, hashes[i]);
+            atomicOr(&out[rank >> 5], 1u << (rank & 31));
+        }
+    }
+}
+
+// common[local row][col] = popcount(bits[row] & bits[col]) for a 64 x 64 tile; lane (tr, tc) owns the
+// 4 x 4 pairs (tr + 16 i, tc + 16 j).  Rows of the launch are the 16-row tiles rb_first,
+// rb_first + rb_stride, ... (same dealing as compare.hip); four of them form one 64-row group.
+__global__ __launch_bounds__(256) void bitmatrix_kernel(const uint32_t* __restrict__ bits, uint32_t words_per_row,
+                                                        uint32_t n, uint32_t rb_first, uint32_t rb_stride,
+                                                        uint32_t rb_count, uint32_t* __restrict__ common) {
+    __shared__ __attribute__((aligned(16))) uint32_t sA[BT * BSTRIDE];
+    __shared__ __attribute__((aligned(16))) uint32_t sB[BT * BSTRIDE];
+    const int tid = threadIdx.x;
+    const int tr = tid >> 4, tc = tid & 15;
+    const uint32_t col0 = blockIdx.x * BT;
+    const uint32_t grp = blockIdx.y;                                 // 64-row group = 4 owned 16-row tiles
+
+    auto global_row = [&](uint32_t local) -> uint32_t {              // local row in the group -> global row
+        const uint32_t t = grp * 4 + (local >> 4);
+        if (t >= rb_count) return 0xffffffffu;
+        return (rb_first + t * rb_stride) * 16 + (local & 15);
+    };
+
+    uint32_t acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = 0;
+
+    // staging assignment: 64 rows x 8 chunks of 4 words = 512 chunks per operand, 2 per thread
+    for (uint32_t k0 = 0; k0 < words_per_row; k0 += BKC) {
+        __syncthreads();
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int chunk = tid + q * 256;
+            const int row = chunk >> 3, kc = (chunk & 7) * 4;
+            const uint32_t gr = global_row((uint32_t)row);
+            uint4 va = make_uint4(0, 0, 0, 0), vb = make_uint4(0, 0, 0, 0);
+            if (gr < n) va = *reinterpret_cast<const uint4*>(bits + (uint64_t)gr * words_per_row + k0 + kc);
+            const uint32_t gc = col0 + (uint32_t)row;
+            if (gc < n) vb = *reinterpret_cast<const uint4*>(bits + (uint64_t)gc * words_per_row + k0 + kc);
+            *reinterpret_cast<uint4*>(&sA[row * BSTRIDE + kc]) = va;
+            *reinterpret_cast<uint4*>(&sB[row * BSTRIDE + kc]) = vb;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k4 = 0; k4 < BKC; k4 += 4) {
+            uint4 a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = *reinterpret_cast<const uint4*>(&sA[(tr + 16 * i) * BSTRIDE + k4]);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[j] = *reinterpret_cast<const uint4*>(&sB[(tc + 16 * j) * BSTRIDE + k4]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    acc[i][j] += __popc(a[i].x & b[j].x) + __popc(a[i].y & b[j].y) + __popc(a[i].z & b[j].z) +
+                                 __popc(a[i].w & b[j].w);
+                }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t local = (uint32_t)(tr + 16 * i);
+        const uint32_t gr = global_row(local);
+        if (gr >= n) continue;
+        const uint64_t out_row = (uint64_t)(grp * 64 + local) * n;     // owned tiles back to back
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t gc = col0 + (uint32_t)(tc + 16 * j);
+            if (gc < n) common[out_row + gc] = acc[i][j];
+        }
+    }
+}
+
+hipError_t bitmap_build_launch(const uint64_t* d_hashes, const uint64_t* d_offsets, uint32_t n, const uint64_t* d_dict,
+                               uint64_t U, uint32_t* d_bits, uint32_t words_per_row, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    hipError_t e = hipMemsetAsync(d_bits, 0, (size_t)n * words_per_row * 4, stream);
+    if (e != hipSuccess) return e;
+    const uint64_t blocks = ((uint64_t)n + 3) / 4;
+    hipLaunchKernelGGL(bitmap_build_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, stream,
+                       d_hashes, d_offsets, n, d_dict, U, d_bits, words_per_row);
+    return hipGetLastError();
+}
+
+hipError_t bitmatrix_launch(const uint32_t* d_bits, uint32_t words_per_row, uint32_t n, uint32_t rb_first,
+                            uint32_t rb_stride, uint32_t rb_count, uint32_t* d_common, hipStream_t stream) {
+    if (n == 0 || rb_count == 0) return hipSuccess;
+    dim3 grid((n + BT - 1) / BT, (rb_count + 3) / 4);
+    hipLaunchKernelGGL(bitmatrix_kernel, grid, dim3(256), 0, stream, d_bits, words_per_row, n, rb_first, rb_stride,
+                       rb_count, d_common);
+    return hipGetLastError();
+}
+
+}  // namespace smg

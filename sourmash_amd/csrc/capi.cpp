@@ -609,6 +609,63 @@ void smgpu_jaccard_raw(const uint32_t* d_common, const uint64_t* d_offsets, uint
     });
 }
 
+// ---- dense compare path: bit rows over the collection's own dictionary --------------------------------
+struct BitIndex {
+    uint32_t n = 0, words_per_row = 0;
+    uint64_t universe = 0, total = 0;
+    uint32_t* bits = nullptr;
+    ~BitIndex() { if (bits) (void)hipFree(bits); }
+};
+
+// Build the dictionary (sort + unique of every hash) and, if the collection is dense enough, the bit rows.
+// Returns nullptr (no error) when the merge kernel is the better tool.
+static BitIndex* bitindex_build(const uint64_t* d_hashes, const uint64_t* d_offsets, uint32_t n, hipStream_t st) {
+    if (n == 0) return nullptr;
+    uint64_t total = 0;
+    hip_check(hipMemcpyAsync(&total, d_offsets + n, 8, hipMemcpyDeviceToHost, st), "D2H");
+    hip_check(hipStreamSynchronize(st), "sync");
+    if (total == 0 || total > 0xffffffffull) return nullptr;
+    DevBuf keys, uniq, tmp, scal;
+    struct Free { DevBuf& b; ~Free() { if (b.p) (void)hipFree(b.p); } } f1{keys}, f2{uniq}, f3{tmp}, f4{scal};
+    keys.reserve(total * 8);
+    uniq.reserve(total * 8);
+    scal.reserve(64);
+    const size_t tb = sort_unique_temp_bytes(total);
+    tmp.reserve(tb);
+    hip_check(hipMemcpyAsync(keys.p, d_hashes, total * 8, hipMemcpyDeviceToDevice, st), "D2D");
+    hip_check(sort_unique(keys.as<uint64_t>(), total, uniq.as<uint64_t>(), nullptr, scal.as<uint64_t>(), tmp.p, tb, 64, st),
+              "sort_unique");
+    uint64_t U = 0;
+    hip_check(hipMemcpyAsync(&U, scal.p, 8, hipMemcpyDeviceToHost, st), "D2H");
+    hip_check(hipStreamSynchronize(st), "sync");
+    // cost model: bit rows win while U <= ~512 x mean sketch size; cap the bitmap at 8 GiB
+    const double mean_len = (double)total / n;
+    const uint32_t words = (uint32_t)(((U + 31) / 32 + 31) / 32 * 32);        // whole 32-word k-steps
+    if ((double)U > 512.0 * mean_len || (double)n * words * 4.0 > 8.0 * (1ull << 30)) return nullptr;
+    std::unique_ptr<BitIndex> bi(new BitIndex());
+    bi->n = n; bi->universe = U; bi->total = total; bi->words_per_row = words;
+    hip_check(hipMalloc((void**)&bi->bits, (size_t)n * words * 4), "hipMalloc");
+    hip_check(bitmap_build_launch(d_hashes, d_offsets, n, uniq.as<uint64_t>(), U, bi->bits, words, st), "bitmap_build");
+    hip_check(hipStreamSynchronize(st), "sync");      // the dictionary buffers are released on return
+    return bi.release();
+}
+
+SmgpuBitIndex* smgpu_bitindex_new(const uint64_t* d_hashes, const uint64_t* d_offsets, uint32_t n, void* stream) {
+    return landing<SmgpuBitIndex*>([&]() -> SmgpuBitIndex* {
+        return reinterpret_cast<SmgpuBitIndex*>(bitindex_build(d_hashes, d_offsets, n, (hipStream_t)stream));
+    });
+}
+void smgpu_bitindex_free(SmgpuBitIndex* p) { delete reinterpret_cast<BitIndex*>(p); }
+uint64_t smgpu_bitindex_universe(const SmgpuBitIndex* p) { return reinterpret_cast<const BitIndex*>(p)->universe; }
+void smgpu_bitindex_compare_raw(const SmgpuBitIndex* p, uint32_t rb_first, uint32_t rb_stride, uint32_t rb_count,
+                                uint32_t* d_common, void* stream) {
+    landing_void([&] {
+        const BitIndex* bi = reinterpret_cast<const BitIndex*>(p);
+        hip_check(bitmatrix_launch(bi->bits, bi->words_per_row, bi->n, rb_first, rb_stride, rb_count, d_common,
+                                   (hipStream_t)stream), "bitmatrix");
+    });
+}
+
 void smgpu_compare_all_pairs(const SourmashKmerMinHash* const* mhs, uintptr_t n, uint32_t* common_out, double* jaccard_out) {
     landing_void([&] {
         if (n == 0) return;
@@ -626,13 +683,18 @@ void smgpu_compare_all_pairs(const SourmashKmerMinHash* const* mhs, uintptr_t n,
         struct Free { DevBuf& b; ~Free() { if (b.p) (void)hipFree(b.p); } } f1{dh}, f2{doff}, f3{dc}, f4{dj};
         dh.reserve(total * 8 + 16);
         doff.reserve((n + 1) * 8);
-        dc.reserve((size_t)n * n * 4);
+        dc.reserve((size_t)((n + 15) / 16 * 16) * n * 4);
         for (uintptr_t i = 0; i < n; ++i)
             if (MH(mhs[i])->size())
                 hip_check(hipMemcpyAsync(dh.as<uint64_t>() + offsets[i], MH(mhs[i])->mins.data(), MH(mhs[i])->size() * 8,
                                          hipMemcpyHostToDevice, st), "H2D");
         hip_check(hipMemcpyAsync(doff.p, offsets.data(), (n + 1) * 8, hipMemcpyHostToDevice, st), "H2D");
-        hip_check(compare_counts_launch(dh.as<uint64_t>(), doff.as<uint64_t>(), (uint32_t)n, 0, (uint32_t)n, dc.as<uint32_t>(), st), "compare");
+        std::unique_ptr<BitIndex> bi(bitindex_build(dh.as<uint64_t>(), doff.as<uint64_t>(), (uint32_t)n, st));
+        if (bi)   // dense collection: bit rows + popcount(AND)
+            hip_check(bitmatrix_launch(bi->bits, bi->words_per_row, (uint32_t)n, 0, 1, (uint32_t)((n + 15) / 16),
+                                       dc.as<uint32_t>(), st), "bitmatrix");
+        else      // sparse collection: LDS-tiled merge walk
+            hip_check(compare_counts_launch(dh.as<uint64_t>(), doff.as<uint64_t>(), (uint32_t)n, 0, (uint32_t)n, dc.as<uint32_t>(), st), "compare");
         if (jaccard_out) {
             dj.reserve((size_t)n * n * 8);
             hip_check(jaccard_from_counts_launch(dc.as<uint32_t>(), doff.as<uint64_t>(), (uint32_t)n, 0, (uint32_t)n, dj.as<double>(), st), "jaccard");

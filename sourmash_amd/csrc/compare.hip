@@ -34,106 +34,191 @@ constexpr int CT = 16;            // tile edge (sketches)
 constexpr int SEG = 128;          // hashes per sketch per round
 constexpr int SEG_STRIDE = SEG + 1;  // +1 u64 pad: spreads the 16 column segments over distinct LDS banks
 constexpr int CMP_BLOCK = CT * CT;
+constexpr int CMP_ZMAX = 16;      // hash-range slices per tile (grid.z); a tile uses ceil(longest / slice_len) of them
 
+__device__ __forceinline__ uint64_t lower_bound_row(const uint64_t* __restrict__ a, uint64_t lo, uint64_t hi, uint64_t x) {
+    while (lo < hi) {
+        const uint64_t mid = (lo + hi) >> 1;
+        if (a[mid] < x) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// One unit of work: slice z (of zt) of the tile (row tile index `ty` in launch order, column tile cb).
+struct WorkItem { uint32_t ty, cb, z, zt; };
+
+// Planning pass: one lane per tile decides how many hash-range slices the tile is cut into
+// (ceil(longest sketch / slice_len), at most CMP_ZMAX) and appends its work items.  Tiles that get
+// sliced (they contain an unusually long sketch) go to the `heavy` list, which the workers drain
+// first: longest-processing-time-first scheduling keeps ragged collections from leaving a tail.
+__global__ __launch_bounds__(256) void compare_plan_kernel(
+    const uint64_t* __restrict__ offsets, uint32_t n, uint32_t row_lo, uint32_t row_hi, int symmetric,
+    uint32_t rb_first, uint32_t rb_stride, uint32_t n_row_tiles, uint32_t n_col_tiles, uint32_t slice_len,
+    WorkItem* __restrict__ heavy, WorkItem* __restrict__ light, unsigned int* __restrict__ counters) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_row_tiles * n_col_tiles) return;
+    const uint32_t ty = t / n_col_tiles, cb = t % n_col_tiles;
+    const uint32_t rb = rb_first + ty * rb_stride;
+    const uint32_t row0 = row_lo + rb * CT, col0 = cb * CT;
+    if (symmetric && col0 + CT <= row0) return;              // strictly below the diagonal
+    uint64_t best = 0;
+    for (int i = 0; i < CT; ++i) {
+        const uint32_t r = row0 + i, c = col0 + i;
+        if (r < row_hi) { const uint64_t l = offsets[r + 1] - offsets[r]; best = l > best ? l : best; }
+        if (c < n) { const uint64_t l = offsets[c + 1] - offsets[c]; best = l > best ? l : best; }
+    }
+    if (best == 0) return;                                    // nothing can intersect
+    uint32_t zt = (uint32_t)((best + slice_len - 1) / slice_len);
+    zt = zt < 1 ? 1 : (zt > (uint32_t)CMP_ZMAX ? (uint32_t)CMP_ZMAX : zt);
+    WorkItem* list = zt > 1 ? heavy : light;
+    const unsigned int base = atomicAdd(&counters[zt > 1 ? 0 : 1], zt);
+    for (uint32_t z = 0; z < zt; ++z) list[base + z] = WorkItem{ty, cb, z, zt};
+}
+
+// Worker: persistent workgroups pull work items (heavy list first) with one atomic per item.
 __global__ __launch_bounds__(CMP_BLOCK) void compare_tile_kernel(
     const uint64_t* __restrict__ hashes, const uint64_t* __restrict__ offsets, uint32_t n,
     uint32_t row_lo, uint32_t row_hi, uint32_t* __restrict__ common, int symmetric,
-    uint32_t rb_first, uint32_t rb_stride) {
-    // Row tiles: blockIdx.y-th tile covers global rows row_lo + (rb_first + blockIdx.y * rb_stride) * CT ...;
-    // the output holds the tiles this launch owns back to back (local row = blockIdx.y * CT + r).
-    // symmetric: 0 = every tile; 1 = all rows local: skip tiles below the diagonal and mirror on
-    // write; 2 = upper tiles only, no mirror (sharded launch; smg::symmetrize fills the rest).
+    uint32_t rb_first, uint32_t rb_stride, const WorkItem* __restrict__ heavy,
+    const WorkItem* __restrict__ light, unsigned int* __restrict__ counters) {
+    // symmetric: 0 = every tile; 1 = all rows local: tiles on/above the diagonal, mirrored on write;
+    // 2 = upper tiles only, no mirror (sharded launch; symmetrize_kernel fills the rest).
+    // counters: [0] heavy items, [1] light items, [2] next heavy, [3] next light.
+    // Output rows: the tiles this launch owns back to back (local row = ty * CT + r); pre-zeroed,
+    // partial counts of the slices of a tile are combined with atomicAdd.
     __shared__ uint64_t s_seg[2 * CT][SEG_STRIDE];
     __shared__ uint64_t s_pos[2 * CT], s_end[2 * CT];
     __shared__ uint32_t s_take[2 * CT];
     __shared__ unsigned long long s_hi;
     __shared__ uint32_t s_live[2];   // [0] rows with data left, [1] columns with data left
-
-    const uint32_t rb = rb_first + blockIdx.y * rb_stride, cb = blockIdx.x;
-    const uint32_t row0 = row_lo + rb * CT, col0 = cb * CT;
-    if (symmetric && col0 + CT <= row0) return;   // tile strictly below the diagonal: mirrored from above
+    __shared__ uint64_t s_piv[2];
+    __shared__ WorkItem s_item;
+    __shared__ int s_have;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = tid / CT, c = tid % CT;
 
-    if (tid < 2 * CT) {
-        const uint32_t s = tid < CT ? row0 + tid : col0 + (tid - CT);
-        const bool ok = tid < CT ? (s < row_hi) : (s < n);
-        s_pos[tid] = ok ? offsets[s] : 0;
-        s_end[tid] = ok ? offsets[s + 1] : 0;
-    }
-    uint32_t cnt = 0;
-    __syncthreads();
-
     for (;;) {
-        if (tid == 0) { s_hi = ~0ull; s_live[0] = 0; s_live[1] = 0; }
-        __syncthreads();
-        // ---- stage the next <= SEG hashes of each of the 32 sketches: wave w takes sketches 8w..8w+7,
-        //      lane l the hashes 2l, 2l+1 (one 16-byte load when aligned) ----
-        uint64_t e0[8], e1[8];
-        uint32_t have[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int s = wave * 8 + i;
-            const uint64_t pos = s_pos[s], end = s_end[s];
-            const uint64_t left = end - pos;
-            const uint32_t len = left < (uint64_t)SEG ? (uint32_t)left : (uint32_t)SEG;
-            have[i] = len;
-            const uint64_t* p = hashes + pos + 2 * lane;
-            uint64_t v0 = ~0ull, v1 = ~0ull;
-            if ((uint32_t)(2 * lane + 1) < len) {
-                if ((pos & 1) == 0) {
-                    const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(p);
-                    v0 = v.x; v1 = v.y;
-                } else { v0 = p[0]; v1 = p[1]; }
-            } else if ((uint32_t)(2 * lane) < len) {
-                v0 = p[0];
+        // ---- fetch the next work item ----
+        __syncthreads();                                   // previous item fully done (LDS reuse)
+        if (tid == 0) {
+            int have = 0;
+            unsigned int i = atomicAdd(&counters[2], 1u);
+            if (i < counters[0]) { s_item = heavy[i]; have = 1; }
+            else {
+                i = atomicAdd(&counters[3], 1u);
+                if (i < counters[1]) { s_item = light[i]; have = 1; }
             }
-            e0[i] = v0; e1[i] = v1;
-            s_seg[s][2 * lane] = v0;
-            s_seg[s][2 * lane + 1] = v1;
-            if (lane == 0) {
-                if (left > (uint64_t)SEG) atomicMin(&s_hi, (unsigned long long)hashes[pos + SEG - 1]);
-                if (len) atomicOr(&s_live[s < CT ? 0 : 1], 1u);
-            }
+            s_have = have;
         }
         __syncthreads();
-        if (s_live[0] == 0 || s_live[1] == 0) break;   // every row or every column exhausted
-        const uint64_t hi = s_hi;
-        // ---- how many staged hashes of each sketch are <= hi ----
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int s = wave * 8 + i;
-            const bool in0 = (uint32_t)(2 * lane) < have[i] && e0[i] <= hi;
-            const bool in1 = (uint32_t)(2 * lane + 1) < have[i] && e1[i] <= hi;
-            const uint32_t take = (uint32_t)__popcll(__ballot(in0)) + (uint32_t)__popcll(__ballot(in1));
-            if (lane == 0) { s_take[s] = take; s_pos[s] += take; }
-        }
-        __syncthreads();
-        // ---- the merge walk of minhash.rs:915-953 on the LDS-resident parts ----
-        {
-            const uint32_t na = s_take[r], nb = s_take[CT + c];
-            const uint64_t* A = s_seg[r];
-            const uint64_t* B = s_seg[CT + c];
-            uint32_t ia = 0, ib = 0;
-            while (ia < na && ib < nb) {
-                const uint64_t a = A[ia], b = B[ib];
-                cnt += (a == b);
-                ia += (a <= b);
-                ib += (b <= a);
-            }
-        }
-        // next round's staging overwrites s_seg: the barrier at the top of the loop orders it
-    }
+        if (!s_have) return;
+        const WorkItem it = s_item;
+        const uint32_t rb = rb_first + it.ty * rb_stride;
+        const uint32_t row0 = row_lo + rb * CT, col0 = it.cb * CT;
 
-    const uint32_t row = row0 + r, col = col0 + c;
-    if (row < row_hi && col < n) {
-        const uint64_t idx = (uint64_t)(blockIdx.y * CT + r) * n + col;
-        if (!symmetric) {
-            common[idx] = cnt;
-        } else if (col >= row) {
-            common[idx] = cnt;
-            if (symmetric == 1) common[(uint64_t)(col - row_lo) * n + row] = cnt;   // all rows local, rb_stride == 1
+        if (tid < 2 * CT) {
+            const uint32_t s = tid < CT ? row0 + tid : col0 + (tid - CT);
+            const bool ok = tid < CT ? (s < row_hi) : (s < n);
+            s_pos[tid] = ok ? offsets[s] : 0;
+            s_end[tid] = ok ? offsets[s + 1] : 0;
+        }
+        __syncthreads();
+        // ---- hash-range slice: the tile's longest sketch is cut into zt equal pieces (pivot values);
+        //      slice z of EVERY sketch is its part inside [pivot_z, pivot_z+1) ----
+        if (it.zt > 1) {
+            if (tid == 0) {
+                uint64_t best_len = 0, best_pos = 0;
+                for (int i = 0; i < 2 * CT; ++i) {
+                    const uint64_t len = s_end[i] - s_pos[i];
+                    if (len > best_len) { best_len = len; best_pos = s_pos[i]; }
+                }
+                s_piv[0] = it.z == 0 ? 0ull : hashes[best_pos + (uint64_t)it.z * best_len / it.zt];
+                s_piv[1] = it.z + 1 == it.zt ? ~0ull : hashes[best_pos + (uint64_t)(it.z + 1) * best_len / it.zt];
+            }
+            __syncthreads();
+            if (tid < 2 * CT) {
+                const uint64_t lo = s_pos[tid], hi = s_end[tid];
+                const uint64_t a = it.z == 0 ? lo : lower_bound_row(hashes, lo, hi, s_piv[0]);
+                const uint64_t b = it.z + 1 == it.zt ? hi : lower_bound_row(hashes, a, hi, s_piv[1]);
+                s_pos[tid] = a;
+                s_end[tid] = b;
+            }
+            __syncthreads();
+        }
+        uint32_t cnt = 0;
+
+        for (;;) {
+            if (tid == 0) { s_hi = ~0ull; s_live[0] = 0; s_live[1] = 0; }
+            __syncthreads();
+            // ---- stage the next <= SEG hashes of each of the 32 sketches: wave w takes sketches 8w..8w+7,
+            //      lane l the hashes 2l, 2l+1 (one 16-byte load when aligned) ----
+            uint64_t e0[8], e1[8];
+            uint32_t have[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int s = wave * 8 + i;
+                const uint64_t pos = s_pos[s], end = s_end[s];
+                const uint64_t left = end - pos;
+                const uint32_t len = left < (uint64_t)SEG ? (uint32_t)left : (uint32_t)SEG;
+                have[i] = len;
+                const uint64_t* p = hashes + pos + 2 * lane;
+                uint64_t v0 = ~0ull, v1 = ~0ull;
+                if ((uint32_t)(2 * lane + 1) < len) {
+                    if ((pos & 1) == 0) {
+                        const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(p);
+                        v0 = v.x; v1 = v.y;
+                    } else { v0 = p[0]; v1 = p[1]; }
+                } else if ((uint32_t)(2 * lane) < len) {
+                    v0 = p[0];
+                }
+                e0[i] = v0; e1[i] = v1;
+                s_seg[s][2 * lane] = v0;
+                s_seg[s][2 * lane + 1] = v1;
+                if (lane == 0) {
+                    if (left > (uint64_t)SEG) atomicMin(&s_hi, (unsigned long long)hashes[pos + SEG - 1]);
+                    if (len) atomicOr(&s_live[s < CT ? 0 : 1], 1u);
+                }
+            }
+            __syncthreads();
+            if (s_live[0] == 0 || s_live[1] == 0) break;   // every row or every column exhausted
+            const uint64_t hi = s_hi;
+            // ---- how many staged hashes of each sketch are <= hi ----
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int s = wave * 8 + i;
+                const bool in0 = (uint32_t)(2 * lane) < have[i] && e0[i] <= hi;
+                const bool in1 = (uint32_t)(2 * lane + 1) < have[i] && e1[i] <= hi;
+                const uint32_t take = (uint32_t)__popcll(__ballot(in0)) + (uint32_t)__popcll(__ballot(in1));
+                if (lane == 0) { s_take[s] = take; s_pos[s] += take; }
+            }
+            __syncthreads();
+            // ---- the merge walk of minhash.rs:915-953 on the LDS-resident parts ----
+            {
+                const uint32_t na = s_take[r], nb = s_take[CT + c];
+                const uint64_t* A = s_seg[r];
+                const uint64_t* B = s_seg[CT + c];
+                uint32_t ia = 0, ib = 0;
+                while (ia < na && ib < nb) {
+                    const uint64_t a = A[ia], b = B[ib];
+                    const bool lt = a < b, gt = b < a;         // two 64-bit compares; equality is !(lt | gt)
+                    cnt += !(lt | gt);
+                    ia += !gt;
+                    ib += !lt;
+                }
+            }
+            // next round's staging overwrites s_seg: the barrier at the top of the loop orders it
+        }
+
+        const uint32_t row = row0 + r, col = col0 + c;
+        if (row < row_hi && col < n && cnt) {
+            const uint64_t idx = (uint64_t)(it.ty * CT + r) * n + col;
+            if (!symmetric) {
+                atomicAdd(&common[idx], cnt);
+            } else if (col >= row) {
+                atomicAdd(&common[idx], cnt);
+                if (symmetric == 1 && col != row) atomicAdd(&common[(uint64_t)(col - row_lo) * n + row], cnt);
+            }
         }
     }
 }
@@ -159,14 +244,54 @@ __global__ __launch_bounds__(256) void jaccard_from_counts_kernel(const uint32_t
     }
 }
 
+// Slice length: long enough that ordinary sketches (a few thousand hashes) are never cut when there
+// are plenty of tiles, shorter when the tile count alone cannot fill 256 CUs x 4 workgroups.
+static uint32_t pick_slice_len(uint64_t n_tiles) {
+    if (n_tiles >= 2048) return 8192;
+    if (n_tiles >= 512) return 2048;
+    return 1024;
+}
+
+size_t compare_workspace_bytes(uint32_t n_row_tiles, uint32_t n_col_tiles) {
+    const size_t tiles = (size_t)n_row_tiles * n_col_tiles;
+    return 256 + tiles * sizeof(WorkItem) * (CMP_ZMAX + 1);        // heavy (x ZMAX) + light (x 1) lists
+}
+
+static hipError_t compare_launch(const uint64_t* d_hashes, const uint64_t* d_offsets, uint32_t n, uint32_t row_lo,
+                                 uint32_t row_hi, int symmetric, uint32_t rb_first, uint32_t rb_stride,
+                                 uint32_t n_row_tiles, uint32_t* d_common, hipStream_t stream) {
+    const uint32_t n_col_tiles = (n + CT - 1) / CT;
+    const size_t tiles = (size_t)n_row_tiles * n_col_tiles;
+    hipError_t e = hipMemsetAsync(d_common, 0, (size_t)n_row_tiles * CT * n * sizeof(uint32_t), stream);
+    if (e != hipSuccess) return e;
+    void* ws = nullptr;
+    e = hipMallocAsync(&ws, compare_workspace_bytes(n_row_tiles, n_col_tiles), stream);   // stream-ordered scratch
+    if (e != hipSuccess) return e;
+    unsigned int* counters = (unsigned int*)ws;
+    WorkItem* heavy = (WorkItem*)((char*)ws + 256);
+    WorkItem* light = heavy + tiles * CMP_ZMAX;
+    e = hipMemsetAsync(counters, 0, 256, stream);
+    if (e == hipSuccess) {
+        const uint64_t work_tiles = tiles / (symmetric ? 2 : 1);
+        hipLaunchKernelGGL(compare_plan_kernel, dim3((unsigned)((tiles + 255) / 256)), dim3(256), 0, stream, d_offsets, n,
+                           row_lo, row_hi, symmetric, rb_first, rb_stride, n_row_tiles, n_col_tiles,
+                           pick_slice_len(work_tiles), heavy, light, counters);
+        const uint64_t cap = 256ull * 4;                         // 4 resident workgroups per CU (33 KiB LDS each)
+        const unsigned grid = (unsigned)(work_tiles + 1 < cap ? work_tiles + 1 : cap);
+        hipLaunchKernelGGL(compare_tile_kernel, dim3(grid < 1 ? 1 : grid), dim3(CMP_BLOCK), 0, stream, d_hashes,
+                           d_offsets, n, row_lo, row_hi, d_common, symmetric, rb_first, rb_stride, heavy, light, counters);
+        e = hipGetLastError();
+    }
+    const hipError_t e2 = hipFreeAsync(ws, stream);
+    return e != hipSuccess ? e : e2;
+}
+
 hipError_t compare_counts_launch(const uint64_t* d_hashes, const uint64_t* d_offsets, uint32_t n, uint32_t row_lo,
                                  uint32_t row_hi, uint32_t* d_common, hipStream_t stream) {
     if (row_hi <= row_lo || n == 0) return hipSuccess;
     const int symmetric = (row_lo == 0 && row_hi == n) ? 1 : 0;
-    dim3 grid((n + CT - 1) / CT, (row_hi - row_lo + CT - 1) / CT);
-    hipLaunchKernelGGL(compare_tile_kernel, grid, dim3(CMP_BLOCK), 0, stream, d_hashes, d_offsets, n, row_lo, row_hi,
-                       d_common, symmetric, 0u, 1u);
-    return hipGetLastError();
+    return compare_launch(d_hashes, d_offsets, n, row_lo, row_hi, symmetric, 0u, 1u, (row_hi - row_lo + CT - 1) / CT,
+                          d_common, stream);
 }
 
 // Sharded form: this launch owns the row tiles rb_first, rb_first + rb_stride, ... (rb_count of them)
@@ -174,10 +299,7 @@ hipError_t compare_counts_launch(const uint64_t* d_hashes, const uint64_t* d_off
 hipError_t compare_blocks_launch(const uint64_t* d_hashes, const uint64_t* d_offsets, uint32_t n, uint32_t rb_first,
                                  uint32_t rb_stride, uint32_t rb_count, uint32_t* d_common, hipStream_t stream) {
     if (rb_count == 0 || n == 0) return hipSuccess;
-    dim3 grid((n + CT - 1) / CT, rb_count);
-    hipLaunchKernelGGL(compare_tile_kernel, grid, dim3(CMP_BLOCK), 0, stream, d_hashes, d_offsets, n, 0u, n, d_common,
-                       2, rb_first, rb_stride);
-    return hipGetLastError();
+    return compare_launch(d_hashes, d_offsets, n, 0u, n, 2, rb_first, rb_stride, rb_count, d_common, stream);
 }
 
 __global__ __launch_bounds__(256) void symmetrize_kernel(uint32_t* __restrict__ m, uint32_t n) {

@@ -46,4 +46,11 @@ hipError_t symmetrize_launch(uint32_t* d_common, uint32_t n, hipStream_t stream)
 hipError_t jaccard_from_counts_launch(const uint32_t* d_common, const uint64_t* d_offsets, uint32_t n,
                                       uint32_t row_lo, uint32_t row_hi, double* d_out, hipStream_t stream);
 
+// ---- bitindex.hip (dense compare path) ---------------------------------------------------------
+hipError_t bitmap_build_launch(const uint64_t* d_hashes, const uint64_t* d_offsets, uint32_t n, const uint64_t* d_dict,
+                               uint64_t U, uint32_t* d_bits, uint32_t words_per_row, hipStream_t stream);
+// rows: 16-row tiles rb_first, rb_first + rb_stride, ... (rb_count); all columns; d_common [rb_count*16][n]
+hipError_t bitmatrix_launch(const uint32_t* d_bits, uint32_t words_per_row, uint32_t n, uint32_t rb_first,
+                            uint32_t rb_stride, uint32_t rb_count, uint32_t* d_common, hipStream_t stream);
+
 }  // namespace smg

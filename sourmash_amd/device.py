@@ -114,17 +114,59 @@ def pack_csr(sketches, device="cuda"):
     return hashes, torch.from_numpy(offsets).to(device)
 
 
-def compare_rows(hashes, offsets, row_lo=0, row_hi=None, want_jaccard=True, common=None, jaccard=None):
+class BitIndex:
+    """Dense form of a device CSR: one U-bit row per sketch over the collection's own hash dictionary
+    (smgpu_bitindex_*).  `BitIndex.build` returns None when the collection is too sparse for it."""
+
+    def __init__(self, ptr, n):
+        self._ptr, self.n = ptr, n
+
+    @classmethod
+    def build(cls, hashes, offsets):
+        torch = _torch()
+        n = offsets.numel() - 1
+        ptr = rustcall(lib.smgpu_bitindex_new, _ptr(hashes), _ptr(offsets), n, _stream(torch))
+        return cls(ptr, n) if ptr else None
+
+    @property
+    def universe(self):
+        return lib.smgpu_bitindex_universe(self._ptr)
+
+    def compare_tiles(self, first, stride, count, out=None):
+        "u32 counts for the 16-row tiles first, first+stride, ... (count of them), all columns"
+        torch = _torch()
+        if out is None:
+            out = torch.empty((count * 16, self.n), dtype=torch.int32, device="cuda")
+        rustcall(lib.smgpu_bitindex_compare_raw, self._ptr, first, stride, count, _ptr(out), _stream(torch))
+        return out
+
+    def __del__(self):
+        if getattr(self, "_ptr", None):
+            lib.smgpu_bitindex_free(self._ptr)
+            self._ptr = None
+
+
+def compare_rows(hashes, offsets, row_lo=0, row_hi=None, want_jaccard=True, common=None, jaccard=None, index=None):
     """common[(row_hi-row_lo), n] (int32 view of u32) and jaccard (float64) for a row block of the
-    all-pairs matrix of a device CSR.  Asynchronous on the current stream."""
+    all-pairs matrix of a device CSR.  Asynchronous on the current stream.
+
+    index: a BitIndex built for this CSR (dense collections) -> popcount path; None -> merge kernel."""
     torch = _torch()
     n = offsets.numel() - 1
     row_hi = n if row_hi is None else row_hi
     rows = row_hi - row_lo
-    if common is None:
-        common = torch.empty((rows, n), dtype=torch.int32, device=hashes.device)
     if want_jaccard and jaccard is None:
         jaccard = torch.empty((rows, n), dtype=torch.float64, device=hashes.device)
+    if index is not None and row_lo % 16 == 0:
+        count = (rows + 15) // 16
+        if common is None or common.shape[0] < count * 16:
+            common = torch.empty((count * 16, n), dtype=torch.int32, device=hashes.device)
+        index.compare_tiles(row_lo // 16, 1, count, out=common)
+        if want_jaccard:
+            rustcall(lib.smgpu_jaccard_raw, _ptr(common), _ptr(offsets), n, row_lo, row_hi, _ptr(jaccard), _stream(torch))
+        return common[:rows], (jaccard if want_jaccard else None)
+    if common is None:
+        common = torch.empty((rows, n), dtype=torch.int32, device=hashes.device)
     rustcall(lib.smgpu_compare_raw, _ptr(hashes), _ptr(offsets), n, row_lo, row_hi, _ptr(common),
              _ptr(jaccard) if want_jaccard else None, _stream(torch))
     return common, (jaccard if want_jaccard else None)

@@ -53,6 +53,7 @@ class DeviceBackend:
         self.torch, self.lib, self.rustcall = torch, lib, rustcall
         self.device = device if device is not None else torch.device("cuda", torch.cuda.current_device())
         self._ws = None
+        self._index, self._index_key = None, None
 
     # -- helpers --
     def _p(self, t):
@@ -73,10 +74,24 @@ class DeviceBackend:
         return self._ws
 
     # -- compare --
-    def compare_tiles(self, hashes, offsets, n, first, stride, count):
+    def compare_tiles(self, hashes, offsets, n, first, stride, count, method="auto"):
+        """counts for the owned 16-row tiles.  method: "merge" (LDS-tiled merge walk, upper triangle),
+        "bits" (bit rows + popcount, all columns) or "auto" (bits when the collection is dense enough)."""
         out = self.zeros((count * TILE, n), self.torch.int32)
-        self.rustcall(self.lib.smgpu_compare_blocks_raw, self._p(hashes), self._p(offsets), n, first, stride, count,
-                      self._p(out), self._s())
+        index = None
+        if method in ("auto", "bits"):
+            key = (hashes.data_ptr(), offsets.data_ptr(), n)
+            if self._index_key != key:
+                from .device import BitIndex
+                self._index, self._index_key = BitIndex.build(hashes, offsets), key
+            index = self._index
+            if index is None and method == "bits":
+                raise ValueError("collection too sparse for the bit-row path")
+        if index is not None:
+            index.compare_tiles(first, stride, count, out=out)
+        else:
+            self.rustcall(self.lib.smgpu_compare_blocks_raw, self._p(hashes), self._p(offsets), n, first, stride, count,
+                          self._p(out), self._s())
         return out
 
     def symmetrize(self, common, n):
