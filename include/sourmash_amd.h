@@ -222,6 +222,14 @@ bool smgpu_available(void);
  * byte outside ACGTacgt, e.g. '\n'; no NUL needed) into `ptr`. */
 void smgpu_minhash_add_buffer(SourmashKmerMinHash *ptr, const char *buf, uintptr_t len, bool force);
 
+/* The whole `sourmash sketch dna <file>` inner loop (command_sketch.py:697,746-768) in one call: a native
+ * FASTA / FASTQ (plain or gzip) reader strips headers and line breaks, streams 64 MiB chunks through
+ * pinned staging buffers to the GPU, and every sketch of the signature (all ksizes) is filled in the same
+ * pass.  force=True semantics (bytes outside ACGTacgt drop the k-mers covering them).  Returns the
+ * number of sequence bytes read; *n_records = number of records. */
+uint64_t smgpu_signature_add_file(SourmashSignature *ptr, const char *path, uint64_t *n_records);
+uint64_t smgpu_minhash_add_file(SourmashKmerMinHash *ptr, const char *path, uint64_t *n_records);
+
 /* Scratch size needed by smgpu_sketch_dna_raw for an output capacity. */
 uint64_t smgpu_sketch_workspace_bytes(uint64_t out_capacity);
 /* Device-resident sketching: d_seq[0,len) ASCII (any alignment) -> sorted unique

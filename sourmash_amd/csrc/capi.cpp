@@ -13,6 +13,7 @@
 #include <sstream>
 #include "../../include/sourmash_amd.h"
 #include "device_ctx.hpp"
+#include "ingest.hpp"
 #include "murmur3.hpp"
 #include "signature_host.hpp"
 
@@ -534,6 +535,28 @@ void smgpu_minhash_add_buffer(SourmashKmerMinHash* p, const char* buf, uintptr_t
     landing_void([&] {
         if (!buf && len) throw err_internal("null buffer");
         add_sequence_dna(*MH(p), (const uint8_t*)buf, len, force);
+    });
+}
+
+uint64_t smgpu_signature_add_file(SourmashSignature* p, const char* path, uint64_t* n_records) {
+    return landing<uint64_t>([&]() -> uint64_t {
+        if (!path) throw err_internal("null path");
+        std::vector<KmerMinHash*> mhs;
+        for (auto& mh : SIG(p)->sketches) mhs.push_back(&mh);
+        uint64_t recs = 0, bases = 0;
+        sketch_file_into(mhs, path, &recs, &bases);
+        if (n_records) *n_records = recs;
+        return bases;
+    });
+}
+uint64_t smgpu_minhash_add_file(SourmashKmerMinHash* p, const char* path, uint64_t* n_records) {
+    return landing<uint64_t>([&]() -> uint64_t {
+        if (!path) throw err_internal("null path");
+        std::vector<KmerMinHash*> mhs{MH(p)};
+        uint64_t recs = 0, bases = 0;
+        sketch_file_into(mhs, path, &recs, &bases);
+        if (n_records) *n_records = recs;
+        return bases;
     });
 }
 

@@ -236,7 +236,20 @@ def _add_buffer_to_signature(sig, buf):
 
 
 def sketch_file(path, param_str=DEFAULTS["dna"], *, name=None, check_sequence=False, singleton=False):
-    "`sourmash sketch dna -p <param_str> <path>` -> list of SourmashSignature."
+    """`sourmash sketch dna -p <param_str> <path>` -> list of SourmashSignature.
+
+    Default mode (one signature per file, force=True) runs the native streaming ingest
+    (smgpu_signature_add_file: C++ FASTA/FASTQ(.gz) reader -> pinned buffers -> GPU, every ksize in one
+    pass); --singleton and --check-sequence go record by record like the reference."""
+    if not singleton and not check_sequence:
+        params = ComputeParameters.from_param_str(param_str)
+        sig = SourmashSignature.from_params(params)
+        n_records = C.c_uint64(0)
+        rustcall(lib.smgpu_signature_add_file, sig._get_objptr(), str(path).encode("utf-8"), C.byref(n_records))
+        if name:
+            sig.name = name
+        sig.filename = str(path)
+        return [sig]
     recs = list(read_records(path))
     if name is None and not singleton and recs:
         name = ""

@@ -1,0 +1,113 @@
+"""GPU parity of the native FASTA/FASTQ(.gz) ingest path (smgpu_signature_add_file) against the
+oracle and the golden genome sketches.  Run with -m gpu."""
+import gzip
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import oracle
+from conftest import golden, ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def sm():
+    import torch  # noqa: F401
+    import sourmash_amd
+    assert sourmash_amd.gpu_available()
+    return sourmash_amd
+
+
+def _write_fasta(path, records, width=70, crlf=False, gz=False):
+    eol = "\r\n" if crlf else "\n"
+    text = "".join(f">{n}{eol}" + eol.join(s[i:i + width] for i in range(0, len(s), width)) + eol for n, s in records)
+    (gzip.open if gz else open)(path, "wb").write(text.encode())
+
+
+def _records(rng, n=7):
+    out = []
+    for i in range(n):
+        L = int(rng.integers(10, 40_000))
+        s = bytearray(rng.choice(np.frombuffer(b"ACGTacgt", dtype=np.uint8), size=L).tobytes())
+        for j in range(5, L, 501):
+            s[j] = ord("N")
+        out.append((f"rec{i} some description", s.decode()))
+    out.append(("short", "ACG"))
+    out.append(("empty", ""))
+    return out
+
+
+def _oracle_sig(records, k, scaled=0, num=0, abund=False):
+    mh = oracle.OracleMinHash(num, k, scaled=scaled, track_abundance=abund)
+    for _, s in records:
+        mh.add_sequence(s, force=True)
+    return mh
+
+
+def test_golden_genomes_through_native_ingest(sm):
+    from sourmash_amd.sketch import sketch_file
+    fa = golden("ecoli", "GCF_000005845.2_ASM584v2_genomic.fna.gz")
+    want = {s["ksize"]: s["md5sum"] for s in oracle.read_sig_json(fa + ".sig")}
+    sig, = sketch_file(fa, "k=21,k=31,k=51,scaled=1000")
+    assert {mh.ksize: mh.md5sum() for mh in sig.minhashes()} == want
+    assert sig.filename == fa
+    fa = golden("num", "genome-s10.fa.gz")                       # multi-record, num sketches
+    for w in [s for s in oracle.read_sig_json(fa + ".sig") if s["molecule"].lower() == "dna"]:
+        sig, = sketch_file(fa, f"k={w['ksize']},num={w['num']}")
+        assert sig.md5sum() == w["md5sum"]
+
+
+@pytest.mark.parametrize("crlf,gz", [(False, False), (True, False), (False, True)])
+def test_fasta_variants_vs_oracle(sm, tmp_path, crlf, gz):
+    from sourmash_amd.sketch import sketch_file
+    recs = _records(np.random.default_rng(3))
+    path = str(tmp_path / ("x.fa.gz" if gz else "x.fa"))
+    _write_fasta(path, recs, crlf=crlf, gz=gz)
+    sig, = sketch_file(path, "k=21,k=31,scaled=50,abund")
+    for mh in sig.minhashes():
+        want = _oracle_sig(recs, mh.ksize, scaled=50, abund=True)
+        assert np.array_equal(mh._mins_array(), want.mins), mh.ksize
+        assert list(mh.hashes.values()) == want.abunds.tolist()
+
+
+def test_fastq_and_chunk_boundaries(sm, tmp_path):
+    """Many tiny chunks (SMG_INGEST_CHUNK) so that records and k-mers straddle chunk boundaries; run in a
+    subprocess because the chunk size is read when the library first ingests."""
+    recs = _records(np.random.default_rng(5), n=5)
+    fq = str(tmp_path / "r.fastq")
+    with open(fq, "w") as fh:
+        for n, s in recs:
+            fh.write(f"@{n}\n{s}\n+\n{'I' * len(s)}\n")
+    fa = str(tmp_path / "r.fa")
+    _write_fasta(fa, recs, width=61)
+    code = f"""
+import sys, numpy as np
+sys.path.insert(0, {ROOT!r})
+import torch
+from sourmash_amd.sketch import sketch_file
+for path in ({fq!r}, {fa!r}):
+    sig, = sketch_file(path, "k=21,k=51,scaled=20,abund")
+    for mh in sig.minhashes():
+        np.save(path + f".k{{mh.ksize}}.npy", np.array([list(mh.hashes.keys()), list(mh.hashes.values())], dtype=np.uint64))
+    sig, = sketch_file(path, "k=31,num=300")
+    np.save(path + ".num.npy", sig.minhash._mins_array())
+"""
+    env = dict(os.environ, SMG_INGEST_CHUNK="1000")
+    subprocess.check_call([sys.executable, "-c", code], env=env)
+    for path in (fq, fa):
+        for k in (21, 51):
+            got = np.load(path + f".k{k}.npy")
+            want = _oracle_sig(recs, k, scaled=20, abund=True)
+            assert np.array_equal(got[0], want.mins), (path, k)
+            assert np.array_equal(got[1], want.abunds), (path, k)          # no k-mer hashed twice at a boundary
+        assert np.array_equal(np.load(path + ".num.npy"), _oracle_sig(recs, 31, num=300).mins)
+
+
+def test_missing_file_raises(sm):
+    from sourmash_amd.sketch import sketch_file
+    with pytest.raises(sm.exceptions.SourmashError):
+        sketch_file("/nonexistent/file.fa")
