@@ -21,6 +21,8 @@ def main():
         con = sqlite3.connect(path)
         cur = con.cursor()
         print(f"== {path}")
+        # (min/max are shown because one kernel name can cover launches of different sizes, e.g. the
+        #  1e9-byte CPU-baseline sample next to the 1e10-byte bench steps)
         rows = cur.execute("select name, count(*), sum(duration), avg(duration), min(duration), max(duration), "
                            "max(vgpr_count), max(sgpr_count), max(lds_size), max(grid_x), max(workgroup_x) "
                            "from kernels group by name order by sum(duration) desc").fetchall()

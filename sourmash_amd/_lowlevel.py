@@ -98,6 +98,12 @@ class _Lib:
 
     def _load(self):
         if self._cdll is None:
+            if not os.path.exists(LIBPATH) and os.path.exists("/opt/rocm/bin/hipcc"):
+                # first use in a fresh checkout: build the HIP library in-tree (same recipe as __graft_entry__.build)
+                import subprocess
+                import sys
+                print("sourmash_amd: building libsourmash_amd.so (make -C sourmash_amd/csrc) ...", file=sys.stderr)
+                subprocess.check_call(["make", "-C", os.path.join(_PKG, "csrc"), "-j8", "-s"])
             if not os.path.exists(LIBPATH):
                 raise ImportError(
                     f"{LIBPATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "

@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""End-to-end file -> sketch throughput of the native ingest path (GPU box; writes to /tmp)."""
+import os, sys, time, gzip
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+import oracle
+from sourmash_amd.sketch import sketch_file
+from sourmash_amd import device as smd
+
+n = int(float(sys.argv[1])) if len(sys.argv) > 1 else 1_000_000_000
+rec = 10_000_000
+seq = smd.synth_dna(n + n // rec, seed=42, record_len=rec).cpu().numpy()
+path = "/tmp/synth.fa"
+t0 = time.perf_counter()
+with open(path, "wb") as fh:
+    recs = bytes(seq).split(b"\n")
+    for i, r in enumerate(recs):
+        fh.write(b">synth_%d\n" % i)
+        a = np.frombuffer(r, dtype=np.uint8)
+        full = (len(a) // 80) * 80
+        if full:
+            lines = np.concatenate([a[:full].reshape(-1, 80), np.full((full // 80, 1), 10, dtype=np.uint8)], axis=1)
+            fh.write(lines.tobytes())
+        if len(a) > full:
+            fh.write(a[full:].tobytes() + b"\n")
+print(f"wrote {os.path.getsize(path) / 1e9:.2f} GB FASTA in {time.perf_counter() - t0:.1f} s")
+for p in ("k=31,scaled=1000", "k=21,k=31,k=51,scaled=1000"):
+    sketch_file(path, p)                      # warm (page cache, allocations)
+    t0 = time.perf_counter()
+    sig, = sketch_file(path, p)
+    dt = time.perf_counter() - t0
+    bases = sum(len(r) for r in recs)
+    print(f"{p}: {dt:.2f} s  {bases / dt / 1e9:.2f} Gbase/s end to end  ({len(sig.minhash)} hashes)")
+want = oracle.sketch_dna_bulk(seq[:200_000_000], 31, scaled=1000, nthreads=os.cpu_count())
+sk = smd.DeviceSketcher(31, 1000)
+print("device path matches oracle on 2e8 prefix:", bool(np.array_equal(sk.sketch(torch.from_numpy(seq[:200_000_000]).cuda()).cpu().numpy().view(np.uint64), want)))
