@@ -68,8 +68,11 @@ def main():
         sys.exit(2)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # SMG_BENCH_FORCE_COLLECTIVES=1 exercises the RCCL code path even with a single rank (1-GPU test boxes)
+    use_dist = world > 1 or os.environ.get("SMG_BENCH_FORCE_COLLECTIVES") == "1"
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import sourmash_amd as sm
@@ -88,7 +91,7 @@ def main():
     sk = smd.DeviceSketcher(ksize=args.ksize, scaled=args.scaled, seed=42, device=dev)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -107,7 +110,7 @@ def main():
     n_unique_local = int(hashes.numel())
     gather_ms = None
     n_unique_total = n_unique_local
-    if world > 1:
+    if use_dist:
         tg = time.perf_counter()
         sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
         dist.all_gather(sizes, torch.tensor([n_unique_local], dtype=torch.int64, device=dev))
@@ -246,7 +249,7 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu, "extra": extra,
         }
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 
