@@ -296,6 +296,33 @@ void smgpu_counter_get(const SmgpuCounter *ptr, uint64_t *counts_out);
 void smgpu_counter_set(SmgpuCounter *ptr, uint64_t index, uint64_t value);
 bool smgpu_counter_best(const SmgpuCounter *ptr, uint64_t *index, uint64_t *count);
 void smgpu_counter_consume(SmgpuCounter *ptr, const SourmashKmerMinHash *intersect);
+/* The whole min-set-cover loop of GatherDatabases (src/sourmash/search.py:877-949) from the counter's current
+ * state, every round on the GPU: winner index (order of smgpu_sketchset_new) and |intersect| per round into the
+ * host arrays; -> number of rounds.  threshold_hashes = ceil(threshold_bp / scaled) (search.py:15-37). */
+uint64_t smgpu_counter_gather(SmgpuCounter *ptr, uint64_t threshold_hashes, uint64_t *out_index, uint64_t *out_isect,
+                              uint64_t cap);
+
+/* The same loop over caller-owned device buffers (query: sorted unique u64; database: CSR shard whose rows have
+ * global indices index_base, index_base+1, ...).  new_raw inverts the shard against the query once (query hash ->
+ * rows holding it), so a round costs |I| postings walks instead of a pass over the database.
+ *   single GPU:  begin, run.
+ *   sharded:     begin, then per round  pick_raw (local best, packed (count << 32) | ~index, into d_key)
+ *                -> MAX all-reduce of d_key -> export_raw (stop rules; the owner writes [len, hashes...] of the
+ *                winning row into d_rowbuf[0,cap), everyone else zeros) -> SUM all-reduce of d_rowbuf ->
+ *                apply_raw; poll every few rounds.  Nothing in a round needs the host. */
+typedef struct SmgpuGather SmgpuGather;
+SmgpuGather *smgpu_gather_new_raw(const uint64_t *d_query, uint64_t nq, const uint64_t *d_hashes,
+                                  const uint64_t *d_offsets, uint64_t ndb, uint64_t index_base, void *stream);
+void smgpu_gather_free(SmgpuGather *ptr);
+uint64_t smgpu_gather_postings(const SmgpuGather *ptr);
+void smgpu_gather_counters_get(const SmgpuGather *ptr, uint64_t *counts_out, void *stream);
+void smgpu_gather_begin(SmgpuGather *ptr, uint64_t threshold_hashes, uint64_t max_rounds, void *stream);
+uint64_t smgpu_gather_run(SmgpuGather *ptr, uint64_t *out_index, uint64_t *out_isect, uint64_t cap, void *stream);
+void smgpu_gather_pick_raw(SmgpuGather *ptr, uint64_t *d_key, void *stream);
+void smgpu_gather_export_raw(SmgpuGather *ptr, const uint64_t *d_key, uint64_t *d_rowbuf, uint64_t cap, void *stream);
+void smgpu_gather_apply_raw(SmgpuGather *ptr, const uint64_t *d_rowbuf, void *stream);
+uint64_t smgpu_gather_poll(SmgpuGather *ptr, bool *done, void *stream);
+uint64_t smgpu_gather_results(SmgpuGather *ptr, uint64_t *out_index, uint64_t *out_isect, uint64_t cap, void *stream);
 
 /* Gather primitives (src/sourmash/index/__init__.py:735-909):
  *   overlap:  d_overlap[d] = |Q ∩ D_d| (op 0, CounterGather.add) or

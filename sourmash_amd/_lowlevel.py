@@ -32,7 +32,8 @@ _SCALARS = {
     "uintptr_t": C.c_size_t, "HashFunctions": C.c_uint32, "SourmashErrorCode": C.c_uint32,
     "SourmashStr": SourmashStr,
 }
-_OPAQUE = {"SourmashKmerMinHash", "SourmashSignature", "SourmashComputeParameters", "SmgpuSketchSet", "SmgpuCounter", "SmgpuBitIndex"}
+_OPAQUE = {"SourmashKmerMinHash", "SourmashSignature", "SourmashComputeParameters", "SmgpuSketchSet", "SmgpuCounter", "SmgpuBitIndex",
+           "SmgpuGather"}
 
 
 def _ctype(decl, is_arg=False):

@@ -736,17 +736,40 @@ struct SketchSet {
 };
 struct GatherCounter {
     const SketchSet* set = nullptr;
-    DevBuf counters, q, scal;
+    DevBuf q, list, scal;
+    uint64_t nq = 0;
+    GatherDev g;
     ~GatherCounter() {
-        if (counters.p) (void)hipFree(counters.p);
+        gather_destroy(g);
         if (q.p) (void)hipFree(q.p);
+        if (list.p) (void)hipFree(list.p);
         if (scal.p) (void)hipFree(scal.p);
     }
-    void upload(const KmerMinHash& mh, hipStream_t st) {
-        q.reserve(mh.size() * 8 + 16);
-        if (mh.size()) hip_check(hipMemcpyAsync(q.p, mh.mins.data(), mh.size() * 8, hipMemcpyHostToDevice, st), "H2D");
-    }
 };
+// raw variant: query and database are caller-owned device buffers (torch tensors)
+struct GatherRaw {
+    GatherDev g;
+    ~GatherRaw() { gather_destroy(g); }
+};
+
+// run the armed loop to exhaustion; -> number of results (host copies if out_* given)
+static uint64_t gather_drain(GatherDev& g, uint64_t* out_idx, uint64_t* out_isect, uint64_t cap, hipStream_t st) {
+    unsigned long long head[GS_SLOTS];
+    unsigned batch = 32;
+    for (;;) {
+        hip_check(gather_enqueue_rounds(g, batch, st), "gather rounds");
+        hip_check(hipMemcpyAsync(head, g.state, sizeof(head), hipMemcpyDeviceToHost, st), "D2H");
+        hip_check(hipStreamSynchronize(st), "sync");
+        if (head[GS_DONE]) break;
+        if (batch < 512) batch *= 2;
+    }
+    const uint64_t n = head[GS_ROUNDS];
+    const uint64_t m = n < cap ? n : cap;
+    if (m && out_idx) hip_check(hipMemcpyAsync(out_idx, g.out_idx, m * 8, hipMemcpyDeviceToHost, st), "D2H");
+    if (m && out_isect) hip_check(hipMemcpyAsync(out_isect, g.out_isect, m * 8, hipMemcpyDeviceToHost, st), "D2H");
+    hip_check(hipStreamSynchronize(st), "sync");
+    return n;
+}
 
 SmgpuSketchSet* smgpu_sketchset_new(const SourmashKmerMinHash* const* mhs, uintptr_t n) {
     return landing<SmgpuSketchSet*>([&]() -> SmgpuSketchSet* {
@@ -780,13 +803,18 @@ SmgpuCounter* smgpu_counter_new(const SmgpuSketchSet* set, const SourmashKmerMin
         hipStream_t st = ctx.stream();
         std::unique_ptr<GatherCounter> c(new GatherCounter());
         c->set = s;
-        c->counters.reserve(s->n * 8 + 16);
+        c->nq = MH(query)->size();
+        c->q.reserve(c->nq * 8 + 16);
         c->scal.reserve(64);
-        c->upload(*MH(query), st);
-        hip_check(hipMemsetAsync(c->counters.p, 0, s->n * 8 + 16, st), "memset");
-        hip_check(overlap_vector_launch(c->q.as<uint64_t>(), MH(query)->size(), s->hashes.as<uint64_t>(),
-                                        s->offsets.as<uint64_t>(), s->n, c->counters.as<unsigned long long>(), 0, st), "overlap");
-        hip_check(hipStreamSynchronize(st), "sync");
+        if (c->nq) hip_check(hipMemcpyAsync(c->q.p, MH(query)->mins.data(), c->nq * 8, hipMemcpyHostToDevice, st), "H2D");
+        c->g.Q = c->q.as<uint64_t>();
+        c->g.nq = c->nq;
+        c->g.hashes = s->hashes.as<uint64_t>();
+        c->g.offsets = s->offsets.as<uint64_t>();
+        c->g.ndb = s->n;
+        c->g.index_base = 0;
+        hip_check(gather_build(c->g, st), "gather index");        // postings + counters = |Q ∩ D_d| for every d
+        hip_check(gather_begin(c->g, 0, s->n ? s->n : 1, st), "gather arm");
         return reinterpret_cast<SmgpuCounter*>(c.release());
     });
 }
@@ -796,7 +824,7 @@ void smgpu_counter_get(const SmgpuCounter* p, uint64_t* out) {
         const GatherCounter* c = reinterpret_cast<const GatherCounter*>(p);
         DeviceCtx& ctx = DeviceCtx::get();
         std::lock_guard<std::mutex> g(ctx.mutex());
-        if (c->set->n) hip_check(hipMemcpyAsync(out, c->counters.p, c->set->n * 8, hipMemcpyDeviceToHost, ctx.stream()), "D2H");
+        if (c->set->n) hip_check(hipMemcpyAsync(out, c->g.counters, c->set->n * 8, hipMemcpyDeviceToHost, ctx.stream()), "D2H");
         hip_check(hipStreamSynchronize(ctx.stream()), "sync");
     });
 }
@@ -806,19 +834,19 @@ void smgpu_counter_set(SmgpuCounter* p, uint64_t index, uint64_t value) {
         if (index >= c->set->n) throw err_internal("counter index out of range");
         DeviceCtx& ctx = DeviceCtx::get();
         std::lock_guard<std::mutex> g(ctx.mutex());
-        hip_check(hipMemcpyAsync(c->counters.as<uint64_t>() + index, &value, 8, hipMemcpyHostToDevice, ctx.stream()), "H2D");
+        hip_check(hipMemcpyAsync(c->g.counters + index, &value, 8, hipMemcpyHostToDevice, ctx.stream()), "H2D");
         hip_check(hipStreamSynchronize(ctx.stream()), "sync");
     });
 }
 bool smgpu_counter_best(const SmgpuCounter* p, uint64_t* index, uint64_t* count) {
     return landing<bool>([&]() -> bool {
-        const GatherCounter* c = reinterpret_cast<const GatherCounter*>(p);
+        GatherCounter* c = const_cast<GatherCounter*>(reinterpret_cast<const GatherCounter*>(p));
         DeviceCtx& ctx = DeviceCtx::get();
         std::lock_guard<std::mutex> g(ctx.mutex());
         hipStream_t st = ctx.stream();
-        unsigned long long* d_best = const_cast<GatherCounter*>(c)->scal.as<unsigned long long>();
+        unsigned long long* d_best = c->scal.as<unsigned long long>();
         hip_check(hipMemsetAsync(d_best, 0, 8, st), "memset");
-        hip_check(argmax_launch(c->counters.as<unsigned long long>(), c->set->n, 0, d_best, st), "argmax");
+        hip_check(argmax_launch(c->g.counters, c->set->n, 0, d_best, st), "argmax");
         unsigned long long key = 0;
         hip_check(hipMemcpyAsync(&key, d_best, 8, hipMemcpyDeviceToHost, st), "D2H");
         hip_check(hipStreamSynchronize(st), "sync");
@@ -831,14 +859,116 @@ bool smgpu_counter_best(const SmgpuCounter* p, uint64_t* index, uint64_t* count)
 void smgpu_counter_consume(SmgpuCounter* p, const SourmashKmerMinHash* intersect) {
     landing_void([&] {
         GatherCounter* c = reinterpret_cast<GatherCounter*>(p);
-        if (MH(intersect)->size() == 0) return;
+        const uint64_t ni = MH(intersect)->size();
+        if (ni == 0) return;
         DeviceCtx& ctx = DeviceCtx::get();
         std::lock_guard<std::mutex> g(ctx.mutex());
         hipStream_t st = ctx.stream();
-        c->upload(*MH(intersect), st);
-        hip_check(overlap_vector_launch(c->q.as<uint64_t>(), MH(intersect)->size(), c->set->hashes.as<uint64_t>(),
-                                        c->set->offsets.as<uint64_t>(), c->set->n, c->counters.as<unsigned long long>(), 1, st), "consume");
+        c->list.reserve((ni + 1) * 8 + 16);
+        uint64_t* d_list = c->list.as<uint64_t>();
+        hip_check(hipMemcpyAsync(d_list, &ni, 8, hipMemcpyHostToDevice, st), "H2D");
+        hip_check(hipMemcpyAsync(d_list + 1, MH(intersect)->mins.data(), ni * 8, hipMemcpyHostToDevice, st), "H2D");
+        // the postings cover hashes of the original query only; an intersect holding anything else (a caller
+        // outside the peek/consume protocol) takes the streaming kernel over the whole database instead
+        unsigned long long* d_hits = c->scal.as<unsigned long long>() + 1;
+        hip_check(hipMemsetAsync(d_hits, 0, 32, st), "memset");
+        hip_check(pair_match_launch(d_list + 1, ni, c->g.Q, c->nq, nullptr, nullptr, nullptr, d_hits, 0, st), "pair_match");
+        unsigned long long hits = 0;
+        hip_check(hipMemcpyAsync(&hits, d_hits, 8, hipMemcpyDeviceToHost, st), "D2H");
         hip_check(hipStreamSynchronize(st), "sync");
+        if (hits == ni)
+            hip_check(gather_consume_list(c->g, d_list, st), "consume");
+        else
+            hip_check(overlap_vector_launch(d_list + 1, ni, c->set->hashes.as<uint64_t>(), c->set->offsets.as<uint64_t>(),
+                                            c->set->n, c->g.counters, 1, st), "consume");
+        hip_check(hipStreamSynchronize(st), "sync");
+    });
+}
+uint64_t smgpu_counter_gather(SmgpuCounter* p, uint64_t threshold_hashes, uint64_t* out_index, uint64_t* out_isect,
+                              uint64_t cap) {
+    return landing<uint64_t>([&]() -> uint64_t {
+        GatherCounter* c = reinterpret_cast<GatherCounter*>(p);
+        DeviceCtx& ctx = DeviceCtx::get();
+        std::lock_guard<std::mutex> g(ctx.mutex());
+        hipStream_t st = ctx.stream();
+        hip_check(gather_begin(c->g, threshold_hashes, c->set->n ? c->set->n : 1, st), "gather arm");
+        return gather_drain(c->g, out_index, out_isect, cap, st);
+    });
+}
+
+// ---- raw gather over caller-owned device buffers ----------------------------------------------------------------
+SmgpuGather* smgpu_gather_new_raw(const uint64_t* d_query, uint64_t nq, const uint64_t* d_hashes, const uint64_t* d_offsets,
+                                  uint64_t ndb, uint64_t index_base, void* stream) {
+    return landing<SmgpuGather*>([&]() -> SmgpuGather* {
+        std::unique_ptr<GatherRaw> r(new GatherRaw());
+        r->g.Q = d_query;
+        r->g.nq = nq;
+        r->g.hashes = d_hashes;
+        r->g.offsets = d_offsets;
+        r->g.ndb = ndb;
+        r->g.index_base = index_base;
+        hip_check(gather_build(r->g, (hipStream_t)stream), "gather index");
+        return reinterpret_cast<SmgpuGather*>(r.release());
+    });
+}
+void smgpu_gather_free(SmgpuGather* p) { delete reinterpret_cast<GatherRaw*>(p); }
+uint64_t smgpu_gather_postings(const SmgpuGather* p) { return reinterpret_cast<const GatherRaw*>(p)->g.npairs; }
+void smgpu_gather_counters_get(const SmgpuGather* p, uint64_t* out, void* stream) {
+    landing_void([&] {
+        const GatherDev& g = reinterpret_cast<const GatherRaw*>(p)->g;
+        if (g.ndb) hip_check(hipMemcpyAsync(out, g.counters, g.ndb * 8, hipMemcpyDeviceToHost, (hipStream_t)stream), "D2H");
+        hip_check(hipStreamSynchronize((hipStream_t)stream), "sync");
+    });
+}
+void smgpu_gather_begin(SmgpuGather* p, uint64_t threshold_hashes, uint64_t max_rounds, void* stream) {
+    landing_void([&] {
+        hip_check(gather_begin(reinterpret_cast<GatherRaw*>(p)->g, threshold_hashes, max_rounds, (hipStream_t)stream),
+                  "gather arm");
+    });
+}
+uint64_t smgpu_gather_run(SmgpuGather* p, uint64_t* out_index, uint64_t* out_isect, uint64_t cap, void* stream) {
+    return landing<uint64_t>([&]() -> uint64_t {
+        return gather_drain(reinterpret_cast<GatherRaw*>(p)->g, out_index, out_isect, cap, (hipStream_t)stream);
+    });
+}
+void smgpu_gather_pick_raw(SmgpuGather* p, uint64_t* d_key, void* stream) {
+    landing_void([&] {
+        hip_check(gather_pick(reinterpret_cast<GatherRaw*>(p)->g, (unsigned long long*)d_key, 0, (hipStream_t)stream), "pick");
+    });
+}
+void smgpu_gather_export_raw(SmgpuGather* p, const uint64_t* d_key, uint64_t* d_rowbuf, uint64_t cap, void* stream) {
+    landing_void([&] {
+        hip_check(gather_export(reinterpret_cast<GatherRaw*>(p)->g, (const unsigned long long*)d_key, d_rowbuf, cap,
+                                (hipStream_t)stream), "export");
+    });
+}
+void smgpu_gather_apply_raw(SmgpuGather* p, const uint64_t* d_rowbuf, void* stream) {
+    landing_void([&] { hip_check(gather_apply(reinterpret_cast<GatherRaw*>(p)->g, d_rowbuf, (hipStream_t)stream), "apply"); });
+}
+uint64_t smgpu_gather_poll(SmgpuGather* p, bool* done, void* stream) {
+    return landing<uint64_t>([&]() -> uint64_t {
+        GatherDev& g = reinterpret_cast<GatherRaw*>(p)->g;
+        unsigned long long head[GS_SLOTS];
+        hip_check(hipMemcpyAsync(head, g.state, sizeof(head), hipMemcpyDeviceToHost, (hipStream_t)stream), "D2H");
+        hip_check(hipStreamSynchronize((hipStream_t)stream), "sync");
+        if (done) *done = head[GS_DONE] != 0;
+        return head[GS_ROUNDS];
+    });
+}
+uint64_t smgpu_gather_results(SmgpuGather* p, uint64_t* out_index, uint64_t* out_isect, uint64_t cap, void* stream) {
+    return landing<uint64_t>([&]() -> uint64_t {
+        GatherDev& g = reinterpret_cast<GatherRaw*>(p)->g;
+        hipStream_t st = (hipStream_t)stream;
+        unsigned long long head[GS_SLOTS];
+        hip_check(hipMemcpyAsync(head, g.state, sizeof(head), hipMemcpyDeviceToHost, st), "D2H");
+        hip_check(hipStreamSynchronize(st), "sync");
+        const uint64_t n = head[GS_ROUNDS], m = n < cap ? n : cap;
+        if (m) {
+            hip_check(hipMemcpyAsync(out_index, g.out_idx, m * 8, hipMemcpyDeviceToHost, st), "D2H");
+            hip_check(hipMemcpyAsync(out_isect, g.out_isect, m * 8, hipMemcpyDeviceToHost, st), "D2H");
+            hip_check(hipStreamSynchronize(st), "sync");
+        }
+        return n;
     });
 }
 

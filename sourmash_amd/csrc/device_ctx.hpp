@@ -14,6 +14,7 @@
 #include <vector>
 #include "device_api.hpp"
 #include "minhash_host.hpp"
+#include "gather_api.hpp"
 #include "pair_api.hpp"
 #include "smg_errors.hpp"
 

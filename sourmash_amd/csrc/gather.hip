@@ -1,0 +1,416 @@
+// gather.hip -- min-set-cover gather with every round resident on the GPU.
+//
+// What the reference does per round (src/sourmash/index/__init__.py:735-909 CounterGather, driven by
+// src/sourmash/search.py:877-949 GatherDatabases.__next__):
+//   peek     pick the dataset with the largest remaining overlap (ties: first inserted), stop when the overlap is
+//            below threshold_bp / scaled hashes (search.py:15-37) or the query is exhausted;
+//   I        = current query ∩ match;     current query -= match;
+//   consume  for every remaining dataset d: counter[d] -= |I ∩ D_d| (drop at 0).
+// consume is the expensive line: the reference walks the whole database every round.  Here the database is
+// inverted once against the query (hash position -> rows containing it, a CSR of u32 row ids), so a round touches
+// only the postings of the hashes in I: total work over a whole gather is sum_d |Q ∩ D_d| counter decrements, the
+// same number the reference spends on round 0 alone.  One round = three small kernels (partial arg-max, final
+// arg-max + stop rules + bookkeeping, apply); the host enqueues rounds in batches and only looks at a done flag,
+// so there is no host round trip per round.  Every kernel is a no-op once the flag is set.
+//
+// Multi-GPU (database sharded by dataset, query replicated): the same kernels, with the 8-byte packed winner
+// all-reduced (MAX) between pick and export, and the winner's row all-reduced (SUM of zeros + one copy) between
+// export and apply -- see sourmash_amd/parallel.py.
+#include <hip/hip_runtime.h>
+#include <cstring>
+#include <rocprim/device/device_scan.hpp>
+#include "gather_api.hpp"
+
+namespace smg {
+
+namespace {
+
+constexpr uint32_t NONE32 = 0xffffffffu;
+
+// first-level table over the sorted query: bucket b = x >> shift covers Q[T[b], T[b+1])
+struct QIndex {
+    const uint64_t* Q;
+    uint64_t nq;
+    const uint32_t* T;
+    uint32_t shift;
+    uint64_t qmax;
+};
+
+__device__ __forceinline__ uint32_t q_find(const QIndex& qi, uint64_t x) {
+    if (x > qi.qmax) return NONE32;
+    const uint64_t b = x >> qi.shift;
+    uint32_t lo = qi.T[b], hi = qi.T[b + 1];
+    while (lo < hi) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (qi.Q[mid] < x) lo = mid + 1; else hi = mid;
+    }
+    return (lo < qi.nq && qi.Q[lo] == x) ? lo : NONE32;
+}
+
+__global__ __launch_bounds__(256) void qtable_kernel(const uint64_t* __restrict__ Q, uint64_t nq, uint32_t shift,
+                                                     uint32_t n_buckets, uint32_t* __restrict__ T) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b > n_buckets) return;
+    if (b == n_buckets) { T[b] = (uint32_t)nq; return; }
+    const uint64_t x = (uint64_t)b << shift;
+    uint64_t lo = 0, hi = nq;
+    while (lo < hi) {
+        const uint64_t mid = (lo + hi) >> 1;
+        if (Q[mid] < x) lo = mid + 1; else hi = mid;
+    }
+    T[b] = (uint32_t)lo;
+}
+
+// pass 1 over the database: qpos of every element, postings histogram, initial counters (CounterGather.add)
+__global__ __launch_bounds__(256) void build_count_kernel(QIndex qi, const uint64_t* __restrict__ hashes,
+                                                          const uint64_t* __restrict__ offsets, uint64_t ndb,
+                                                          uint32_t* __restrict__ qpos, unsigned long long* post_cnt,
+                                                          unsigned long long* __restrict__ counters) {
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    for (uint64_t d = wave; d < ndb; d += n_waves) {
+        const uint64_t lo = offsets[d], hi = offsets[d + 1];
+        unsigned long long cnt = 0;
+        for (uint64_t i = lo + lane; i < hi; i += 64) {
+            const uint32_t j = q_find(qi, hashes[i]);
+            qpos[i] = j;
+            if (j != NONE32) {
+                atomicAdd(&post_cnt[j], 1ull);
+                ++cnt;
+            }
+        }
+        for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off);
+        if (lane == 0) counters[d] = cnt;
+    }
+}
+
+// pass 2: scatter the row ids into the postings
+__global__ __launch_bounds__(256) void build_fill_kernel(const uint32_t* __restrict__ qpos,
+                                                         const uint64_t* __restrict__ offsets, uint64_t ndb,
+                                                         unsigned long long* cursor, uint32_t* __restrict__ post_rows) {
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    for (uint64_t d = wave; d < ndb; d += n_waves) {
+        const uint64_t lo = offsets[d], hi = offsets[d + 1];
+        for (uint64_t i = lo + lane; i < hi; i += 64) {
+            const uint32_t j = qpos[i];
+            if (j != NONE32) post_rows[atomicAdd(&cursor[j], 1ull)] = (uint32_t)d;
+        }
+    }
+}
+
+__device__ __forceinline__ unsigned long long wave_max(unsigned long long k) {
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long o = __shfl_down(k, off);
+        k = o > k ? o : k;
+    }
+    return k;
+}
+
+// packed arg-max with the reference tie-break (highest count, then lowest global index)
+__global__ __launch_bounds__(256) void pick_partial_kernel(const unsigned long long* __restrict__ counters, uint64_t ndb,
+                                                           uint64_t index_base, const unsigned long long* state,
+                                                           unsigned long long* __restrict__ partials) {
+    if (state[GS_DONE]) return;
+    __shared__ unsigned long long red[4];
+    unsigned long long k = 0;
+    for (uint64_t d = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; d < ndb; d += (uint64_t)gridDim.x * blockDim.x) {
+        const unsigned long long c = counters[d];
+        if (c) {
+            const unsigned long long key = (c << 32) | (0xffffffffull & ~(unsigned long long)(index_base + d));
+            k = key > k ? key : k;
+        }
+    }
+    k = wave_max(k);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = k;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) k = red[w] > k ? red[w] : k;
+        partials[blockIdx.x] = k;
+    }
+}
+
+__device__ __forceinline__ void record_pending(unsigned long long* state, uint64_t* out_idx, uint64_t* out_isect) {
+    if (state[GS_PENDING]) {
+        const unsigned long long r = state[GS_ROUNDS], acc = state[GS_ACC];
+        out_idx[r] = 0xffffffffull & ~state[GS_KEY];
+        out_isect[r] = acc;
+        state[GS_QLEN] -= acc;
+        state[GS_ACC] = 0;
+        state[GS_ROUNDS] = r + 1;
+        state[GS_PENDING] = 0;
+        if (r + 1 >= state[GS_MAXR]) state[GS_DONE] = 1;
+    }
+}
+
+// search.py:15-37 + index/__init__.py:817-861: stop when nothing overlaps, the query is exhausted, the threshold
+// is unattainable (more hashes than the query has left) or the best overlap is below it
+__device__ __forceinline__ void stop_rules(unsigned long long* state, unsigned long long key) {
+    const unsigned long long count = key >> 32, qlen = state[GS_QLEN], thr = state[GS_THR];
+    if (key == 0 || qlen == 0 || qlen < thr || count < thr) state[GS_DONE] = 1;
+    else state[GS_PENDING] = 1;
+}
+
+__global__ __launch_bounds__(256) void pick_final_kernel(const unsigned long long* __restrict__ partials, unsigned n_part,
+                                                         unsigned long long* state, uint64_t* out_idx,
+                                                         uint64_t* out_isect, unsigned long long* key_out,
+                                                         int check_stop) {
+    __shared__ unsigned long long red[4];
+    if (threadIdx.x == 0) record_pending(state, out_idx, out_isect);
+    __syncthreads();
+    if (state[GS_DONE]) {
+        if (threadIdx.x == 0 && key_out) *key_out = 0;
+        return;
+    }
+    unsigned long long k = 0;
+    for (unsigned i = threadIdx.x; i < n_part; i += blockDim.x) k = partials[i] > k ? partials[i] : k;
+    k = wave_max(k);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = k;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) k = red[w] > k ? red[w] : k;
+        state[GS_KEY] = k;
+        if (key_out) *key_out = k;
+        if (check_stop) stop_rules(state, k);
+    }
+}
+
+__global__ void adopt_key_kernel(unsigned long long* state, const unsigned long long* key) {
+    if (state[GS_DONE]) return;
+    state[GS_KEY] = *key;
+    stop_rules(state, *key);
+}
+
+__global__ __launch_bounds__(256) void export_row_kernel(const unsigned long long* state,
+                                                         const uint64_t* __restrict__ hashes,
+                                                         const uint64_t* __restrict__ offsets, uint64_t ndb,
+                                                         uint64_t index_base, uint64_t* __restrict__ rowbuf, uint64_t cap) {
+    if (state[GS_DONE]) return;
+    const uint64_t gidx = 0xffffffffull & ~state[GS_KEY];
+    const bool mine = gidx >= index_base && gidx < index_base + ndb;
+    uint64_t lo = 0, len = 0;
+    if (mine) {
+        lo = offsets[gidx - index_base];
+        len = offsets[gidx - index_base + 1] - lo;
+        if (len + 1 > cap) len = cap - 1;                      // cannot happen when cap covers the longest row
+    }
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cap; i += (uint64_t)gridDim.x * blockDim.x)
+        rowbuf[i] = i == 0 ? len : (i <= len ? hashes[lo + i - 1] : 0);
+}
+
+// one lane looks one hash of the row up in the query; the wave then walks the postings of its hits together
+template <bool GATE>
+__global__ __launch_bounds__(256) void apply_kernel(QIndex qi, uint8_t* alive, const uint64_t* __restrict__ post_off,
+                                                    const uint32_t* __restrict__ post_rows,
+                                                    unsigned long long* counters, unsigned long long* state,
+                                                    const uint64_t* __restrict__ rowbuf,
+                                                    const uint64_t* __restrict__ hashes,
+                                                    const uint64_t* __restrict__ offsets, uint64_t index_base) {
+    if (GATE && state[GS_DONE]) return;
+    const uint64_t* row;
+    uint64_t len;
+    if (rowbuf) {
+        len = rowbuf[0];
+        row = rowbuf + 1;
+    } else {
+        const uint64_t d = (0xffffffffull & ~state[GS_KEY]) - index_base;
+        row = hashes + offsets[d];
+        len = offsets[d + 1] - offsets[d];
+    }
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    for (uint64_t base = wave * 64; base < len; base += n_waves * 64) {
+        const uint64_t i = base + lane;
+        uint32_t j = NONE32;
+        if (i < len) {
+            j = q_find(qi, row[i]);
+            if (GATE && j != NONE32) {
+                if (alive[j]) alive[j] = 0;                    // row hashes are distinct: no two lanes share j
+                else j = NONE32;
+            }
+        }
+        unsigned long long hits = __ballot(j != NONE32);
+        if (GATE) {
+            if (lane == 0 && hits) atomicAdd(&state[GS_ACC], (unsigned long long)__popcll(hits));
+        } else {
+            // protocol path: the hashes leave the uncovered set as well, so a later fused run starts from the truth
+            bool fresh = false;
+            if (j != NONE32 && alive[j]) {
+                alive[j] = 0;
+                fresh = true;
+            }
+            const unsigned long long gone = __ballot(fresh);
+            if (lane == 0 && gone) atomicAdd(&state[GS_QLEN], 0ull - (unsigned long long)__popcll(gone));
+        }
+        while (hits) {
+            const int src = __ffsll((long long)hits) - 1;
+            hits &= hits - 1;
+            const uint32_t jq = __shfl(j, src);
+            const uint64_t lo = post_off[jq], hi = post_off[jq + 1];
+            for (uint64_t p = lo + lane; p < hi; p += 64) {
+                unsigned long long* c = &counters[post_rows[p]];
+                if (GATE) {
+                    atomicAdd(c, ~0ull);                       // invariant: counters[d] = |row_d ∩ uncovered| >= 1 here
+                } else {
+                    const unsigned long long old = atomicAdd(c, ~0ull);
+                    if (old == 0) atomicAdd(c, 1ull);          // saturate (counter already dropped)
+                }
+            }
+        }
+    }
+}
+
+unsigned blocks_for_rows(uint64_t ndb) {
+    const uint64_t b = (ndb + 3) / 4;
+    return (unsigned)(b < 1 ? 1 : (b > 16384 ? 16384 : b));
+}
+
+}  // namespace
+
+static QIndex qindex_of(const GatherDev& g) { return QIndex{g.Q, g.nq, g.q_table, g.q_shift, g.q_max}; }
+
+#define SMG_TRY(expr)                      \
+    do {                                   \
+        hipError_t e_ = (expr);            \
+        if (e_ != hipSuccess) return e_;   \
+    } while (0)
+
+void gather_destroy(GatherDev& g) {
+    void* owned[] = {g.q_table, g.alive, g.post_off, g.post_rows, g.counters, g.state, g.partials, g.out_idx, g.out_isect};
+    for (void* p : owned)
+        if (p) (void)hipFree(p);
+    g = GatherDev();
+}
+
+hipError_t gather_build(GatherDev& g, hipStream_t stream) {
+    if (g.nq >= NONE32) return hipErrorInvalidValue;             // query positions are u32
+    if (g.ndb >= NONE32) return hipErrorInvalidValue;            // row ids are u32
+    const uint64_t nq1 = g.nq + 1;
+    SMG_TRY(hipMalloc(&g.state, GS_SLOTS * 8));
+    SMG_TRY(hipMalloc(&g.partials, GATHER_PICK_BLOCKS * 8));
+    SMG_TRY(hipMalloc(&g.counters, (g.ndb + 1) * 8));
+    SMG_TRY(hipMalloc(&g.alive, g.nq + 16));
+    SMG_TRY(hipMalloc(&g.post_off, nq1 * 8));
+    SMG_TRY(hipMemsetAsync(g.state, 0, GS_SLOTS * 8, stream));
+    SMG_TRY(hipMemsetAsync(g.counters, 0, (g.ndb + 1) * 8, stream));
+    SMG_TRY(hipMemsetAsync(g.alive, 1, g.nq + 16, stream));
+    SMG_TRY(hipMemcpyAsync(&g.state[GS_QLEN], &g.nq, 8, hipMemcpyHostToDevice, stream));
+    // database size and the largest query hash decide the table geometry
+    uint64_t total = 0;
+    g.q_max = 0;
+    if (g.ndb) SMG_TRY(hipMemcpyAsync(&total, g.offsets + g.ndb, 8, hipMemcpyDeviceToHost, stream));
+    if (g.nq) SMG_TRY(hipMemcpyAsync(&g.q_max, g.Q + g.nq - 1, 8, hipMemcpyDeviceToHost, stream));
+    SMG_TRY(hipStreamSynchronize(stream));
+    uint32_t bucket_bits = 0;
+    while (bucket_bits < 24 && (4ull << bucket_bits) < g.nq) ++bucket_bits;      // ~4 query hashes per bucket
+    uint32_t value_bits = 0;
+    while (value_bits < 64 && (g.q_max >> value_bits)) ++value_bits;
+    g.q_shift = value_bits > bucket_bits ? value_bits - bucket_bits : 0;
+    g.q_buckets = (uint32_t)(g.q_max >> g.q_shift) + 1;
+    SMG_TRY(hipMalloc(&g.q_table, ((uint64_t)g.q_buckets + 1) * 4));
+    hipLaunchKernelGGL(qtable_kernel, dim3((g.q_buckets + 256) / 256), dim3(256), 0, stream, g.Q, g.nq, g.q_shift,
+                       g.q_buckets, g.q_table);
+    SMG_TRY(hipGetLastError());
+    if (g.ndb == 0 || total == 0 || g.nq == 0) {
+        SMG_TRY(hipMemsetAsync(g.post_off, 0, nq1 * 8, stream));
+        g.npairs = 0;
+        return hipStreamSynchronize(stream);
+    }
+    // scratch: qpos of every database element, the histogram / cursors, scan temp
+    uint32_t* qpos = nullptr;
+    unsigned long long* post_cnt = nullptr;
+    SMG_TRY(hipMallocAsync((void**)&qpos, total * 4, stream));
+    SMG_TRY(hipMallocAsync((void**)&post_cnt, nq1 * 8, stream));
+    SMG_TRY(hipMemsetAsync(post_cnt, 0, nq1 * 8, stream));
+    const QIndex qi = qindex_of(g);
+    hipLaunchKernelGGL(build_count_kernel, dim3(blocks_for_rows(g.ndb)), dim3(256), 0, stream, qi, g.hashes, g.offsets,
+                       g.ndb, qpos, post_cnt, g.counters);
+    SMG_TRY(hipGetLastError());
+    size_t scan_bytes = 0;
+    SMG_TRY(rocprim::exclusive_scan(nullptr, scan_bytes, (uint64_t*)post_cnt, g.post_off, (uint64_t)0, (size_t)nq1,
+                                    rocprim::plus<uint64_t>(), stream));
+    void* scan_tmp = nullptr;
+    SMG_TRY(hipMallocAsync(&scan_tmp, scan_bytes + 256, stream));
+    SMG_TRY(rocprim::exclusive_scan(scan_tmp, scan_bytes, (uint64_t*)post_cnt, g.post_off, (uint64_t)0, (size_t)nq1,
+                                    rocprim::plus<uint64_t>(), stream));
+    SMG_TRY(hipMemcpyAsync(&g.npairs, g.post_off + g.nq, 8, hipMemcpyDeviceToHost, stream));
+    SMG_TRY(hipMemcpyAsync(post_cnt, g.post_off, nq1 * 8, hipMemcpyDeviceToDevice, stream));   // cursors
+    SMG_TRY(hipStreamSynchronize(stream));
+    SMG_TRY(hipMalloc(&g.post_rows, (g.npairs + 4) * 4));
+    hipLaunchKernelGGL(build_fill_kernel, dim3(blocks_for_rows(g.ndb)), dim3(256), 0, stream, qpos, g.offsets, g.ndb,
+                       post_cnt, g.post_rows);
+    SMG_TRY(hipGetLastError());
+    SMG_TRY(hipFreeAsync(scan_tmp, stream));
+    SMG_TRY(hipFreeAsync(post_cnt, stream));
+    SMG_TRY(hipFreeAsync(qpos, stream));
+    return hipStreamSynchronize(stream);
+}
+
+hipError_t gather_begin(GatherDev& g, uint64_t thr_hashes, uint64_t max_rounds, hipStream_t stream) {
+    if (max_rounds == 0) max_rounds = 1;
+    if (max_rounds > g.out_cap) {
+        SMG_TRY(hipStreamSynchronize(stream));
+        if (g.out_idx) (void)hipFree(g.out_idx);
+        if (g.out_isect) (void)hipFree(g.out_isect);
+        g.out_idx = g.out_isect = nullptr;
+        SMG_TRY(hipMalloc(&g.out_idx, max_rounds * 8));
+        SMG_TRY(hipMalloc(&g.out_isect, max_rounds * 8));
+        g.out_cap = max_rounds;
+    }
+    // rounds restart at 0; the uncovered set, its size and the counters carry over
+    unsigned long long head[GS_SLOTS] = {0};
+    SMG_TRY(hipMemcpyAsync(head, g.state, GS_SLOTS * 8, hipMemcpyDeviceToHost, stream));
+    SMG_TRY(hipStreamSynchronize(stream));
+    const unsigned long long qlen = head[GS_QLEN];
+    memset(head, 0, sizeof(head));
+    head[GS_QLEN] = qlen;
+    head[GS_THR] = thr_hashes;
+    head[GS_MAXR] = max_rounds;
+    SMG_TRY(hipMemcpyAsync(g.state, head, GS_SLOTS * 8, hipMemcpyHostToDevice, stream));
+    return hipStreamSynchronize(stream);                          // `head` is on this stack frame
+}
+
+hipError_t gather_pick(GatherDev& g, unsigned long long* d_key_out, int check_stop, hipStream_t stream) {
+    const uint64_t want = (g.ndb + 1023) / 1024;
+    const unsigned n_part = (unsigned)(want < 1 ? 1 : (want > GATHER_PICK_BLOCKS ? GATHER_PICK_BLOCKS : want));
+    hipLaunchKernelGGL(pick_partial_kernel, dim3(n_part), dim3(256), 0, stream, g.counters, g.ndb, g.index_base, g.state,
+                       g.partials);
+    hipLaunchKernelGGL(pick_final_kernel, dim3(1), dim3(256), 0, stream, g.partials, n_part, g.state, g.out_idx,
+                       g.out_isect, d_key_out, check_stop);
+    return hipGetLastError();
+}
+
+hipError_t gather_export(GatherDev& g, const unsigned long long* d_key, uint64_t* d_rowbuf, uint64_t cap,
+                         hipStream_t stream) {
+    if (cap == 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(adopt_key_kernel, dim3(1), dim3(1), 0, stream, g.state, d_key);
+    const uint64_t b = (cap + 255) / 256;
+    hipLaunchKernelGGL(export_row_kernel, dim3((unsigned)(b > 1024 ? 1024 : b)), dim3(256), 0, stream, g.state, g.hashes,
+                       g.offsets, g.ndb, g.index_base, d_rowbuf, cap);
+    return hipGetLastError();
+}
+
+hipError_t gather_apply(GatherDev& g, const uint64_t* d_rowbuf, hipStream_t stream) {
+    hipLaunchKernelGGL(apply_kernel<true>, dim3(64), dim3(256), 0, stream, qindex_of(g), g.alive, g.post_off,
+                       g.post_rows, g.counters, g.state, d_rowbuf, g.hashes, g.offsets, g.index_base);
+    return hipGetLastError();
+}
+
+hipError_t gather_consume_list(GatherDev& g, const uint64_t* d_list, hipStream_t stream) {
+    hipLaunchKernelGGL(apply_kernel<false>, dim3(64), dim3(256), 0, stream, qindex_of(g), g.alive, g.post_off,
+                       g.post_rows, g.counters, g.state, d_list, g.hashes, g.offsets, g.index_base);
+    return hipGetLastError();
+}
+
+hipError_t gather_enqueue_rounds(GatherDev& g, unsigned rounds, hipStream_t stream) {
+    for (unsigned r = 0; r < rounds; ++r) {
+        SMG_TRY(gather_pick(g, nullptr, 1, stream));
+        SMG_TRY(gather_apply(g, nullptr, stream));
+    }
+    return hipSuccess;
+}
+
+}  // namespace smg

@@ -1,0 +1,68 @@
+// Device-resident min-set-cover gather (gather.hip).  Raw device pointers; owns its index and counters.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+namespace smg {
+
+// slots of the 16 x u64 device state block
+enum GatherSlot {
+    GS_KEY = 0,      // packed winner of the round in flight: (count << 32) | (0xffffffff & ~global index)
+    GS_DONE = 1,     // 1 once a stop rule fired
+    GS_ROUNDS = 2,   // results recorded so far
+    GS_QLEN = 3,     // hashes of the query still uncovered
+    GS_ACC = 4,      // |I| of the round in flight
+    GS_PENDING = 5,  // a round was applied and is not recorded yet
+    GS_THR = 6,      // minimum overlap in hashes (ceil(threshold_bp / scaled))
+    GS_MAXR = 7,     // maximum number of results
+    GS_SLOTS = 16
+};
+
+struct GatherDev {
+    // borrowed (must outlive the object)
+    const uint64_t* Q = nullptr;        // sorted unique query hashes
+    uint64_t nq = 0;
+    const uint64_t* hashes = nullptr;   // CSR database shard
+    const uint64_t* offsets = nullptr;
+    uint64_t ndb = 0, index_base = 0;
+    // owned
+    uint32_t* q_table = nullptr;        // [q_buckets + 1] first-level table over Q: bucket b = x >> q_shift
+    uint32_t q_shift = 0, q_buckets = 1;
+    uint64_t q_max = 0;                 // Q[nq - 1]
+    uint8_t* alive = nullptr;           // [nq] 1 while the query hash is uncovered
+    uint64_t* post_off = nullptr;       // [nq + 1] postings of query hash j: post_rows[post_off[j] .. post_off[j+1])
+    uint32_t* post_rows = nullptr;      // local row ids
+    uint64_t npairs = 0;
+    unsigned long long* counters = nullptr;   // [ndb] |row_d ∩ uncovered query|
+    unsigned long long* state = nullptr;      // [GS_SLOTS]
+    unsigned long long* partials = nullptr;   // [GATHER_PICK_BLOCKS]
+    uint64_t* out_idx = nullptr;        // [out_cap] global index of the round's winner
+    uint64_t* out_isect = nullptr;      // [out_cap] |I| of the round
+    uint64_t out_cap = 0;
+};
+
+constexpr unsigned GATHER_PICK_BLOCKS = 256;
+
+// Build the inverted index and the initial counters (one-off; synchronises the stream once to size the postings).
+hipError_t gather_build(GatherDev& g, hipStream_t stream);
+void gather_destroy(GatherDev& g);
+// Arm the loop: thresholds, result capacity (reallocated if too small), state reset except alive/counters.
+hipError_t gather_begin(GatherDev& g, uint64_t thr_hashes, uint64_t max_rounds, hipStream_t stream);
+// Record the previous round (if one is pending), then the local best -> state[GS_KEY] and *d_key_out (may be null).
+// check_stop != 0: also evaluate the stop rules on that key (single-GPU loop).
+hipError_t gather_pick(GatherDev& g, unsigned long long* d_key_out, int check_stop, hipStream_t stream);
+// Multi-GPU: adopt the all-reduced key, evaluate the stop rules, and let the owner write [len, hashes...] of the
+// winning row into d_rowbuf[0, cap) (zeros elsewhere; every other rank writes zeros only).
+hipError_t gather_export(GatherDev& g, const unsigned long long* d_key, uint64_t* d_rowbuf, uint64_t cap,
+                         hipStream_t stream);
+// Apply the round: I = row ∩ uncovered query; uncovered -= I; counters[d] -= |I ∩ row_d| through the postings.
+// d_rowbuf == nullptr: the winner of state[GS_KEY] is read from the local CSR.
+hipError_t gather_apply(GatherDev& g, const uint64_t* d_rowbuf, hipStream_t stream);
+// CounterGather.consume for a caller-provided list ([len, hashes...] on device, every hash a member of Q):
+// counters[d] -= |list ∩ row_d| (saturating at 0), and the hashes leave the uncovered set.
+hipError_t gather_consume_list(GatherDev& g, const uint64_t* d_list, hipStream_t stream);
+// Enqueue `rounds` rounds of pick(check) + apply on one GPU (kernels are no-ops once GS_DONE is set).
+hipError_t gather_enqueue_rounds(GatherDev& g, unsigned rounds, hipStream_t stream);
+
+}  // namespace smg

@@ -12,6 +12,7 @@ What changes underneath: the collection lives in HBM as one CSR (`SketchSet`), s
 Results (which signatures, which order, which numbers) are those of the reference.
 """
 import ctypes as C
+import math
 from collections import namedtuple
 
 import numpy as np
@@ -64,6 +65,14 @@ class _DeviceCounter(RustObject):
 
     def set(self, index, value):
         self._methodcall(lib.smgpu_counter_set, index, value)
+
+    def gather(self, threshold_hashes=0):
+        "Every remaining round of the min-set-cover loop on the GPU -> (winner indices, |intersect| per round)."
+        n = max(len(self._set), 1)
+        idx, isect = np.zeros(n, dtype=np.uint64), np.zeros(n, dtype=np.uint64)
+        k = self._methodcall(lib.smgpu_counter_gather, int(threshold_hashes), idx.ctypes.data_as(C.c_void_p),
+                             isect.ctypes.data_as(C.c_void_p), n)
+        return idx[:k], isect[:k]
 
 
 class LinearIndex:
@@ -358,7 +367,19 @@ class CounterGather:
     # ---- batch extension: the whole min-set-cover loop ---------------------------------------------------
     def gather_all(self, threshold_bp=0):
         """Run gather to exhaustion; -> list of (md5, |intersect|) in rank order.  Same decisions as
-        GatherDatabases over this single counter, without building result objects."""
+        GatherDatabases over this single counter, without building result objects.  When every sketch shares
+        the query's scaled the whole loop is one native call (smgpu_counter_gather); otherwise it goes round
+        by round through peek/consume."""
+        if not self.siglist:
+            return []
+        scaled = self.orig_query_mh.scaled
+        if all(ss.minhash.scaled == scaled for ss in self.siglist.values()):
+            self.query_started = 1
+            dev, order = self._device()
+            # search.py:15-37: stop below threshold_bp / scaled hashes; integer counts compare against its ceiling
+            thr = math.ceil(float(threshold_bp) / scaled) if threshold_bp else 0
+            idx, isect = dev.gather(thr)
+            return [(order[int(i)], int(c)) for i, c in zip(idx, isect)]
         out = []
         query_mh = self.orig_query_mh.to_mutable()
         while query_mh:

@@ -11,8 +11,10 @@ Only the two places where the path has a real exchange use a collective (SURVEY.
   gather (BASELINE config C5)   the database is sharded by dataset; query, counters and the min-set-cover
       loop are replicated.  Per round: local arg-max packed as (count << 32) | ~global_index, ONE u64
       MAX all-reduce (this also implements the reference's tie-break: highest count, then lowest index),
-      the owner broadcasts the winning sketch (<= a few thousand u64), every rank intersects it with its
-      copy of the query and updates its own counters.  The stop test is deterministic and replicated.
+      the owner's copy of the winning sketch reaches everyone through a SUM all-reduce (zeros elsewhere, a
+      few thousand u64), every rank intersects it with its copy of the uncovered query and walks its own
+      postings to update its counters.  The stop test is deterministic and replicated; no step of a round
+      needs the host, which only polls a done flag every few rounds.
 
 The numerical work is behind a small `backend` interface.  DeviceBackend (the product) drives the HIP
 kernels through the raw C-ABI on torch CUDA tensors.  The distributed control flow itself is
@@ -20,6 +22,7 @@ backend-agnostic, which is what lets tests/test_parallel_gloo.py run these very 
 world_size 2 over gloo on CPU tensors (there the test injects an oracle-backed backend).
 """
 import ctypes as C
+import math
 
 TILE = 16   # rows per compare tile (csrc/compare.hip CT)
 
@@ -41,6 +44,63 @@ def tiles_for_rank(n, world, rank):
     n_tiles = (n + TILE - 1) // TILE
     count = (n_tiles - rank + world - 1) // world if n_tiles > rank else 0
     return rank, world, count
+
+
+class _DeviceGatherState:
+    "smgpu_gather_* over torch tensors: the per-rank state of a sharded gather (counters, postings, uncovered set)."
+
+    def __init__(self, backend, query, nq, hashes, offsets, ndb, index_base):
+        self.b, self.lib, self.rustcall = backend, backend.lib, backend.rustcall
+        self._keep = (query, hashes, offsets)            # borrowed by the native object
+        self._ptr = self.rustcall(self.lib.smgpu_gather_new_raw, backend._p(query), nq, backend._p(hashes),
+                                  backend._p(offsets), ndb, index_base, backend._s())
+        self._cap = 1
+
+    def __del__(self):
+        if getattr(self, "_ptr", None):
+            self.lib.smgpu_gather_free(self._ptr)
+            self._ptr = None
+
+    def begin(self, threshold_hashes, max_rounds):
+        self._cap = max(int(max_rounds), 1)
+        self.rustcall(self.lib.smgpu_gather_begin, self._ptr, int(threshold_hashes), self._cap, self.b._s())
+
+    def pick(self, key):
+        self.rustcall(self.lib.smgpu_gather_pick_raw, self._ptr, self.b._p(key), self.b._s())
+
+    def export(self, key, rowbuf):
+        self.rustcall(self.lib.smgpu_gather_export_raw, self._ptr, self.b._p(key), self.b._p(rowbuf), rowbuf.numel(),
+                      self.b._s())
+
+    def apply(self, rowbuf):
+        self.rustcall(self.lib.smgpu_gather_apply_raw, self._ptr, self.b._p(rowbuf), self.b._s())
+
+    def poll(self):
+        done = C.c_bool(False)
+        rounds = self.rustcall(self.lib.smgpu_gather_poll, self._ptr, C.byref(done), self.b._s())
+        return int(rounds), bool(done.value)
+
+    def _fetch(self, fn):
+        import numpy as np
+        idx, isect = np.zeros(self._cap, dtype=np.uint64), np.zeros(self._cap, dtype=np.uint64)
+        n = self.rustcall(fn, self._ptr, idx.ctypes.data_as(C.c_void_p), isect.ctypes.data_as(C.c_void_p), self._cap,
+                          self.b._s())
+        return [(int(i), int(c)) for i, c in zip(idx[:n], isect[:n])]
+
+    def results(self):
+        return self._fetch(self.lib.smgpu_gather_results)
+
+    def run(self):
+        "single GPU: every round enqueued back to back, the host only polls the done flag"
+        return self._fetch(self.lib.smgpu_gather_run)
+
+    def counters(self):
+        "remaining overlap of every local dataset (host copy)"
+        import numpy as np
+        ndb = self._keep[2].numel() - 1
+        out = np.zeros(max(ndb, 1), dtype=np.uint64)
+        self.rustcall(self.lib.smgpu_gather_counters_get, self._ptr, out.ctypes.data_as(C.c_void_p), self.b._s())
+        return out[:ndb]
 
 
 class DeviceBackend:
@@ -103,6 +163,10 @@ class DeviceBackend:
         return out
 
     # -- gather --
+    def gather_state(self, query, nq, hashes, offsets, ndb, index_base):
+        "Invert the shard against the query; -> step object (pick / export / apply / poll / results / run)."
+        return _DeviceGatherState(self, query, nq, hashes, offsets, ndb, index_base)
+
     def overlaps(self, query, nq, hashes, offsets, ndb, counters, op):
         self.rustcall(self.lib.smgpu_overlap_raw, self._p(query), nq, self._p(hashes), self._p(offsets), ndb,
                       self._p(counters), op, self._s())
@@ -171,62 +235,52 @@ def unpack_key(key):
 
 
 def gather_distributed(query, nq, shard_hashes, shard_offsets, n_shard, index_base, threshold_bp, scaled, backend,
-                       group=None, max_rounds=None):
+                       group=None, max_rounds=None, stepwise=False):
     """Min-set-cover gather over a dataset-sharded database.
 
     query: sorted u64 hashes (int64 bit patterns) replicated on every rank; shard_*: this rank's CSR of
     n_shard sketches whose global indices start at index_base.  Returns [(global index, |intersect|)],
-    identical on every rank and identical to the single-process result (ties -> lowest global index)."""
+    identical on every rank and identical to the single-process result (ties -> lowest global index).
+
+    Every rank inverts its shard against the query once (backend.gather_state).  A round is then
+        pick    local best, packed (count << 32) | ~index          -> MAX all-reduce (8 bytes)
+        export  stop rules; the owner writes [len, hashes...]      -> SUM all-reduce (one row; zeros elsewhere)
+        apply   I = row ∩ uncovered query; counters -= postings(I)
+    all of it enqueued without a host round trip; the host polls a done flag every few rounds (rounds enqueued
+    past the end are no-ops on every rank alike).  One rank without `stepwise` runs the fused native loop."""
     dist = _dist()
     rank, world = world_info(group)
     torch = backend.torch if hasattr(backend, "torch") else __import__("torch")
-    counters = backend.zeros((max(n_shard, 1),), torch.int64)
-    backend.overlaps(query, nq, shard_hashes, shard_offsets, n_shard, counters, 0)        # CounterGather.add
-    # one-off layout exchange: who owns which global indices, and the longest sketch anywhere
+    state = backend.gather_state(query, nq, shard_hashes, shard_offsets, n_shard, index_base)
+    # search.py:15-37: the float threshold threshold_bp / scaled, compared with integer counts -> its ceiling
+    thr = math.ceil(float(threshold_bp) / scaled) if threshold_bp else 0
     host_off = shard_offsets.cpu()
     longest = int((host_off[1:] - host_off[:-1]).max().item()) if n_shard else 0
-    layout = backend.zeros((3,), torch.int64)
-    layout[0], layout[1], layout[2] = index_base, n_shard, longest
-    if world > 1:
-        layouts = [backend.zeros((3,), torch.int64) for _ in range(world)]
-        dist.all_gather(layouts, layout, group=group)
-        layouts = [tuple(int(v) for v in t.tolist()) for t in layouts]
-    else:
-        layouts = [(index_base, n_shard, longest)]
-    max_len = max(t[2] for t in layouts)
-    results = []
-    cur, ncur = query, nq
-    while max_rounds is None or len(results) < max_rounds:
-        if ncur == 0:
+    layout_max = backend.zeros((1,), torch.int64)
+    layout_sum = backend.zeros((1,), torch.int64)
+    layout_max[0], layout_sum[0] = longest, n_shard
+    if world > 1:                                          # one-off: longest row anywhere, number of datasets
+        dist.all_reduce(layout_max, op=dist.ReduceOp.MAX, group=group)
+        dist.all_reduce(layout_sum, op=dist.ReduceOp.SUM, group=group)
+    total = int(layout_sum.item())
+    cap = 1 + max(int(layout_max.item()), 1)
+    state.begin(thr, min(max_rounds, total) if max_rounds is not None else total)
+    if world == 1 and not stepwise:
+        return state.run()
+    key = backend.zeros((1,), torch.int64)
+    rowbuf = backend.zeros((cap,), torch.int64)
+    batch = 8
+    while True:
+        for _ in range(batch):
+            state.pick(key)
+            if world > 1:
+                dist.all_reduce(key, op=dist.ReduceOp.MAX, group=group)        # collective 1: the winner
+            state.export(key, rowbuf)
+            if world > 1:
+                dist.all_reduce(rowbuf, op=dist.ReduceOp.SUM, group=group)     # collective 2: its hashes
+            state.apply(rowbuf)
+        _, done = state.poll()
+        if done:
             break
-        n_threshold_hashes = 0.0
-        if threshold_bp:                                           # search.py:15-37, float arithmetic as in Python
-            n_threshold_hashes = float(threshold_bp) / scaled
-            if n_threshold_hashes / ncur > 1.0:
-                break
-        best = backend.argmax(counters, n_shard, index_base)       # local winner, packed with the tie-break
-        if world > 1:
-            dist.all_reduce(best, op=dist.ReduceOp.MAX, group=group)   # collective 1 of the round: 8 bytes
-        key = int(best.item())
-        if key == 0:
-            break
-        count, gidx = unpack_key(key)
-        if count < n_threshold_hashes:
-            break
-        # collective 2 of the round: the owner broadcasts [len, hashes...] of the winning sketch
-        owner = next(r for r, (base, cnt, _) in enumerate(layouts) if base <= gidx < base + cnt)
-        msg = backend.zeros((1 + max(max_len, 1),), torch.int64)
-        if owner == rank:
-            lo, hi = int(host_off[gidx - index_base].item()), int(host_off[gidx - index_base + 1].item())
-            msg[0] = hi - lo
-            msg[1:1 + hi - lo] = shard_hashes[lo:hi]
-        if world > 1:
-            src = dist.get_global_rank(group, owner) if group is not None else owner
-            dist.broadcast(msg, src=src, group=group)
-        m = int(msg[0].item())
-        row = msg[1:1 + max(m, 1)]
-        isect, ni = backend.select(cur, ncur, row, m, invert=False)    # I = Q ∩ match
-        results.append((gidx, ni))
-        backend.overlaps(isect, ni, shard_hashes, shard_offsets, n_shard, counters, 1)   # consume
-        cur, ncur = backend.select(cur, ncur, row, m, invert=True)     # Q <- Q minus the whole match
-    return results
+        batch = min(batch * 2, 128)
+    return state.results()

@@ -64,3 +64,58 @@ def test_gather_world1_device_loop(be):
     c, g = parallel.unpack_key(key)
     want = [oracle.intersection_size(qh, d)[0] for d in dbh[lo:hi]]
     assert c == max(want) and g == lo + int(np.argmax(want))
+
+
+def test_gather_step_protocol_and_emulated_shards(be):
+    """The sharded round (pick -> MAX -> export -> SUM -> apply) with the real kernels: once on one state
+    (stepwise=True), once on three states sharing this GPU whose 'all-reduces' are plain torch ops."""
+    import torch
+    from sourmash_amd import device as smd, parallel
+    from sourmash_amd.synth import synth_gather
+    qh, dbh = synth_gather(n_query=50_000, n_db=900, db_size=700)
+    dbh[400] = dbh[2].copy()                                     # tie across shards: lowest global index wins
+    dbh[17] = np.zeros(0, dtype=np.uint64)                       # an empty sketch
+    dbh[18] = np.array([5], dtype=np.uint64)                     # nothing in common with the query
+    q = torch.from_numpy(qh.view(np.int64).copy()).cuda()
+    fh, foff = oracle.make_csr(dbh)
+    h, off = smd.pack_csr(dbh)
+    for thr_bp in (0, 30_000):
+        want = oracle.gather(qh, fh, foff, threshold_bp=thr_bp, scaled=1000)
+        assert parallel.gather_distributed(q, len(qh), h, off, len(dbh), 0, thr_bp, 1000, be, stepwise=True) == want
+        assert parallel.gather_distributed(q, len(qh), h, off, len(dbh), 0, thr_bp, 1000, be, max_rounds=7) == want[:7]
+    # three shards, one GPU
+    bounds = [(0, 250), (250, 610), (610, 900)]
+    shards = [smd.pack_csr(dbh[lo:hi]) for lo, hi in bounds]
+    states = [be.gather_state(q, len(qh), sh, so, hi - lo, lo) for (sh, so), (lo, hi) in zip(shards, bounds)]
+    want_counts = np.array([oracle.intersection_size(qh, d)[0] for d in dbh], dtype=np.uint64)
+    assert np.array_equal(np.concatenate([s.counters() for s in states]), want_counts)
+    cap = 1 + max(len(d) for d in dbh)
+    thr_bp = 30_000
+    want = oracle.gather(qh, fh, foff, threshold_bp=thr_bp, scaled=1000)
+    for s in states:
+        s.begin(int(np.ceil(thr_bp / 1000)), len(dbh))
+    keys = [be.zeros((1,), torch.int64) for _ in states]
+    bufs = [be.zeros((cap,), torch.int64) for _ in states]
+    done = False
+    while not done:
+        for _ in range(16):
+            for s, k in zip(states, keys):
+                s.pick(k)
+            gkey = torch.stack(keys).max(dim=0).values               # the MAX all-reduce
+            for s, b in zip(states, bufs):
+                s.export(gkey, b)
+            grow = torch.stack(bufs).sum(dim=0)                      # the SUM all-reduce
+            for s in states:
+                s.apply(grow)
+        polls = [s.poll() for s in states]
+        assert len({p for p in polls}) == 1                          # replicated, deterministic state
+        done = polls[0][1]
+    for s in states:
+        assert s.results() == want
+    # the counters every shard ends with are the true remaining overlaps
+    covered = set()
+    for gidx, _ in want:
+        covered.update(int(x) for x in dbh[gidx])
+    left = np.array([x for x in qh if int(x) not in covered], dtype=np.uint64)
+    want_left = np.array([oracle.intersection_size(left, d)[0] for d in dbh], dtype=np.uint64)
+    assert np.array_equal(np.concatenate([s.counters() for s in states]), want_left)

@@ -65,30 +65,74 @@ class OracleBackend:
         np.fill_diagonal(j, 1.0)
         return torch.from_numpy(j)
 
-    def overlaps(self, query, nq, hashes, offsets, ndb, counters, op):
-        q, h, off = self._u64(query, nq), self._u64(hashes), self._u64(offsets)
-        cnt = counters.numpy()
-        for d in range(ndb):
-            if op == 1 and cnt[d] == 0:
-                continue
-            c, _ = oracle.intersection_size(q, h[off[d]:off[d + 1]])
-            cnt[d] = c if op == 0 else max(0, cnt[d] - c)
+    def gather_state(self, query, nq, hashes, offsets, ndb, index_base):
+        return OracleGatherState(self._u64(query, nq), self._u64(hashes), self._u64(offsets), ndb, index_base)
 
-    def argmax(self, counters, ndb, index_base):
-        cnt = counters.numpy()[:ndb]
+
+class OracleGatherState:
+    """CPU stand-in for the native per-rank gather state (same steps, plain numpy sets): counters by direct
+    intersection with the uncovered query, i.e. the textbook CounterGather rather than the postings walk."""
+
+    def __init__(self, q, h, off, ndb, index_base):
+        self.rows = [h[off[d]:off[d + 1]].copy() for d in range(ndb)]
+        self.base, self.uncovered = index_base, set(int(x) for x in q)
+        self.cnt = np.array([len(self.uncovered.intersection(int(x) for x in r)) for r in self.rows], dtype=np.int64)
+        self.done, self.pending, self.out, self.key, self.acc = False, False, [], 0, 0
+
+    def begin(self, thr, max_rounds):
+        self.thr, self.maxr, self.done, self.pending, self.out = thr, max(max_rounds, 1), False, False, []
+
+    def _record(self):
+        if self.pending:
+            self.out.append((parallel.unpack_key(self.key)[1], self.acc))
+            self.pending = False
+            if len(self.out) >= self.maxr:
+                self.done = True
+
+    def pick(self, key):
+        self._record()
         best = 0
-        for d in range(ndb):
-            if cnt[d]:
-                best = max(best, parallel.pack_key(cnt[d], index_base + d))
-        return torch.tensor([best], dtype=torch.int64)
+        if not self.done:
+            for d, c in enumerate(self.cnt):
+                if c:
+                    best = max(best, parallel.pack_key(int(c), self.base + d))
+        key[0] = best
 
-    def select(self, a, na, b, nb, invert):
-        x, y = self._u64(a, na), self._u64(b, nb)
-        keep = ~np.isin(x, y) if invert else np.isin(x, y)
-        out = x[keep]
-        t = torch.zeros(max(na, 1), dtype=torch.int64)
-        t[:len(out)] = torch.from_numpy(out.view(np.int64).copy())
-        return t, len(out)
+    def export(self, key, rowbuf):
+        if self.done:
+            return
+        self.key = int(key[0])
+        count = self.key >> 32
+        if self.key == 0 or not self.uncovered or len(self.uncovered) < self.thr or count < self.thr:
+            self.done = True
+            return
+        self.pending = True
+        rowbuf.zero_()
+        gidx = parallel.unpack_key(self.key)[1]
+        if self.base <= gidx < self.base + len(self.rows):
+            row = self.rows[gidx - self.base]
+            rowbuf[0] = len(row)
+            rowbuf[1:1 + len(row)] = torch.from_numpy(row.view(np.int64).copy())
+
+    def apply(self, rowbuf):
+        if self.done:
+            return
+        n = int(rowbuf[0])
+        isect = self.uncovered.intersection(int(x) for x in rowbuf[1:1 + n].numpy().view(np.uint64))
+        self.acc = len(isect)
+        self.uncovered -= isect
+        for d, r in enumerate(self.rows):
+            if self.cnt[d]:
+                self.cnt[d] -= len(isect.intersection(int(x) for x in r))
+
+    def poll(self):
+        return len(self.out), self.done
+
+    def results(self):
+        return list(self.out)
+
+    def run(self):
+        raise AssertionError("single-rank fused loop is a device feature; the gloo tests run the step protocol")
 
 
 def _csr(sketches):
