@@ -1,0 +1,147 @@
+"""Gather (BASELINE config C5) at full size on one GPU: inputs generated in HBM, index build and the
+min-set-cover loop timed separately, results checked through size-independent properties with an
+independent kernel (the streaming overlap kernel of pair_ops.hip, which shares no code with the postings walk).
+
+    python tools/bench_gather.py                      # C5: 1e6-hash query vs 100,000 x ~5,000
+    python tools/bench_gather.py --ndb 12500          # one GPU's shard of the 8-GPU layout
+
+Generator (device-side variant of sourmash_amd/synth.py: synth_gather; same construction, hashes drawn as
+(splitmix64(x) >>> 1) mod m so that torch's signed int64 arithmetic can express it): query = nq distinct
+hashes below max_hash(scaled=1000); every database sketch takes half of its hashes from the query and half
+from a private stream."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from sourmash_amd import parallel  # noqa: E402
+
+MAX_HASH_1000 = 18446744073709552
+
+
+def _lsr(x, s):
+    return (x >> s) & ((1 << (64 - s)) - 1)
+
+
+def splitmix63(x):
+    "splitmix64 finaliser on int64 tensors (wrapping), top bit dropped -> non-negative"
+    def c(v):
+        return v - (1 << 64) if v >= (1 << 63) else v
+    x = x + c(0x9E3779B97F4A7C15)
+    x = (x ^ _lsr(x, 30)) * c(0xBF58476D1CE4E5B9)
+    x = (x ^ _lsr(x, 27)) * c(0x94D049BB133111EB)
+    x = x ^ _lsr(x, 31)
+    return _lsr(x, 1)
+
+
+def make_inputs(nq, ndb, dbsize, dev, seed=777, chunk=10_000):
+    q = torch.unique(splitmix63(torch.arange(int(nq * 1.01) + 16, device=dev, dtype=torch.int64) + seed) % (MAX_HASH_1000 + 1))
+    q = q[q > 0][:nq].contiguous()
+    half = dbsize // 2
+    rows, lens = [], []
+    col = torch.arange(half, device=dev, dtype=torch.int64)
+    for lo in range(0, ndb, chunk):
+        d = torch.arange(lo, min(lo + chunk, ndb), device=dev, dtype=torch.int64)[:, None]
+        shared = q[splitmix63((d << 32) ^ col[None, :] ^ seed) % len(q)]
+        priv = splitmix63((1 << 62) + (d << 33) + col[None, :] + seed) % MAX_HASH_1000 + 1
+        x = torch.sort(torch.cat([shared, priv], dim=1), dim=1).values
+        keep = torch.ones_like(x, dtype=torch.bool)
+        keep[:, 1:] = x[:, 1:] != x[:, :-1]
+        rows.append(x[keep])
+        lens.append(keep.sum(dim=1))
+    hashes = torch.cat(rows)
+    offsets = torch.zeros(ndb + 1, dtype=torch.int64, device=dev)
+    offsets[1:] = torch.cumsum(torch.cat(lens), 0)
+    return q, hashes, offsets
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--nq", type=int, default=1_000_000)
+    ap.add_argument("--ndb", type=int, default=100_000)
+    ap.add_argument("--dbsize", type=int, default=5000)
+    ap.add_argument("--threshold-bp", type=int, default=50_000)
+    ap.add_argument("--stepwise", action="store_true", help="time the sharded step protocol (one rank) as well")
+    args = ap.parse_args()
+    dev = torch.device("cuda", 0)
+    be = parallel.DeviceBackend(dev)
+    t0 = time.perf_counter()
+    q, hashes, offsets = make_inputs(args.nq, args.ndb, args.dbsize, dev)
+    torch.cuda.synchronize()
+    gen_s = time.perf_counter() - t0
+    nq, ndb, total = len(q), args.ndb, int(offsets[-1].item())
+
+    def timed_build():
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        st = be.gather_state(q, nq, hashes, offsets, ndb, 0)
+        torch.cuda.synchronize()
+        return st, time.perf_counter() - t
+
+    st, _ = timed_build()                                  # warm (allocator, code objects)
+    del st
+    st, build_s = timed_build()
+    thr = int(np.ceil(args.threshold_bp / 1000))
+    st.begin(thr, ndb)
+    torch.cuda.synchronize()
+    t = time.perf_counter()
+    res = st.run()
+    torch.cuda.synchronize()
+    run_s = time.perf_counter() - t
+    idx = np.array([r[0] for r in res], dtype=np.int64)
+    isect = np.array([r[1] for r in res], dtype=np.int64)
+
+    # ---- properties that hold for the reference's greedy loop at any size --------------------------------
+    checks = {}
+    checks["winners_distinct"] = bool(len(set(idx.tolist())) == len(idx))
+    checks["overlaps_non_increasing"] = bool((np.diff(isect) <= 0).all())
+    checks["all_rounds_meet_threshold"] = bool((isect >= thr).all())
+    # the union of the winners covers exactly sum(isect) query hashes
+    off_h = offsets.cpu().numpy()
+    covered = torch.zeros(nq, dtype=torch.bool, device=dev)
+    for gi in idx.tolist():
+        row = hashes[off_h[gi]:off_h[gi + 1]]
+        pos = torch.searchsorted(q, row).clamp_(max=nq - 1)
+        covered[pos[q[pos] == row]] = True
+    checks["sum_isect_equals_covered"] = bool(int(covered.sum().item()) == int(isect.sum()))
+    # remaining counters == |row ∩ uncovered query| recomputed by the streaming kernel; none reaches the threshold
+    left = q[~covered].contiguous()
+    recount = be.zeros((ndb,), torch.int64)
+    be.overlaps(left, len(left), hashes, offsets, ndb, recount, 0)
+    torch.cuda.synchronize()
+    recount = recount.cpu().numpy().view(np.uint64)
+    checks["final_counters_match_streaming_recount"] = bool(np.array_equal(st.counters(), recount))
+    checks["stop_rule_holds"] = bool(recount.max() < max(thr, 1) or len(left) < thr or len(res) == ndb)
+    # replay of round 0 and of the last round with the streaming kernel: the winner is the arg-max, ties lowest
+    first = be.zeros((ndb,), torch.int64)
+    be.overlaps(q, nq, hashes, offsets, ndb, first, 0)
+    first = first.cpu().numpy().view(np.uint64)
+    checks["round0_is_argmax_lowest_index"] = bool(len(res) == 0 or (int(np.argmax(first)) == idx[0] and int(first.max()) == isect[0]))
+
+    out = {"config": {"query_hashes": nq, "datasets": ndb, "db_hashes": total, "db_bytes": total * 8,
+                      "threshold_bp": args.threshold_bp, "scaled": 1000},
+           "generate_s": round(gen_s, 3), "index_build_ms": round(build_s * 1e3, 2),
+           "postings": int(be.lib.smgpu_gather_postings(st._ptr)),
+           "rounds": len(res), "loop_ms": round(run_s * 1e3, 2),
+           "us_per_round": round(run_s * 1e6 / max(len(res), 1), 2),
+           "total_ms": round((build_s + run_s) * 1e3, 2),
+           "streaming_equivalent_bytes": int(8 * (nq + total) * max(len(res), 1)),
+           "first": res[:3], "last": res[-3:], "checks": checks}
+    if args.stepwise:
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        res2 = parallel.gather_distributed(q, nq, hashes, offsets, ndb, 0, args.threshold_bp, 1000, be, stepwise=True)
+        torch.cuda.synchronize()
+        out["stepwise_total_ms"] = round((time.perf_counter() - t) * 1e3, 2)
+        out["stepwise_identical"] = bool(res2 == res)
+    print(json.dumps(out))
+    return 0 if all(checks.values()) else 1
+
+
+if __name__ == "__main__":
+    sys.exit(main())
