@@ -290,6 +290,41 @@ typedef struct SmgpuCounter SmgpuCounter;
 SmgpuSketchSet *smgpu_sketchset_new(const SourmashKmerMinHash *const *mhs, uintptr_t n);
 void smgpu_sketchset_free(SmgpuSketchSet *ptr);
 uintptr_t smgpu_sketchset_len(const SmgpuSketchSet *ptr);
+/* Bulk loading: signature files -> one CSR in HBM, with no per-sketch host object.  Replaces the per-signature
+ * loops of src/sourmash/save_load.py:218-234,448-549 / src/core/src/signature.rs:569-659 for the collection side
+ * of compare / search / gather.  `paths`: .sig, .sig.gz, .zip (members chosen through SOURMASH-MANIFEST.csv when
+ * present, src/sourmash/manifest.py:15-387), directories (walked for *.sig / *.sig.gz) or text files listing one
+ * path per line.  Selection: ksize (0 = any), moltype ("DNA", "protein", "dayhoff", "hp"; NULL = any), scaled
+ * (0 = as stored; otherwise sketches with scaled <= this, downsampled to it).  Rows keep the input order; all
+ * selected sketches must share ksize / moltype / seed / scaled (the reference's compatibility errors otherwise).
+ * n_threads = 0 uses every host core. */
+typedef struct SmgpuCollection SmgpuCollection;
+/* The host half on its own (no GPU needed): the CSR and manifest of what sketchset_load would put in HBM. */
+SmgpuCollection *smgpu_collection_load(const char *const *paths, uintptr_t n_paths, uint32_t ksize, const char *moltype,
+                                       uint64_t scaled, uint32_t n_threads);
+void smgpu_collection_free(SmgpuCollection *ptr);
+uintptr_t smgpu_collection_len(const SmgpuCollection *ptr);
+uint64_t smgpu_collection_total_hashes(const SmgpuCollection *ptr);
+uint64_t smgpu_collection_skipped(const SmgpuCollection *ptr);
+const uint64_t *smgpu_collection_hashes(const SmgpuCollection *ptr);   /* borrowed, valid until free */
+const uint64_t *smgpu_collection_offsets(const SmgpuCollection *ptr);  /* borrowed, len + 1 entries */
+SourmashStr smgpu_collection_manifest(const SmgpuCollection *ptr);
+void smgpu_collection_params(const SmgpuCollection *ptr, uint32_t *ksize, uint32_t *hash_function, uint64_t *seed,
+                             uint64_t *max_hash, uint64_t *num);
+SmgpuSketchSet *smgpu_sketchset_from_collection(const SmgpuCollection *ptr);
+SmgpuSketchSet *smgpu_sketchset_load(const char *const *paths, uintptr_t n_paths, uint32_t ksize, const char *moltype,
+                                     uint64_t scaled, uint32_t n_threads);
+uint64_t smgpu_sketchset_total_hashes(const SmgpuSketchSet *ptr);
+uint64_t smgpu_sketchset_skipped(const SmgpuSketchSet *ptr);
+/* One manifest row per CSR row, in the reference's CSV manifest format (manifest.py:29-41,128-146). */
+SourmashStr smgpu_sketchset_manifest(const SmgpuSketchSet *ptr);
+void smgpu_sketchset_params(const SmgpuSketchSet *ptr, uint32_t *ksize, uint32_t *hash_function, uint64_t *seed,
+                            uint64_t *max_hash, uint64_t *num);
+void smgpu_sketchset_sizes(const SmgpuSketchSet *ptr, uint64_t *sizes_out);
+SourmashKmerMinHash *smgpu_sketchset_get(const SmgpuSketchSet *ptr, uint64_t index);
+void smgpu_sketchset_device_csr(const SmgpuSketchSet *ptr, const uint64_t **d_hashes, const uint64_t **d_offsets);
+/* n x n matrices of a loaded set on the host (either may be NULL); same kernels as smgpu_compare_all_pairs. */
+void smgpu_sketchset_compare(const SmgpuSketchSet *ptr, uint32_t *common_out, double *jaccard_out);
 SmgpuCounter *smgpu_counter_new(const SmgpuSketchSet *set, const SourmashKmerMinHash *query);
 void smgpu_counter_free(SmgpuCounter *ptr);
 void smgpu_counter_get(const SmgpuCounter *ptr, uint64_t *counts_out);

@@ -33,7 +33,7 @@ _SCALARS = {
     "SourmashStr": SourmashStr,
 }
 _OPAQUE = {"SourmashKmerMinHash", "SourmashSignature", "SourmashComputeParameters", "SmgpuSketchSet", "SmgpuCounter", "SmgpuBitIndex",
-           "SmgpuGather"}
+           "SmgpuGather", "SmgpuCollection"}
 
 
 def _ctype(decl, is_arg=False):

@@ -12,6 +12,7 @@
 #include <memory>
 #include <sstream>
 #include "../../include/sourmash_amd.h"
+#include "collection.hpp"
 #include "device_ctx.hpp"
 #include "ingest.hpp"
 #include "murmur3.hpp"
@@ -689,6 +690,27 @@ void smgpu_bitindex_compare_raw(const SmgpuBitIndex* p, uint32_t rb_first, uint3
     });
 }
 
+// n x n counts (+ Jaccard) of a device-resident CSR into host matrices; dense collections take the bit-row path
+static void compare_device_csr(const uint64_t* d_hashes, const uint64_t* d_offsets, uint64_t n, uint32_t* common_out,
+                               double* jaccard_out, hipStream_t st) {
+    DevBuf dc, dj;
+    struct Free { DevBuf& b; ~Free() { if (b.p) (void)hipFree(b.p); } } f3{dc}, f4{dj};
+    dc.reserve((size_t)((n + 15) / 16 * 16) * n * 4);
+    std::unique_ptr<BitIndex> bi(bitindex_build(d_hashes, d_offsets, (uint32_t)n, st));
+    if (bi)   // dense collection: bit rows + popcount(AND)
+        hip_check(bitmatrix_launch(bi->bits, bi->words_per_row, (uint32_t)n, 0, 1, (uint32_t)((n + 15) / 16),
+                                   dc.as<uint32_t>(), st), "bitmatrix");
+    else      // sparse collection: LDS-tiled merge walk
+        hip_check(compare_counts_launch(d_hashes, d_offsets, (uint32_t)n, 0, (uint32_t)n, dc.as<uint32_t>(), st), "compare");
+    if (jaccard_out) {
+        dj.reserve((size_t)n * n * 8);
+        hip_check(jaccard_from_counts_launch(dc.as<uint32_t>(), d_offsets, (uint32_t)n, 0, (uint32_t)n, dj.as<double>(), st), "jaccard");
+        hip_check(hipMemcpyAsync(jaccard_out, dj.p, (size_t)n * n * 8, hipMemcpyDeviceToHost, st), "D2H");
+    }
+    if (common_out) hip_check(hipMemcpyAsync(common_out, dc.p, (size_t)n * n * 4, hipMemcpyDeviceToHost, st), "D2H");
+    hip_check(hipStreamSynchronize(st), "sync");
+}
+
 void smgpu_compare_all_pairs(const SourmashKmerMinHash* const* mhs, uintptr_t n, uint32_t* common_out, double* jaccard_out) {
     landing_void([&] {
         if (n == 0) return;
@@ -702,29 +724,16 @@ void smgpu_compare_all_pairs(const SourmashKmerMinHash* const* mhs, uintptr_t n,
         DeviceCtx& ctx = DeviceCtx::get();
         std::lock_guard<std::mutex> g(ctx.mutex());
         hipStream_t st = ctx.stream();
-        DevBuf dh, doff, dc, dj;
-        struct Free { DevBuf& b; ~Free() { if (b.p) (void)hipFree(b.p); } } f1{dh}, f2{doff}, f3{dc}, f4{dj};
+        DevBuf dh, doff;
+        struct Free { DevBuf& b; ~Free() { if (b.p) (void)hipFree(b.p); } } f1{dh}, f2{doff};
         dh.reserve(total * 8 + 16);
         doff.reserve((n + 1) * 8);
-        dc.reserve((size_t)((n + 15) / 16 * 16) * n * 4);
         for (uintptr_t i = 0; i < n; ++i)
             if (MH(mhs[i])->size())
                 hip_check(hipMemcpyAsync(dh.as<uint64_t>() + offsets[i], MH(mhs[i])->mins.data(), MH(mhs[i])->size() * 8,
                                          hipMemcpyHostToDevice, st), "H2D");
         hip_check(hipMemcpyAsync(doff.p, offsets.data(), (n + 1) * 8, hipMemcpyHostToDevice, st), "H2D");
-        std::unique_ptr<BitIndex> bi(bitindex_build(dh.as<uint64_t>(), doff.as<uint64_t>(), (uint32_t)n, st));
-        if (bi)   // dense collection: bit rows + popcount(AND)
-            hip_check(bitmatrix_launch(bi->bits, bi->words_per_row, (uint32_t)n, 0, 1, (uint32_t)((n + 15) / 16),
-                                       dc.as<uint32_t>(), st), "bitmatrix");
-        else      // sparse collection: LDS-tiled merge walk
-            hip_check(compare_counts_launch(dh.as<uint64_t>(), doff.as<uint64_t>(), (uint32_t)n, 0, (uint32_t)n, dc.as<uint32_t>(), st), "compare");
-        if (jaccard_out) {
-            dj.reserve((size_t)n * n * 8);
-            hip_check(jaccard_from_counts_launch(dc.as<uint32_t>(), doff.as<uint64_t>(), (uint32_t)n, 0, (uint32_t)n, dj.as<double>(), st), "jaccard");
-            hip_check(hipMemcpyAsync(jaccard_out, dj.p, (size_t)n * n * 8, hipMemcpyDeviceToHost, st), "D2H");
-        }
-        if (common_out) hip_check(hipMemcpyAsync(common_out, dc.p, (size_t)n * n * 4, hipMemcpyDeviceToHost, st), "D2H");
-        hip_check(hipStreamSynchronize(st), "sync");
+        compare_device_csr(dh.as<uint64_t>(), doff.as<uint64_t>(), n, common_out, jaccard_out, st);
     });
 }
 
@@ -732,6 +741,11 @@ void smgpu_compare_all_pairs(const SourmashKmerMinHash* const* mhs, uintptr_t n,
 struct SketchSet {
     DevBuf hashes, offsets;
     uint64_t n = 0, total = 0;
+    // filled by smgpu_sketchset_load (empty for sets built from sketch handles)
+    std::vector<uint64_t> host_offsets;
+    std::vector<ManifestRow> rows;
+    uint32_t ksize = 0, hash_function = HF_DNA;
+    uint64_t seed = 42, max_hash = 0, num = 0, skipped = 0;
     ~SketchSet() { if (hashes.p) (void)hipFree(hashes.p); if (offsets.p) (void)hipFree(offsets.p); }
 };
 struct GatherCounter {
@@ -794,6 +808,133 @@ SmgpuSketchSet* smgpu_sketchset_new(const SourmashKmerMinHash* const* mhs, uintp
 }
 void smgpu_sketchset_free(SmgpuSketchSet* p) { delete reinterpret_cast<SketchSet*>(p); }
 uintptr_t smgpu_sketchset_len(const SmgpuSketchSet* p) { return reinterpret_cast<const SketchSet*>(p)->n; }
+
+// files -> host CSR (collection.hpp); no device needed
+static LoadedCollection load_collection(const char* const* paths, uintptr_t n_paths, uint32_t ksize, const char* moltype,
+                                        uint64_t scaled, uint32_t n_threads) {
+    LoadSelect sel;
+    sel.ksize = ksize;
+    sel.hash_function = (moltype && *moltype) ? (int)molecule_from_name(moltype) : -1;
+    sel.scaled = scaled;
+    CollectionLoader loader(sel, n_threads);
+    for (uintptr_t i = 0; i < n_paths; ++i) loader.add_path(paths[i]);
+    return loader.run();
+}
+SmgpuCollection* smgpu_collection_load(const char* const* paths, uintptr_t n_paths, uint32_t ksize, const char* moltype,
+                                       uint64_t scaled, uint32_t n_threads) {
+    return landing<SmgpuCollection*>([&]() -> SmgpuCollection* {
+        return reinterpret_cast<SmgpuCollection*>(new LoadedCollection(load_collection(paths, n_paths, ksize, moltype, scaled, n_threads)));
+    });
+}
+void smgpu_collection_free(SmgpuCollection* p) { delete reinterpret_cast<LoadedCollection*>(p); }
+uintptr_t smgpu_collection_len(const SmgpuCollection* p) { return reinterpret_cast<const LoadedCollection*>(p)->rows.size(); }
+uint64_t smgpu_collection_total_hashes(const SmgpuCollection* p) { return reinterpret_cast<const LoadedCollection*>(p)->hashes.size(); }
+uint64_t smgpu_collection_skipped(const SmgpuCollection* p) { return reinterpret_cast<const LoadedCollection*>(p)->skipped; }
+const uint64_t* smgpu_collection_hashes(const SmgpuCollection* p) { return reinterpret_cast<const LoadedCollection*>(p)->hashes.data(); }
+const uint64_t* smgpu_collection_offsets(const SmgpuCollection* p) { return reinterpret_cast<const LoadedCollection*>(p)->offsets.data(); }
+SourmashStr smgpu_collection_manifest(const SmgpuCollection* p) {
+    return landing<SourmashStr>([&]() -> SourmashStr {
+        return make_str(manifest_to_csv(reinterpret_cast<const LoadedCollection*>(p)->rows));
+    });
+}
+void smgpu_collection_params(const SmgpuCollection* p, uint32_t* ksize, uint32_t* hash_function, uint64_t* seed,
+                             uint64_t* max_hash, uint64_t* num) {
+    const LoadedCollection* c = reinterpret_cast<const LoadedCollection*>(p);
+    *ksize = c->ksize; *hash_function = c->hash_function; *seed = c->seed; *max_hash = c->max_hash; *num = c->num;
+}
+
+static SketchSet* upload_collection(LoadedCollection&& col) {
+    DeviceCtx& ctx = DeviceCtx::get();
+    std::lock_guard<std::mutex> g(ctx.mutex());
+    hipStream_t st = ctx.stream();
+    std::unique_ptr<SketchSet> s(new SketchSet());
+    s->n = col.rows.size();
+    s->total = col.hashes.size();
+    s->hashes.reserve(s->total * 8 + 16);
+    s->offsets.reserve((s->n + 1) * 8);
+    if (s->total) hip_check(hipMemcpyAsync(s->hashes.p, col.hashes.data(), s->total * 8, hipMemcpyHostToDevice, st), "H2D");
+    hip_check(hipMemcpyAsync(s->offsets.p, col.offsets.data(), (s->n + 1) * 8, hipMemcpyHostToDevice, st), "H2D");
+    hip_check(hipStreamSynchronize(st), "sync");
+    s->host_offsets = std::move(col.offsets);
+    s->rows = std::move(col.rows);
+    s->ksize = col.ksize; s->hash_function = col.hash_function; s->seed = col.seed;
+    s->max_hash = col.max_hash; s->num = col.num; s->skipped = col.skipped;
+    return s.release();
+}
+// files -> CSR in HBM, no per-sketch objects
+SmgpuSketchSet* smgpu_sketchset_load(const char* const* paths, uintptr_t n_paths, uint32_t ksize, const char* moltype,
+                                     uint64_t scaled, uint32_t n_threads) {
+    return landing<SmgpuSketchSet*>([&]() -> SmgpuSketchSet* {
+        (void)DeviceCtx::get();                                     // fail before parsing when there is no GPU
+        return reinterpret_cast<SmgpuSketchSet*>(upload_collection(load_collection(paths, n_paths, ksize, moltype, scaled, n_threads)));
+    });
+}
+SmgpuSketchSet* smgpu_sketchset_from_collection(const SmgpuCollection* p) {
+    return landing<SmgpuSketchSet*>([&]() -> SmgpuSketchSet* {
+        LoadedCollection copy = *reinterpret_cast<const LoadedCollection*>(p);
+        return reinterpret_cast<SmgpuSketchSet*>(upload_collection(std::move(copy)));
+    });
+}
+uint64_t smgpu_sketchset_total_hashes(const SmgpuSketchSet* p) { return reinterpret_cast<const SketchSet*>(p)->total; }
+uint64_t smgpu_sketchset_skipped(const SmgpuSketchSet* p) { return reinterpret_cast<const SketchSet*>(p)->skipped; }
+SourmashStr smgpu_sketchset_manifest(const SmgpuSketchSet* p) {
+    return landing<SourmashStr>([&]() -> SourmashStr {
+        return make_str(manifest_to_csv(reinterpret_cast<const SketchSet*>(p)->rows));
+    });
+}
+void smgpu_sketchset_params(const SmgpuSketchSet* p, uint32_t* ksize, uint32_t* hash_function, uint64_t* seed,
+                            uint64_t* max_hash, uint64_t* num) {
+    const SketchSet* s = reinterpret_cast<const SketchSet*>(p);
+    *ksize = s->ksize; *hash_function = s->hash_function; *seed = s->seed; *max_hash = s->max_hash; *num = s->num;
+}
+void smgpu_sketchset_sizes(const SmgpuSketchSet* p, uint64_t* out) {
+    landing_void([&] {
+        const SketchSet* s = reinterpret_cast<const SketchSet*>(p);
+        if (s->host_offsets.size() == s->n + 1) {
+            for (uint64_t i = 0; i < s->n; ++i) out[i] = s->host_offsets[i + 1] - s->host_offsets[i];
+            return;
+        }
+        std::vector<uint64_t> off(s->n + 1);
+        DeviceCtx& ctx = DeviceCtx::get();
+        std::lock_guard<std::mutex> g(ctx.mutex());
+        hip_check(hipMemcpyAsync(off.data(), s->offsets.p, (s->n + 1) * 8, hipMemcpyDeviceToHost, ctx.stream()), "D2H");
+        hip_check(hipStreamSynchronize(ctx.stream()), "sync");
+        for (uint64_t i = 0; i < s->n; ++i) out[i] = off[i + 1] - off[i];
+    });
+}
+// the sketch of row `index` as a new handle (for result rows that need a full object)
+SourmashKmerMinHash* smgpu_sketchset_get(const SmgpuSketchSet* p, uint64_t index) {
+    return landing<SourmashKmerMinHash*>([&]() -> SourmashKmerMinHash* {
+        const SketchSet* s = reinterpret_cast<const SketchSet*>(p);
+        if (index >= s->n) throw err_internal("sketch index out of range");
+        if (s->host_offsets.size() != s->n + 1) throw err_internal("smgpu_sketchset_get needs a set made by smgpu_sketchset_load");
+        const uint64_t lo = s->host_offsets[index], len = s->host_offsets[index + 1] - lo;
+        std::unique_ptr<KmerMinHash> mh(new KmerMinHash(0, s->ksize * (s->hash_function == HF_DNA ? 1 : 3), s->hash_function,
+                                                        s->seed, false, (uint32_t)s->num));
+        mh->max_hash = s->max_hash;
+        mh->mins.resize(len);
+        DeviceCtx& ctx = DeviceCtx::get();
+        std::lock_guard<std::mutex> g(ctx.mutex());
+        if (len) hip_check(hipMemcpyAsync(mh->mins.data(), s->hashes.as<uint64_t>() + lo, len * 8, hipMemcpyDeviceToHost, ctx.stream()), "D2H");
+        hip_check(hipStreamSynchronize(ctx.stream()), "sync");
+        return reinterpret_cast<SourmashKmerMinHash*>(mh.release());
+    });
+}
+void smgpu_sketchset_device_csr(const SmgpuSketchSet* p, const uint64_t** d_hashes, const uint64_t** d_offsets) {
+    const SketchSet* s = reinterpret_cast<const SketchSet*>(p);
+    *d_hashes = s->hashes.as<uint64_t>();
+    *d_offsets = s->offsets.as<uint64_t>();
+}
+void smgpu_sketchset_compare(const SmgpuSketchSet* p, uint32_t* common_out, double* jaccard_out) {
+    landing_void([&] {
+        const SketchSet* s = reinterpret_cast<const SketchSet*>(p);
+        if (s->n == 0) return;
+        if (s->num != 0) throw err_internal("smgpu_sketchset_compare handles scaled sketches");
+        DeviceCtx& ctx = DeviceCtx::get();
+        std::lock_guard<std::mutex> g(ctx.mutex());
+        compare_device_csr(s->hashes.as<uint64_t>(), s->offsets.as<uint64_t>(), s->n, common_out, jaccard_out, ctx.stream());
+    });
+}
 
 SmgpuCounter* smgpu_counter_new(const SmgpuSketchSet* set, const SourmashKmerMinHash* query) {
     return landing<SmgpuCounter*>([&]() -> SmgpuCounter* {

@@ -61,7 +61,7 @@ class Parser {
         return v;
     }
 
-  private:
+  protected:
     [[noreturn]] void fail(const char* what) { throw Error(E_SERDE, std::string("JSON parse error: ") + what); }
     void skip_ws() { while (p_ < end_ && (*p_ == ' ' || *p_ == '\n' || *p_ == '\r' || *p_ == '\t')) ++p_; }
     bool eat(char c) { skip_ws(); if (p_ < end_ && *p_ == c) { ++p_; return true; } return false; }

@@ -11,8 +11,11 @@ What changes underneath: the collection lives in HBM as one CSR (`SketchSet`), s
     the reference tie-break, and consume() are single kernel launches.
 Results (which signatures, which order, which numbers) are those of the reference.
 """
+import csv
 import ctypes as C
+import io
 import math
+import os
 from collections import namedtuple
 
 import numpy as np
@@ -21,24 +24,158 @@ from ._lowlevel import lib
 from .minhash import flatten_and_downsample_num, flatten_and_downsample_scaled, flatten_and_intersect_scaled
 from .search import calc_threshold_from_bp, make_containment_query, make_jaccard_search_query
 from .signature import SourmashSignature
-from .utils import RustObject, rustcall
+from .utils import RustObject, decode_str, rustcall
 
-__all__ = ["IndexSearchResult", "SketchSet", "LinearIndex", "CounterGather"]
+__all__ = ["IndexSearchResult", "Collection", "SketchSet", "LinearIndex", "CounterGather"]
 
 IndexSearchResult = namedtuple("Result", "score, signature, location")
 
 
+def _path_array(paths):
+    if isinstance(paths, (str, bytes)) or hasattr(paths, "__fspath__"):
+        paths = [paths]
+    enc = [os.fsencode(p) for p in paths]
+    return (C.c_char_p * max(len(enc), 1))(*enc), len(enc)
+
+
+def _manifest_rows(csv_text):
+    "manifest CSV -> list of dict rows with the reference's column types (manifest.py:84-98)"
+    lines = csv_text.splitlines(keepends=True)
+    rows = list(csv.DictReader(io.StringIO("".join(lines[1:]), newline="")))
+    for row in rows:
+        for k in ("num", "scaled", "ksize", "n_hashes"):
+            row[k] = int(row[k])
+        row["with_abundance"] = bool(int(row["with_abundance"]))
+    return rows
+
+
+class Collection(RustObject):
+    """Signature files parsed into one host CSR + manifest by the native multi-threaded loader
+    (smgpu_collection_*; no GPU involved).  `to_device()` uploads it as a SketchSet."""
+    __dealloc_func__ = lib.smgpu_collection_free
+
+    def __init__(self, paths, *, ksize=0, moltype=None, scaled=0, threads=0):
+        arr, n = _path_array(paths)
+        self._objptr = rustcall(lib.smgpu_collection_load, arr, n, int(ksize or 0),
+                                moltype.encode() if moltype else None, int(scaled or 0), int(threads))
+
+    def __len__(self):
+        return self._methodcall(lib.smgpu_collection_len)
+
+    @property
+    def total_hashes(self):
+        return self._methodcall(lib.smgpu_collection_total_hashes)
+
+    @property
+    def skipped(self):
+        "sketches seen in the inputs that the selection left out"
+        return self._methodcall(lib.smgpu_collection_skipped)
+
+    @property
+    def manifest_csv(self):
+        return decode_str(self._methodcall(lib.smgpu_collection_manifest))
+
+    @property
+    def manifest(self):
+        return _manifest_rows(self.manifest_csv)
+
+    @property
+    def offsets(self):
+        ptr = self._methodcall(lib.smgpu_collection_offsets)
+        return np.ctypeslib.as_array(ptr, shape=(len(self) + 1,)).copy()
+
+    @property
+    def hashes(self):
+        n = self.total_hashes
+        if not n:
+            return np.zeros(0, dtype=np.uint64)
+        return np.ctypeslib.as_array(self._methodcall(lib.smgpu_collection_hashes), shape=(n,)).copy()
+
+    def to_device(self):
+        return SketchSet._from_objptr(self._methodcall(lib.smgpu_sketchset_from_collection))
+
+
 class SketchSet(RustObject):
-    "n flat sketches packed as one device-resident CSR (smgpu_sketchset_*)."
+    """n flat sketches packed as one device-resident CSR (smgpu_sketchset_*).
+
+    Built from MinHash objects (`SketchSet(minhashes)`) or straight from files (`SketchSet.load(paths, ...)`:
+    .sig / .sig.gz / .zip / directories / path lists, parsed by the native loader without creating a Python
+    object per sketch).  A loaded set answers compare / search / gather by row number; `manifest[row]` says
+    which signature that is, `signature(row)` materialises it."""
     __dealloc_func__ = lib.smgpu_sketchset_free
+    _keep = ()
+    _manifest = None
 
     def __init__(self, minhashes):
         self._keep = list(minhashes)
         ptrs = (C.c_void_p * max(len(self._keep), 1))(*[mh._get_objptr() for mh in self._keep])
         self._objptr = rustcall(lib.smgpu_sketchset_new, ptrs, len(self._keep))
 
+    @classmethod
+    def load(cls, paths, *, ksize=0, moltype=None, scaled=0, threads=0):
+        arr, n = _path_array(paths)
+        return cls._from_objptr(rustcall(lib.smgpu_sketchset_load, arr, n, int(ksize or 0),
+                                         moltype.encode() if moltype else None, int(scaled or 0), int(threads)))
+
     def __len__(self):
         return self._methodcall(lib.smgpu_sketchset_len)
+
+    @property
+    def total_hashes(self):
+        return self._methodcall(lib.smgpu_sketchset_total_hashes)
+
+    @property
+    def manifest(self):
+        if self._manifest is None:
+            self._manifest = _manifest_rows(decode_str(self._methodcall(lib.smgpu_sketchset_manifest)))
+        return self._manifest
+
+    @property
+    def sizes(self):
+        out = np.zeros(max(len(self), 1), dtype=np.uint64)
+        self._methodcall(lib.smgpu_sketchset_sizes, out.ctypes.data_as(C.c_void_p))
+        return out[:len(self)]
+
+    @property
+    def params(self):
+        "(ksize, moltype, seed, scaled, num) shared by every row of a loaded set"
+        k, hf, seed, mx, num = C.c_uint32(), C.c_uint32(), C.c_uint64(), C.c_uint64(), C.c_uint64()
+        self._methodcall(lib.smgpu_sketchset_params, C.byref(k), C.byref(hf), C.byref(seed), C.byref(mx), C.byref(num))
+        from .minhash import _get_scaled_for_max_hash
+        moltype = {1: "DNA", 2: "protein", 3: "dayhoff", 4: "hp"}[hf.value]
+        return k.value, moltype, seed.value, _get_scaled_for_max_hash(mx.value) if mx.value else 0, num.value
+
+    def minhash(self, row):
+        from .minhash import MinHash
+        return MinHash._from_objptr(self._methodcall(lib.smgpu_sketchset_get, int(row)))
+
+    def signature(self, row):
+        "SourmashSignature of a row of a loaded set (name / filename from the manifest)"
+        m = self.manifest[row]
+        return SourmashSignature(self.minhash(row), name=m["name"], filename=m["filename"])
+
+    def compare(self, *, jaccard=True):
+        "-> (common u32 [n, n], jaccard f64 [n, n] or None) for the whole set"
+        n = len(self)
+        common = np.zeros((n, n), dtype=np.uint32)
+        jac = np.zeros((n, n), dtype=np.float64) if jaccard else None
+        self._methodcall(lib.smgpu_sketchset_compare, common.ctypes.data_as(C.c_void_p),
+                         jac.ctypes.data_as(C.c_void_p) if jaccard else None)
+        return common, jac
+
+    def overlaps(self, query_mh):
+        "|query ∩ row| for every row (one pass)"
+        return _DeviceCounter(self, query_mh.flatten()).values()
+
+    def gather(self, query_mh, threshold_bp=0):
+        """Min-set-cover of the query by the rows of this set -> [(row, |intersect|)] in rank order; the whole
+        loop runs on the GPU (GatherDatabases semantics, search.py:877-949, for equal scaled)."""
+        scaled = query_mh.scaled
+        if not scaled:
+            raise ValueError("gather requires scaled signatures")
+        thr = math.ceil(float(threshold_bp) / scaled) if threshold_bp else 0
+        idx, isect = _DeviceCounter(self, query_mh.flatten()).gather(thr)
+        return [(int(i), int(c)) for i, c in zip(idx, isect)]
 
 
 class _DeviceCounter(RustObject):

@@ -54,6 +54,11 @@ for name in ["GCF_000006945.2_ASM694v2", "GCF_000007545.1_ASM754v1", "GCF_000008
     FILES.append((f"tests/test-data/gather/{name}_genomic.fna.gz.sig", f"gather/{name}_genomic.fna.gz.sig",
                   "tests/test_index_protocol.py:1057-1097 golden gather"))
 FILES.append(("tests/test-data/gather/combined.sig", "gather/combined.sig", "golden gather query"))
+FILES.append(("tests/test-data/track_abund/track_abund.zip", "zips/track_abund.zip",
+              "a zip as `sourmash sig cat -o x.zip` writes it: stored signatures/<md5>.sig.gz members + SOURMASH-MANIFEST.csv"))
+FILES.append(("tests/test-data/prot/all.zip", "zips/all.zip",
+              "tests/test_index.py:821-906: deflated members, directories, a non-signature member, 8 manifest rows "
+              "(DNA x2, protein/dayhoff/hp x2 each)"))
 
 
 def main():
