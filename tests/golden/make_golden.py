@@ -54,6 +54,10 @@ for name in ["GCF_000006945.2_ASM694v2", "GCF_000007545.1_ASM754v1", "GCF_000008
     FILES.append((f"tests/test-data/gather/{name}_genomic.fna.gz.sig", f"gather/{name}_genomic.fna.gz.sig",
                   "tests/test_index_protocol.py:1057-1097 golden gather"))
 FILES.append(("tests/test-data/gather/combined.sig", "gather/combined.sig", "golden gather query"))
+for name in ["genome-s10.fa.gz.sig", "genome-s11.fa.gz.sig", "genome-s12.fa.gz.sig", "reads-s10-s11.sig", "reads-s10x10-s11.sig"]:
+    FILES.append((f"tests/test-data/gather-abund/{name}", f"gather-abund/{name}",
+                  "tests/test_sourmash.py:6386-6600 abundance-weighted gather (p_query / p_match / avg_abund columns)"))
+FILES.append(("tests/test-data/47+63.fa.sig", "pairs/47+63.fa.sig", "tests/test_search.py:257-590 result-row fixtures"))
 FILES.append(("tests/test-data/track_abund/track_abund.zip", "zips/track_abund.zip",
               "a zip as `sourmash sig cat -o x.zip` writes it: stored signatures/<md5>.sig.gz members + SOURMASH-MANIFEST.csv"))
 FILES.append(("tests/test-data/prot/all.zip", "zips/all.zip",
