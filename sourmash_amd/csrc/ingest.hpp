@@ -1,94 +1,34 @@
-// ingest.hpp -- FASTA / FASTQ (.gz) file -> device -> sketches, in one streaming pass.
+// ingest.hpp -- FASTA / FASTQ (.gz) file -> HBM -> sketches, in one streaming pass.
 //
-// the step right before the kernel.  The reference parses records in
-// Python (screed, src/sourmash/command_sketch.py:697,746-768) and crosses the FFI once per record;
-// here a native reader strips headers and line breaks, writes the records back to back with ONE
-// separator byte between them (a byte outside ACGT kills exactly the k-mers that would span two
-// records), and ships 64 MiB chunks through two pinned staging buffers so that parsing chunk i+1
-// overlaps the H2D copy and the kernels of chunk i.  Consecutive chunks overlap by kmax-1 bytes, so
-// every k-mer is hashed exactly once.  Kept hashes of all chunks accumulate in HBM per sketch and
-// are sorted / uniqued (with multiplicities for abundance sketches) once at the end.
+// the step right before the kernel.  The reference parses records in Python
+// (screed, src/sourmash/command_sketch.py:697,746-768) and crosses the FFI once per record.  Here the host does
+// no parsing at all:
+//   reader threads   raw file bytes -> pinned ring buffers (plain files: several threads pread different chunks
+//                    at once; gzip: one zlib inflate stream, which is then the limit)
+//   copy stream      pinned -> HBM, overlapped with everything else
+//   compute stream   fastx.hip resolves the record structure on the device (headers, line breaks, FASTQ quality
+//                    lines) and compacts the sequence bytes, one separator byte per record; sketch.hip hashes the
+//                    compacted chunk for every sketch of the signature (all ksizes in one pass over the file)
+// Consecutive chunks are joined by a k-1 byte halo kept on the device, so every k-mer is hashed exactly once.
+// Kept hashes of all chunks accumulate in HBM per sketch and are sorted / uniqued (with multiplicities for
+// abundance sketches) at the end, or whenever 64M entries have piled up.
 #pragma once
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
 #include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
 #include <string>
+#include <thread>
 #include <vector>
 #include "device_ctx.hpp"
+#include "fastx_api.hpp"
 #include "signature_host.hpp"
 
 namespace smg {
-
-// Streaming FASTA/FASTQ reader (gz or plain: zlib's gzread handles both).  fill() appends sequence
-// bytes and '\n' record separators to dst until it is full or the file ends.
-class SeqFileReader {
-  public:
-    explicit SeqFileReader(const std::string& path) : buf_(1 << 20) {
-        f_ = gzopen(path.c_str(), "rb");
-        if (!f_) throw Error(E_IO, "No such file or directory: " + path);
-        gzbuffer(f_, 1 << 20);
-    }
-    ~SeqFileReader() { if (f_) gzclose(f_); }
-
-    uint64_t n_records = 0, n_bases = 0;
-
-    // returns bytes written; 0 at end of file
-    size_t fill(uint8_t* dst, size_t cap) {
-        size_t w = 0;
-        while (w < cap) {
-            if (pos_ == len_) {
-                if (eof_) break;
-                const int got = gzread(f_, buf_.data(), (unsigned)buf_.size());
-                if (got < 0) throw Error(E_NIFFLER, "error while reading sequence file");
-                if (got == 0) { eof_ = true; break; }
-                pos_ = 0; len_ = (size_t)got;
-            }
-            const uint8_t* p = buf_.data() + pos_;
-            const size_t avail = len_ - pos_;
-            if (at_line_start_) {
-                at_line_start_ = false;
-                const uint8_t c = *p;
-                if (format_ == UNKNOWN) format_ = (c == '@') ? FASTQ : FASTA;
-                bool header;
-                if (format_ == FASTA) header = (c == '>');
-                else header = (line_in_record_ == 0);
-                if (header) {
-                    if (emitted_since_sep_) { dst[w++] = '\n'; emitted_since_sep_ = false; }
-                    ++n_records;
-                    seq_line_ = false;
-                } else {
-                    seq_line_ = (format_ == FASTA) || (line_in_record_ == 1);
-                }
-                if (w == cap) break;     // the separator filled dst; the line itself is handled next call
-            }
-            const uint8_t* nl = (const uint8_t*)memchr(p, '\n', avail);
-            const size_t span = nl ? (size_t)(nl - p) : avail;
-            size_t take = span;
-            if (seq_line_) {
-                take = std::min(span, cap - w);
-                size_t copy = take;
-                if (copy && p[copy - 1] == '\r') --copy;      // CRLF files
-                memcpy(dst + w, p, copy);
-                w += copy; n_bases += copy;
-                if (copy) emitted_since_sep_ = true;
-            }
-            pos_ += take;
-            if (take < span) break;                          // dst full mid-line; resume here next call
-            if (!nl) continue;                               // the line continues in the next read block
-            ++pos_;                                          // the newline itself
-            at_line_start_ = true;
-            if (format_ == FASTQ) line_in_record_ = (line_in_record_ + 1) & 3;
-        }
-        return w;
-    }
-
-  private:
-    enum Format { UNKNOWN, FASTA, FASTQ } format_ = UNKNOWN;
-    gzFile f_ = nullptr;
-    std::vector<uint8_t> buf_;
-    size_t pos_ = 0, len_ = 0;
-    bool eof_ = false, at_line_start_ = true, seq_line_ = false, emitted_since_sep_ = false;
-    int line_in_record_ = 0;
-};
 
 struct PinnedBuf {
     uint8_t* p = nullptr;
@@ -96,13 +36,186 @@ struct PinnedBuf {
     void reserve(size_t n) {
         if (n <= cap) return;
         if (p) (void)hipHostFree(p);
+        p = nullptr; cap = 0;
         hip_check(hipHostMalloc((void**)&p, n, hipHostMallocDefault), "hipHostMalloc");
         cap = n;
     }
     ~PinnedBuf() { if (p) (void)hipHostFree(p); }
 };
 
-// Sketch a sequence file into every (DNA) sketch of `sigs`.  force == true semantics.
+// Produces the raw bytes of a file as an ordered sequence of chunks in a ring of pinned buffers.
+class RawChunkSource {
+  public:
+    static constexpr int SLOTS = 8;
+
+    RawChunkSource(const std::string& path, size_t chunk, PinnedBuf* ring) : path_(path), chunk_(chunk), ring_(ring) {
+        fd_ = ::open(path.c_str(), O_RDONLY);
+        if (fd_ < 0) throw Error(E_IO, "No such file or directory: " + path);
+        struct stat st;
+        if (fstat(fd_, &st) != 0 || !S_ISREG(st.st_mode)) { ::close(fd_); throw Error(E_IO, "cannot read " + path); }
+        size_ = (uint64_t)st.st_size;
+        uint8_t magic[2] = {0, 0};
+        const ssize_t got = ::pread(fd_, magic, 2, 0);
+        gz_ = got == 2 && magic[0] == 0x1f && magic[1] == 0x8b;
+        for (int s = 0; s < SLOTS; ++s) { owner_[s] = s; filled_[s] = -1; len_[s] = 0; }
+        if (gz_) {
+            gzf_ = gzdopen(dup(fd_), "rb");
+            if (!gzf_) { ::close(fd_); throw Error(E_NIFFLER, "cannot initialise gzip reader for " + path); }
+            gzbuffer(gzf_, 1 << 20);
+            threads_.emplace_back([this] { produce_gz(); });
+        } else {
+            const uint64_t n_chunks = (size_ + chunk_ - 1) / chunk_;
+            end_seq_ = (int64_t)n_chunks;
+            unsigned want = 6;                      // SMG_INGEST_THREADS overrides (tuning)
+            if (const char* e = getenv("SMG_INGEST_THREADS")) { const long v = atol(e); if (v >= 1 && v <= SLOTS) want = (unsigned)v; }
+            const unsigned nt = (unsigned)std::min<uint64_t>(want, n_chunks);
+            for (unsigned t = 0; t < nt; ++t) threads_.emplace_back([this] { produce_plain(); });
+        }
+    }
+    ~RawChunkSource() {
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            abort_ = true;
+        }
+        cv_.notify_all();
+        for (auto& t : threads_) t.join();
+        if (gzf_) gzclose(gzf_);
+        if (fd_ >= 0) ::close(fd_);
+    }
+
+    // blocks until chunk `seq` is in its slot; false when the file has no such chunk
+    bool wait(int64_t seq, const uint8_t** data, size_t* len) {
+        std::unique_lock<std::mutex> lk(mu_);
+        const int s = (int)(seq % SLOTS);
+        cv_.wait(lk, [&] { return filled_[s] == seq || (end_seq_ >= 0 && seq >= end_seq_) || failed_; });
+        if (failed_) throw Error(error_code_, error_);
+        if (filled_[s] != seq) return false;
+        *data = ring_[s].p;
+        *len = len_[s];
+        return true;
+    }
+    // the consumer no longer needs the slot of chunk `seq`
+    void release(int64_t seq) {
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            owner_[seq % SLOTS] = seq + SLOTS;
+        }
+        cv_.notify_all();
+    }
+    bool gzip() const { return gz_; }
+
+  private:
+    bool claim(int64_t seq) {                       // wait until the slot's previous tenant has been released
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [&] { return owner_[seq % SLOTS] == seq || abort_; });
+        return !abort_;
+    }
+    void publish(int64_t seq, size_t len) {
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            len_[seq % SLOTS] = len;
+            filled_[seq % SLOTS] = seq;
+        }
+        cv_.notify_all();
+    }
+    void fail(uint32_t code, const std::string& what) {
+        {
+            std::lock_guard<std::mutex> g(mu_);
+            failed_ = true; error_code_ = code; error_ = what;
+        }
+        cv_.notify_all();
+    }
+    void produce_plain() {
+        for (;;) {
+            const int64_t seq = next_seq_.fetch_add(1);
+            if (seq >= end_seq_) return;
+            if (!claim(seq)) return;
+            const uint64_t off = (uint64_t)seq * chunk_;
+            const size_t want = (size_t)std::min<uint64_t>(chunk_, size_ - off);
+            size_t got = 0;
+            while (got < want) {
+                const ssize_t r = ::pread(fd_, ring_[seq % SLOTS].p + got, want - got, (off_t)(off + got));
+                if (r <= 0) { fail(E_IO, "short read on " + path_); return; }
+                got += (size_t)r;
+            }
+            publish(seq, got);
+        }
+    }
+    void produce_gz() {
+        for (int64_t seq = 0;; ++seq) {
+            if (!claim(seq)) return;
+            size_t got = 0;
+            while (got < chunk_) {
+                const int r = gzread(gzf_, ring_[seq % SLOTS].p + got, (unsigned)std::min<size_t>(chunk_ - got, 1u << 30));
+                if (r < 0) { fail(E_NIFFLER, "error while reading sequence file " + path_); return; }
+                if (r == 0) break;
+                got += (size_t)r;
+            }
+            if (got) publish(seq, got);
+            if (got < chunk_) {                     // end of stream
+                {
+                    std::lock_guard<std::mutex> g(mu_);
+                    end_seq_ = got ? seq + 1 : seq;
+                }
+                cv_.notify_all();
+                return;
+            }
+        }
+    }
+
+    std::string path_;
+    size_t chunk_;
+    PinnedBuf* ring_;
+    int fd_ = -1;
+    gzFile gzf_ = nullptr;
+    uint64_t size_ = 0;
+    bool gz_ = false;
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::vector<std::thread> threads_;
+    std::atomic<int64_t> next_seq_{0};
+    int64_t end_seq_ = -1;                          // first chunk number that does not exist (-1: not known yet)
+    int64_t owner_[SLOTS], filled_[SLOTS];
+    size_t len_[SLOTS];
+    bool abort_ = false, failed_ = false;
+    uint32_t error_code_ = 0;
+    std::string error_;
+};
+
+// Buffers that survive between files: pinned ring, device chunks, scratch (allocation would otherwise dominate
+// small inputs such as a single bacterial genome).
+struct IngestScratch {
+    size_t chunk = 0;
+    PinnedBuf ring[RawChunkSource::SLOTS];
+    DevBuf raw[2], comp[2], state, temp, small;
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t copied[2] = {nullptr, nullptr}, consumed[2] = {nullptr, nullptr};
+    size_t temp_bytes = 0;
+    static constexpr size_t HALO = 256;             // bytes reserved in front of every compacted chunk
+
+    void prepare(size_t chunk_bytes) {
+        if (!copy_stream) {
+            hip_check(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking), "hipStreamCreate");
+            for (int i = 0; i < 2; ++i) {
+                hip_check(hipEventCreateWithFlags(&copied[i], hipEventDisableTiming), "hipEventCreate");
+                hip_check(hipEventCreateWithFlags(&consumed[i], hipEventDisableTiming), "hipEventCreate");
+            }
+            small.reserve(256);
+        }
+        if (chunk_bytes <= chunk) return;
+        chunk = chunk_bytes;
+        for (auto& r : ring) r.reserve(chunk + 64);
+        for (int i = 0; i < 2; ++i) {
+            raw[i].reserve(chunk + 64);
+            comp[i].reserve(HALO + chunk + 64);
+        }
+        state.reserve(chunk + 64);
+        temp_bytes = fastx_temp_bytes(chunk);
+        temp.reserve(temp_bytes);
+    }
+};
+
+// Sketch a sequence file into every (DNA) sketch of `mhs`.  force == true semantics.
 inline void sketch_file_into(std::vector<KmerMinHash*>& mhs, const std::string& path, uint64_t* n_records,
                              uint64_t* n_bases) {
     for (auto* mh : mhs)
@@ -110,22 +223,18 @@ inline void sketch_file_into(std::vector<KmerMinHash*>& mhs, const std::string& 
     uint32_t kmax = 0;
     for (auto* mh : mhs) kmax = std::max(kmax, mh->ksize);
     if (mhs.empty() || kmax == 0) return;
+    if (kmax > IngestScratch::HALO) throw err_internal("ksize too large for the streaming ingest");
     DeviceCtx& ctx = DeviceCtx::get();
     std::lock_guard<std::mutex> g(ctx.mutex());
     hipStream_t st = ctx.stream();
 
-    // 64 MiB chunks; SMG_INGEST_CHUNK (bytes) overrides it so tests can force many chunk boundaries
-    size_t CHUNK = (size_t)64 << 20;
+    // 32 MiB chunks; SMG_INGEST_CHUNK (bytes) overrides it so tests can force many chunk boundaries
+    size_t CHUNK = (size_t)32 << 20;
     if (const char* e = getenv("SMG_INGEST_CHUNK")) { const long v = atol(e); if (v >= 256) CHUNK = (size_t)v; }
-    const size_t halo = kmax - 1;
-    PinnedBuf pin[2];
-    DevBuf dseq[2];
-    hipEvent_t done[2];
-    for (int i = 0; i < 2; ++i) {
-        pin[i].reserve(CHUNK + halo + 64);
-        dseq[i].reserve(CHUNK + halo + 64);
-        hip_check(hipEventCreateWithFlags(&done[i], hipEventDisableTiming), "hipEventCreate");
-    }
+    static IngestScratch scratch;                   // guarded by the context mutex
+    scratch.prepare(CHUNK);
+    const int halo = (int)kmax - 1;
+
     struct Acc {                       // per sketch: unordered kept hashes since the last flush
         DevBuf out, cnt;
         size_t cap = 0;
@@ -133,6 +242,10 @@ inline void sketch_file_into(std::vector<KmerMinHash*>& mhs, const std::string& 
     };
     std::vector<Acc> acc(mhs.size());
     for (auto& a : acc) { a.cnt.reserve(64); hip_check(hipMemsetAsync(a.cnt.p, 0, 64, st), "memset"); }
+    struct FreeAcc {
+        std::vector<Acc>& v;
+        ~FreeAcc() { for (auto& a : v) { if (a.out.p) (void)hipFree(a.out.p); if (a.cnt.p) (void)hipFree(a.cnt.p); a.out.p = a.cnt.p = nullptr; } }
+    } free_acc{acc};
 
     // flush: sort + unique (+ multiplicities) what has accumulated, merge it into the host container
     auto flush = [&](size_t s) {
@@ -171,31 +284,75 @@ inline void sketch_file_into(std::vector<KmerMinHash*>& mhs, const std::string& 
         mh.add_sorted_batch(hs.data(), mh.track_abundance ? cs.data() : nullptr, hs.size());
     };
 
-    SeqFileReader rd(path);
-    std::vector<uint8_t> carry;        // last kmax-1 bytes of the previous chunk
-    bool pending[2] = {false, false};
+    // device scalars: [0,4) parser carry, [8,16) compacted length of this chunk, [16,24) records
+    uint8_t* d_carry = scratch.small.as<uint8_t>();
+    unsigned long long* d_n = reinterpret_cast<unsigned long long*>(scratch.small.as<uint8_t>() + 8);
+    unsigned long long* d_records = d_n + 1;
+    hip_check(hipMemsetAsync(scratch.small.p, 0, 64, st), "memset");
+    for (int b = 0; b < 2; ++b)                      // nothing precedes the first chunk: a halo of separators
+        hip_check(hipMemsetAsync(scratch.comp[b].p, '\n', IngestScratch::HALO, st), "memset");
+    hip_check(hipStreamSynchronize(st), "sync");     // the copy stream must not race these
+
+    const bool trace = getenv("SMG_INGEST_TRACE") != nullptr;
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_start = now();
+    double t_wait = 0, t_sync = 0;
+    RawChunkSource src(path, CHUNK, scratch.ring);
     constexpr size_t FLUSH_AT = (size_t)64 << 20;            // entries; keeps scratch bounded on huge inputs
-    for (int b = 0;; b ^= 1) {
-        if (pending[b]) { hip_check(hipEventSynchronize(done[b]), "event sync"); pending[b] = false; }
-        memcpy(pin[b].p, carry.data(), carry.size());
-        const size_t got = rd.fill(pin[b].p + carry.size(), CHUNK);
-        if (got == 0) break;
-        const size_t len = carry.size() + got;
-        hip_check(hipMemcpyAsync(dseq[b].p, pin[b].p, len, hipMemcpyHostToDevice, st), "H2D");
+    int fastq = -1;
+    uint64_t total_kept = 0;
+    bool used[2] = {false, false};
+    // the copy of chunk seq+1 is queued before chunk seq is parsed, so the copy engine never waits for the host
+    struct Staged { const uint8_t* data = nullptr; size_t len = 0; bool ok = false; };
+    auto stage = [&](int64_t seq) -> Staged {
+        Staged c;
+        const double t0 = now();
+        c.ok = src.wait(seq, &c.data, &c.len);
+        t_wait += now() - t0;
+        if (!c.ok) return c;
+        const int b = (int)(seq & 1);
+        if (used[b]) hip_check(hipStreamWaitEvent(scratch.copy_stream, scratch.consumed[b], 0), "wait");   // parse of seq-2 read raw[b]
+        hip_check(hipMemcpyAsync(scratch.raw[b].p, c.data, c.len, hipMemcpyHostToDevice, scratch.copy_stream), "H2D");
+        hip_check(hipEventRecord(scratch.copied[b], scratch.copy_stream), "record");
+        return c;
+    };
+    Staged cur = stage(0);
+    for (int64_t seq = 0; cur.ok; ++seq) {
+        const int b = (int)(seq & 1);
+        const size_t len = cur.len;
+        if (fastq < 0) {                                      // format by the first byte of the (inflated) file
+            fastq = cur.data[0] == '@' ? 1 : 0;
+            const uint8_t init[4] = {(uint8_t)(fastq ? 3 : 1), 1, 0, 0};
+            hip_check(hipMemcpyAsync(d_carry, init, 4, hipMemcpyHostToDevice, st), "H2D");
+            hip_check(hipStreamSynchronize(st), "sync");
+        }
+        // compute stream: parse + compact behind the halo that the previous chunk left in comp[b]
+        hip_check(hipStreamWaitEvent(st, scratch.copied[b], 0), "wait");
+        uint8_t* comp = scratch.comp[b].as<uint8_t>() + IngestScratch::HALO;
+        hip_check(fastx_compact_launch(scratch.raw[b].as<uint8_t>(), len, fastq, d_carry, scratch.state.as<uint8_t>(), comp,
+                                       d_n, d_records, scratch.temp.p, scratch.temp_bytes, st), "fastx");
+        hip_check(hipEventRecord(scratch.consumed[b], st), "record");
+        used[b] = true;
+        const Staged next = stage(seq + 1);                   // raw[b^1] was consumed by the parse of chunk seq-1; queued
+                                                              // before the (blocking) read-backs below
+        unsigned long long n_kept = 0;
+        hip_check(hipMemcpyAsync(&n_kept, d_n, 8, hipMemcpyDeviceToHost, st), "D2H");
+        for (auto& a : acc) hip_check(hipMemcpyAsync(&a.count, a.cnt.p, 8, hipMemcpyDeviceToHost, st), "D2H");
+        const double t1 = now();
+        hip_check(hipStreamSynchronize(st), "sync");          // also: every launch of the previous chunk is done
+        t_sync += now() - t1;
+        src.release(seq);                                     // the copy is complete: the pinned slot can be refilled
+        total_kept += n_kept;
         for (size_t s = 0; s < mhs.size(); ++s) {
             KmerMinHash& mh = *mhs[s];
             Acc& a = acc[s];
             if (mh.num == 0 && mh.max_hash == 0) continue;
             const uint32_t k = mh.ksize;
-            // this sketch only needs k-1 bytes of overlap: skip the rest of the carried prefix so that no
-            // k-mer is hashed in two chunks (matters for abundances)
-            const size_t skip = carry.size() > (size_t)(k - 1) ? carry.size() - (k - 1) : 0;
-            const size_t slen = len - skip;
+            const size_t slen = (size_t)(k - 1) + (size_t)n_kept;   // this sketch's halo is its own k-1 bytes
+            if (slen < k) continue;
             const uint64_t thr = mh.max_hash ? mh.max_hash : ~0ull;
             const double frac = (double)thr / 18446744073709551616.0;
             const size_t expect = std::min(slen, (size_t)((double)slen * frac * 1.5 + 8.0 * std::sqrt((double)slen * frac + 1.0)) + 4096);
-            hip_check(hipMemcpyAsync(&a.count, a.cnt.p, 8, hipMemcpyDeviceToHost, st), "D2H");
-            hip_check(hipStreamSynchronize(st), "sync");
             if (a.count > a.cap) throw err_internal("sketch output overflow while ingesting " + path);
             if (a.count && (mh.num != 0 || a.count + expect > FLUSH_AT)) flush(s);
             const size_t need = (size_t)a.count + expect;
@@ -209,22 +366,25 @@ inline void sketch_file_into(std::vector<KmerMinHash*>& mhs, const std::string& 
                 a.out = bigger; bigger.p = nullptr; bigger.cap = 0;
                 a.cap = ncap;
             }
-            hip_check(sketch_dna_launch(dseq[b].as<uint8_t>() + skip, slen, k, mh.seed, thr, a.out.as<uint64_t>(),
+            hip_check(sketch_dna_launch(comp - (k - 1), slen, k, mh.seed, thr, a.out.as<uint64_t>(),
                                         a.cnt.as<unsigned long long>(), a.cap, st), "sketch_dna");
         }
-        hip_check(hipEventRecord(done[b], st), "event record");
-        pending[b] = true;
-        const size_t keep = std::min(halo, len);             // the next chunk starts with these bytes
-        carry.assign(pin[b].p + len - keep, pin[b].p + len);
+        // the next chunk's halo: the last kmax-1 bytes of the stream so far
+        hip_check(fastx_halo_launch(comp, d_n, halo, scratch.comp[b ^ 1].as<uint8_t>() + IngestScratch::HALO - halo, st), "halo");
+        cur = next;
     }
-    for (int i = 0; i < 2; ++i)
-        if (pending[i]) hip_check(hipEventSynchronize(done[i]), "event sync");
-    if (n_records) *n_records = rd.n_records;
-    if (n_bases) *n_bases = rd.n_bases;
+    unsigned long long recs = 0;
+    hip_check(hipMemcpyAsync(&recs, d_records, 8, hipMemcpyDeviceToHost, st), "D2H");
+    hip_check(hipStreamSynchronize(st), "sync");
+    hip_check(hipStreamSynchronize(scratch.copy_stream), "sync");
+    const double t_loop = now();
+    if (n_records) *n_records = recs;
+    if (n_bases) *n_bases = total_kept - recs;               // one separator byte per record is in the stream
     for (size_t s = 0; s < mhs.size(); ++s)
         if (acc[s].cnt.p && !(mhs[s]->num == 0 && mhs[s]->max_hash == 0)) flush(s);
-    for (auto& a : acc) { if (a.out.p) (void)hipFree(a.out.p); if (a.cnt.p) (void)hipFree(a.cnt.p); a.out.p = a.cnt.p = nullptr; }
-    for (int i = 0; i < 2; ++i) { (void)hipEventDestroy(done[i]); if (dseq[i].p) (void)hipFree(dseq[i].p); dseq[i].p = nullptr; }
+    if (trace)
+        fprintf(stderr, "[ingest] %s: loop %.3f s (waiting for the reader %.3f s, for the GPU %.3f s), final flush %.3f s\n",
+                path.c_str(), t_loop - t_start, t_wait, t_sync, now() - t_loop);
 }
 
 }  // namespace smg
