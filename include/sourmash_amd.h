@@ -105,6 +105,10 @@ SourmashStr sourmash_str_from_cstr(const char *s);
 
 /* ---- include/sourmash.h:133 (ffi/mod.rs:22-31; lib.rs:57-59): MurmurHash3_x64_128 h1 ---- */
 uint64_t hash_murmur(const char *kmer, uint64_t seed);
+/* include/sourmash.h:416-418,467 -- residue helpers of the protein / dayhoff / hp sketches */
+char sourmash_aa_to_dayhoff(char aa);
+char sourmash_aa_to_hp(char aa);
+char sourmash_translate_codon(const char *codon);
 
 /* ---- compute parameters: include/sourmash.h:89-131 (ffi/cmd/compute.rs:1-170) ---- */
 SourmashComputeParameters *computeparams_new(void);

@@ -59,6 +59,11 @@ def lib():
         "orc_mh_add_many": (None, [vp, vp, u64]),
         "orc_mh_remove_many": (None, [vp, vp, u64]),
         "orc_mh_add_sequence": (C.c_int64, [vp, C.c_char_p, u64, C.c_int]),
+        "orc_mh_add_protein": (None, [vp, C.c_char_p, u64]),
+        "orc_translate_codon": (C.c_uint8, [C.c_uint8, C.c_uint8, C.c_uint8]),
+        "orc_aa_to_dayhoff": (C.c_uint8, [C.c_uint8]),
+        "orc_aa_to_hp": (C.c_uint8, [C.c_uint8]),
+        "orc_seq_to_hashes_protein": (u64, [C.c_char_p, u64, C.c_uint32, C.c_uint32, u64, C.c_int, vp]),
         "orc_mh_check_compatible": (C.c_uint32, [vp, vp]),
         "orc_mh_merge": (C.c_uint32, [vp, vp]),
         "orc_intersection_size": (u64, [vp, u64, vp, u64, u64p]),
@@ -131,6 +136,31 @@ def seq_to_hashes(seq, ksize, seed=42, force=False, bad_kmers_as_zeroes=False):
     if force and bad_kmers_as_zeroes:
         return hs
     return [h for h in hs if h != 0]
+
+
+HF_BY_MOLTYPE = {"dna": 1, "protein": 2, "dayhoff": 3, "hp": 4}
+
+
+def seq_to_hashes_protein(seq, ksize, moltype="protein", seed=42, is_protein=True):
+    """Hashes of every residue k-mer (ksize = residues; signature.rs:307-393): `seq` holds residues
+    (is_protein) or DNA that is translated in six frames."""
+    b = _as_bytes(seq)
+    hf = HF_BY_MOLTYPE[moltype.lower()]
+    n = lib().orc_seq_to_hashes_protein(b, len(b), ksize * 3, hf, seed, int(is_protein), None)
+    out = np.zeros(max(n, 1), dtype=np.uint64)
+    lib().orc_seq_to_hashes_protein(b, len(b), ksize * 3, hf, seed, int(is_protein), _ptr(out))
+    return out[:n]
+
+
+def translate_codon(codon):
+    c = _as_bytes(codon).upper()
+    if len(c) == 1:
+        return "X"                       # encodings.rs:309-311
+    if len(c) == 2:
+        c += b"N"
+    if len(c) != 3:
+        raise ValueError(f"{len(c)}")
+    return chr(lib().orc_translate_codon(c[0], c[1], c[2]))
 
 
 def sketch_dna_bulk(buf, ksize, seed=42, max_hash=0, scaled=None, nthreads=1):
@@ -272,6 +302,10 @@ class OracleMinHash:
     def remove_many(self, hs):
         a = np.ascontiguousarray(hs, dtype=np.uint64)
         lib().orc_mh_remove_many(self._p, _ptr(a), a.size)
+
+    def add_protein(self, seq):
+        b = _as_bytes(seq)
+        lib().orc_mh_add_protein(self._p, b, len(b))
 
     def add_sequence(self, seq, force=False):
         b = _as_bytes(seq)

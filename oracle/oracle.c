@@ -172,6 +172,94 @@ ORC_API int64_t orc_seq_to_hashes_dna(const uint8_t *seq, uint64_t len, uint32_t
 }
 
 /* ------------------------------------------------------------------------ */
+/* seq -> hashes, protein / dayhoff / hp branches.                           */
+/* reference: src/core/src/encodings.rs:103-368 (codon table incl. the       */
+/* third-position-N entries, dayhoff and hp alphabets, unknown -> 'X',       */
+/* to_aa drops a trailing partial codon), src/core/src/signature.rs:307-393  */
+/* (translate: frames 0..2, forward then reverse complement per frame, every */
+/* window hashed -- no validity test in this mode; protein input: windows of */
+/* the upper-cased residues, mapped first for dayhoff / hp).                 */
+/* hash_function: 2 protein, 3 dayhoff, 4 hp (include/sourmash.h:11-17).     */
+/* ------------------------------------------------------------------------ */
+static int nt_code(uint8_t c) { return c == 'A' ? 0 : c == 'C' ? 1 : c == 'G' ? 2 : c == 'T' ? 3 : c == 'N' ? 4 : 5; }
+
+ORC_API uint8_t orc_translate_codon(uint8_t a, uint8_t b, uint8_t c) {
+    /* rows TCAG as in the standard table, written out by first/second base */
+    static const char *TABLE[4][4] = {
+        /* A */ {"KNKN", "TTTT", "RSRS", "IIMI"},   /* AA* AC* AG* AT*  (third base A C G T) */
+        /* C */ {"QHQH", "PPPP", "RRRR", "LLLL"},
+        /* G */ {"EDED", "AAAA", "GGGG", "VVVV"},
+        /* T */ {"*Y*Y", "SSSS", "*CWC", "LFLF"},
+    };
+    const int x = nt_code(a), y = nt_code(b), z = nt_code(c);
+    if (x > 3 || y > 3 || z > 4) return 'X';
+    const char *row = TABLE[x][y];
+    if (z == 4)                                   /* ..N: only the four-fold degenerate families are in the table */
+        return (row[0] == row[1] && row[1] == row[2] && row[2] == row[3]) ? (uint8_t)row[0] : 'X';
+    return (uint8_t)row[z];
+}
+
+ORC_API uint8_t orc_aa_to_dayhoff(uint8_t aa) {
+    switch (aa) {
+    case 'C': return 'a';
+    case 'A': case 'G': case 'P': case 'S': case 'T': return 'b';
+    case 'D': case 'E': case 'N': case 'Q': return 'c';
+    case 'H': case 'K': case 'R': return 'd';
+    case 'I': case 'L': case 'M': case 'V': return 'e';
+    case 'F': case 'W': case 'Y': return 'f';
+    case '*': return '*';
+    default: return 'X';
+    }
+}
+
+ORC_API uint8_t orc_aa_to_hp(uint8_t aa) {
+    switch (aa) {
+    case 'A': case 'F': case 'G': case 'I': case 'L': case 'M': case 'P': case 'V': case 'W': case 'Y': return 'h';
+    case 'N': case 'C': case 'S': case 'T': case 'D': case 'E': case 'R': case 'H': case 'K': case 'Q': return 'p';
+    case '*': return '*';
+    default: return 'X';
+    }
+}
+
+static uint8_t aa_encode(uint8_t aa, uint32_t hf) { return hf == 3 ? orc_aa_to_dayhoff(aa) : hf == 4 ? orc_aa_to_hp(aa) : aa; }
+
+/* Hashes of every residue k-mer, in the reference's order.  ksize is the STORED ksize (3 x residues).  out must
+ * hold the return value of a call with out == NULL.  is_protein: seq holds residues; else DNA to translate. */
+ORC_API uint64_t orc_seq_to_hashes_protein(const uint8_t *seq, uint64_t len, uint32_t ksize, uint32_t hf,
+                                           uint64_t seed, int is_protein, uint64_t *out) {
+    const uint64_t k = ksize / 3;                                  /* signature.rs:199-203 */
+    uint64_t n = 0;
+    if (k == 0 || len < k) return 0;
+    if (is_protein) {
+        uint8_t *aa = (uint8_t *)malloc(len);
+        for (uint64_t i = 0; i < len; ++i) aa[i] = aa_encode(ascii_upper(seq[i]), hf);
+        for (uint64_t i = 0; i + k <= len; ++i, ++n)
+            if (out) out[n] = orc_hash_murmur(aa + i, k, seed);
+        free(aa);
+        return n;
+    }
+    if (len < 3 * k) return 0;                                     /* signature.rs:259-261 */
+    uint8_t *up = (uint8_t *)malloc(len), *rc = (uint8_t *)malloc(len), *aa = (uint8_t *)malloc(len / 3 + 1);
+    for (uint64_t i = 0; i < len; ++i) up[i] = ascii_upper(seq[i]);
+    for (uint64_t i = 0; i < len; ++i) {                           /* encodings.rs:85-101: unknown bases complement to NUL */
+        const uint8_t c = up[len - 1 - i];
+        rc[i] = c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : c == 'T' ? 'A' : c == 'N' ? 'N' : 0;
+    }
+    for (int frame = 0; frame < 3; ++frame) {
+        for (int strand = 0; strand < 2; ++strand) {
+            const uint8_t *s = strand ? rc : up;
+            uint64_t na = 0;
+            for (uint64_t i = (uint64_t)frame; i + 3 <= len; i += 3)
+                aa[na++] = aa_encode(orc_translate_codon(s[i], s[i + 1], s[i + 2]), hf);
+            for (uint64_t i = 0; i + k <= na; ++i, ++n)
+                if (out) out[n] = orc_hash_murmur(aa + i, k, seed);
+        }
+    }
+    free(up); free(rc); free(aa);
+    return n;
+}
+
+/* ------------------------------------------------------------------------ */
 /* Sketch container (Vec-backed KmerMinHash semantics).                      */
 /* reference: src/core/src/sketch/minhash.rs:36-913.                         */
 /* ------------------------------------------------------------------------ */
@@ -289,7 +377,21 @@ ORC_API void orc_mh_remove_many(orc_mh *m, const uint64_t *hs, uint64_t n) {
 /* add_sequence: SigsTrait default, src/core/src/signature.rs:38-58: walk the
  * k-mer hashes, skip hash == 0 (:50), add the rest; on error the earlier
  * hashes stay added.  Returns 0, or -1 - kmer_index on InvalidDNA. */
+static void mh_add_protein_hashes(orc_mh *m, const uint8_t *seq, uint64_t len, int is_protein) {
+    const uint64_t n = orc_seq_to_hashes_protein(seq, len, m->ksize, m->hash_function, m->seed, is_protein, NULL);
+    if (!n) return;
+    uint64_t *hs = (uint64_t *)malloc(n * 8);
+    orc_seq_to_hashes_protein(seq, len, m->ksize, m->hash_function, m->seed, is_protein, hs);
+    for (uint64_t i = 0; i < n; ++i)
+        if (hs[i] != 0) orc_mh_add_hash(m, hs[i]);
+    free(hs);
+}
+
+/* signature.rs:60-80 */
+ORC_API void orc_mh_add_protein(orc_mh *m, const uint8_t *seq, uint64_t len) { mh_add_protein_hashes(m, seq, len, 1); }
+
 ORC_API int64_t orc_mh_add_sequence(orc_mh *m, const uint8_t *seq, uint64_t len, int force) {
+    if (m->hash_function != 1) { mh_add_protein_hashes(m, seq, len, 0); return 0; }   /* translate, no validity test */
     if (len < m->ksize) return 0;
     uint64_t nk = len - m->ksize + 1;
     uint64_t *hs = (uint64_t *)malloc(nk * 8);

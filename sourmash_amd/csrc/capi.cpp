@@ -16,6 +16,7 @@
 #include "device_ctx.hpp"
 #include "ingest.hpp"
 #include "murmur3.hpp"
+#include "residues.hpp"
 #include "signature_host.hpp"
 
 using namespace smg;
@@ -85,10 +86,23 @@ inline uint64_t keep_threshold(const KmerMinHash& mh) { return mh.max_hash ? mh.
 // The DNA add_sequence path (signature.rs:38-58 + :246-306) on the GPU.
 // force == false: the walk is streaming in the reference, so the hashes of every
 // k-mer before the first offending one are added before InvalidDNA is raised.
+// protein / dayhoff / hp sketches: residues (is_protein) or DNA translated in six frames; no validity test in
+// either mode (signature.rs:307-393), so `force` plays no role
+void add_residue_kmers(KmerMinHash& mh, const uint8_t* seq, size_t len, bool is_protein) {
+    if (mh.num == 0 && mh.max_hash == 0) return;
+    if (mh.ksize / 3 == 0 || len < mh.ksize / 3) return;
+    if (mh.is_dna())                                                // signature.rs:367-384: no alphabet to map to
+        throw Error(E_INVALID_HASH_FUNCTION, "Invalid hash function: \"DNA\"");
+    DeviceCtx& ctx = DeviceCtx::get();
+    std::lock_guard<std::mutex> g(ctx.mutex());
+    std::vector<uint64_t> hs, cs;
+    ctx.protein_sketch_host(seq, len, mh.ksize, mh.hash_function, mh.seed, is_protein, keep_threshold(mh),
+                            mh.track_abundance, mh.num, hs, cs);
+    mh.add_sorted_batch(hs.data(), mh.track_abundance ? cs.data() : nullptr, hs.size());
+}
+
 void add_sequence_dna(KmerMinHash& mh, const uint8_t* seq, size_t len, bool force) {
-    if (!mh.is_dna())
-        throw err_internal("sourmash_amd accelerates DNA sketches only; protein/dayhoff/hp sketching is out of scope "
-                           "(SURVEY.md section 8f)");
+    if (!mh.is_dna()) { add_residue_kmers(mh, seq, len, false); return; }
     const uint32_t k = mh.ksize;
     if (len < k || k == 0) return;                                  // signature.rs:206-210
     if (mh.num == 0 && mh.max_hash == 0) return;                    // sketch that can never hold anything
@@ -182,6 +196,19 @@ SourmashStr sourmash_err_get_backtrace(void) { SourmashStr s = {nullptr, 0, fals
 void sourmash_str_free(SourmashStr* s) {
     if (s && s->owned && s->data) { free(s->data); s->data = nullptr; s->len = 0; s->owned = false; }
 }
+// module-level residue helpers (ffi/mod.rs; encodings.rs:299-347)
+char sourmash_aa_to_dayhoff(char aa) { return (char)aa_to_dayhoff((uint8_t)aa); }
+char sourmash_aa_to_hp(char aa) { return (char)aa_to_hp((uint8_t)aa); }
+char sourmash_translate_codon(const char* codon) {
+    return landing<char>([&]() -> char {
+        const size_t n = codon ? strlen(codon) : 0;
+        if (n == 1) return 'X';                                                 // encodings.rs:309-311
+        if (n == 2) return (char)translate_codon(ascii_upper((uint8_t)codon[0]), ascii_upper((uint8_t)codon[1]), 'N');
+        if (n == 3) return (char)translate_codon(ascii_upper((uint8_t)codon[0]), ascii_upper((uint8_t)codon[1]),
+                                                 ascii_upper((uint8_t)codon[2]));
+        throw Error(E_INVALID_CODON_LENGTH, std::to_string(n));
+    });
+}
 SourmashStr sourmash_str_from_cstr(const char* s) { return make_str(s ? s : ""); }
 
 uint64_t hash_murmur(const char* kmer, uint64_t seed) {           // ffi/mod.rs:22-31
@@ -243,10 +270,26 @@ const uint64_t* kmerminhash_seq_to_hashes(SourmashKmerMinHash* p, const char* se
                                           bool bad_kmers_as_zeroes, bool is_protein, uintptr_t* size) {
     return landing<const uint64_t*>([&]() -> const uint64_t* {
         KmerMinHash& mh = *MH(p);
-        if (is_protein || !mh.is_dna())
-            throw err_internal("sourmash_amd accelerates DNA sketches only; protein k-mers are out of scope");
         const uint8_t* seq = (const uint8_t*)sequence;
         std::vector<uint64_t> out;
+        if (is_protein || !mh.is_dna()) {
+            const uint32_t kr = mh.ksize / 3;
+            if (kr == 0 || insize < kr || (!is_protein && insize < (uintptr_t)kr * 3)) return slice_out(out, size);
+            if (mh.is_dna()) throw Error(E_INVALID_HASH_FUNCTION, "Invalid hash function: \"DNA\"");
+            std::vector<uint64_t> hs;
+            {
+                DeviceCtx& ctx = DeviceCtx::get();
+                std::lock_guard<std::mutex> g(ctx.mutex());
+                ctx.protein_hashes_host(seq, insize, mh.ksize, mh.hash_function, mh.seed, is_protein, hs);
+            }
+            const bool zeros = force && bad_kmers_as_zeroes;
+            // the translate iterator brackets its buffer with two Ok(0) markers (signature.rs:330-348), which only
+            // the keep-zeroes mode lets through (ffi/minhash.rs:76-84)
+            if (zeros && !is_protein) out.push_back(0);
+            for (uint64_t h : hs) if (h != 0 || zeros) out.push_back(h);
+            if (zeros && !is_protein) out.push_back(0);
+            return slice_out(out, size);
+        }
         const uint32_t k = mh.ksize;
         if (insize >= k && k != 0) {
             DeviceCtx& ctx = DeviceCtx::get();
@@ -285,8 +328,11 @@ void kmerminhash_add_word(SourmashKmerMinHash* p, const char* word) {           
     if (!word) return;
     MH(p)->add_hash(mmh3_h1_bytes((const uint8_t*)word, strlen(word), MH(p)->seed));
 }
-void kmerminhash_add_protein(SourmashKmerMinHash*, const char*) {
-    landing_void([&] { throw err_internal("protein sketching is out of scope of sourmash_amd (SURVEY.md section 8f)"); });
+void kmerminhash_add_protein(SourmashKmerMinHash* p, const char* sequence) {
+    landing_void([&] {
+        if (!sequence) throw err_internal("null sequence");
+        add_residue_kmers(*MH(p), (const uint8_t*)sequence, strlen(sequence), true);
+    });
 }
 void kmerminhash_remove_hash(SourmashKmerMinHash* p, uint64_t h) { MH(p)->remove_hash(h); }
 void kmerminhash_remove_many(SourmashKmerMinHash* p, const uint64_t* hs, uintptr_t n) {
@@ -434,8 +480,12 @@ void signature_add_sequence(SourmashSignature* p, const char* sequence, bool for
         for (auto& mh : SIG(p)->sketches) add_sequence_dna(mh, (const uint8_t*)sequence, len, force);
     });
 }
-void signature_add_protein(SourmashSignature*, const char*) {
-    landing_void([&] { throw err_internal("protein sketching is out of scope of sourmash_amd (SURVEY.md section 8f)"); });
+void signature_add_protein(SourmashSignature* p, const char* sequence) {
+    landing_void([&] {                                                          // signature.rs:679-697
+        if (!sequence) throw err_internal("null sequence");
+        const size_t len = strlen(sequence);
+        for (auto& mh : SIG(p)->sketches) add_residue_kmers(mh, (const uint8_t*)sequence, len, true);
+    });
 }
 void signature_set_name(SourmashSignature* p, const char* name) { landing_void([&] { if (name) SIG(p)->name = std::string(name); }); }
 void signature_set_filename(SourmashSignature* p, const char* name) { landing_void([&] { if (name) SIG(p)->filename = std::string(name); }); }
@@ -535,6 +585,8 @@ bool smgpu_available(void) { return smgpu_device_count() > 0; }
 void smgpu_minhash_add_buffer(SourmashKmerMinHash* p, const char* buf, uintptr_t len, bool force) {
     landing_void([&] {
         if (!buf && len) throw err_internal("null buffer");
+        if (!MH(p)->is_dna())     // records joined in one buffer would shift the reading frames of the later records
+            throw err_internal("smgpu_minhash_add_buffer takes DNA sketches; feed protein sketches record by record");
         add_sequence_dna(*MH(p), (const uint8_t*)buf, len, force);
     });
 }

@@ -21,6 +21,18 @@ hipError_t kmer_hashes_launch(const uint8_t* d_seq, uint64_t len, uint32_t k, ui
 // *d_first = min(*d_first, position of the first byte outside ACGTacgt)
 hipError_t first_invalid_launch(const uint8_t* d_seq, uint64_t len, unsigned long long* d_first, hipStream_t stream);
 
+// ---- protein.hip (protein / dayhoff / hp sketches) ---------------------------------------------
+// d_aa[i] = alphabet(upper(d_seq[i]))  (hash_function 2 protein, 3 dayhoff, 4 hp)
+hipError_t residues_launch(const uint8_t* d_seq, uint64_t len, uint32_t hash_function, uint8_t* d_aa, hipStream_t stream);
+// six-frame translation of DNA: segments frame0 fwd, frame0 rc, frame1 fwd, ... each followed by a 0xFF separator;
+// d_aa must hold translated_bytes(len) bytes
+uint64_t translated_bytes(uint64_t len);
+hipError_t translate_launch(const uint8_t* d_seq, uint64_t len, uint32_t hash_function, uint8_t* d_aa, hipStream_t stream);
+// hashes of the windows of k residues that do not touch a separator: appended (1 <= h <= thr; *d_count += n) or,
+// dense, d_out[i] = hash of the window starting at i (d_out pre-zeroed, cap = number of entries)
+hipError_t residue_windows_launch(const uint8_t* d_aa, uint64_t n, uint32_t k, uint64_t seed, uint64_t thr, uint64_t* d_out,
+                                  unsigned long long* d_count, uint64_t cap, bool dense, hipStream_t stream);
+
 // ---- device_sort.hip ------------------------------------------------------------
 size_t sort_unique_temp_bytes(uint64_t n);
 // keys[0,n) -> sorted unique in out[0,*d_n_out); if d_counts != nullptr also the

@@ -183,8 +183,106 @@ class DeviceCtx {
         return st;
     }
 
+    // ---- protein / dayhoff / hp sketches (protein.hip) ----------------------------------------------
+    // Residue k-mers of `seq` (residues if is_protein, else DNA translated in six frames): sorted unique kept
+    // hashes (+ multiplicities).  ksize is the stored ksize (3 x residues).
+    void protein_sketch_host(const uint8_t* seq, size_t len, uint32_t ksize, uint32_t hf, uint64_t seed, bool is_protein,
+                             uint64_t thr, bool want_counts, size_t limit, std::vector<uint64_t>& hashes,
+                             std::vector<uint64_t>& counts) {
+        hashes.clear(); counts.clear();
+        const uint32_t k = ksize / 3;
+        const size_t n_aa = residues_to_device(seq, len, k, hf, is_protein);
+        if (n_aa < k) return;
+        const size_t nw = n_aa - k + 1;
+        const double expect = (double)nw * ((double)thr / 18446744073709551616.0);
+        size_t cap = (size_t)(expect * 1.5 + 8.0 * std::sqrt(expect + 1.0)) + 4096;
+        if (cap > nw) cap = nw;
+        unsigned long long* d_cnt = scalars_.as<unsigned long long>();
+        unsigned long long kept = 0;
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            out_.reserve(cap * 8);
+            hip_check(hipMemsetAsync(d_cnt, 0, 16, stream_), "memset");
+            hip_check(residue_windows_launch(aa_.as<uint8_t>(), n_aa, k, seed, thr, out_.as<uint64_t>(), d_cnt, cap, false,
+                                             stream_), "residue_windows");
+            hip_check(hipMemcpyAsync(&kept, d_cnt, 8, hipMemcpyDeviceToHost, stream_), "D2H");
+            hip_check(hipStreamSynchronize(stream_), "sync");
+            if (kept <= cap) break;
+            cap = (size_t)kept;
+        }
+        if (kept == 0) return;
+        sorted_unique_to_host(kept, thr, want_counts, limit, hashes, counts);
+    }
+
+    // One hash per residue window in the reference's iteration order (signature.rs:307-393): for translated
+    // DNA frame 0 forward, frame 0 reverse complement, frame 1 forward, ...
+    void protein_hashes_host(const uint8_t* seq, size_t len, uint32_t ksize, uint32_t hf, uint64_t seed, bool is_protein,
+                             std::vector<uint64_t>& out) {
+        out.clear();
+        const uint32_t k = ksize / 3;
+        const size_t n_aa = residues_to_device(seq, len, k, hf, is_protein);
+        if (n_aa < k) return;
+        const size_t nw = n_aa - k + 1;
+        out_.reserve(nw * 8);
+        hip_check(hipMemsetAsync(out_.p, 0, nw * 8, stream_), "memset");
+        hip_check(residue_windows_launch(aa_.as<uint8_t>(), n_aa, k, seed, ~0ull, out_.as<uint64_t>(), nullptr, nw, true,
+                                         stream_), "residue_windows");
+        std::vector<uint64_t> dense(nw);
+        hip_check(hipMemcpyAsync(dense.data(), out_.p, nw * 8, hipMemcpyDeviceToHost, stream_), "D2H");
+        hip_check(hipStreamSynchronize(stream_), "sync");
+        if (is_protein) { out.swap(dense); return; }
+        size_t start = 0;                                          // drop the windows that straddle a separator
+        for (int s = 0; s < 6; ++s) {
+            const size_t na = (len - (size_t)(s >> 1)) / 3;
+            if (na >= k) out.insert(out.end(), dense.begin() + start, dense.begin() + start + (na - k + 1));
+            start += na + 1;
+        }
+    }
+
   private:
     DeviceCtx() = default;
+
+    // residues (mapped to the sketch's alphabet) of `seq` on the device -> number of bytes in aa_ (0: nothing to hash)
+    size_t residues_to_device(const uint8_t* seq, size_t len, uint32_t k, uint32_t hf, bool is_protein) {
+        if (k == 0 || len < k) return 0;                             // signature.rs:199-210
+        if (!is_protein && len < (size_t)k * 3) return 0;           // signature.rs:259-261
+        upload_seq(seq, len);
+        if (is_protein) {
+            aa_.reserve(len + 64);
+            hip_check(residues_launch(seq_.as<uint8_t>(), len, hf, aa_.as<uint8_t>(), stream_), "residues");
+            return len;
+        }
+        const size_t total = (size_t)translated_bytes(len);
+        aa_.reserve(total + 64);
+        hip_check(translate_launch(seq_.as<uint8_t>(), len, hf, aa_.as<uint8_t>(), stream_), "translate");
+        return total;
+    }
+
+    // out_[0,kept) -> sorted unique (+ counts) on the host, truncated to `limit` if non-zero
+    void sorted_unique_to_host(unsigned long long kept, uint64_t thr, bool want_counts, size_t limit,
+                               std::vector<uint64_t>& hashes, std::vector<uint64_t>& counts) {
+        unsigned long long* d_cnt = scalars_.as<unsigned long long>();
+        const size_t tb = sort_unique_temp_bytes(kept);
+        temp_.reserve(tb);
+        uniq_.reserve((size_t)kept * 16 + 64);
+        uint64_t* d_u = uniq_.as<uint64_t>();
+        uint64_t* d_c = d_u + kept;
+        int bits = 64;
+        if (thr != ~0ull) { bits = 1; while (bits < 64 && (thr >> bits)) ++bits; }
+        hip_check(sort_unique(out_.as<uint64_t>(), kept, d_u, d_c, (uint64_t*)(d_cnt + 1), temp_.p, tb, bits, stream_),
+                  "sort_unique");
+        unsigned long long nu = 0;
+        hip_check(hipMemcpyAsync(&nu, d_cnt + 1, 8, hipMemcpyDeviceToHost, stream_), "D2H");
+        hip_check(hipStreamSynchronize(stream_), "sync");
+        size_t take = (size_t)nu;
+        if (limit && take > limit) take = limit;        // bottom-k: only the smallest `num` can ever be kept
+        hashes.resize(take);
+        hip_check(hipMemcpyAsync(hashes.data(), d_u, take * 8, hipMemcpyDeviceToHost, stream_), "D2H");
+        if (want_counts) {
+            counts.resize(take);
+            hip_check(hipMemcpyAsync(counts.data(), d_c, take * 8, hipMemcpyDeviceToHost, stream_), "D2H");
+        }
+        hip_check(hipStreamSynchronize(stream_), "sync");
+    }
 
     void upload_seq(const uint8_t* seq, size_t len) {
         seq_.reserve(len + 64);
@@ -213,32 +311,12 @@ class DeviceCtx {
             cap = (size_t)kept;                 // repetitive input beat the estimate: rerun with the exact size
         }
         if (kept == 0) return;
-        const size_t tb = sort_unique_temp_bytes(kept);
-        temp_.reserve(tb);
-        uniq_.reserve((size_t)kept * 16 + 64);
-        uint64_t* d_u = uniq_.as<uint64_t>();
-        uint64_t* d_c = d_u + kept;
-        int bits = 64;
-        if (thr != ~0ull) { bits = 1; while (bits < 64 && (thr >> bits)) ++bits; }
-        hip_check(sort_unique(out_.as<uint64_t>(), kept, d_u, d_c, (uint64_t*)(d_cnt + 1), temp_.p, tb, bits, stream_),
-                  "sort_unique");
-        unsigned long long nu = 0;
-        hip_check(hipMemcpyAsync(&nu, d_cnt + 1, 8, hipMemcpyDeviceToHost, stream_), "D2H");
-        hip_check(hipStreamSynchronize(stream_), "sync");
-        size_t take = (size_t)nu;
-        if (limit && take > limit) take = limit;        // bottom-k: only the smallest `num` can ever be kept
-        hashes.resize(take);
-        hip_check(hipMemcpyAsync(hashes.data(), d_u, take * 8, hipMemcpyDeviceToHost, stream_), "D2H");
-        if (want_counts) {
-            counts.resize(take);
-            hip_check(hipMemcpyAsync(counts.data(), d_c, take * 8, hipMemcpyDeviceToHost, stream_), "D2H");
-        }
-        hip_check(hipStreamSynchronize(stream_), "sync");
+        sorted_unique_to_host(kept, thr, want_counts, limit, hashes, counts);
     }
 
     hipStream_t stream_ = nullptr;
     std::mutex mu_;
-    DevBuf seq_, out_, uniq_, temp_, scalars_, pair_, flags_;
+    DevBuf seq_, aa_, out_, uniq_, temp_, scalars_, pair_, flags_;
 };
 
 }  // namespace smg

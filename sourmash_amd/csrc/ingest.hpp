@@ -219,7 +219,7 @@ struct IngestScratch {
 inline void sketch_file_into(std::vector<KmerMinHash*>& mhs, const std::string& path, uint64_t* n_records,
                              uint64_t* n_bases) {
     for (auto* mh : mhs)
-        if (!mh->is_dna()) throw err_internal("sourmash_amd accelerates DNA sketches only");
+        if (!mh->is_dna()) throw err_internal("the streaming file ingest takes DNA sketches; protein / dayhoff / hp sketches are fed record by record");
     uint32_t kmax = 0;
     for (auto* mh : mhs) kmax = std::max(kmax, mh->ksize);
     if (mhs.empty() || kmax == 0) return;

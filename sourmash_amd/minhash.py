@@ -16,7 +16,8 @@ import numpy as np
 from ._lowlevel import ffi, lib
 from .utils import RustObject, rustcall, decode_str
 
-__all__ = ["get_minhash_default_seed", "get_minhash_max_hash", "hash_murmur", "MinHash", "FrozenMinHash"]
+__all__ = ["get_minhash_default_seed", "get_minhash_max_hash", "hash_murmur", "translate_codon", "MinHash",
+           "FrozenMinHash"]
 
 MINHASH_DEFAULT_SEED = 42
 MINHASH_MAX_HASH = 0xFFFFFFFFFFFFFFFF
@@ -66,6 +67,15 @@ def hash_murmur(kmer, seed=MINHASH_DEFAULT_SEED):
     return lib.hash_murmur(to_bytes(kmer), seed)
 
 
+def translate_codon(codon):
+    "One codon (1-3 bases; a missing third base counts as N) -> residue letter; ValueError for other lengths."
+    from .exceptions import SourmashError
+    try:
+        return rustcall(lib.sourmash_translate_codon, to_bytes(codon)).decode("utf-8")
+    except SourmashError as e:
+        raise ValueError(e.message)
+
+
 def flatten_and_downsample_scaled(mh, *scaled_vals):
     "Flatten and downsample to the max of the given scaled values."
     assert mh.scaled
@@ -113,6 +123,9 @@ class _HashesWrapper(Mapping):
 
     def __setitem__(self, k, v):
         raise RuntimeError("cannot modify hashes directly; use 'add' methods")
+
+
+_DNA_COMPLEMENT = str.maketrans("ACGT", "TGCA")
 
 
 def _u64_array(values):
@@ -222,17 +235,29 @@ class MinHash(RustObject):
             lib.kmerminhash_slice_free(ptr, size.value)
 
     def kmers_and_hashes(self, sequence, *, force=False, is_protein=False):
-        "Yield (k-mer, hash) for every k-mer; invalid k-mers give None when force is set."
-        if self.moltype != "DNA":
-            raise NotImplementedError("sourmash_amd: kmers_and_hashes is implemented for DNA sketches only")
+        """Yield (k-mer, hash) for every k-mer without adding anything; invalid DNA k-mers give None when force
+        is set.  DNA handed to a protein / dayhoff / hp sketch is translated: the k-mers are then the DNA
+        windows of 3 x ksize bases in the order the hashes come (frame by frame, forward strand, then reverse
+        complement)."""
         sequence = sequence.upper()
         hashvals = self.seq_to_hashes(sequence, force=force, is_protein=is_protein, bad_kmers_as_zeroes=force)
         if force:
             hashvals = [None if h == 0 else h for h in hashvals]
-        ksize = self.ksize
-        assert len(hashvals) == max(len(sequence) - ksize + 1, 0)
-        for i, h in enumerate(hashvals):
-            yield sequence[i:i + ksize], h
+        translate = self.moltype != "DNA" and not is_protein
+        if not translate:
+            ksize = self.ksize
+            assert len(hashvals) == max(len(sequence) - ksize + 1, 0)
+            for i, h in enumerate(hashvals):
+                yield sequence[i:i + ksize], h
+            return
+        span = self.ksize * 3
+        assert len(hashvals) == max(len(sequence) - span + 1, 0) * 2
+        revcomp = sequence.translate(_DNA_COMPLEMENT)[::-1]
+        it = iter(hashvals)
+        for frame in (0, 1, 2):
+            for strand in (sequence, revcomp):
+                for start in range(frame, len(strand) - span + 1, 3):
+                    yield strand[start:start + span], next(it)
 
     def add_kmer(self, kmer):
         "Add one k-mer."

@@ -20,7 +20,8 @@ from .minhash import MINHASH_DEFAULT_SEED
 from .signature import SourmashSignature
 from .utils import RustObject, rustcall
 
-DEFAULTS = dict(dna="k=31,scaled=1000,noabund")   # command_sketch.py:25-30 (DNA row; other moltypes are out of scope)
+DEFAULTS = dict(dna="k=31,scaled=1000,noabund", protein="k=10,scaled=200,noabund",      # command_sketch.py:25-30
+                dayhoff="k=16,scaled=200,noabund", hp="k=42,scaled=200,noabund")
 MIN_SCALED, MAX_SCALED = 100, 1e6                 # advisory bounds of sourmash_args.py:61-82 (warnings there, not errors)
 
 
@@ -90,17 +91,18 @@ class ComputeParameters(RustObject):
         "One parameter string layered over the moltype defaults (command_sketch.py:90-186)."
         moltype, params = parse_params_str(params_str)
         moltype = moltype or default_moltype
-        if moltype != "dna":
-            raise ValueError("sourmash_amd sketches DNA only (protein/dayhoff/hp are out of scope, SURVEY.md 8f)")
-        _, merged = parse_params_str(DEFAULTS["dna"])
+        _, merged = parse_params_str(DEFAULTS[moltype])
         if params["ksize"]:
             merged["ksize"] = params["ksize"]
+        if moltype != "dna":
+            merged["ksize"] = [k * 3 for k in merged["ksize"]]      # residues -> stored ksize (command_sketch.py:156)
         for key in ("seed", "track_abundance"):
             if key in params:
                 merged[key] = params[key]
         if "num" in params or "scaled" in params:
             merged["num"], merged["scaled"] = params.get("num", 0), params.get("scaled", 0)
-        return cls(ksizes=merged["ksize"], seed=merged.get("seed", MINHASH_DEFAULT_SEED), dna=True,
+        return cls(ksizes=merged["ksize"], seed=merged.get("seed", MINHASH_DEFAULT_SEED), dna=moltype == "dna",
+                   protein=moltype == "protein", dayhoff=moltype == "dayhoff", hp=moltype == "hp",
                    num_hashes=merged.get("num", 0), track_abundance=merged.get("track_abundance", False),
                    scaled=merged.get("scaled", 0))
 
@@ -181,14 +183,36 @@ def read_records(path):
 
 
 def sketch_records(records, param_str=DEFAULTS["dna"], *, name="", filename="", check_sequence=False,
-                   singleton=False):
+                   singleton=False, moltype="dna", input_is_protein=False):
     """Sketch an iterable of (name, sequence) records.
 
     singleton=False: one SourmashSignature (all ksizes) for the whole input
     (command_sketch.py:741-768); singleton=True: one per record (:712-739).
-    check_sequence=True maps to force=False (cli/sketch/dna.py:42-46)."""
-    params = ComputeParameters.from_param_str(param_str)
+    check_sequence=True maps to force=False (cli/sketch/dna.py:42-46).
+    moltype protein / dayhoff / hp: `sourmash sketch protein` (input_is_protein=True, records are residues) or
+    `sourmash sketch translate` (records are DNA, translated in six frames); one call per record."""
+    params = ComputeParameters.from_param_str(param_str, default_moltype=moltype)
     force = not check_sequence
+    if not params.dna:
+        add = (lambda sig, seq: sig.add_protein(seq)) if input_is_protein else (lambda sig, seq: sig.add_sequence(seq, force))
+        if singleton:
+            out = []
+            for rec_name, seq in records:
+                sig = SourmashSignature.from_params(params)
+                add(sig, seq)
+                sig.name = rec_name
+                if filename:
+                    sig.filename = filename
+                out.append(sig)
+            return out
+        sig = SourmashSignature.from_params(params)
+        for _, seq in records:
+            add(sig, seq)
+        if name:
+            sig.name = name
+        if filename:
+            sig.filename = filename
+        return [sig]
     if singleton:
         out = []
         for rec_name, seq in records:
@@ -235,14 +259,15 @@ def _add_buffer_to_signature(sig, buf):
             rustcall(lib.signature_push_mh, sig._get_objptr(), mh._get_objptr())
 
 
-def sketch_file(path, param_str=DEFAULTS["dna"], *, name=None, check_sequence=False, singleton=False):
+def sketch_file(path, param_str=DEFAULTS["dna"], *, name=None, check_sequence=False, singleton=False, moltype="dna",
+                input_is_protein=False):
     """`sourmash sketch dna -p <param_str> <path>` -> list of SourmashSignature.
 
     Default mode (one signature per file, force=True) runs the native streaming ingest
     (smgpu_signature_add_file: C++ FASTA/FASTQ(.gz) reader -> pinned buffers -> GPU, every ksize in one
     pass); --singleton and --check-sequence go record by record like the reference."""
-    if not singleton and not check_sequence:
-        params = ComputeParameters.from_param_str(param_str)
+    params = ComputeParameters.from_param_str(param_str, default_moltype=moltype)
+    if not singleton and not check_sequence and params.dna:
         sig = SourmashSignature.from_params(params)
         n_records = C.c_uint64(0)
         rustcall(lib.smgpu_signature_add_file, sig._get_objptr(), str(path).encode("utf-8"), C.byref(n_records))
@@ -254,4 +279,4 @@ def sketch_file(path, param_str=DEFAULTS["dna"], *, name=None, check_sequence=Fa
     if name is None and not singleton and recs:
         name = ""
     return sketch_records(recs, param_str, name=name or "", filename=str(path), check_sequence=check_sequence,
-                          singleton=singleton)
+                          singleton=singleton, moltype=moltype, input_is_protein=input_is_protein)

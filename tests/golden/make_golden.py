@@ -57,6 +57,10 @@ FILES.append(("tests/test-data/gather/combined.sig", "gather/combined.sig", "gol
 for name in ["genome-s10.fa.gz.sig", "genome-s11.fa.gz.sig", "genome-s12.fa.gz.sig", "reads-s10-s11.sig", "reads-s10x10-s11.sig"]:
     FILES.append((f"tests/test-data/gather-abund/{name}", f"gather-abund/{name}",
                   "tests/test_sourmash.py:6386-6600 abundance-weighted gather (p_query / p_match / avg_abund columns)"))
+for name, why in (("ecoli.faa", "protein input, tests/test_sourmash_compute.py:811-930"),
+                  ("benchmark.input_prot.sig", "independent restatement of protein-input hashing (utils/compute-input-prot-another-way.py)"),
+                  ("benchmark.prot.sig", "independent restatement of six-frame translation hashing (utils/compute-prot-mh-another-way.py)")):
+    FILES.append((f"tests/test-data/{name}", f"genes/{name}", why))
 FILES.append(("tests/test-data/47+63.fa.sig", "pairs/47+63.fa.sig", "tests/test_search.py:257-590 result-row fixtures"))
 FILES.append(("tests/test-data/track_abund/track_abund.zip", "zips/track_abund.zip",
               "a zip as `sourmash sig cat -o x.zip` writes it: stored signatures/<md5>.sig.gz members + SOURMASH-MANIFEST.csv"))

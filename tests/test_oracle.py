@@ -288,3 +288,72 @@ def test_synth_dna_is_reproducible():
     assert np.array_equal(a[500:], b)
     assert set(np.unique(a).tolist()) <= set(b"ACGT\n")
     assert (a[99::100] == ord("\n")).all() and (a[:99] != ord("\n")).all()
+
+
+# ---- protein / dayhoff / hp: the oracle's restatement, pinned -----------------
+def _prot_mh(moltype, k, **kw):
+    "OracleMinHash with the STORED ksize (3 x residues), like MinHash(..., is_protein=True) does (minhash.py:225-241)"
+    return oracle.OracleMinHash(kw.pop("n", 0), k * 3, hash_function=oracle.HF_BY_MOLTYPE[moltype], **kw)
+
+
+def test_protein_known_answers():
+    # tests/test_minhash.py:290-452 of the reference
+    for moltype, want in (("protein", 4), ("dayhoff", 4), ("hp", 1)):
+        mh = _prot_mh(moltype, 2, n=10)
+        for _ in range(3):
+            mh.add_protein("AGYYG")
+        assert len(mh) == want, moltype
+    mh = _prot_mh("dayhoff", 7, scaled=1)
+    mh.add_protein("CADHIFC")
+    assert list(mh.mins) == [oracle.hash_murmur("abcdefa")]
+    assert list(oracle.seq_to_hashes_protein("CADHIFC", 7, "dayhoff")) == [oracle.hash_murmur("abcdefa")]
+    assert list(oracle.seq_to_hashes_protein("CADHIF*", 7, "dayhoff")) == [oracle.hash_murmur("abcdef*")]     # stop codon kept
+    assert list(oracle.seq_to_hashes_protein("ANA", 3, "hp")) == [oracle.hash_murmur("hph")]
+    assert list(oracle.seq_to_hashes_protein("AN*", 3, "hp")) == [oracle.hash_murmur("hp*")]
+    assert list(oracle.seq_to_hashes_protein("ag", 9, "protein")) == []                                    # :454-458 short
+    # translation: tests/test_minhash.py:363-410
+    assert [oracle.translate_codon(c) for c in ("TCT", "TC", "T", "TCN", "TAA", "TGA", "TGG", "ATG", "ATN", "NTC", "TC?")] == \
+        ["S", "S", "X", "S", "*", "*", "W", "M", "X", "X", "X"]
+    for moltype in ("protein", "dayhoff", "hp"):
+        mh = _prot_mh(moltype, 2, n=10)
+        mh.add_sequence("ACTGAC")                     # frames: TD / LT* ... -> 2 distinct windows overall (:372-388)
+        assert len(mh) == 2, moltype
+    # ACTGAC: forward frame 0 = T D, reverse complement GTCAGT frame 0 = V S
+    want = {oracle.hash_murmur("TD"), oracle.hash_murmur("VS")}
+    assert set(oracle.seq_to_hashes_protein("ACTGAC", 2, "protein", is_protein=False).tolist()) == want
+    assert list(oracle.seq_to_hashes_protein("ACTGA", 2, "dayhoff", is_protein=False)) == []                # :283-287 shorter than 3k
+
+
+def test_protein_golden_sketches():
+    # six-frame translation of a genome: the reference's own sketches (k=21/30 -> 7/10 residues, num=500)
+    recs = list(oracle.read_fasta(golden("num", "genome-s10.fa.gz")))
+    golden_prot = [s for s in oracle.read_sig_json(golden("num", "genome-s10.fa.gz.sig")) if s["molecule"] == "protein"]
+    assert sorted(s["ksize"] for s in golden_prot) == [21, 30]
+    for want in golden_prot:
+        mh = oracle.OracleMinHash(want["num"], want["ksize"], hash_function=2)
+        for _, seq in recs:
+            mh.add_sequence(seq, force=True)
+        assert mh.md5sum() == want["md5sum"] and np.array_equal(mh.mins, np.sort(want["mins"]))
+    # tests/test_sourmash_compute.py:811-930: protein input and translated genes vs independent restatements
+    faa = list(oracle.read_fasta(golden("genes", "ecoli.faa")))
+    fna = list(oracle.read_fasta(golden("genes", "ecoli.genes.fna")))
+    def sketch(records, translate):
+        out = {}
+        for name, seq in records:
+            mh = oracle.OracleMinHash(500, 21, hash_function=2)
+            (mh.add_sequence if translate else mh.add_protein)(seq)
+            out[name.split()[0]] = mh
+        return out
+    aa, tr = sketch(faa, False), sketch(fna, True)
+    good_aa = next(s for s in oracle.read_sig_json(golden("genes", "benchmark.input_prot.sig")))
+    good_tr = next(s for s in oracle.read_sig_json(golden("genes", "benchmark.prot.sig")))
+    assert np.array_equal(aa["NP_414543.1"].mins, np.sort(good_aa["mins"]))
+    assert np.array_equal(tr["gi|556503834:337-2799"].mins, np.sort(good_tr["mins"]))
+    def jac(a, b):
+        c, u = oracle.intersection_size(a.mins, b.mins)
+        merged = np.union1d(a.mins, b.mins)[:500]                    # num rule (minhash.rs:593-621)
+        common = np.intersect1d(np.intersect1d(a.mins, b.mins), merged).size
+        return common / max(1, min(500, merged.size))
+    assert round(jac(aa["NP_414544.1"], tr["gi|556503834:2801-3733"]), 3) == 0.166
+    assert round(jac(aa["NP_414543.1"], tr["gi|556503834:337-2799"]), 3) == 0.174
+    assert jac(aa["NP_414543.1"], tr["gi|556503834:2801-3733"]) == 0.0
