@@ -269,15 +269,23 @@ void smgpu_compare_blocks_raw(const uint64_t *d_hashes, const uint64_t *d_offset
 void smgpu_symmetrize_raw(uint32_t *d_common, uint32_t n, void *stream);
 void smgpu_jaccard_raw(const uint32_t *d_common, const uint64_t *d_offsets, uint32_t n, uint32_t row_lo,
                        uint32_t row_hi, double *d_jaccard, void *stream);
-/* Dense path of the same comparison: when the collection's U distinct hashes are at most ~512 x the mean
- * sketch size, sketches become U-bit rows over the collection's own dictionary and |A ∩ B| =
- * popcount(A & B).  smgpu_bitindex_new sorts/uniques all hashes (synchronises the stream), measures U
- * and returns NULL -- with no error set -- when the collection is too sparse (use smgpu_compare_*_raw).
+/* Indexed paths of the same comparison.  smgpu_bitindex_new sorts every (hash, row) of the collection by hash
+ * (synchronises the stream) and splits the hashes by how many sketches hold them: frequent ones become bit columns
+ * (|A ∩ B| = popcount(A & B) over bit rows), rare ones inverted lists whose pairs are incremented directly.  A
+ * collection drawn from one pool ends up all bit rows, a collection of unrelated genomes all inverted lists.
+ * Returns NULL -- with no error set -- when the cost model prefers the merge kernel (smgpu_compare_*_raw).
  * smgpu_bitindex_compare_raw fills d_common[rb_count*16][n] for the owned 16-row tiles, ALL columns. */
 typedef struct SmgpuBitIndex SmgpuBitIndex;
 SmgpuBitIndex *smgpu_bitindex_new(const uint64_t *d_hashes, const uint64_t *d_offsets, uint32_t n, void *stream);
+/* same, with the frequent/rare split forced (threshold > 0) instead of taken from the cost model; never NULL for a
+ * non-empty collection unless the bit rows would exceed the memory cap */
+SmgpuBitIndex *smgpu_bitindex_new_with_threshold(const uint64_t *d_hashes, const uint64_t *d_offsets, uint32_t n,
+                                                 uint32_t threshold, void *stream);
 void smgpu_bitindex_free(SmgpuBitIndex *ptr);
 uint64_t smgpu_bitindex_universe(const SmgpuBitIndex *ptr);
+/* how the index splits the collection: hashes held by more than `threshold` sketches are bit columns, the others
+ * are inverted lists costing `rare_pairs` matrix increments per compare */
+void smgpu_bitindex_stats(const SmgpuBitIndex *ptr, uint64_t *frequent_hashes, uint64_t *rare_pairs, uint32_t *threshold);
 void smgpu_bitindex_compare_raw(const SmgpuBitIndex *ptr, uint32_t rb_first, uint32_t rb_stride, uint32_t rb_count,
                                 uint32_t *d_common, void *stream);
 /* Host convenience: n sketch handles -> n x n matrices on the host (either may be NULL). */

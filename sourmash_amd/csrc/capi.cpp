@@ -685,45 +685,110 @@ void smgpu_jaccard_raw(const uint32_t* d_common, const uint64_t* d_offsets, uint
     });
 }
 
-// ---- dense compare path: bit rows over the collection's own dictionary --------------------------------
+// ---- compare indexes: bit rows over the collection's dictionary, or bit rows for the frequent hashes plus an
+//      inverted list of the rare ones (bitindex.hip / sparse_pairs.hip) -----------------------------------------
 struct BitIndex {
     uint32_t n = 0, words_per_row = 0;
     uint64_t universe = 0, total = 0;
-    uint32_t* bits = nullptr;
-    ~BitIndex() { if (bits) (void)hipFree(bits); }
+    uint32_t* bits = nullptr;              // [n][words_per_row]; null when no hash is frequent
+    // inverted part (null for the pure bit-row index)
+    uint32_t* rows_sorted = nullptr;       // row of every (hash, row) element, ordered by hash
+    uint32_t* run_end = nullptr;           // end of the element's run if its hash is rare, else 0
+    uint64_t frequent = 0, rare_pairs = 0;
+    uint32_t threshold = 0;
+    ~BitIndex() {
+        if (bits) (void)hipFree(bits);
+        if (rows_sorted) (void)hipFree(rows_sorted);
+        if (run_end) (void)hipFree(run_end);
+    }
 };
 
-// Build the dictionary (sort + unique of every hash) and, if the collection is dense enough, the bit rows.
-// Returns nullptr (no error) when the merge kernel is the better tool.
-static BitIndex* bitindex_build(const uint64_t* d_hashes, const uint64_t* d_offsets, uint32_t n, hipStream_t st) {
+// measured rates behind the cost model (1 x MI355X)
+constexpr double RATE_MERGE_STEPS = 2.5e12;   // merge steps / s   (compare_tile_kernel at C4)
+constexpr double RATE_BIT_WORDS = 7.5e12;     // 32-bit AND+popcount / s (bitmatrix_kernel at C4)
+constexpr double RATE_PAIR_ATOMICS = 4.0e9;   // matrix increments / s (rare_pairs_kernel; two per pair)
+
+// Build the cheapest exact index for the collection, or return nullptr (no error) when the merge kernel is.
+static BitIndex* bitindex_build(const uint64_t* d_hashes, const uint64_t* d_offsets, uint32_t n, hipStream_t st,
+                                uint32_t forced_threshold = 0) {
     if (n == 0) return nullptr;
     uint64_t total = 0;
     hip_check(hipMemcpyAsync(&total, d_offsets + n, 8, hipMemcpyDeviceToHost, st), "D2H");
     hip_check(hipStreamSynchronize(st), "sync");
     if (total == 0 || total > 0xffffffffull) return nullptr;
-    DevBuf keys, uniq, tmp, scal;
-    struct Free { DevBuf& b; ~Free() { if (b.p) (void)hipFree(b.p); } } f1{keys}, f2{uniq}, f3{tmp}, f4{scal};
-    keys.reserve(total * 8);
-    uniq.reserve(total * 8);
+    // (hash, row) of the whole collection sorted by hash; runs = distinct hashes with their number of holders
+    DevBuf keys_a, keys_b, rows_tmp, counts, tmp, scal, flags, run_off, freq_rank;
+    struct Free { DevBuf& b; ~Free() { if (b.p) (void)hipFree(b.p); } } f1{keys_a}, f2{keys_b}, f3{rows_tmp}, f4{counts}, f5{tmp},
+        f6{scal}, f7{flags}, f8{run_off}, f9{freq_rank};
+    std::unique_ptr<BitIndex> bi(new BitIndex());
+    bi->n = n; bi->total = total;
+    keys_a.reserve(total * 8);
+    keys_b.reserve(total * 8);
+    rows_tmp.reserve(total * 4);
+    counts.reserve((total + 1) * 4);
     scal.reserve(64);
-    const size_t tb = sort_unique_temp_bytes(total);
+    const size_t tb = inverted_temp_bytes(total);
     tmp.reserve(tb);
-    hip_check(hipMemcpyAsync(keys.p, d_hashes, total * 8, hipMemcpyDeviceToDevice, st), "D2D");
-    hip_check(sort_unique(keys.as<uint64_t>(), total, uniq.as<uint64_t>(), nullptr, scal.as<uint64_t>(), tmp.p, tb, 64, st),
-              "sort_unique");
+    hip_check(hipMalloc((void**)&bi->rows_sorted, total * 4 + 16), "hipMalloc");
+    hip_check(hipMemsetAsync(scal.p, 0, 64, st), "memset");
+    hip_check(inverted_sort_launch(d_hashes, d_offsets, n, total, keys_a.as<uint64_t>(), keys_b.as<uint64_t>(),
+                                   rows_tmp.as<uint32_t>(), bi->rows_sorted, counts.as<uint32_t>(), scal.as<uint64_t>(), tmp.p, tb, st),
+              "inverted sort");
     uint64_t U = 0;
     hip_check(hipMemcpyAsync(&U, scal.p, 8, hipMemcpyDeviceToHost, st), "D2H");
     hip_check(hipStreamSynchronize(st), "sync");
-    // cost model: bit rows win while U <= ~512 x mean sketch size; cap the bitmap at 8 GiB
+    bi->universe = U;
     const double mean_len = (double)total / n;
-    const uint32_t words = (uint32_t)(((U + 31) / 32 + 31) / 32 * 32);        // whole 32-word k-steps
-    if ((double)U > 512.0 * mean_len || (double)n * words * 4.0 > 8.0 * (1ull << 30)) return nullptr;
-    std::unique_ptr<BitIndex> bi(new BitIndex());
-    bi->n = n; bi->universe = U; bi->total = total; bi->words_per_row = words;
-    hip_check(hipMalloc((void**)&bi->bits, (size_t)n * words * 4), "hipMalloc");
-    hip_check(bitmap_build_launch(d_hashes, d_offsets, n, uniq.as<uint64_t>(), U, bi->bits, words, st), "bitmap_build");
-    hip_check(hipStreamSynchronize(st), "sync");      // the dictionary buffers are released on return
+    const double pairs = 0.5 * (double)n * (double)n;
+    const double t_merge = (double)n * (double)total / RATE_MERGE_STEPS;
+    // a hash held by m sketches costs m^2 increments as a rare hash, or one bit column (n^2/2 pairs x 1/32 word) as
+    // a frequent one: the two meet at m ~ n * sqrt(RATE_PAIR_ATOMICS / (64 * RATE_BIT_WORDS))
+    uint32_t threshold = (uint32_t)((double)n * std::sqrt(RATE_PAIR_ATOMICS / (64.0 * RATE_BIT_WORDS)));
+    if (threshold < 1) threshold = 1;
+    if (forced_threshold) threshold = forced_threshold;
+    flags.reserve((U + 1) * 4);
+    run_off.reserve((U + 2) * 8);
+    freq_rank.reserve((U + 2) * 8);
+    hip_check(hipMemsetAsync((char*)flags.p + U * 4, 0, 4, st), "memset");
+    unsigned long long* d_rare = scal.as<unsigned long long>() + 1;
+    hip_check(inverted_classify_launch(counts.as<uint32_t>(), U, threshold, flags.as<uint32_t>(), d_rare, st), "classify");
+    hip_check(inverted_offsets_launch(counts.as<uint32_t>(), flags.as<uint32_t>(), U, run_off.as<uint64_t>(),
+                                      freq_rank.as<uint64_t>(), tmp.p, tb, st), "run offsets");
+    uint64_t n_freq = 0;
+    unsigned long long rare_pairs = 0;
+    hip_check(hipMemcpyAsync(&n_freq, freq_rank.as<uint64_t>() + U, 8, hipMemcpyDeviceToHost, st), "D2H");
+    hip_check(hipMemcpyAsync(&rare_pairs, d_rare, 8, hipMemcpyDeviceToHost, st), "D2H");
+    hip_check(hipStreamSynchronize(st), "sync");
+    const uint32_t words = n_freq ? (uint32_t)(((n_freq + 31) / 32 + 31) / 32 * 32) : 0;     // whole 32-word k-steps
+    const double t_index = pairs * (double)words / RATE_BIT_WORDS + 2.0 * (double)rare_pairs / RATE_PAIR_ATOMICS +
+                           (double)total / 2.0e10;                                         // + one pass over the elements
+    (void)mean_len;
+    if ((t_index > t_merge && !forced_threshold) || (double)n * words * 4.0 > 8.0 * (1ull << 30)) return nullptr;   // merge kernel wins / bitmap cap
+    bi->frequent = n_freq; bi->rare_pairs = rare_pairs; bi->threshold = threshold; bi->words_per_row = words;
+    if (words) {
+        hip_check(hipMalloc((void**)&bi->bits, (size_t)n * words * 4), "hipMalloc");
+        hip_check(hipMemsetAsync(bi->bits, 0, (size_t)n * words * 4, st), "memset");
+    }
+    hip_check(hipMalloc((void**)&bi->run_end, total * 4 + 16), "hipMalloc");
+    hip_check(inverted_apply_launch(run_off.as<uint64_t>(), flags.as<uint32_t>(), freq_rank.as<uint64_t>(), U, bi->rows_sorted,
+                                    bi->run_end, bi->bits, words, st), "inverted apply");
+    hip_check(hipStreamSynchronize(st), "sync");      // the scratch buffers are released on return
+    if (rare_pairs == 0 && n_freq == U) {             // nothing is rare: plain bit rows, drop the inverted part
+        (void)hipFree(bi->rows_sorted); (void)hipFree(bi->run_end);
+        bi->rows_sorted = bi->run_end = nullptr;
+    }
     return bi.release();
+}
+
+static void bitindex_compare(const BitIndex* bi, uint32_t rb_first, uint32_t rb_stride, uint32_t rb_count, uint32_t* d_common,
+                             hipStream_t st) {
+    if (bi->bits)
+        hip_check(bitmatrix_launch(bi->bits, bi->words_per_row, bi->n, rb_first, rb_stride, rb_count, d_common, st), "bitmatrix");
+    else
+        hip_check(hipMemsetAsync(d_common, 0, (size_t)rb_count * 16 * bi->n * 4, st), "memset");
+    if (bi->run_end)
+        hip_check(rare_pairs_launch(bi->rows_sorted, bi->run_end, bi->total, bi->n, rb_first, rb_stride, rb_count, d_common, st),
+                  "rare pairs");
 }
 
 SmgpuBitIndex* smgpu_bitindex_new(const uint64_t* d_hashes, const uint64_t* d_offsets, uint32_t n, void* stream) {
@@ -731,14 +796,24 @@ SmgpuBitIndex* smgpu_bitindex_new(const uint64_t* d_hashes, const uint64_t* d_of
         return reinterpret_cast<SmgpuBitIndex*>(bitindex_build(d_hashes, d_offsets, n, (hipStream_t)stream));
     });
 }
+SmgpuBitIndex* smgpu_bitindex_new_with_threshold(const uint64_t* d_hashes, const uint64_t* d_offsets, uint32_t n,
+                                                uint32_t threshold, void* stream) {
+    return landing<SmgpuBitIndex*>([&]() -> SmgpuBitIndex* {
+        return reinterpret_cast<SmgpuBitIndex*>(bitindex_build(d_hashes, d_offsets, n, (hipStream_t)stream, threshold));
+    });
+}
 void smgpu_bitindex_free(SmgpuBitIndex* p) { delete reinterpret_cast<BitIndex*>(p); }
 uint64_t smgpu_bitindex_universe(const SmgpuBitIndex* p) { return reinterpret_cast<const BitIndex*>(p)->universe; }
+void smgpu_bitindex_stats(const SmgpuBitIndex* p, uint64_t* frequent_hashes, uint64_t* rare_pairs, uint32_t* threshold) {
+    const BitIndex* bi = reinterpret_cast<const BitIndex*>(p);
+    *frequent_hashes = bi->frequent ? bi->frequent : (bi->run_end ? 0 : bi->universe);
+    *rare_pairs = bi->rare_pairs;
+    *threshold = bi->threshold;
+}
 void smgpu_bitindex_compare_raw(const SmgpuBitIndex* p, uint32_t rb_first, uint32_t rb_stride, uint32_t rb_count,
                                 uint32_t* d_common, void* stream) {
     landing_void([&] {
-        const BitIndex* bi = reinterpret_cast<const BitIndex*>(p);
-        hip_check(bitmatrix_launch(bi->bits, bi->words_per_row, bi->n, rb_first, rb_stride, rb_count, d_common,
-                                   (hipStream_t)stream), "bitmatrix");
+        bitindex_compare(reinterpret_cast<const BitIndex*>(p), rb_first, rb_stride, rb_count, d_common, (hipStream_t)stream);
     });
 }
 
@@ -749,10 +824,9 @@ static void compare_device_csr(const uint64_t* d_hashes, const uint64_t* d_offse
     struct Free { DevBuf& b; ~Free() { if (b.p) (void)hipFree(b.p); } } f3{dc}, f4{dj};
     dc.reserve((size_t)((n + 15) / 16 * 16) * n * 4);
     std::unique_ptr<BitIndex> bi(bitindex_build(d_hashes, d_offsets, (uint32_t)n, st));
-    if (bi)   // dense collection: bit rows + popcount(AND)
-        hip_check(bitmatrix_launch(bi->bits, bi->words_per_row, (uint32_t)n, 0, 1, (uint32_t)((n + 15) / 16),
-                                   dc.as<uint32_t>(), st), "bitmatrix");
-    else      // sparse collection: LDS-tiled merge walk
+    if (bi)   // bit rows for the frequent hashes + inverted lists for the rare ones
+        bitindex_compare(bi.get(), 0, 1, (uint32_t)((n + 15) / 16), dc.as<uint32_t>(), st);
+    else      // LDS-tiled merge walk
         hip_check(compare_counts_launch(d_hashes, d_offsets, (uint32_t)n, 0, (uint32_t)n, dc.as<uint32_t>(), st), "compare");
     if (jaccard_out) {
         dj.reserve((size_t)n * n * 8);

@@ -115,22 +115,33 @@ def pack_csr(sketches, device="cuda"):
 
 
 class BitIndex:
-    """Dense form of a device CSR: one U-bit row per sketch over the collection's own hash dictionary
-    (smgpu_bitindex_*).  `BitIndex.build` returns None when the collection is too sparse for it."""
+    """Compare index of a device CSR (smgpu_bitindex_*): hashes held by many sketches as bit columns, hashes held
+    by few as inverted lists.  `BitIndex.build` returns None when the merge kernel is the cheaper tool."""
 
     def __init__(self, ptr, n):
         self._ptr, self.n = ptr, n
 
     @classmethod
-    def build(cls, hashes, offsets):
+    def build(cls, hashes, offsets, threshold=None):
+        "threshold: hashes held by more sketches than this become bit columns (None: the library's cost model)"
         torch = _torch()
         n = offsets.numel() - 1
-        ptr = rustcall(lib.smgpu_bitindex_new, _ptr(hashes), _ptr(offsets), n, _stream(torch))
+        if threshold:
+            ptr = rustcall(lib.smgpu_bitindex_new_with_threshold, _ptr(hashes), _ptr(offsets), n, int(threshold), _stream(torch))
+        else:
+            ptr = rustcall(lib.smgpu_bitindex_new, _ptr(hashes), _ptr(offsets), n, _stream(torch))
         return cls(ptr, n) if ptr else None
 
     @property
     def universe(self):
         return lib.smgpu_bitindex_universe(self._ptr)
+
+    @property
+    def stats(self):
+        "(frequent hashes = bit columns, matrix increments the rare hashes cost per compare, threshold)"
+        f, r, t = C.c_uint64(), C.c_uint64(), C.c_uint32()
+        lib.smgpu_bitindex_stats(self._ptr, C.byref(f), C.byref(r), C.byref(t))
+        return f.value, r.value, t.value
 
     def compare_tiles(self, first, stride, count, out=None):
         "u32 counts for the 16-row tiles first, first+stride, ... (count of them), all columns"

@@ -179,3 +179,74 @@ def test_containment_matrices(sm):
     assert m[0, 1] == m[1, 0] == sigs[0].max_containment(sigs[1])
     a = compare_serial_avg_containment(sigs)
     assert a[0, 1] == sigs[0].avg_containment(sigs[1])
+
+
+def _mixed_collection(n, seed=3):
+    """Sketches with three kinds of hashes: a shared pool (held by ~1/4 of the sketches each: bit columns), hashes
+    shared by exactly two or three sketches (inverted lists) and private ones (runs of length one)."""
+    from sourmash_amd.synth import splitmix64, MAX_HASH_1000
+    rng = np.random.default_rng(seed)
+    pool = np.unique(splitmix64(np.arange(600, dtype=np.uint64) + np.uint64(17)) % np.uint64(MAX_HASH_1000))
+    few = np.unique(splitmix64(np.arange(4000, dtype=np.uint64) + np.uint64(1 << 40)) % np.uint64(MAX_HASH_1000))
+    rows = [set(pool[rng.random(len(pool)) < 0.25].tolist()) for _ in range(n)]
+    for h in few.tolist():
+        for r in rng.choice(n, size=int(rng.integers(2, 4)), replace=False):
+            rows[int(r)].add(h)
+    for i in range(n):
+        priv = splitmix64(np.arange(300, dtype=np.uint64) + np.uint64((i + 1) << 44)) % np.uint64(MAX_HASH_1000)
+        rows[i].update(priv.tolist())
+    rows[5] = set()                                                       # an empty sketch in the middle
+    return [np.array(sorted(r), dtype=np.uint64) for r in rows]
+
+
+def test_compare_index_splits_frequent_and_rare_hashes(sm):
+    "the indexed path (bit columns + inverted lists) against the oracle and against the merge kernel, whole and sharded"
+    import torch
+    from sourmash_amd import device as smd
+    sk = _mixed_collection(333)
+    n = len(sk)
+    wc, wj = oracle.compare_all_pairs(*oracle.make_csr(sk), nthreads=8)
+    h, off = smd.pack_csr(sk)
+    idx = smd.BitIndex.build(h, off, threshold=8)                        # pool hashes -> bit columns, the rest -> lists
+    frequent, rare_pairs, threshold = idx.stats
+    assert 0 < frequent <= 600 and rare_pairs > 4000 and threshold == 8   # both parts are in play
+    auto = smd.BitIndex.build(h, off)                                    # the cost model's own split gives the same matrix
+    assert auto is not None
+    c_auto, _ = smd.compare_rows(h, off, index=auto)
+    assert np.array_equal(c_auto.cpu().numpy().view(np.uint32), wc)
+    c_idx, j_idx = smd.compare_rows(h, off, index=idx)
+    c_mrg, j_mrg = smd.compare_rows(h, off)
+    torch.cuda.synchronize()
+    assert np.array_equal(c_idx.cpu().numpy().view(np.uint32), wc)
+    assert np.array_equal(c_mrg.cpu().numpy().view(np.uint32), wc)
+    assert np.array_equal(j_idx.cpu().numpy().view(np.uint64), wj.view(np.uint64))
+    for first, stride, count in ((0, 2, 11), (1, 2, 10), (3, 5, 4)):     # owned 16-row tiles of a sharded launch
+        out = idx.compare_tiles(first, stride, count).cpu().numpy().view(np.uint32)
+        for t in range(count):
+            lo = (first + t * stride) * 16
+            hi = min(lo + 16, n)
+            assert np.array_equal(out[t * 16:t * 16 + hi - lo], wc[lo:hi]), (first, stride, t)
+    # the host convenience entry point picks the same path and the same numbers
+    mhs = []
+    for hs in sk[:60]:
+        mh = sm.MinHash(0, 31, scaled=1000)
+        mh.add_many(hs)
+        mhs.append(mh)
+    from sourmash_amd.compare import compare_all_pairs
+    got = compare_all_pairs([sm.SourmashSignature(m, name=str(i)) for i, m in enumerate(mhs)], ignore_abundance=True)
+    assert np.array_equal(got.view(np.uint64), wj[:60, :60].view(np.uint64))
+
+
+def test_compare_index_all_rare(sm):
+    "unrelated sketches: no bit columns at all, and a collection with nothing in common"
+    import torch
+    from sourmash_amd import device as smd
+    from sourmash_amd.synth import synth_sketches
+    sk = synth_sketches(200, pool_size=400_000, keep_one_in=400, planted=False)    # every pool hash in ~0.5 sketches
+    h, off = smd.pack_csr(sk)
+    idx = smd.BitIndex.build(h, off, threshold=200)                      # no hash can be held by more than all sketches
+    assert idx is not None and idx.stats[0] == 0 and idx.stats[1] > 0
+    c, j = smd.compare_rows(h, off, index=idx)
+    torch.cuda.synchronize()
+    wc, wj = oracle.compare_all_pairs(*oracle.make_csr(sk), nthreads=8)
+    assert np.array_equal(c.cpu().numpy().view(np.uint32), wc) and np.array_equal(j.cpu().numpy().view(np.uint64), wj.view(np.uint64))
