@@ -710,12 +710,14 @@ constexpr double RATE_PAIR_ATOMICS = 4.0e9;   // matrix increments / s (rare_pai
 
 // Build the cheapest exact index for the collection, or return nullptr (no error) when the merge kernel is.
 static BitIndex* bitindex_build(const uint64_t* d_hashes, const uint64_t* d_offsets, uint32_t n, hipStream_t st,
-                                uint32_t forced_threshold = 0) {
+                                uint32_t forced_threshold = 0, bool one_shot = false) {
     if (n == 0) return nullptr;
     uint64_t total = 0;
     hip_check(hipMemcpyAsync(&total, d_offsets + n, 8, hipMemcpyDeviceToHost, st), "D2H");
     hip_check(hipStreamSynchronize(st), "sync");
     if (total == 0 || total > 0xffffffffull) return nullptr;
+    // an index that serves ONE compare must also pay for its own sort (~1.5 ms of fixed cost + total / 5e9 s measured)
+    if (one_shot && (double)n * (double)total / RATE_MERGE_STEPS < 1.5e-3 + (double)total / 5.0e9) return nullptr;
     // (hash, row) of the whole collection sorted by hash; runs = distinct hashes with their number of holders
     DevBuf keys_a, keys_b, rows_tmp, counts, tmp, scal, flags, run_off, freq_rank;
     struct Free { DevBuf& b; ~Free() { if (b.p) (void)hipFree(b.p); } } f1{keys_a}, f2{keys_b}, f3{rows_tmp}, f4{counts}, f5{tmp},
@@ -823,7 +825,7 @@ static void compare_device_csr(const uint64_t* d_hashes, const uint64_t* d_offse
     DevBuf dc, dj;
     struct Free { DevBuf& b; ~Free() { if (b.p) (void)hipFree(b.p); } } f3{dc}, f4{dj};
     dc.reserve((size_t)((n + 15) / 16 * 16) * n * 4);
-    std::unique_ptr<BitIndex> bi(bitindex_build(d_hashes, d_offsets, (uint32_t)n, st));
+    std::unique_ptr<BitIndex> bi(bitindex_build(d_hashes, d_offsets, (uint32_t)n, st, 0, true));
     if (bi)   // bit rows for the frequent hashes + inverted lists for the rare ones
         bitindex_compare(bi.get(), 0, 1, (uint32_t)((n + 15) / 16), dc.as<uint32_t>(), st);
     else      // LDS-tiled merge walk

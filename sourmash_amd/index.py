@@ -167,6 +167,38 @@ class SketchSet(RustObject):
         "|query ∩ row| for every row (one pass)"
         return _DeviceCounter(self, query_mh.flatten()).values()
 
+    def search(self, query_mh, *, threshold=0.0, do_containment=False, do_max_containment=False, best_only=False):
+        """Rows scoring >= threshold against the query, best first -> [(score, row)].  Jaccard by default, query
+        containment or max containment on request: the scores of JaccardSearch (search.py:88-160) from one overlap
+        pass over the whole set."""
+        if do_containment and do_max_containment:
+            raise TypeError("'do_containment' and 'do_max_containment' cannot both be True")
+        if (do_containment or do_max_containment) and not query_mh.scaled:
+            raise TypeError("this search requires a scaled signature")
+        shared = self.overlaps(query_mh).astype(np.float64)
+        sizes = self.sizes.astype(np.float64)
+        nq = float(len(query_mh))
+        if do_containment:
+            score = shared / nq if nq else np.zeros_like(shared)
+        elif do_max_containment:
+            score = np.divide(shared, np.minimum(sizes, nq), out=np.zeros_like(shared), where=np.minimum(sizes, nq) > 0)
+        else:
+            union = sizes + nq - shared
+            score = np.divide(shared, union, out=np.zeros_like(shared), where=union > 0)
+        keep = np.flatnonzero((score >= threshold) & (score > 0))
+        order = keep[np.argsort(-score[keep], kind="stable")]
+        hits = [(float(score[r]), int(r)) for r in order]
+        return hits[:1] if best_only else hits
+
+    def prefetch(self, query_mh, threshold_bp=0):
+        "Rows sharing at least threshold_bp with the query -> [(row, |intersect|)] in row order (search.py:956-976)."
+        scaled = query_mh.scaled
+        if not scaled:
+            raise ValueError("prefetch requires scaled signatures")
+        shared = self.overlaps(query_mh)
+        need = float(threshold_bp) / scaled if threshold_bp else 0.0
+        return [(int(r), int(shared[r])) for r in np.flatnonzero((shared >= need) & (shared > 0))]
+
     def gather(self, query_mh, threshold_bp=0):
         """Min-set-cover of the query by the rows of this set -> [(row, |intersect|)] in rank order; the whole
         loop runs on the GPU (GatherDatabases semantics, search.py:877-949, for equal scaled)."""

@@ -78,6 +78,18 @@ def test_compare_and_rows_from_a_zip(sm, tmp_path):
         ss = db.signature(row)
         assert ss.name == sigs[row].name and ss.md5sum() == db.manifest[row]["md5"] == sigs[row].md5sum()
         assert ss.minhash == sigs[row].minhash
+    # search / prefetch by row number == the object route over a LinearIndex
+    from sourmash_amd.index import LinearIndex
+    lin = LinearIndex(sigs)
+    q = sigs[5]
+    for kw in ({}, {"do_containment": True}, {"do_max_containment": True}):
+        want = lin.search(q, threshold=0.08, **kw)
+        got = db.search(q.minhash, threshold=0.08, **kw)
+        assert [round(s, 12) for s, _ in got] == [round(r.score, 12) for r in want]
+        assert {sigs[row].name for _, row in got} == {r.signature.name for r in want}
+    assert db.search(q.minhash, threshold=0.0, best_only=True)[0][1] in (5, len(sk) - 4)       # itself or its planted duplicate
+    pre = db.prefetch(q.minhash, threshold_bp=100_000)
+    assert [(row, n) for row, n in pre] == [(i, int(wc[5, i])) for i in range(len(sk)) if wc[5, i] >= 100]
     # downsampling at load time == downsampling the objects
     db2 = SketchSet.load(zpath, ksize=31, scaled=4000)
     assert db2.params[3] == 4000
