@@ -200,7 +200,11 @@ __global__ __launch_bounds__(256) void export_row_kernel(const unsigned long lon
         rowbuf[i] = i == 0 ? len : (i <= len ? hashes[lo + i - 1] : 0);
 }
 
-// one lane looks one hash of the row up in the query; the wave then walks the postings of its hits together
+// A wave takes APPLY_EPW hashes of the row: one lane each looks its hash up in the query; the postings of the
+// wave's hits are then treated as ONE list (prefix sums over the hits) that all 64 lanes walk together, so short
+// and long posting lists keep the lanes equally busy and every load / atomic of an iteration is independent.
+constexpr int APPLY_EPW = 16;
+
 template <bool GATE>
 __global__ __launch_bounds__(256) void apply_kernel(QIndex qi, uint8_t* alive, const uint64_t* __restrict__ post_off,
                                                     const uint32_t* __restrict__ post_rows,
@@ -222,17 +226,17 @@ __global__ __launch_bounds__(256) void apply_kernel(QIndex qi, uint8_t* alive, c
     const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
     const int lane = threadIdx.x & 63;
-    for (uint64_t base = wave * 64; base < len; base += n_waves * 64) {
+    for (uint64_t base = wave * APPLY_EPW; base < len; base += n_waves * APPLY_EPW) {
         const uint64_t i = base + lane;
         uint32_t j = NONE32;
-        if (i < len) {
+        if (lane < APPLY_EPW && i < len) {
             j = q_find(qi, row[i]);
             if (GATE && j != NONE32) {
                 if (alive[j]) alive[j] = 0;                    // row hashes are distinct: no two lanes share j
                 else j = NONE32;
             }
         }
-        unsigned long long hits = __ballot(j != NONE32);
+        const unsigned long long hits = __ballot(j != NONE32);
         if (GATE) {
             if (lane == 0 && hits) atomicAdd(&state[GS_ACC], (unsigned long long)__popcll(hits));
         } else {
@@ -245,13 +249,47 @@ __global__ __launch_bounds__(256) void apply_kernel(QIndex qi, uint8_t* alive, c
             const unsigned long long gone = __ballot(fresh);
             if (lane == 0 && gone) atomicAdd(&state[GS_QLEN], 0ull - (unsigned long long)__popcll(gone));
         }
-        while (hits) {
-            const int src = __ffsll((long long)hits) - 1;
-            hits &= hits - 1;
-            const uint32_t jq = __shfl(j, src);
-            const uint64_t lo = post_off[jq], hi = post_off[jq + 1];
-            for (uint64_t p = lo + lane; p < hi; p += 64) {
-                unsigned long long* c = &counters[post_rows[p]];
+        if (!hits) continue;
+        // lane l < APPLY_EPW: posting list [lo, lo + n) of its hit; inclusive prefix sums over those lanes
+        uint64_t lo = 0;
+        uint32_t n = 0;
+        if (j != NONE32) {
+            lo = post_off[j];
+            n = (uint32_t)(post_off[j + 1] - lo);
+        }
+        uint32_t incl = n;
+#pragma unroll
+        for (int d = 1; d < APPLY_EPW; d <<= 1) {
+            const uint32_t v = __shfl_up(incl, d);
+            if (lane >= d) incl += v;
+        }
+        const uint32_t total = __shfl(incl, APPLY_EPW - 1);
+        uint32_t bound[APPLY_EPW - 1];                          // wave-uniform: end of the lists of hits 0 .. 14
+#pragma unroll
+        for (int k = 0; k < APPLY_EPW - 1; ++k) bound[k] = __shfl(incl, k);
+        const uint32_t excl = incl - n;
+        const uint32_t lo_lo = (uint32_t)lo, lo_hi = (uint32_t)(lo >> 32);
+        // wave-uniform trip count (the shuffles read lanes 0 .. 15, which must not have left the loop); four
+        // independent loads are in flight before their atomics are issued
+        constexpr int UNROLL = 4;
+        for (uint32_t t0 = 0; t0 < total; t0 += 64 * UNROLL) {
+            uint32_t target[UNROLL];
+            bool live[UNROLL];
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
+                const uint32_t t = t0 + (uint32_t)(64 * u + lane);
+                int h = 0;
+#pragma unroll
+                for (int k = 0; k < APPLY_EPW - 1; ++k) h += t >= bound[k];
+                const uint64_t start = ((uint64_t)(uint32_t)__shfl((int)lo_hi, h) << 32) | (uint32_t)__shfl((int)lo_lo, h);
+                const uint32_t first = (uint32_t)__shfl((int)excl, h);
+                live[u] = t < total;
+                target[u] = live[u] ? post_rows[start + (t - first)] : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < UNROLL; ++u) {
+                if (!live[u]) continue;
+                unsigned long long* c = &counters[target[u]];
                 if (GATE) {
                     atomicAdd(c, ~0ull);                       // invariant: counters[d] = |row_d ∩ uncovered| >= 1 here
                 } else {
@@ -394,13 +432,13 @@ hipError_t gather_export(GatherDev& g, const unsigned long long* d_key, uint64_t
 }
 
 hipError_t gather_apply(GatherDev& g, const uint64_t* d_rowbuf, hipStream_t stream) {
-    hipLaunchKernelGGL(apply_kernel<true>, dim3(64), dim3(256), 0, stream, qindex_of(g), g.alive, g.post_off,
+    hipLaunchKernelGGL(apply_kernel<true>, dim3(128), dim3(256), 0, stream, qindex_of(g), g.alive, g.post_off,
                        g.post_rows, g.counters, g.state, d_rowbuf, g.hashes, g.offsets, g.index_base);
     return hipGetLastError();
 }
 
 hipError_t gather_consume_list(GatherDev& g, const uint64_t* d_list, hipStream_t stream) {
-    hipLaunchKernelGGL(apply_kernel<false>, dim3(64), dim3(256), 0, stream, qindex_of(g), g.alive, g.post_off,
+    hipLaunchKernelGGL(apply_kernel<false>, dim3(128), dim3(256), 0, stream, qindex_of(g), g.alive, g.post_off,
                        g.post_rows, g.counters, g.state, d_list, g.hashes, g.offsets, g.index_base);
     return hipGetLastError();
 }
