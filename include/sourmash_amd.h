@@ -277,10 +277,12 @@ void smgpu_jaccard_raw(const uint32_t *d_common, const uint64_t *d_offsets, uint
  * smgpu_bitindex_compare_raw fills d_common[rb_count*16][n] for the owned 16-row tiles, ALL columns. */
 typedef struct SmgpuBitIndex SmgpuBitIndex;
 SmgpuBitIndex *smgpu_bitindex_new(const uint64_t *d_hashes, const uint64_t *d_offsets, uint32_t n, void *stream);
-/* same, with the frequent/rare split forced (threshold > 0) instead of taken from the cost model; never NULL for a
- * non-empty collection unless the bit rows would exceed the memory cap */
-SmgpuBitIndex *smgpu_bitindex_new_with_threshold(const uint64_t *d_hashes, const uint64_t *d_offsets, uint32_t n,
-                                                 uint32_t threshold, void *stream);
+/* same with the knobs exposed: total_hashes = d_offsets[n] if the caller knows it (0: read back, one more
+ * synchronisation); threshold > 0 forces the frequent/rare split instead of the cost model's (and then never returns NULL
+ * unless the bit rows would exceed the memory cap); one_shot: the index will serve a single compare, so its own build
+ * time counts against it. */
+SmgpuBitIndex *smgpu_bitindex_new_ex(const uint64_t *d_hashes, const uint64_t *d_offsets, uint32_t n, uint64_t total_hashes,
+                                     uint32_t threshold, bool one_shot, void *stream);
 void smgpu_bitindex_free(SmgpuBitIndex *ptr);
 uint64_t smgpu_bitindex_universe(const SmgpuBitIndex *ptr);
 /* how the index splits the collection: hashes held by more than `threshold` sketches are bit columns, the others

@@ -696,10 +696,11 @@ struct BitIndex {
     uint32_t* run_end = nullptr;           // end of the element's run if its hash is rare, else 0
     uint64_t frequent = 0, rare_pairs = 0;
     uint32_t threshold = 0;
+    hipStream_t stream = nullptr;          // the arrays come from this stream's pool and go back to it, in order
     ~BitIndex() {
-        if (bits) (void)hipFree(bits);
-        if (rows_sorted) (void)hipFree(rows_sorted);
-        if (run_end) (void)hipFree(run_end);
+        if (bits) (void)hipFreeAsync(bits, stream);
+        if (rows_sorted) (void)hipFreeAsync(rows_sorted, stream);
+        if (run_end) (void)hipFreeAsync(run_end, stream);
     }
 };
 
@@ -710,76 +711,62 @@ constexpr double RATE_PAIR_ATOMICS = 4.0e9;   // matrix increments / s (rare_pai
 
 // Build the cheapest exact index for the collection, or return nullptr (no error) when the merge kernel is.
 static BitIndex* bitindex_build(const uint64_t* d_hashes, const uint64_t* d_offsets, uint32_t n, hipStream_t st,
-                                uint32_t forced_threshold = 0, bool one_shot = false) {
+                                uint32_t forced_threshold = 0, bool one_shot = false, uint64_t total = 0) {
     if (n == 0) return nullptr;
-    uint64_t total = 0;
-    hip_check(hipMemcpyAsync(&total, d_offsets + n, 8, hipMemcpyDeviceToHost, st), "D2H");
-    hip_check(hipStreamSynchronize(st), "sync");
+    if (total == 0) {                                               // the caller did not say how many hashes there are
+        hip_check(hipMemcpyAsync(&total, d_offsets + n, 8, hipMemcpyDeviceToHost, st), "D2H");
+        hip_check(hipStreamSynchronize(st), "sync");
+    }
     if (total == 0 || total > 0xffffffffull) return nullptr;
-    // an index that serves ONE compare must also pay for its own sort (~1.5 ms of fixed cost + total / 5e9 s measured)
-    if (one_shot && (double)n * (double)total / RATE_MERGE_STEPS < 1.5e-3 + (double)total / 5.0e9) return nullptr;
-    // (hash, row) of the whole collection sorted by hash; runs = distinct hashes with their number of holders
-    DevBuf keys_a, keys_b, rows_tmp, counts, tmp, scal, flags, run_off, freq_rank;
-    struct Free { DevBuf& b; ~Free() { if (b.p) (void)hipFree(b.p); } } f1{keys_a}, f2{keys_b}, f3{rows_tmp}, f4{counts}, f5{tmp},
-        f6{scal}, f7{flags}, f8{run_off}, f9{freq_rank};
-    std::unique_ptr<BitIndex> bi(new BitIndex());
-    bi->n = n; bi->total = total;
-    keys_a.reserve(total * 8);
-    keys_b.reserve(total * 8);
-    rows_tmp.reserve(total * 4);
-    counts.reserve((total + 1) * 4);
-    scal.reserve(64);
-    const size_t tb = inverted_temp_bytes(total);
-    tmp.reserve(tb);
-    hip_check(hipMalloc((void**)&bi->rows_sorted, total * 4 + 16), "hipMalloc");
-    hip_check(hipMemsetAsync(scal.p, 0, 64, st), "memset");
-    hip_check(inverted_sort_launch(d_hashes, d_offsets, n, total, keys_a.as<uint64_t>(), keys_b.as<uint64_t>(),
-                                   rows_tmp.as<uint32_t>(), bi->rows_sorted, counts.as<uint32_t>(), scal.as<uint64_t>(), tmp.p, tb, st),
-              "inverted sort");
-    uint64_t U = 0;
-    hip_check(hipMemcpyAsync(&U, scal.p, 8, hipMemcpyDeviceToHost, st), "D2H");
-    hip_check(hipStreamSynchronize(st), "sync");
-    bi->universe = U;
-    const double mean_len = (double)total / n;
-    const double pairs = 0.5 * (double)n * (double)n;
     const double t_merge = (double)n * (double)total / RATE_MERGE_STEPS;
+    // an index that serves ONE compare must also pay for its own sort (~0.6 ms of fixed cost + total / 5e9 s measured)
+    if (one_shot && !forced_threshold && t_merge < 0.6e-3 + (double)total / 5.0e9) return nullptr;
+    // (hash, row) of the whole collection sorted by hash; runs = distinct hashes with their number of holders.
+    // Scratch comes from the stream-ordered pool and the host reads back once: the kernels of a small build take
+    // less time than one hipMalloc / hipFree pair or one extra synchronisation.
+    std::unique_ptr<BitIndex> bi(new BitIndex());
+    bi->n = n; bi->total = total; bi->stream = st;
+    const size_t tb = inverted_temp_bytes(total);
+    AsyncBuf keys_a(total * 8, st), keys_b(total * 8, st), rows_tmp(total * 4, st), counts((total + 2) * 4, st), tmp(tb, st),
+        scal(64, st), flags((total + 2) * 4, st), run_off((total + 2) * 8, st), freq_rank((total + 2) * 8, st);
+    hip_check(hipMallocAsync((void**)&bi->rows_sorted, total * 4 + 16, st), "hipMallocAsync");
+    hip_check(hipMemsetAsync(scal.p, 0, 64, st), "memset");
+    uint64_t* d_n_runs = scal.as<uint64_t>();
+    unsigned long long* d_out = scal.as<unsigned long long>() + 1;      // [runs, frequent, rare pair increments]
+    hip_check(inverted_sort_launch(d_hashes, d_offsets, n, total, keys_a.as<uint64_t>(), keys_b.as<uint64_t>(),
+                                   rows_tmp.as<uint32_t>(), bi->rows_sorted, counts.as<uint32_t>(), d_n_runs, tmp.p, tb, st),
+              "inverted sort");
     // a hash held by m sketches costs m^2 increments as a rare hash, or one bit column (n^2/2 pairs x 1/32 word) as
     // a frequent one: the two meet at m ~ n * sqrt(RATE_PAIR_ATOMICS / (64 * RATE_BIT_WORDS))
     uint32_t threshold = (uint32_t)((double)n * std::sqrt(RATE_PAIR_ATOMICS / (64.0 * RATE_BIT_WORDS)));
     if (threshold < 1) threshold = 1;
     if (forced_threshold) threshold = forced_threshold;
-    flags.reserve((U + 1) * 4);
-    run_off.reserve((U + 2) * 8);
-    freq_rank.reserve((U + 2) * 8);
-    hip_check(hipMemsetAsync((char*)flags.p + U * 4, 0, 4, st), "memset");
-    unsigned long long* d_rare = scal.as<unsigned long long>() + 1;
-    hip_check(inverted_classify_launch(counts.as<uint32_t>(), U, threshold, flags.as<uint32_t>(), d_rare, st), "classify");
-    hip_check(inverted_offsets_launch(counts.as<uint32_t>(), flags.as<uint32_t>(), U, run_off.as<uint64_t>(),
-                                      freq_rank.as<uint64_t>(), tmp.p, tb, st), "run offsets");
-    uint64_t n_freq = 0;
-    unsigned long long rare_pairs = 0;
-    hip_check(hipMemcpyAsync(&n_freq, freq_rank.as<uint64_t>() + U, 8, hipMemcpyDeviceToHost, st), "D2H");
-    hip_check(hipMemcpyAsync(&rare_pairs, d_rare, 8, hipMemcpyDeviceToHost, st), "D2H");
+    hip_check(inverted_classify_launch(counts.as<uint32_t>(), d_n_runs, total, threshold, flags.as<uint32_t>(),
+                                       run_off.as<uint64_t>(), freq_rank.as<uint64_t>(), d_out, tmp.p, tb, st), "classify");
+    unsigned long long out[3] = {0, 0, 0};
+    hip_check(hipMemcpyAsync(out, d_out, 24, hipMemcpyDeviceToHost, st), "D2H");
     hip_check(hipStreamSynchronize(st), "sync");
+    const uint64_t U = out[0], n_freq = out[1], rare_pairs = out[2];
+    bi->universe = U;
+    const double pairs = 0.5 * (double)n * (double)n;
     const uint32_t words = n_freq ? (uint32_t)(((n_freq + 31) / 32 + 31) / 32 * 32) : 0;     // whole 32-word k-steps
     const double t_index = pairs * (double)words / RATE_BIT_WORDS + 2.0 * (double)rare_pairs / RATE_PAIR_ATOMICS +
                            (double)total / 2.0e10;                                         // + one pass over the elements
-    (void)mean_len;
-    if ((t_index > t_merge && !forced_threshold) || (double)n * words * 4.0 > 8.0 * (1ull << 30)) return nullptr;   // merge kernel wins / bitmap cap
+    if ((t_index > t_merge && !forced_threshold) || (double)n * words * 4.0 > 8.0 * (1ull << 30))
+        return nullptr;                                             // merge kernel wins / bitmap cap (~BitIndex frees)
     bi->frequent = n_freq; bi->rare_pairs = rare_pairs; bi->threshold = threshold; bi->words_per_row = words;
     if (words) {
-        hip_check(hipMalloc((void**)&bi->bits, (size_t)n * words * 4), "hipMalloc");
+        hip_check(hipMallocAsync((void**)&bi->bits, (size_t)n * words * 4, st), "hipMallocAsync");
         hip_check(hipMemsetAsync(bi->bits, 0, (size_t)n * words * 4, st), "memset");
     }
-    hip_check(hipMalloc((void**)&bi->run_end, total * 4 + 16), "hipMalloc");
-    hip_check(inverted_apply_launch(run_off.as<uint64_t>(), flags.as<uint32_t>(), freq_rank.as<uint64_t>(), U, bi->rows_sorted,
+    hip_check(hipMallocAsync((void**)&bi->run_end, total * 4 + 16, st), "hipMallocAsync");
+    hip_check(inverted_apply_launch(run_off.as<uint64_t>(), flags.as<uint32_t>(), freq_rank.as<uint64_t>(), U, total, bi->rows_sorted,
                                     bi->run_end, bi->bits, words, st), "inverted apply");
-    hip_check(hipStreamSynchronize(st), "sync");      // the scratch buffers are released on return
     if (rare_pairs == 0 && n_freq == U) {             // nothing is rare: plain bit rows, drop the inverted part
-        (void)hipFree(bi->rows_sorted); (void)hipFree(bi->run_end);
+        (void)hipFreeAsync(bi->rows_sorted, st); (void)hipFreeAsync(bi->run_end, st);
         bi->rows_sorted = bi->run_end = nullptr;
     }
-    return bi.release();
+    return bi.release();                              // stream-ordered: usable by later work on `st` without a sync
 }
 
 static void bitindex_compare(const BitIndex* bi, uint32_t rb_first, uint32_t rb_stride, uint32_t rb_count, uint32_t* d_common,
@@ -798,10 +785,11 @@ SmgpuBitIndex* smgpu_bitindex_new(const uint64_t* d_hashes, const uint64_t* d_of
         return reinterpret_cast<SmgpuBitIndex*>(bitindex_build(d_hashes, d_offsets, n, (hipStream_t)stream));
     });
 }
-SmgpuBitIndex* smgpu_bitindex_new_with_threshold(const uint64_t* d_hashes, const uint64_t* d_offsets, uint32_t n,
-                                                uint32_t threshold, void* stream) {
+SmgpuBitIndex* smgpu_bitindex_new_ex(const uint64_t* d_hashes, const uint64_t* d_offsets, uint32_t n, uint64_t total_hashes,
+                                     uint32_t threshold, bool one_shot, void* stream) {
     return landing<SmgpuBitIndex*>([&]() -> SmgpuBitIndex* {
-        return reinterpret_cast<SmgpuBitIndex*>(bitindex_build(d_hashes, d_offsets, n, (hipStream_t)stream, threshold));
+        return reinterpret_cast<SmgpuBitIndex*>(bitindex_build(d_hashes, d_offsets, n, (hipStream_t)stream, threshold, one_shot,
+                                                               total_hashes));
     });
 }
 void smgpu_bitindex_free(SmgpuBitIndex* p) { delete reinterpret_cast<BitIndex*>(p); }
@@ -820,12 +808,12 @@ void smgpu_bitindex_compare_raw(const SmgpuBitIndex* p, uint32_t rb_first, uint3
 }
 
 // n x n counts (+ Jaccard) of a device-resident CSR into host matrices; dense collections take the bit-row path
-static void compare_device_csr(const uint64_t* d_hashes, const uint64_t* d_offsets, uint64_t n, uint32_t* common_out,
-                               double* jaccard_out, hipStream_t st) {
+static void compare_device_csr(const uint64_t* d_hashes, const uint64_t* d_offsets, uint64_t n, uint64_t total,
+                               uint32_t* common_out, double* jaccard_out, hipStream_t st) {
     DevBuf dc, dj;
     struct Free { DevBuf& b; ~Free() { if (b.p) (void)hipFree(b.p); } } f3{dc}, f4{dj};
     dc.reserve((size_t)((n + 15) / 16 * 16) * n * 4);
-    std::unique_ptr<BitIndex> bi(bitindex_build(d_hashes, d_offsets, (uint32_t)n, st, 0, true));
+    std::unique_ptr<BitIndex> bi(bitindex_build(d_hashes, d_offsets, (uint32_t)n, st, 0, true, total));
     if (bi)   // bit rows for the frequent hashes + inverted lists for the rare ones
         bitindex_compare(bi.get(), 0, 1, (uint32_t)((n + 15) / 16), dc.as<uint32_t>(), st);
     else      // LDS-tiled merge walk
@@ -861,7 +849,7 @@ void smgpu_compare_all_pairs(const SourmashKmerMinHash* const* mhs, uintptr_t n,
                 hip_check(hipMemcpyAsync(dh.as<uint64_t>() + offsets[i], MH(mhs[i])->mins.data(), MH(mhs[i])->size() * 8,
                                          hipMemcpyHostToDevice, st), "H2D");
         hip_check(hipMemcpyAsync(doff.p, offsets.data(), (n + 1) * 8, hipMemcpyHostToDevice, st), "H2D");
-        compare_device_csr(dh.as<uint64_t>(), doff.as<uint64_t>(), n, common_out, jaccard_out, st);
+        compare_device_csr(dh.as<uint64_t>(), doff.as<uint64_t>(), n, total, common_out, jaccard_out, st);
     });
 }
 
@@ -1060,7 +1048,7 @@ void smgpu_sketchset_compare(const SmgpuSketchSet* p, uint32_t* common_out, doub
         if (s->num != 0) throw err_internal("smgpu_sketchset_compare handles scaled sketches");
         DeviceCtx& ctx = DeviceCtx::get();
         std::lock_guard<std::mutex> g(ctx.mutex());
-        compare_device_csr(s->hashes.as<uint64_t>(), s->offsets.as<uint64_t>(), s->n, common_out, jaccard_out, ctx.stream());
+        compare_device_csr(s->hashes.as<uint64_t>(), s->offsets.as<uint64_t>(), s->n, s->total, common_out, jaccard_out, ctx.stream());
     });
 }
 

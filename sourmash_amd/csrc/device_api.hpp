@@ -70,13 +70,14 @@ size_t inverted_temp_bytes(uint64_t total);
 hipError_t inverted_sort_launch(const uint64_t* d_hashes, const uint64_t* d_offsets, uint32_t n, uint64_t total,
                                 uint64_t* d_keys_a, uint64_t* d_keys_b, uint32_t* d_rows_tmp, uint32_t* d_rows_sorted,
                                 uint32_t* d_counts, uint64_t* d_n_runs, void* d_temp, size_t temp_bytes, hipStream_t stream);
-hipError_t inverted_classify_launch(const uint32_t* d_counts, uint64_t n_runs, uint32_t threshold, uint32_t* d_freq_flag,
-                                    unsigned long long* d_rare_pairs, hipStream_t stream);
-hipError_t inverted_offsets_launch(const uint32_t* d_counts, const uint32_t* d_freq_flag, uint64_t n_runs, uint64_t* d_run_off,
-                                   uint64_t* d_freq_rank, void* d_temp, size_t temp_bytes, hipStream_t stream);
+// one read-back for the host: d_out[0] distinct hashes, d_out[1] frequent ones, d_out[2] rare pair increments (zeroed by
+// the caller); flags / run offsets / frequent ranks sized for max_runs (= total elements) + 1 entries
+hipError_t inverted_classify_launch(const uint32_t* d_counts, const uint64_t* d_n_runs, uint64_t max_runs, uint32_t threshold,
+                                    uint32_t* d_freq_flag, uint64_t* d_run_off, uint64_t* d_freq_rank, unsigned long long* d_out,
+                                    void* d_temp, size_t temp_bytes, hipStream_t stream);
 hipError_t inverted_apply_launch(const uint64_t* d_run_off, const uint32_t* d_freq_flag, const uint64_t* d_freq_rank,
-                                 uint64_t n_runs, const uint32_t* d_rows_sorted, uint32_t* d_run_end, uint32_t* d_bits,
-                                 uint32_t words_per_row, hipStream_t stream);
+                                 uint64_t n_runs, uint64_t total, const uint32_t* d_rows_sorted, uint32_t* d_run_end,
+                                 uint32_t* d_bits, uint32_t words_per_row, hipStream_t stream);
 // common[local row][col] += rare-hash contributions, for the rows of the 16-row tiles rb_first, rb_first + rb_stride, ...
 hipError_t rare_pairs_launch(const uint32_t* d_rows_sorted, const uint32_t* d_run_end, uint64_t total, uint32_t n,
                              uint32_t rb_first, uint32_t rb_stride, uint32_t rb_count, uint32_t* d_common, hipStream_t stream);

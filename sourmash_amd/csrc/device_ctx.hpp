@@ -39,6 +39,37 @@ struct DevBuf {
     template <class T> T* as() const { return static_cast<T*>(p); }
 };
 
+// Stream-ordered scratch (hipMallocAsync pool): no device-wide synchronisation on allocation or release, which is
+// what plain hipMalloc / hipFree cost -- matters for index builds whose kernels take less time than that.
+// The default pool hands freed memory back to the driver at the next synchronisation unless told otherwise; scratch
+// that is allocated again and again (index builds, compare work lists) should stay in the pool.
+inline void keep_pool_memory() {
+    static const bool once = [] {
+        int dev = 0;
+        hipMemPool_t pool = nullptr;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess && pool) {
+            uint64_t keep = ~0ull;
+            (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+        }
+        return true;
+    }();
+    (void)once;
+}
+
+struct AsyncBuf {
+    void* p = nullptr;
+    hipStream_t st = nullptr;
+    AsyncBuf() = default;
+    AsyncBuf(size_t bytes, hipStream_t stream) : st(stream) {
+        keep_pool_memory();
+        hip_check(hipMallocAsync(&p, bytes + 256, stream), "hipMallocAsync");
+    }
+    AsyncBuf(const AsyncBuf&) = delete;
+    AsyncBuf& operator=(const AsyncBuf&) = delete;
+    ~AsyncBuf() { if (p) (void)hipFreeAsync(p, st); }
+    template <class T> T* as() const { return static_cast<T*>(p); }
+};
+
 struct PairStats {
     uint64_t common = 0;       // |A ∩ B|
     uint64_t prod = 0;         // sum abundA*abundB over the intersection

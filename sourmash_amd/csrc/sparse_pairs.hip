@@ -32,9 +32,11 @@ __global__ __launch_bounds__(256) void row_ids_kernel(const uint64_t* __restrict
 }
 
 // per run: frequent flag, and the number of pair increments the rare runs will cost
-__global__ __launch_bounds__(256) void classify_runs_kernel(const uint32_t* __restrict__ counts, uint64_t n_runs,
-                                                            uint32_t threshold, uint32_t* __restrict__ freq_flag,
+__global__ __launch_bounds__(256) void classify_runs_kernel(const uint32_t* __restrict__ counts,
+                                                            const uint64_t* __restrict__ d_n_runs, uint32_t threshold,
+                                                            uint32_t* __restrict__ freq_flag,
                                                             unsigned long long* __restrict__ rare_pairs) {
+    const uint64_t n_runs = *d_n_runs;
     unsigned long long pairs = 0;
     for (uint64_t u = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; u < n_runs; u += (uint64_t)gridDim.x * blockDim.x) {
         const uint32_t m = counts[u];
@@ -61,6 +63,28 @@ __global__ __launch_bounds__(256) void runs_apply_kernel(const uint64_t* __restr
             }
         } else {
             for (uint64_t p = lo; p < hi; ++p) run_end[p] = (uint32_t)hi;
+        }
+    }
+}
+
+// the same, one lane per ELEMENT (its run found by binary search in run_off): for collections whose runs are long
+// (few distinct hashes, each held by many sketches) a lane per run would serialise thousands of atomics
+__global__ __launch_bounds__(256) void elements_apply_kernel(const uint64_t* __restrict__ run_off, const uint32_t* __restrict__ freq_flag,
+                                                             const uint64_t* __restrict__ freq_rank, uint64_t n_runs, uint64_t total,
+                                                             const uint32_t* __restrict__ rows, uint32_t* __restrict__ run_end,
+                                                             uint32_t* __restrict__ bits, uint32_t words_per_row) {
+    for (uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; p < total; p += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t lo = 0, hi = n_runs;                             // last run with run_off[u] <= p
+        while (hi - lo > 1) {
+            const uint64_t mid = (lo + hi) >> 1;
+            if (run_off[mid] <= p) lo = mid; else hi = mid;
+        }
+        if (freq_flag[lo]) {
+            const uint64_t f = freq_rank[lo];
+            run_end[p] = 0;
+            atomicOr(&bits[(uint64_t)rows[p] * words_per_row + (f >> 5)], 1u << (f & 31));
+        } else {
+            run_end[p] = (uint32_t)run_off[lo + 1];
         }
     }
 }
@@ -132,31 +156,44 @@ hipError_t inverted_sort_launch(const uint64_t* d_hashes, const uint64_t* d_offs
                                       d_counts, d_n_runs, stream);
 }
 
-// flags + cost of the rare part; *d_rare_pairs must be zero
-hipError_t inverted_classify_launch(const uint32_t* d_counts, uint64_t n_runs, uint32_t threshold, uint32_t* d_freq_flag,
-                                    unsigned long long* d_rare_pairs, hipStream_t stream) {
-    if (n_runs == 0) return hipSuccess;
-    hipLaunchKernelGGL(classify_runs_kernel, dim3(grid_for(n_runs)), dim3(256), 0, stream, d_counts, n_runs, threshold,
-                       d_freq_flag, d_rare_pairs);
+__global__ void publish_kernel(const uint64_t* __restrict__ d_n_runs, const uint64_t* __restrict__ freq_rank,
+                               unsigned long long* __restrict__ out) {
+    out[0] = *d_n_runs;                 // distinct hashes
+    out[1] = freq_rank[*d_n_runs];      // frequent ones
+}
+
+// Everything the host has to know in ONE read-back: d_out[0] = number of runs (distinct hashes), d_out[1] = frequent
+// runs, d_out[2] = pair increments of the rare runs (d_out[2] must be zero on entry).  The number of runs stays on the
+// device: flags and scans cover max_runs (= total elements) entries, of which only the first *d_n_runs mean anything.
+// d_run_off[u] = first element of run u, d_freq_rank[u] = index of run u among the frequent runs.
+hipError_t inverted_classify_launch(const uint32_t* d_counts, const uint64_t* d_n_runs, uint64_t max_runs, uint32_t threshold,
+                                    uint32_t* d_freq_flag, uint64_t* d_run_off, uint64_t* d_freq_rank, unsigned long long* d_out,
+                                    void* d_temp, size_t temp_bytes, hipStream_t stream) {
+    if (max_runs == 0) return hipSuccess;
+    hipLaunchKernelGGL(classify_runs_kernel, dim3(grid_for(max_runs)), dim3(256), 0, stream, d_counts, d_n_runs, threshold,
+                       d_freq_flag, d_out + 2);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    size_t tb = temp_bytes;
+    e = rocprim::exclusive_scan(d_temp, tb, d_counts, d_run_off, (uint64_t)0, (size_t)max_runs + 1, rocprim::plus<uint64_t>(), stream);
+    if (e != hipSuccess) return e;
+    tb = temp_bytes;
+    e = rocprim::exclusive_scan(d_temp, tb, d_freq_flag, d_freq_rank, (uint64_t)0, (size_t)max_runs + 1, rocprim::plus<uint64_t>(),
+                                stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(publish_kernel, dim3(1), dim3(1), 0, stream, d_n_runs, d_freq_rank, d_out);
     return hipGetLastError();
 }
 
-// d_run_off[u] = first element of run u (n_runs + 1 entries), d_freq_rank[u] = index among the frequent runs
-hipError_t inverted_offsets_launch(const uint32_t* d_counts, const uint32_t* d_freq_flag, uint64_t n_runs, uint64_t* d_run_off,
-                                   uint64_t* d_freq_rank, void* d_temp, size_t temp_bytes, hipStream_t stream) {
-    size_t tb = temp_bytes;
-    hipError_t e = rocprim::exclusive_scan(d_temp, tb, d_counts, d_run_off, (uint64_t)0, (size_t)n_runs + 1,
-                                           rocprim::plus<uint64_t>(), stream);
-    if (e != hipSuccess) return e;
-    tb = temp_bytes;
-    return rocprim::exclusive_scan(d_temp, tb, d_freq_flag, d_freq_rank, (uint64_t)0, (size_t)n_runs + 1,
-                                   rocprim::plus<uint64_t>(), stream);
-}
-
 hipError_t inverted_apply_launch(const uint64_t* d_run_off, const uint32_t* d_freq_flag, const uint64_t* d_freq_rank,
-                                 uint64_t n_runs, const uint32_t* d_rows_sorted, uint32_t* d_run_end, uint32_t* d_bits,
-                                 uint32_t words_per_row, hipStream_t stream) {
+                                 uint64_t n_runs, uint64_t total, const uint32_t* d_rows_sorted, uint32_t* d_run_end,
+                                 uint32_t* d_bits, uint32_t words_per_row, hipStream_t stream) {
     if (n_runs == 0) return hipSuccess;
+    if (total / n_runs >= 8) {                                    // long runs: a lane per element
+        hipLaunchKernelGGL(elements_apply_kernel, dim3(grid_for(total, 256, 16384)), dim3(256), 0, stream, d_run_off, d_freq_flag,
+                           d_freq_rank, n_runs, total, d_rows_sorted, d_run_end, d_bits, words_per_row);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(runs_apply_kernel, dim3(grid_for(n_runs)), dim3(256), 0, stream, d_run_off, d_freq_flag, d_freq_rank,
                        n_runs, d_rows_sorted, d_run_end, d_bits, words_per_row);
     return hipGetLastError();

@@ -122,14 +122,13 @@ class BitIndex:
         self._ptr, self.n = ptr, n
 
     @classmethod
-    def build(cls, hashes, offsets, threshold=None):
-        "threshold: hashes held by more sketches than this become bit columns (None: the library's cost model)"
+    def build(cls, hashes, offsets, threshold=None, one_shot=False):
+        """threshold: hashes held by more sketches than this become bit columns (None: the library's cost model);
+        one_shot: the index serves one compare only, so its own build time counts against it."""
         torch = _torch()
         n = offsets.numel() - 1
-        if threshold:
-            ptr = rustcall(lib.smgpu_bitindex_new_with_threshold, _ptr(hashes), _ptr(offsets), n, int(threshold), _stream(torch))
-        else:
-            ptr = rustcall(lib.smgpu_bitindex_new, _ptr(hashes), _ptr(offsets), n, _stream(torch))
+        ptr = rustcall(lib.smgpu_bitindex_new_ex, _ptr(hashes), _ptr(offsets), n, 0, int(threshold or 0), bool(one_shot),
+                       _stream(torch))
         return cls(ptr, n) if ptr else None
 
     @property
@@ -152,17 +151,22 @@ class BitIndex:
         return out
 
     def __del__(self):
-        if getattr(self, "_ptr", None):
+        if getattr(self, "_ptr", None) and lib is not None:        # (module globals are gone at interpreter exit)
             lib.smgpu_bitindex_free(self._ptr)
             self._ptr = None
 
 
-def compare_rows(hashes, offsets, row_lo=0, row_hi=None, want_jaccard=True, common=None, jaccard=None, index=None):
+def compare_rows(hashes, offsets, row_lo=0, row_hi=None, want_jaccard=True, common=None, jaccard=None, index=None,
+                 method="merge"):
     """common[(row_hi-row_lo), n] (int32 view of u32) and jaccard (float64) for a row block of the
     all-pairs matrix of a device CSR.  Asynchronous on the current stream.
 
-    index: a BitIndex built for this CSR (dense collections) -> popcount path; None -> merge kernel."""
+    index: a BitIndex built for this CSR -> indexed path (bit columns + inverted lists).  Without one, method
+    "merge" runs the LDS-tiled merge kernel and "auto" first lets the library build a one-shot index if its cost
+    model says that beats merging (what smgpu_compare_all_pairs does)."""
     torch = _torch()
+    if index is None and method == "auto":
+        index = BitIndex.build(hashes, offsets, one_shot=True)
     n = offsets.numel() - 1
     row_hi = n if row_hi is None else row_hi
     rows = row_hi - row_lo
