@@ -185,7 +185,7 @@ extern "C" {
 // ---------------------------------------------------------------------------------------------
 // library / errors
 // ---------------------------------------------------------------------------------------------
-void sourmash_init(void) {}
+void sourmash_init(void) { keep_pool_memory(); }   // stream-ordered scratch stays in the pool between calls
 void sourmash_err_clear(void) { g_err_code = 0; g_err_msg.clear(); }
 SourmashErrorCode sourmash_err_get_last_code(void) { return g_err_code; }
 SourmashStr sourmash_err_get_last_message(void) {

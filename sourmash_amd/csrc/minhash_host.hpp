@@ -119,6 +119,15 @@ struct KmerMinHash {
     void add_sorted_batch(const uint64_t* hs, const uint64_t* counts, size_t n) {
         if (n == 0) return;
         if (num == 0 && max_hash == 0) return;
+        if (mins.empty() && num == 0) {                        // first batch of a scaled sketch: it IS the sketch
+            const size_t keep = (size_t)(std::upper_bound(hs, hs + n, max_hash) - hs);
+            mins.assign(hs, hs + keep);
+            if (track_abundance) {
+                if (counts) abunds.assign(counts, counts + keep);
+                else abunds.assign(keep, 1);
+            }
+            return;
+        }
         std::vector<uint64_t> mm, ma;
         mm.reserve(mins.size() + n);
         if (track_abundance) ma.reserve(mins.size() + n);
