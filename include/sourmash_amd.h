@@ -232,6 +232,12 @@ void smgpu_minhash_add_buffer(SourmashKmerMinHash *ptr, const char *buf, uintptr
  * pass.  force=True semantics (bytes outside ACGTacgt drop the k-mers covering them).  Returns the
  * number of sequence bytes read; *n_records = number of records. */
 uint64_t smgpu_signature_add_file(SourmashSignature *ptr, const char *path, uint64_t *n_records);
+/* `sourmash sketch dna` over many files at once: n_threads workers (0 = min(16, host cores)), each with its own
+ * stream, pinned ring and device buffers, one signature per file in input order (every ksize of `params` in it).
+ * Returns an array of n signature handles (free each with signature_free and the array with nodegraph_buffer_free,
+ * like signatures_load_buffer's). */
+SourmashSignature **smgpu_sketch_files(const char *const *paths, uintptr_t n, const SourmashComputeParameters *params,
+                                       uint32_t n_threads, uint64_t *total_bases);
 uint64_t smgpu_minhash_add_file(SourmashKmerMinHash *ptr, const char *path, uint64_t *n_records);
 
 /* Scratch size needed by smgpu_sketch_dna_raw for an output capacity. */

@@ -602,6 +602,21 @@ uint64_t smgpu_signature_add_file(SourmashSignature* p, const char* path, uint64
         return bases;
     });
 }
+SourmashSignature** smgpu_sketch_files(const char* const* paths, uintptr_t n, const SourmashComputeParameters* params,
+                                       uint32_t n_threads, uint64_t* total_bases) {
+    return landing<SourmashSignature**>([&]() -> SourmashSignature** {
+        if (!paths && n) throw err_internal("null paths");
+        if (!CP(params)->dna || CP(params)->protein || CP(params)->dayhoff || CP(params)->hp)
+            throw err_internal("smgpu_sketch_files takes DNA parameters; protein / dayhoff / hp sketches are fed record by record");
+        std::vector<std::string> files(paths, paths + n);
+        std::vector<Signature> sigs;
+        uint64_t bases = 0;
+        sketch_files_parallel(files, *CP(params), n_threads, sigs, &bases);
+        if (total_bases) *total_bases = bases;
+        uintptr_t size = 0;
+        return sigs_out(std::move(sigs), &size);
+    });
+}
 uint64_t smgpu_minhash_add_file(SourmashKmerMinHash* p, const char* path, uint64_t* n_records) {
     return landing<uint64_t>([&]() -> uint64_t {
         if (!path) throw err_internal("null path");

@@ -48,7 +48,8 @@ class RawChunkSource {
   public:
     static constexpr int SLOTS = 8;
 
-    RawChunkSource(const std::string& path, size_t chunk, PinnedBuf* ring) : path_(path), chunk_(chunk), ring_(ring) {
+    RawChunkSource(const std::string& path, size_t chunk, PinnedBuf* ring, unsigned max_readers = 6)
+        : path_(path), chunk_(chunk), ring_(ring) {
         fd_ = ::open(path.c_str(), O_RDONLY);
         if (fd_ < 0) throw Error(E_IO, "No such file or directory: " + path);
         struct stat st;
@@ -66,7 +67,7 @@ class RawChunkSource {
         } else {
             const uint64_t n_chunks = (size_ + chunk_ - 1) / chunk_;
             end_seq_ = (int64_t)n_chunks;
-            unsigned want = 6;                      // SMG_INGEST_THREADS overrides (tuning)
+            unsigned want = max_readers;            // SMG_INGEST_THREADS overrides (tuning)
             if (const char* e = getenv("SMG_INGEST_THREADS")) { const long v = atol(e); if (v >= 1 && v <= SLOTS) want = (unsigned)v; }
             const unsigned nt = (unsigned)std::min<uint64_t>(want, n_chunks);
             for (unsigned t = 0; t < nt; ++t) threads_.emplace_back([this] { produce_plain(); });
@@ -215,37 +216,54 @@ struct IngestScratch {
     }
 };
 
-// Sketch a sequence file into every (DNA) sketch of `mhs`.  force == true semantics.
-inline void sketch_file_into(std::vector<KmerMinHash*>& mhs, const std::string& path, uint64_t* n_records,
-                             uint64_t* n_bases) {
+struct IngestSlot {
+    void* p = nullptr;
+    template <class T> T* as() const { return static_cast<T*>(p); }
+};
+
+// One ingest pipeline: a compute stream and the buffers that go with it.  The single-file entry points share one
+// (on the context's stream, under its mutex); smgpu_sketch_files gives every worker thread its own, so many files
+// stream concurrently -- what a gzip-bound `sketch` over a directory of genomes needs.
+struct IngestWorker {
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    IngestScratch scratch;
+    void init_own_stream() {
+        if (!stream) { hip_check(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking), "hipStreamCreate"); own_stream = true; }
+    }
+    ~IngestWorker() { if (own_stream && stream) (void)hipStreamDestroy(stream); }
+};
+
+// Sketch a sequence file into every (DNA) sketch of `mhs` on the worker's pipeline.  force == true semantics.
+inline void sketch_file_with(IngestWorker& w, std::vector<KmerMinHash*>& mhs, const std::string& path, size_t CHUNK,
+                             unsigned max_readers, uint64_t* n_records, uint64_t* n_bases) {
     for (auto* mh : mhs)
         if (!mh->is_dna()) throw err_internal("the streaming file ingest takes DNA sketches; protein / dayhoff / hp sketches are fed record by record");
     uint32_t kmax = 0;
     for (auto* mh : mhs) kmax = std::max(kmax, mh->ksize);
     if (mhs.empty() || kmax == 0) return;
     if (kmax > IngestScratch::HALO) throw err_internal("ksize too large for the streaming ingest");
-    DeviceCtx& ctx = DeviceCtx::get();
-    std::lock_guard<std::mutex> g(ctx.mutex());
-    hipStream_t st = ctx.stream();
-
-    // 32 MiB chunks; SMG_INGEST_CHUNK (bytes) overrides it so tests can force many chunk boundaries
-    size_t CHUNK = (size_t)32 << 20;
-    if (const char* e = getenv("SMG_INGEST_CHUNK")) { const long v = atol(e); if (v >= 256) CHUNK = (size_t)v; }
-    static IngestScratch scratch;                   // guarded by the context mutex
+    hipStream_t st = w.stream;
+    IngestScratch& scratch = w.scratch;
     scratch.prepare(CHUNK);
     const int halo = (int)kmax - 1;
 
     struct Acc {                       // per sketch: unordered kept hashes since the last flush
-        DevBuf out, cnt;
+        IngestSlot out, cnt;       // stream-ordered allocations (no device-wide sync: other workers keep running)
         size_t cap = 0;
         unsigned long long count = 0;  // host copy, exact after a sync
     };
+    keep_pool_memory();
     std::vector<Acc> acc(mhs.size());
-    for (auto& a : acc) { a.cnt.reserve(64); hip_check(hipMemsetAsync(a.cnt.p, 0, 64, st), "memset"); }
     struct FreeAcc {
         std::vector<Acc>& v;
-        ~FreeAcc() { for (auto& a : v) { if (a.out.p) (void)hipFree(a.out.p); if (a.cnt.p) (void)hipFree(a.cnt.p); a.out.p = a.cnt.p = nullptr; } }
-    } free_acc{acc};
+        hipStream_t st;
+        ~FreeAcc() { for (auto& a : v) { if (a.out.p) (void)hipFreeAsync(a.out.p, st); if (a.cnt.p) (void)hipFreeAsync(a.cnt.p, st); a.out.p = a.cnt.p = nullptr; } }
+    } free_acc{acc, st};
+    for (auto& a : acc) {
+        hip_check(hipMallocAsync(&a.cnt.p, 64, st), "hipMallocAsync");
+        hip_check(hipMemsetAsync(a.cnt.p, 0, 64, st), "memset");
+    }
 
     // flush: sort + unique (+ multiplicities) what has accumulated, merge it into the host container
     auto flush = [&](size_t s) {
@@ -255,11 +273,8 @@ inline void sketch_file_into(std::vector<KmerMinHash*>& mhs, const std::string& 
         hip_check(hipStreamSynchronize(st), "sync");
         if (a.count > a.cap) throw err_internal("sketch output overflow while ingesting " + path);
         if (a.count == 0) return;
-        DevBuf uniq, tmp;
-        struct Free { DevBuf& b; ~Free() { if (b.p) (void)hipFree(b.p); } } f1{uniq}, f2{tmp};
         const size_t tb = sort_unique_temp_bytes(a.count);
-        tmp.reserve(tb);
-        uniq.reserve((size_t)a.count * 16 + 64);
+        AsyncBuf tmp(tb, st), uniq((size_t)a.count * 16 + 64, st);
         uint64_t* d_u = uniq.as<uint64_t>();
         uint64_t* d_c = d_u + a.count;
         const uint64_t thr = mh.max_hash ? mh.max_hash : ~0ull;
@@ -297,7 +312,7 @@ inline void sketch_file_into(std::vector<KmerMinHash*>& mhs, const std::string& 
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_start = now();
     double t_wait = 0, t_sync = 0;
-    RawChunkSource src(path, CHUNK, scratch.ring);
+    RawChunkSource src(path, CHUNK, scratch.ring, max_readers);
     constexpr size_t FLUSH_AT = (size_t)64 << 20;            // entries; keeps scratch bounded on huge inputs
     int fastq = -1;
     uint64_t total_kept = 0;
@@ -358,12 +373,11 @@ inline void sketch_file_into(std::vector<KmerMinHash*>& mhs, const std::string& 
             const size_t need = (size_t)a.count + expect;
             if (need > a.cap) {
                 const size_t ncap = std::max(need + need / 2, (size_t)1 << 16);
-                DevBuf bigger;
-                bigger.reserve(ncap * 8);
-                if (a.count) hip_check(hipMemcpyAsync(bigger.p, a.out.p, (size_t)a.count * 8, hipMemcpyDeviceToDevice, st), "D2D");
-                hip_check(hipStreamSynchronize(st), "sync");
-                if (a.out.p) (void)hipFree(a.out.p);
-                a.out = bigger; bigger.p = nullptr; bigger.cap = 0;
+                void* bigger = nullptr;
+                hip_check(hipMallocAsync(&bigger, ncap * 8, st), "hipMallocAsync");
+                if (a.count) hip_check(hipMemcpyAsync(bigger, a.out.p, (size_t)a.count * 8, hipMemcpyDeviceToDevice, st), "D2D");
+                if (a.out.p) hip_check(hipFreeAsync(a.out.p, st), "hipFreeAsync");
+                a.out.p = bigger;
                 a.cap = ncap;
             }
             hip_check(sketch_dna_launch(comp - (k - 1), slen, k, mh.seed, thr, a.out.as<uint64_t>(),
@@ -385,6 +399,64 @@ inline void sketch_file_into(std::vector<KmerMinHash*>& mhs, const std::string& 
     if (trace)
         fprintf(stderr, "[ingest] %s: loop %.3f s (waiting for the reader %.3f s, for the GPU %.3f s), final flush %.3f s\n",
                 path.c_str(), t_loop - t_start, t_wait, t_sync, now() - t_loop);
+}
+
+// single-file entry point: the shared pipeline on the context's stream
+inline void sketch_file_into(std::vector<KmerMinHash*>& mhs, const std::string& path, uint64_t* n_records,
+                             uint64_t* n_bases) {
+    DeviceCtx& ctx = DeviceCtx::get();
+    std::lock_guard<std::mutex> g(ctx.mutex());
+    static IngestWorker shared;                     // guarded by the context mutex
+    shared.stream = ctx.stream();
+    // 32 MiB chunks; SMG_INGEST_CHUNK (bytes) overrides it so tests can force many chunk boundaries
+    size_t chunk = (size_t)32 << 20;
+    if (const char* e = getenv("SMG_INGEST_CHUNK")) { const long v = atol(e); if (v >= 256) chunk = (size_t)v; }
+    sketch_file_with(shared, mhs, path, chunk, 6, n_records, n_bases);
+}
+
+// Many files at once: `threads` workers, each with its own stream, pinned ring and device chunks (4 MiB pieces: the
+// inputs are typically single genomes), pull files from a shared counter.  out[i] is the signature of paths[i].
+inline void sketch_files_parallel(const std::vector<std::string>& paths, const ComputeParameters& params, unsigned threads,
+                                  std::vector<Signature>& out, uint64_t* total_bases) {
+    (void)DeviceCtx::get();                         // fail early without a GPU
+    out.assign(paths.size(), Signature());
+    if (threads == 0) threads = std::min<unsigned>(16, std::max(1u, std::thread::hardware_concurrency()));
+    if (threads > paths.size()) threads = (unsigned)std::max<size_t>(paths.size(), 1);
+    std::atomic<size_t> next(0);
+    std::atomic<uint64_t> bases(0);
+    std::mutex err_mutex;
+    std::vector<Error> errors;
+    int device = 0;
+    (void)hipGetDevice(&device);
+    auto run = [&]() {
+        (void)hipSetDevice(device);
+        IngestWorker w;
+        try {
+            w.init_own_stream();
+            for (;;) {
+                const size_t i = next.fetch_add(1);
+                if (i >= paths.size()) break;
+                Signature sig = Signature::from_params(params);
+                std::vector<KmerMinHash*> mhs;
+                for (auto& mh : sig.sketches) mhs.push_back(&mh);
+                uint64_t recs = 0, b = 0;
+                sketch_file_with(w, mhs, paths[i], (size_t)4 << 20, 1, &recs, &b);
+                sig.filename = paths[i];
+                bases += b;
+                out[i] = std::move(sig);
+            }
+            hip_check(hipStreamSynchronize(w.stream), "sync");
+        } catch (const Error& e) {
+            std::lock_guard<std::mutex> g(err_mutex);
+            errors.push_back(e);
+        }
+    };
+    std::vector<std::thread> pool;
+    for (unsigned t = 1; t < threads; ++t) pool.emplace_back(run);
+    run();
+    for (auto& t : pool) t.join();
+    if (!errors.empty()) throw errors.front();
+    if (total_bases) *total_bases = bases.load();
 }
 
 }  // namespace smg

@@ -280,3 +280,20 @@ def sketch_file(path, param_str=DEFAULTS["dna"], *, name=None, check_sequence=Fa
         name = ""
     return sketch_records(recs, param_str, name=name or "", filename=str(path), check_sequence=check_sequence,
                           singleton=singleton, moltype=moltype, input_is_protein=input_is_protein)
+
+
+def sketch_files(paths, param_str=DEFAULTS["dna"], *, threads=0):
+    """`sourmash sketch dna -p <param_str> f1 f2 ...` -> one SourmashSignature per file, in order.
+
+    The files stream through `threads` independent pipelines (host reader / inflate thread -> pinned ring -> HBM ->
+    device-side parse -> sketch), so a directory of gzipped genomes is no longer bound by one zlib stream."""
+    paths = [str(p) for p in paths]
+    if not paths:
+        return []
+    params = ComputeParameters.from_param_str(param_str)
+    arr = (C.c_char_p * len(paths))(*[p.encode("utf-8") for p in paths])
+    bases = C.c_uint64(0)
+    ptr = rustcall(lib.smgpu_sketch_files, arr, len(paths), params._get_objptr(), int(threads), C.byref(bases))
+    sigs = [SourmashSignature._from_objptr(ptr[i]) for i in range(len(paths))]
+    lib.nodegraph_buffer_free(C.cast(ptr, C.POINTER(C.c_uint8)), len(paths) * C.sizeof(C.c_void_p))
+    return sigs

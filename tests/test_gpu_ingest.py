@@ -111,3 +111,32 @@ def test_missing_file_raises(sm):
     from sourmash_amd.sketch import sketch_file
     with pytest.raises(sm.exceptions.SourmashError):
         sketch_file("/nonexistent/file.fa")
+
+
+def test_many_files_in_parallel(sm, tmp_path):
+    "smgpu_sketch_files: independent pipelines, one signature per file in input order, same sketches as file by file"
+    from sourmash_amd.sketch import sketch_file, sketch_files
+    recs = _records(np.random.default_rng(9), n=4)
+    fa, fq = str(tmp_path / "a.fa"), str(tmp_path / "b.fastq")
+    _write_fasta(fa, recs, width=60)
+    with open(fq, "w") as fh:
+        for n, s in recs[::-1]:
+            fh.write(f"@{n}\n{s}\n+\n{'I' * len(s)}\n")
+    paths = [golden("ecoli", "GCF_000005845.2_ASM584v2_genomic.fna.gz"), fa, golden("num", "genome-s10.fa.gz"), fq,
+             golden("scaled100", "GCF_000006945.1_ASM694v1_genomic.fna.gz")] * 3
+    params = "k=21,k=31,k=51,scaled=1000,abund"
+    one_by_one = {p: sketch_file(p, params)[0] for p in set(paths)}
+    for threads in (1, 4, 0):
+        sigs = sketch_files(paths, params, threads=threads)
+        assert [s.filename for s in sigs] == paths
+        for p, sig in zip(paths, sigs):
+            want = {mh.ksize: mh for mh in one_by_one[p].minhashes()}
+            got = {mh.ksize: mh for mh in sig.minhashes()}
+            assert sorted(got) == [21, 31, 51]
+            for k in got:
+                assert got[k] == want[k], (p, k, threads)
+    flat = sketch_files(paths[:1], "k=31,scaled=1000")[0]
+    assert flat.minhash.md5sum() == "0a8632c67e6d88f737ddb510bef90337"          # the reference's E. coli k=31 sketch
+    assert sketch_files([]) == []
+    with pytest.raises(sm.exceptions.SourmashError):
+        sketch_files([fa, "/nonexistent/file.fa"], params)
