@@ -231,6 +231,8 @@ class FrozenSourmashSignature(SourmashSignature):
 # ---- JSON -------------------------------------------------------------------------------------
 def _as_buffer(data):
     "file-like / path / str / bytes -> bytes or None"
+    if hasattr(data, "__fspath__") or (hasattr(data, "strpath") and not isinstance(data, (str, bytes))):
+        data = os.fspath(data) if hasattr(data, "__fspath__") else data.strpath
     if hasattr(data, "read"):
         if hasattr(data, "mode") and "t" in data.mode and hasattr(data, "buffer"):
             data = data.buffer
@@ -295,7 +297,7 @@ def load_one_signature_from_json(data, ksize=None, select_moltype=None, ignore_m
 
 
 def save_signatures_to_json(siglist, fp=None, compression=0):
-    "Serialise signatures to a JSON string (bytes when compressed), or write to `fp`."
+    "Serialise signatures to JSON bytes (gzip when compression > 0; src/sourmash/signature.py:493-527), or write to `fp`."
     sigs = list(siglist)
     ptrs = (C.c_void_p * max(len(sigs), 1))(*[s._get_objptr() for s in sigs])
     size = ffi.new_size()
@@ -304,12 +306,10 @@ def save_signatures_to_json(siglist, fp=None, compression=0):
         result = C.string_at(raw, size.value)
     finally:
         lib.nodegraph_buffer_free(raw, size.value)
-    if not compression:
-        result = result.decode("utf-8")
     if fp is None:
         return result
     try:
         fp.write(result)
-    except TypeError:
-        fp.write(result.decode("utf-8") if isinstance(result, bytes) else result.encode("utf-8"))
+    except TypeError:                                    # a text-mode handle
+        fp.write(result.decode("utf-8"))
     return None

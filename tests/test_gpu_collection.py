@@ -65,7 +65,7 @@ def test_compare_and_rows_from_a_zip(sm, tmp_path):
             md5 = ss.md5sum()
             loc = f"signatures/{md5}.sig.gz"
             if loc not in zf.namelist():                                # the planted duplicate shares its md5
-                zf.writestr(loc, gzip.compress(sm.save_signatures_to_json([ss]).encode()))
+                zf.writestr(loc, gzip.compress(sm.save_signatures_to_json([ss])))
             man.write(f'{loc},{md5},{md5[:8]},31,DNA,0,1000,{len(ss.minhash)},0,"{ss.name}",{ss.filename}\r\n')
         zf.writestr("SOURMASH-MANIFEST.csv", man.getvalue())
     db = SketchSet.load(zpath, ksize=31, moltype="DNA", scaled=1000, threads=4)
