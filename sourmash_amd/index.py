@@ -26,7 +26,7 @@ from .search import calc_threshold_from_bp, make_containment_query, make_jaccard
 from .signature import SourmashSignature
 from .utils import RustObject, decode_str, rustcall
 
-__all__ = ["IndexSearchResult", "Collection", "SketchSet", "LinearIndex", "CounterGather"]
+__all__ = ["IndexSearchResult", "Collection", "SketchSet", "select_signature", "LinearIndex", "CounterGather"]
 
 IndexSearchResult = namedtuple("Result", "score, signature, location")
 
@@ -244,6 +244,47 @@ class _DeviceCounter(RustObject):
         return idx[:k], isect[:k]
 
 
+def _check_select_parameters(**kw):
+    "types of the 'select' arguments (index/__init__.py:1229-1270)"
+    extra = set(kw) - {"ksize", "num", "moltype", "scaled", "abund", "picklist", "containment"}
+    if extra:
+        raise ValueError(f"unknown 'select' parameters: {extra}")
+    for key in ("ksize", "scaled", "num"):
+        v = kw.get(key)
+        if v is not None and not isinstance(v, int):
+            raise ValueError(f"{key} value '{v}' must be an integer, is: {type(v)}")
+    moltype = kw.get("moltype")
+    if moltype is not None and moltype not in ("DNA", "protein", "dayhoff", "hp"):
+        raise ValueError(f"unknown moltype: {moltype}")
+    for key in ("containment", "abund"):
+        v = kw.get(key)
+        if v is not None and not isinstance(v, bool):
+            raise ValueError(f"{key} value '{v}' must be a bool, is: {type(v)}")
+
+
+def select_signature(ss, *, ksize=None, moltype=None, scaled=0, num=0, containment=False, abund=None, picklist=None):
+    "does the signature meet the requirements? (index/__init__.py:349-394)"
+    mh = ss.minhash
+    if ksize and ksize != mh.ksize:
+        return False
+    if moltype and moltype != mh.moltype:
+        return False
+    if containment:                              # containment needs scaled sketches; similarity does not
+        if not scaled:
+            raise ValueError("'containment' requires 'scaled' in Index.select'")
+        if not mh.scaled:
+            return False
+    if scaled and mh.num:                        # 'scaled' and 'num' exclude each other
+        return False
+    if num and (mh.scaled or num != mh.num):
+        return False
+    if abund and not mh.track_abundance:         # a sketch with abundances can always be flattened
+        return False
+    if picklist is not None and ss not in picklist:
+        return False
+    return True
+
+
 class LinearIndex:
     "An in-memory list of signatures searched exhaustively -- on the GPU, all at once."
     is_database = False
@@ -274,24 +315,13 @@ class LinearIndex:
         self._signatures.append(node)
         self._packed = None
 
-    def select(self, ksize=None, moltype=None, scaled=None, num=None, abund=None, containment=None, **kw):
-        "Filter by sketch parameters (index/__init__.py:333-394 semantics for the common keys)."
-        def ok(ss):
-            mh = ss.minhash
-            if ksize is not None and mh.ksize != ksize:
-                return False
-            if moltype is not None and mh.moltype != moltype:
-                return False
-            if containment and not mh.scaled:
-                raise ValueError("Containment requires scaled signatures.")
-            if scaled is not None and scaled and (not mh.scaled or mh.scaled > scaled):
-                return False
-            if num is not None and num and mh.num != num:
-                return False
-            if abund and not mh.track_abundance:
-                return False
-            return True
-        return LinearIndex([ss for ss in self._signatures if ok(ss)], self.filename)
+    manifest = None                  # an in-memory list carries no manifest (index/__init__.py:397-453)
+
+    def select(self, **kwargs):
+        """New LinearIndex with the signatures that match the requirements; never raises for 'nothing matches'
+        (index/__init__.py:441-453 over select_signature :349-394, parameters checked as in :1229-1270)."""
+        _check_select_parameters(**kwargs)
+        return LinearIndex([ss for ss in self._signatures if select_signature(ss, **kwargs)], self.filename)
 
     # ---- batched scoring --------------------------------------------------------------------------
     def _scaled_counts(self, query_mh):
