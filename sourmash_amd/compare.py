@@ -107,7 +107,7 @@ def _debias_matrix(common, sizes, scaled, mode):
 
 def _containment(siglist, downsample, mode, return_ani):
     if return_ani:
-        raise NotImplementedError("ANI matrices: use MinHash.containment_ani per pair (host float layer)")
+        return _containment_ani(siglist, downsample, mode)
     mhs = [s.minhash for s in siglist]
     if not all(mh.scaled for mh in mhs):
         raise TypeError("Error: can only calculate containment for scaled MinHashes")
@@ -115,6 +115,28 @@ def _containment(siglist, downsample, mode, return_ani):
     common, _ = common_matrix(mhs, want_jaccard=False)
     sizes = [len(mh) for mh in mhs]
     return _debias_matrix(common, sizes, mhs[0].scaled if mhs else 1, mode)
+
+
+def _containment_ani(siglist, downsample, mode):
+    """ANI matrices from the containment family (compare.py:67-180 of the reference): the counts behind every entry
+    are GPU intersections, the ANI point estimates host floats per pair; a missing estimate is reported as 0."""
+    from .sketchcomparison import FracMinHashComparison
+    n = len(siglist)
+    out = np.ones((n, n))
+    for i in range(n):
+        for j in range(n):
+            if i == j or (mode != "containment" and j < i):
+                continue
+            if mode == "containment":
+                ani = siglist[j].containment_ani(siglist[i], downsample=downsample).ani
+                out[i][j] = 0.0 if ani is None else ani
+                continue
+            if mode == "max":
+                ani = siglist[j].max_containment_ani(siglist[i], downsample=downsample).ani
+            else:
+                ani = FracMinHashComparison(siglist[j].minhash, siglist[i].minhash).avg_containment_ani
+            out[i][j] = out[j][i] = 0.0 if ani is None else ani
+    return out
 
 
 def compare_serial_containment(siglist, *, downsample=False, return_ani=False):

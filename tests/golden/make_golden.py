@@ -61,6 +61,7 @@ for name, why in (("ecoli.faa", "protein input, tests/test_sourmash_compute.py:8
                   ("benchmark.input_prot.sig", "independent restatement of protein-input hashing (utils/compute-input-prot-another-way.py)"),
                   ("benchmark.prot.sig", "independent restatement of six-frame translation hashing (utils/compute-prot-mh-another-way.py)")):
     FILES.append((f"tests/test-data/{name}", f"genes/{name}", why))
+FILES.append(("tests/test-data/2+63.fa.sig", "pairs/2+63.fa.sig", "tests/test_compare.py:94-196 (ANI matrices of 2 / 2+63 / 47 / 63)"))
 FILES.append(("tests/test-data/2.fa.sig", "pairs/2.fa.sig", "tests/test_index_protocol.py:31-700 (the three-signature index cases)"))
 FILES.append(("tests/test-data/47+63.fa.sig", "pairs/47+63.fa.sig", "tests/test_search.py:257-590 result-row fixtures"))
 FILES.append(("tests/test-data/track_abund/track_abund.zip", "zips/track_abund.zip",

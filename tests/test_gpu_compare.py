@@ -250,3 +250,41 @@ def test_compare_index_all_rare(sm):
     torch.cuda.synchronize()
     wc, wj = oracle.compare_all_pairs(*oracle.make_csr(sk), nthreads=8)
     assert np.array_equal(c.cpu().numpy().view(np.uint32), wc) and np.array_equal(j.cpu().numpy().view(np.uint64), wj.view(np.uint64))
+
+
+def test_ani_matrices_golden(sm):
+    "tests/test_compare.py:94-196 of the reference: Jaccard / containment / max / avg containment ANI of four genomes"
+    from sourmash_amd.compare import (compare_all_pairs, compare_parallel, compare_serial, compare_serial_avg_containment,
+                                      compare_serial_containment, compare_serial_max_containment)
+    sigs = []
+    for f in ("2.fa.sig", "2+63.fa.sig", "47.fa.sig", "63.fa.sig"):
+        sigs.extend(s for s in sm.load_signatures_from_json(golden("pairs", f), ksize=31) if s.minhash.scaled)
+    assert len(sigs) == 4
+    for ignore_abundance in (True, False):
+        j_ani = compare_serial(sigs, ignore_abundance, downsample=False, return_ani=True)
+        np.testing.assert_array_almost_equal(j_ani, np.array([[1.0, 0.978, 0.0, 0.0],
+                                                              [0.978, 1.0, 0.96973012, 0.99262776],
+                                                              [0.0, 0.96973012, 1.0, 0.97697011],
+                                                              [0.0, 0.99262776, 0.97697011, 1.0]]), decimal=3)
+        assert np.array_equal(compare_parallel(sigs, ignore_abundance, downsample=False, n_jobs=2, return_ani=True), j_ani)
+        assert np.array_equal(compare_all_pairs(sigs, ignore_abundance, downsample=False, n_jobs=2, return_ani=True), j_ani)
+    np.testing.assert_array_almost_equal(compare_serial_containment(sigs, return_ani=True),
+                                         np.array([[1, 0.966, 0.0, 0.0],
+                                                   [1, 1.0, 0.97715525, 1.0],
+                                                   [0.0, 0.96377054, 1.0, 0.97678608],
+                                                   [0.0, 0.98667513, 0.97715525, 1.0]]), decimal=3)
+    np.testing.assert_array_almost_equal(compare_serial_max_containment(sigs, return_ani=True),
+                                         np.array([[1.0, 1.0, 0.0, 0.0],
+                                                   [1.0, 1.0, 0.97715525, 1.0],
+                                                   [0.0, 0.97715525, 1.0, 0.97715525],
+                                                   [0.0, 1.0, 0.97715525, 1.0]]), decimal=3)
+    np.testing.assert_array_almost_equal(compare_serial_avg_containment(sigs, return_ani=True),
+                                         np.array([[1.0, 0.983, 0.0, 0.0],
+                                                   [0.983, 1.0, 0.97046289, 0.99333757],
+                                                   [0.0, 0.97046289, 1.0, 0.97697067],
+                                                   [0.0, 0.99333757, 0.97697067, 1.0]]), decimal=3)
+    # the plain (non-ANI) containment matrices against the per-pair API
+    cont = compare_serial_containment(sigs)
+    for i in range(4):
+        for j in range(4):
+            assert cont[i][j] == (1.0 if i == j else sigs[j].contained_by(sigs[i]))
