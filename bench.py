@@ -76,7 +76,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import sourmash_amd as sm
-    from sourmash_amd import device as smd
+    from sourmash_amd import device as smd, parallel
 
     n_bases = int(args.bases)
     rec = args.record_len
@@ -112,15 +112,7 @@ def main():
     n_unique_total = n_unique_local
     if use_dist:
         tg = time.perf_counter()
-        sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
-        dist.all_gather(sizes, torch.tensor([n_unique_local], dtype=torch.int64, device=dev))
-        mx = int(max(int(s.item()) for s in sizes))
-        pad = torch.full((mx,), -1, dtype=torch.int64, device=dev)   # u64 max sentinel sorts last
-        pad[:n_unique_local] = hashes
-        parts = [torch.empty(mx, dtype=torch.int64, device=dev) for _ in range(world)]
-        dist.all_gather(parts, pad)
-        merged = torch.cat([p[:int(s.item())] for p, s in zip(parts, sizes)])
-        n_unique_total = int(torch.unique(merged).numel())
+        n_unique_total = int(parallel.allgather_union(hashes, force=True).numel())
         torch.cuda.synchronize()
         gather_ms = (time.perf_counter() - tg) * 1e3
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)

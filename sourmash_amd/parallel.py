@@ -39,6 +39,31 @@ def world_info(group=None):
     return 0, 1
 
 
+def allgather_union(local_hashes, group=None, force=False):
+    """Sketching shards by records: every rank holds the sorted unique kept hashes of ITS records (int64 tensor of u64
+    bit patterns); one all-gather later every rank holds the sketch of the whole input -- set union is associative,
+    which is all `merge` (minhash.rs:432-516) needs for flat scaled sketches.  Two collectives: the sizes, then the
+    padded hash vectors (~L / scaled / world u64 each)."""
+    dist = _dist()
+    rank, world = world_info(group)
+    torch = __import__("torch")
+    if world == 1 and not force:                        # force: run the collectives even alone (1-GPU test boxes)
+        return local_hashes
+    dev = local_hashes.device
+    n_local = torch.tensor([local_hashes.numel()], dtype=torch.int64, device=dev)
+    sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(sizes, n_local, group=group)
+    sizes = [int(t.item()) for t in sizes]
+    longest = max(max(sizes), 1)
+    pad = torch.zeros(longest, dtype=torch.int64, device=dev)
+    pad[:local_hashes.numel()] = local_hashes
+    parts = [torch.empty(longest, dtype=torch.int64, device=dev) for _ in range(world)]
+    dist.all_gather(parts, pad, group=group)
+    merged = torch.cat([p[:n] for p, n in zip(parts, sizes)])
+    flip = torch.iinfo(torch.int64).min                 # order as unsigned: flip the sign bit around the sort
+    return torch.unique(merged ^ flip) ^ flip
+
+
 def tiles_for_rank(n, world, rank):
     "-> (first_tile, tile_stride, tile_count): 16-row tiles rank, rank + world, ... of an n-row problem"
     n_tiles = (n + TILE - 1) // TILE

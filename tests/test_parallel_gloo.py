@@ -167,7 +167,17 @@ def _worker(rank, world, port, ret):
             res[thr] = parallel.gather_distributed(q, len(qh), sh, soff, hi - lo, lo, thr, 1000, be)
         fh, foff = oracle.make_csr(dbh)
         ok_g = all(res[thr] == oracle.gather(qh, fh, foff, threshold_bp=thr, scaled=1000) for thr in res)
-        ret[rank] = (bool(ok_cmp), bool(ok_g), len(res[0]))
+        # ---- sketch: records dealt to the ranks, one all-gather of the kept hashes, union = sketch of everything ----
+        seq = oracle.synth_dna(0, 600_000, seed=42, record_len=50_000)           # 11 records + separators
+        bounds = [0, 6 * 50_001, len(seq)]                                       # whole records per rank
+        mine = oracle.sketch_dna_bulk(seq[bounds[rank]:bounds[rank + 1]], 31, scaled=100)
+        union = parallel.allgather_union(torch.from_numpy(mine.view(np.int64).copy()))
+        whole = oracle.sketch_dna_bulk(seq, 31, scaled=100)
+        ok_s = np.array_equal(union.numpy().view(np.uint64), whole)
+        big = torch.tensor([5, -3, -1, 7], dtype=torch.int64) if rank == 0 else torch.tensor([-2, 5], dtype=torch.int64)
+        ordered = parallel.allgather_union(big).numpy().view(np.uint64)          # u64 order with the top bit set (scaled = 1)
+        ok_s = ok_s and list(ordered) == sorted({5, 7, 2**64 - 3, 2**64 - 1, 2**64 - 2})
+        ret[rank] = (bool(ok_cmp), bool(ok_g), len(res[0]), bool(ok_s))
     finally:
         dist.destroy_process_group()
 
@@ -180,7 +190,8 @@ def test_two_rank_compare_and_gather_over_gloo():
     mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
     assert set(ret.keys()) == {0, 1}
     for r in range(world):
-        ok_cmp, ok_g, rounds = ret[r]
+        ok_cmp, ok_g, rounds, ok_s = ret[r]
+        assert ok_s, f"rank {r}: all-gathered sketch union differs from the oracle's sketch of the whole input"
         assert ok_cmp, f"rank {r}: distributed compare differs from the oracle"
         assert ok_g, f"rank {r}: distributed gather differs from the oracle"
         assert rounds > 5
