@@ -9,8 +9,8 @@
 // consume is the expensive line: the reference walks the whole database every round.  Here the database is
 // inverted once against the query (hash position -> rows containing it, a CSR of u32 row ids), so a round touches
 // only the postings of the hashes in I: total work over a whole gather is sum_d |Q ∩ D_d| counter decrements, the
-// same number the reference spends on round 0 alone.  One round = three small kernels (partial arg-max, final
-// arg-max + stop rules + bookkeeping, apply); the host enqueues rounds in batches and only looks at a done flag,
+// same number the reference spends on round 0 alone.  One round = two small kernels (arg-max with stop rules and
+// bookkeeping in its last workgroup, apply); the host enqueues rounds in batches and only looks at a done flag,
 // so there is no host round trip per round.  Every kernel is a no-op once the flag is set.
 //
 // Multi-GPU (database sharded by dataset, query replicated): the same kernels, with the 8-byte packed winner
@@ -18,6 +18,7 @@
 // export and apply -- see sourmash_amd/parallel.py.
 #include <hip/hip_runtime.h>
 #include <cstring>
+#include <stdlib.h>
 #include <rocprim/device/device_scan.hpp>
 #include "gather_api.hpp"
 
@@ -109,29 +110,6 @@ __device__ __forceinline__ unsigned long long wave_max(unsigned long long k) {
     return k;
 }
 
-// packed arg-max with the reference tie-break (highest count, then lowest global index)
-__global__ __launch_bounds__(256) void pick_partial_kernel(const unsigned long long* __restrict__ counters, uint64_t ndb,
-                                                           uint64_t index_base, const unsigned long long* state,
-                                                           unsigned long long* __restrict__ partials) {
-    if (state[GS_DONE]) return;
-    __shared__ unsigned long long red[4];
-    unsigned long long k = 0;
-    for (uint64_t d = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; d < ndb; d += (uint64_t)gridDim.x * blockDim.x) {
-        const unsigned long long c = counters[d];
-        if (c) {
-            const unsigned long long key = (c << 32) | (0xffffffffull & ~(unsigned long long)(index_base + d));
-            k = key > k ? key : k;
-        }
-    }
-    k = wave_max(k);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = k;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int w = 1; w < 4; ++w) k = red[w] > k ? red[w] : k;
-        partials[blockIdx.x] = k;
-    }
-}
-
 __device__ __forceinline__ void record_pending(unsigned long long* state, uint64_t* out_idx, uint64_t* out_isect) {
     if (state[GS_PENDING]) {
         const unsigned long long r = state[GS_ROUNDS], acc = state[GS_ACC];
@@ -153,20 +131,53 @@ __device__ __forceinline__ void stop_rules(unsigned long long* state, unsigned l
     else state[GS_PENDING] = 1;
 }
 
-__global__ __launch_bounds__(256) void pick_final_kernel(const unsigned long long* __restrict__ partials, unsigned n_part,
-                                                         unsigned long long* state, uint64_t* out_idx,
-                                                         uint64_t* out_isect, unsigned long long* key_out,
-                                                         int check_stop) {
+// Packed arg-max with the reference tie-break (highest count, then lowest global index) over all counters, then --
+// in the workgroup that finishes last (ticket counter) -- the bookkeeping of the previous round, the final reduction
+// and, if asked, the stop rules.  (Measured: the same speed as a partial + a final launch -- a round is bound by the
+// dependency between its kernels, not by their number -- but one kernel less to reason about.)
+__global__ __launch_bounds__(256) void pick_kernel(const unsigned long long* __restrict__ counters, uint64_t ndb,
+                                                   uint64_t index_base, unsigned long long* state,
+                                                   unsigned long long* partials, uint64_t* out_idx, uint64_t* out_isect,
+                                                   unsigned long long* key_out, int check_stop) {
     __shared__ unsigned long long red[4];
-    if (threadIdx.x == 0) record_pending(state, out_idx, out_isect);
+    __shared__ int s_last;
+    if (state[GS_DONE]) {                                           // stable for the whole launch: only a last block sets it
+        if (blockIdx.x == 0 && threadIdx.x == 0 && key_out) *key_out = 0;
+        return;
+    }
+    unsigned long long k = 0;
+    for (uint64_t d = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; d < ndb; d += (uint64_t)gridDim.x * blockDim.x) {
+        const unsigned long long c = counters[d];
+        if (c) {
+            const unsigned long long key = (c << 32) | (0xffffffffull & ~(unsigned long long)(index_base + d));
+            k = key > k ? key : k;
+        }
+    }
+    k = wave_max(k);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = k;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 4; ++w) k = red[w] > k ? red[w] : k;
+        partials[blockIdx.x] = k;
+        __threadfence();                                            // the partial is visible before the ticket is
+        s_last = atomicAdd(&state[GS_TICKET], 1ull) == (unsigned long long)gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    if (threadIdx.x == 0) {
+        state[GS_TICKET] = 0;
+        record_pending(state, out_idx, out_isect);
+    }
     __syncthreads();
     if (state[GS_DONE]) {
         if (threadIdx.x == 0 && key_out) *key_out = 0;
         return;
     }
-    unsigned long long k = 0;
-    for (unsigned i = threadIdx.x; i < n_part; i += blockDim.x) k = partials[i] > k ? partials[i] : k;
+    const volatile unsigned long long* vp = partials;
+    k = 0;
+    for (unsigned i = threadIdx.x; i < gridDim.x; i += blockDim.x) { const unsigned long long v = vp[i]; k = v > k ? v : k; }
     k = wave_max(k);
+    __syncthreads();                                                // red[] is reused
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = k;
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -414,10 +425,8 @@ hipError_t gather_begin(GatherDev& g, uint64_t thr_hashes, uint64_t max_rounds, 
 hipError_t gather_pick(GatherDev& g, unsigned long long* d_key_out, int check_stop, hipStream_t stream) {
     const uint64_t want = (g.ndb + 1023) / 1024;
     const unsigned n_part = (unsigned)(want < 1 ? 1 : (want > GATHER_PICK_BLOCKS ? GATHER_PICK_BLOCKS : want));
-    hipLaunchKernelGGL(pick_partial_kernel, dim3(n_part), dim3(256), 0, stream, g.counters, g.ndb, g.index_base, g.state,
-                       g.partials);
-    hipLaunchKernelGGL(pick_final_kernel, dim3(1), dim3(256), 0, stream, g.partials, n_part, g.state, g.out_idx,
-                       g.out_isect, d_key_out, check_stop);
+    hipLaunchKernelGGL(pick_kernel, dim3(n_part), dim3(256), 0, stream, g.counters, g.ndb, g.index_base, g.state, g.partials,
+                       g.out_idx, g.out_isect, d_key_out, check_stop);
     return hipGetLastError();
 }
 

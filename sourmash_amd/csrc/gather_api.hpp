@@ -16,6 +16,7 @@ enum GatherSlot {
     GS_PENDING = 5,  // a round was applied and is not recorded yet
     GS_THR = 6,      // minimum overlap in hashes (ceil(threshold_bp / scaled))
     GS_MAXR = 7,     // maximum number of results
+    GS_TICKET = 8,   // workgroups of the running pick kernel that have delivered their partial arg-max
     GS_SLOTS = 16
 };
 
