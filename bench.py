@@ -246,6 +246,48 @@ def main():
                                                 "note": "C5 at full size: profiles/r01_gather_c5.json (tools/bench_gather.py)"}
             except Exception as e:   # the headline metric must still print
                 extra["error"] = repr(e)
+            # ---- BASELINE configs C4 and C5 at full size on this one GPU (a few seconds; tools/ hold the property checks) ----
+            try:
+                del seq                                              # 10 GB back before the big matrices
+                torch.cuda.empty_cache()
+                sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
+                import bench_gather as bg
+                big = synth_sketches(10_000, seed=1234)
+                bh, boff = smd.pack_csr(big, device=dev)
+                bn = len(big)
+                bpairs = bn * (bn - 1) // 2
+                bc, bj = smd.compare_rows(bh, boff)
+                ms_big = timed(lambda: smd.compare_rows(bh, boff, common=bc, jaccard=bj), reps=1)
+                t0 = time.perf_counter()
+                ca, ja = smd.compare_rows(bh, boff, method="auto")
+                torch.cuda.synchronize()
+                auto_big = (time.perf_counter() - t0) * 1e3
+                extra["compare_10000x10000"] = {
+                    "pairs": bpairs, "merge_ms": round(ms_big, 2), "merge_pairs_per_s": round(bpairs / (ms_big * 1e-3), 1),
+                    "auto_ms": round(auto_big, 2), "auto_pairs_per_s": round(bpairs / (auto_big * 1e-3), 1),
+                    "identical": bool((ca == bc).all().item() and (ja == bj).all().item()),
+                    "note": "config C4 (pool-drawn sketches: the cost model picks bit columns); auto includes the index build"}
+                del bc, bj, ca, ja, bh, boff
+                torch.cuda.empty_cache()
+                gq5, gh5, goff5 = bg.make_inputs(1_000_000, 100_000, 5000, dev)
+                torch.cuda.synchronize()
+                for _ in range(2):
+                    t0 = time.perf_counter()
+                    st5 = be.gather_state(gq5, gq5.numel(), gh5, goff5, 100_000, 0)
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    st5.begin(50, 100_000)
+                    res5 = st5.run()
+                    torch.cuda.synchronize()
+                    t2 = time.perf_counter()
+                iso = [r[1] for r in res5]
+                extra["gather_1M_vs_100000"] = {
+                    "db_bytes": int(gh5.numel() * 8), "rounds": len(res5), "index_build_ms": round((t1 - t0) * 1e3, 2),
+                    "loop_ms": round((t2 - t1) * 1e3, 2), "total_ms": round((t2 - t0) * 1e3, 2),
+                    "overlaps_non_increasing": bool(all(a >= b for a, b in zip(iso, iso[1:]))), "last_overlap": iso[-1] if iso else None,
+                    "note": "config C5 on one GPU, threshold_bp 50,000; full property checks: tools/bench_gather.py"}
+            except Exception as e:
+                extra["error_full_size"] = repr(e)
 
         out = {
             "metric": "Gbase/s sketched (k=31, scaled=1000)", "value": round(value, 3), "unit": "Gbase/s",
