@@ -2,7 +2,9 @@
 """BASELINE config C2 at FULL size, bit for bit: the 10 GB synthetic batch of bench.py (1,000 records x 1e7 bases,
 seed 42) sketched on the GPU (k=31, scaled=1000) and by the CPU oracle on every host core; the two sorted u64
 hash vectors must be identical.  Also checks the lower-case and N-every-89th variants of SURVEY.md section 8d on a
-1e8 prefix.   python tools/check_c2_full.py  (GPU box; ~1 min of host time for the oracle)"""
+1e8 prefix.   python tests/check_c2_full.py  (GPU box; ~1 min of host time for the oracle).
+Lives under tests/ because it calls the oracle (test infrastructure); not collected by pytest -- its size-independent
+counterparts in the suite are tests/test_gpu_sketch.py and bench.py's 1e9-byte parity sample."""
 import hashlib
 import json
 import os
