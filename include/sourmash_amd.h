@@ -343,6 +343,8 @@ void smgpu_sketchset_params(const SmgpuSketchSet *ptr, uint32_t *ksize, uint32_t
 void smgpu_sketchset_sizes(const SmgpuSketchSet *ptr, uint64_t *sizes_out);
 SourmashKmerMinHash *smgpu_sketchset_get(const SmgpuSketchSet *ptr, uint64_t index);
 void smgpu_sketchset_device_csr(const SmgpuSketchSet *ptr, const uint64_t **d_hashes, const uint64_t **d_offsets);
+/* counts_out[row] = |query ∩ row| for every row of the set (Index.find's shared sizes, index/__init__.py:115-170) */
+void smgpu_sketchset_overlaps(const SmgpuSketchSet *ptr, const SourmashKmerMinHash *query, uint64_t *counts_out);
 /* n x n matrices of a loaded set on the host (either may be NULL); same kernels as smgpu_compare_all_pairs. */
 void smgpu_sketchset_compare(const SmgpuSketchSet *ptr, uint32_t *common_out, double *jaccard_out);
 SmgpuCounter *smgpu_counter_new(const SmgpuSketchSet *set, const SourmashKmerMinHash *query);

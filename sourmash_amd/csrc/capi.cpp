@@ -1056,6 +1056,24 @@ void smgpu_sketchset_device_csr(const SmgpuSketchSet* p, const uint64_t** d_hash
     *d_hashes = s->hashes.as<uint64_t>();
     *d_offsets = s->offsets.as<uint64_t>();
 }
+// |query ∩ row| for every row: one streaming pass, no gather index (search / prefetch over a loaded collection)
+void smgpu_sketchset_overlaps(const SmgpuSketchSet* p, const SourmashKmerMinHash* query, uint64_t* out) {
+    landing_void([&] {
+        const SketchSet* s = reinterpret_cast<const SketchSet*>(p);
+        if (s->n == 0) return;
+        const uint64_t nq = MH(query)->size();
+        DeviceCtx& ctx = DeviceCtx::get();
+        std::lock_guard<std::mutex> g(ctx.mutex());
+        hipStream_t st = ctx.stream();
+        AsyncBuf dq(nq * 8 + 16, st), dc(s->n * 8 + 16, st);
+        if (nq) hip_check(hipMemcpyAsync(dq.p, MH(query)->mins.data(), nq * 8, hipMemcpyHostToDevice, st), "H2D");
+        hip_check(hipMemsetAsync(dc.p, 0, s->n * 8, st), "memset");
+        hip_check(overlap_vector_launch(dq.as<uint64_t>(), nq, s->hashes.as<uint64_t>(), s->offsets.as<uint64_t>(), s->n,
+                                        dc.as<unsigned long long>(), 0, st), "overlap");
+        hip_check(hipMemcpyAsync(out, dc.p, s->n * 8, hipMemcpyDeviceToHost, st), "D2H");
+        hip_check(hipStreamSynchronize(st), "sync");
+    });
+}
 void smgpu_sketchset_compare(const SmgpuSketchSet* p, uint32_t* common_out, double* jaccard_out) {
     landing_void([&] {
         const SketchSet* s = reinterpret_cast<const SketchSet*>(p);

@@ -164,8 +164,10 @@ class SketchSet(RustObject):
         return common, jac
 
     def overlaps(self, query_mh):
-        "|query ∩ row| for every row (one pass)"
-        return _DeviceCounter(self, query_mh.flatten()).values()
+        "|query ∩ row| for every row (one streaming pass over the CSR)"
+        out = np.zeros(max(len(self), 1), dtype=np.uint64)
+        self._methodcall(lib.smgpu_sketchset_overlaps, query_mh.flatten()._get_objptr(), out.ctypes.data_as(C.c_void_p))
+        return out[:len(self)]
 
     def search(self, query_mh, *, threshold=0.0, do_containment=False, do_max_containment=False, best_only=False):
         """Rows scoring >= threshold against the query, best first -> [(score, row)].  Jaccard by default, query
@@ -333,8 +335,7 @@ class LinearIndex:
             subj = [flatten_and_downsample_scaled(ss.minhash, qs) for ss in self._signatures]
             self._packed = (key, SketchSet(subj), subj)
         _, sset, subj = self._packed
-        counter = _DeviceCounter(sset, query_mh)
-        return counter.values(), subj
+        return sset.overlaps(query_mh), subj
 
     def find(self, search_fn, query, **kwargs):
         search_fn.check_is_compatible(query)
