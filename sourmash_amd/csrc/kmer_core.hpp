@@ -179,8 +179,8 @@ struct PosOps {
         ((R[D] = rev<D>(C)), ...);
     }
 
-    // hash of the canonical k-mer at this position
-    static SMG_HD uint64_t hash(const uint32_t* U, const uint32_t* C, uint64_t seed) {
+    // hash of the canonical k-mer at this position, last fmix64 multiplies left open (murmur3.hpp)
+    static SMG_HD Mmh3Open hash_open(const uint32_t* U, const uint32_t* C, uint64_t seed) {
         uint32_t F[G::NWK], R[G::NWK];
         build(U, C, F, R, std::make_integer_sequence<int, G::NWK>{});
         const uint64_t bf = be_chunk<0>(F), br = be_chunk<0>(R);
@@ -191,7 +191,7 @@ struct PosOps {
         const uint32_t m = gt ? 0xffffffffu : 0u;
 #pragma unroll
         for (int d = 0; d < G::NWK; ++d) W[d] = bitselect(m, R[d], F[d]);
-        return mmh3_h1_words<K>(W, seed);
+        return mmh3_open_words<K>(W, seed);
     }
 };
 
@@ -209,10 +209,17 @@ SMG_HD uint32_t nonzero_bytes4(uint32_t x) {
 //              bytes past the end of the sequence must be non-ACGT, e.g. 0)
 //   thr      : keep iff 1 <= h <= thr   (thr = max_hash, or 2^64-1 for num sketches)
 //   emit(o,h): called for every kept k-mer (o = position within the lane's run)
-template <int K, int P, class Emit, int... O>
+//
+// EARLY: test the top dword of the hash first and finish it only when some lane of the wave may keep its k-mer
+// (1 wave-step in 16 at scaled = 1000); the result is the same either way.  Dense callers (every hash wanted) turn
+// it off.
+template <int K, int P, bool EARLY, class Emit, int... O>
 SMG_HD void process_lane_impl(const uint32_t* raw, uint64_t seed, uint64_t thr, Emit&& emit,
                               std::integer_sequence<int, O...>) {
     using G = LaneGeom<K, P>;
+    // top dword t of a kept hash satisfies t <= thr >> 32; the open form knows t or t - 1 (mod 2^32)
+    const uint32_t thr_hi = (uint32_t)(thr >> 32);
+    const uint32_t lim = thr_hi >= 0xfffffffeu ? 0xffffffffu : thr_hi + 1u;
     uint32_t U[G::NW], C[G::NW];
     uint32_t anybad = 0;
 #pragma unroll
@@ -243,7 +250,12 @@ SMG_HD void process_lane_impl(const uint32_t* raw, uint64_t seed, uint64_t thr, 
     static_assert(G::NBYTES <= 128, "window too long for the 128-bit validity mask");
     (
         [&] {
-            uint64_t h = PosOps<K, P, O>::hash(U, C, seed);
+            const Mmh3Open open = PosOps<K, P, O>::hash_open(U, C, seed);
+            if constexpr (EARLY) {
+                // s in {t, t - 1}: (s + 1) mod 2^32 <= thr_hi + 1 whenever t <= thr_hi
+                if (!any_lane((uint32_t)(mmh3_close_hi(open) + 1u) <= lim)) return;
+            }
+            const uint64_t h = mmh3_close(open);
             bool ok = (h - 1) < thr;                          // h != 0 (signature.rs:50) and h <= thr (minhash.rs:319)
             if (anybad != 0) {
                 // any invalid byte in [O, O+K) kills the k-mer (signature.rs:271-286, force=true)
@@ -260,9 +272,9 @@ SMG_HD void process_lane_impl(const uint32_t* raw, uint64_t seed, uint64_t thr, 
         ...);
 }
 
-template <int K, int P, class Emit>
+template <int K, int P, bool EARLY = true, class Emit>
 SMG_HD void process_lane(const uint32_t* raw, uint64_t seed, uint64_t thr, Emit&& emit) {
-    process_lane_impl<K, P>(raw, seed, thr, static_cast<Emit&&>(emit), std::make_integer_sequence<int, P>{});
+    process_lane_impl<K, P, EARLY>(raw, seed, thr, static_cast<Emit&&>(emit), std::make_integer_sequence<int, P>{});
 }
 
 }  // namespace smg

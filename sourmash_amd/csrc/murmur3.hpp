@@ -73,6 +73,30 @@ SMG_HD uint64_t fmix64(uint64_t k) {
     return k;
 }
 
+// fmix64 split around its last multiply.  fmix64(k) == fmix64_tail(fmix64_head(k)); the top dword of the result is
+// the top dword of the last product (the closing xor-shift by 33 leaves it alone), so a scaled sketch can reject a
+// k-mer from fmix64_tail_hi() of both halves without finishing either (kmer_core.hpp, process_lane).
+SMG_HD uint64_t fmix64_head(uint64_t k) {
+    k ^= k >> 33;
+    k *= 0xff51afd7ed558ccdULL;
+    k ^= k >> 33;
+    return k;
+}
+SMG_HD uint64_t fmix64_tail(uint64_t k) {
+    k *= 0xc4ceb9fe1a85ec53ULL;
+    k ^= k >> 33;
+    return k;
+}
+SMG_HD uint32_t fmix64_tail_hi(uint64_t k) {
+    const uint32_t lo = (uint32_t)k, hi = (uint32_t)(k >> 32);
+    const uint32_t clo = 0x1a85ec53u, chi = 0xc4ceb9feu;
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umulhi(lo, clo) + lo * chi + hi * clo;
+#else
+    return (uint32_t)(((uint64_t)lo * clo) >> 32) + lo * chi + hi * clo;
+#endif
+}
+
 SMG_HD void mmh3_block(uint64_t& h1, uint64_t& h2, uint64_t k1, uint64_t k2) {
     k1 *= MMH3_C1; k1 = rotl64<31>(k1); k1 *= MMH3_C2; h1 ^= k1;
     h1 = rotl64<27>(h1); h1 += h2; h1 = mul5_add(h1, 0x52dce729);
@@ -87,9 +111,20 @@ SMG_HD uint64_t mmh3_finish(uint64_t h1, uint64_t h2, uint64_t len) {
     return h1 + h2;
 }
 
+// The hash with the last multiply of both fmix64 left undone: h == fmix64_tail(a) + fmix64_tail(b).
+struct Mmh3Open { uint64_t a, b; };
+SMG_HD Mmh3Open mmh3_finish_open(uint64_t h1, uint64_t h2, uint64_t len) {
+    h1 ^= len; h2 ^= len;
+    h1 += h2; h2 += h1;
+    return Mmh3Open{fmix64_head(h1), fmix64_head(h2)};
+}
+SMG_HD uint64_t mmh3_close(Mmh3Open o) { return fmix64_tail(o.a) + fmix64_tail(o.b); }
+// top dword of mmh3_close(o), short of the carry out of the low dwords: the true value is this or this + 1
+SMG_HD uint32_t mmh3_close_hi(Mmh3Open o) { return fmix64_tail_hi(o.a) + fmix64_tail_hi(o.b); }
+
 // Key given as zero-padded little-endian dwords w[0 .. ceil(K/4)-1].
 template <int K>
-SMG_HD uint64_t mmh3_h1_words(const uint32_t* w, uint64_t seed) {
+SMG_HD Mmh3Open mmh3_open_words(const uint32_t* w, uint64_t seed) {
     constexpr int NB = K / 16;     // full 16-byte blocks
     constexpr int T = K % 16;      // tail bytes
     constexpr int NW = (K + 3) / 4;
@@ -111,8 +146,10 @@ SMG_HD uint64_t mmh3_h1_words(const uint32_t* w, uint64_t seed) {
         if (tb + 1 < NW) k1 |= (uint64_t)w[tb + 1] << 32;
         k1 *= MMH3_C1; k1 = rotl64<31>(k1); k1 *= MMH3_C2; h1 ^= k1;
     }
-    return mmh3_finish(h1, h2, (uint64_t)K);
+    return mmh3_finish_open(h1, h2, (uint64_t)K);
 }
+template <int K>
+SMG_HD uint64_t mmh3_h1_words(const uint32_t* w, uint64_t seed) { return mmh3_close(mmh3_open_words<K>(w, seed)); }
 
 // Any length, byte pointer (host `hash_murmur`, `add_word`; generic-k kernel).
 SMG_HD uint64_t mmh3_h1_bytes(const uint8_t* data, uint64_t len, uint64_t seed) {

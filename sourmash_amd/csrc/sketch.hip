@@ -86,7 +86,7 @@ __global__ __launch_bounds__(SK_BLOCK) void sketch_dna_kernel(
                 raw[4 * i] = p32[0]; raw[4 * i + 1] = p32[1]; raw[4 * i + 2] = p32[2]; raw[4 * i + 3] = p32[3];
             }
         }
-        process_lane<K, P>(raw, seed, thr, [&](int o, uint64_t h) {
+        process_lane<K, P, !DENSE>(raw, seed, thr, [&](int o, uint64_t h) {
             if constexpr (DENSE) {
                 const uint64_t pos = base + (uint64_t)tid * P + (uint64_t)o - skip;   // valid k-mers never start in the prefix
                 if (pos < out_cap) out[pos] = h;

@@ -32,3 +32,22 @@ extern "C" uint64_t emul_sketch(const uint8_t* seq, uint64_t len, uint32_t k, ui
 #undef CASE
     return ~0ull;
 }
+
+// murmur3.hpp's split fmix64: returns the number of (a, b) pairs out of n for which the open form disagrees with
+// the closed one (full value, or top dword not in {t, t - 1}).
+extern "C" uint64_t emul_open_form_violations(uint64_t n, uint64_t seed) {
+    uint64_t bad = 0, x = seed;
+    auto next = [&] { x += 0x9e3779b97f4a7c15ULL; uint64_t z = x; z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ULL;
+                      z = (z ^ (z >> 27)) * 0x94d049bb133111ebULL; return z ^ (z >> 31); };
+    for (uint64_t i = 0; i < n; ++i) {
+        uint64_t h1 = next(), h2 = next();
+        if (i % 7 == 0) h2 = (uint64_t)0 - h1;                 // sums that wrap
+        if (smg::fmix64(h1) != smg::fmix64_tail(smg::fmix64_head(h1))) ++bad;
+        smg::Mmh3Open o{smg::fmix64_head(h1), smg::fmix64_head(h2)};
+        const uint64_t h = smg::fmix64(h1) + smg::fmix64(h2);
+        if (smg::mmh3_close(o) != h) ++bad;
+        const uint32_t t = (uint32_t)(h >> 32), s = smg::mmh3_close_hi(o);
+        if (s != t && (uint32_t)(s + 1u) != t) ++bad;
+    }
+    return bad;
+}

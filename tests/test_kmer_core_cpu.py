@@ -32,6 +32,7 @@ def emul():
         n = lib.emul_sketch(a.ctypes.data, len(a), k, p, seed, thr, out.ctypes.data, len(out))
         assert n != 2**64 - 1, "k/p combination not instantiated"
         return np.sort(out[:n])
+    run.lib = lib
     return run
 
 
@@ -81,3 +82,29 @@ def test_threshold_and_seed(emul):
     got = emul(s, 31, 16, 42, thr)
     assert np.array_equal(got, _oracle_all(s, 31, 42, thr)) and 300 < len(got) < 700
     assert np.array_equal(emul(s, 21, 16, 7, thr), _oracle_all(s, 21, 7, thr))
+
+
+def test_open_form_of_the_hash(emul):
+    "fmix64 split around its last multiply: same value, top dword known to within the carry"
+    emul.lib.emul_open_form_violations.restype = C.c_uint64
+    emul.lib.emul_open_form_violations.argtypes = [C.c_uint64, C.c_uint64]
+    assert emul.lib.emul_open_form_violations(2_000_000, 42) == 0
+
+
+def test_threshold_boundaries(emul):
+    """The early reject works on the top dword of the hash: thresholds sitting exactly on, just below and just above
+    real hash values, and on dword boundaries, must keep exactly the hashes <= thr."""
+    rng = np.random.default_rng(11)
+    s = bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), 6000))
+    allh = _oracle_all(s, 31)
+    assert len(allh) > 5000
+    picks = [allh[0], allh[1], allh[len(allh) // 2], allh[-1]]
+    thrs = set()
+    for h in map(int, picks):
+        t = h >> 32
+        thrs.update([h, h - 1, h + 1, (t << 32), (t << 32) - 1, (t << 32) | 0xffffffff, ((t + 1) << 32),
+                     ((t - 1) << 32) | 0xffffffff if t else 0])
+    thrs.update([1, 0xffffffff, 1 << 32, (1 << 32) - 1, (0xfffffffe << 32) | 5, (0xffffffff << 32), 2**64 - 2])
+    for thr in sorted(x for x in thrs if 0 < x < 2**64):
+        got = emul(s, 31, 16, 42, thr)
+        assert np.array_equal(got, allh[allh <= np.uint64(thr)]), hex(thr)
