@@ -16,14 +16,14 @@ import ctypes as C
 import io
 import math
 import os
-from collections import namedtuple
+from collections import Counter, namedtuple
 
 import numpy as np
 
 from ._lowlevel import lib
 from .minhash import flatten_and_downsample_num, flatten_and_downsample_scaled, flatten_and_intersect_scaled
 from .search import calc_threshold_from_bp, make_containment_query, make_jaccard_search_query
-from .signature import SourmashSignature
+from .signature import SourmashSignature, load_signatures_from_json, save_signatures_to_json
 from .utils import RustObject, decode_str, rustcall
 
 __all__ = ["IndexSearchResult", "Collection", "SketchSet", "select_signature", "LinearIndex", "CounterGather"]
@@ -319,6 +319,17 @@ class LinearIndex:
 
     manifest = None                  # an in-memory list carries no manifest (index/__init__.py:397-453)
 
+    def save(self, path):
+        "All signatures as one JSON file (index/__init__.py:427-429)."
+        with open(path, "wb") as fp:
+            save_signatures_to_json(self.signatures(), fp)
+
+    @classmethod
+    def load(cls, location, filename=None):
+        "From a JSON signature file; raises when it cannot be parsed (index/__init__.py:431-439)."
+        si = load_signatures_from_json(location, do_raise=True)
+        return cls(si, filename=location if filename is None else filename)
+
     def select(self, **kwargs):
         """New LinearIndex with the signatures that match the requirements; never raises for 'nothing matches'
         (index/__init__.py:441-453 over select_signature :349-394, parameters checked as in :1229-1270)."""
@@ -328,21 +339,34 @@ class LinearIndex:
     # ---- batched scoring --------------------------------------------------------------------------
     def _scaled_counts(self, query_mh):
         """shared sizes of a scaled query against every scaled signature, one kernel.
-        Subject sketches are flattened and downsampled to the query's scaled when finer (find :125-131)."""
+        Subject sketches are flattened and downsampled to the query's scaled when finer (find :125-131).
+        The reference walks the signatures one at a time, so a signature whose sketch cannot be read fails only
+        when the walk reaches it: the batch stops in front of it and hands the exception back (third value).
+        None when a num sketch is among the subjects (per-pair loop instead)."""
         qs = query_mh.scaled
         key = ("scaled", qs)
         if self._packed is None or self._packed[0] != key:
-            subj = [flatten_and_downsample_scaled(ss.minhash, qs) for ss in self._signatures]
-            self._packed = (key, SketchSet(subj), subj)
-        _, sset, subj = self._packed
-        return sset.overlaps(query_mh), subj
+            subj, pending = [], None
+            for ss in self._signatures:
+                try:
+                    mh = ss.minhash
+                except Exception as exc:                     # noqa: BLE001  (re-raised by find at this position)
+                    pending = exc
+                    break
+                if not mh.scaled:
+                    return None
+                subj.append(flatten_and_downsample_scaled(mh, qs))
+            self._packed = (key, SketchSet(subj) if subj else None, subj, pending)
+        _, sset, subj, pending = self._packed
+        return (sset.overlaps(query_mh) if sset is not None else []), subj, pending
 
     def find(self, search_fn, query, **kwargs):
         search_fn.check_is_compatible(query)
         query_mh = query.minhash
         assert not query_mh.track_abundance
-        if query_mh.scaled and all(ss.minhash.scaled for ss in self._signatures):
-            shared, subj = self._scaled_counts(query_mh)
+        batch = self._scaled_counts(query_mh) if query_mh.scaled else None
+        if batch is not None:
+            shared, subj, pending = batch
             for i, (ss, subj_mh) in enumerate(zip(self._signatures, subj)):
                 # the query is downsampled to the subject's scaled when the subject is coarser (:129-131)
                 q_mh = query_mh if subj_mh.scaled <= query_mh.scaled else flatten_and_downsample_scaled(query_mh, subj_mh.scaled)
@@ -353,6 +377,8 @@ class LinearIndex:
                 score = search_fn.score_fn(q_size, n_shared, s_size, total)
                 if search_fn.passes(score) and search_fn.collect(score, ss):
                     yield IndexSearchResult(score, ss, self.location)
+            if pending is not None:
+                raise pending
             return
         # num sketches (or mixed): per-pair GPU intersections, like the reference loop
         for ss in self._signatures:
@@ -518,12 +544,12 @@ class CounterGather:
 
     @property
     def counter(self):
-        "md5 -> remaining overlap (a dict view of the device counters; zero entries dropped)."
+        "md5 -> remaining overlap: a collections.Counter snapshot of the device counters, zero entries dropped."
         if not self.siglist:
-            return {}
+            return Counter()
         dev, order = self._device()
         vals = dev.values()
-        return {m: int(v) for m, v in zip(order, vals) if v}
+        return Counter({m: int(v) for m, v in zip(order, vals) if v})
 
     # ---- gather protocol ---------------------------------------------------------------------------------
     def peek(self, cur_query_mh, *, threshold_bp=0):

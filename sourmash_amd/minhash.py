@@ -9,6 +9,7 @@ also offers batch helpers (``add_sequence_buffer``) that hand whole buffers to
 the GPU in one call.
 """
 import ctypes as C
+import warnings
 from collections.abc import Mapping
 
 import numpy as np
@@ -338,10 +339,14 @@ class MinHash(RustObject):
         return _HashesWrapper({k: 1 for k in mins})
 
     def get_mins(self, with_abundance=False):
+        "Deprecated since the reference's 3.5 (src/sourmash/minhash.py:498-511): use .hashes."
+        warnings.warn("get_mins is deprecated; use the .hashes property", DeprecationWarning, stacklevel=2)
         mins = self.hashes
         return mins if with_abundance else mins.keys()
 
     def get_hashes(self):
+        "Deprecated since the reference's 3.5 (src/sourmash/minhash.py:513-521): use .hashes."
+        warnings.warn("get_hashes is deprecated; use the .hashes property", DeprecationWarning, stacklevel=2)
         return self.hashes.keys()
 
     @property

@@ -9,6 +9,8 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+collect_ignore = ["refcompat", "check_c2_full.py"]          # harness for the reference's own tests / a standalone script
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

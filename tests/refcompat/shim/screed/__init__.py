@@ -1,0 +1,56 @@
+"""The two screed entry points the reference's tests use (test harness only)."""
+import gzip
+
+
+class Record:
+    def __init__(self, name, sequence):
+        self.name, self.sequence = name, sequence
+
+    def __getitem__(self, key):
+        return getattr(self, key)
+
+
+def _records(path):
+    opener = gzip.open if open(path, "rb").read(2) == b"\x1f\x8b" else open
+    name, chunks, fastq = None, [], False
+    with opener(path, "rt") as fh:
+        lines = iter(fh)
+        for line in lines:
+            line = line.rstrip("\r\n")
+            if line.startswith(">"):
+                if name is not None:
+                    yield Record(name, "".join(chunks))
+                name, chunks = line[1:], []
+            elif line.startswith("@") and name is None and not chunks:
+                fastq = True
+                seq = next(lines).rstrip("\r\n")
+                next(lines), next(lines)
+                yield Record(line[1:], seq)
+            elif not fastq:
+                chunks.append(line)
+    if name is not None:
+        yield Record(name, "".join(chunks))
+
+
+class open:                                                  # noqa: A001  (screed.open is the API)
+    def __init__(self, path):
+        self._it = _records(str(path))
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+    def __iter__(self):
+        return self._it
+
+    def close(self):
+        pass
+
+
+_COMP = str.maketrans("ACGTNacgtn", "TGCANtgcan")
+
+
+def rc(seq):
+    return seq.translate(_COMP)[::-1]
