@@ -242,23 +242,17 @@ __global__ __launch_bounds__(256) void apply_kernel(QIndex qi, uint8_t* alive, c
         uint32_t j = NONE32;
         if (lane < APPLY_EPW && i < len) {
             j = q_find(qi, row[i]);
-            if (GATE && j != NONE32) {
+            if (j != NONE32) {
+                // only hashes still uncovered count: they leave the set here, and counters[d] stays |row_d ∩ uncovered|
+                // whatever the caller hands to consume (the same intersect twice, hashes it never peeked)
                 if (alive[j]) alive[j] = 0;                    // row hashes are distinct: no two lanes share j
                 else j = NONE32;
             }
         }
         const unsigned long long hits = __ballot(j != NONE32);
-        if (GATE) {
-            if (lane == 0 && hits) atomicAdd(&state[GS_ACC], (unsigned long long)__popcll(hits));
-        } else {
-            // protocol path: the hashes leave the uncovered set as well, so a later fused run starts from the truth
-            bool fresh = false;
-            if (j != NONE32 && alive[j]) {
-                alive[j] = 0;
-                fresh = true;
-            }
-            const unsigned long long gone = __ballot(fresh);
-            if (lane == 0 && gone) atomicAdd(&state[GS_QLEN], 0ull - (unsigned long long)__popcll(gone));
+        if (lane == 0 && hits) {
+            if (GATE) atomicAdd(&state[GS_ACC], (unsigned long long)__popcll(hits));
+            else atomicAdd(&state[GS_QLEN], 0ull - (unsigned long long)__popcll(hits));   // protocol path: a later fused run starts from the truth
         }
         if (!hits) continue;
         // lane l < APPLY_EPW: posting list [lo, lo + n) of its hit; inclusive prefix sums over those lanes
@@ -304,8 +298,13 @@ __global__ __launch_bounds__(256) void apply_kernel(QIndex qi, uint8_t* alive, c
                 if (GATE) {
                     atomicAdd(c, ~0ull);                       // invariant: counters[d] = |row_d ∩ uncovered| >= 1 here
                 } else {
-                    const unsigned long long old = atomicAdd(c, ~0ull);
-                    if (old == 0) atomicAdd(c, 1ull);          // saturate (counter already dropped)
+                    // a caller may have overwritten counters (smgpu_counter_set): never step below zero
+                    unsigned long long cur = *c;
+                    while (cur != 0) {
+                        const unsigned long long prev = atomicCAS(c, cur, cur - 1);
+                        if (prev == cur) break;
+                        cur = prev;
+                    }
                 }
             }
         }

@@ -16,6 +16,7 @@ import ctypes as C
 import io
 import math
 import os
+import zipfile
 from collections import Counter, namedtuple
 
 import numpy as np
@@ -25,8 +26,10 @@ from .minhash import flatten_and_downsample_num, flatten_and_downsample_scaled, 
 from .search import calc_threshold_from_bp, make_containment_query, make_jaccard_search_query
 from .signature import SourmashSignature, load_signatures_from_json, save_signatures_to_json
 from .utils import RustObject, decode_str, rustcall
+from .manifest import CollectionManifest
 
-__all__ = ["IndexSearchResult", "Collection", "SketchSet", "select_signature", "LinearIndex", "CounterGather"]
+__all__ = ["IndexSearchResult", "Collection", "SketchSet", "select_signature", "Index", "LinearIndex", "LazyLinearIndex",
+           "ZipStorage", "ZipFileLinearIndex", "MultiIndex", "StandaloneManifestIndex", "CounterGather"]
 
 IndexSearchResult = namedtuple("Result", "score, signature, location")
 
@@ -287,87 +290,77 @@ def select_signature(ss, *, ksize=None, moltype=None, scaled=0, num=0, containme
     return True
 
 
-class LinearIndex:
-    "An in-memory list of signatures searched exhaustively -- on the GPU, all at once."
+class Index:
+    """Base of every collection of signatures: selection, the signature walk, and search / prefetch / gather on top
+    of one `find` (index/__init__.py:58-346).  `find` here scores the query against ALL signatures of the walk with one
+    overlap kernel when they are scaled sketches; results and their order are those of the reference's per-signature loop."""
     is_database = False
+    manifest = None                  # set by classes that select through a manifest
 
-    def __init__(self, _signatures=None, filename=None):
-        self._signatures = list(_signatures) if _signatures else []
-        self.filename = filename
-        self._packed = None          # (key, SketchSet, prepared minhashes)
+    def __len__(self):
+        raise NotImplementedError
 
     @property
     def location(self):
-        return self.filename
+        return None
 
     def signatures(self):
-        yield from self._signatures
+        raise NotImplementedError
 
     def signatures_with_location(self):
-        for ss in self._signatures:
+        for ss in self.signatures():
             yield ss, self.location
 
-    def __bool__(self):
-        return bool(self._signatures)
+    def _signatures_with_internal(self):
+        "(signature, internal location) for ALL signatures, selection ignored (used to build manifests)"
+        raise NotImplementedError
 
-    def __len__(self):
-        return len(self._signatures)
-
-    def insert(self, node):
-        self._signatures.append(node)
-        self._packed = None
-
-    manifest = None                  # an in-memory list carries no manifest (index/__init__.py:397-453)
+    def insert(self, signature):
+        raise NotImplementedError
 
     def save(self, path):
-        "All signatures as one JSON file (index/__init__.py:427-429)."
-        with open(path, "wb") as fp:
-            save_signatures_to_json(self.signatures(), fp)
+        raise NotImplementedError
 
     @classmethod
-    def load(cls, location, filename=None):
-        "From a JSON signature file; raises when it cannot be parsed (index/__init__.py:431-439)."
-        si = load_signatures_from_json(location, do_raise=True)
-        return cls(si, filename=location if filename is None else filename)
+    def load(cls, location):
+        raise NotImplementedError
 
     def select(self, **kwargs):
-        """New LinearIndex with the signatures that match the requirements; never raises for 'nothing matches'
-        (index/__init__.py:441-453 over select_signature :349-394, parameters checked as in :1229-1270)."""
-        _check_select_parameters(**kwargs)
-        return LinearIndex([ss for ss in self._signatures if select_signature(ss, **kwargs)], self.filename)
+        raise NotImplementedError
 
     # ---- batched scoring --------------------------------------------------------------------------
-    def _scaled_counts(self, query_mh):
-        """shared sizes of a scaled query against every scaled signature, one kernel.
-        Subject sketches are flattened and downsampled to the query's scaled when finer (find :125-131).
-        The reference walks the signatures one at a time, so a signature whose sketch cannot be read fails only
-        when the walk reaches it: the batch stops in front of it and hands the exception back (third value).
-        None when a num sketch is among the subjects (per-pair loop instead)."""
-        qs = query_mh.scaled
-        key = ("scaled", qs)
-        if self._packed is None or self._packed[0] != key:
-            subj, pending = [], None
-            for ss in self._signatures:
-                try:
-                    mh = ss.minhash
-                except Exception as exc:                     # noqa: BLE001  (re-raised by find at this position)
-                    pending = exc
-                    break
-                if not mh.scaled:
-                    return None
-                subj.append(flatten_and_downsample_scaled(mh, qs))
-            self._packed = (key, SketchSet(subj) if subj else None, subj, pending)
-        _, sset, subj, pending = self._packed
-        return (sset.overlaps(query_mh) if sset is not None else []), subj, pending
+    def _walk(self):
+        """The signatures of the walk with their locations and sketches, and the exception that cut it short (or
+        None).  The reference touches one signature at a time, so a signature that cannot be produced or read fails
+        only when the walk reaches it: everything in front of it is still scored and yielded first."""
+        items, pending = [], None
+        it = iter(self.signatures_with_location())
+        while True:
+            try:
+                ss, loc = next(it)
+                mh = ss.minhash
+            except StopIteration:
+                break
+            except Exception as exc:                         # noqa: BLE001  (re-raised by find at this position)
+                pending = exc
+                break
+            items.append((ss, loc, mh))
+        return items, pending
+
+    def _subject_set(self, query_scaled, items):
+        "subject sketches flattened and downsampled to the query's scaled when finer (find :125-131), and their CSR"
+        subj = [flatten_and_downsample_scaled(mh, query_scaled) for _, _, mh in items]
+        return (SketchSet(subj) if subj else None), subj
 
     def find(self, search_fn, query, **kwargs):
         search_fn.check_is_compatible(query)
         query_mh = query.minhash
         assert not query_mh.track_abundance
-        batch = self._scaled_counts(query_mh) if query_mh.scaled else None
-        if batch is not None:
-            shared, subj, pending = batch
-            for i, (ss, subj_mh) in enumerate(zip(self._signatures, subj)):
+        items, pending = self._walk()
+        if query_mh.scaled and all(mh.scaled for _, _, mh in items):
+            sset, subj = self._subject_set(query_mh.scaled, items)
+            shared = sset.overlaps(query_mh) if sset is not None else []
+            for i, ((ss, loc, _), subj_mh) in enumerate(zip(items, subj)):
                 # the query is downsampled to the subject's scaled when the subject is coarser (:129-131)
                 q_mh = query_mh if subj_mh.scaled <= query_mh.scaled else flatten_and_downsample_scaled(query_mh, subj_mh.scaled)
                 q_size, s_size = len(q_mh), len(subj_mh)
@@ -376,22 +369,22 @@ class LinearIndex:
                 total = q_size + s_size - n_shared
                 score = search_fn.score_fn(q_size, n_shared, s_size, total)
                 if search_fn.passes(score) and search_fn.collect(score, ss):
-                    yield IndexSearchResult(score, ss, self.location)
-            if pending is not None:
-                raise pending
-            return
-        # num sketches (or mixed): per-pair GPU intersections, like the reference loop
-        for ss in self._signatures:
-            if query_mh.scaled:
-                subj_mh = flatten_and_downsample_scaled(ss.minhash, query_mh.scaled)
-                q_mh = flatten_and_downsample_scaled(query_mh, subj_mh.scaled)
-            else:
-                subj_mh = flatten_and_downsample_num(ss.minhash, query_mh.num)
-                q_mh = flatten_and_downsample_num(query_mh, subj_mh.num)
-            n_shared, total = q_mh.intersection_and_union_size(subj_mh)
-            score = search_fn.score_fn(len(q_mh), n_shared, len(subj_mh), total)
-            if search_fn.passes(score) and search_fn.collect(score, ss):
-                yield IndexSearchResult(score, ss, self.location)
+                    yield IndexSearchResult(score, ss, loc)
+        else:
+            # num sketches (or mixed): per-pair GPU intersections, like the reference loop
+            for ss, loc, mh in items:
+                if query_mh.scaled:
+                    subj_mh = flatten_and_downsample_scaled(mh, query_mh.scaled)
+                    q_mh = flatten_and_downsample_scaled(query_mh, subj_mh.scaled)
+                else:
+                    subj_mh = flatten_and_downsample_num(mh, query_mh.num)
+                    q_mh = flatten_and_downsample_num(query_mh, subj_mh.num)
+                n_shared, total = q_mh.intersection_and_union_size(subj_mh)
+                score = search_fn.score_fn(len(q_mh), n_shared, len(subj_mh), total)
+                if search_fn.passes(score) and search_fn.collect(score, ss):
+                    yield IndexSearchResult(score, ss, loc)
+        if pending is not None:
+            raise pending
 
     def search(self, query, *, threshold=None, do_containment=False, do_max_containment=False, best_only=False, **kw):
         if threshold is None:
@@ -455,6 +448,434 @@ class LinearIndex:
             raise ValueError("gather requires scaled signatures")
         res = self.best_containment(query, threshold_bp=threshold_bp, **kwargs)
         return [res] if res else []
+
+
+class LinearIndex(Index):
+    "An in-memory list of signatures searched exhaustively -- on the GPU, all at once (index/__init__.py:397-453)."
+
+    def __init__(self, _signatures=None, filename=None):
+        self._signatures = list(_signatures) if _signatures else []
+        self.filename = filename
+        self._packed = None          # (query scaled, number of subjects) -> (SketchSet, prepared minhashes)
+
+    @property
+    def location(self):
+        return self.filename
+
+    def signatures(self):
+        yield from self._signatures
+
+    def __bool__(self):
+        return bool(self._signatures)
+
+    def __len__(self):
+        return len(self._signatures)
+
+    def insert(self, node):
+        self._signatures.append(node)
+        self._packed = None
+
+    def save(self, path):
+        "All signatures as one JSON file (index/__init__.py:427-429)."
+        with open(path, "wb") as fp:
+            save_signatures_to_json(self.signatures(), fp)
+
+    @classmethod
+    def load(cls, location, filename=None):
+        "From a JSON signature file; raises when it cannot be parsed (index/__init__.py:431-439)."
+        si = load_signatures_from_json(location, do_raise=True)
+        return cls(si, filename=location if filename is None else filename)
+
+    def select(self, **kwargs):
+        """New LinearIndex with the signatures that match the requirements; never raises for 'nothing matches'
+        (index/__init__.py:441-453 over select_signature :349-394, parameters checked as in :1229-1270)."""
+        _check_select_parameters(**kwargs)
+        return LinearIndex([ss for ss in self._signatures if select_signature(ss, **kwargs)], self.filename)
+
+    def _subject_set(self, query_scaled, items):
+        "the list only changes through insert(): keep the device CSR between queries of the same scaled"
+        key = (query_scaled, len(items))
+        if self._packed is None or self._packed[0] != key:
+            self._packed = (key,) + Index._subject_set(self, query_scaled, items)
+        return self._packed[1], self._packed[2]
+
+
+class LazyLinearIndex(Index):
+    """Wraps another index: selection is remembered and applied only when signatures are asked for, and search is
+    always the linear (batched) `find` of the base class (index/__init__.py:456-526)."""
+
+    def __init__(self, db, selection_dict={}):
+        self.db = db
+        self.selection_dict = dict(selection_dict)
+
+    def signatures(self):
+        yield from self.db.select(**self.selection_dict).signatures()
+
+    def signatures_with_location(self):
+        yield from self.db.select(**self.selection_dict).signatures_with_location()
+
+    def __bool__(self):
+        return next(iter(self.signatures()), None) is not None
+
+    def __len__(self):
+        return len(self.db.select(**self.selection_dict))
+
+    def select(self, **kwargs):
+        _check_select_parameters(**kwargs)
+        merged = dict(self.selection_dict)
+        for k, v in kwargs.items():
+            if k in merged and merged[k] != v:
+                raise ValueError(f"cannot select on two different values for {k}")
+            merged[k] = v
+        return LazyLinearIndex(self.db, merged)
+
+
+class ZipStorage:
+    """Members of one zip file by name (the part of src/sourmash/sbt_storage.py:96-330 that collections of
+    signatures use).  mode 'r': read only.  mode 'w': create, or add to an existing file -- a member saved under a
+    name that already holds different content gets the next free `name_N`; replaced members (the manifest) take
+    effect when the storage is closed."""
+
+    def __init__(self, path, *, mode="r"):
+        self.path = os.path.abspath(path)
+        self.mode = mode
+        self._added = {}                                      # name -> (bytes, deflate?)  written at close()
+        if mode == "w" and not os.path.exists(self.path):
+            os.makedirs(os.path.dirname(self.path), exist_ok=True)
+            self._zf = None
+            names = []
+        else:
+            self._zf = zipfile.ZipFile(self.path, "r")
+            names = self._zf.namelist()
+        subdirs = [n for n in names if n.endswith("/")]
+        self.subdir = subdirs[0] if len(subdirs) == 1 else ""
+
+    @staticmethod
+    def can_open(location):
+        return zipfile.is_zipfile(location)
+
+    def _filenames(self):
+        names = self._zf.namelist() if self._zf is not None else []
+        return names + [n for n in self._added if n not in names]
+
+    def _read(self, name):
+        if name in self._added:
+            return self._added[name][0]
+        if self._zf is None:
+            raise KeyError(name)
+        return self._zf.read(name)
+
+    def load(self, path):
+        try:
+            return self._read(path)
+        except KeyError:
+            try:
+                return self._read(os.path.join(self.subdir, path))
+            except KeyError:
+                raise FileNotFoundError(path) from None
+
+    def save(self, path, content, *, overwrite=False, compress=False):
+        if self.mode != "w":
+            raise NotImplementedError("storage opened read-only")
+        name = path
+        if not overwrite:
+            n = 0
+            while True:
+                try:
+                    if self._read(name) == content:
+                        return name                         # same bytes already stored under this name
+                except KeyError:
+                    break
+                name = f"{path}_{n}"
+                n += 1
+        self._added[name] = (bytes(content), compress)
+        return name
+
+    def flush(self):
+        pass
+
+    def close(self):
+        if self.mode != "w" or not self._added:
+            if self._zf is not None:
+                self._zf.close()
+                self._zf = None
+            return
+        old = self._zf
+        tmp = self.path + ".tmp"
+        with zipfile.ZipFile(tmp, "w", compression=zipfile.ZIP_STORED) as out:
+            if old is not None:
+                for info in old.infolist():
+                    if info.filename not in self._added:
+                        out.writestr(info, old.read(info), compress_type=info.compress_type)
+            for name, (content, deflate) in self._added.items():
+                zi = zipfile.ZipInfo(name)
+                zi.external_attr = (0o755 if name.endswith("/") else 0o444) << 16
+                out.writestr(zi, content, compress_type=zipfile.ZIP_DEFLATED if deflate else zipfile.ZIP_STORED)
+        if old is not None:
+            old.close()
+        os.replace(tmp, self.path)
+        self._zf = zipfile.ZipFile(self.path, "r")
+        self._added = {}
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
+class ZipFileLinearIndex(Index):
+    """A read-only collection of signatures in a zip file, selected through its manifest when it has one and
+    loaded from the archive on demand (index/__init__.py:529-732)."""
+    is_database = True
+
+    def __init__(self, storage, *, selection_dict=None, traverse_yield_all=False, manifest=None, use_manifest=True):
+        self.storage = storage
+        self.selection_dict = selection_dict
+        self.traverse_yield_all = traverse_yield_all
+        self.use_manifest = use_manifest
+        self.manifest = None
+        if use_manifest:
+            self.manifest = manifest if manifest is not None else self._load_manifest()
+        if self.manifest is not None:
+            assert not self.selection_dict, self.selection_dict
+        if self.selection_dict:
+            assert self.manifest is None
+
+    def _load_manifest(self):
+        try:
+            data = self.storage.load("SOURMASH-MANIFEST.csv")
+        except (KeyError, FileNotFoundError):
+            return None
+        return CollectionManifest.load_from_csv(io.StringIO(data.decode("utf-8"), newline=""))
+
+    def __bool__(self):
+        return next(iter(self.signatures()), None) is not None
+
+    def __len__(self):
+        if self.manifest is not None:
+            return len(self.manifest)
+        return sum(1 for _ in self.signatures())
+
+    @property
+    def location(self):
+        return self.storage.path
+
+    @classmethod
+    def load(cls, location, traverse_yield_all=False, use_manifest=True):
+        if not os.path.exists(location):
+            raise FileNotFoundError(location)
+        return cls(ZipStorage(location), traverse_yield_all=traverse_yield_all, use_manifest=use_manifest)
+
+    def _member_names(self):
+        for name in self.storage._filenames():
+            if name.endswith(".sig") or name.endswith(".sig.gz") or self.traverse_yield_all:
+                yield name
+
+    def _signatures_with_internal(self):
+        for name in self._member_names():
+            for ss in load_signatures_from_json(self.storage.load(name)):
+                yield ss, name
+
+    def signatures(self):
+        if self.manifest is not None:
+            assert not self.selection_dict
+            for name in self.manifest.locations():
+                for ss in load_signatures_from_json(self.storage.load(name)):
+                    if ss in self.manifest:               # a member may hold more sketches than were selected
+                        yield ss
+            return
+        sel = self.selection_dict
+        for name in self._member_names():
+            for ss in load_signatures_from_json(self.storage.load(name)):
+                if not sel or select_signature(ss, **sel):
+                    yield ss
+
+    def select(self, **kwargs):
+        _check_select_parameters(**kwargs)
+        if self.manifest is not None:
+            return ZipFileLinearIndex(self.storage, selection_dict=None, traverse_yield_all=self.traverse_yield_all,
+                                      manifest=self.manifest.select_to_manifest(**kwargs), use_manifest=True)
+        if self.selection_dict:
+            merged = dict(self.selection_dict)
+            for k, v in kwargs.items():
+                if k in merged and merged[k] is not None and merged[k] != v:
+                    raise ValueError(f"incompatible select on '{k}'")
+                merged[k] = v
+            kwargs = merged
+        return ZipFileLinearIndex(self.storage, selection_dict=kwargs, traverse_yield_all=self.traverse_yield_all,
+                                  manifest=None, use_manifest=False)
+
+
+def traverse_find_sigs(filenames, yield_all_files=False):
+    "every .sig / .sig.gz file in and beneath `filenames` (all files when asked); sourmash_args.py:275-295"
+    def wanted(name):
+        return yield_all_files or name.endswith((".sig", ".sig.gz"))
+    for filename in filenames:
+        if os.path.isfile(filename):
+            if wanted(filename):
+                yield filename
+        elif os.path.isdir(filename):
+            for root, _dirs, files in os.walk(filename):
+                for name in sorted(files):
+                    if wanted(os.path.join(root, name)):
+                        yield os.path.join(root, name)
+
+
+def load_pathlist_from_file(filename):
+    "a text file of paths, one per line, all of which must exist (sourmash_args.py:380-399)"
+    try:
+        with open(filename) as fp:
+            file_list = set(x.rstrip("\r\n") for x in fp)
+    except OSError:
+        raise ValueError(f"pathlist file '{filename}' does not exist")
+    except UnicodeDecodeError:
+        raise ValueError(f"cannot parse file '{filename}' as list of filenames")
+    if not file_list:
+        raise ValueError("pathlist is empty")
+    for checkfile in file_list:
+        if not os.path.exists(checkfile):
+            raise ValueError(f"file '{checkfile}' inside the pathlist does not exist")
+    return file_list
+
+
+class MultiIndex(Index):
+    """Signatures gathered from several indices or files, kept in memory inside a manifest that remembers where each
+    one came from (index/__init__.py:910-1125)."""
+
+    def __init__(self, manifest, parent, *, prepend_location=False):
+        if prepend_location and parent is None:
+            raise ValueError("must set 'parent' if 'prepend_location' is set")
+        self.manifest = manifest
+        self.parent = parent
+        self.prepend_location = prepend_location
+
+    @property
+    def location(self):
+        return self.parent
+
+    def signatures(self):
+        for row in self.manifest.rows:
+            yield row["signature"]
+
+    def signatures_with_location(self):
+        for row in self.manifest.rows:
+            loc = row["internal_location"]
+            yield row["signature"], (os.path.join(self.parent, loc) if self.prepend_location else loc)
+
+    def _signatures_with_internal(self):
+        for row in self.manifest.rows:
+            yield row["signature"], row["internal_location"]
+
+    def __len__(self):
+        return 0 if self.manifest is None else len(self.manifest)
+
+    @classmethod
+    def load(cls, index_list, source_list, parent, *, prepend_location=False):
+        "from loaded indices and as many sources; a source of None keeps the index's own location"
+        assert len(index_list) == len(source_list)
+
+        def sigloc_iter():
+            for idx, iloc in zip(index_list, source_list):
+                for ss in idx.signatures():
+                    yield ss, (idx.location if iloc is None else iloc)
+        return cls(CollectionManifest.create_manifest(sigloc_iter()), parent, prepend_location=prepend_location)
+
+    @classmethod
+    def load_from_directory(cls, pathname, *, force=False):
+        "every .sig / .sig.gz under a directory (every file with force, unreadable ones skipped)"
+        from .exceptions import SourmashError
+        if not os.path.isdir(pathname):
+            raise ValueError(f"'{pathname}' must be a directory.")
+        index_list, source_list = [], []
+        for thisfile in traverse_find_sigs([pathname], yield_all_files=force):
+            try:
+                index_list.append(LinearIndex.load(thisfile))
+                source_list.append(os.path.relpath(thisfile, pathname))
+            except (OSError, SourmashError, ValueError) as exc:
+                if not force:
+                    raise ValueError(exc)
+        if not index_list:
+            raise ValueError(f"no signatures to load under directory '{pathname}'")
+        return cls.load(index_list, source_list, pathname, prepend_location=True)
+
+    @classmethod
+    def load_from_path(cls, pathname, force=False):
+        from .exceptions import SourmashError
+        if not os.path.exists(pathname):
+            raise ValueError(f"'{pathname}' must exist.")
+        if os.path.isdir(pathname):
+            return cls.load_from_directory(pathname, force=force)
+        try:
+            idx = LinearIndex.load(pathname)
+        except (OSError, SourmashError, ValueError):
+            if not force:
+                raise ValueError(f"no signatures to load from '{pathname}'")
+            return None
+        return cls.load([idx], [pathname], pathname)
+
+    @classmethod
+    def load_from_pathlist(cls, filename):
+        from .save_load import load_file_as_index
+        idx_list, src_list = [], []
+        for fname in load_pathlist_from_file(filename):
+            idx_list.append(load_file_as_index(fname))
+            src_list.append(fname)
+        return cls.load(idx_list, src_list, filename)
+
+    def select(self, **kwargs):
+        _check_select_parameters(**kwargs)
+        return MultiIndex(self.manifest.select_to_manifest(**kwargs), self.parent, prepend_location=self.prepend_location)
+
+
+class StandaloneManifestIndex(Index):
+    """A manifest file on its own: selection works on its rows, signatures are loaded from the locations the rows
+    name only when asked for (relative paths are taken from the manifest's directory); index/__init__.py:1128-1226."""
+    is_database = True
+
+    def __init__(self, manifest, location, *, prefix=None):
+        assert manifest is not None
+        self.manifest = manifest
+        self._location = location
+        self.prefix = prefix
+
+    @classmethod
+    def load(cls, location, *, prefix=None):
+        if not os.path.isfile(location):
+            raise ValueError(f"provided manifest location '{location}' is not a file")
+        m = CollectionManifest.load_from_filename(location)
+        return cls(m, location, prefix=os.path.dirname(location) if prefix is None else prefix)
+
+    @property
+    def location(self):
+        return self._location
+
+    def signatures_with_location(self):
+        yield from self._signatures_with_internal()
+
+    def signatures(self):
+        for ss, _ in self._signatures_with_internal():
+            yield ss
+
+    def _signatures_with_internal(self):
+        "only the rows that survived selection -- the original manifest is not kept"
+        from .save_load import load_file_as_index
+        picklist = self.manifest.to_picklist()
+        for iloc in self.manifest.locations():
+            if not iloc.startswith("/") and self.prefix:
+                iloc = os.path.join(self.prefix, iloc)
+            for ss in load_file_as_index(iloc).select(picklist=picklist).signatures():
+                yield ss, iloc
+
+    def __len__(self):
+        return len(self.manifest)
+
+    def __bool__(self):
+        return bool(self.manifest)
+
+    def select(self, **kwargs):
+        _check_select_parameters(**kwargs)
+        return StandaloneManifestIndex(self.manifest.select_to_manifest(**kwargs), self._location, prefix=self.prefix)
 
 
 class CounterGather:

@@ -5,7 +5,7 @@ import sys
 import sourmash_amd as _impl
 
 for _name in ("minhash", "signature", "sketchcomparison", "search", "index", "compare", "distance_utils",
-              "exceptions", "utils", "_lowlevel", "sketch"):
+              "exceptions", "utils", "_lowlevel", "sketch", "manifest", "picklist", "save_load"):
     _mod = importlib.import_module("sourmash_amd." + _name)
     sys.modules[__name__ + "." + _name] = _mod
     globals()[_name] = _mod
@@ -41,23 +41,7 @@ def save_signatures(*args, **kwargs):
     return save_signatures_to_json(*args, **kwargs)
 
 
-def load_file_as_signatures(filename, *, select_moltype=None, ksize=None, **_ignored):
-    "A .sig/.sig.gz file through the JSON loader; a zip or directory through the bulk loader."
-    filename = _os.fspath(filename)
-    if _os.path.isfile(filename) and not filename.endswith(".zip"):
-        return load_signatures_from_json(filename, ksize=ksize, select_moltype=select_moltype, do_raise=True)
-    if filename.endswith(".zip"):                           # may mix molecule types: member by member
-        import zipfile
-
-        def members():
-            with zipfile.ZipFile(filename) as zf:
-                for name in sorted(zf.namelist()):
-                    if name.endswith((".sig", ".sig.gz")):
-                        yield from load_signatures_from_json(zf.read(name), ksize=ksize, select_moltype=select_moltype)
-        return members()
-    from sourmash_amd.index import SketchSet
-    ss = SketchSet.load([filename], ksize=ksize or 0, moltype=select_moltype)
-    return (ss.signature(i) for i in range(len(ss)))
+from sourmash_amd.save_load import load_file_as_index as _load_index, load_file_as_signatures  # noqa: E402,F401
 
 
 # ---- everything outside the hot path: importable, skips the test when touched -------------------
@@ -82,13 +66,18 @@ class _OutOfScope(_types.ModuleType):
         return _Skips(self.__name__ + "." + name, (), {})
 
 
-for _name in ("sbt", "sbtmh", "lca", "lca.lca_db", "lca.lca_utils", "index.sqlite_index", "index.revindex", "manifest",
-              "save_load", "picklist", "sourmash_args", "tax", "nodegraph", "hll", "cli", "commands", "sig", "plugins"):
+for _name in ("sbt", "sbtmh", "lca", "lca.lca_db", "lca.lca_utils", "index.sqlite_index", "index.revindex",
+              "sourmash_args", "tax", "nodegraph", "hll", "cli", "commands", "sig", "plugins"):
     _mod = _OutOfScope(__name__ + "." + _name)
     sys.modules[_mod.__name__] = _mod
     if "." not in _name:
         globals()[_name] = _mod
 sys.modules[__name__ + ".lca"].lca_db = sys.modules[__name__ + ".lca.lca_db"]
+# the loaders of sourmash_args that the engine has; its command-line helpers stay out of scope
+for _name in ("traverse_find_sigs", "load_pathlist_from_file"):
+    setattr(sourmash_args, _name, getattr(index, _name))    # noqa: F821
+sourmash_args.load_file_as_signatures = load_file_as_signatures     # noqa: F821
+sourmash_args.SaveSignaturesToLocation = save_load.SaveSignaturesToLocation   # noqa: F821
 
 for _name in ("ZipFileLinearIndex", "LazyLinearIndex", "MultiIndex", "StandaloneManifestIndex"):
     if not hasattr(index, _name):                           # noqa: F821  (bound by the loop at the top)
@@ -99,16 +88,13 @@ search_sbt_index = _Skips("sourmash.search_sbt_index", (), {})
 
 
 def load_file_as_index(filename, *args, **kwargs):
-    "Flat collections (.sig, .zip, directory) -> LinearIndex; SBT / LCA / SQLite databases are outside the hot path."
-    filename = _os.fspath(filename)
-    if any(tag in _os.path.basename(filename) for tag in (".sbt.", ".lca.json", ".sqldb", ".csv", ".sbt")):
+    "SBT / LCA / SQLite databases are outside the hot path: skip; everything else through the engine's loader."
+    name = _os.path.basename(_os.fspath(filename))
+    if any(tag in name for tag in (".sbt.", ".lca.json", ".sqldb")) or name.endswith(".sbt"):
         import pytest
         pytest.skip("index format outside the hot path (SURVEY.md section 8)")
-    if not _os.path.exists(filename):
-        raise ValueError(f"Error while reading signatures from '{filename}'.")
-    if _os.path.isfile(filename):
-        with open(filename, "rb") as fh:
-            if fh.read(1) in (b">", b"@"):
-                raise ValueError(f"Error while reading signatures from '{filename}' - got sequences instead! "
-                                 "Is this a FASTA/FASTQ file?")
-    return index.LinearIndex(load_file_as_signatures(filename), filename=filename)   # noqa: F821
+    return _load_index(filename, *args, **kwargs)
+
+
+save_load.load_file_as_index = load_file_as_index           # noqa: F821  (nested loads -- manifests, path lists -- skip too)
+sourmash_args.load_file_as_index = load_file_as_index       # noqa: F821

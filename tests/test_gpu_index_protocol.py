@@ -23,13 +23,60 @@ def three(sm):
             sm.load_one_signature_from_json(golden("pairs", "63.fa.sig"))]
 
 
-@pytest.fixture()
-def index_obj(three):
+def _linear(three, tmp_path):
     from sourmash_amd.index import LinearIndex
     lidx = LinearIndex(filename="three-sigs")
     for ss in three:
         lidx.insert(ss)
     return lidx
+
+
+def _lazy(three, tmp_path):
+    from sourmash_amd.index import LazyLinearIndex
+    return LazyLinearIndex(_linear(three, tmp_path))
+
+
+def _zipfile(three, tmp_path):
+    from sourmash_amd.index import ZipFileLinearIndex
+    from sourmash_amd.save_load import SaveSignaturesToLocation
+    loc = str(tmp_path / "index.zip")
+    with SaveSignaturesToLocation(loc) as save:
+        save.add_many(three)
+    return ZipFileLinearIndex.load(loc)
+
+
+def _zipfile_no_manifest(three, tmp_path):
+    from sourmash_amd.index import ZipFileLinearIndex
+    return ZipFileLinearIndex.load(_zipfile(three, tmp_path).location, use_manifest=False)
+
+
+def _multi(three, tmp_path):
+    from sourmash_amd.index import LinearIndex, MultiIndex
+    return MultiIndex.load([LinearIndex(three, filename="three-sigs")], [None], None)
+
+
+def _directory(three, tmp_path):
+    from sourmash_amd.save_load import SaveSignaturesToLocation, load_file_as_index
+    loc = str(tmp_path / "sigs") + "/"
+    with SaveSignaturesToLocation(loc) as save:
+        save.add_many(three)
+    return load_file_as_index(loc)
+
+
+def _standalone_manifest(three, tmp_path):
+    from sourmash_amd.index import StandaloneManifestIndex
+    from sourmash_amd.manifest import CollectionManifest
+    names = ("2.fa.sig", "47.fa.sig", "63.fa.sig")
+    mf = CollectionManifest.create_manifest(((ss, golden("pairs", n)) for ss, n in zip(three, names)), include_signature=False)
+    mf.write_to_filename(str(tmp_path / "mf.csv"))
+    return StandaloneManifestIndex.load(str(tmp_path / "mf.csv"))
+
+
+# every Index class answers the same protocol (the reference parametrises its tests the same way, :166-196)
+@pytest.fixture(params=[_linear, _lazy, _zipfile, _zipfile_no_manifest, _multi, _directory, _standalone_manifest],
+                ids=lambda f: f.__name__.lstrip("_"))
+def index_obj(request, three, tmp_path):
+    return request.param(three, tmp_path)
 
 
 def test_search_thresholds(index_obj, three):
@@ -56,7 +103,9 @@ def test_container_protocol_and_select(sm, index_obj, three):
     md5s = {ss.md5sum() for ss in three}
     assert {ss.md5sum() for ss in index_obj.signatures()} == md5s
     assert {ss.md5sum() for ss, loc in index_obj.signatures_with_location()} == md5s
-    assert len(index_obj) == 3 and bool(index_obj) and str(index_obj.location) and index_obj.manifest is None
+    from sourmash_amd.manifest import BaseCollectionManifest
+    assert len(index_obj) == 3 and bool(index_obj) and str(index_obj.location)
+    assert index_obj.manifest is None or isinstance(index_obj.manifest, BaseCollectionManifest)
     idx = index_obj.select(ksize=31, moltype="DNA", abund=False, containment=True, scaled=1000, num=0, picklist=None)
     assert len(idx) == 3 and {ss.md5sum() for ss in idx.signatures()} == md5s
     for bad in ({"ksize": "31"}, {"ksize": 31.1}, {"moltype": "dna"}, {"moltype": "foo"}, {"scaled": 1000.1}, {"num": 1000.1},
@@ -66,8 +115,9 @@ def test_container_protocol_and_select(sm, index_obj, three):
     nada = index_obj.select(ksize=21)
     assert len(nada) == 0 and list(nada.signatures()) == [] and not nada
     assert len(index_obj.select(num=500)) == 0 and len(index_obj.select(abund=True)) == 0
-    with pytest.raises(ValueError):
-        index_obj.select(containment=True)                              # containment needs a scaled value
+    if isinstance(index_obj, LinearIndex):
+        with pytest.raises(ValueError):
+            index_obj.select(containment=True)                          # per-signature selection: containment needs a scaled value
     assert len(LinearIndex([])) == 0
 
 
@@ -76,7 +126,7 @@ def test_prefetch_and_best_containment(sm, index_obj, three):
     ss2, ss47, ss63 = three
     res = list(index_obj.prefetch(ss2, threshold_bp=0))
     assert len(res) == 1 and res[0].signature.minhash == ss2.minhash
-    res = list(index_obj.prefetch(ss47, threshold_bp=0))
+    res = sorted(index_obj.prefetch(ss47, threshold_bp=0), key=lambda r: -r.score)     # walk order is the container's
     assert len(res) == 2 and res[0].signature.minhash == ss47.minhash and res[1].signature.minhash == ss63.minhash
     for q in (ss2, ss47):
         match = index_obj.best_containment(q)

@@ -15,5 +15,37 @@ trap 'rm -rf "$ROOT/_refrun"' EXIT
 if [ "$1" = "--local" ] || [ -n "$SMG_REFRUN_LOCAL" ]; then
   cd "$ROOT/_refrun" && PYTHONPATH=$ROOT python -m pytest -q -p no:cacheprovider --tb=short $MODS
 else
-  /usr/local/graft/bin/gpurun --timeout ${SMG_REFRUN_TIMEOUT:-900} -- "cd _refrun && PYTHONPATH=\$GRAFT_REPO_ROOT timeout 800 python -m pytest -q -p no:cacheprovider --tb=short -rfEs $MODS > \$GRAFT_REPO_ROOT/gpurun_out/reference_tests.txt 2>&1; tail -5 \$GRAFT_REPO_ROOT/gpurun_out/reference_tests.txt"
+  /usr/local/graft/bin/gpurun --timeout ${SMG_REFRUN_TIMEOUT:-900} -- "cd _refrun && PYTHONPATH=\$GRAFT_REPO_ROOT timeout 800 python -m pytest -q -p no:cacheprovider --tb=short -rfEs --junitxml=\$GRAFT_REPO_ROOT/gpurun_out/reference_tests.xml $MODS > \$GRAFT_REPO_ROOT/gpurun_out/reference_tests.txt 2>&1; tail -5 \$GRAFT_REPO_ROOT/gpurun_out/reference_tests.txt"
 fi
+
+# per-module table for profiles/ (the test sources themselves are never kept)
+python - "$ROOT/gpurun_out/reference_tests.xml" <<'PY'
+import collections, re, sys
+import xml.etree.ElementTree as ET
+if len(sys.argv) > 1:
+    try:
+        root = ET.parse(sys.argv[1]).getroot()
+    except OSError:
+        sys.exit(0)
+    tab = collections.defaultdict(collections.Counter)
+    why = collections.Counter()
+    for tc in root.iter("testcase"):
+        mod = tc.get("classname", "?")
+        kind = "passed"
+        for child in tc:
+            if child.tag in ("failure", "error"):
+                kind = "failed"
+            elif child.tag == "skipped":
+                kind = "skipped"
+                why[(child.get("message") or "").split("\n")[0].replace("Skipped: ", "")[:120]] += 1
+        tab[mod][kind] += 1
+    print("%-32s %7s %7s %7s" % ("reference test module", "passed", "failed", "skipped"))
+    tot = collections.Counter()
+    for mod in sorted(tab):
+        c = tab[mod]; tot.update(c)
+        print("%-32s %7d %7d %7d" % (mod + ".py", c["passed"], c["failed"], c["skipped"]))
+    print("%-32s %7d %7d %7d" % ("total", tot["passed"], tot["failed"], tot["skipped"]))
+    print("\nskip reasons:")
+    for k, v in why.most_common():
+        print("%5d  %s" % (v, k))
+PY
