@@ -121,6 +121,9 @@ def _one_sketch_each(siglist):
     yield from sigmod.load_signatures_from_json(sigmod.save_signatures_to_json(siglist))
 
 
+_get_signatures_from_rust = _one_sketch_each               # the reference's name for it (save_load.py:250-259)
+
+
 class SaveSignatures_NoOutput(Base_SaveSignaturesToLocation):
     def __repr__(self):
         return "SaveSignatures_NoOutput()"

@@ -11,9 +11,11 @@ records of a file with a separator byte and crosses it once per file: a byte
 outside ACGT kills exactly the k-mers that would span two records, which is what
 one add_sequence call per record achieves (force=True semantics, the CLI default).
 """
+import argparse
 import ctypes as C
 import gzip
 import io
+import sys
 
 from ._lowlevel import ffi, lib
 from .minhash import MINHASH_DEFAULT_SEED
@@ -23,6 +25,34 @@ from .utils import RustObject, rustcall
 DEFAULTS = dict(dna="k=31,scaled=1000,noabund", protein="k=10,scaled=200,noabund",      # command_sketch.py:25-30
                 dayhoff="k=16,scaled=200,noabund", hp="k=42,scaled=200,noabund")
 MIN_SCALED, MAX_SCALED = 100, 1e6                 # advisory bounds of sourmash_args.py:61-82 (warnings there, not errors)
+
+
+def _notify(msg):
+    print(msg, file=sys.stderr)
+
+
+def check_scaled_bounds(arg):
+    "negative is an error, outside [100, 1e6] a warning (sourmash_args.py:61-70)"
+    f = float(arg)
+    if f < 0:
+        raise argparse.ArgumentTypeError("ERROR: scaled value must be positive")
+    if f < MIN_SCALED:
+        _notify("WARNING: scaled value should be >= 100. Continuing anyway.")
+    if f > MAX_SCALED:
+        _notify("WARNING: scaled value should be <= 1e6. Continuing anyway.")
+    return f
+
+
+def check_num_bounds(arg):
+    "negative is an error, outside [50, 50000] a warning (sourmash_args.py:73-82)"
+    f = int(arg)
+    if f < 0:
+        raise argparse.ArgumentTypeError("ERROR: num value must be positive")
+    if f < 50:
+        _notify("WARNING: num value should be >= 50. Continuing anyway.")
+    if f > 50000:
+        _notify("WARNING: num value should be <= 50000. Continuing anyway.")
+    return f
 
 
 def parse_params_str(params_str):
@@ -44,9 +74,7 @@ def parse_params_str(params_str):
                 scaled = int(item[7:])
             except ValueError:
                 raise ValueError(f"cannot parse scaled='{item[7:]}' as an integer")
-            if scaled < 0:
-                raise ValueError("ERROR: scaled value must be positive")
-            params["scaled"], params["num"] = scaled, 0
+            params["scaled"], params["num"] = int(check_scaled_bounds(scaled)), 0
         elif item.startswith("seed"):
             if len(item) < 6 or item[4] != "=":
                 raise ValueError("seed takes a parameter, e.g. 'seed=42'")
@@ -60,9 +88,7 @@ def parse_params_str(params_str):
                 num = int(item[4:])
             except ValueError:
                 raise ValueError(f"cannot parse num='{item[4:]}' as a number")
-            if num < 0:
-                raise ValueError("ERROR: num value must be positive")
-            params["num"], params["scaled"] = num, 0
+            params["num"], params["scaled"] = check_num_bounds(num), 0
         elif item.startswith("k"):
             if len(item) < 3 or item[1] != "=":
                 raise ValueError("k takes a parameter, e.g. 'k=31'")
@@ -136,16 +162,103 @@ class ComputeParameters(RustObject):
 
     @property
     def moltype(self):
-        return "DNA" if self.dna else "protein" if self.protein else "dayhoff" if self.dayhoff else "hp"
+        assert self.dna or self.protein or self.hp or self.dayhoff
+        return "DNA" if self.dna else "protein" if self.protein else "hp" if self.hp else "dayhoff"
+
+    @classmethod
+    def from_manifest_row(cls, row):
+        "the parameters that rebuild the sketch a manifest row describes (command_sketch.py:892-924)"
+        moltype = row["moltype"]
+        assert moltype in ("DNA", "protein", "hp", "dayhoff")
+        return cls(ksizes=[row["ksize"] if moltype == "DNA" else row["ksize"] * 3], seed=MINHASH_DEFAULT_SEED,
+                   protein=moltype == "protein", dayhoff=moltype == "dayhoff", hp=moltype == "hp", dna=moltype == "DNA",
+                   num_hashes=row["num"], track_abundance=row["with_abundance"], scaled=row["scaled"])
 
     def to_param_str(self):
+        "the parameter string that gives these parameters back: ksizes in residues, defaults left out (:926-964)"
         parts = ["dna" if self.dna else "protein" if self.protein else "hp" if self.hp else "dayhoff"]
-        parts += [f"k={k}" for k in self.ksizes]
-        parts.append(f"scaled={self.scaled}" if self.scaled else f"num={self.num_hashes}")
+        parts += [f"k={k if self.dna else k // 3}" for k in self.ksizes]
+        assert self.num_hashes or self.scaled
+        parts.append(f"num={self.num_hashes}" if self.num_hashes else f"scaled={self.scaled}")
+        if self.track_abundance:
+            parts.append("abund")
         if self.seed != MINHASH_DEFAULT_SEED:
             parts.append(f"seed={self.seed}")
-        parts.append("abund" if self.track_abundance else "noabund")
         return ",".join(parts)
+
+    def __repr__(self):
+        return (f"ComputeParameters(ksizes={self.ksizes}, seed={self.seed}, protein={self.protein}, dayhoff={self.dayhoff}, "
+                f"hp={self.hp}, dna={self.dna}, num_hashes={self.num_hashes}, track_abundance={self.track_abundance}, "
+                f"scaled={self.scaled})")
+
+    def __eq__(self, other):
+        return all(getattr(self, k) == getattr(other, k) for k in
+                   ("ksizes", "seed", "protein", "dayhoff", "hp", "dna", "num_hashes", "track_abundance", "scaled"))
+
+    @staticmethod
+    def from_args(args):
+        "every attribute of an argparse namespace that names a parameter (command_sketch.py:982-993)"
+        ret = ComputeParameters._from_objptr(lib.computeparams_new())
+        for arg, value in vars(args).items():
+            prop = getattr(ComputeParameters, arg, None)
+            if isinstance(prop, property) and prop.fset is not None:
+                prop.fset(ret, value)
+        return ret
+
+
+class _signatures_for_sketch_factory:                        # noqa: N801  (the reference's name, command_sketch.py:90)
+    """Signature templates for a list of parameter strings: each string is laid over the defaults of its molecule
+    type; `default_moltype` is the subcommand's (dna / protein / translate input)."""
+
+    def __init__(self, params_str_list, default_moltype):
+        self.defaults = {}
+        for moltype, pstr in DEFAULTS.items():
+            mt, d = parse_params_str(pstr)
+            assert mt is None
+            self.defaults[moltype] = d
+        self.params_list = []
+        self.mult_ksize_by_3 = True
+        if not params_str_list:
+            if default_moltype is None:
+                raise ValueError("No default moltype and none specified in param string")
+            self.params_list.append((default_moltype, {}))
+            return
+        for params_str in params_str_list:
+            moltype, params = parse_params_str(params_str)
+            if moltype and moltype != "dna" and default_moltype == "dna":
+                raise ValueError(f"Incompatible sketch type ({default_moltype}) and parameter override ({moltype}) in "
+                                 f"'{params_str}'; maybe use 'sketch translate'?")
+            if moltype == "dna" and default_moltype and default_moltype != "dna":
+                raise ValueError(f"Incompatible sketch type ({default_moltype}) and parameter override ({moltype}) in "
+                                 f"'{params_str}'")
+            if moltype is None:
+                if default_moltype is None:
+                    raise ValueError("No default moltype and none specified in param string")
+                moltype = default_moltype
+            self.params_list.append((moltype, params))
+
+    def get_compute_params(self, *, split_ksizes=False):
+        for moltype, given in self.params_list:
+            dflt = self.defaults[moltype]
+            ksizes = given.get("ksize") or dflt["ksize"]
+            if self.mult_ksize_by_3 and moltype != "dna":
+                ksizes = [k * 3 for k in ksizes]              # residues -> stored ksize
+
+            def make(ks):
+                return ComputeParameters(ksizes=ks, seed=given.get("seed", dflt.get("seed", MINHASH_DEFAULT_SEED)),
+                                         protein=moltype == "protein", dayhoff=moltype == "dayhoff", hp=moltype == "hp",
+                                         dna=moltype == "dna", num_hashes=given.get("num", dflt.get("num", 0)),
+                                         track_abundance=given.get("track_abundance", dflt["track_abundance"]),
+                                         scaled=given.get("scaled", dflt.get("scaled", 0)))
+            if split_ksizes:
+                for k in ksizes:
+                    yield make([k])
+            else:
+                yield make(ksizes)
+
+    def __call__(self, *, split_ksizes=False):
+        "fresh signatures, one per parameter set"
+        return [SourmashSignature.from_params(p) for p in self.get_compute_params(split_ksizes=split_ksizes)]
 
 
 # ---- FASTA / FASTQ ingest (screed replacement; SURVEY.md section 8f rank 1) --------------------

@@ -50,6 +50,21 @@ def prefetch_gather(request):
     return request.param
 
 
+def _choice_fixture(name, choices):
+    @pytest.fixture(params=choices, name=name)
+    def fx(request):
+        return request.param
+    return fx
+
+
+lca_db_format = _choice_fixture("lca_db_format", ["json", "sql"])
+manifest_db_format = _choice_fixture("manifest_db_format", ["csv", "sql"])
+sig_save_extension = _choice_fixture("sig_save_extension", ["sig", "sig.gz", "zip", ".d/", ".sqldb"])
+sig_save_extension_abund = _choice_fixture("sig_save_extension_abund", ["sig", "sig.gz", "zip", ".d/"])
+abspath_or_relpath = _choice_fixture("abspath_or_relpath", ["--abspath", "--relpath"])
+abspath_relpath_v4 = _choice_fixture("abspath_relpath_v4", ["--no-abspath", "--abspath", "--relpath"])
+
+
 def pytest_addoption(parser):
     parser.addoption("--run-hypothesis", action="store_true", help="run hypothesis tests")
 

@@ -10,6 +10,8 @@ for _name in ("minhash", "signature", "sketchcomparison", "search", "index", "co
     sys.modules[__name__ + "." + _name] = _mod
     globals()[_name] = _mod
 
+sys.modules[__name__ + ".command_sketch"] = command_sketch = sketch   # noqa: F821  (one module here)
+
 from sourmash_amd import *                                  # noqa: F401,F403,E402
 from sourmash_amd import (MinHash, FrozenMinHash, SourmashSignature, load_signatures_from_json,  # noqa: E402
                           load_one_signature_from_json, save_signatures_to_json, DEFAULT_SEED, MAX_HASH)
@@ -67,7 +69,7 @@ class _OutOfScope(_types.ModuleType):
 
 
 for _name in ("sbt", "sbtmh", "lca", "lca.lca_db", "lca.lca_utils", "index.sqlite_index", "index.revindex",
-              "sourmash_args", "tax", "nodegraph", "hll", "cli", "commands", "sig", "plugins"):
+              "sourmash_args", "tax", "nodegraph", "hll", "cli", "cli.utils", "commands", "sig", "plugins", "sbt_storage", "logging"):
     _mod = _OutOfScope(__name__ + "." + _name)
     sys.modules[_mod.__name__] = _mod
     if "." not in _name:

@@ -151,7 +151,8 @@ def test_params_and_templates(sm):
     assert (p.ksizes, p.scaled, p.num_hashes, p.seed, p.track_abundance, p.dna) == ([21, 51], 100, 0, 7, True, True)
     sig = sm.SourmashSignature.from_params(p)
     assert [(m.ksize, m.scaled, m.seed, m.track_abundance) for m in sig.minhashes()] == [(21, 100, 7, True), (51, 100, 7, True)]
-    assert ComputeParameters.from_param_str("dna").to_param_str() == "dna,k=31,scaled=1000,noabund"
+    assert ComputeParameters.from_param_str("dna").to_param_str() == "dna,k=31,scaled=1000"       # defaults are left out (command_sketch.py:926-964)
+    assert ComputeParameters.from_param_str("protein,k=7,abund,seed=3").to_param_str() == "protein,k=7,scaled=200,abund,seed=3"
 
 
 def test_gpu_only_operations_fail_loudly_without_a_device(sm):
