@@ -290,6 +290,14 @@ def select_signature(ss, *, ksize=None, moltype=None, scaled=0, num=0, containme
     return True
 
 
+def _zero_overlap_never_matches(search_fn, q_size):
+    "true for the Jaccard / containment searches of search.py: no shared hash -> score 0 -> never passes"
+    try:
+        return search_fn.score_fn(q_size, 0, 1, q_size + 1) == 0 and not search_fn.passes(0)
+    except Exception:                                        # noqa: BLE001  (an unusual search object: score every row)
+        return False
+
+
 class Index:
     """Base of every collection of signatures: selection, the signature walk, and search / prefetch / gather on top
     of one `find` (index/__init__.py:58-346).  `find` here scores the query against ALL signatures of the walk with one
@@ -360,7 +368,10 @@ class Index:
         if query_mh.scaled and all(mh.scaled for _, _, mh in items):
             sset, subj = self._subject_set(query_mh.scaled, items)
             shared = sset.overlaps(query_mh) if sset is not None else []
+            skip_zero = _zero_overlap_never_matches(search_fn, len(query_mh))
             for i, ((ss, loc, _), subj_mh) in enumerate(zip(items, subj)):
+                if skip_zero and not shared[i]:
+                    continue
                 # the query is downsampled to the subject's scaled when the subject is coarser (:129-131)
                 q_mh = query_mh if subj_mh.scaled <= query_mh.scaled else flatten_and_downsample_scaled(query_mh, subj_mh.scaled)
                 q_size, s_size = len(q_mh), len(subj_mh)
@@ -690,6 +701,60 @@ class ZipFileLinearIndex(Index):
             for ss in load_signatures_from_json(self.storage.load(name)):
                 if not sel or select_signature(ss, **sel):
                     yield ss
+
+    # ---- search: the archive goes to HBM once, signatures are materialised for the matches only --------------
+    _bulk_cache = None
+
+    def _bulk(self, query_mh):
+        """(SketchSet, sizes, rows per member) of the selected sketches, parsed by the native reader straight into one
+        CSR in HBM (no signature objects) and downsampled to the query's scaled; kept for the next query.  None when
+        the rows cannot share one CSR with this query (num sketches, a coarser scaled, another ksize or molecule
+        type) -- the per-signature walk of the base class handles, or rejects, those exactly like the reference."""
+        m = self.manifest
+        qs = query_mh.scaled
+        if m is None or not qs or not m.rows:
+            return None
+        ksize, moltype = query_mh.ksize, query_mh.moltype
+        for row in m.rows:
+            if row["num"] or not row["scaled"] or row["scaled"] > qs or row["ksize"] != ksize or row["moltype"] != moltype:
+                return None
+        if self._bulk_cache is None or self._bulk_cache[0] != (qs, ksize, moltype):
+            sset = SketchSet.load([self.storage.path], ksize=ksize, moltype=moltype, scaled=qs)
+            by_member = {}
+            for r, row in enumerate(sset.manifest):
+                by_member.setdefault(row["internal_location"], []).append(r)
+            # the order of signatures(): members as the manifest lists them, then the selected sketches within each
+            wanted = m._md5_set
+            walk = [r for member in m.locations() for r in by_member.get(member, ()) if sset.manifest[r]["md5"] in wanted]
+            self._bulk_cache = ((qs, ksize, moltype), sset, sset.sizes, np.asarray(walk, dtype=np.int64))
+        return self._bulk_cache[1:]
+
+    def find(self, search_fn, query, **kwargs):
+        search_fn.check_is_compatible(query)
+        query_mh = query.minhash
+        assert not query_mh.track_abundance
+        bulk = self._bulk(query_mh)
+        if bulk is None:
+            yield from Index.find(self, search_fn, query, **kwargs)
+            return
+        sset, sizes, walk = bulk
+        shared = sset.overlaps(query_mh)
+        q_size = len(query_mh)
+        if _zero_overlap_never_matches(search_fn, q_size):
+            walk = walk[shared[walk] > 0]                     # most of a large database: nothing to score, nothing to load
+        rows = sset.manifest
+        loaded_member, loaded = None, None
+        for r in walk.tolist():
+            n_shared, s_size = int(shared[r]), int(sizes[r])
+            score = search_fn.score_fn(q_size, n_shared, s_size, q_size + s_size - n_shared)
+            if not search_fn.passes(score):
+                continue
+            member, md5 = rows[r]["internal_location"], rows[r]["md5"]
+            if member != loaded_member:                      # signatures are materialised for the matches only
+                loaded = {ss.md5sum(): ss for ss in load_signatures_from_json(self.storage.load(member))}
+                loaded_member = member
+            if search_fn.collect(score, loaded[md5]):
+                yield IndexSearchResult(score, loaded[md5], self.location)
 
     def select(self, **kwargs):
         _check_select_parameters(**kwargs)

@@ -163,3 +163,42 @@ def test_gather_over_the_index(sm, index_obj, three):
     assert rows[0].f_match == 1.0 and rows[0].unique_intersect_bp == len(ss63.minhash) * 1000
     assert rows[1].unique_intersect_bp == (len(ss47.minhash) - ss47.minhash.count_common(ss63.minhash)) * 1000
     assert rows[1].remaining_bp == 0 and round(sum(r.f_unique_to_query for r in rows), 6) == 1.0
+
+
+def test_zipfile_search_goes_through_the_bulk_loader(sm, tmp_path):
+    """A zip collection is parsed natively into one CSR in HBM and scored in one pass; signatures are materialised
+    for the matches only.  Same results, same order as the per-signature walk of the base class."""
+    import glob
+    from sourmash_amd.index import Index, ZipFileLinearIndex
+    from sourmash_amd.save_load import SaveSignaturesToLocation
+    from sourmash_amd.search import make_containment_query, make_jaccard_search_query
+    loc = str(tmp_path / "genomes.zip")
+    with SaveSignaturesToLocation(loc) as save:
+        for path in sorted(glob.glob(golden("gather", "GCF_*.sig"))):
+            save.add_many(sm.load_signatures_from_json(path))
+    query = sm.load_one_signature_from_json(golden("gather", "combined.sig"))
+    zidx = ZipFileLinearIndex.load(loc).select(ksize=query.minhash.ksize, moltype="DNA")
+    assert len(zidx) == 12 and zidx._bulk_cache is None
+
+    def rows(results):
+        return [(r.score, r.signature.md5sum(), r.signature.name, r.location) for r in results]
+    for make in (lambda: make_containment_query(query.minhash, 0), lambda: make_containment_query(query.minhash, 50000),
+                 lambda: make_jaccard_search_query(threshold=0.05), lambda: make_jaccard_search_query(do_containment=True, threshold=0.1),
+                 lambda: make_jaccard_search_query(do_max_containment=True, threshold=0.0, best_only=True)):
+        fast = rows(zidx.find(make(), query))
+        assert zidx._bulk_cache is not None                              # the native path ran
+        assert fast == rows(Index.find(zidx, make(), query)) and (fast or make().threshold > 0)
+    assert len(list(zidx.prefetch(query, threshold_bp=0))) == 12
+    best = zidx.best_containment(query)
+    assert best.signature.name.startswith("NC_003198.1") and round(best.score * len(query.minhash)) == 487
+    # a picklist narrows the manifest; the CSR still holds everything, the walk skips what was not selected
+    from sourmash_amd.picklist import SignaturePicklist
+    pl = SignaturePicklist("identprefix")
+    pl.init(["NC_003198", "NC_000853"])
+    two = zidx.select(picklist=pl)
+    assert sorted(r.signature.name.split(".")[0] for r in two.prefetch(query, threshold_bp=0)) == ["NC_000853", "NC_003198"]
+    # protein sketches take the same path (manifest ksize is in residues, like MinHash.ksize)
+    coarse = ZipFileLinearIndex.load(golden("zips", "all.zip")).select(moltype="protein", ksize=19)
+    q = next(iter(coarse.signatures()))
+    res = coarse.search(q, threshold=0.9)
+    assert len(res) == 1 and res[0].score == 1.0 and res[0].signature == q and coarse._bulk_cache is not None
