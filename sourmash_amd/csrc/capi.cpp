@@ -1006,6 +1006,39 @@ SmgpuSketchSet* smgpu_sketchset_from_collection(const SmgpuCollection* p) {
         return reinterpret_cast<SmgpuSketchSet*>(upload_collection(std::move(copy)));
     });
 }
+// rows[0..n) of a loaded set as a new set (device-to-device row gather; manifest rows follow)
+SmgpuSketchSet* smgpu_sketchset_subset(const SmgpuSketchSet* p, const uint64_t* rows, uintptr_t n) {
+    return landing<SmgpuSketchSet*>([&]() -> SmgpuSketchSet* {
+        const SketchSet* s = reinterpret_cast<const SketchSet*>(p);
+        if (s->host_offsets.size() != s->n + 1) throw err_internal("smgpu_sketchset_subset needs a set made by smgpu_sketchset_load");
+        std::unique_ptr<SketchSet> out(new SketchSet());
+        out->n = n;
+        out->ksize = s->ksize; out->hash_function = s->hash_function; out->seed = s->seed;
+        out->max_hash = s->max_hash; out->num = s->num;
+        out->host_offsets.assign(n + 1, 0);
+        out->rows.reserve(n);
+        for (uintptr_t i = 0; i < n; ++i) {
+            if (rows[i] >= s->n) throw err_internal("sketch index out of range");
+            out->host_offsets[i + 1] = out->host_offsets[i] + (s->host_offsets[rows[i] + 1] - s->host_offsets[rows[i]]);
+            if (rows[i] < s->rows.size()) out->rows.push_back(s->rows[rows[i]]);
+        }
+        out->total = out->host_offsets[n];
+        DeviceCtx& ctx = DeviceCtx::get();
+        std::lock_guard<std::mutex> g(ctx.mutex());
+        hipStream_t st = ctx.stream();
+        out->hashes.reserve((out->total + 1) * 8);
+        out->offsets.reserve((n + 1) * 8);
+        DevBuf d_rows;
+        d_rows.reserve((n + 1) * 8);
+        hip_check(hipMemcpyAsync(out->offsets.p, out->host_offsets.data(), (n + 1) * 8, hipMemcpyHostToDevice, st), "H2D");
+        if (n) hip_check(hipMemcpyAsync(d_rows.p, rows, n * 8, hipMemcpyHostToDevice, st), "H2D");
+        hip_check(copy_rows_launch(s->hashes.as<uint64_t>(), s->offsets.as<uint64_t>(), d_rows.as<uint64_t>(), n,
+                                   out->offsets.as<uint64_t>(), out->hashes.as<uint64_t>(), st), "copy_rows");
+        hip_check(hipStreamSynchronize(st), "sync");
+        if (d_rows.p) (void)hipFree(d_rows.p);
+        return reinterpret_cast<SmgpuSketchSet*>(out.release());
+    });
+}
 uint64_t smgpu_sketchset_total_hashes(const SmgpuSketchSet* p) { return reinterpret_cast<const SketchSet*>(p)->total; }
 uint64_t smgpu_sketchset_skipped(const SmgpuSketchSet* p) { return reinterpret_cast<const SketchSet*>(p)->skipped; }
 SourmashStr smgpu_sketchset_manifest(const SmgpuSketchSet* p) {

@@ -20,6 +20,9 @@ hipError_t select_flagged(const uint64_t* in, const uint8_t* flags, uint64_t n, 
 // op 0: overlap[d] = |Q ∩ D_d| ; op 1: overlap[d] -= |Q ∩ D_d| (saturating, rows at 0 skipped)
 hipError_t overlap_vector_launch(const uint64_t* Q, uint64_t nq, const uint64_t* hashes, const uint64_t* offsets,
                                  uint64_t ndb, unsigned long long* overlap, int op, hipStream_t stream);
+// CSR row gather: row i of the destination = row rows[i] of the source (dst_off = prefix sums of the row lengths)
+hipError_t copy_rows_launch(const uint64_t* src, const uint64_t* src_off, const uint64_t* rows, uint64_t n_rows,
+                            const uint64_t* dst_off, uint64_t* dst, hipStream_t stream);
 // *best = max(*best, (count << 32) | ~(index_base + d)) over rows with count > 0
 hipError_t argmax_launch(const unsigned long long* overlap, uint64_t ndb, uint64_t index_base,
                          unsigned long long* best, hipStream_t stream);

@@ -184,6 +184,24 @@ hipError_t overlap_vector_launch(const uint64_t* Q, uint64_t nq, const uint64_t*
     return hipGetLastError();
 }
 
+// one workgroup per destination row: dst[dst_off[i] ..) = src[src_off[rows[i]] ..), 8-byte coalesced copies
+__global__ __launch_bounds__(256) void copy_rows_kernel(const uint64_t* __restrict__ src, const uint64_t* __restrict__ src_off,
+                                                        const uint64_t* __restrict__ rows, uint64_t n_rows,
+                                                        const uint64_t* __restrict__ dst_off, uint64_t* __restrict__ dst) {
+    for (uint64_t i = blockIdx.x; i < n_rows; i += gridDim.x) {
+        const uint64_t lo = src_off[rows[i]], len = src_off[rows[i] + 1] - lo, out = dst_off[i];
+        for (uint64_t t = threadIdx.x; t < len; t += blockDim.x) dst[out + t] = src[lo + t];
+    }
+}
+
+hipError_t copy_rows_launch(const uint64_t* src, const uint64_t* src_off, const uint64_t* rows, uint64_t n_rows,
+                            const uint64_t* dst_off, uint64_t* dst, hipStream_t stream) {
+    if (n_rows == 0) return hipSuccess;
+    hipLaunchKernelGGL(copy_rows_kernel, dim3((unsigned)(n_rows < 65536 ? n_rows : 65536)), dim3(256), 0, stream, src, src_off,
+                       rows, n_rows, dst_off, dst);
+    return hipGetLastError();
+}
+
 hipError_t argmax_launch(const unsigned long long* overlap, uint64_t ndb, uint64_t index_base,
                          unsigned long long* best, hipStream_t stream) {
     if (ndb == 0) return hipSuccess;

@@ -152,6 +152,11 @@ class SketchSet(RustObject):
         from .minhash import MinHash
         return MinHash._from_objptr(self._methodcall(lib.smgpu_sketchset_get, int(row)))
 
+    def subset(self, rows):
+        "the given rows of a loaded set as a new set (device-side row gather; the manifest rows follow)"
+        rows = np.ascontiguousarray(rows, dtype=np.uint64)
+        return SketchSet._from_objptr(self._methodcall(lib.smgpu_sketchset_subset, rows.ctypes.data_as(C.c_void_p), len(rows)))
+
     def signature(self, row):
         "SourmashSignature of a row of a loaded set (name / filename from the manifest)"
         m = self.manifest[row]
@@ -756,6 +761,29 @@ class ZipFileLinearIndex(Index):
             if search_fn.collect(score, loaded[md5]):
                 yield IndexSearchResult(score, loaded[md5], self.location)
 
+    def counter_gather(self, query, threshold_bp, **kwargs):
+        """The reference prefetches and adds every match to a CounterGather, one signature object each
+        (index/__init__.py:302-320).  Here the prefetch is the overlap pass over the resident CSR, the matching rows are
+        gathered into their own CSR on the device, and the counter reads signatures from the archive only when a
+        round returns one."""
+        prefetch_query = query.to_mutable()
+        prefetch_query.minhash = prefetch_query.minhash.flatten()
+        bulk = self._bulk(prefetch_query.minhash)
+        if bulk is None:
+            return Index.counter_gather(self, query, threshold_bp, **kwargs)
+        if not self:
+            raise ValueError("no signatures to search")
+        sset, sizes, walk = bulk
+        query_mh = prefetch_query.minhash
+        search_fn = make_containment_query(query_mh, threshold_bp, best_only=kwargs.get("best_only", False))
+        search_fn.check_is_compatible(prefetch_query)
+        shared = sset.overlaps(query_mh)
+        q_size = len(query_mh)
+        walk = walk[shared[walk] > 0]
+        keep = [r for r in walk.tolist()
+                if search_fn.passes(search_fn.score_fn(q_size, int(shared[r]), int(sizes[r]), q_size + int(sizes[r]) - int(shared[r])))]
+        return _ArchiveCounterGather(prefetch_query, self, sset, keep)
+
     def select(self, **kwargs):
         _check_select_parameters(**kwargs)
         if self.manifest is not None:
@@ -1105,3 +1133,89 @@ class CounterGather:
             query_mh = query_mh.downsample(scaled=scaled).to_mutable() if scaled != query_mh.scaled else query_mh
             query_mh.remove_many(sr.signature.minhash.downsample(scaled=scaled).flatten())
         return out
+
+
+class _LazySignatures:
+    "md5 -> signature for rows of an archive-backed set, read from the archive on first use (insertion ordered)"
+
+    def __init__(self, index, rows):
+        self._index = index
+        self._rows = {row["md5"]: row for row in rows}      # first row wins, like the md5-keyed dict of the reference
+        self._loaded = {}
+
+    def __len__(self):
+        return len(self._rows)
+
+    def __bool__(self):
+        return bool(self._rows)
+
+    def __iter__(self):
+        return iter(self._rows)
+
+    def __contains__(self, md5):
+        return md5 in self._rows
+
+    def __getitem__(self, md5):
+        if md5 not in self._loaded:
+            member = self._rows[md5]["internal_location"]
+            for ss in load_signatures_from_json(self._index.storage.load(member)):
+                self._loaded.setdefault(ss.md5sum(), ss)
+        return self._loaded[md5]
+
+    def keys(self):
+        return self._rows.keys()
+
+    def values(self):
+        return (self[md5] for md5 in self._rows)
+
+    def items(self):
+        return ((md5, self[md5]) for md5 in self._rows)
+
+
+class _ArchiveCounterGather(CounterGather):
+    """CounterGather over rows of a collection that is already in HBM: same protocol, same decisions; the candidate
+    rows are gathered into their own CSR on the device instead of being added one signature object at a time."""
+
+    def __init__(self, query, index, sset, rows):
+        CounterGather.__init__(self, query)
+        # one entry per md5, first occurrence wins (CounterGather keys by md5)
+        seen, first = set(), []
+        for r in rows:
+            md5 = sset.manifest[r]["md5"]
+            if md5 not in seen:
+                seen.add(md5)
+                first.append(r)
+        self._cand = sset.subset(first) if first else None
+        man = self._cand.manifest if first else []
+        self.siglist = _LazySignatures(index, man)
+        self.locations = {row["md5"]: index.location for row in man}
+        for row in man:                                      # every candidate has the collection's scaled after loading
+            self.downsample(row["scaled"])
+        self.downsample(sset.params[3])
+
+    def add(self, *args, **kwargs):
+        raise ValueError("this counter was built from a resident collection; candidates cannot be added")
+
+    add_many = add
+
+    def _device(self):
+        if self._dev is None:
+            self._dev = (_DeviceCounter(self._cand, self.orig_query_mh), list(self.siglist))
+        return self._dev
+
+    @property
+    def union_found(self):
+        found_mh = self.orig_query_mh.copy_and_clear()
+        for i in range(len(self._cand) if self._cand is not None else 0):
+            found_mh.add_many(flatten_and_intersect_scaled(self._cand.minhash(i), self.orig_query_mh))
+        return found_mh
+
+    def gather_all(self, threshold_bp=0):
+        if not self.siglist:
+            return []
+        self.query_started = 1
+        dev, order = self._device()
+        scaled = self.orig_query_mh.scaled
+        thr = math.ceil(float(threshold_bp) / scaled) if threshold_bp else 0
+        idx, isect = dev.gather(thr)
+        return [(order[int(i)], int(c)) for i, c in zip(idx, isect)]

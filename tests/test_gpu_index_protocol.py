@@ -202,3 +202,48 @@ def test_zipfile_search_goes_through_the_bulk_loader(sm, tmp_path):
     q = next(iter(coarse.signatures()))
     res = coarse.search(q, threshold=0.9)
     assert len(res) == 1 and res[0].score == 1.0 and res[0].signature == q and coarse._bulk_cache is not None
+
+
+def test_zipfile_counter_gather_from_the_resident_collection(sm, tmp_path):
+    """counter_gather on a zip collection: candidates come from the overlap pass over the CSR already in HBM and are
+    gathered into their own CSR on the device; signatures are read from the archive only when a round returns them.
+    Same rows as the object route, which is the reference's golden gather (tests/test_index_protocol.py:1057-1097)."""
+    import glob
+    from sourmash_amd.index import Index, ZipFileLinearIndex, _ArchiveCounterGather
+    from sourmash_amd.save_load import SaveSignaturesToLocation
+    from sourmash_amd.search import GatherDatabases
+    loc = str(tmp_path / "genomes.zip")
+    with SaveSignaturesToLocation(loc) as save:
+        for path in sorted(glob.glob(golden("gather", "GCF_*.sig"))):
+            save.add_many(sm.load_signatures_from_json(path))
+    query = sm.load_one_signature_from_json(golden("gather", "combined.sig"))
+    zidx = ZipFileLinearIndex.load(loc).select(ksize=query.minhash.ksize, moltype="DNA")
+
+    def run(counter):
+        return [(r.match.name.split()[0], r.unique_intersect_bp // query.minhash.scaled, r.f_match, r.remaining_bp)
+                for r in GatherDatabases(query, [counter], threshold_bp=0)]
+    fast_counter = zidx.counter_gather(query, 0)
+    assert isinstance(fast_counter, _ArchiveCounterGather) and len(fast_counter.siglist) == 12
+    slow_counter = Index.counter_gather(zidx, query, 0)
+    assert fast_counter.counter == slow_counter.counter
+    ov = sorted(slow_counter.counter.values(), reverse=True)
+    assert len(ov) == 12
+    assert fast_counter.union_found == slow_counter.union_found
+    fast, slow = run(fast_counter), run(slow_counter)
+    assert fast == slow
+    assert [(n, c) for n, c, _, _ in fast] == [
+        ("NC_003198.1", 487), ("NC_000853.1", 192), ("NC_011978.1", 169), ("NC_002163.1", 157), ("NC_003197.2", 152),
+        ("NC_009486.1", 92), ("NC_006905.1", 76), ("NC_011080.1", 59), ("NC_011274.1", 42), ("NC_006511.1", 31),
+        ("NC_011294.1", 7), ("NC_004631.1", 2)]
+    # the whole loop in one native call, and a prefetch threshold that keeps 5 candidates
+    assert [c for _, c in zidx.counter_gather(query, 0).gather_all()] == [c for _, c, _, _ in fast]
+    cut_bp = ov[4] * query.minhash.scaled                              # keeps the rows overlapping at least as much as the 5th
+    few = zidx.counter_gather(query, cut_bp)
+    assert len(few.siglist) == len(Index.counter_gather(zidx, query, cut_bp).siglist) == sum(v >= ov[4] for v in ov) < 12
+    with pytest.raises(ValueError):
+        few.add(query)
+    # nothing in common: an empty counter that answers the protocol
+    mh = query.minhash.copy_and_clear()
+    mh.add_many([1, 2, 3])
+    empty = zidx.counter_gather(sm.SourmashSignature(mh), 0)
+    assert len(empty.siglist) == 0 and empty.peek(mh) == [] and not empty.counter
