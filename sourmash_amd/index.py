@@ -863,6 +863,15 @@ class MultiIndex(Index):
     def __len__(self):
         return 0 if self.manifest is None else len(self.manifest)
 
+    _packed = None
+
+    def _subject_set(self, query_scaled, items):
+        "the manifest never changes after construction: keep the device CSR between queries of the same scaled"
+        key = (query_scaled, len(items))
+        if self._packed is None or self._packed[0] != key:
+            self._packed = (key,) + Index._subject_set(self, query_scaled, items)
+        return self._packed[1], self._packed[2]
+
     @classmethod
     def load(cls, index_list, source_list, parent, *, prepend_location=False):
         "from loaded indices and as many sources; a source of None keeps the index's own location"
