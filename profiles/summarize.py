@@ -12,6 +12,7 @@ def short(name):
                   r"reduce_by_key_init_kernel|partition_kernel|select)", name)
     if "rocprim" in name and m:
         return "rocprim::" + m.group(1)
+    name = name.replace("(anonymous namespace)::", "")
     name = re.sub(r"\(.*", "", name)
     return name[:90]
 

@@ -37,15 +37,50 @@ struct QIndex {
     uint64_t qmax;
 };
 
+// Wide loads from addresses that are only 4- / 8-byte aligned.  The hardware takes them (global memory, dword
+// alignment); hipcc splits them into narrower instructions unless they are spelled out.
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void load_u32_pair(const uint32_t* p, uint32_t& a, uint32_t& b) {
+    u32x2_t v;
+    asm volatile("global_load_dwordx2 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(p) : "memory");
+    a = v.x; b = v.y;
+}
+
+__device__ __forceinline__ void load_u64_quad(const uint64_t* p, uint64_t& a, uint64_t& b, uint64_t& c, uint64_t& d) {
+    u32x4_t v0, v1;
+    asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:16\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(v0), "=&v"(v1) : "v"(p) : "memory");
+    a = (uint64_t)v0.x | ((uint64_t)v0.y << 32); b = (uint64_t)v0.z | ((uint64_t)v0.w << 32);
+    c = (uint64_t)v1.x | ((uint64_t)v1.y << 32); d = (uint64_t)v1.z | ((uint64_t)v1.w << 32);
+}
+
+// Position of x in Q, or NONE32.  The table is sized for about one query hash per bucket, so a bucket almost always
+// holds <= 4: those are fetched with two 16-byte loads and compared in registers.  Three load instructions per lookup
+// (table pair, two halves of the bucket): every lane of a lookup goes to a different cache line, and a CU serves such
+// loads at about one line per cycle, so the number of load INSTRUCTIONS is what a lookup costs.
+// Fuller buckets finish with a binary search.
 __device__ __forceinline__ uint32_t q_find(const QIndex& qi, uint64_t x) {
     if (x > qi.qmax) return NONE32;
-    const uint64_t b = x >> qi.shift;
-    uint32_t lo = qi.T[b], hi = qi.T[b + 1];
-    while (lo < hi) {
-        const uint32_t mid = (lo + hi) >> 1;
-        if (qi.Q[mid] < x) lo = mid + 1; else hi = mid;
+    uint32_t lo, hi;
+    load_u32_pair(qi.T + (x >> qi.shift), lo, hi);
+    if (lo == hi) return NONE32;
+    // qi.Q is gather_build's padded copy of the query (4 extra entries), so lo + 3 is always readable
+    uint64_t q0, q1, q2, q3;
+    load_u64_quad(qi.Q + lo, q0, q1, q2, q3);
+    const uint32_t nq = (uint32_t)qi.nq;
+    if (q0 == x) return lo;
+    if (q1 == x) return lo + 1 < nq ? lo + 1 : NONE32;
+    if (q2 == x) return lo + 2 < nq ? lo + 2 : NONE32;
+    if (q3 == x) return lo + 3 < nq ? lo + 3 : NONE32;
+    if (hi - lo <= 4) return NONE32;
+    uint32_t l = lo + 4, h = hi;
+    while (l < h) {
+        const uint32_t mid = (l + h) >> 1;
+        if (qi.Q[mid] < x) l = mid + 1; else h = mid;
     }
-    return (lo < qi.nq && qi.Q[lo] == x) ? lo : NONE32;
+    return (l < hi && qi.Q[l] == x) ? l : NONE32;
 }
 
 __global__ __launch_bounds__(256) void qtable_kernel(const uint64_t* __restrict__ Q, uint64_t nq, uint32_t shift,
@@ -100,6 +135,154 @@ __global__ __launch_bounds__(256) void build_fill_kernel(const uint32_t* __restr
             if (j != NONE32) post_rows[atomicAdd(&cursor[j], 1ull)] = (uint32_t)d;
         }
     }
+}
+
+// ---- range-partitioned build (large databases) ------------------------------------------------------------------
+// The two kernels above spend their time in device-scope atomics (one per database element that hits the query, twice).
+// Here the query positions are cut into ranges of BR_RANGE and the rows into B blocks; workgroup (range r, block b)
+// walks the slices of its rows that fall into the range -- contiguous, because rows are sorted -- and keeps the
+// histogram / the cursors of those BR_RANGE postings in LDS.  Global atomics: one per (row, range) for the counters.
+//   bounds   [R + 1][ndb]  first position of row d whose hash is >= Q[r * BR_RANGE]  (row length for r = R)
+//   partial  [B][nq]       pass 1: postings of query hash j contributed by block b; then its exclusive prefix over b
+// so that in pass 2 the slot of an element is post_off[j] + partial[b][j] + (LDS cursor of j in this workgroup).
+constexpr int BR_RANGE = 32768;      // query positions per range: row slices long enough (~1 KB) to read DRAM efficiently
+constexpr int BR_EPW = 16;           // row slices a wave flattens per step (see apply_kernel)
+constexpr int BR_THREADS = 512;      // 64 KB of LDS per workgroup (u16 slots, two per word): 2 workgroups = 16 waves per CU
+
+__global__ __launch_bounds__(256) void build_bounds_kernel(const uint64_t* __restrict__ Q, uint32_t R,
+                                                           const uint64_t* __restrict__ hashes,
+                                                           const uint64_t* __restrict__ offsets, uint64_t ndb,
+                                                           uint32_t* __restrict__ bounds) {
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    for (uint64_t d = wave; d < ndb; d += n_waves) {
+        const uint64_t base = offsets[d], len = offsets[d + 1] - base;
+        for (uint32_t r = lane; r <= R; r += 64) {
+            uint64_t lo = 0, hi = len;
+            if (r < R) {
+                const uint64_t x = Q[(uint64_t)r * BR_RANGE];
+                while (lo < hi) {
+                    const uint64_t mid = (lo + hi) >> 1;
+                    if (hashes[base + mid] < x) lo = mid + 1; else hi = mid;
+                }
+            } else {
+                lo = len;
+            }
+            bounds[(uint64_t)r * ndb + d] = (uint32_t)lo;
+        }
+    }
+}
+
+template <bool FILL>
+__global__ __launch_bounds__(BR_THREADS) void build_range_kernel(QIndex qi, const uint64_t* __restrict__ hashes,
+                                                          const uint64_t* __restrict__ offsets, uint64_t ndb,
+                                                          const uint32_t* __restrict__ bounds, uint32_t R, uint32_t B,
+                                                          uint64_t rows_per_block, uint32_t* __restrict__ partial,
+                                                          const uint64_t* __restrict__ post_off,
+                                                          uint32_t* __restrict__ post_rows, unsigned long long* counters) {
+    // pass 1: histogram; pass 2: cursors.  A block holds < 65536 rows and a row adds at most 1 to a slot, so 16 bits do
+    __shared__ uint32_t s_slot[BR_RANGE / 2];
+    // Launch order: ranges in groups of 8, range (8g + x) entirely on workgroup ids = x mod 8, i.e. on one XCD (workgroups
+    // are dealt to the 8 XCDs round-robin), blocks in ascending order.  The 4-byte stores of pass 2 that fill one posting
+    // list then meet in a single L2, whose working set is one open cache line per list of the range.
+    const uint32_t local = blockIdx.x % (8u * B);
+    const uint32_t r = (blockIdx.x / (8u * B)) * 8u + (local & 7u), b = local >> 3;
+    if (r >= R) return;
+    const uint64_t j0 = (uint64_t)r * BR_RANGE;
+    const uint32_t nj = (uint32_t)(qi.nq - j0 < (uint64_t)BR_RANGE ? qi.nq - j0 : (uint64_t)BR_RANGE);
+    for (int k = threadIdx.x; k < BR_RANGE / 2; k += BR_THREADS) s_slot[k] = 0;
+    __syncthreads();
+    const uint64_t d_lo = (uint64_t)b * rows_per_block;
+    const uint64_t d_hi = d_lo + rows_per_block < ndb ? d_lo + rows_per_block : ndb;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint32_t* part_b = partial + (uint64_t)b * qi.nq;
+    for (uint64_t dbase = d_lo + (uint64_t)wave * BR_EPW; dbase < d_hi; dbase += (BR_THREADS / 64) * BR_EPW) {
+        // lane l < BR_EPW: the slice of row dbase + l inside this range
+        uint64_t lo = 0;
+        uint32_t n = 0;
+        const uint64_t d = dbase + lane;
+        if (lane < BR_EPW && d < d_hi) {
+            const uint32_t a = bounds[(uint64_t)r * ndb + d], e = bounds[(uint64_t)(r + 1) * ndb + d];
+            lo = offsets[d] + a;
+            n = e - a;
+        }
+        uint32_t incl = n;
+#pragma unroll
+        for (int s = 1; s < BR_EPW; s <<= 1) {
+            const uint32_t v = __shfl_up(incl, s);
+            if (lane >= s) incl += v;
+        }
+        const uint32_t total = __shfl(incl, BR_EPW - 1);
+        if (total == 0) continue;
+        uint32_t bound[BR_EPW - 1];                                 // wave-uniform: end of slices 0 .. 14
+#pragma unroll
+        for (int k = 0; k < BR_EPW - 1; ++k) bound[k] = __shfl(incl, k);
+        const uint32_t excl = incl - n;
+        const uint32_t lo_lo = (uint32_t)lo, lo_hi = (uint32_t)(lo >> 32);
+        uint32_t row_hits = 0;                                      // lane l < BR_EPW: hits of slice l
+        for (uint32_t t0 = 0; t0 < total; t0 += 64) {               // wave-uniform trip count: the shuffles read lanes 0 .. 15
+            const uint32_t t = t0 + (uint32_t)lane;
+            int h = 0;
+#pragma unroll
+            for (int k = 0; k < BR_EPW - 1; ++k) h += t >= bound[k];
+            const uint64_t start = ((uint64_t)(uint32_t)__shfl((int)lo_hi, h) << 32) | (uint32_t)__shfl((int)lo_lo, h);
+            const uint32_t first = (uint32_t)__shfl((int)excl, h);
+            uint32_t j = NONE32;
+            if (t < total) j = q_find(qi, hashes[start + (t - first)]);
+            const bool hit = j != NONE32;
+            if (hit) {
+                const uint32_t k = j - (uint32_t)j0;                // < nj: the slice lies inside the range
+                const uint32_t sh = 16u * (k & 1u);
+                if (FILL) {
+                    const uint32_t mine = (atomicAdd(&s_slot[k >> 1], 1u << sh) >> sh) & 0xffffu;
+                    const uint64_t at = post_off ? post_off[j] + part_b[j] : (uint64_t)part_b[j];   // null: partial already holds absolute slots
+                    post_rows[at + mine] = (uint32_t)(dbase + (uint64_t)h);
+                } else {
+                    atomicAdd(&s_slot[k >> 1], 1u << sh);
+                }
+            }
+            if (!FILL) {
+                // slice l occupies the flattened positions [excl, incl): its lanes in this step are a contiguous run
+                const unsigned long long hits = __ballot(hit);
+                const uint32_t a = excl > t0 ? (excl - t0 < 64u ? excl - t0 : 64u) : 0u;
+                const uint32_t e = incl > t0 ? (incl - t0 < 64u ? incl - t0 : 64u) : 0u;
+                const unsigned long long upto_e = e >= 64u ? ~0ull : ((1ull << e) - 1ull);
+                const unsigned long long upto_a = a >= 64u ? ~0ull : ((1ull << a) - 1ull);
+                row_hits += (uint32_t)__popcll(hits & upto_e & ~upto_a);
+            }
+        }
+        if (!FILL && lane < BR_EPW && row_hits) atomicAdd(&counters[d], (unsigned long long)row_hits);
+    }
+    if (FILL) return;
+    __syncthreads();
+    uint32_t* out = partial + (uint64_t)b * qi.nq + j0;
+    for (uint32_t k = threadIdx.x; k < nj; k += BR_THREADS) out[k] = (s_slot[k >> 1] >> (16u * (k & 1u))) & 0xffffu;
+}
+
+// partial[b][j] += post_off[j]: absolute slots, when all of them fit 32 bits (one load less per element in pass 2)
+__global__ __launch_bounds__(256) void build_absolute_kernel(uint32_t* __restrict__ partial, uint32_t B, uint64_t nq,
+                                                             const uint64_t* __restrict__ post_off) {
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= nq) return;
+    const uint32_t base = (uint32_t)post_off[j];
+    for (uint32_t b = 0; b < B; ++b) partial[(uint64_t)b * nq + j] += base;
+}
+
+// partial[b][j] -> its exclusive prefix over b; post_cnt[j] = the sum (post_cnt[nq] = 0 for the scan)
+__global__ __launch_bounds__(256) void build_merge_counts_kernel(uint32_t* __restrict__ partial, uint32_t B, uint64_t nq,
+                                                                 unsigned long long* __restrict__ post_cnt) {
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j > nq) return;
+    unsigned long long run = 0;
+    if (j < nq) {
+        for (uint32_t b = 0; b < B; ++b) {
+            const uint32_t v = partial[(uint64_t)b * nq + j];
+            partial[(uint64_t)b * nq + j] = (uint32_t)run;
+            run += v;
+        }
+    }
+    post_cnt[j] = run;
 }
 
 __device__ __forceinline__ unsigned long long wave_max(unsigned long long k) {
@@ -318,7 +501,7 @@ unsigned blocks_for_rows(uint64_t ndb) {
 
 }  // namespace
 
-static QIndex qindex_of(const GatherDev& g) { return QIndex{g.Q, g.nq, g.q_table, g.q_shift, g.q_max}; }
+static QIndex qindex_of(const GatherDev& g) { return QIndex{g.q_padded, g.nq, g.q_table, g.q_shift, g.q_max}; }
 
 #define SMG_TRY(expr)                      \
     do {                                   \
@@ -327,7 +510,7 @@ static QIndex qindex_of(const GatherDev& g) { return QIndex{g.Q, g.nq, g.q_table
     } while (0)
 
 void gather_destroy(GatherDev& g) {
-    void* owned[] = {g.q_table, g.alive, g.post_off, g.post_rows, g.counters, g.state, g.partials, g.out_idx, g.out_isect};
+    void* owned[] = {g.q_padded, g.q_table, g.alive, g.post_off, g.post_rows, g.counters, g.state, g.partials, g.out_idx, g.out_isect};
     for (void* p : owned)
         if (p) (void)hipFree(p);
     g = GatherDev();
@@ -352,8 +535,12 @@ hipError_t gather_build(GatherDev& g, hipStream_t stream) {
     if (g.ndb) SMG_TRY(hipMemcpyAsync(&total, g.offsets + g.ndb, 8, hipMemcpyDeviceToHost, stream));
     if (g.nq) SMG_TRY(hipMemcpyAsync(&g.q_max, g.Q + g.nq - 1, 8, hipMemcpyDeviceToHost, stream));
     SMG_TRY(hipStreamSynchronize(stream));
+    SMG_TRY(hipMalloc(&g.q_padded, (g.nq + 4) * 8));
+    if (g.nq) SMG_TRY(hipMemcpyAsync(g.q_padded, g.Q, g.nq * 8, hipMemcpyDeviceToDevice, stream));
+    for (int i = 0; i < 4; ++i)                                   // &g.q_max outlives the copies: the stream is synchronised below
+        SMG_TRY(hipMemcpyAsync(g.q_padded + g.nq + i, &g.q_max, 8, hipMemcpyHostToDevice, stream));
     uint32_t bucket_bits = 0;
-    while (bucket_bits < 24 && (4ull << bucket_bits) < g.nq) ++bucket_bits;      // ~4 query hashes per bucket
+    while (bucket_bits < 26 && (1ull << bucket_bits) < g.nq) ++bucket_bits;      // about one query hash per bucket
     uint32_t value_bits = 0;
     while (value_bits < 64 && (g.q_max >> value_bits)) ++value_bits;
     g.q_shift = value_bits > bucket_bits ? value_bits - bucket_bits : 0;
@@ -367,33 +554,74 @@ hipError_t gather_build(GatherDev& g, hipStream_t stream) {
         g.npairs = 0;
         return hipStreamSynchronize(stream);
     }
-    // scratch: qpos of every database element, the histogram / cursors, scan temp
-    uint32_t* qpos = nullptr;
-    unsigned long long* post_cnt = nullptr;
-    SMG_TRY(hipMallocAsync((void**)&qpos, total * 4, stream));
-    SMG_TRY(hipMallocAsync((void**)&post_cnt, nq1 * 8, stream));
-    SMG_TRY(hipMemsetAsync(post_cnt, 0, nq1 * 8, stream));
     const QIndex qi = qindex_of(g);
-    hipLaunchKernelGGL(build_count_kernel, dim3(blocks_for_rows(g.ndb)), dim3(256), 0, stream, qi, g.hashes, g.offsets,
-                       g.ndb, qpos, post_cnt, g.counters);
-    SMG_TRY(hipGetLastError());
+    unsigned long long* post_cnt = nullptr;
+    SMG_TRY(hipMallocAsync((void**)&post_cnt, nq1 * 8, stream));
     size_t scan_bytes = 0;
     SMG_TRY(rocprim::exclusive_scan(nullptr, scan_bytes, (uint64_t*)post_cnt, g.post_off, (uint64_t)0, (size_t)nq1,
                                     rocprim::plus<uint64_t>(), stream));
     void* scan_tmp = nullptr;
     SMG_TRY(hipMallocAsync(&scan_tmp, scan_bytes + 256, stream));
-    SMG_TRY(rocprim::exclusive_scan(scan_tmp, scan_bytes, (uint64_t*)post_cnt, g.post_off, (uint64_t)0, (size_t)nq1,
-                                    rocprim::plus<uint64_t>(), stream));
-    SMG_TRY(hipMemcpyAsync(&g.npairs, g.post_off + g.nq, 8, hipMemcpyDeviceToHost, stream));
-    SMG_TRY(hipMemcpyAsync(post_cnt, g.post_off, nq1 * 8, hipMemcpyDeviceToDevice, stream));   // cursors
-    SMG_TRY(hipStreamSynchronize(stream));
-    SMG_TRY(hipMalloc(&g.post_rows, (g.npairs + 4) * 4));
-    hipLaunchKernelGGL(build_fill_kernel, dim3(blocks_for_rows(g.ndb)), dim3(256), 0, stream, qpos, g.offsets, g.ndb,
-                       post_cnt, g.post_rows);
-    SMG_TRY(hipGetLastError());
+    // Small problems: one atomic per element is cheapest.  Large ones: range-partitioned, histogram and cursors in LDS.
+    const char* force = getenv("SMG_GATHER_BUILD");
+    const bool ranges = force ? !strcmp(force, "ranges") : (total >= (8ull << 20) && g.ndb >= 256);
+    if (!ranges) {
+        uint32_t* qpos = nullptr;                                   // query position of every database element
+        SMG_TRY(hipMallocAsync((void**)&qpos, total * 4, stream));
+        SMG_TRY(hipMemsetAsync(post_cnt, 0, nq1 * 8, stream));
+        hipLaunchKernelGGL(build_count_kernel, dim3(blocks_for_rows(g.ndb)), dim3(256), 0, stream, qi, g.hashes, g.offsets,
+                           g.ndb, qpos, post_cnt, g.counters);
+        SMG_TRY(hipGetLastError());
+        SMG_TRY(rocprim::exclusive_scan(scan_tmp, scan_bytes, (uint64_t*)post_cnt, g.post_off, (uint64_t)0, (size_t)nq1,
+                                        rocprim::plus<uint64_t>(), stream));
+        SMG_TRY(hipMemcpyAsync(&g.npairs, g.post_off + g.nq, 8, hipMemcpyDeviceToHost, stream));
+        SMG_TRY(hipMemcpyAsync(post_cnt, g.post_off, nq1 * 8, hipMemcpyDeviceToDevice, stream));   // cursors
+        SMG_TRY(hipStreamSynchronize(stream));
+        SMG_TRY(hipMalloc(&g.post_rows, (g.npairs + 4) * 4));
+        hipLaunchKernelGGL(build_fill_kernel, dim3(blocks_for_rows(g.ndb)), dim3(256), 0, stream, qpos, g.offsets, g.ndb,
+                           post_cnt, g.post_rows);
+        SMG_TRY(hipGetLastError());
+        SMG_TRY(hipFreeAsync(qpos, stream));
+    } else {
+        const uint32_t R = (uint32_t)((g.nq + BR_RANGE - 1) / BR_RANGE);
+        uint64_t B = 64;
+        if (const char* e = getenv("SMG_GATHER_BUILD_BLOCKS")) B = strtoull(e, nullptr, 10);
+        if (B < (g.ndb + 65534) / 65535) B = (g.ndb + 65534) / 65535;   // 16-bit slots: fewer than 65536 rows per block
+        if (B > (g.ndb + 127) / 128) B = (g.ndb + 127) / 128;       // at least one full step (8 waves x 16 rows) per block
+        if (B < 1) B = 1;
+        const uint64_t rows_per_block = (g.ndb + B - 1) / B;
+        uint32_t *bounds = nullptr, *partial = nullptr;
+        SMG_TRY(hipMallocAsync((void**)&bounds, ((uint64_t)R + 1) * g.ndb * 4, stream));
+        SMG_TRY(hipMallocAsync((void**)&partial, B * g.nq * 4, stream));
+        hipLaunchKernelGGL(build_bounds_kernel, dim3(blocks_for_rows(g.ndb)), dim3(256), 0, stream, g.Q, R, g.hashes,
+                           g.offsets, g.ndb, bounds);
+        SMG_TRY(hipGetLastError());
+        hipLaunchKernelGGL(build_range_kernel<false>, dim3((unsigned)(((R + 7) / 8) * 8 * B)), dim3(BR_THREADS), 0, stream, qi, g.hashes, g.offsets,
+                           g.ndb, bounds, R, (uint32_t)B, rows_per_block, partial, (const uint64_t*)nullptr, (uint32_t*)nullptr, g.counters);
+        SMG_TRY(hipGetLastError());
+        hipLaunchKernelGGL(build_merge_counts_kernel, dim3((unsigned)((nq1 + 255) / 256)), dim3(256), 0, stream, partial,
+                           (uint32_t)B, g.nq, post_cnt);
+        SMG_TRY(hipGetLastError());
+        SMG_TRY(rocprim::exclusive_scan(scan_tmp, scan_bytes, (uint64_t*)post_cnt, g.post_off, (uint64_t)0, (size_t)nq1,
+                                        rocprim::plus<uint64_t>(), stream));
+        SMG_TRY(hipMemcpyAsync(&g.npairs, g.post_off + g.nq, 8, hipMemcpyDeviceToHost, stream));
+        SMG_TRY(hipStreamSynchronize(stream));
+        SMG_TRY(hipMalloc(&g.post_rows, (g.npairs + 4) * 4));
+        const bool absolute = g.npairs < 0xffffffffull;
+        if (absolute) {
+            hipLaunchKernelGGL(build_absolute_kernel, dim3((unsigned)((g.nq + 255) / 256)), dim3(256), 0, stream, partial,
+                               (uint32_t)B, g.nq, (const uint64_t*)g.post_off);
+            SMG_TRY(hipGetLastError());
+        }
+        hipLaunchKernelGGL(build_range_kernel<true>, dim3((unsigned)(((R + 7) / 8) * 8 * B)), dim3(BR_THREADS), 0, stream, qi, g.hashes, g.offsets,
+                           g.ndb, bounds, R, (uint32_t)B, rows_per_block, partial, absolute ? (const uint64_t*)nullptr : (const uint64_t*)g.post_off,
+                           g.post_rows, g.counters);
+        SMG_TRY(hipGetLastError());
+        SMG_TRY(hipFreeAsync(bounds, stream));
+        SMG_TRY(hipFreeAsync(partial, stream));
+    }
     SMG_TRY(hipFreeAsync(scan_tmp, stream));
     SMG_TRY(hipFreeAsync(post_cnt, stream));
-    SMG_TRY(hipFreeAsync(qpos, stream));
     return hipStreamSynchronize(stream);
 }
 

@@ -143,7 +143,11 @@ def test_search_and_prefetch_vs_oracle(sm):
     assert db.best_containment(q).signature.name in ("s5", "s116")          # itself or its planted duplicate
 
 
-def test_synthetic_gather_vs_oracle(sm):
+@pytest.mark.parametrize("build", ["atomic", "ranges"])
+def test_synthetic_gather_vs_oracle(sm, build, monkeypatch):
+    # both builders of the inverted index (csrc/gather.hip: one atomic per element / range-partitioned with the
+    # histogram in LDS) -- the size heuristic would pick "atomic" for a database this small
+    monkeypatch.setenv("SMG_GATHER_BUILD", build)
     from sourmash_amd.index import CounterGather
     from sourmash_amd.synth import synth_gather
     qh, dbh = synth_gather(n_query=60_000, n_db=1500, db_size=600)
