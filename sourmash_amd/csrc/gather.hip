@@ -397,7 +397,9 @@ __global__ __launch_bounds__(256) void export_row_kernel(const unsigned long lon
 // A wave takes APPLY_EPW hashes of the row: one lane each looks its hash up in the query; the postings of the
 // wave's hits are then treated as ONE list (prefix sums over the hits) that all 64 lanes walk together, so short
 // and long posting lists keep the lanes equally busy and every load / atomic of an iteration is independent.
-constexpr int APPLY_EPW = 16;
+// Few hashes per wave and a grid of 4096 waves: a round is one dependent chain (row -> table -> bucket -> postings ->
+// counters), so its length is the postings one wave has to walk -- 16 hashes per wave took 24 us per round at C5, 2 take 18.
+constexpr int APPLY_EPW = 2;
 
 template <bool GATE>
 __global__ __launch_bounds__(256) void apply_kernel(QIndex qi, uint8_t* alive, const uint64_t* __restrict__ post_off,
@@ -668,7 +670,7 @@ hipError_t gather_export(GatherDev& g, const unsigned long long* d_key, uint64_t
 }
 
 hipError_t gather_apply(GatherDev& g, const uint64_t* d_rowbuf, hipStream_t stream) {
-    hipLaunchKernelGGL(apply_kernel<true>, dim3(128), dim3(256), 0, stream, qindex_of(g), g.alive, g.post_off,
+    hipLaunchKernelGGL(apply_kernel<true>, dim3(1024), dim3(256), 0, stream, qindex_of(g), g.alive, g.post_off,
                        g.post_rows, g.counters, g.state, d_rowbuf, g.hashes, g.offsets, g.index_base);
     return hipGetLastError();
 }
