@@ -398,7 +398,8 @@ __global__ __launch_bounds__(256) void export_row_kernel(const unsigned long lon
 // wave's hits are then treated as ONE list (prefix sums over the hits) that all 64 lanes walk together, so short
 // and long posting lists keep the lanes equally busy and every load / atomic of an iteration is independent.
 // Few hashes per wave and a grid of 4096 waves: a round is one dependent chain (row -> table -> bucket -> postings ->
-// counters), so its length is the postings one wave has to walk -- 16 hashes per wave took 24 us per round at C5, 2 take 18.
+// counters), so its length is the postings one wave has to walk (C5: 33 us per round with 16 hashes per wave on 512
+// waves, 29 us with 2 on 4096).
 constexpr int APPLY_EPW = 2;
 
 template <bool GATE>
