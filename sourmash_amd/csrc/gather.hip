@@ -21,80 +21,15 @@
 #include <stdlib.h>
 #include <rocprim/device/device_scan.hpp>
 #include "gather_api.hpp"
+#include "qindex.hpp"
 
 namespace smg {
 
 namespace {
 
-constexpr uint32_t NONE32 = 0xffffffffu;
-
-// first-level table over the sorted query: bucket b = x >> shift covers Q[T[b], T[b+1])
-struct QIndex {
-    const uint64_t* Q;
-    uint64_t nq;
-    const uint32_t* T;
-    uint32_t shift;
-    uint64_t qmax;
-};
-
-// Wide loads from addresses that are only 4- / 8-byte aligned.  The hardware takes them (global memory, dword
-// alignment); hipcc splits them into narrower instructions unless they are spelled out.
-typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
-typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ void load_u32_pair(const uint32_t* p, uint32_t& a, uint32_t& b) {
-    u32x2_t v;
-    asm volatile("global_load_dwordx2 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(p) : "memory");
-    a = v.x; b = v.y;
-}
-
-__device__ __forceinline__ void load_u64_quad(const uint64_t* p, uint64_t& a, uint64_t& b, uint64_t& c, uint64_t& d) {
-    u32x4_t v0, v1;
-    asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:16\n\ts_waitcnt vmcnt(0)"
-                 : "=&v"(v0), "=&v"(v1) : "v"(p) : "memory");
-    a = (uint64_t)v0.x | ((uint64_t)v0.y << 32); b = (uint64_t)v0.z | ((uint64_t)v0.w << 32);
-    c = (uint64_t)v1.x | ((uint64_t)v1.y << 32); d = (uint64_t)v1.z | ((uint64_t)v1.w << 32);
-}
-
-// Position of x in Q, or NONE32.  The table is sized for about one query hash per bucket, so a bucket almost always
-// holds <= 4: those are fetched with two 16-byte loads and compared in registers.  Three load instructions per lookup
-// (table pair, two halves of the bucket): every lane of a lookup goes to a different cache line, and a CU serves such
-// loads at about one line per cycle, so the number of load INSTRUCTIONS is what a lookup costs.
-// Fuller buckets finish with a binary search.
-__device__ __forceinline__ uint32_t q_find(const QIndex& qi, uint64_t x) {
-    if (x > qi.qmax) return NONE32;
-    uint32_t lo, hi;
-    load_u32_pair(qi.T + (x >> qi.shift), lo, hi);
-    if (lo == hi) return NONE32;
-    // qi.Q is gather_build's padded copy of the query (4 extra entries), so lo + 3 is always readable
-    uint64_t q0, q1, q2, q3;
-    load_u64_quad(qi.Q + lo, q0, q1, q2, q3);
-    const uint32_t nq = (uint32_t)qi.nq;
-    if (q0 == x) return lo;
-    if (q1 == x) return lo + 1 < nq ? lo + 1 : NONE32;
-    if (q2 == x) return lo + 2 < nq ? lo + 2 : NONE32;
-    if (q3 == x) return lo + 3 < nq ? lo + 3 : NONE32;
-    if (hi - lo <= 4) return NONE32;
-    uint32_t l = lo + 4, h = hi;
-    while (l < h) {
-        const uint32_t mid = (l + h) >> 1;
-        if (qi.Q[mid] < x) l = mid + 1; else h = mid;
-    }
-    return (l < hi && qi.Q[l] == x) ? l : NONE32;
-}
-
 __global__ __launch_bounds__(256) void qtable_kernel(const uint64_t* __restrict__ Q, uint64_t nq, uint32_t shift,
                                                      uint32_t n_buckets, uint32_t* __restrict__ T) {
-    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b > n_buckets) return;
-    if (b == n_buckets) { T[b] = (uint32_t)nq; return; }
-    const uint64_t x = (uint64_t)b << shift;
-    uint64_t lo = 0, hi = nq;
-    while (lo < hi) {
-        const uint64_t mid = (lo + hi) >> 1;
-        if (Q[mid] < x) lo = mid + 1; else hi = mid;
-    }
-    T[b] = (uint32_t)lo;
+    qindex_fill_bucket(Q, nq, shift, n_buckets, T, blockIdx.x * blockDim.x + threadIdx.x);
 }
 
 // pass 1 over the database: qpos of every element, postings histogram, initial counters (CounterGather.add)
@@ -542,12 +477,7 @@ hipError_t gather_build(GatherDev& g, hipStream_t stream) {
     if (g.nq) SMG_TRY(hipMemcpyAsync(g.q_padded, g.Q, g.nq * 8, hipMemcpyDeviceToDevice, stream));
     for (int i = 0; i < 4; ++i)                                   // &g.q_max outlives the copies: the stream is synchronised below
         SMG_TRY(hipMemcpyAsync(g.q_padded + g.nq + i, &g.q_max, 8, hipMemcpyHostToDevice, stream));
-    uint32_t bucket_bits = 0;
-    while (bucket_bits < 26 && (1ull << bucket_bits) < g.nq) ++bucket_bits;      // about one query hash per bucket
-    uint32_t value_bits = 0;
-    while (value_bits < 64 && (g.q_max >> value_bits)) ++value_bits;
-    g.q_shift = value_bits > bucket_bits ? value_bits - bucket_bits : 0;
-    g.q_buckets = (uint32_t)(g.q_max >> g.q_shift) + 1;
+    qindex_geometry(g.nq, g.q_max, &g.q_shift, &g.q_buckets);
     SMG_TRY(hipMalloc(&g.q_table, ((uint64_t)g.q_buckets + 1) * 4));
     hipLaunchKernelGGL(qtable_kernel, dim3((g.q_buckets + 256) / 256), dim3(256), 0, stream, g.Q, g.nq, g.q_shift,
                        g.q_buckets, g.q_table);

@@ -17,6 +17,7 @@
 #include <rocprim/device/device_select.hpp>
 #include "device_api.hpp"
 #include "pair_api.hpp"
+#include "qindex.hpp"
 
 namespace smg {
 
@@ -86,12 +87,43 @@ __global__ __launch_bounds__(256) void num_rank_kernel(const uint64_t* __restric
     if ((threadIdx.x & 63) == 0 && cnt) atomicAdd(dst, cnt);
 }
 
-// overlap[d] (op == 0: =, op == 1: -=) |Q ∩ D_d| for every row d of a CSR database:
-// one wave per row chunk, lanes binary-search Q.
-__global__ __launch_bounds__(256) void overlap_vector_kernel(const uint64_t* __restrict__ Q, uint64_t nq,
+// ---- overlap[d] (op == 0: =, op == 1: -=) |Q ∩ D_d| for every row d of a CSR database ----------------------------------
+// The query gets a first-level table (qindex.hpp) built on the stream in front of the pass, so a database element
+// costs three load instructions instead of the log2(nq) dependent probes of a binary search.  Everything is
+// stream-ordered: the table geometry is worked out on the device from Q[nq - 1].
+struct QIndexHeader {
+    QIndex qi;
+    uint32_t buckets;
+};
+constexpr size_t QIH_BYTES = 64;                              // header, then the padded copy of Q, then the table
+
+__global__ __launch_bounds__(256) void qindex_setup_kernel(const uint64_t* __restrict__ Q, uint64_t nq, uint8_t* scratch) {
+    uint64_t* pad = reinterpret_cast<uint64_t*>(scratch + QIH_BYTES);
+    const uint64_t qmax = Q[nq - 1];
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nq + 4; i += (uint64_t)gridDim.x * blockDim.x)
+        pad[i] = i < nq ? Q[i] : qmax;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        QIndexHeader* h = reinterpret_cast<QIndexHeader*>(scratch);
+        h->qi.Q = pad;
+        h->qi.nq = nq;
+        h->qi.T = reinterpret_cast<const uint32_t*>(pad + nq + 4);
+        h->qi.qmax = qmax;
+        qindex_geometry(nq, qmax, &h->qi.shift, &h->buckets);
+    }
+}
+
+__global__ __launch_bounds__(256) void qindex_table_kernel(uint8_t* scratch) {
+    const QIndexHeader* h = reinterpret_cast<const QIndexHeader*>(scratch);
+    qindex_fill_bucket(h->qi.Q, h->qi.nq, h->qi.shift, h->buckets, const_cast<uint32_t*>(h->qi.T),
+                       blockIdx.x * blockDim.x + threadIdx.x);
+}
+
+// one wave per row, 64 elements per step
+__global__ __launch_bounds__(256) void overlap_vector_kernel(const QIndexHeader* __restrict__ hdr,
                                                              const uint64_t* __restrict__ hashes,
                                                              const uint64_t* __restrict__ offsets, uint64_t ndb,
                                                              unsigned long long* __restrict__ overlap, int op) {
+    const QIndex qi = hdr->qi;
     const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
     const int lane = threadIdx.x & 63;
@@ -99,11 +131,7 @@ __global__ __launch_bounds__(256) void overlap_vector_kernel(const uint64_t* __r
         const uint64_t lo = offsets[d], hi = offsets[d + 1];
         if (op == 1 && overlap[d] == 0) continue;          // dropped from the counter (index/__init__.py:908-909)
         unsigned long long cnt = 0;
-        for (uint64_t i = lo + lane; i < hi; i += 64) {
-            const uint64_t x = hashes[i];
-            const uint64_t j = lower_bound_dev(Q, nq, x);
-            cnt += (j < nq && Q[j] == x) ? 1 : 0;
-        }
+        for (uint64_t i = lo + lane; i < hi; i += 64) cnt += q_find(qi, hashes[i]) != NONE32 ? 1 : 0;
         for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off);
         if (lane == 0) {
             if (op == 0) overlap[d] = cnt;
@@ -177,11 +205,25 @@ hipError_t select_flagged(const uint64_t* in, const uint8_t* flags, uint64_t n, 
 hipError_t overlap_vector_launch(const uint64_t* Q, uint64_t nq, const uint64_t* hashes, const uint64_t* offsets,
                                  uint64_t ndb, unsigned long long* overlap, int op, hipStream_t stream) {
     if (ndb == 0) return hipSuccess;
-    const uint64_t waves = ndb;                       // one wave per dataset, capped
-    const uint64_t blocks = (waves + 3) / 4;
-    hipLaunchKernelGGL(overlap_vector_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, stream, Q,
-                       nq, hashes, offsets, ndb, overlap, op);
-    return hipGetLastError();
+    if (nq == 0) {                                        // nothing in common with anything
+        return op == 0 ? hipMemsetAsync(overlap, 0, ndb * 8, stream) : hipSuccess;
+    }
+    if (nq >= NONE32) return hipErrorInvalidValue;
+    // scratch: header, padded query, table of at most 2 * nq + 2 entries; allocated and released in stream order
+    uint8_t* scratch = nullptr;
+    const size_t bytes = QIH_BYTES + (nq + 4) * 8 + (2 * nq + 4) * 4;
+    hipError_t e = hipMallocAsync((void**)&scratch, bytes, stream);
+    if (e != hipSuccess) return e;
+    const uint64_t copy_blocks = (nq + 4 + 255) / 256;
+    hipLaunchKernelGGL(qindex_setup_kernel, dim3((unsigned)(copy_blocks < 1024 ? copy_blocks : 1024)), dim3(256), 0, stream, Q,
+                       nq, scratch);
+    hipLaunchKernelGGL(qindex_table_kernel, dim3((unsigned)((2 * nq + 2 + 255) / 256)), dim3(256), 0, stream, scratch);
+    const uint64_t blocks = (ndb + 3) / 4;                // one wave per dataset, capped
+    hipLaunchKernelGGL(overlap_vector_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, stream,
+                       reinterpret_cast<const QIndexHeader*>(scratch), hashes, offsets, ndb, overlap, op);
+    e = hipGetLastError();
+    const hipError_t f = hipFreeAsync(scratch, stream);
+    return e != hipSuccess ? e : f;
 }
 
 // one workgroup per destination row: dst[dst_off[i] ..) = src[src_off[rows[i]] ..), 8-byte coalesced copies
