@@ -32,10 +32,10 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
 # HBM traffic of sketch_dna_kernel<31,16,false> on the default C2 batch from the PMC passes committed in
-# profiles/r01_final_pmc.txt (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate runs):
-# FETCH_SIZE 5,030,609 KiB, doubled as MI355X_MICROARCH.md prescribes for 16 B/lane streaming reads on
-# gfx950, + WRITE_SIZE 78,534 KiB.  Only quoted when the live run uses that exact batch.
-PMC_C2_BYTES = 2 * 5_030_609 * 1024 + 78_534 * 1024
+# profiles/r01_end_pmc.txt (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate runs):
+# FETCH_SIZE 5,030,617 KiB, doubled as MI355X_MICROARCH.md prescribes for 16 B/lane streaming reads on
+# gfx950, + WRITE_SIZE 78,545 KiB.  Only quoted when the live run uses that exact batch.
+PMC_C2_BYTES = 2 * 5_030_617 * 1024 + 78_545 * 1024
 PMC_C2_INPUT_BYTES = 9_990_000_999
 
 
@@ -145,7 +145,7 @@ def main():
         roofline = {"bound": "hbm", "kernel": "sketch_dna_kernel<31,16>", "achieved": round(achieved, 2),
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                     "traffic": PMC_C2_BYTES if (n_bytes == PMC_C2_INPUT_BYTES and args.ksize == 31) else None,
-                    "traffic_source": "profiles/r01_final_pmc.txt (PMC passes of this same command)",
+                    "traffic_source": "profiles/r01_end_pmc.txt (PMC passes of this same command)",
                     "kernel_ms": round(kern_ms, 3), "algorithmic_bytes": alg_bytes,
                     "note": "VALU-integer bound (12 x 64-bit multiplies per k-mer), see DESIGN.md; "
                             "kernel-only Gbase/s = %.1f" % (bases_per_step / (kern_ms * 1e-3) / 1e9)}
