@@ -152,7 +152,7 @@ def main():
 
         # ---- CPU baseline: the oracle on a bounded sample of the same stream ----
         cpu = None
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:         # the contract: rank 0 at N = 1 only
             import oracle
             cores = os.cpu_count() or 1
             sample = int(args.cpu_sample) if args.cpu_sample else int(min(n_bytes, 25e6 * cores, 1e9))
@@ -170,7 +170,7 @@ def main():
 
         # ---- secondary metrics: 1,000 x 1,000 compare (config C3) and a gather run (scaled-down C5) ----
         extra = {}
-        if not args.no_compare:
+        if not args.no_compare and world == 1:              # single-GPU secondary metrics; N > 1 runs time the sketch only
             try:
                 from sourmash_amd.synth import synth_sketches, synth_gather
                 from sourmash_amd import parallel
