@@ -115,7 +115,8 @@ __global__ __launch_bounds__(BR_THREADS) void build_range_kernel(QIndex qi, cons
                                                           const uint32_t* __restrict__ bounds, uint32_t R, uint32_t B,
                                                           uint64_t rows_per_block, uint32_t* __restrict__ partial,
                                                           const uint64_t* __restrict__ post_off,
-                                                          uint32_t* __restrict__ post_rows, unsigned long long* counters) {
+                                                          uint32_t* __restrict__ post_rows, unsigned long long* counters,
+                                                          uint32_t* __restrict__ qpos) {
     // pass 1: histogram; pass 2: cursors.  A block holds < 65536 rows and a row adds at most 1 to a slot, so 16 bits do
     __shared__ uint32_t s_slot[BR_RANGE / 2];
     // Launch order: ranges in groups of 8, range (8g + x) entirely on workgroup ids = x mod 8, i.e. on one XCD (workgroups
@@ -164,7 +165,14 @@ __global__ __launch_bounds__(BR_THREADS) void build_range_kernel(QIndex qi, cons
             const uint64_t start = ((uint64_t)(uint32_t)__shfl((int)lo_hi, h) << 32) | (uint32_t)__shfl((int)lo_lo, h);
             const uint32_t first = (uint32_t)__shfl((int)excl, h);
             uint32_t j = NONE32;
-            if (t < total) j = q_find(qi, hashes[start + (t - first)]);
+            if (t < total) {
+                if (FILL) {
+                    j = qpos[start + (t - first)];                  // pass 1 left it there
+                } else {
+                    j = q_find(qi, hashes[start + (t - first)]);
+                    qpos[start + (t - first)] = j;
+                }
+            }
             const bool hit = j != NONE32;
             if (hit) {
                 const uint32_t k = j - (uint32_t)j0;                // < nj: the slice lies inside the range
@@ -343,9 +351,11 @@ __global__ __launch_bounds__(256) void apply_kernel(QIndex qi, uint8_t* alive, c
                                                     unsigned long long* counters, unsigned long long* state,
                                                     const uint64_t* __restrict__ rowbuf,
                                                     const uint64_t* __restrict__ hashes,
-                                                    const uint64_t* __restrict__ offsets, uint64_t index_base) {
+                                                    const uint64_t* __restrict__ offsets, uint64_t index_base,
+                                                    const uint32_t* __restrict__ qpos) {
     if (GATE && state[GS_DONE]) return;
     const uint64_t* row;
+    const uint32_t* row_pos = nullptr;                              // query positions of the row, when it is a local one
     uint64_t len;
     if (rowbuf) {
         len = rowbuf[0];
@@ -353,6 +363,7 @@ __global__ __launch_bounds__(256) void apply_kernel(QIndex qi, uint8_t* alive, c
     } else {
         const uint64_t d = (0xffffffffull & ~state[GS_KEY]) - index_base;
         row = hashes + offsets[d];
+        row_pos = qpos + offsets[d];
         len = offsets[d + 1] - offsets[d];
     }
     const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -362,7 +373,7 @@ __global__ __launch_bounds__(256) void apply_kernel(QIndex qi, uint8_t* alive, c
         const uint64_t i = base + lane;
         uint32_t j = NONE32;
         if (lane < APPLY_EPW && i < len) {
-            j = q_find(qi, row[i]);
+            j = row_pos ? row_pos[i] : q_find(qi, row[i]);
             if (j != NONE32) {
                 // only hashes still uncovered count: they leave the set here, and counters[d] stays |row_d ∩ uncovered|
                 // whatever the caller hands to consume (the same intersect twice, hashes it never peeked)
@@ -448,7 +459,7 @@ static QIndex qindex_of(const GatherDev& g) { return QIndex{g.q_padded, g.nq, g.
     } while (0)
 
 void gather_destroy(GatherDev& g) {
-    void* owned[] = {g.q_padded, g.q_table, g.alive, g.post_off, g.post_rows, g.counters, g.state, g.partials, g.out_idx, g.out_isect};
+    void* owned[] = {g.q_padded, g.q_table, g.alive, g.post_off, g.post_rows, g.qpos, g.counters, g.state, g.partials, g.out_idx, g.out_isect};
     for (void* p : owned)
         if (p) (void)hipFree(p);
     g = GatherDev();
@@ -495,12 +506,12 @@ hipError_t gather_build(GatherDev& g, hipStream_t stream) {
                                     rocprim::plus<uint64_t>(), stream));
     void* scan_tmp = nullptr;
     SMG_TRY(hipMallocAsync(&scan_tmp, scan_bytes + 256, stream));
+    SMG_TRY(hipMalloc(&g.qpos, (total + 4) * 4));                // kept: apply reads it instead of looking hashes up again
     // Small problems: one atomic per element is cheapest.  Large ones: range-partitioned, histogram and cursors in LDS.
     const char* force = getenv("SMG_GATHER_BUILD");
     const bool ranges = force ? !strcmp(force, "ranges") : (total >= (8ull << 20) && g.ndb >= 256);
     if (!ranges) {
-        uint32_t* qpos = nullptr;                                   // query position of every database element
-        SMG_TRY(hipMallocAsync((void**)&qpos, total * 4, stream));
+        uint32_t* qpos = g.qpos;
         SMG_TRY(hipMemsetAsync(post_cnt, 0, nq1 * 8, stream));
         hipLaunchKernelGGL(build_count_kernel, dim3(blocks_for_rows(g.ndb)), dim3(256), 0, stream, qi, g.hashes, g.offsets,
                            g.ndb, qpos, post_cnt, g.counters);
@@ -514,7 +525,6 @@ hipError_t gather_build(GatherDev& g, hipStream_t stream) {
         hipLaunchKernelGGL(build_fill_kernel, dim3(blocks_for_rows(g.ndb)), dim3(256), 0, stream, qpos, g.offsets, g.ndb,
                            post_cnt, g.post_rows);
         SMG_TRY(hipGetLastError());
-        SMG_TRY(hipFreeAsync(qpos, stream));
     } else {
         const uint32_t R = (uint32_t)((g.nq + BR_RANGE - 1) / BR_RANGE);
         uint64_t B = 64;
@@ -526,11 +536,12 @@ hipError_t gather_build(GatherDev& g, hipStream_t stream) {
         uint32_t *bounds = nullptr, *partial = nullptr;
         SMG_TRY(hipMallocAsync((void**)&bounds, ((uint64_t)R + 1) * g.ndb * 4, stream));
         SMG_TRY(hipMallocAsync((void**)&partial, B * g.nq * 4, stream));
+        SMG_TRY(hipMemsetAsync(g.qpos, 0xff, total * 4, stream));   // elements below Q[0] lie in no range
         hipLaunchKernelGGL(build_bounds_kernel, dim3(blocks_for_rows(g.ndb)), dim3(256), 0, stream, g.Q, R, g.hashes,
                            g.offsets, g.ndb, bounds);
         SMG_TRY(hipGetLastError());
         hipLaunchKernelGGL(build_range_kernel<false>, dim3((unsigned)(((R + 7) / 8) * 8 * B)), dim3(BR_THREADS), 0, stream, qi, g.hashes, g.offsets,
-                           g.ndb, bounds, R, (uint32_t)B, rows_per_block, partial, (const uint64_t*)nullptr, (uint32_t*)nullptr, g.counters);
+                           g.ndb, bounds, R, (uint32_t)B, rows_per_block, partial, (const uint64_t*)nullptr, (uint32_t*)nullptr, g.counters, g.qpos);
         SMG_TRY(hipGetLastError());
         hipLaunchKernelGGL(build_merge_counts_kernel, dim3((unsigned)((nq1 + 255) / 256)), dim3(256), 0, stream, partial,
                            (uint32_t)B, g.nq, post_cnt);
@@ -548,7 +559,7 @@ hipError_t gather_build(GatherDev& g, hipStream_t stream) {
         }
         hipLaunchKernelGGL(build_range_kernel<true>, dim3((unsigned)(((R + 7) / 8) * 8 * B)), dim3(BR_THREADS), 0, stream, qi, g.hashes, g.offsets,
                            g.ndb, bounds, R, (uint32_t)B, rows_per_block, partial, absolute ? (const uint64_t*)nullptr : (const uint64_t*)g.post_off,
-                           g.post_rows, g.counters);
+                           g.post_rows, g.counters, g.qpos);
         SMG_TRY(hipGetLastError());
         SMG_TRY(hipFreeAsync(bounds, stream));
         SMG_TRY(hipFreeAsync(partial, stream));
@@ -602,13 +613,13 @@ hipError_t gather_export(GatherDev& g, const unsigned long long* d_key, uint64_t
 
 hipError_t gather_apply(GatherDev& g, const uint64_t* d_rowbuf, hipStream_t stream) {
     hipLaunchKernelGGL(apply_kernel<true>, dim3(1024), dim3(256), 0, stream, qindex_of(g), g.alive, g.post_off,
-                       g.post_rows, g.counters, g.state, d_rowbuf, g.hashes, g.offsets, g.index_base);
+                       g.post_rows, g.counters, g.state, d_rowbuf, g.hashes, g.offsets, g.index_base, g.qpos);
     return hipGetLastError();
 }
 
 hipError_t gather_consume_list(GatherDev& g, const uint64_t* d_list, hipStream_t stream) {
     hipLaunchKernelGGL(apply_kernel<false>, dim3(128), dim3(256), 0, stream, qindex_of(g), g.alive, g.post_off,
-                       g.post_rows, g.counters, g.state, d_list, g.hashes, g.offsets, g.index_base);
+                       g.post_rows, g.counters, g.state, d_list, g.hashes, g.offsets, g.index_base, g.qpos);
     return hipGetLastError();
 }
 

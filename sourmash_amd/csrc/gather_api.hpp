@@ -35,6 +35,8 @@ struct GatherDev {
     uint8_t* alive = nullptr;           // [nq] 1 while the query hash is uncovered
     uint64_t* post_off = nullptr;       // [nq + 1] postings of query hash j: post_rows[post_off[j] .. post_off[j+1])
     uint32_t* post_rows = nullptr;      // local row ids
+    uint32_t* qpos = nullptr;           // [database elements] position in Q of every element of the shard (NONE32: not in Q):
+                                        // a round applied from the local CSR skips the lookup (two dependent loads)
     uint64_t npairs = 0;
     unsigned long long* counters = nullptr;   // [ndb] |row_d ∩ uncovered query|
     unsigned long long* state = nullptr;      // [GS_SLOTS]
