@@ -37,6 +37,13 @@ HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 T
 # gfx950, + WRITE_SIZE 78,545 KiB.  Only quoted when the live run uses that exact batch.
 PMC_C2_BYTES = 2 * 5_030_617 * 1024 + 78_545 * 1024
 PMC_C2_INPUT_BYTES = 9_990_000_999
+# SQ_INSTS_VALU of the same kernel on the same batch (same file): wave-instructions per launch.  The issue model prices
+# them by the kernel's static mix: 71 % of the per-k-mer instructions (multiplies, v_add3, v_alignbit, v_lshl_add_u64,
+# permutes, compares) cost 4.3 cycles per wave-instruction per SIMD, 29 % (xor / and / add / lshr / bitop3 / mov) 2.45
+# (profiles/r01_ubench_valu.txt) = 3.76 on average; 1,024 SIMDs at the 2.36 GHz the kernel runs at
+# (GRBM_GUI_ACTIVE / 8 XCDs / kernel time).
+PMC_C2_VALU_INSTS = 18_194_765_969
+VALU_CYCLES_PER_INST, N_SIMDS, SHADER_HZ = 3.76, 1024, 2.36e9
 
 
 def parse():
@@ -147,6 +154,11 @@ def main():
                     "traffic": PMC_C2_BYTES if (n_bytes == PMC_C2_INPUT_BYTES and args.ksize == 31) else None,
                     "traffic_source": "profiles/r01_end_pmc.txt (PMC passes of this same command)",
                     "kernel_ms": round(kern_ms, 3), "algorithmic_bytes": alg_bytes,
+                    "valu": ({"insts_per_kmer": round(PMC_C2_VALU_INSTS * 64 / bases_per_step, 1),
+                              "issue_busy_frac_model": round(PMC_C2_VALU_INSTS * VALU_CYCLES_PER_INST / N_SIMDS / SHADER_HZ
+                                                             / (kern_ms * 1e-3), 3),
+                              "source": "profiles/r01_end_pmc.txt SQ_INSTS_VALU x 3.76 cycles (static mix x r01_ubench_valu.txt) / 1024 SIMDs / 2.36 GHz"}
+                             if (n_bytes == PMC_C2_INPUT_BYTES and args.ksize == 31) else None),
                     "note": "VALU-integer bound (12 x 64-bit multiplies per k-mer), see DESIGN.md; "
                             "kernel-only Gbase/s = %.1f" % (bases_per_step / (kern_ms * 1e-3) / 1e9)}
 
