@@ -313,10 +313,19 @@ def main():
                        "unique_hashes_job": n_unique_total, "allgather_ms": gather_ms},
             "roofline": roofline, "cpu_baseline": cpu, "extra": extra,
         }
-        print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    if out is not None:
+        # RCCL prints a version banner through C stdio, which sits in libc's buffer until exit when stdout is a file
+        # or a pipe: push it out first so that the JSON is the last line of rank 0's output
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
