@@ -509,7 +509,15 @@ hipError_t gather_build(GatherDev& g, hipStream_t stream) {
     SMG_TRY(hipMalloc(&g.qpos, (total + 4) * 4));                // kept: apply reads it instead of looking hashes up again
     // Small problems: one atomic per element is cheapest.  Large ones: range-partitioned, histogram and cursors in LDS.
     const char* force = getenv("SMG_GATHER_BUILD");
-    const bool ranges = force ? !strcmp(force, "ranges") : (total >= (8ull << 20) && g.ndb >= 256);
+    bool ranges = force ? !strcmp(force, "ranges") : (total >= (8ull << 20) && g.ndb >= 256);
+    // scratch of the range-partitioned builder: B x nq per-block prefixes and (R + 1) x ndb slice bounds, 4 bytes each.
+    // B can shrink to what the 16-bit LDS slots allow (< 65536 rows per block); past 8 GB the atomic builder is used.
+    uint64_t B = 64;
+    if (const char* e = getenv("SMG_GATHER_BUILD_BLOCKS")) B = strtoull(e, nullptr, 10);
+    const uint64_t R64 = (g.nq + BR_RANGE - 1) / BR_RANGE, B_min = (g.ndb + 65534) / 65535;
+    while (B > B_min && B > 1 && B * g.nq * 4 > (4ull << 30)) B /= 2;
+    if (B < B_min) B = B_min;
+    if (ranges && !force && (B * g.nq + (R64 + 1) * g.ndb) * 4 > (8ull << 30)) ranges = false;
     if (!ranges) {
         uint32_t* qpos = g.qpos;
         SMG_TRY(hipMemsetAsync(post_cnt, 0, nq1 * 8, stream));
@@ -527,10 +535,8 @@ hipError_t gather_build(GatherDev& g, hipStream_t stream) {
         SMG_TRY(hipGetLastError());
     } else {
         const uint32_t R = (uint32_t)((g.nq + BR_RANGE - 1) / BR_RANGE);
-        uint64_t B = 64;
-        if (const char* e = getenv("SMG_GATHER_BUILD_BLOCKS")) B = strtoull(e, nullptr, 10);
-        if (B < (g.ndb + 65534) / 65535) B = (g.ndb + 65534) / 65535;   // 16-bit slots: fewer than 65536 rows per block
         if (B > (g.ndb + 127) / 128) B = (g.ndb + 127) / 128;       // at least one full step (8 waves x 16 rows) per block
+        if (B < B_min) B = B_min;
         if (B < 1) B = 1;
         const uint64_t rows_per_block = (g.ndb + B - 1) / B;
         uint32_t *bounds = nullptr, *partial = nullptr;
