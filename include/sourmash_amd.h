@@ -334,8 +334,9 @@ void smgpu_collection_params(const SmgpuCollection *ptr, uint32_t *ksize, uint32
 SmgpuSketchSet *smgpu_sketchset_from_collection(const SmgpuCollection *ptr);
 SmgpuSketchSet *smgpu_sketchset_load(const char *const *paths, uintptr_t n_paths, uint32_t ksize, const char *moltype,
                                      uint64_t scaled, uint32_t n_threads);
-/* rows[0..n) of a loaded set as a new set: row gather on the device, manifest rows follow (search results -> gather
- * candidates without going back to the files). */
+/* rows[0..n) of a loaded set as a new set: row gather on the device, manifest rows follow.  Replaces the object loop of
+ * Index.counter_gather (src/sourmash/index/__init__.py:302-320: `for result in self.prefetch(...): counter.add(
+ * result.signature, ...)`): the rows that pass the prefetch become the counter's database without leaving HBM. */
 SmgpuSketchSet *smgpu_sketchset_subset(const SmgpuSketchSet *set, const uint64_t *rows, uintptr_t n);
 uint64_t smgpu_sketchset_total_hashes(const SmgpuSketchSet *ptr);
 uint64_t smgpu_sketchset_skipped(const SmgpuSketchSet *ptr);
