@@ -10,16 +10,21 @@ unique pass, leaving the sorted unique hash vector (the sketch) in HBM.
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--bases B]
 
-N > 1 is launched by the driver with torch.distributed.run; every rank sketches
-its own 10 GB slice of the stream (weak scaling), ranks exchange their hash
-vectors with one RCCL all-gather after the timed region's last step so that every
-rank holds the sketch of the whole input (set union is associative), and
-value = (bases sketched by all ranks) / (max over ranks of the elapsed time).
+N > 1 is launched by the driver with torch.distributed.run.  Every rank sketches
+its own 10 GB slice of the stream (weak scaling); value = (bases sketched by all
+ranks) / (max over ranks of the elapsed time).  After the timed region the ranks
+also run the two multi-GPU configurations of BASELINE.json through
+sourmash_amd.parallel (the same code at every N; N = 1 takes the same functions,
+SMG_BENCH_FORCE_COLLECTIVES=1 makes a single rank issue the collectives too):
+    extra.compare_c4_dist   10,000 x 10,000 compare, row tiles dealt to the ranks, ONE all-gather
+    extra.gather_c5_dist    10^6-hash query vs 100,000 sketches sharded 100,000 / N per rank,
+                            one all-gather of candidate rows per batch of rounds
 
 Prints ONE JSON line on rank 0 with the contract fields plus
   roofline:     HBM roofline of the dominant kernel (algorithmic bytes / measured kernel time)
-  cpu_baseline: the oracle (CPU restatement of the reference algorithm) on a bounded sample
-  extra:        secondary metric: sketch-pairs/s on the 1,000 x 1,000 compare (config C3)
+  cpu_baseline: the oracle (CPU restatement of the reference algorithm) on bounded samples,
+                one thread and as many threads as this container may run (N = 1 only)
+  extra:        secondary metrics, each with its own roofline object
 """
 import argparse
 import json
@@ -31,19 +36,15 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
-# HBM traffic of sketch_dna_kernel<31,16,false> on the default C2 batch from the PMC passes committed in
-# profiles/r01_end_pmc.txt (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate runs):
-# FETCH_SIZE 5,030,617 KiB, doubled as MI355X_MICROARCH.md prescribes for 16 B/lane streaming reads on
-# gfx950, + WRITE_SIZE 78,545 KiB.  Only quoted when the live run uses that exact batch.
-PMC_C2_BYTES = 2 * 5_030_617 * 1024 + 78_545 * 1024
+HBM_ACHIEVABLE_GBS = 6290.0  # same guide: 6.29 TB/s measured with a float4 copy
+LDS_PEAK_GBS = 150_000.0   # same guide, LDS: ~150 TB/s aggregate for ds_read_b64/b128 with every CU streaming
+# Counter readings of sketch_dna_kernel<31,16,false> on the default C2 batch, QUOTED from the committed PMC passes
+# (rocprofv3 --pmc, separate runs; profiles/README.md says which file belongs to which round).  They are constants of
+# a previous run of this same command, not measurements of the present one: the JSON labels them `*_quoted_from`.
+PMC_FILE = "profiles/r01_end_pmc.txt"
+PMC_C2_BYTES = 2 * 5_030_617 * 1024 + 78_545 * 1024      # 2 x FETCH_SIZE (gfx950 correction for 16 B/lane reads) + WRITE_SIZE
 PMC_C2_INPUT_BYTES = 9_990_000_999
-# SQ_INSTS_VALU of the same kernel on the same batch (same file): wave-instructions per launch.  The issue model prices
-# them by the kernel's static mix: 71 % of the per-k-mer instructions (multiplies, v_add3, v_alignbit, v_lshl_add_u64,
-# permutes, compares) cost 4.3 cycles per wave-instruction per SIMD, 29 % (xor / and / add / lshr / bitop3 / mov) 2.45
-# (profiles/r01_ubench_valu.txt) = 3.76 on average; 1,024 SIMDs at the 2.36 GHz the kernel runs at
-# (GRBM_GUI_ACTIVE / 8 XCDs / kernel time).
-PMC_C2_VALU_INSTS = 18_194_765_969
-VALU_CYCLES_PER_INST, N_SIMDS, SHADER_HZ = 3.76, 1024, 2.36e9
+PMC_C2_VALU_INSTS = 18_194_765_969                        # SQ_INSTS_VALU, wave-instructions per launch
 
 
 def parse():
@@ -56,8 +57,8 @@ def parse():
     ap.add_argument("--ksize", type=int, default=31)
     ap.add_argument("--scaled", type=int, default=1000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-compare", action="store_true")
-    ap.add_argument("--cpu-sample", type=float, default=0.0, help="bases for the CPU baseline (0 = auto)")
+    ap.add_argument("--no-compare", action="store_true", help="skip every secondary metric (compare / gather)")
+    ap.add_argument("--cpu-sample", type=float, default=0.0, help="bases for the N-thread CPU sketch leg (0 = auto)")
     return ap.parse_args()
 
 
@@ -82,8 +83,9 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
-    import sourmash_amd as sm
+    import sourmash_amd as sm  # noqa: F401
     from sourmash_amd import device as smd, parallel
+    from sourmash_amd.synth import synth_sketches, synth_gather, synth_gather_device
 
     n_bases = int(args.bases)
     rec = args.record_len
@@ -101,6 +103,13 @@ def main():
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
+
+    def max_over_ranks(seconds):
+        if not use_dist:
+            return seconds
+        t = torch.tensor([seconds], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
 
     hashes = None
     for _ in range(args.warmup):
@@ -122,16 +131,14 @@ def main():
         n_unique_total = int(parallel.allgather_union(hashes, force=True).numel())
         torch.cuda.synchronize()
         gather_ms = (time.perf_counter() - tg) * 1e3
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    elapsed = max_over_ranks(elapsed)
 
     total_bases = bases_per_step * world * args.steps
     value = total_bases / elapsed / 1e9
 
-    out = None
+    # ---- roofline of the dominant kernel (sketch_dna_kernel): HIP events on the launch stream (rank 0) ----
+    roofline = None
     if rank == 0:
-        # ---- roofline of the dominant kernel (sketch_dna_kernel): HIP events on the launch stream ----
         cap = sk.cap
         raw = torch.empty(cap, dtype=torch.int64, device=dev)
         cnt = torch.zeros(2, dtype=torch.int64, device=dev)
@@ -149,158 +156,64 @@ def main():
         kept = int(cnt[0].item())
         alg_bytes = n_bytes + 8 * kept                      # 1 B/base in + 8 B per kept hash out
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+        quoted = n_bytes == PMC_C2_INPUT_BYTES and args.ksize == 31
         roofline = {"bound": "hbm", "kernel": "sketch_dna_kernel<31,16>", "achieved": round(achieved, 2),
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                    "traffic": PMC_C2_BYTES if (n_bytes == PMC_C2_INPUT_BYTES and args.ksize == 31) else None,
-                    "traffic_source": "profiles/r01_end_pmc.txt (PMC passes of this same command)",
+                    "traffic": PMC_C2_BYTES if quoted else None,
+                    "traffic_quoted_from": PMC_FILE + " (PMC passes of this same command, an earlier run)" if quoted else None,
                     "kernel_ms": round(kern_ms, 3), "algorithmic_bytes": alg_bytes,
                     "valu": ({"insts_per_kmer": round(PMC_C2_VALU_INSTS * 64 / bases_per_step, 1),
-                              "issue_busy_frac_model": round(PMC_C2_VALU_INSTS * VALU_CYCLES_PER_INST / N_SIMDS / SHADER_HZ
-                                                             / (kern_ms * 1e-3), 3),
-                              "source": "profiles/r01_end_pmc.txt SQ_INSTS_VALU x 3.76 cycles (static mix x r01_ubench_valu.txt) / 1024 SIMDs / 2.36 GHz"}
-                             if (n_bytes == PMC_C2_INPUT_BYTES and args.ksize == 31) else None),
+                              "quoted_from": PMC_FILE + " SQ_INSTS_VALU; measured VALU-busy fraction: DESIGN.md 4.1"}
+                             if quoted else None),
                     "note": "VALU-integer bound (12 x 64-bit multiplies per k-mer), see DESIGN.md; "
                             "kernel-only Gbase/s = %.1f" % (bases_per_step / (kern_ms * 1e-3) / 1e9)}
+        del raw, cnt
 
-        # ---- CPU baseline: the oracle on a bounded sample of the same stream ----
-        cpu = None
-        if not args.no_cpu_baseline and world == 1:         # the contract: rank 0 at N = 1 only
-            import oracle
-            cores = os.cpu_count() or 1
-            sample = int(args.cpu_sample) if args.cpu_sample else int(min(n_bytes, 25e6 * cores, 1e9))
-            host = seq[:sample].cpu().numpy()
-            tc = time.perf_counter()
-            ref = oracle.sketch_dna_bulk(host, args.ksize, scaled=args.scaled, nthreads=cores)
-            tcpu = time.perf_counter() - tc
-            sample_bases = int((host != 10).sum())
-            # parity spot check of the GPU path on the very same sample
-            got = sk.sketch(seq[:sample]).cpu().numpy().view(np.uint64)
-            cpu = {"value": round(sample_bases / tcpu / 1e9, 4), "unit": "Gbase/s", "cores": cores, "kind": "port",
-                   "sample": f"first {sample} bytes of the same synthetic stream ({sample_bases} bases), "
-                             f"oracle.sketch_dna_bulk with {cores} OpenMP threads, {tcpu:.1f} s",
-                   "gpu_matches_oracle_on_sample": bool(np.array_equal(got, ref))}
+    # ---- CPU baseline (rank 0, N = 1 only): the oracle on bounded samples of the same workloads ----
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(args, seq, n_bytes, sk, np)
 
-        # ---- secondary metrics: 1,000 x 1,000 compare (config C3) and a gather run (scaled-down C5) ----
-        extra = {}
-        if not args.no_compare and world == 1:              # single-GPU secondary metrics; N > 1 runs time the sketch only
-            try:
-                from sourmash_amd.synth import synth_sketches, synth_gather
-                from sourmash_amd import parallel
-                sketches = synth_sketches(1000, seed=1234)
-                h, off = smd.pack_csr(sketches, device=dev)
-                n = len(sketches)
-                pairs = n * (n - 1) // 2
-                sizes = (off[1:] - off[:-1]).cpu().numpy().astype(np.int64)
-                alg = 8 * int((sizes.sum() * (n - 1)))             # sum over pairs of 8*(n_i+n_j)
+    extra = {}
+    del seq, hashes                                          # 10 GB back before the matrices
+    torch.cuda.empty_cache()
+    be = parallel.DeviceBackend(dev)
 
-                def timed(fn, reps=5):
-                    fn()
-                    torch.cuda.synchronize()
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e0.record()
-                    for _ in range(reps):
-                        fn()
-                    e1.record()
-                    torch.cuda.synchronize()
-                    return e0.elapsed_time(e1) / reps
+    def timed(fn, reps=5):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
 
-                common, jac = smd.compare_rows(h, off)
-                ms_merge = timed(lambda: smd.compare_rows(h, off, common=common, jaccard=jac))
-                extra["compare_1000x1000_merge"] = {
-                    "pairs_per_s": round(pairs / (ms_merge * 1e-3), 1), "ms": round(ms_merge, 3), "pairs": pairs,
-                    "algorithmic_GBps": round(alg / (ms_merge * 1e-3) / 1e9, 1),
-                    "kernel": "compare_tile_kernel (LDS-tiled merge walk; the general path)"}
-                build_ms = 0.0
-                for _ in range(3):                                  # last build: memory pool warm
-                    idx = None
-                    torch.cuda.synchronize()
-                    t0 = time.perf_counter()
-                    idx = smd.BitIndex.build(h, off)
-                    torch.cuda.synchronize()
-                    build_ms = (time.perf_counter() - t0) * 1e3
-                if idx is not None:
-                    c2, j2 = smd.compare_rows(h, off, index=idx)
-                    ms_bits = timed(lambda: smd.compare_rows(h, off, common=c2, jaccard=j2, index=idx))
-                    extra["compare_1000x1000_bits"] = {
-                        "pairs_per_s_incl_index_build": round(pairs / ((ms_bits + build_ms) * 1e-3), 1),
-                        "matrix_ms": round(ms_bits, 3), "index_build_ms": round(build_ms, 3), "universe": idx.universe,
-                        "identical_to_merge": bool((c2 == common).all().item() and (j2 == jac).all().item()),
-                        "kernel": "bitmatrix_kernel (hashes held by many sketches as bit columns + popcount; auto-selected)"}
-                    auto_ms = 0.0
-                    for _ in range(3):                              # what smgpu_compare_all_pairs does: decide, build, compare
-                        torch.cuda.synchronize()
-                        t0 = time.perf_counter()
-                        ca, ja = smd.compare_rows(h, off, method="auto")
-                        torch.cuda.synchronize()
-                        auto_ms = (time.perf_counter() - t0) * 1e3
-                    extra["compare_1000x1000_auto"] = {"ms": round(auto_ms, 3), "pairs_per_s": round(pairs / (auto_ms * 1e-3), 1),
-                                                       "identical_to_merge": bool((ca == common).all().item() and (ja == jac).all().item()),
-                                                       "note": "one-shot: cost model + index build + matrix + Jaccard, data resident in HBM"}
-                # gather: 2e5-hash query vs 5,000 x ~1,000-hash database, threshold_bp = 50 kbp
-                qh, dbh = synth_gather(n_query=200_000, n_db=5000, db_size=1000)
-                gh, goff = smd.pack_csr(dbh, device=dev)
-                gq = torch.from_numpy(qh.view(np.int64).copy()).to(dev)
-                be = parallel.DeviceBackend(dev)
-                thr_hashes = 50
-                for _ in range(2):                                  # second pass: allocator / code objects warm
-                    torch.cuda.synchronize()
-                    t0 = time.perf_counter()
-                    state = be.gather_state(gq, len(qh), gh, goff, len(dbh), 0)      # invert the database against the query
-                    torch.cuda.synchronize()
-                    t1 = time.perf_counter()
-                    state.begin(thr_hashes, len(dbh))
-                    res = state.run()                                # every round on the device
-                    torch.cuda.synchronize()
-                    t2 = time.perf_counter()
-                extra["gather_200k_vs_5000"] = {"rounds": len(res), "index_build_ms": round((t1 - t0) * 1e3, 2),
-                                                "loop_ms": round((t2 - t1) * 1e3, 2),
-                                                "us_per_round": round((t2 - t1) * 1e6 / max(len(res), 1), 1),
-                                                "note": "C5 at full size: profiles/r01_gather_c5.json (tools/bench_gather.py)"}
-            except Exception as e:   # the headline metric must still print
-                extra["error"] = repr(e)
-            # ---- BASELINE configs C4 and C5 at full size on this one GPU (a few seconds; tools/ hold the property checks) ----
-            try:
-                del seq                                              # 10 GB back before the big matrices
-                torch.cuda.empty_cache()
-                sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools"))
-                import bench_gather as bg
-                big = synth_sketches(10_000, seed=1234)
-                bh, boff = smd.pack_csr(big, device=dev)
-                bn = len(big)
-                bpairs = bn * (bn - 1) // 2
-                bc, bj = smd.compare_rows(bh, boff)
-                ms_big = timed(lambda: smd.compare_rows(bh, boff, common=bc, jaccard=bj), reps=1)
-                t0 = time.perf_counter()
-                ca, ja = smd.compare_rows(bh, boff, method="auto")
-                torch.cuda.synchronize()
-                auto_big = (time.perf_counter() - t0) * 1e3
-                extra["compare_10000x10000"] = {
-                    "pairs": bpairs, "merge_ms": round(ms_big, 2), "merge_pairs_per_s": round(bpairs / (ms_big * 1e-3), 1),
-                    "auto_ms": round(auto_big, 2), "auto_pairs_per_s": round(bpairs / (auto_big * 1e-3), 1),
-                    "identical": bool((ca == bc).all().item() and (ja == bj).all().item()),
-                    "note": "config C4 (pool-drawn sketches: the cost model picks bit columns); auto includes the index build"}
-                del bc, bj, ca, ja, bh, boff
-                torch.cuda.empty_cache()
-                gq5, gh5, goff5 = bg.make_inputs(1_000_000, 100_000, 5000, dev)
-                torch.cuda.synchronize()
-                for _ in range(2):
-                    t0 = time.perf_counter()
-                    st5 = be.gather_state(gq5, gq5.numel(), gh5, goff5, 100_000, 0)
-                    torch.cuda.synchronize()
-                    t1 = time.perf_counter()
-                    st5.begin(50, 100_000)
-                    res5 = st5.run()
-                    torch.cuda.synchronize()
-                    t2 = time.perf_counter()
-                iso = [r[1] for r in res5]
-                extra["gather_1M_vs_100000"] = {
-                    "db_bytes": int(gh5.numel() * 8), "rounds": len(res5), "index_build_ms": round((t1 - t0) * 1e3, 2),
-                    "loop_ms": round((t2 - t1) * 1e3, 2), "total_ms": round((t2 - t0) * 1e3, 2),
-                    "overlaps_non_increasing": bool(all(a >= b for a, b in zip(iso, iso[1:]))), "last_overlap": iso[-1] if iso else None,
-                    "note": "config C5 on one GPU, threshold_bp 50,000; full property checks: tools/bench_gather.py"}
-            except Exception as e:
-                extra["error_full_size"] = repr(e)
+    # ---- BASELINE configs C4 / C5 through the multi-GPU drivers (every rank; same code at N = 1) ----
+    if not args.no_compare:
+        try:
+            extra["compare_c4_dist"] = bench_compare_dist(torch, dist, np, dev, be, parallel, smd, synth_sketches, world, rank,
+                                                          use_dist, barrier, max_over_ranks)
+        except Exception as e:   # the headline metric must still print
+            extra["compare_c4_dist"] = {"error": repr(e)}
+        torch.cuda.empty_cache()
+        try:
+            extra["gather_c5_dist"] = bench_gather_dist(torch, np, dev, be, parallel, synth_gather_device, world, rank,
+                                                        use_dist, barrier, max_over_ranks)
+        except Exception as e:
+            extra["gather_c5_dist"] = {"error": repr(e)}
+        torch.cuda.empty_cache()
 
+    # ---- single-GPU secondary metrics (N = 1): config C3 and the kernels behind C4 / C5 one by one ----
+    if rank == 0 and world == 1 and not args.no_compare:
+        try:
+            single_gpu_extras(extra, torch, np, dev, be, smd, synth_sketches, synth_gather, synth_gather_device, timed)
+        except Exception as e:
+            extra["error"] = repr(e)
+
+    out = None
+    if rank == 0:
         out = {
             "metric": "Gbase/s sketched (k=31, scaled=1000)", "value": round(value, 3), "unit": "Gbase/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -310,7 +223,8 @@ def main():
                                    "ASCII resident in HBM), k=31 scaled=1000 seed=42; kernel + radix sort + unique",
                        "bases_per_gpu": bases_per_step, "bytes_per_gpu": n_bytes, "ksize": args.ksize,
                        "scaled": args.scaled, "unique_hashes_rank0": n_unique_local,
-                       "unique_hashes_job": n_unique_total, "allgather_ms": gather_ms},
+                       "unique_hashes_job": n_unique_total, "allgather_ms": gather_ms,
+                       "collectives": "rccl" if use_dist else "none (single rank)"},
             "roofline": roofline, "cpu_baseline": cpu, "extra": extra,
         }
     if use_dist:
@@ -326,6 +240,262 @@ def main():
             pass
         sys.stdout.flush()
         print(json.dumps(out), flush=True)
+
+
+def cpu_baseline(args, seq, n_bytes, sk, np):
+    """The oracle (kind "port": a C restatement of the reference's algorithm, not the Rust crate) on this box's host
+    cores: one thread -- the analogue of single-threaded sourmash (doc/faq.md:307) -- and as many threads as the
+    container may run (affinity capped by the cgroup quota; os.cpu_count() is the machine's figure)."""
+    import oracle
+    from sourmash_amd.synth import synth_sketches, synth_gather
+    threads = oracle.usable_cpus()
+    # sketch: ~10 s per leg
+    s1 = int(min(n_bytes, 2.5e8))
+    sn = int(args.cpu_sample) if args.cpu_sample else int(min(n_bytes, 2.5e8 * threads, 4e9))
+    host = seq[:max(s1, sn)].cpu().numpy()
+    legs = {}
+    for name, nthr, size in (("threads_1", 1, s1), ("threads_n", threads, sn)):
+        tc = time.perf_counter()
+        ref = oracle.sketch_dna_bulk(host[:size], args.ksize, scaled=args.scaled, nthreads=nthr)
+        dt = time.perf_counter() - tc
+        bases = int((host[:size] != 10).sum())
+        got = sk.sketch(seq[:size]).cpu().numpy().view(np.uint64)     # parity spot check of the GPU path on the very same sample
+        legs[name] = {"threads": nthr, "Gbase_per_s": round(bases / dt / 1e9, 4),
+                      "Mbase_per_s_per_thread": round(bases / dt / 1e6 / nthr, 2), "sample_bases": bases,
+                      "seconds": round(dt, 2), "gpu_matches_oracle_on_sample": bool(np.array_equal(got, ref))}
+    per1, pern = legs["threads_1"]["Mbase_per_s_per_thread"], legs["threads_n"]["Mbase_per_s_per_thread"]
+    oversub = pern < 0.25 * per1
+    if oversub:
+        print(f"bench.py: CPU baseline is oversubscribed: {pern} Mbase/s/thread with {threads} threads vs {per1} with one; "
+              f"reporting the single-thread leg as the baseline value", file=sys.stderr)
+    best = legs["threads_1"] if oversub else legs["threads_n"]
+    cpu = {"value": best["Gbase_per_s"], "unit": "Gbase/s", "cores": best["threads"], "kind": "port",
+           "sample": f"first {best['sample_bases']} bases of the same synthetic stream, oracle.sketch_dna_bulk "
+                     f"(OpenMP, contiguous slice per thread), {best['seconds']} s",
+           "cpu_model": oracle.cpu_model(), "os_cpu_count": os.cpu_count(), "usable_cpus": threads,
+           "oversubscribed": bool(oversub), "sketch": legs,
+           "gpu_matches_oracle_on_sample": all(v["gpu_matches_oracle_on_sample"] for v in legs.values()),
+           "note": "CPU restatement of the reference algorithm (the Rust crate cannot be built in this image); a "
+                   "scalar port, byte-wise canonicalisation + MurmurHash3 per k-mer like signature.rs:246-306"}
+    # compare: config C3 (1,000 x 1,000), the reference's loop (every pair, two-pointer walk)
+    sk3 = synth_sketches(1000, seed=1234)
+    h3, o3 = oracle.make_csr(sk3)
+    pairs = 1000 * 999 // 2
+    cmp_legs = {}
+    for name, nthr in (("threads_1", 1), ("threads_n", threads)):
+        tc = time.perf_counter()
+        oracle.compare_all_pairs(h3, o3, nthreads=nthr)
+        dt = time.perf_counter() - tc
+        cmp_legs[name] = {"threads": nthr, "pairs_per_s": round(pairs / dt, 1), "seconds": round(dt, 2)}
+    cpu["compare_c3"] = {"pairs": pairs, **cmp_legs, "what": "oracle.compare_all_pairs on config C3 (minhash.rs:915-953 walk per pair)"}
+    # gather: scaled-down C5 (2e5-hash query vs 5,000 x ~1,000), the reference's loop (every dataset every round)
+    qh, dbh = synth_gather(n_query=200_000, n_db=5000, db_size=1000)
+    gh, go = oracle.make_csr(dbh)
+    tc = time.perf_counter()
+    res = oracle.gather(qh, gh, go, threshold_bp=50_000, scaled=1000, nthreads=threads)
+    dt = time.perf_counter() - tc
+    cpu["gather_200k_vs_5000"] = {"threads": threads, "rounds": len(res), "seconds": round(dt, 2),
+                                  "us_per_round": round(dt * 1e6 / max(len(res), 1), 1),
+                                  "what": "oracle.gather (CounterGather walk, index/__init__.py:856-909) on the scaled-down C5 of extra.gather_200k_vs_5000"}
+    return cpu
+
+
+def bench_compare_dist(torch, dist, np, dev, be, parallel, smd, synth_sketches, world, rank, use_dist, barrier, max_over_ranks):
+    "config C4 through parallel.compare_all_pairs_distributed: CSR replicated, 16-row tiles dealt to the ranks, ONE all-gather"
+    n = 10_000
+    if rank == 0:
+        big = synth_sketches(n, seed=1234)
+        bh, boff = smd.pack_csr(big, device=dev)
+        meta = torch.tensor([bh.numel()], dtype=torch.int64, device=dev)
+    else:
+        meta = torch.zeros(1, dtype=torch.int64, device=dev)
+    if world > 1:                                            # the collection reaches the other ranks once (replicated CSR)
+        dist.broadcast(meta, 0)
+        if rank != 0:
+            bh = torch.empty(int(meta.item()), dtype=torch.int64, device=dev)
+            boff = torch.empty(n + 1, dtype=torch.int64, device=dev)
+        dist.broadcast(bh, 0)
+        dist.broadcast(boff, 0)
+    pairs = n * (n - 1) // 2
+    timing = {}
+    parallel.compare_all_pairs_distributed(bh, boff, n, be, force_collectives=use_dist)     # warm: pool, code objects, RCCL buffers
+    be._index, be._index_key = None, None                   # the timed call builds its compare index again
+    barrier()
+    t0 = time.perf_counter()
+    full, jac = parallel.compare_all_pairs_distributed(bh, boff, n, be, force_collectives=use_dist, timing=timing)
+    barrier()
+    dt = max_over_ranks(time.perf_counter() - t0)
+    checksum = int(full.to(torch.int64).sum().item())
+    out = {"ranks": world, "pairs": pairs, "ms": round(dt * 1e3, 2), "pairs_per_s": round(pairs / dt, 1),
+           "tiles_ms_rank0": round(timing.get("tiles_ms", 0.0), 2), "allgather_ms": round(timing.get("allgather_ms", 0.0), 2),
+           "mirror_and_jaccard_ms": round(timing.get("finish_ms", 0.0), 2), "collective": "all-gather (rccl)" if use_dist else "none",
+           "exchange_bytes": int(((n + 15) // 16 + world - 1) // world * world * 16 * n * 4) if use_dist else 0,
+           "counts_checksum": checksum,
+           "note": "wall clock from the resident CSR to the symmetric u32 matrix + f64 Jaccard on every rank: cost model + "
+                   "compare-index build + owned row tiles + all-gather + mirror + Jaccard"}
+    del full, jac
+    return out
+
+
+def bench_gather_dist(torch, np, dev, be, parallel, synth_gather_device, world, rank, use_dist, barrier, max_over_ranks):
+    "config C5 through parallel.gather_distributed: the database sharded by dataset, candidate exchange per batch of rounds"
+    nq, ndb, dbsize, thr_bp = 1_000_000, 100_000, 5000, 50_000
+    lo, hi = ndb * rank // world, ndb * (rank + 1) // world
+    q, gh, goff = synth_gather_device(nq, ndb, dbsize, dev, row_lo=lo, row_hi=hi)
+    torch.cuda.synchronize()
+    best = None
+    for _ in range(2):                                      # second pass: allocator / code objects / RCCL buffers warm
+        stats = {}
+        barrier()
+        t0 = time.perf_counter()
+        res = parallel.gather_distributed(q, q.numel(), gh, goff, hi - lo, lo, thr_bp, 1000, be, force_collectives=use_dist,
+                                          stats=stats)
+        barrier()
+        best = max_over_ranks(time.perf_counter() - t0)
+    iso = [r[1] for r in res]
+    out = {"ranks": world, "datasets": ndb, "datasets_per_rank": hi - lo, "query_hashes": int(q.numel()),
+           "db_bytes_per_rank": int(gh.numel() * 8), "rounds": len(res), "total_ms": round(best * 1e3, 2),
+           "us_per_round_incl_index_build": round(best * 1e6 / max(len(res), 1), 1),
+           "exchanges": stats.get("exchanges"), "rounds_per_exchange": stats.get("rounds_per_exchange"),
+           "records_per_rank": stats.get("records_per_rank"),
+           "exchange_bytes_per_rank": (stats["records_per_rank"] * stats["record_words"] * 8) if stats else None,
+           "collective": "all-gather of candidate rows (rccl)" if use_dist else "none (native single-shard loop)",
+           "overlaps_non_increasing": bool(all(a >= b for a, b in zip(iso, iso[1:]))),
+           "first": res[:2], "last": res[-1:] if res else None,
+           "note": "wall clock of index build + every round, threshold_bp 50,000; exact parity at this size: "
+                   "tests/test_gpu_full_configs.py"}
+    return out
+
+
+def single_gpu_extras(extra, torch, np, dev, be, smd, synth_sketches, synth_gather, synth_gather_device, timed):
+    sketches = synth_sketches(1000, seed=1234)
+    h, off = smd.pack_csr(sketches, device=dev)
+    n = len(sketches)
+    pairs = n * (n - 1) // 2
+    sizes = (off[1:] - off[:-1]).cpu().numpy().astype(np.int64)
+    alg = 8 * int((sizes.sum() * (n - 1)))             # sum over pairs of 8*(n_i+n_j)
+
+    common, jac = smd.compare_rows(h, off)
+    ms_merge = timed(lambda: smd.compare_rows(h, off, common=common, jaccard=jac))
+    extra["compare_1000x1000_merge"] = {
+        "pairs_per_s": round(pairs / (ms_merge * 1e-3), 1), "ms": round(ms_merge, 3), "pairs": pairs,
+        "roofline": merge_roofline(alg, ms_merge),
+        "kernel": "compare_tile_kernel (LDS-tiled merge walk; the general path)"}
+    build_ms = 0.0
+    for _ in range(3):                                  # last build: memory pool warm
+        idx = None
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        idx = smd.BitIndex.build(h, off)
+        torch.cuda.synchronize()
+        build_ms = (time.perf_counter() - t0) * 1e3
+    if idx is not None:
+        c2, j2 = smd.compare_rows(h, off, index=idx)
+        ms_bits = timed(lambda: smd.compare_rows(h, off, common=c2, jaccard=j2, index=idx))
+        extra["compare_1000x1000_bits"] = {
+            "pairs_per_s_incl_index_build": round(pairs / ((ms_bits + build_ms) * 1e-3), 1),
+            "matrix_ms": round(ms_bits, 3), "index_build_ms": round(build_ms, 3), "universe": idx.universe,
+            "identical_to_merge": bool((c2 == common).all().item() and (j2 == jac).all().item()),
+            "kernel": "bitmatrix_kernel (hashes held by many sketches as bit columns + popcount; auto-selected)"}
+        auto_ms = 0.0
+        for _ in range(3):                              # what smgpu_compare_all_pairs does: decide, build, compare
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            ca, ja = smd.compare_rows(h, off, method="auto")
+            torch.cuda.synchronize()
+            auto_ms = (time.perf_counter() - t0) * 1e3
+        extra["compare_1000x1000_auto"] = {"ms": round(auto_ms, 3), "pairs_per_s": round(pairs / (auto_ms * 1e-3), 1),
+                                           "identical_to_merge": bool((ca == common).all().item() and (ja == jac).all().item()),
+                                           "note": "one-shot: cost model + index build + matrix + Jaccard, data resident in HBM"}
+    del idx
+    # gather: 2e5-hash query vs 5,000 x ~1,000-hash database, threshold_bp = 50 kbp
+    qh, dbh = synth_gather(n_query=200_000, n_db=5000, db_size=1000)
+    gh, goff = smd.pack_csr(dbh, device=dev)
+    gq = torch.from_numpy(qh.view(np.int64).copy()).to(dev)
+    for _ in range(2):                                  # second pass: allocator / code objects warm
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        state = be.gather_state(gq, len(qh), gh, goff, len(dbh), 0)      # invert the database against the query
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        state.begin(50, len(dbh))
+        res = state.run()                                # every round on the device
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+    extra["gather_200k_vs_5000"] = {"rounds": len(res), "index_build_ms": round((t1 - t0) * 1e3, 2),
+                                    "loop_ms": round((t2 - t1) * 1e3, 2),
+                                    "us_per_round": round((t2 - t1) * 1e6 / max(len(res), 1), 1)}
+    del state, gh, goff, gq
+    # ---- the kernels behind C4 and C5 one by one, each against its roof ----
+    big = synth_sketches(10_000, seed=1234)
+    bh, boff = smd.pack_csr(big, device=dev)
+    bn = len(big)
+    bpairs = bn * (bn - 1) // 2
+    bsizes = (boff[1:] - boff[:-1]).cpu().numpy().astype(np.int64)
+    balg = 8 * int(bsizes.sum() * (bn - 1))
+    bc, bj = smd.compare_rows(bh, boff)
+    ms_big = timed(lambda: smd.compare_rows(bh, boff, common=bc, jaccard=bj), reps=1)
+    t0 = time.perf_counter()
+    ca, ja = smd.compare_rows(bh, boff, method="auto")
+    torch.cuda.synchronize()
+    auto_big = (time.perf_counter() - t0) * 1e3
+    extra["compare_10000x10000"] = {
+        "pairs": bpairs, "merge_ms": round(ms_big, 2), "merge_pairs_per_s": round(bpairs / (ms_big * 1e-3), 1),
+        "merge_roofline": merge_roofline(balg, ms_big),
+        "auto_ms": round(auto_big, 2), "auto_pairs_per_s": round(bpairs / (auto_big * 1e-3), 1),
+        "identical": bool((ca == bc).all().item() and (ja == bj).all().item()),
+        "note": "config C4 (pool-drawn sketches: the cost model picks bit columns); auto includes the index build"}
+    del bc, bj, ca, ja, bh, boff
+    torch.cuda.empty_cache()
+    gq5, gh5, goff5 = synth_gather_device(1_000_000, 100_000, 5000, dev)
+    torch.cuda.synchronize()
+    for _ in range(2):
+        t0 = time.perf_counter()
+        st5 = be.gather_state(gq5, gq5.numel(), gh5, goff5, 100_000, 0)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        st5.begin(50, 100_000)
+        res5 = st5.run()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+    postings = int(be.lib.smgpu_gather_postings(st5._ptr))
+    db_bytes = int(gh5.numel() * 8)
+    # index build: every database hash is read once (8 B), one u32 row id is written per posting, the per-element query
+    # position (4 B) is written by pass 1 and read by pass 2
+    build_alg = db_bytes + 4 * postings + 2 * 4 * int(gh5.numel())
+    extra["gather_1M_vs_100000"] = {
+        "db_bytes": db_bytes, "postings": postings, "rounds": len(res5), "index_build_ms": round((t1 - t0) * 1e3, 2),
+        "loop_ms": round((t2 - t1) * 1e3, 2), "total_ms": round((t2 - t0) * 1e3, 2),
+        "us_per_round": round((t2 - t1) * 1e6 / max(len(res5), 1), 2),
+        "index_build_roofline": hbm_roofline(build_alg, (t1 - t0) * 1e3,
+                                             "8 B per database hash + 4 B per posting + 2 x 4 B query position per element; wall clock of smgpu_gather_new_raw"),
+        "loop_note": "a dependent chain of small kernels (latency, not bandwidth): %d rounds touch %.1f MB of postings in all"
+                     % (len(res5), postings * 4 / 1e6)}
+    # overlap pass (search / prefetch over the resident collection): |Q ∩ row| for every row
+    cnt = be.zeros((100_000,), torch.int64)
+    ms_ov = timed(lambda: be.overlaps(gq5, gq5.numel(), gh5, goff5, 100_000, cnt, 0), reps=3)
+    extra["overlaps_1M_vs_100000"] = {"ms": round(ms_ov, 3), "sketches_per_s": round(100_000 / (ms_ov * 1e-3), 1),
+                                      "roofline": hbm_roofline(db_bytes + 8 * int(gq5.numel()), ms_ov,
+                                                               "8 B per database hash + the query once; overlap_vector_kernel")}
+
+
+def hbm_roofline(alg_bytes, ms, what):
+    achieved = alg_bytes / (ms * 1e-3) / 1e9
+    return {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "frac_of_achievable": round(achieved / HBM_ACHIEVABLE_GBS, 4),
+            "algorithmic_bytes": int(alg_bytes), "ms": round(ms, 3), "traffic": None, "what": what}
+
+
+def merge_roofline(alg_bytes, ms):
+    """The merge kernel re-uses every staged hash for 16 pairs out of LDS, so HBM is the wrong roof (the collection is
+    L2 / Infinity-Cache resident and the convention figure exceeds the HBM peak).  Each merge step reads one u64 from
+    each of two LDS segments: the LDS read rate is the roof."""
+    achieved = alg_bytes / (ms * 1e-3) / 1e9
+    return {"bound": "lds", "achieved": round(achieved, 1), "peak": LDS_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / LDS_PEAK_GBS, 4), "algorithmic_bytes": int(alg_bytes), "ms": round(ms, 3),
+            "hbm_convention_frac": round(achieved / HBM_PEAK_GBS, 3),
+            "what": "8 B x (n_i + n_j) per pair = LDS bytes the walks read (SURVEY.md 8d convention); roof = aggregate LDS read "
+                    "bandwidth (~150 TB/s, MI355X_MICROARCH.md); HBM traffic is 1/16 of it by the tiling"}
 
 
 if __name__ == "__main__":

@@ -296,6 +296,10 @@ uint64_t smgpu_bitindex_universe(const SmgpuBitIndex *ptr);
 void smgpu_bitindex_stats(const SmgpuBitIndex *ptr, uint64_t *frequent_hashes, uint64_t *rare_pairs, uint32_t *threshold);
 void smgpu_bitindex_compare_raw(const SmgpuBitIndex *ptr, uint32_t rb_first, uint32_t rb_stride, uint32_t rb_count,
                                 uint32_t *d_common, void *stream);
+/* Host float helper for the containment / ANI matrices of compare (src/sourmash/compare.py:67-187): out[i] =
+ * pow(x[i], y[ny == 1 ? 0 : i]) with the host libm, i.e. the bits of the reference's per-pair Python `**`
+ * (src/sourmash/minhash.py:832-834, src/sourmash/distance_utils.py:283).  n_threads = 0: every host core. */
+void smgpu_host_pow_f64(const double *x, const double *y, uintptr_t ny, double *out, uintptr_t n, uint32_t n_threads);
 /* Host convenience: n sketch handles -> n x n matrices on the host (either may be NULL). */
 void smgpu_compare_all_pairs(const SourmashKmerMinHash *const *mhs, uintptr_t n, uint32_t *common_out,
                              double *jaccard_out);
@@ -367,10 +371,15 @@ uint64_t smgpu_counter_gather(SmgpuCounter *ptr, uint64_t threshold_hashes, uint
  * global indices index_base, index_base+1, ...).  new_raw inverts the shard against the query once (query hash ->
  * rows holding it), so a round costs |I| postings walks instead of a pass over the database.
  *   single GPU:  begin, run.
- *   sharded:     begin, then per round  pick_raw (local best, packed (count << 32) | ~index, into d_key)
- *                -> MAX all-reduce of d_key -> export_raw (stop rules; the owner writes [len, hashes...] of the
- *                winning row into d_rowbuf[0,cap), everyone else zeros) -> SUM all-reduce of d_rowbuf ->
- *                apply_raw; poll every few rounds.  Nothing in a round needs the host. */
+ *   sharded:     begin, then per exchange  topk_export_raw (this shard's k best rows as records
+ *                [key, bound, len, hashes...] of `stride` u64 words, key = (count << 32) | ~global index, bound = the
+ *                best key the shard keeps back) -> ONE all-gather of the records -> cands_load_raw on every rank
+ *                (at most 64 records in all) -> replay_raw(rounds): each round takes the best candidate, which is
+ *                the global arg-max as long as its key is not below any kept-back key (counters only decrease), and
+ *                applies it to the local postings and to the candidates' counters; rounds turn into no-ops once that
+ *                test fails (the next exchange decides) or a stop rule fired.  poll every few exchanges.  Nothing
+ *                between two polls needs the host; every rank replays the same rounds.
+ *                Replaces the per-round walk of CounterGather.peek / consume, src/sourmash/index/__init__.py:817-909. */
 typedef struct SmgpuGather SmgpuGather;
 SmgpuGather *smgpu_gather_new_raw(const uint64_t *d_query, uint64_t nq, const uint64_t *d_hashes,
                                   const uint64_t *d_offsets, uint64_t ndb, uint64_t index_base, void *stream);
@@ -379,9 +388,11 @@ uint64_t smgpu_gather_postings(const SmgpuGather *ptr);
 void smgpu_gather_counters_get(const SmgpuGather *ptr, uint64_t *counts_out, void *stream);
 void smgpu_gather_begin(SmgpuGather *ptr, uint64_t threshold_hashes, uint64_t max_rounds, void *stream);
 uint64_t smgpu_gather_run(SmgpuGather *ptr, uint64_t *out_index, uint64_t *out_isect, uint64_t cap, void *stream);
-void smgpu_gather_pick_raw(SmgpuGather *ptr, uint64_t *d_key, void *stream);
-void smgpu_gather_export_raw(SmgpuGather *ptr, const uint64_t *d_key, uint64_t *d_rowbuf, uint64_t cap, void *stream);
-void smgpu_gather_apply_raw(SmgpuGather *ptr, const uint64_t *d_rowbuf, void *stream);
+uint64_t smgpu_gather_longest_row(const SmgpuGather *ptr);   /* hashes in the shard's longest row: stride >= 3 + the longest row of any shard */
+void smgpu_gather_topk_export_raw(SmgpuGather *ptr, uint64_t *d_records, uint32_t k, uint64_t stride, void *stream);
+void smgpu_gather_cands_load_raw(SmgpuGather *ptr, const uint64_t *d_records, uint32_t n_records, uint64_t stride,
+                                 void *stream);
+void smgpu_gather_replay_raw(SmgpuGather *ptr, uint32_t rounds, void *stream);
 uint64_t smgpu_gather_poll(SmgpuGather *ptr, bool *done, void *stream);
 uint64_t smgpu_gather_results(SmgpuGather *ptr, uint64_t *out_index, uint64_t *out_isect, uint64_t cap, void *stream);
 

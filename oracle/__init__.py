@@ -83,6 +83,11 @@ def lib():
         "orc_synth_dna": (None, [vp, u64, u64, u64, u64]),
         "orc_compare_all_pairs": (None, [vp, vp, u64, vp, vp, C.c_int]),
         "orc_gather": (u64, [vp, u64, vp, vp, u64, u64, u64, vp, vp, u64]),
+        "orc_gather_mt": (u64, [vp, u64, vp, vp, u64, u64, u64, vp, vp, u64, C.c_int]),
+        "orc_contained_by": (C.c_double, [u64, u64, u64]),
+        "orc_max_containment": (C.c_double, [u64, u64, u64, u64]),
+        "orc_avg_containment": (C.c_double, [u64, u64, u64, u64]),
+        "orc_containment_to_distance_point": (C.c_double, [C.c_double, C.c_uint32]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
@@ -90,6 +95,39 @@ def lib():
         fn.argtypes = args
     _lib = L
     return L
+
+
+def usable_cpus():
+    """Threads this process can really run at once: the scheduler affinity mask, capped by the cgroup CPU quota
+    (cpu.max "quota period" on cgroup v2, cpu.cfs_quota_us / cpu.cfs_period_us on v1).  os.cpu_count() is the
+    machine's figure and oversubscribes a container that was given fewer."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = int(q) / int(p)
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and p > 0:
+                quota = q / p
+        except (OSError, ValueError):
+            pass
+    if quota is not None:
+        n = min(n, max(1, int(quota)))
+    return max(1, n)
+
+
+def cpu_model():
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def _as_bytes(s):
@@ -228,7 +266,7 @@ def compare_all_pairs(hashes, offsets, nthreads=1):
     return common, jac
 
 
-def gather(query, hashes, offsets, threshold_bp=0, scaled=1000, max_rounds=None):
+def gather(query, hashes, offsets, threshold_bp=0, scaled=1000, max_rounds=None, nthreads=1):
     query = np.ascontiguousarray(query, dtype=np.uint64)
     hashes = np.ascontiguousarray(hashes, dtype=np.uint64)
     offsets = np.ascontiguousarray(offsets, dtype=np.uint64)
@@ -237,9 +275,27 @@ def gather(query, hashes, offsets, threshold_bp=0, scaled=1000, max_rounds=None)
         max_rounds = ndb
     idx = np.zeros(max(max_rounds, 1), dtype=np.uint64)
     isz = np.zeros(max(max_rounds, 1), dtype=np.uint64)
-    r = lib().orc_gather(_ptr(query), query.size, _ptr(hashes), _ptr(offsets), ndb, threshold_bp,
-                         scaled, _ptr(idx), _ptr(isz), max_rounds)
+    r = lib().orc_gather_mt(_ptr(query), query.size, _ptr(hashes), _ptr(offsets), ndb, threshold_bp,
+                            scaled, _ptr(idx), _ptr(isz), max_rounds, nthreads)
     return [(int(idx[i]), int(isz[i])) for i in range(r)]
+
+
+def contained_by(common, denom, scaled):
+    "minhash.py:819-841 on counts: |A ∩ B| / (|A| * bias(|A|, scaled)), clamped"
+    return float(lib().orc_contained_by(int(common), int(denom), int(scaled)))
+
+
+def max_containment(common, n_self, n_other, scaled):
+    return float(lib().orc_max_containment(int(common), int(n_self), int(n_other), int(scaled)))
+
+
+def avg_containment(common, n_self, n_other, scaled):
+    return float(lib().orc_avg_containment(int(common), int(n_self), int(n_other), int(scaled)))
+
+
+def containment_to_distance_point(containment, ksize):
+    "distance_utils.py:276-283: the point estimate of containment_to_distance"
+    return float(lib().orc_containment_to_distance_point(float(containment), int(ksize)))
 
 
 # --------------------------------------------------------------------------- #

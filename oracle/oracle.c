@@ -440,16 +440,39 @@ ORC_API uint32_t orc_mh_merge(orc_mh *a, const orc_mh *b) {
  * (intersection_size): returns common, writes union size. */
 ORC_API uint64_t orc_intersection_size(const uint64_t *a, uint64_t na, const uint64_t *b,
                                        uint64_t nb, uint64_t *union_size) {
+    /* the same walk without data-dependent branches (a[i] < b[j]: ++i; b[j] < a[i]: ++j; equal: both and ++common) --
+     * the full-size parity runs of tests/test_gpu_full_configs.py take 10^12 of these steps */
     uint64_t i = 0, j = 0, common = 0, uni = 0;
     while (i < na && j < nb) {
-        if (a[i] < b[j]) ++i;
-        else if (b[j] < a[i]) ++j;
-        else { ++i; ++j; ++common; }
+        const uint64_t x = a[i], y = b[j];
+        common += (x == y);
+        i += (x <= y);
+        j += (y <= x);
         ++uni;
     }
     uni += (na - i) + (nb - j);
     if (union_size) *union_size = uni;
     return common;
+}
+
+/* Four of the walks above at once, one list `a` against four lists b[0..3]: the same steps in the same order for
+ * every pair, interleaved only so that an out-of-order core overlaps the four load->compare->advance chains (the
+ * full-size parity runs take 10^12 steps).  common[t] = |a ∩ b[t]|. */
+static void intersection_size_x4(const uint64_t *a, uint64_t na, const uint64_t *const b[4], const uint64_t nb[4],
+                                 uint64_t common[4]) {
+    uint64_t i0 = 0, i1 = 0, i2 = 0, i3 = 0, j0 = 0, j1 = 0, j2 = 0, j3 = 0, c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+    const uint64_t *b0 = b[0], *b1 = b[1], *b2 = b[2], *b3 = b[3];
+    while (i0 < na && j0 < nb[0] && i1 < na && j1 < nb[1] && i2 < na && j2 < nb[2] && i3 < na && j3 < nb[3]) {
+        const uint64_t x0 = a[i0], y0 = b0[j0], x1 = a[i1], y1 = b1[j1], x2 = a[i2], y2 = b2[j2], x3 = a[i3], y3 = b3[j3];
+        c0 += (x0 == y0); i0 += (x0 <= y0); j0 += (y0 <= x0);
+        c1 += (x1 == y1); i1 += (x1 <= y1); j1 += (y1 <= x1);
+        c2 += (x2 == y2); i2 += (x2 <= y2); j2 += (y2 <= x2);
+        c3 += (x3 == y3); i3 += (x3 <= y3); j3 += (y3 <= x3);
+    }
+    common[0] = c0 + orc_intersection_size(a + i0, na - i0, b0 + j0, nb[0] - j0, NULL);
+    common[1] = c1 + orc_intersection_size(a + i1, na - i1, b1 + j1, nb[1] - j1, NULL);
+    common[2] = c2 + orc_intersection_size(a + i2, na - i2, b2 + j2, nb[2] - j2, NULL);
+    common[3] = c3 + orc_intersection_size(a + i3, na - i3, b3 + j3, nb[3] - j3, NULL);
 }
 
 /* intersection list, minhash.rs:1721-1763 */
@@ -767,7 +790,22 @@ ORC_API void orc_compare_all_pairs(const uint64_t *hashes, const uint64_t *offse
         uint64_t ni = offsets[i + 1] - offsets[i];
         if (common) common[i * n + i] = (uint32_t)ni;
         if (jaccard) jaccard[i * n + i] = 1.0;               /* compare.py:33 np.ones */
-        for (uint64_t j = i + 1; j < n; ++j) {
+        uint64_t j = i + 1;
+        for (; j + 4 <= n; j += 4) {                          /* four columns at a time (see intersection_size_x4) */
+            const uint64_t *b[4]; uint64_t nb[4], c4[4];
+            for (int t = 0; t < 4; ++t) { b[t] = hashes + offsets[j + t]; nb[t] = offsets[j + t + 1] - offsets[j + t]; }
+            intersection_size_x4(hashes + offsets[i], ni, b, nb, c4);
+            for (int t = 0; t < 4; ++t) {
+                /* the walk's union count is every step + both tails = ni + nj - common (sorted unique lists) */
+                uint64_t c = c4[t], uni = ni + nb[t] - c;
+                if (common) { common[i * n + j + t] = (uint32_t)c; common[(j + t) * n + i] = (uint32_t)c; }
+                if (jaccard) {
+                    double s = (double)c / (double)(uni > 1 ? uni : 1);
+                    jaccard[i * n + j + t] = s; jaccard[(j + t) * n + i] = s;
+                }
+            }
+        }
+        for (; j < n; ++j) {
             uint64_t nj = offsets[j + 1] - offsets[j], uni = 0;
             uint64_t c = orc_intersection_size(hashes + offsets[i], ni, hashes + offsets[j], nj, &uni);
             if (common) { common[i * n + j] = (uint32_t)c; common[j * n + i] = (uint32_t)c; }
@@ -792,18 +830,34 @@ ORC_API void orc_compare_all_pairs(const uint64_t *hashes, const uint64_t *offse
 /* Inputs: sorted query, CSR db (all at the query's scaled), threshold_bp.    */
 /* Outputs: per round the dataset index and |intersect|.  Returns rounds.    */
 /* ------------------------------------------------------------------------ */
-ORC_API uint64_t orc_gather(const uint64_t *query, uint64_t nq, const uint64_t *hashes,
-                            const uint64_t *offsets, uint64_t ndb, uint64_t threshold_bp,
-                            uint64_t scaled, uint64_t *out_idx, uint64_t *out_isect,
-                            uint64_t max_rounds) {
+ORC_API uint64_t orc_gather_mt(const uint64_t *query, uint64_t nq, const uint64_t *hashes,
+                               const uint64_t *offsets, uint64_t ndb, uint64_t threshold_bp,
+                               uint64_t scaled, uint64_t *out_idx, uint64_t *out_isect,
+                               uint64_t max_rounds, int nthreads) {
+    /* nthreads > 1: the two loops over the datasets (prefetch, consume) and the arg-max run on OpenMP threads.  Every
+     * dataset's update is independent and the arg-max keeps the reference's rule (largest counter, first-inserted =
+     * lowest index on ties), so the result does not depend on the thread count. */
+    if (nthreads < 1) nthreads = 1;
     uint64_t *q = (uint64_t *)malloc((nq ? nq : 1) * 8);
     memcpy(q, query, nq * 8);
     uint64_t *counter = (uint64_t *)malloc((ndb ? ndb : 1) * 8);
     uint64_t *isect = (uint64_t *)malloc((nq ? nq : 1) * 8);
     /* prefetch: overlap of every dataset with the original query; datasets with
      * zero overlap never enter the counter (index/__init__.py:783-789). */
-    for (uint64_t d = 0; d < ndb; ++d)
-        counter[d] = orc_intersection_size(q, nq, hashes + offsets[d], offsets[d + 1] - offsets[d], NULL);
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(nthreads) schedule(static)
+#endif
+    for (uint64_t g = 0; g < (ndb + 3) / 4; ++g) {
+        const uint64_t d0 = g * 4;
+        if (d0 + 4 <= ndb) {
+            const uint64_t *b[4]; uint64_t nb[4];
+            for (int t = 0; t < 4; ++t) { b[t] = hashes + offsets[d0 + t]; nb[t] = offsets[d0 + t + 1] - offsets[d0 + t]; }
+            intersection_size_x4(q, nq, b, nb, counter + d0);
+        } else {
+            for (uint64_t d = d0; d < ndb; ++d)
+                counter[d] = orc_intersection_size(q, nq, hashes + offsets[d], offsets[d + 1] - offsets[d], NULL);
+        }
+    }
     uint64_t rounds = 0;
     while (rounds < max_rounds) {
         if (nq == 0) break;                                   /* search.py:879-880; index/__init__.py:838-839 */
@@ -814,8 +868,21 @@ ORC_API uint64_t orc_gather(const uint64_t *query, uint64_t nq, const uint64_t *
             if (n_threshold_hashes / (double)nq > 1.0) break; /* unattainable -> [] */
         }
         uint64_t best = 0, best_d = 0;
-        for (uint64_t d = 0; d < ndb; ++d)
-            if (counter[d] > best) { best = counter[d]; best_d = d; }   /* strict > : first-inserted wins ties */
+#ifdef _OPENMP
+#pragma omp parallel num_threads(nthreads)
+#endif
+        {
+            uint64_t my_best = 0, my_d = 0;
+#ifdef _OPENMP
+#pragma omp for schedule(static) nowait
+#endif
+            for (uint64_t d = 0; d < ndb; ++d)
+                if (counter[d] > my_best) { my_best = counter[d]; my_d = d; }   /* strict > : first-inserted wins ties */
+#ifdef _OPENMP
+#pragma omp critical
+#endif
+            if (my_best > best || (my_best == best && my_best != 0 && my_d < best_d)) { best = my_best; best_d = my_d; }
+        }
         if (best == 0) break;                                           /* empty counter */
         if ((double)best < n_threshold_hashes) break;                   /* index/__init__.py:860-861 */
         const uint64_t *m = hashes + offsets[best_d];
@@ -824,10 +891,23 @@ ORC_API uint64_t orc_gather(const uint64_t *query, uint64_t nq, const uint64_t *
         out_idx[rounds] = best_d; out_isect[rounds] = ni;
         ++rounds;
         /* consume (:897-909): every live counter -= |intersect ∩ D_d|; zero -> deleted */
-        for (uint64_t d = 0; d < ndb; ++d) {
-            if (counter[d] == 0) continue;
-            uint64_t c = orc_intersection_size(isect, ni, hashes + offsets[d], offsets[d + 1] - offsets[d], NULL);
-            counter[d] = c >= counter[d] ? 0 : counter[d] - c;
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(nthreads) schedule(static)
+#endif
+        for (uint64_t g = 0; g < (ndb + 3) / 4; ++g) {
+            const uint64_t d0 = g * 4;
+            if (d0 + 4 <= ndb && counter[d0] && counter[d0 + 1] && counter[d0 + 2] && counter[d0 + 3]) {
+                const uint64_t *b[4]; uint64_t nb[4], c4[4];
+                for (int t = 0; t < 4; ++t) { b[t] = hashes + offsets[d0 + t]; nb[t] = offsets[d0 + t + 1] - offsets[d0 + t]; }
+                intersection_size_x4(isect, ni, b, nb, c4);
+                for (int t = 0; t < 4; ++t) counter[d0 + t] = c4[t] >= counter[d0 + t] ? 0 : counter[d0 + t] - c4[t];
+                continue;
+            }
+            for (uint64_t d = d0; d < d0 + 4 && d < ndb; ++d) {
+                if (counter[d] == 0) continue;
+                uint64_t c = orc_intersection_size(isect, ni, hashes + offsets[d], offsets[d + 1] - offsets[d], NULL);
+                counter[d] = c >= counter[d] ? 0 : counter[d] - c;
+            }
         }
         /* query <- query minus the whole match sketch (search.py:915-919) */
         uint64_t i = 0, j = 0, w = 0;
@@ -840,4 +920,49 @@ ORC_API uint64_t orc_gather(const uint64_t *query, uint64_t nq, const uint64_t *
     }
     free(q); free(counter); free(isect);
     return rounds;
+}
+
+ORC_API uint64_t orc_gather(const uint64_t *query, uint64_t nq, const uint64_t *hashes,
+                            const uint64_t *offsets, uint64_t ndb, uint64_t threshold_bp,
+                            uint64_t scaled, uint64_t *out_idx, uint64_t *out_isect,
+                            uint64_t max_rounds) {
+    return orc_gather_mt(query, nq, hashes, offsets, ndb, threshold_bp, scaled, out_idx, out_isect, max_rounds, 1);
+}
+
+/* ------------------------------------------------------------------------ */
+/* Host float layer of the containment family (test infrastructure like the  */
+/* rest of this file): scalar restatements, one pair at a time, using this   */
+/* libm's pow() -- the function CPython's float `**` ends in.                */
+/* ------------------------------------------------------------------------ */
+
+/* src/sourmash/minhash.py:819-841 MinHash.contained_by: count_common / (denom * bias_factor) with
+ * bias_factor = 1 - (1 - 1/scaled)^(denom * scaled), clamped to [0, 1]; 0.0 for an empty self. */
+ORC_API double orc_contained_by(uint64_t common, uint64_t denom, uint64_t scaled) {
+    if (denom == 0) return 0.0;
+    double total_denom = (double)(denom * scaled);
+    double bias_factor = 1.0 - pow(1.0 - 1.0 / (double)scaled, total_denom);
+    double containment = (double)common / ((double)denom * bias_factor);
+    if (containment >= 1.0) return 1.0;
+    if (containment <= 0.0) return 0.0;
+    return containment;
+}
+
+/* src/sourmash/minhash.py:881-905 MinHash.max_containment: the same with denom = min(|self|, |other|) */
+ORC_API double orc_max_containment(uint64_t common, uint64_t n_self, uint64_t n_other, uint64_t scaled) {
+    return orc_contained_by(common, n_self < n_other ? n_self : n_other, scaled);
+}
+
+/* src/sourmash/minhash.py:946-959 MinHash.avg_containment: mean of the two directed containments */
+ORC_API double orc_avg_containment(uint64_t common, uint64_t n_self, uint64_t n_other, uint64_t scaled) {
+    double c1 = orc_contained_by(common, n_self, scaled), c2 = orc_contained_by(common, n_other, scaled);
+    return (c1 + c2) / 2;
+}
+
+/* src/sourmash/distance_utils.py:276-283 containment_to_distance, point estimate only:
+ * 1.0 for containment 0, 0.0 for containment 1, else 1 - containment^(1/ksize).
+ * ANI = 1 - distance (distance_utils.py ANIResult.ani). */
+ORC_API double orc_containment_to_distance_point(double containment, uint32_t ksize) {
+    if (containment == 0.0) return 1.0;
+    if (containment == 1.0) return 0.0;
+    return 1.0 - pow(containment, 1.0 / (double)ksize);
 }

@@ -11,6 +11,7 @@
 #include <fstream>
 #include <memory>
 #include <sstream>
+#include <thread>
 #include "../../include/sourmash_amd.h"
 #include "collection.hpp"
 #include "device_ctx.hpp"
@@ -575,6 +576,27 @@ void nodegraph_buffer_free(uint8_t* ptr, uintptr_t) { free(ptr); }
 // =============================================================================================
 // PART 2: batch extensions
 // =============================================================================================
+// host float helper of the compare layer: out[i] = pow(x[i], y[ny == 1 ? 0 : i]) with this process's libm -- the
+// function CPython's float ** ends in (floatobject.c float_pow), which is what the reference's containment / ANI
+// formulas evaluate (minhash.py:832-834, distance_utils.py:283).  No device involved; threads split the array.
+void smgpu_host_pow_f64(const double* x, const double* y, uintptr_t ny, double* out, uintptr_t n, uint32_t n_threads) {
+    landing_void([&] {
+        if (n == 0) return;
+        if (!x || !y || !out) throw err_internal("null pointer");
+        size_t t = n_threads ? n_threads : std::thread::hardware_concurrency();
+        if (t > 64) t = 64;
+        if (t < 1 || n < 65536) t = 1;
+        auto work = [&](size_t lo, size_t hi) {
+            if (ny == 1) { const double e = y[0]; for (size_t i = lo; i < hi; ++i) out[i] = std::pow(x[i], e); }
+            else for (size_t i = lo; i < hi; ++i) out[i] = std::pow(x[i], y[i]);
+        };
+        if (t == 1) { work(0, n); return; }
+        std::vector<std::thread> pool;
+        for (size_t k = 0; k < t; ++k) pool.emplace_back(work, n * k / t, n * (k + 1) / t);
+        for (auto& th : pool) th.join();
+    });
+}
+
 int32_t smgpu_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
@@ -897,12 +919,23 @@ struct GatherRaw {
     ~GatherRaw() { gather_destroy(g); }
 };
 
-// run the armed loop to exhaustion; -> number of results (host copies if out_* given)
+// run the armed loop to exhaustion; -> number of results (host copies if out_* given).
+// Two device loops with identical results: "scan" picks the arg-max over all counters every round; "replay" selects the
+// 16 best rows once per 16 rounds and replays the rounds among those candidates (the multi-GPU protocol with one shard).
+static bool gather_use_replay() {
+    static const int mode = [] {
+        const char* e = getenv("SMG_GATHER_LOOP");
+        return e && !strcmp(e, "scan") ? 0 : (e && !strcmp(e, "replay") ? 1 : -1);
+    }();
+    return mode != 0;                                               // default: replay
+}
 static uint64_t gather_drain(GatherDev& g, uint64_t* out_idx, uint64_t* out_isect, uint64_t cap, hipStream_t st) {
     unsigned long long head[GS_SLOTS];
+    const bool replay = gather_use_replay() && g.ndb > 0 && g.nq > 0;
     unsigned batch = 32;
     for (;;) {
-        hip_check(gather_enqueue_rounds(g, batch, st), "gather rounds");
+        if (replay) hip_check(gather_enqueue_replay(g, (batch + GATHER_TOPK_MAX - 1) / GATHER_TOPK_MAX, st), "gather rounds");
+        else hip_check(gather_enqueue_rounds(g, batch, st), "gather rounds");
         hip_check(hipMemcpyAsync(head, g.state, sizeof(head), hipMemcpyDeviceToHost, st), "D2H");
         hip_check(hipStreamSynchronize(st), "sync");
         if (head[GS_DONE]) break;
@@ -1254,19 +1287,22 @@ uint64_t smgpu_gather_run(SmgpuGather* p, uint64_t* out_index, uint64_t* out_ise
         return gather_drain(reinterpret_cast<GatherRaw*>(p)->g, out_index, out_isect, cap, (hipStream_t)stream);
     });
 }
-void smgpu_gather_pick_raw(SmgpuGather* p, uint64_t* d_key, void* stream) {
+uint64_t smgpu_gather_longest_row(const SmgpuGather* p) { return reinterpret_cast<const GatherRaw*>(p)->g.longest_row; }
+void smgpu_gather_topk_export_raw(SmgpuGather* p, uint64_t* d_records, uint32_t k, uint64_t stride, void* stream) {
     landing_void([&] {
-        hip_check(gather_pick(reinterpret_cast<GatherRaw*>(p)->g, (unsigned long long*)d_key, 0, (hipStream_t)stream), "pick");
+        hip_check(gather_topk_export(reinterpret_cast<GatherRaw*>(p)->g, d_records, k, stride, (hipStream_t)stream), "top-k export");
     });
 }
-void smgpu_gather_export_raw(SmgpuGather* p, const uint64_t* d_key, uint64_t* d_rowbuf, uint64_t cap, void* stream) {
+void smgpu_gather_cands_load_raw(SmgpuGather* p, const uint64_t* d_records, uint32_t n_records, uint64_t stride, void* stream) {
     landing_void([&] {
-        hip_check(gather_export(reinterpret_cast<GatherRaw*>(p)->g, (const unsigned long long*)d_key, d_rowbuf, cap,
-                                (hipStream_t)stream), "export");
+        hip_check(gather_cands_load(reinterpret_cast<GatherRaw*>(p)->g, d_records, n_records, stride, (hipStream_t)stream),
+                  "candidate load");
     });
 }
-void smgpu_gather_apply_raw(SmgpuGather* p, const uint64_t* d_rowbuf, void* stream) {
-    landing_void([&] { hip_check(gather_apply(reinterpret_cast<GatherRaw*>(p)->g, d_rowbuf, (hipStream_t)stream), "apply"); });
+void smgpu_gather_replay_raw(SmgpuGather* p, uint32_t rounds, void* stream) {
+    landing_void([&] {
+        hip_check(gather_replay_rounds(reinterpret_cast<GatherRaw*>(p)->g, rounds, (hipStream_t)stream), "replay");
+    });
 }
 uint64_t smgpu_gather_poll(SmgpuGather* p, bool* done, void* stream) {
     return landing<uint64_t>([&]() -> uint64_t {

@@ -13,9 +13,12 @@
 // bookkeeping in its last workgroup, apply); the host enqueues rounds in batches and only looks at a done flag,
 // so there is no host round trip per round.  Every kernel is a no-op once the flag is set.
 //
-// Multi-GPU (database sharded by dataset, query replicated): the same kernels, with the 8-byte packed winner
-// all-reduced (MAX) between pick and export, and the winner's row all-reduced (SUM of zeros + one copy) between
-// export and apply -- see sourmash_amd/parallel.py.
+// Multi-GPU (database sharded by dataset, query replicated): rounds are replayed from exchanged candidates.  Every
+// shard exports its K best rows (packed key, hashes) plus the best key it keeps back; ONE all-gather hands all of
+// them to every rank, which inverts them against the query as well (one bit per candidate and query hash, cmask) so
+// that apply keeps the candidates' counters as exact as the local ones.  The winner of a round is then the best
+// candidate -- provably the global arg-max while its key is not below any kept-back key (counters only decrease) --
+// and rounds run back to back with no exchange until that test fails.  See sourmash_amd/parallel.py.
 #include <hip/hip_runtime.h>
 #include <cstring>
 #include <stdlib.h>
@@ -314,27 +317,201 @@ __global__ __launch_bounds__(256) void pick_kernel(const unsigned long long* __r
     }
 }
 
-__global__ void adopt_key_kernel(unsigned long long* state, const unsigned long long* key) {
-    if (state[GS_DONE]) return;
-    state[GS_KEY] = *key;
-    stop_rules(state, *key);
+// ---- candidate replay ---------------------------------------------------------------------------------------------
+// Top-K selection: every thread keeps the sorted list of its TOPK_LIST best keys, a wave merges its 64 lists by
+// TOPK_LIST rounds of wave-max (the lane that owned the maximum shifts its list), wave 0 merges the 4 wave lists the
+// same way; the last workgroup to finish (ticket) merges the per-workgroup lists.  Keys are distinct (the index is
+// part of the key), zeros are "nothing".
+constexpr int TOPK_LIST = (int)GATHER_TOPK_MAX + 1;
+
+__device__ __forceinline__ void topk_insert(unsigned long long (&best)[TOPK_LIST], unsigned long long key) {
+    if (key <= best[TOPK_LIST - 1]) return;
+    best[TOPK_LIST - 1] = key;
+#pragma unroll
+    for (int i = TOPK_LIST - 1; i > 0; --i) {
+        const unsigned long long a = best[i - 1], b = best[i];
+        best[i - 1] = a > b ? a : b;
+        best[i] = a > b ? b : a;
+    }
 }
 
-__global__ __launch_bounds__(256) void export_row_kernel(const unsigned long long* state,
-                                                         const uint64_t* __restrict__ hashes,
-                                                         const uint64_t* __restrict__ offsets, uint64_t ndb,
-                                                         uint64_t index_base, uint64_t* __restrict__ rowbuf, uint64_t cap) {
-    if (state[GS_DONE]) return;
-    const uint64_t gidx = 0xffffffffull & ~state[GS_KEY];
-    const bool mine = gidx >= index_base && gidx < index_base + ndb;
-    uint64_t lo = 0, len = 0;
-    if (mine) {
-        lo = offsets[gidx - index_base];
-        len = offsets[gidx - index_base + 1] - lo;
-        if (len + 1 > cap) len = cap - 1;                      // cannot happen when cap covers the longest row
+// all lanes of the wave get the wave's `want` best keys in out[] (descending); best[] is consumed
+__device__ __forceinline__ void topk_wave_merge(unsigned long long (&best)[TOPK_LIST], int want,
+                                                unsigned long long (&out)[TOPK_LIST]) {
+#pragma unroll
+    for (int it = 0; it < TOPK_LIST; ++it) {
+        unsigned long long m = 0;
+        if (it < want) {
+            m = best[0];
+            for (int off = 32; off > 0; off >>= 1) {
+                const unsigned long long o = __shfl_xor(m, off);
+                m = o > m ? o : m;
+            }
+            if (m != 0 && best[0] == m) {
+#pragma unroll
+                for (int i = 0; i + 1 < TOPK_LIST; ++i) best[i] = best[i + 1];
+                best[TOPK_LIST - 1] = 0;
+            }
+        }
+        out[it] = m;
     }
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cap; i += (uint64_t)gridDim.x * blockDim.x)
-        rowbuf[i] = i == 0 ? len : (i <= len ? hashes[lo + i - 1] : 0);
+}
+
+// workgroup-wide: thread lists -> s_list[0][0..want) (valid after the call for every thread)
+__device__ __forceinline__ void topk_block_merge(unsigned long long (&best)[TOPK_LIST], int want,
+                                                 unsigned long long (*s_list)[TOPK_LIST]) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    unsigned long long out[TOPK_LIST];
+    topk_wave_merge(best, want, out);
+    if (lane == 0) {
+#pragma unroll
+        for (int i = 0; i < TOPK_LIST; ++i) s_list[wave][i] = out[i];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int i = 0; i < TOPK_LIST; ++i) best[i] = lane < 4 ? s_list[lane][i] : 0ull;
+        topk_wave_merge(best, want, out);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int i = 0; i < TOPK_LIST; ++i) s_list[0][i] = out[i];
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void topk_kernel(const unsigned long long* __restrict__ counters, uint64_t ndb,
+                                                   uint64_t index_base, unsigned long long* state,
+                                                   unsigned long long* partials, unsigned long long* sel, int want) {
+    __shared__ unsigned long long s_list[4][TOPK_LIST];
+    __shared__ int s_last;
+    if (state[GS_DONE]) return;
+    unsigned long long best[TOPK_LIST];
+#pragma unroll
+    for (int i = 0; i < TOPK_LIST; ++i) best[i] = 0;
+    for (uint64_t d = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; d < ndb; d += (uint64_t)gridDim.x * blockDim.x) {
+        const unsigned long long c = counters[d];
+        if (c) topk_insert(best, (c << 32) | (0xffffffffull & ~(unsigned long long)(index_base + d)));
+    }
+    topk_block_merge(best, want, s_list);
+    if (threadIdx.x < TOPK_LIST)
+        __hip_atomic_store(&partials[(uint64_t)blockIdx.x * TOPK_LIST + threadIdx.x], s_list[0][threadIdx.x],
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();                                            // the partial list is visible before the ticket is
+        s_last = atomicAdd(&state[GS_TICKET], 1ull) == (unsigned long long)gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    if (threadIdx.x == 0) state[GS_TICKET] = 0;
+#pragma unroll
+    for (int i = 0; i < TOPK_LIST; ++i)                             // thread t adopts workgroup t's (sorted) list
+        best[i] = threadIdx.x < gridDim.x
+                      ? __hip_atomic_load(&partials[(uint64_t)threadIdx.x * TOPK_LIST + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                      : 0ull;
+    topk_block_merge(best, want, s_list);
+    if (threadIdx.x < TOPK_LIST) sel[threadIdx.x] = threadIdx.x < want ? s_list[0][threadIdx.x] : 0ull;
+}
+
+// records [key, bound, len, hashes...] of the K selected rows; bound = sel[K] (the best key kept back)
+__global__ __launch_bounds__(256) void export_cands_kernel(const unsigned long long* state,
+                                                           const unsigned long long* __restrict__ sel, uint32_t K,
+                                                           const uint64_t* __restrict__ hashes,
+                                                           const uint64_t* __restrict__ offsets, uint64_t ndb,
+                                                           uint64_t index_base, uint64_t* __restrict__ out, uint64_t stride) {
+    const uint32_t c = blockIdx.y;
+    uint64_t* rec = out + (uint64_t)c * stride;
+    const unsigned long long key = state[GS_DONE] ? 0ull : sel[c];
+    uint64_t lo = 0, len = 0;
+    if (key) {
+        const uint64_t d = (0xffffffffull & ~key) - index_base;
+        lo = offsets[d];
+        len = offsets[d + 1] - lo;
+        if (len + GATHER_CAND_HEAD > stride) len = stride - GATHER_CAND_HEAD;   // cannot happen when stride covers the longest row
+    }
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < len + GATHER_CAND_HEAD;
+         i += (uint64_t)gridDim.x * blockDim.x)
+        rec[i] = i == 0 ? key : i == 1 ? (state[GS_DONE] ? 0ull : sel[K]) : i == 2 ? len : hashes[lo + i - GATHER_CAND_HEAD];
+}
+
+// take the bits of the previous exchange's candidates out of cmask (one workgroup per candidate)
+__global__ __launch_bounds__(256) void cands_clear_kernel(uint64_t* __restrict__ cmask, const uint32_t* __restrict__ cand_len,
+                                                          const uint32_t* __restrict__ cand_qpos, uint64_t qstride) {
+    const uint32_t c = blockIdx.x, len = cand_len[c];
+    const uint32_t* pos = cand_qpos + (uint64_t)c * qstride;
+    for (uint32_t i = threadIdx.x; i < len; i += blockDim.x) {
+        const uint32_t j = pos[i];
+        if (j != NONE32) cmask[j] = 0;
+    }
+}
+
+// adopt the gathered records: query positions of candidate c's hashes, bit c in cmask for the uncovered ones, counters
+// from the keys, the largest kept-back key; re-arms the replay (GS_NEEDX = 0)
+__global__ __launch_bounds__(256) void cands_load_kernel(QIndex qi, const uint8_t* __restrict__ alive,
+                                                         const uint64_t* __restrict__ cands, uint32_t n_cand, uint64_t stride,
+                                                         uint64_t* cmask, unsigned long long* __restrict__ cand_count,
+                                                         unsigned long long* __restrict__ cand_key,
+                                                         uint32_t* __restrict__ cand_len, uint32_t* __restrict__ cand_qpos,
+                                                         uint64_t qstride, unsigned long long* state) {
+    const uint32_t c = blockIdx.x;
+    const uint64_t* rec = cands + (uint64_t)c * stride;
+    const unsigned long long key = rec[0];
+    const uint32_t len = key ? (uint32_t)rec[2] : 0u;
+    if (threadIdx.x == 0) {
+        cand_key[c] = key;
+        cand_count[c] = key >> 32;
+        cand_len[c] = len;
+        if (c == 0) {
+            unsigned long long bound = 0;
+            for (uint32_t k = 0; k < n_cand; ++k) {
+                const uint64_t* r = cands + (uint64_t)k * stride;
+                if (r[0] && r[1] > bound) bound = r[1];
+            }
+            state[GS_BOUND] = bound;
+            state[GS_NEEDX] = 0;
+        }
+    }
+    uint32_t* pos = cand_qpos + (uint64_t)c * qstride;
+    for (uint32_t i = threadIdx.x; i < len; i += blockDim.x) {
+        const uint32_t j = q_find(qi, rec[GATHER_CAND_HEAD + i]);
+        pos[i] = j;
+        if (j != NONE32 && alive[j]) atomicOr((unsigned long long*)&cmask[j], 1ull << c);
+    }
+}
+
+// one wave: bookkeeping of the previous round, then the best candidate.  It is the global arg-max as long as its key
+// is not below the largest key any shard kept back: rows outside the candidate set had smaller keys at the exchange
+// and keys only decrease.  Otherwise the round is left to the next exchange (GS_NEEDX).
+__global__ __launch_bounds__(64) void replay_pick_kernel(const unsigned long long* __restrict__ cand_count,
+                                                         const unsigned long long* __restrict__ cand_key, uint32_t n_cand,
+                                                         unsigned long long* state, uint64_t* out_idx, uint64_t* out_isect) {
+    if (state[GS_DONE]) return;
+    const int lane = threadIdx.x;
+    if (lane == 0) record_pending(state, out_idx, out_isect);
+    __syncthreads();
+    if (state[GS_DONE] || state[GS_NEEDX]) return;
+    unsigned long long key = 0;
+    if ((uint32_t)lane < n_cand) {
+        const unsigned long long cnt = cand_count[lane];
+        if (cnt && cand_key[lane]) key = (cnt << 32) | (0xffffffffull & cand_key[lane]);
+    }
+    unsigned long long best = key;
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long o = __shfl_xor(best, off);
+        best = o > best ? o : best;
+    }
+    const unsigned long long who = __ballot(key == best && key != 0);
+    if (lane == 0) {
+        if (best < state[GS_BOUND]) {
+            state[GS_NEEDX] = 1;
+        } else {
+            state[GS_KEY] = best;
+            state[GS_WSLOT] = who ? (unsigned long long)__ffsll((long long)who) - 1ull : 0ull;
+            stop_rules(state, best);
+        }
+    }
 }
 
 // A wave takes APPLY_EPW hashes of the row: one lane each looks its hash up in the query; the postings of the
@@ -345,6 +522,17 @@ __global__ __launch_bounds__(256) void export_row_kernel(const unsigned long lon
 // waves, 29 us with 2 on 4096).
 constexpr int APPLY_EPW = 2;
 
+// The replay form (cands != nullptr) reads the winner from its candidate record, whose query positions cands_load
+// left in cand_qpos, and keeps the candidates' counters exact through cmask.
+struct CandView {
+    const uint64_t* cands;          // records [key, bound, len, hashes...]; null: not a replay round
+    uint64_t stride;
+    const uint32_t* qpos;           // [n_cand][qstride]
+    uint64_t qstride;
+    const uint64_t* cmask;
+    unsigned long long* count;
+};
+
 template <bool GATE>
 __global__ __launch_bounds__(256) void apply_kernel(QIndex qi, uint8_t* alive, const uint64_t* __restrict__ post_off,
                                                     const uint32_t* __restrict__ post_rows,
@@ -352,12 +540,18 @@ __global__ __launch_bounds__(256) void apply_kernel(QIndex qi, uint8_t* alive, c
                                                     const uint64_t* __restrict__ rowbuf,
                                                     const uint64_t* __restrict__ hashes,
                                                     const uint64_t* __restrict__ offsets, uint64_t index_base,
-                                                    const uint32_t* __restrict__ qpos) {
-    if (GATE && state[GS_DONE]) return;
+                                                    const uint32_t* __restrict__ qpos, CandView cv) {
+    if (GATE && (state[GS_DONE] || state[GS_NEEDX])) return;
     const uint64_t* row;
-    const uint32_t* row_pos = nullptr;                              // query positions of the row, when it is a local one
+    const uint32_t* row_pos = nullptr;                              // query positions of the row, when they are known
     uint64_t len;
-    if (rowbuf) {
+    if (cv.cands) {
+        const uint64_t slot = state[GS_WSLOT];
+        const uint64_t* rec = cv.cands + slot * cv.stride;
+        len = rec[2];
+        row = rec + GATHER_CAND_HEAD;
+        row_pos = cv.qpos + slot * cv.qstride;
+    } else if (rowbuf) {
         len = rowbuf[0];
         row = rowbuf + 1;
     } else {
@@ -379,6 +573,13 @@ __global__ __launch_bounds__(256) void apply_kernel(QIndex qi, uint8_t* alive, c
                 // whatever the caller hands to consume (the same intersect twice, hashes it never peeked)
                 if (alive[j]) alive[j] = 0;                    // row hashes are distinct: no two lanes share j
                 else j = NONE32;
+            }
+            if (j != NONE32 && cv.cands) {                     // the candidates holding this hash lose it too
+                uint64_t m = cv.cmask[j];
+                while (m) {
+                    atomicAdd(&cv.count[__ffsll((long long)m) - 1], ~0ull);
+                    m &= m - 1;
+                }
             }
         }
         const unsigned long long hits = __ballot(j != NONE32);
@@ -443,6 +644,17 @@ __global__ __launch_bounds__(256) void apply_kernel(QIndex qi, uint8_t* alive, c
     }
 }
 
+__global__ __launch_bounds__(256) void longest_row_kernel(const uint64_t* __restrict__ offsets, uint64_t ndb,
+                                                         unsigned long long* out) {
+    unsigned long long m = 0;
+    for (uint64_t d = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; d < ndb; d += (uint64_t)gridDim.x * blockDim.x) {
+        const unsigned long long l = offsets[d + 1] - offsets[d];
+        m = l > m ? l : m;
+    }
+    m = wave_max(m);
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
+
 unsigned blocks_for_rows(uint64_t ndb) {
     const uint64_t b = (ndb + 3) / 4;
     return (unsigned)(b < 1 ? 1 : (b > 16384 ? 16384 : b));
@@ -459,7 +671,8 @@ static QIndex qindex_of(const GatherDev& g) { return QIndex{g.q_padded, g.nq, g.
     } while (0)
 
 void gather_destroy(GatherDev& g) {
-    void* owned[] = {g.q_padded, g.q_table, g.alive, g.post_off, g.post_rows, g.qpos, g.counters, g.state, g.partials, g.out_idx, g.out_isect};
+    void* owned[] = {g.q_padded, g.q_table, g.alive, g.post_off, g.post_rows, g.qpos, g.counters, g.state, g.partials, g.out_idx, g.out_isect,
+                     g.topk_sel, g.topk_partials, g.cmask, g.cand_count, g.cand_key, g.cand_len, g.cand_qpos, g.own_cands};
     for (void* p : owned)
         if (p) (void)hipFree(p);
     g = GatherDev();
@@ -482,6 +695,13 @@ hipError_t gather_build(GatherDev& g, hipStream_t stream) {
     uint64_t total = 0;
     g.q_max = 0;
     if (g.ndb) SMG_TRY(hipMemcpyAsync(&total, g.offsets + g.ndb, 8, hipMemcpyDeviceToHost, stream));
+    g.longest_row = 0;
+    if (g.ndb) {                                                  // state[GS_KEY] as scratch: zeroed above, zeroed again by begin
+        hipLaunchKernelGGL(longest_row_kernel, dim3(blocks_for_rows(g.ndb) > 256 ? 256 : blocks_for_rows(g.ndb)), dim3(256), 0,
+                           stream, g.offsets, g.ndb, &g.state[GS_KEY]);
+        SMG_TRY(hipMemcpyAsync(&g.longest_row, &g.state[GS_KEY], 8, hipMemcpyDeviceToHost, stream));
+        SMG_TRY(hipMemsetAsync(&g.state[GS_KEY], 0, 8, stream));
+    }
     if (g.nq) SMG_TRY(hipMemcpyAsync(&g.q_max, g.Q + g.nq - 1, 8, hipMemcpyDeviceToHost, stream));
     SMG_TRY(hipStreamSynchronize(stream));
     SMG_TRY(hipMalloc(&g.q_padded, (g.nq + 4) * 8));
@@ -607,32 +827,112 @@ hipError_t gather_pick(GatherDev& g, unsigned long long* d_key_out, int check_st
     return hipGetLastError();
 }
 
-hipError_t gather_export(GatherDev& g, const unsigned long long* d_key, uint64_t* d_rowbuf, uint64_t cap,
-                         hipStream_t stream) {
-    if (cap == 0) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(adopt_key_kernel, dim3(1), dim3(1), 0, stream, g.state, d_key);
-    const uint64_t b = (cap + 255) / 256;
-    hipLaunchKernelGGL(export_row_kernel, dim3((unsigned)(b > 1024 ? 1024 : b)), dim3(256), 0, stream, g.state, g.hashes,
-                       g.offsets, g.ndb, g.index_base, d_rowbuf, cap);
-    return hipGetLastError();
-}
+static CandView no_cands() { return CandView{nullptr, 0, nullptr, 0, nullptr, nullptr}; }
 
-hipError_t gather_apply(GatherDev& g, const uint64_t* d_rowbuf, hipStream_t stream) {
+hipError_t gather_apply(GatherDev& g, hipStream_t stream) {
     hipLaunchKernelGGL(apply_kernel<true>, dim3(1024), dim3(256), 0, stream, qindex_of(g), g.alive, g.post_off,
-                       g.post_rows, g.counters, g.state, d_rowbuf, g.hashes, g.offsets, g.index_base, g.qpos);
+                       g.post_rows, g.counters, g.state, (const uint64_t*)nullptr, g.hashes, g.offsets, g.index_base, g.qpos,
+                       no_cands());
     return hipGetLastError();
 }
 
 hipError_t gather_consume_list(GatherDev& g, const uint64_t* d_list, hipStream_t stream) {
     hipLaunchKernelGGL(apply_kernel<false>, dim3(128), dim3(256), 0, stream, qindex_of(g), g.alive, g.post_off,
-                       g.post_rows, g.counters, g.state, d_list, g.hashes, g.offsets, g.index_base, g.qpos);
+                       g.post_rows, g.counters, g.state, d_list, g.hashes, g.offsets, g.index_base, g.qpos, no_cands());
     return hipGetLastError();
 }
 
 hipError_t gather_enqueue_rounds(GatherDev& g, unsigned rounds, hipStream_t stream) {
     for (unsigned r = 0; r < rounds; ++r) {
         SMG_TRY(gather_pick(g, nullptr, 1, stream));
-        SMG_TRY(gather_apply(g, nullptr, stream));
+        SMG_TRY(gather_apply(g, stream));
+    }
+    return hipSuccess;
+}
+
+// ---- candidate replay --------------------------------------------------------------------------------------------
+static hipError_t replay_buffers(GatherDev& g, hipStream_t stream) {
+    if (g.cmask) return hipSuccess;
+    SMG_TRY(hipMalloc(&g.topk_sel, (GATHER_TOPK_MAX + 1) * 8));
+    SMG_TRY(hipMalloc(&g.topk_partials, (size_t)GATHER_PICK_BLOCKS * (GATHER_TOPK_MAX + 1) * 8));
+    SMG_TRY(hipMalloc(&g.cmask, (g.nq + 1) * 8));
+    SMG_TRY(hipMalloc(&g.cand_count, GATHER_CAND_MAX * 8));
+    SMG_TRY(hipMalloc(&g.cand_key, GATHER_CAND_MAX * 8));
+    SMG_TRY(hipMalloc(&g.cand_len, GATHER_CAND_MAX * 4));
+    SMG_TRY(hipMemsetAsync(g.cmask, 0, (g.nq + 1) * 8, stream));
+    SMG_TRY(hipMemsetAsync(g.cand_count, 0, GATHER_CAND_MAX * 8, stream));
+    SMG_TRY(hipMemsetAsync(g.cand_key, 0, GATHER_CAND_MAX * 8, stream));
+    SMG_TRY(hipMemsetAsync(g.cand_len, 0, GATHER_CAND_MAX * 4, stream));
+    return hipSuccess;
+}
+
+hipError_t gather_topk_export(GatherDev& g, uint64_t* d_out, uint32_t K, uint64_t stride, hipStream_t stream) {
+    if (K == 0 || K > GATHER_TOPK_MAX || stride < GATHER_CAND_HEAD + 1) return hipErrorInvalidValue;
+    SMG_TRY(replay_buffers(g, stream));
+    const uint64_t want = (g.ndb + 1023) / 1024;
+    const unsigned n_part = (unsigned)(want < 1 ? 1 : (want > GATHER_PICK_BLOCKS ? GATHER_PICK_BLOCKS : want));
+    hipLaunchKernelGGL(topk_kernel, dim3(n_part), dim3(256), 0, stream, g.counters, g.ndb, g.index_base, g.state,
+                       g.topk_partials, g.topk_sel, (int)K + 1);
+    const uint64_t per_row = (stride + 255) / 256;
+    hipLaunchKernelGGL(export_cands_kernel, dim3((unsigned)(per_row > 64 ? 64 : per_row), K), dim3(256), 0, stream, g.state,
+                       g.topk_sel, K, g.hashes, g.offsets, g.ndb, g.index_base, d_out, stride);
+    return hipGetLastError();
+}
+
+hipError_t gather_cands_load(GatherDev& g, const uint64_t* d_cands, uint32_t n_cand, uint64_t stride, hipStream_t stream) {
+    if (n_cand == 0 || n_cand > GATHER_CAND_MAX || stride < GATHER_CAND_HEAD + 1) return hipErrorInvalidValue;
+    SMG_TRY(replay_buffers(g, stream));
+    if (g.cand_qstride < stride) {                               // first load, or longer records than before
+        if (g.cand_qpos) {
+            SMG_TRY(hipStreamSynchronize(stream));
+            // the old positions are about to go: clear their bits now
+            hipLaunchKernelGGL(cands_clear_kernel, dim3(GATHER_CAND_MAX), dim3(256), 0, stream, g.cmask, g.cand_len, g.cand_qpos,
+                               g.cand_qstride);
+            SMG_TRY(hipMemsetAsync(g.cand_len, 0, GATHER_CAND_MAX * 4, stream));
+            SMG_TRY(hipStreamSynchronize(stream));
+            (void)hipFree(g.cand_qpos);
+            g.cand_qpos = nullptr;
+        }
+        SMG_TRY(hipMalloc(&g.cand_qpos, (size_t)GATHER_CAND_MAX * stride * 4));
+        g.cand_qstride = stride;
+    }
+    hipLaunchKernelGGL(cands_clear_kernel, dim3(GATHER_CAND_MAX), dim3(256), 0, stream, g.cmask, g.cand_len, g.cand_qpos,
+                       g.cand_qstride);
+    if (n_cand < GATHER_CAND_MAX)                                // slots beyond this exchange hold nothing
+        SMG_TRY(hipMemsetAsync(g.cand_len + n_cand, 0, (GATHER_CAND_MAX - n_cand) * 4, stream));
+    hipLaunchKernelGGL(cands_load_kernel, dim3(n_cand), dim3(256), 0, stream, qindex_of(g), g.alive, d_cands, n_cand, stride,
+                       g.cmask, g.cand_count, g.cand_key, g.cand_len, g.cand_qpos, g.cand_qstride, g.state);
+    g.cands = d_cands;
+    g.cand_stride = stride;
+    g.n_cand = n_cand;
+    return hipGetLastError();
+}
+
+hipError_t gather_replay_rounds(GatherDev& g, unsigned rounds, hipStream_t stream) {
+    if (!g.cands) return hipErrorInvalidValue;
+    const CandView cv{g.cands, g.cand_stride, g.cand_qpos, g.cand_qstride, g.cmask, g.cand_count};
+    for (unsigned r = 0; r < rounds; ++r) {
+        hipLaunchKernelGGL(replay_pick_kernel, dim3(1), dim3(64), 0, stream, g.cand_count, g.cand_key, g.n_cand, g.state,
+                           g.out_idx, g.out_isect);
+        hipLaunchKernelGGL(apply_kernel<true>, dim3(1024), dim3(256), 0, stream, qindex_of(g), g.alive, g.post_off,
+                           g.post_rows, g.counters, g.state, (const uint64_t*)nullptr, g.hashes, g.offsets, g.index_base,
+                           g.qpos, cv);
+    }
+    return hipGetLastError();
+}
+
+hipError_t gather_enqueue_replay(GatherDev& g, unsigned exchanges, hipStream_t stream) {
+    // single shard: the K + 1 best rows by key are exactly the next candidates, so K rounds per exchange can succeed
+    const uint32_t K = GATHER_TOPK_MAX;
+    if (!g.own_cands) {
+        g.own_cands_words = (GATHER_CAND_HEAD + (g.longest_row ? g.longest_row : 1)) * K;
+        SMG_TRY(hipMalloc(&g.own_cands, g.own_cands_words * 8));
+    }
+    const uint64_t stride = g.own_cands_words / K;
+    for (unsigned x = 0; x < exchanges; ++x) {
+        SMG_TRY(gather_topk_export(g, g.own_cands, K, stride, stream));
+        SMG_TRY(gather_cands_load(g, g.own_cands, K, stride, stream));
+        SMG_TRY(gather_replay_rounds(g, K, stream));
     }
     return hipSuccess;
 }

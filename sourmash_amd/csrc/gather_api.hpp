@@ -16,7 +16,10 @@ enum GatherSlot {
     GS_PENDING = 5,  // a round was applied and is not recorded yet
     GS_THR = 6,      // minimum overlap in hashes (ceil(threshold_bp / scaled))
     GS_MAXR = 7,     // maximum number of results
-    GS_TICKET = 8,   // workgroups of the running pick kernel that have delivered their partial arg-max
+    GS_TICKET = 8,   // workgroups of the running pick / top-K kernel that have delivered their partial result
+    GS_NEEDX = 9,    // replay: the best candidate fell below what a rank kept back -> the next exchange decides
+    GS_WSLOT = 10,   // replay: candidate slot of the round's winner
+    GS_BOUND = 11,   // replay: largest key any rank kept back at the last exchange (0: nothing kept back)
     GS_SLOTS = 16
 };
 
@@ -38,15 +41,33 @@ struct GatherDev {
     uint32_t* qpos = nullptr;           // [database elements] position in Q of every element of the shard (NONE32: not in Q):
                                         // a round applied from the local CSR skips the lookup (two dependent loads)
     uint64_t npairs = 0;
+    uint64_t longest_row = 0;           // hashes in the shard's longest row (sizes the candidate records)
     unsigned long long* counters = nullptr;   // [ndb] |row_d ∩ uncovered query|
     unsigned long long* state = nullptr;      // [GS_SLOTS]
     unsigned long long* partials = nullptr;   // [GATHER_PICK_BLOCKS]
     uint64_t* out_idx = nullptr;        // [out_cap] global index of the round's winner
     uint64_t* out_isect = nullptr;      // [out_cap] |I| of the round
     uint64_t out_cap = 0;
+    // candidate replay (see gather_topk_export): allocated on first use
+    unsigned long long* topk_sel = nullptr;       // [GATHER_TOPK_MAX + 1] best local keys, descending; the last one is kept back
+    unsigned long long* topk_partials = nullptr;  // [GATHER_PICK_BLOCKS][GATHER_TOPK_MAX + 1]
+    uint64_t* cmask = nullptr;          // [nq] bit c set: candidate c of the current exchange holds query hash j
+    unsigned long long* cand_count = nullptr;     // [64] |candidate row ∩ uncovered query|, kept exact by apply
+    unsigned long long* cand_key = nullptr;       // [64] key the candidate was exported with (its global index)
+    uint32_t* cand_len = nullptr;       // [64] row lengths of the loaded candidates (to take their bits out again)
+    uint32_t* cand_qpos = nullptr;      // [64][cand_qstride] query positions of the candidates' hashes
+    uint64_t cand_qstride = 0;
+    const uint64_t* cands = nullptr;    // borrowed: the gathered candidate records of the current exchange
+    uint64_t cand_stride = 0;           // u64 words per record: [key, bound, len, hashes...]
+    uint32_t n_cand = 0;
+    uint64_t* own_cands = nullptr;      // single-GPU loop: this shard's own export buffer
+    uint64_t own_cands_words = 0;
 };
 
 constexpr unsigned GATHER_PICK_BLOCKS = 256;
+constexpr unsigned GATHER_TOPK_MAX = 16;     // candidates a rank can export per exchange
+constexpr unsigned GATHER_CAND_MAX = 64;     // candidates of all ranks together (one bit each in cmask)
+constexpr unsigned GATHER_CAND_HEAD = 3;     // record header words: key, bound, len
 
 // Build the inverted index and the initial counters (one-off; synchronises the stream once to size the postings).
 hipError_t gather_build(GatherDev& g, hipStream_t stream);
@@ -56,13 +77,21 @@ hipError_t gather_begin(GatherDev& g, uint64_t thr_hashes, uint64_t max_rounds, 
 // Record the previous round (if one is pending), then the local best -> state[GS_KEY] and *d_key_out (may be null).
 // check_stop != 0: also evaluate the stop rules on that key (single-GPU loop).
 hipError_t gather_pick(GatherDev& g, unsigned long long* d_key_out, int check_stop, hipStream_t stream);
-// Multi-GPU: adopt the all-reduced key, evaluate the stop rules, and let the owner write [len, hashes...] of the
-// winning row into d_rowbuf[0, cap) (zeros elsewhere; every other rank writes zeros only).
-hipError_t gather_export(GatherDev& g, const unsigned long long* d_key, uint64_t* d_rowbuf, uint64_t cap,
-                         hipStream_t stream);
 // Apply the round: I = row ∩ uncovered query; uncovered -= I; counters[d] -= |I ∩ row_d| through the postings.
-// d_rowbuf == nullptr: the winner of state[GS_KEY] is read from the local CSR.
-hipError_t gather_apply(GatherDev& g, const uint64_t* d_rowbuf, hipStream_t stream);
+// The winner of state[GS_KEY] is read from the local CSR.
+hipError_t gather_apply(GatherDev& g, hipStream_t stream);
+// ---- candidate replay: several rounds per exchange (sharded databases; also the single-GPU loop) ----
+// The K best local rows (by the packed key) as records [key, bound, len, hashes...] of `stride` u64 words into
+// d_out[K][stride]; `bound` = the best key this shard keeps back (0: none).  stride >= 3 + longest row.
+hipError_t gather_topk_export(GatherDev& g, uint64_t* d_out, uint32_t K, uint64_t stride, hipStream_t stream);
+// Adopt the gathered records of all shards (n_cand <= 64, same stride; borrowed until the next load): their hashes'
+// query positions become bits in cmask, their counters start from the exported keys.
+hipError_t gather_cands_load(GatherDev& g, const uint64_t* d_cands, uint32_t n_cand, uint64_t stride, hipStream_t stream);
+// `rounds` rounds of: winner among the candidates (valid while it beats every kept-back key; stop rules) + apply to
+// the local postings and to the candidates' counters.  No-ops once a stop rule fired or an exchange is needed.
+hipError_t gather_replay_rounds(GatherDev& g, unsigned rounds, hipStream_t stream);
+// single-GPU loop built from the three calls above (export into an own buffer, no collective)
+hipError_t gather_enqueue_replay(GatherDev& g, unsigned exchanges, hipStream_t stream);
 // CounterGather.consume for a caller-provided list ([len, hashes...] on device, every hash a member of Q):
 // counters[d] -= |list ∩ row_d| (saturating at 0), and the hashes leave the uncovered set.
 hipError_t gather_consume_list(GatherDev& g, const uint64_t* d_list, hipStream_t stream);

@@ -8,13 +8,17 @@ Only the two places where the path has a real exchange use a collective (SURVEY.
       u32 count matrix (u32 instead of f64 halves the bytes on the per-link-bound xGMI ring), then every
       rank mirrors the triangle and converts to f64 Jaccard locally.
 
-  gather (BASELINE config C5)   the database is sharded by dataset; query, counters and the min-set-cover
-      loop are replicated.  Per round: local arg-max packed as (count << 32) | ~global_index, ONE u64
-      MAX all-reduce (this also implements the reference's tie-break: highest count, then lowest index),
-      the owner's copy of the winning sketch reaches everyone through a SUM all-reduce (zeros elsewhere, a
-      few thousand u64), every rank intersects it with its copy of the uncovered query and walks its own
-      postings to update its counters.  The stop test is deterministic and replicated; no step of a round
-      needs the host, which only polls a done flag every few rounds.
+  gather (BASELINE config C5)   the database is sharded by dataset; the query, its uncovered set and the
+      min-set-cover loop are replicated.  Rounds are replayed from exchanged candidates: every rank exports its K
+      best rows -- key (count << 32) | ~global_index (the reference's order: highest count, then lowest index),
+      hashes, and the best key it keeps back -- ONE all-gather hands the W x K records to everyone, every rank
+      inverts them against the query next to its own shard, and then rounds run back to back with no exchange: the
+      best candidate is the global arg-max as long as its key is not below any kept-back key (counters only
+      decrease), its row is already on every rank, and applying it updates the local counters through the shard's
+      postings and the candidates' counters through their bit masks.  When the test fails the remaining rounds of the
+      batch are no-ops and the next exchange decides.  The stop test is deterministic and replicated; nothing between
+      two polls of the done flag needs the host.  (The per-round form -- an 8-byte MAX all-reduce plus a row
+      broadcast each round -- would spend two collectives where a single-GPU round takes 25 us.)
 
 The numerical work is behind a small `backend` interface.  DeviceBackend (the product) drives the HIP
 kernels through the raw C-ABI on torch CUDA tensors.  The distributed control flow itself is
@@ -25,6 +29,9 @@ import ctypes as C
 import math
 
 TILE = 16   # rows per compare tile (csrc/compare.hip CT)
+TOPK_MAX = 16    # candidates a rank can export per exchange (csrc/gather_api.hpp GATHER_TOPK_MAX)
+CAND_MAX = 64    # candidates of all ranks together (GATHER_CAND_MAX: one mask bit each)
+CAND_HEAD = 3    # record header: key, bound, len
 
 
 def _dist():
@@ -90,15 +97,20 @@ class _DeviceGatherState:
         self._cap = max(int(max_rounds), 1)
         self.rustcall(self.lib.smgpu_gather_begin, self._ptr, int(threshold_hashes), self._cap, self.b._s())
 
-    def pick(self, key):
-        self.rustcall(self.lib.smgpu_gather_pick_raw, self._ptr, self.b._p(key), self.b._s())
+    def longest_row(self):
+        return int(self.lib.smgpu_gather_longest_row(self._ptr))
 
-    def export(self, key, rowbuf):
-        self.rustcall(self.lib.smgpu_gather_export_raw, self._ptr, self.b._p(key), self.b._p(rowbuf), rowbuf.numel(),
-                      self.b._s())
+    def export_topk(self, records, k):
+        "this shard's k best rows as records [key, bound, len, hashes...] into records[k][stride]"
+        self.rustcall(self.lib.smgpu_gather_topk_export_raw, self._ptr, self.b._p(records), int(k), records.shape[1], self.b._s())
 
-    def apply(self, rowbuf):
-        self.rustcall(self.lib.smgpu_gather_apply_raw, self._ptr, self.b._p(rowbuf), self.b._s())
+    def load_candidates(self, records, n):
+        "adopt the gathered records of every shard (borrowed until the next load)"
+        self._cands = records
+        self.rustcall(self.lib.smgpu_gather_cands_load_raw, self._ptr, self.b._p(records), int(n), records.shape[1], self.b._s())
+
+    def replay(self, rounds):
+        self.rustcall(self.lib.smgpu_gather_replay_raw, self._ptr, int(rounds), self.b._s())
 
     def poll(self):
         done = C.c_bool(False)
@@ -212,15 +224,27 @@ class DeviceBackend:
 
 
 # ---------------------------------------------------------------------------------------------------
-def compare_all_pairs_distributed(hashes, offsets, n, backend, group=None, want_jaccard=True):
+def compare_all_pairs_distributed(hashes, offsets, n, backend, group=None, want_jaccard=True, force_collectives=False,
+                                  timing=None):
     """N x N common-hash matrix (int32 bit patterns of u32) and f64 Jaccard on every rank.
-    hashes / offsets: the full CSR, replicated on every rank."""
+    hashes / offsets: the full CSR, replicated on every rank.
+    timing (dict, optional; CUDA tensors only): receives tiles_ms / allgather_ms / finish_ms from stream events."""
     dist = _dist()
     rank, world = world_info(group)
+    marks = []
+
+    def mark():
+        if timing is not None and hashes.is_cuda:
+            ev = backend.torch.cuda.Event(enable_timing=True)
+            ev.record()
+            marks.append(ev)
+
+    mark()
     first, stride, count = tiles_for_rank(n, world, rank)
     local = backend.compare_tiles(hashes, offsets, n, first, stride, count)
+    mark()
     n_tiles = (n + TILE - 1) // TILE
-    if world == 1:
+    if world == 1 and not force_collectives:
         full = local[:n]
     else:
         max_count = (n_tiles + world - 1) // world
@@ -231,8 +255,14 @@ def compare_all_pairs_distributed(hashes, offsets, n, backend, group=None, want_
         pieces = [backend.empty((max_count * TILE, n), local.dtype) for _ in range(world)]
         dist.all_gather(pieces, local, group=group)               # the ONE collective of the compare path
         full = assemble_tiles(pieces, n, world, backend)
+    mark()
     backend.symmetrize(full, n)
     jac = backend.jaccard(full, offsets, n) if want_jaccard else None
+    mark()
+    if marks:
+        backend.torch.cuda.synchronize()
+        timing.update(tiles_ms=marks[0].elapsed_time(marks[1]), allgather_ms=marks[1].elapsed_time(marks[2]),
+                      finish_ms=marks[2].elapsed_time(marks[3]))
     return full, jac
 
 
@@ -259,53 +289,73 @@ def unpack_key(key):
     return key >> 32, 0xFFFFFFFF & ~key
 
 
+def exchange_geometry(world):
+    "-> (K records per rank, replay rounds per exchange)"
+    k = max(1, min(TOPK_MAX, CAND_MAX // max(world, 1)))
+    # one shard: exactly its K best can win before the kept-back key interferes; W shards: the global order interleaves
+    # the shards' lists, and the batch ends when the best shard's K are used up -- about K + (W - 1) K / 2 rounds
+    rounds = min(k + (world - 1) * k // 2, world * k)
+    return k, max(rounds, 1)
+
+
 def gather_distributed(query, nq, shard_hashes, shard_offsets, n_shard, index_base, threshold_bp, scaled, backend,
-                       group=None, max_rounds=None, stepwise=False):
+                       group=None, max_rounds=None, stepwise=False, force_collectives=False, stats=None):
     """Min-set-cover gather over a dataset-sharded database.
 
     query: sorted u64 hashes (int64 bit patterns) replicated on every rank; shard_*: this rank's CSR of
     n_shard sketches whose global indices start at index_base.  Returns [(global index, |intersect|)],
     identical on every rank and identical to the single-process result (ties -> lowest global index).
 
-    Every rank inverts its shard against the query once (backend.gather_state).  A round is then
-        pick    local best, packed (count << 32) | ~index          -> MAX all-reduce (8 bytes)
-        export  stop rules; the owner writes [len, hashes...]      -> SUM all-reduce (one row; zeros elsewhere)
-        apply   I = row ∩ uncovered query; counters -= postings(I)
-    all of it enqueued without a host round trip; the host polls a done flag every few rounds (rounds enqueued
-    past the end are no-ops on every rank alike).  One rank without `stepwise` runs the fused native loop."""
+    Every rank inverts its shard against the query once (backend.gather_state).  Then, per exchange:
+        export   the K best local rows as records [key, bound, len, hashes...]      -> ONE all-gather
+        load     every rank adopts all W x K records (their counters stay exact from here on)
+        replay   R rounds: best candidate (valid while >= every kept-back key; stop rules), apply
+    all of it enqueued without a host round trip; the host polls a done flag every few exchanges.  One rank
+    without `stepwise` runs the fused native loop (the same kernels, the exchange being a no-op).
+    stats (dict, optional): receives exchanges / rounds_per_exchange / records_per_rank / record_words."""
     dist = _dist()
     rank, world = world_info(group)
     torch = backend.torch if hasattr(backend, "torch") else __import__("torch")
     state = backend.gather_state(query, nq, shard_hashes, shard_offsets, n_shard, index_base)
     # search.py:15-37: the float threshold threshold_bp / scaled, compared with integer counts -> its ceiling
     thr = math.ceil(float(threshold_bp) / scaled) if threshold_bp else 0
-    host_off = shard_offsets.cpu()
-    longest = int((host_off[1:] - host_off[:-1]).max().item()) if n_shard else 0
+    collect = world > 1 or force_collectives
     layout_max = backend.zeros((1,), torch.int64)
     layout_sum = backend.zeros((1,), torch.int64)
-    layout_max[0], layout_sum[0] = longest, n_shard
-    if world > 1:                                          # one-off: longest row anywhere, number of datasets
+    layout_max[0], layout_sum[0] = state.longest_row(), n_shard
+    if collect:                                            # one-off: longest row anywhere, number of datasets
         dist.all_reduce(layout_max, op=dist.ReduceOp.MAX, group=group)
         dist.all_reduce(layout_sum, op=dist.ReduceOp.SUM, group=group)
     total = int(layout_sum.item())
-    cap = 1 + max(int(layout_max.item()), 1)
+    stride = CAND_HEAD + max(int(layout_max.item()), 1)
     state.begin(thr, min(max_rounds, total) if max_rounds is not None else total)
-    if world == 1 and not stepwise:
+    if world == 1 and not stepwise and not force_collectives:
         return state.run()
-    key = backend.zeros((1,), torch.int64)
-    rowbuf = backend.zeros((cap,), torch.int64)
-    batch = 8
+    k, rounds = exchange_geometry(world)
+    mine = backend.zeros((k, stride), torch.int64)
+    everyone = backend.zeros((world * k, stride), torch.int64) if collect else mine
+    batch, exchanges = 2, 0
     while True:
         for _ in range(batch):
-            state.pick(key)
-            if world > 1:
-                dist.all_reduce(key, op=dist.ReduceOp.MAX, group=group)        # collective 1: the winner
-            state.export(key, rowbuf)
-            if world > 1:
-                dist.all_reduce(rowbuf, op=dist.ReduceOp.SUM, group=group)     # collective 2: its hashes
-            state.apply(rowbuf)
+            state.export_topk(mine, k)
+            if collect:
+                _all_gather_rows(dist, everyone, mine, world, group)       # the ONE collective of an exchange
+            state.load_candidates(everyone, world * k)
+            state.replay(rounds)
+        exchanges += batch
         _, done = state.poll()
         if done:
             break
-        batch = min(batch * 2, 128)
+        batch = min(batch * 2, 16)
+    if stats is not None:
+        stats.update(exchanges=exchanges, rounds_per_exchange=rounds, records_per_rank=k, record_words=stride)
     return state.results()
+
+
+def _all_gather_rows(dist, out, mine, world, group):
+    "out[r * k : (r + 1) * k] = rank r's `mine`"
+    if hasattr(dist, "all_gather_into_tensor") and out.is_cuda:
+        dist.all_gather_into_tensor(out, mine, group=group)
+    else:
+        k = mine.shape[0]
+        dist.all_gather([out[r * k:(r + 1) * k] for r in range(world)], mine, group=group)

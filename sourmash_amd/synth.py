@@ -54,3 +54,48 @@ def synth_gather(n_query=1_000_000, n_db=100_000, db_size=5000, seed=777, max_ha
         priv = splitmix64((np.uint64(1) << np.uint64(62)) + (np.uint64(d) << np.uint64(33)) + np.arange(half, dtype=np.uint64) + np.uint64(seed)) % np.uint64(max_hash + 1)
         db.append(np.unique(np.concatenate([shared, priv[priv > 0]])))
     return q, db
+
+
+# ---- device-side generator of config C5 (torch tensors in HBM; no host copy of the 4 GB database) ----------------
+def _lsr(x, s):
+    return (x >> s) & ((1 << (64 - s)) - 1)
+
+
+def splitmix63(x):
+    "splitmix64 finaliser on int64 tensors (wrapping), top bit dropped -> non-negative"
+    def c(v):
+        return v - (1 << 64) if v >= (1 << 63) else v
+    x = x + c(0x9E3779B97F4A7C15)
+    x = (x ^ _lsr(x, 30)) * c(0xBF58476D1CE4E5B9)
+    x = (x ^ _lsr(x, 27)) * c(0x94D049BB133111EB)
+    x = x ^ _lsr(x, 31)
+    return _lsr(x, 1)
+
+
+def synth_gather_device(nq, ndb, dbsize, dev, seed=777, chunk=10_000, row_lo=0, row_hi=None):
+    """(query, hashes, offsets) as int64 tensors on `dev`: the construction of synth_gather with hashes drawn as
+    (splitmix64(x) >>> 1) mod m so that torch's signed int64 arithmetic can express it.  query = nq distinct hashes
+    below max_hash(scaled=1000); database row d takes half of its hashes from the query and half from a private
+    stream that depends on d only -- rows [row_lo, row_hi) of the ndb-row database are generated (a rank's shard)."""
+    import torch
+    row_hi = ndb if row_hi is None else row_hi
+    q = torch.unique(splitmix63(torch.arange(int(nq * 1.01) + 16, device=dev, dtype=torch.int64) + seed) % (MAX_HASH_1000 + 1))
+    q = q[q > 0][:nq].contiguous()
+    half = dbsize // 2
+    rows, lens = [], []
+    col = torch.arange(half, device=dev, dtype=torch.int64)
+    for lo in range(row_lo, row_hi, chunk):
+        d = torch.arange(lo, min(lo + chunk, row_hi), device=dev, dtype=torch.int64)[:, None]
+        shared = q[splitmix63((d << 32) ^ col[None, :] ^ seed) % len(q)]
+        priv = splitmix63((1 << 62) + (d << 33) + col[None, :] + seed) % MAX_HASH_1000 + 1
+        x = torch.sort(torch.cat([shared, priv], dim=1), dim=1).values
+        keep = torch.ones_like(x, dtype=torch.bool)
+        keep[:, 1:] = x[:, 1:] != x[:, :-1]
+        rows.append(x[keep])
+        lens.append(keep.sum(dim=1))
+    n_rows = row_hi - row_lo
+    hashes = torch.cat(rows) if rows else torch.zeros(2, dtype=torch.int64, device=dev)
+    offsets = torch.zeros(n_rows + 1, dtype=torch.int64, device=dev)
+    if rows:
+        offsets[1:] = torch.cumsum(torch.cat(lens), 0)
+    return q, hashes, offsets

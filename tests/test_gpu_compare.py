@@ -82,7 +82,12 @@ def test_pair_ops_vs_oracle(sm):
     inter = a & b
     want = np.intersect1d(oa.mins, ob.mins)
     assert np.array_equal(inter._mins_array(), want) and inter.scaled == a.scaled
-    assert a.contained_by(b) == pytest.approx(len(want) / len(a), rel=1e-3)
+    # the float layer against its independent restatement (oracle.contained_by follows minhash.py:819-841): same bits
+    assert a.contained_by(b) == oracle.contained_by(len(want), len(a), a.scaled)
+    assert b.contained_by(a) == oracle.contained_by(len(want), len(b), a.scaled)
+    assert a.max_containment(b) == oracle.max_containment(len(want), len(a), len(b), a.scaled)
+    assert a.avg_containment(b) == oracle.avg_containment(len(want), len(a), len(b), a.scaled)
+    assert a.containment_ani(b).dist == oracle.containment_to_distance_point(a.contained_by(b), a.ksize)
     e = sm.MinHash(0, 31, scaled=1000)
     assert a.count_common(e) == 0 and a.jaccard(e) == 0.0 and e.jaccard(e) == 0.0   # tests/test_minhash.py:115-132
     assert e.contained_by(a) == 0.0
@@ -288,3 +293,104 @@ def test_ani_matrices_golden(sm):
     for i in range(4):
         for j in range(4):
             assert cont[i][j] == (1.0 if i == j else sigs[j].contained_by(sigs[i]))
+
+
+def _sigs_from_arrays(sm, arrays, scaled=1000, ksize=31, abund=()):
+    sigs = []
+    for i, arr in enumerate(arrays):
+        mh = sm.MinHash(0, ksize, scaled=scaled, track_abundance=i in abund)
+        if i in abund:
+            mh.set_abundances({int(h): 1 + (int(h) % 7) for h in arr})
+        else:
+            mh.add_many(arr)
+        sigs.append(sm.SourmashSignature(mh, name=f"s{i}"))
+    return sigs
+
+
+def test_float_layer_matrices_bit_exact_on_c3(sm):
+    """compare.py:67-187 on config C3 (1,000 sketches): the whole-array float layer == the oracle's scalar restatement
+    of minhash.py:819-841,881-905,946-959 / distance_utils.py:276-283 for EVERY entry, and == the per-pair object API
+    on a sample of entries.  `==` on f64, not approx."""
+    import time
+    from sourmash_amd.compare import (compare_serial_containment, compare_serial_max_containment,
+                                      compare_serial_avg_containment)
+    from sourmash_amd.synth import synth_sketches
+    sk = synth_sketches(1000, seed=1234)
+    sigs = _sigs_from_arrays(sm, sk)
+    wc, _ = oracle.compare_all_pairs(*oracle.make_csr(sk), nthreads=oracle.usable_cpus())
+    sizes = [len(s) for s in sk]
+    n = len(sk)
+    t0 = time.perf_counter()
+    cont = compare_serial_containment(sigs)
+    mx = compare_serial_max_containment(sigs)
+    avg = compare_serial_avg_containment(sigs)
+    cont_ani = compare_serial_containment(sigs, return_ani=True)
+    mx_ani = compare_serial_max_containment(sigs, return_ani=True)
+    avg_ani = compare_serial_avg_containment(sigs, return_ani=True)
+    assert time.perf_counter() - t0 < 30                          # six 1000 x 1000 matrices (the per-pair loops: ~10 min)
+    trusted = [s.minhash.size_is_accurate() for s in sigs]
+    rng = np.random.default_rng(5)
+    rows = sorted(set(rng.integers(0, n, 40).tolist()) | {0, n - 4, n - 3, n - 2, n - 1})    # incl. the planted rows
+    for i in rows:
+        for j in range(n):
+            if i == j:
+                assert cont[i, j] == mx[i, j] == avg[i, j] == cont_ani[i, j] == 1.0
+                continue
+            c = int(wc[i, j])
+            w = oracle.contained_by(c, sizes[j], 1000)
+            assert cont[i, j] == w, (i, j)
+            wm = oracle.max_containment(c, sizes[j], sizes[i], 1000)
+            assert mx[i, j] == wm, (i, j)
+            assert avg[i, j] == oracle.avg_containment(c, sizes[j], sizes[i], 1000), (i, j)
+            ok = trusted[i] and trusted[j]
+            a1 = 1 - oracle.containment_to_distance_point(w, 31)
+            a2 = 1 - oracle.containment_to_distance_point(oracle.contained_by(c, sizes[i], 1000), 31)
+            assert cont_ani[i, j] == (a1 if ok else 0.0), (i, j)
+            assert mx_ani[i, j] == ((1 - oracle.containment_to_distance_point(wm, 31)) if ok else 0.0), (i, j)
+            assert avg_ani[i, j] == ((a1 + a2) / 2 if ok else 0.0), (i, j)
+    # the per-pair object API (the reference's loop bodies) on a sample
+    for i, j in zip(rng.integers(0, n, 60).tolist(), rng.integers(0, n, 60).tolist()):
+        if i == j:
+            continue
+        assert cont[i, j] == sigs[j].contained_by(sigs[i])
+        assert mx[i, j] == sigs[j].max_containment(sigs[i])
+        assert avg[i, j] == sigs[j].avg_containment(sigs[i])
+        ani = sigs[j].containment_ani(sigs[i]).ani
+        assert cont_ani[i, j] == (0.0 if ani is None else ani)
+        ani = sigs[j].max_containment_ani(sigs[i]).ani
+        assert mx_ani[i, j] == (0.0 if ani is None else ani)
+
+
+def test_mixed_scaled_and_mixed_abundance_follow_the_per_pair_rule(sm):
+    """compare.py:14-187 call similarity / contained_by(downsample=True) PER PAIR: a pair is compared at the coarser scaled
+    of THAT pair (not of the whole list), and angular similarity applies to exactly the pairs whose two sketches track
+    abundance (minhash.rs:682-702)."""
+    from sourmash_amd.compare import compare_serial, compare_serial_containment, compare_serial_max_containment
+    from sourmash_amd.synth import synth_sketches
+    sk = synth_sketches(6, seed=7, pool_size=30_000, keep_one_in=3, planted=False)
+    sigs = _sigs_from_arrays(sm, sk[:4], scaled=1000)
+    coarse = [s.minhash.downsample(scaled=2000) for s in _sigs_from_arrays(sm, sk[4:], scaled=1000)]
+    sigs += [sm.SourmashSignature(mh, name="coarse") for mh in coarse]
+    with pytest.raises(ValueError):
+        compare_serial(sigs, True, downsample=False)                 # MismatchScaled, like the reference's first mixed pair
+    j = compare_serial(sigs, True, downsample=True)
+    c = compare_serial_containment(sigs, downsample=True)
+    m = compare_serial_max_containment(sigs, downsample=True)
+    for a in range(len(sigs)):
+        for b in range(len(sigs)):
+            if a == b:
+                continue
+            assert j[a, b] == sigs[a].similarity(sigs[b], ignore_abundance=True, downsample=True)
+            assert c[a, b] == sigs[b].contained_by(sigs[a], downsample=True)
+            assert m[a, b] == sigs[b].max_containment(sigs[a], downsample=True)
+    # the (0, 1) pair is compared at scaled 1000 although the list holds scaled-2000 sketches
+    assert j[0, 1] == sigs[0].jaccard(sigs[1]) != sigs[0].minhash.downsample(scaled=2000).jaccard(sigs[1].minhash.downsample(scaled=2000))
+    # abundance: sketches 1 and 3 weighted, the others flat
+    mixed = _sigs_from_arrays(sm, sk[:5], abund=(1, 3))
+    sims = compare_serial(mixed, False)
+    for a in range(5):
+        for b in range(5):
+            if a != b:
+                assert sims[a, b] == mixed[a].similarity(mixed[b], ignore_abundance=False)
+    assert sims[1, 3] == mixed[1].minhash.angular_similarity(mixed[3].minhash) != mixed[1].jaccard(mixed[3])
+    assert np.array_equal(compare_serial(mixed, True), compare_serial(_sigs_from_arrays(sm, sk[:5]), True))

@@ -66,9 +66,9 @@ def test_gather_world1_device_loop(be):
     assert c == max(want) and g == lo + int(np.argmax(want))
 
 
-def test_gather_step_protocol_and_emulated_shards(be):
-    """The sharded round (pick -> MAX -> export -> SUM -> apply) with the real kernels: once on one state
-    (stepwise=True), once on three states sharing this GPU whose 'all-reduces' are plain torch ops."""
+def test_gather_exchange_protocol_and_emulated_shards(be):
+    """The sharded protocol (export top-K -> all-gather -> load -> replay rounds) with the real kernels: once on one
+    state (stepwise=True), once on three states sharing this GPU whose 'all-gather' is a torch.cat."""
     import torch
     from sourmash_amd import device as smd, parallel
     from sourmash_amd.synth import synth_gather
@@ -76,46 +76,78 @@ def test_gather_step_protocol_and_emulated_shards(be):
     dbh[400] = dbh[2].copy()                                     # tie across shards: lowest global index wins
     dbh[17] = np.zeros(0, dtype=np.uint64)                       # an empty sketch
     dbh[18] = np.array([5], dtype=np.uint64)                     # nothing in common with the query
+    dbh[700] = np.unique(np.concatenate(dbh[600:640]))           # a long row (sizes the records)
     q = torch.from_numpy(qh.view(np.int64).copy()).cuda()
     fh, foff = oracle.make_csr(dbh)
     h, off = smd.pack_csr(dbh)
     for thr_bp in (0, 30_000):
         want = oracle.gather(qh, fh, foff, threshold_bp=thr_bp, scaled=1000)
-        assert parallel.gather_distributed(q, len(qh), h, off, len(dbh), 0, thr_bp, 1000, be, stepwise=True) == want
+        stats = {}
+        assert parallel.gather_distributed(q, len(qh), h, off, len(dbh), 0, thr_bp, 1000, be, stepwise=True, stats=stats) == want
+        assert stats["exchanges"] * stats["rounds_per_exchange"] >= len(want)
         assert parallel.gather_distributed(q, len(qh), h, off, len(dbh), 0, thr_bp, 1000, be, max_rounds=7) == want[:7]
+        assert parallel.gather_distributed(q, len(qh), h, off, len(dbh), 0, thr_bp, 1000, be, max_rounds=7, stepwise=True) == want[:7]
     # three shards, one GPU
     bounds = [(0, 250), (250, 610), (610, 900)]
     shards = [smd.pack_csr(dbh[lo:hi]) for lo, hi in bounds]
     states = [be.gather_state(q, len(qh), sh, so, hi - lo, lo) for (sh, so), (lo, hi) in zip(shards, bounds)]
     want_counts = np.array([oracle.intersection_size(qh, d)[0] for d in dbh], dtype=np.uint64)
     assert np.array_equal(np.concatenate([s.counters() for s in states]), want_counts)
-    cap = 1 + max(len(d) for d in dbh)
-    thr_bp = 30_000
-    want = oracle.gather(qh, fh, foff, threshold_bp=thr_bp, scaled=1000)
-    for s in states:
-        s.begin(int(np.ceil(thr_bp / 1000)), len(dbh))
-    keys = [be.zeros((1,), torch.int64) for _ in states]
-    bufs = [be.zeros((cap,), torch.int64) for _ in states]
-    done = False
-    while not done:
-        for _ in range(16):
-            for s, k in zip(states, keys):
-                s.pick(k)
-            gkey = torch.stack(keys).max(dim=0).values               # the MAX all-reduce
-            for s, b in zip(states, bufs):
-                s.export(gkey, b)
-            grow = torch.stack(bufs).sum(dim=0)                      # the SUM all-reduce
-            for s in states:
-                s.apply(grow)
-        polls = [s.poll() for s in states]
-        assert len({p for p in polls}) == 1                          # replicated, deterministic state
-        done = polls[0][1]
-    for s in states:
-        assert s.results() == want
-    # the counters every shard ends with are the true remaining overlaps
-    covered = set()
-    for gidx, _ in want:
-        covered.update(int(x) for x in dbh[gidx])
-    left = np.array([x for x in qh if int(x) not in covered], dtype=np.uint64)
-    want_left = np.array([oracle.intersection_size(left, d)[0] for d in dbh], dtype=np.uint64)
-    assert np.array_equal(np.concatenate([s.counters() for s in states]), want_left)
+    assert max(s.longest_row() for s in states) == max(len(d) for d in dbh)
+    stride = parallel.CAND_HEAD + max(len(d) for d in dbh)
+    for thr_bp, k, rounds in ((30_000, 5, 9), (0, 16, 16), (30_000, 1, 3)):
+        want = oracle.gather(qh, fh, foff, threshold_bp=thr_bp, scaled=1000)
+        states = [be.gather_state(q, len(qh), sh, so, hi - lo, lo) for (sh, so), (lo, hi) in zip(shards, bounds)]
+        for s in states:
+            s.begin(int(np.ceil(thr_bp / 1000)), len(dbh))
+        recs = [be.zeros((k, stride), torch.int64) for _ in states]
+        done, exchanges = False, 0
+        while not done:
+            for _ in range(4):
+                for s, r in zip(states, recs):
+                    s.export_topk(r, k)
+                everyone = torch.cat(recs)                               # the all-gather
+                for s in states:
+                    s.load_candidates(everyone, len(states) * k)
+                    s.replay(rounds)
+                exchanges += 1
+            polls = [s.poll() for s in states]
+            assert len({p for p in polls}) == 1                          # replicated, deterministic state
+            done = polls[0][1]
+        for s in states:
+            assert s.results() == want, (thr_bp, k)
+        if k > 1:
+            assert exchanges < len(want)                                 # fewer exchanges than rounds
+        # the counters every shard ends with are the true remaining overlaps
+        covered = set()
+        for gidx, _ in want:
+            covered.update(int(x) for x in dbh[gidx])
+        left = np.array([x for x in qh if int(x) not in covered], dtype=np.uint64)
+        want_left = np.array([oracle.intersection_size(left, d)[0] for d in dbh], dtype=np.uint64)
+        assert np.array_equal(np.concatenate([s.counters() for s in states]), want_left)
+
+
+def test_gather_native_loops_agree(be, monkeypatch):
+    "smgpu_gather_run: the scan loop (arg-max over all counters every round) and the replay loop give the oracle's list"
+    import subprocess, sys, json, os
+    from conftest import ROOT
+    code = (
+        "import sys, json, numpy as np, torch; sys.path.insert(0, %r)\n"
+        "from sourmash_amd import device as smd, parallel\n"
+        "from sourmash_amd.synth import synth_gather\n"
+        "qh, dbh = synth_gather(n_query=60_000, n_db=1500, db_size=600)\n"
+        "dbh[11] = dbh[5].copy()\n"
+        "be = parallel.DeviceBackend(); h, off = smd.pack_csr(dbh)\n"
+        "q = torch.from_numpy(qh.view(np.int64).copy()).cuda()\n"
+        "print(json.dumps(parallel.gather_distributed(q, len(qh), h, off, len(dbh), 0, 20_000, 1000, be)))\n" % ROOT)
+    outs = {}
+    for mode in ("scan", "replay"):
+        env = dict(os.environ, SMG_GATHER_LOOP=mode)
+        p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        outs[mode] = [tuple(x) for x in json.loads(p.stdout.strip().splitlines()[-1])]
+    from sourmash_amd.synth import synth_gather
+    qh, dbh = synth_gather(n_query=60_000, n_db=1500, db_size=600)
+    dbh[11] = dbh[5].copy()
+    want = oracle.gather(qh, *oracle.make_csr(dbh), threshold_bp=20_000, scaled=1000, nthreads=8)
+    assert outs["scan"] == want and outs["replay"] == want

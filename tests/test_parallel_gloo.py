@@ -1,7 +1,7 @@
 """world_size-2 test of the multi-GPU drivers over gloo on CPU.
 
 sourmash_amd.parallel's distributed control flow (tile dealing, the single all-gather of the
-compare path, the per-round MAX all-reduce + broadcast of the gather path) is backend-agnostic.  The
+compare path, the candidate exchange of the gather path: one all-gather per batch of rounds) is backend-agnostic.  The
 product backend launches HIP kernels; here the test injects a CPU backend built on the ORACLE (test
 infrastructure) so the collectives and the partition logic run for real with two processes."""
 import os
@@ -78,9 +78,13 @@ class OracleGatherState:
         self.base, self.uncovered = index_base, set(int(x) for x in q)
         self.cnt = np.array([len(self.uncovered.intersection(int(x) for x in r)) for r in self.rows], dtype=np.int64)
         self.done, self.pending, self.out, self.key, self.acc = False, False, [], 0, 0
+        self.cands, self.bound, self.needx = [], 0, True
 
     def begin(self, thr, max_rounds):
         self.thr, self.maxr, self.done, self.pending, self.out = thr, max(max_rounds, 1), False, False, []
+
+    def longest_row(self):
+        return max([len(r) for r in self.rows] + [0])
 
     def _record(self):
         if self.pending:
@@ -89,41 +93,54 @@ class OracleGatherState:
             if len(self.out) >= self.maxr:
                 self.done = True
 
-    def pick(self, key):
-        self._record()
-        best = 0
-        if not self.done:
-            for d, c in enumerate(self.cnt):
+    def export_topk(self, records, k):
+        records.zero_()
+        if self.done:
+            return
+        keys = sorted((parallel.pack_key(int(c), self.base + d) for d, c in enumerate(self.cnt) if c), reverse=True)
+        bound = keys[k] if len(keys) > k else 0
+        for slot, key in enumerate(keys[:k]):
+            row = self.rows[parallel.unpack_key(key)[1] - self.base]
+            records[slot, 0], records[slot, 1], records[slot, 2] = key, bound, len(row)
+            records[slot, 3:3 + len(row)] = torch.from_numpy(row.view(np.int64).copy())
+
+    def load_candidates(self, records, n):
+        self.cands, self.bound, self.needx = [], 0, False
+        for c in range(n):
+            key = int(records[c, 0])
+            if not key:
+                self.cands.append(None)
+                continue
+            row = set(int(x) for x in records[c, 3:3 + int(records[c, 2])].numpy().view(np.uint64))
+            self.cands.append([key, key >> 32, row])
+            self.bound = max(self.bound, int(records[c, 1]))
+
+    def replay(self, rounds):
+        for _ in range(rounds):
+            if self.done:
+                return
+            self._record()
+            if self.done or self.needx:
+                continue
+            live = [((c[1] << 32) | (c[0] & 0xFFFFFFFF), c) for c in self.cands if c and c[1]]
+            best, winner = max(live, key=lambda t: t[0]) if live else (0, None)
+            if best < self.bound:
+                self.needx = True
+                continue
+            self.key = best
+            if best == 0 or not self.uncovered or len(self.uncovered) < self.thr or (best >> 32) < self.thr:
+                self.done = True
+                return
+            self.pending = True
+            isect = self.uncovered & winner[2]
+            self.acc = len(isect)
+            self.uncovered -= isect
+            for d, r in enumerate(self.rows):
+                if self.cnt[d]:
+                    self.cnt[d] -= len(isect.intersection(int(x) for x in r))
+            for c in self.cands:
                 if c:
-                    best = max(best, parallel.pack_key(int(c), self.base + d))
-        key[0] = best
-
-    def export(self, key, rowbuf):
-        if self.done:
-            return
-        self.key = int(key[0])
-        count = self.key >> 32
-        if self.key == 0 or not self.uncovered or len(self.uncovered) < self.thr or count < self.thr:
-            self.done = True
-            return
-        self.pending = True
-        rowbuf.zero_()
-        gidx = parallel.unpack_key(self.key)[1]
-        if self.base <= gidx < self.base + len(self.rows):
-            row = self.rows[gidx - self.base]
-            rowbuf[0] = len(row)
-            rowbuf[1:1 + len(row)] = torch.from_numpy(row.view(np.int64).copy())
-
-    def apply(self, rowbuf):
-        if self.done:
-            return
-        n = int(rowbuf[0])
-        isect = self.uncovered.intersection(int(x) for x in rowbuf[1:1 + n].numpy().view(np.uint64))
-        self.acc = len(isect)
-        self.uncovered -= isect
-        for d, r in enumerate(self.rows):
-            if self.cnt[d]:
-                self.cnt[d] -= len(isect.intersection(int(x) for x in r))
+                    c[1] -= len(isect & c[2])
 
     def poll(self):
         return len(self.out), self.done
@@ -132,7 +149,7 @@ class OracleGatherState:
         return list(self.out)
 
     def run(self):
-        raise AssertionError("single-rank fused loop is a device feature; the gloo tests run the step protocol")
+        raise AssertionError("single-rank fused loop is a device feature; the gloo tests run the exchange protocol")
 
 
 def _csr(sketches):

@@ -21,43 +21,11 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from sourmash_amd import parallel  # noqa: E402
 
-MAX_HASH_1000 = 18446744073709552
-
-
-def _lsr(x, s):
-    return (x >> s) & ((1 << (64 - s)) - 1)
-
-
-def splitmix63(x):
-    "splitmix64 finaliser on int64 tensors (wrapping), top bit dropped -> non-negative"
-    def c(v):
-        return v - (1 << 64) if v >= (1 << 63) else v
-    x = x + c(0x9E3779B97F4A7C15)
-    x = (x ^ _lsr(x, 30)) * c(0xBF58476D1CE4E5B9)
-    x = (x ^ _lsr(x, 27)) * c(0x94D049BB133111EB)
-    x = x ^ _lsr(x, 31)
-    return _lsr(x, 1)
+from sourmash_amd.synth import synth_gather_device  # noqa: E402
 
 
 def make_inputs(nq, ndb, dbsize, dev, seed=777, chunk=10_000):
-    q = torch.unique(splitmix63(torch.arange(int(nq * 1.01) + 16, device=dev, dtype=torch.int64) + seed) % (MAX_HASH_1000 + 1))
-    q = q[q > 0][:nq].contiguous()
-    half = dbsize // 2
-    rows, lens = [], []
-    col = torch.arange(half, device=dev, dtype=torch.int64)
-    for lo in range(0, ndb, chunk):
-        d = torch.arange(lo, min(lo + chunk, ndb), device=dev, dtype=torch.int64)[:, None]
-        shared = q[splitmix63((d << 32) ^ col[None, :] ^ seed) % len(q)]
-        priv = splitmix63((1 << 62) + (d << 33) + col[None, :] + seed) % MAX_HASH_1000 + 1
-        x = torch.sort(torch.cat([shared, priv], dim=1), dim=1).values
-        keep = torch.ones_like(x, dtype=torch.bool)
-        keep[:, 1:] = x[:, 1:] != x[:, :-1]
-        rows.append(x[keep])
-        lens.append(keep.sum(dim=1))
-    hashes = torch.cat(rows)
-    offsets = torch.zeros(ndb + 1, dtype=torch.int64, device=dev)
-    offsets[1:] = torch.cumsum(torch.cat(lens), 0)
-    return q, hashes, offsets
+    return synth_gather_device(nq, ndb, dbsize, dev, seed=seed, chunk=chunk)
 
 
 def main():
