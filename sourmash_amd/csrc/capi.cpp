@@ -920,14 +920,17 @@ struct GatherRaw {
 };
 
 // run the armed loop to exhaustion; -> number of results (host copies if out_* given).
-// Two device loops with identical results: "scan" picks the arg-max over all counters every round; "replay" selects the
-// 16 best rows once per 16 rounds and replays the rounds among those candidates (the multi-GPU protocol with one shard).
+// Two device loops with identical results: "scan" (default) picks the arg-max over all counters every round; "replay"
+// runs the multi-GPU protocol with one shard (the 16 best rows exported, rounds replayed among those candidates while
+// the best stays above the best key kept back).  Measured on one GPU (profiles/r02_gather_loops.txt): replay wins only
+// when the leading counters are well separated; with clustered counters (config C5: every round lowers all of them by
+// a few hashes, so the kept-back key overtakes after ~3 rounds) the extra exchanges make it slower, 69 vs 29 us / round.
 static bool gather_use_replay() {
     static const int mode = [] {
         const char* e = getenv("SMG_GATHER_LOOP");
-        return e && !strcmp(e, "scan") ? 0 : (e && !strcmp(e, "replay") ? 1 : -1);
+        return e && !strcmp(e, "replay") ? 1 : 0;
     }();
-    return mode != 0;                                               // default: replay
+    return mode == 1;
 }
 static uint64_t gather_drain(GatherDev& g, uint64_t* out_idx, uint64_t* out_isect, uint64_t cap, hipStream_t st) {
     unsigned long long head[GS_SLOTS];

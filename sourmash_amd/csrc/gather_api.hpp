@@ -98,4 +98,11 @@ hipError_t gather_consume_list(GatherDev& g, const uint64_t* d_list, hipStream_t
 // Enqueue `rounds` rounds of pick(check) + apply on one GPU (kernels are no-ops once GS_DONE is set).
 hipError_t gather_enqueue_rounds(GatherDev& g, unsigned rounds, hipStream_t stream);
 
+// overlap[d] = |Q ∩ D_d| (op 0) or overlap[d] -= |Q ∩ D_d| saturating (op 1) with range-partitioned lookups: the form of
+// pair_api.hpp's overlap_vector_launch for queries of many ranges (synchronises the stream once)
+hipError_t overlap_ranges_launch(const uint64_t* Q, uint64_t nq, const uint64_t* hashes, const uint64_t* offsets, uint64_t ndb,
+                                 unsigned long long* overlap, int op, hipStream_t stream);
+constexpr uint64_t OVERLAP_RANGES_MIN_NQ = 4 * 32768;   // below this the one-wave-per-row kernel's table already sits in L2
+constexpr uint64_t OVERLAP_RANGES_MIN_ROWS = 4096;
+
 }  // namespace smg

@@ -18,6 +18,7 @@
 #include "device_api.hpp"
 #include "pair_api.hpp"
 #include "qindex.hpp"
+#include "gather_api.hpp"
 
 namespace smg {
 
@@ -209,6 +210,9 @@ hipError_t overlap_vector_launch(const uint64_t* Q, uint64_t nq, const uint64_t*
         return op == 0 ? hipMemsetAsync(overlap, 0, ndb * 8, stream) : hipSuccess;
     }
     if (nq >= NONE32) return hipErrorInvalidValue;
+    static const bool no_ranges = [] { const char* e = getenv("SMG_OVERLAP"); return e && !strcmp(e, "rows"); }();
+    if (!no_ranges && nq >= OVERLAP_RANGES_MIN_NQ && ndb >= OVERLAP_RANGES_MIN_ROWS && ndb < NONE32)
+        return overlap_ranges_launch(Q, nq, hashes, offsets, ndb, overlap, op, stream);   // gather.hip: lookups stay in L2
     // scratch: header, padded query, table of at most 2 * nq + 2 entries; allocated and released in stream order
     uint8_t* scratch = nullptr;
     const size_t bytes = QIH_BYTES + (nq + 4) * 8 + (2 * nq + 4) * 4;

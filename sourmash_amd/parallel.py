@@ -334,7 +334,7 @@ def gather_distributed(query, nq, shard_hashes, shard_offsets, n_shard, index_ba
     k, rounds = exchange_geometry(world)
     mine = backend.zeros((k, stride), torch.int64)
     everyone = backend.zeros((world * k, stride), torch.int64) if collect else mine
-    batch, exchanges = 2, 0
+    batch, exchanges, done_rounds = 2, 0, 0
     while True:
         for _ in range(batch):
             state.export_topk(mine, k)
@@ -343,12 +343,18 @@ def gather_distributed(query, nq, shard_hashes, shard_offsets, n_shard, index_ba
             state.load_candidates(everyone, world * k)
             state.replay(rounds)
         exchanges += batch
-        _, done = state.poll()
+        now, done = state.poll()
         if done:
             break
+        # rounds an exchange really yields (replicated state -> the same number on every rank): clustered counters end
+        # a batch after a few rounds, and replay rounds past that point are launches that do nothing
+        per_exchange = (now - done_rounds) / batch
+        done_rounds = now
+        rounds = max(2, min(world * k, int(per_exchange * 1.5) + 2))
         batch = min(batch * 2, 16)
     if stats is not None:
-        stats.update(exchanges=exchanges, rounds_per_exchange=rounds, records_per_rank=k, record_words=stride)
+        stats.update(exchanges=exchanges, rounds_per_exchange=rounds, records_per_rank=k, record_words=stride,
+                     rounds=len(state.results()))
     return state.results()
 
 

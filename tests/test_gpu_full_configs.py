@@ -89,4 +89,4 @@ def test_gather_c5_full_size_vs_oracle():
     stats = {}
     got = parallel.gather_distributed(q, len(q), hashes, offsets, ndb, 0, thr_bp, 1000, be, stepwise=True, stats=stats)
     assert got == want                                           # export -> load -> replay, as N ranks run it
-    assert stats["exchanges"] < len(want) / 4
+    assert stats["exchanges"] < len(want) / 2                    # fewer collectives than rounds (two per round before)

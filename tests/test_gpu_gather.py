@@ -143,11 +143,13 @@ def test_search_and_prefetch_vs_oracle(sm):
     assert db.best_containment(q).signature.name in ("s5", "s116")          # itself or its planted duplicate
 
 
-@pytest.mark.parametrize("build", ["atomic", "ranges"])
+@pytest.mark.parametrize("build", ["atomic", "ranges", "ranges-direct"])
 def test_synthetic_gather_vs_oracle(sm, build, monkeypatch):
-    # both builders of the inverted index (csrc/gather.hip: one atomic per element / range-partitioned with the
-    # histogram in LDS) -- the size heuristic would pick "atomic" for a database this small
-    monkeypatch.setenv("SMG_GATHER_BUILD", build)
+    # the builders of the inverted index (csrc/gather.hip: one atomic per element / range-partitioned with the
+    # histogram in LDS, postings filled through the two-level partition or by direct stores) -- the size heuristic
+    # would pick "atomic" for a database this small
+    monkeypatch.setenv("SMG_GATHER_BUILD", build.split("-")[0])
+    monkeypatch.setenv("SMG_GATHER_FILL", "direct" if build.endswith("direct") else "staged")
     from sourmash_amd.index import CounterGather
     from sourmash_amd.synth import synth_gather
     qh, dbh = synth_gather(n_query=60_000, n_db=1500, db_size=600)
@@ -162,3 +164,57 @@ def test_synthetic_gather_vs_oracle(sm, build, monkeypatch):
         md5_to_idx = {s.md5sum(): i for i, s in enumerate(sigs)}
         assert [(md5_to_idx[m], n) for m, n in got] == want, thr_bp
         assert len(want) > 10 or thr_bp == 200_000
+
+
+@pytest.mark.parametrize("fill", ["staged", "direct"])
+def test_range_builder_postings_are_exact(fill, monkeypatch):
+    """The postings themselves (not only the gather they drive): after the range-partitioned build every counter equals
+    |Q ∩ row|, and consuming the whole query through the postings brings every counter to exactly zero -- which holds
+    iff every (query hash, row) pair sits in exactly one posting.  Ragged rows, an empty row, rows outside the query,
+    a query whose last range is a few lists long."""
+    import torch
+    from sourmash_amd import device as smd, parallel
+    from sourmash_amd.synth import synth_gather
+    monkeypatch.setenv("SMG_GATHER_BUILD", "ranges")
+    monkeypatch.setenv("SMG_GATHER_FILL", fill)
+    qh, dbh = synth_gather(n_query=3 * 32768 + 77, n_db=700, db_size=900)
+    dbh[3] = np.zeros(0, dtype=np.uint64)
+    dbh[4] = np.array([1, 2, 3], dtype=np.uint64)
+    dbh[5] = qh[::7].copy()                                       # a long row made of query hashes only
+    dbh[6] = qh[-40:].copy()                                      # only the last (short) range
+    be = parallel.DeviceBackend()
+    h, off = smd.pack_csr(dbh)
+    q = torch.from_numpy(qh.view(np.int64).copy()).cuda()
+    st = be.gather_state(q, len(qh), h, off, len(dbh), 0)
+    want = np.array([oracle.intersection_size(qh, d)[0] for d in dbh], dtype=np.uint64)
+    assert np.array_equal(st.counters(), want)
+    assert int(be.lib.smgpu_gather_postings(st._ptr)) == int(want.sum())
+    # the greedy loop = the oracle's, and when it has run to the end every counter is back to |row ∩ uncovered| = 0
+    st.begin(0, len(dbh))
+    got = st.run()
+    assert got == oracle.gather(qh, *oracle.make_csr(dbh), threshold_bp=0, scaled=1000, nthreads=8)
+    assert not st.counters().any()
+
+
+def test_overlaps_of_a_large_query_take_the_range_partitioned_pass():
+    "smgpu_overlap_raw with a query of >= 4 ranges over >= 4096 rows (gather.hip: overlap_ranges_launch), both ops, vs the oracle"
+    import torch
+    from sourmash_amd import device as smd, parallel
+    from sourmash_amd.synth import synth_gather
+    qh, dbh = synth_gather(n_query=140_000, n_db=4200, db_size=90)
+    dbh[10] = np.zeros(0, dtype=np.uint64)
+    dbh[11] = qh[1000:3000].copy()
+    be = parallel.DeviceBackend()
+    h, off = smd.pack_csr(dbh)
+    q = torch.from_numpy(qh.view(np.int64).copy()).cuda()
+    cnt = be.zeros((len(dbh),), torch.int64)
+    be.overlaps(q, len(qh), h, off, len(dbh), cnt, 0)
+    want = np.array([oracle.intersection_size(qh, d)[0] for d in dbh], dtype=np.int64)
+    assert np.array_equal(cnt.cpu().numpy(), want)
+    part = qh[::2].copy()                                         # consume half of the query: saturating subtraction
+    pq = torch.from_numpy(part.view(np.int64).copy()).cuda()
+    cnt[7] = 1                                                    # a counter someone lowered: must stop at 0
+    be.overlaps(pq, len(part), h, off, len(dbh), cnt, 1)
+    sub = np.array([oracle.intersection_size(part, d)[0] for d in dbh], dtype=np.int64)
+    want[7] = 1
+    assert np.array_equal(cnt.cpu().numpy(), np.maximum(want - sub, 0))
