@@ -231,6 +231,16 @@ void smgpu_minhash_add_buffer(SourmashKmerMinHash *ptr, const char *buf, uintptr
  * pinned staging buffers to the GPU, and every sketch of the signature (all ksizes) is filled in the same
  * pass.  force=True semantics (bytes outside ACGTacgt drop the k-mers covering them).  Returns the
  * number of sequence bytes read; *n_records = number of records. */
+/* Per-record sketching without a launch per record.  kmerminhash_add_sequence / signature_add_sequence (the reference's
+ * loop: src/sourmash/command_sketch.py:746-768, src/core/src/signature.rs:38-58) validate the record, queue it in the
+ * sketch and return; the queue goes through the sketch kernel in one launch when it reaches 32 MiB or when any accessor
+ * looks at the sketch.  force = false still raises InvalidDNA from the offending call, after the k-mers in front of the
+ * first bad one were queued (signature.rs:48-54).  smgpu_minhash_add_sequence_rc is add_sequence with the error code as
+ * the return value (len bytes, a NUL ends the record early like the C string of the reference's entry point);
+ * smgpu_minhash_flush settles the queue now; smgpu_minhash_pending_bytes tells how much is queued. */
+uint32_t smgpu_minhash_add_sequence_rc(SourmashKmerMinHash *ptr, const char *sequence, uintptr_t len, bool force);
+void smgpu_minhash_flush(SourmashKmerMinHash *ptr);
+uint64_t smgpu_minhash_pending_bytes(const SourmashKmerMinHash *ptr);
 uint64_t smgpu_signature_add_file(SourmashSignature *ptr, const char *path, uint64_t *n_records);
 /* `sourmash sketch dna` over many files at once: n_threads workers (0 = min(16, host cores)), each with its own
  * stream, pinned ring and device buffers, one signature per file in input order (every ksize of `params` in it).

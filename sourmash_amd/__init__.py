@@ -14,8 +14,6 @@ from .minhash import MinHash, FrozenMinHash, hash_murmur, get_minhash_default_se
 from .signature import (SourmashSignature, FrozenSourmashSignature, load_signatures_from_json,  # noqa: E402
                         load_one_signature_from_json, save_signatures_to_json)
 
-from .save_load import load_file_as_index, load_file_as_signatures, SaveSignaturesToLocation  # noqa: E402
-
 DEFAULT_SEED = get_minhash_default_seed()
 MAX_HASH = get_minhash_max_hash()
 
@@ -27,5 +25,4 @@ def gpu_available():
 
 __all__ = ["MinHash", "FrozenMinHash", "SourmashSignature", "FrozenSourmashSignature", "hash_murmur",
            "load_signatures_from_json", "load_one_signature_from_json", "save_signatures_to_json",
-           "load_file_as_index", "load_file_as_signatures", "SaveSignaturesToLocation",
            "gpu_available", "DEFAULT_SEED", "MAX_HASH", "VERSION"]

@@ -19,7 +19,8 @@ import re
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG)
 HEADER = os.path.join(_ROOT, "include", "sourmash_amd.h")
-LIBPATH = os.path.join(_PKG, "libsourmash_amd.so")
+# SMG_LIBRARY: another build of the same library (the sanitizer build of tests/test_sanitizers_cpu.py)
+LIBPATH = os.environ.get("SMG_LIBRARY") or os.path.join(_PKG, "libsourmash_amd.so")
 
 
 class SourmashStr(C.Structure):

@@ -62,10 +62,36 @@ SourmashStr make_str(const std::string& s) {
     return out;
 }
 
-inline KmerMinHash* MH(SourmashKmerMinHash* p) { return reinterpret_cast<KmerMinHash*>(p); }
-inline const KmerMinHash* MH(const SourmashKmerMinHash* p) { return reinterpret_cast<const KmerMinHash*>(p); }
-inline Signature* SIG(SourmashSignature* p) { return reinterpret_cast<Signature*>(p); }
-inline const Signature* SIG(const SourmashSignature* p) { return reinterpret_cast<const Signature*>(p); }
+// ---- deferred sketching behind the per-record API -------------------------------------------------------------
+// The reference's loop is one add_sequence per record (src/sourmash/command_sketch.py:746-768, signature.rs:38-58).
+// A kernel launch per 150-base read would cost ~40 us of copy + launch + synchronise each, so add_sequence only
+// validates and appends the record to the sketch's `pending` buffer; the buffer goes through the sketch kernel in one
+// launch when it is large enough or when anything looks at the sketch (every accessor below goes through MH / SIG,
+// which settle first).  Results are those of immediate hashing: adding hashes to a sketch commutes (set union, counts
+// add, bottom-k keeps the smallest), and everything that does not commute with it settles first.
+constexpr size_t PENDING_FLUSH_BYTES = (size_t)32 << 20;
+void settle(KmerMinHash& mh);
+
+inline KmerMinHash* RAW(SourmashKmerMinHash* p) { return reinterpret_cast<KmerMinHash*>(p); }
+inline const KmerMinHash* RAW(const SourmashKmerMinHash* p) { return reinterpret_cast<const KmerMinHash*>(p); }
+inline KmerMinHash* settled(KmerMinHash* m) {
+    if (m && !m->pending.empty()) {
+        // accessors without a landing pad cannot throw across the C boundary: the failure is left in the thread's error slot
+        try { settle(*m); }
+        catch (const Error& e) { set_error(e.code, e.what()); }
+        catch (const std::exception& e) { set_error(E_PANIC, std::string("sourmash panicked: ") + e.what()); }
+    }
+    return m;
+}
+inline KmerMinHash* MH(SourmashKmerMinHash* p) { return settled(reinterpret_cast<KmerMinHash*>(p)); }
+inline const KmerMinHash* MH(const SourmashKmerMinHash* p) { return settled(const_cast<KmerMinHash*>(reinterpret_cast<const KmerMinHash*>(p))); }
+inline Signature* SIGRAW(SourmashSignature* p) { return reinterpret_cast<Signature*>(p); }
+inline Signature* SIG(SourmashSignature* p) {
+    Signature* s = reinterpret_cast<Signature*>(p);
+    if (s) for (auto& mh : s->sketches) settled(&mh);
+    return s;
+}
+inline const Signature* SIG(const SourmashSignature* p) { return SIG(const_cast<SourmashSignature*>(p)); }
 inline ComputeParameters* CP(SourmashComputeParameters* p) { return reinterpret_cast<ComputeParameters*>(p); }
 inline const ComputeParameters* CP(const SourmashComputeParameters* p) { return reinterpret_cast<const ComputeParameters*>(p); }
 
@@ -102,18 +128,44 @@ void add_residue_kmers(KmerMinHash& mh, const uint8_t* seq, size_t len, bool is_
     mh.add_sorted_batch(hs.data(), mh.track_abundance ? cs.data() : nullptr, hs.size());
 }
 
+// first byte outside ACGTacgt (what kills a k-mer, encodings.rs:370-377 after signature.rs:214's upper-casing), or SIZE_MAX.
+// Only decides whether add_sequence(force = false) must raise and where the valid prefix ends; the k-mers themselves
+// are validated again, hashed and filtered by the kernel.
+size_t first_invalid_byte(const uint8_t* seq, size_t len) {
+    static const struct Table {
+        uint8_t bad[256];
+        Table() { memset(bad, 1, sizeof(bad)); for (const char* c = "ACGTacgt"; *c; ++c) bad[(uint8_t)*c] = 0; }
+    } t;
+    for (size_t i = 0; i < len; ++i)
+        if (t.bad[seq[i]]) return i;
+    return SIZE_MAX;
+}
+
+void settle(KmerMinHash& mh) {
+    if (mh.pending.empty()) return;
+    std::string buf;
+    buf.swap(mh.pending);                                           // whatever happens below, the records are consumed once
+    DeviceCtx& ctx = DeviceCtx::get();
+    std::lock_guard<std::mutex> g(ctx.mutex());
+    std::vector<uint64_t> hs, cs;
+    ctx.sketch_host((const uint8_t*)buf.data(), buf.size(), mh.ksize, mh.seed, keep_threshold(mh), mh.track_abundance, mh.num, hs, cs);
+    mh.add_sorted_batch(hs.data(), mh.track_abundance ? cs.data() : nullptr, hs.size());
+}
+
+// The DNA add_sequence path (signature.rs:38-58 + :246-306).
+// force == false: the walk is streaming in the reference, so the hashes of every k-mer before the first offending
+// one are added before InvalidDNA is raised: the valid prefix is queued, then the error is raised from this call.
 void add_sequence_dna(KmerMinHash& mh, const uint8_t* seq, size_t len, bool force) {
     if (!mh.is_dna()) { add_residue_kmers(mh, seq, len, false); return; }
     const uint32_t k = mh.ksize;
     if (len < k || k == 0) return;                                  // signature.rs:206-210
     if (mh.num == 0 && mh.max_hash == 0) return;                    // sketch that can never hold anything
-    DeviceCtx& ctx = DeviceCtx::get();
-    std::lock_guard<std::mutex> g(ctx.mutex());
+    (void)DeviceCtx::get();                                         // no device: fail now, not at the first accessor
     size_t use_len = len;
     bool raise = false;
     size_t bad_kmer = 0;
     if (!force) {
-        const size_t p = ctx.first_invalid_host(seq, len);
+        const size_t p = first_invalid_byte(seq, len);
         if (p != SIZE_MAX) {
             bad_kmer = p + 1 >= k ? p + 1 - k : 0;                  // first k-mer whose window covers byte p
             if (bad_kmer < len - k + 1) {
@@ -123,9 +175,9 @@ void add_sequence_dna(KmerMinHash& mh, const uint8_t* seq, size_t len, bool forc
         }
     }
     if (use_len >= k) {
-        std::vector<uint64_t> hs, cs;
-        ctx.sketch_host(seq, use_len, k, mh.seed, keep_threshold(mh), mh.track_abundance, mh.num, hs, cs);
-        mh.add_sorted_batch(hs.data(), mh.track_abundance ? cs.data() : nullptr, hs.size());
+        mh.pending.append((const char*)seq, use_len);
+        mh.pending.push_back('\n');                                 // records never share a k-mer
+        if (mh.pending.size() >= PENDING_FLUSH_BYTES) settle(mh);
     }
     if (raise) throw err_invalid_dna(upper_ascii(seq + bad_kmer, k));   // errors.rs:49-50
 }
@@ -244,7 +296,7 @@ void computeparams_set_hp(SourmashComputeParameters* p, bool v) { CP(p)->hp = v;
 void computeparams_set_protein(SourmashComputeParameters* p, bool v) { CP(p)->protein = v; }
 void computeparams_set_track_abundance(SourmashComputeParameters* p, bool v) { CP(p)->track_abundance = v; }
 void computeparams_set_ksizes(SourmashComputeParameters* p, const uint32_t* ks, uintptr_t n) {
-    CP(p)->ksizes.assign(ks, ks + n);
+    landing_void([&] { CP(p)->ksizes.assign(ks, ks + n); });
 }
 void computeparams_set_num_hashes(SourmashComputeParameters* p, uint32_t n) { CP(p)->num_hashes = n; }
 void computeparams_set_scaled(SourmashComputeParameters* p, uint64_t s) { CP(p)->scaled = s; }
@@ -255,15 +307,17 @@ void computeparams_set_seed(SourmashComputeParameters* p, uint64_t s) { CP(p)->s
 // ---------------------------------------------------------------------------------------------
 SourmashKmerMinHash* kmerminhash_new(uint64_t scaled, uint32_t k, HashFunctions hf, uint64_t seed, bool track,
                                      uint32_t n) {
-    return reinterpret_cast<SourmashKmerMinHash*>(new KmerMinHash(scaled, k, hf, seed, track, n));
+    return landing<SourmashKmerMinHash*>([&]() -> SourmashKmerMinHash* {
+        return reinterpret_cast<SourmashKmerMinHash*>(new KmerMinHash(scaled, k, hf, seed, track, n));
+    });
 }
-void kmerminhash_free(SourmashKmerMinHash* p) { delete MH(p); }
+void kmerminhash_free(SourmashKmerMinHash* p) { delete RAW(p); }
 void kmerminhash_slice_free(uint64_t* ptr, uintptr_t) { free(ptr); }
 
 void kmerminhash_add_sequence(SourmashKmerMinHash* p, const char* sequence, bool force) {
     landing_void([&] {
         if (!sequence) throw err_internal("null sequence");
-        add_sequence_dna(*MH(p), (const uint8_t*)sequence, strlen(sequence), force);   // CStr: stops at NUL (ffi/minhash.rs:53-59)
+        add_sequence_dna(*RAW(p), (const uint8_t*)sequence, strlen(sequence), force);   // CStr: stops at NUL (ffi/minhash.rs:53-59)
     });
 }
 
@@ -314,8 +368,10 @@ const uint64_t* kmerminhash_seq_to_hashes(SourmashKmerMinHash* p, const char* se
     });
 }
 
-void kmerminhash_add_hash(SourmashKmerMinHash* p, uint64_t h) { MH(p)->add_hash(h); }
-void kmerminhash_add_hash_with_abundance(SourmashKmerMinHash* p, uint64_t h, uint64_t a) { MH(p)->add_hash_with_abundance(h, a); }
+void kmerminhash_add_hash(SourmashKmerMinHash* p, uint64_t h) { RAW(p)->add_hash(h); }   // commutes with the queued records
+void kmerminhash_add_hash_with_abundance(SourmashKmerMinHash* p, uint64_t h, uint64_t a) {
+    landing_void([&] { MH(p)->add_hash_with_abundance(h, a); });   // abundance 0 removes: settles the queued records first
+}
 void kmerminhash_add_many(SourmashKmerMinHash* p, const uint64_t* hs, uintptr_t n) {
     landing_void([&] {
         if (!hs && n) throw err_internal("null hashes pointer");
@@ -327,7 +383,7 @@ void kmerminhash_add_from(SourmashKmerMinHash* p, const SourmashKmerMinHash* o) 
 }
 void kmerminhash_add_word(SourmashKmerMinHash* p, const char* word) {           // minhash.rs:401-404
     if (!word) return;
-    MH(p)->add_hash(mmh3_h1_bytes((const uint8_t*)word, strlen(word), MH(p)->seed));
+    landing_void([&] { RAW(p)->add_hash(mmh3_h1_bytes((const uint8_t*)word, strlen(word), RAW(p)->seed)); });
 }
 void kmerminhash_add_protein(SourmashKmerMinHash* p, const char* sequence) {
     landing_void([&] {
@@ -335,7 +391,7 @@ void kmerminhash_add_protein(SourmashKmerMinHash* p, const char* sequence) {
         add_residue_kmers(*MH(p), (const uint8_t*)sequence, strlen(sequence), true);
     });
 }
-void kmerminhash_remove_hash(SourmashKmerMinHash* p, uint64_t h) { MH(p)->remove_hash(h); }
+void kmerminhash_remove_hash(SourmashKmerMinHash* p, uint64_t h) { landing_void([&] { MH(p)->remove_hash(h); }); }
 void kmerminhash_remove_many(SourmashKmerMinHash* p, const uint64_t* hs, uintptr_t n) {
     landing_void([&] {
         if (n < 16) { for (uintptr_t i = 0; i < n; ++i) MH(p)->remove_hash(hs[i]); return; }
@@ -347,7 +403,7 @@ void kmerminhash_remove_many(SourmashKmerMinHash* p, const uint64_t* hs, uintptr
 void kmerminhash_remove_from(SourmashKmerMinHash* p, const SourmashKmerMinHash* o) {
     landing_void([&] { MH(p)->remove_sorted(MH(o)->mins.data(), MH(o)->mins.size()); });
 }
-void kmerminhash_clear(SourmashKmerMinHash* p) { MH(p)->clear(); }
+void kmerminhash_clear(SourmashKmerMinHash* p) { RAW(p)->clear(); }   // drops the queued records too
 
 const uint64_t* kmerminhash_get_mins(const SourmashKmerMinHash* p, uintptr_t* size) {
     return landing<const uint64_t*>([&]() -> const uint64_t* { return slice_out(MH(p)->mins, size); });
@@ -446,39 +502,43 @@ double kmerminhash_angular_similarity(const SourmashKmerMinHash* p, const Sourma
     return landing<double>([&] { return angular(*MH(p), *MH(o)); });
 }
 
-uint32_t kmerminhash_num(const SourmashKmerMinHash* p) { return MH(p)->num; }
-uint32_t kmerminhash_ksize(const SourmashKmerMinHash* p) { return MH(p)->ksize; }
-uint64_t kmerminhash_seed(const SourmashKmerMinHash* p) { return MH(p)->seed; }
-uint64_t kmerminhash_max_hash(const SourmashKmerMinHash* p) { return MH(p)->max_hash; }
-HashFunctions kmerminhash_hash_function(const SourmashKmerMinHash* p) { return MH(p)->hash_function; }
+uint32_t kmerminhash_num(const SourmashKmerMinHash* p) { return RAW(p)->num; }
+uint32_t kmerminhash_ksize(const SourmashKmerMinHash* p) { return RAW(p)->ksize; }
+uint64_t kmerminhash_seed(const SourmashKmerMinHash* p) { return RAW(p)->seed; }
+uint64_t kmerminhash_max_hash(const SourmashKmerMinHash* p) { return RAW(p)->max_hash; }
+HashFunctions kmerminhash_hash_function(const SourmashKmerMinHash* p) { return RAW(p)->hash_function; }
 void kmerminhash_hash_function_set(SourmashKmerMinHash* p, HashFunctions hf) {
     landing_void([&] {
         if (hf < 1 || hf > 4) throw Error(E_INVALID_HASH_FUNCTION, "Invalid hash function: \"" + std::to_string(hf) + "\"");
         MH(p)->set_hash_function(hf);
     });
 }
-bool kmerminhash_is_protein(const SourmashKmerMinHash* p) { return MH(p)->hash_function == HF_PROTEIN; }
-bool kmerminhash_dayhoff(const SourmashKmerMinHash* p) { return MH(p)->hash_function == HF_DAYHOFF; }
-bool kmerminhash_hp(const SourmashKmerMinHash* p) { return MH(p)->hash_function == HF_HP; }
-bool kmerminhash_track_abundance(const SourmashKmerMinHash* p) { return MH(p)->track_abundance; }
+bool kmerminhash_is_protein(const SourmashKmerMinHash* p) { return RAW(p)->hash_function == HF_PROTEIN; }
+bool kmerminhash_dayhoff(const SourmashKmerMinHash* p) { return RAW(p)->hash_function == HF_DAYHOFF; }
+bool kmerminhash_hp(const SourmashKmerMinHash* p) { return RAW(p)->hash_function == HF_HP; }
+bool kmerminhash_track_abundance(const SourmashKmerMinHash* p) { return RAW(p)->track_abundance; }
 void kmerminhash_enable_abundance(SourmashKmerMinHash* p) { landing_void([&] { MH(p)->enable_abundance(); }); }
 void kmerminhash_disable_abundance(SourmashKmerMinHash* p) { MH(p)->disable_abundance(); }
 
 // ---------------------------------------------------------------------------------------------
 // signature container (ffi/signature.rs)
 // ---------------------------------------------------------------------------------------------
-SourmashSignature* signature_new(void) { return reinterpret_cast<SourmashSignature*>(new Signature()); }
-void signature_free(SourmashSignature* p) { delete SIG(p); }
-SourmashSignature* signature_from_params(const SourmashComputeParameters* p) {
-    return reinterpret_cast<SourmashSignature*>(new Signature(Signature::from_params(*CP(p))));
+SourmashSignature* signature_new(void) {
+    return landing<SourmashSignature*>([&]() -> SourmashSignature* { return reinterpret_cast<SourmashSignature*>(new Signature()); });
 }
-uintptr_t signature_len(const SourmashSignature* p) { return SIG(p)->sketches.size(); }
+void signature_free(SourmashSignature* p) { delete SIGRAW(p); }
+SourmashSignature* signature_from_params(const SourmashComputeParameters* p) {
+    return landing<SourmashSignature*>([&]() -> SourmashSignature* {
+        return reinterpret_cast<SourmashSignature*>(new Signature(Signature::from_params(*CP(p))));
+    });
+}
+uintptr_t signature_len(const SourmashSignature* p) { return SIGRAW(const_cast<SourmashSignature*>(p))->sketches.size(); }
 
 void signature_add_sequence(SourmashSignature* p, const char* sequence, bool force) {
     landing_void([&] {                                                          // signature.rs:661-677
         if (!sequence) throw err_internal("null sequence");
         const size_t len = strlen(sequence);
-        for (auto& mh : SIG(p)->sketches) add_sequence_dna(mh, (const uint8_t*)sequence, len, force);
+        for (auto& mh : SIGRAW(p)->sketches) add_sequence_dna(mh, (const uint8_t*)sequence, len, force);
     });
 }
 void signature_add_protein(SourmashSignature* p, const char* sequence) {
@@ -488,8 +548,8 @@ void signature_add_protein(SourmashSignature* p, const char* sequence) {
         for (auto& mh : SIG(p)->sketches) add_residue_kmers(mh, (const uint8_t*)sequence, len, true);
     });
 }
-void signature_set_name(SourmashSignature* p, const char* name) { landing_void([&] { if (name) SIG(p)->name = std::string(name); }); }
-void signature_set_filename(SourmashSignature* p, const char* name) { landing_void([&] { if (name) SIG(p)->filename = std::string(name); }); }
+void signature_set_name(SourmashSignature* p, const char* name) { landing_void([&] { if (name) SIGRAW(p)->name = std::string(name); }); }
+void signature_set_filename(SourmashSignature* p, const char* name) { landing_void([&] { if (name) SIGRAW(p)->filename = std::string(name); }); }
 SourmashStr signature_get_name(const SourmashSignature* p) {
     return landing<SourmashStr>([&] { return make_str(SIG(p)->name ? *SIG(p)->name : std::string()); });
 }
@@ -609,9 +669,24 @@ void smgpu_minhash_add_buffer(SourmashKmerMinHash* p, const char* buf, uintptr_t
         if (!buf && len) throw err_internal("null buffer");
         if (!MH(p)->is_dna())     // records joined in one buffer would shift the reading frames of the later records
             throw err_internal("smgpu_minhash_add_buffer takes DNA sketches; feed protein sketches record by record");
-        add_sequence_dna(*MH(p), (const uint8_t*)buf, len, force);
+        add_sequence_dna(*RAW(p), (const uint8_t*)buf, len, force);
     });
 }
+
+// add_sequence with the error code as the return value (0 = fine): one call per record for bindings whose call overhead
+// matters (ctypes); the message is left in the thread's error slot as usual.  len bytes, no NUL needed.
+uint32_t smgpu_minhash_add_sequence_rc(SourmashKmerMinHash* p, const char* sequence, uintptr_t len, bool force) {
+    g_err_code = 0;
+    landing_void([&] {
+        if (!sequence && len) throw err_internal("null sequence");
+        const void* nul = len ? memchr(sequence, 0, len) : nullptr;             // C-string semantics of kmerminhash_add_sequence
+        add_sequence_dna(*RAW(p), (const uint8_t*)sequence, nul ? (size_t)((const char*)nul - sequence) : len, force);
+    });
+    return g_err_code;
+}
+// settle the records queued by add_sequence now (the accessors do it on their own; this is for timing and tests)
+void smgpu_minhash_flush(SourmashKmerMinHash* p) { landing_void([&] { settle(*RAW(p)); }); }
+uint64_t smgpu_minhash_pending_bytes(const SourmashKmerMinHash* p) { return RAW(p)->pending.size(); }
 
 uint64_t smgpu_signature_add_file(SourmashSignature* p, const char* path, uint64_t* n_records) {
     return landing<uint64_t>([&]() -> uint64_t {

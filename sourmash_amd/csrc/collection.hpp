@@ -86,6 +86,9 @@ class ZipReader {
         pread_exact(m.local_offset, lh, 30);
         if (le32(lh) != 0x04034b50u) fail("bad local file header");
         const uint64_t data = m.local_offset + 30 + le16(lh + 26) + le16(lh + 28);
+        // the central directory is untrusted input: a member cannot be larger than the archive holds / than deflate can expand
+        if (m.comp_size > file_size_ || data > file_size_ - m.comp_size) fail("member " + m.name + " reaches past the end of the archive");
+        if (m.method == 8 && m.size / 1032 > m.comp_size + 1) fail("implausible size of member " + m.name);
         std::string comp((size_t)m.comp_size, '\0');
         if (m.comp_size) pread_exact(data, &comp[0], m.comp_size);
         if (m.method == 0) return comp;
@@ -94,12 +97,28 @@ class ZipReader {
         z_stream zs;
         memset(&zs, 0, sizeof(zs));
         if (inflateInit2(&zs, -MAX_WBITS) != Z_OK) fail("cannot initialise inflate");
-        zs.next_in = (Bytef*)comp.data();
-        zs.avail_in = (uInt)comp.size();
-        zs.next_out = (Bytef*)(out.empty() ? nullptr : &out[0]);
-        zs.avail_out = (uInt)out.size();
-        const int rc = inflate(&zs, Z_FINISH);
-        const bool ok = (rc == Z_STREAM_END) && zs.total_out == out.size();
+        // zlib counts in uInt: feed and drain in pieces of at most 1 GiB (zip64 members may exceed 4 GiB)
+        const size_t PIECE = (size_t)1 << 30;
+        size_t in_pos = 0, out_pos = 0;
+        int rc = Z_OK;
+        while (rc == Z_OK) {
+            if (zs.avail_in == 0 && in_pos < comp.size()) {
+                const size_t n = std::min(PIECE, comp.size() - in_pos);
+                zs.next_in = (Bytef*)comp.data() + in_pos;
+                zs.avail_in = (uInt)n;
+                in_pos += n;
+            }
+            if (zs.avail_out == 0 && out_pos < out.size()) {
+                const size_t n = std::min(PIECE, out.size() - out_pos);
+                zs.next_out = (Bytef*)&out[0] + out_pos;
+                zs.avail_out = (uInt)n;
+                out_pos += n;
+            }
+            const bool last_in = in_pos == comp.size();
+            rc = inflate(&zs, last_in ? Z_FINISH : Z_NO_FLUSH);
+            if (rc == Z_BUF_ERROR && (in_pos < comp.size() || out_pos < out.size()) && (zs.avail_in == 0 || zs.avail_out == 0)) rc = Z_OK;
+        }
+        const bool ok = (rc == Z_STREAM_END) && (out_pos - zs.avail_out) == out.size() && in_pos == comp.size();
         inflateEnd(&zs);
         if (!ok) fail("corrupt deflate stream in member " + m.name);
         return out;

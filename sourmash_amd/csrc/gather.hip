@@ -35,6 +35,11 @@ __global__ __launch_bounds__(256) void qtable_kernel(const uint64_t* __restrict_
     qindex_fill_bucket(Q, nq, shift, n_buckets, T, blockIdx.x * blockDim.x + threadIdx.x);
 }
 
+__global__ __launch_bounds__(256) void qrec_kernel(const uint64_t* __restrict__ Q, const uint32_t* __restrict__ T,
+                                                   uint32_t n_buckets, QRec* __restrict__ rec) {
+    qindex_fill_record(Q, T, n_buckets, rec, blockIdx.x * blockDim.x + threadIdx.x);
+}
+
 // pass 1 over the database: qpos of every element, postings histogram, initial counters (CounterGather.add)
 __global__ __launch_bounds__(256) void build_count_kernel(QIndex qi, const uint64_t* __restrict__ hashes,
                                                           const uint64_t* __restrict__ offsets, uint64_t ndb,
@@ -88,18 +93,19 @@ constexpr int BR_EPW = 16;           // row slices a wave flattens per step (see
 constexpr int BR_THREADS = 512;      // 64 KB of LDS per workgroup (u16 slots, two per word): 2 workgroups = 16 waves per CU
 // Two-level fill (the default): a 4-byte store per posting straight into its list leaves 32,768 lists x 8 lines open per
 // range -- far more than one L2 -- and partially filled lines were evicted and fetched back (8.1 GB written and 13.6 GB
-// read for 1 GB of postings, profiles/r01_gather_pmc.txt).  Instead, pass 2a re-partitions the postings of workgroup
-// (range, row block) by sub-range of BR_SUB lists, staged per wave in LDS and flushed 64 bytes at a time into an
-// intermediate buffer laid out [range][sub-range][row block] (sizes known from pass 1); pass 2b then gives every
-// sub-range window (BR_SUB lists, ~0.5 MB of postings) to a few workgroups on ONE XCD, each scattering the entries of
-// its row blocks through LDS cursors: a workgroup's stores to a list form one contiguous run of about a line.
-constexpr int BR_SUB = 512;                       // lists per window of the final scatter
-constexpr int BR_NSUB = BR_RANGE / BR_SUB;        // 64 sub-ranges per range: lane l of a wave looks after sub-range l
-constexpr int BR_CHUNK = 16;                      // entries per flush (64 bytes)
-constexpr int BR_RING = 32;                       // staged entries per (wave, sub-range)
-constexpr int BR_ROWBITS = 23;                    // entry = (row << 9) | list within the window: rows < 2^23
+// read for 1 GB of postings, profiles/r01_gather_pmc.txt).  Instead:
+//   pass 2a  workgroup (range, row block) re-partitions its postings by sub-range of BR_SUB lists into an intermediate
+//            buffer laid out [range][sub-range][row block] (exact sizes from pass 1).  A workgroup appends to BR_NSUB
+//            streams, i.e. it has that many lines open: the L2 write-combines them (64 resident workgroups x 16 KB).
+//   pass 2b  a window of BR_SUB lists goes to BR_GROUPS workgroups on ONE XCD; each counting-sorts the entries of its
+//            row blocks by list in LDS and writes every list's run (about a line) with consecutive lanes.
+constexpr int BR_SUB = 256;                       // lists per window of the final scatter
+constexpr int BR_SUB_BITS = 8;
+constexpr int BR_NSUB = BR_RANGE / BR_SUB;        // sub-ranges per range
+constexpr int BR_ROWBITS = 32 - BR_SUB_BITS;      // entry = (row << 8) | list within the window
 constexpr int BR_GROUPS = 8;                      // workgroups per window in pass 2b (each takes B / 8 row blocks)
-static_assert(BR_NSUB == 64, "one sub-range per lane");
+constexpr int BR_SORT_CAP = 12288;                // entries a pass-2b workgroup sorts at a time (48 KB of LDS)
+static_assert((1 << BR_SUB_BITS) == BR_SUB, "");
 
 __global__ __launch_bounds__(256) void build_bounds_kernel(const uint64_t* __restrict__ Q, uint32_t R,
                                                            const uint64_t* __restrict__ hashes,
@@ -141,13 +147,9 @@ __global__ __launch_bounds__(BR_THREADS) void build_range_kernel(QIndex qi, cons
     constexpr bool FILL = MODE == 1;
     constexpr bool PART = MODE == 2;
     constexpr bool COUNT = MODE == 0 || MODE == 3;
-    constexpr int WAVES = BR_THREADS / 64;
     // pass 1: histogram; direct fill: cursors.  A block holds < 65536 rows and a row adds at most 1 to a slot, so 16 bits do.
-    // pass 2a: the same 64 KB hold the per-wave staging rings.
-    __shared__ uint32_t s_slot[MODE == 3 ? 1 : BR_RANGE / 2];
-    __shared__ uint32_t s_head[PART ? WAVES : 1][BR_NSUB], s_tail[PART ? WAVES : 1][BR_NSUB];
-    __shared__ uint32_t s_gbase[BR_NSUB], s_gcur[BR_NSUB];
-    static_assert(WAVES * BR_NSUB * BR_RING <= BR_RANGE / 2, "the staging rings fit the histogram's LDS");
+    __shared__ uint32_t s_slot[(MODE == 3 || PART) ? 1 : BR_RANGE / 2];
+    __shared__ uint32_t s_gbase[BR_NSUB], s_gcur[BR_NSUB];    // pass 2a: start and fill of this workgroup's BR_NSUB streams
     // Launch order: ranges in groups of 8, range (8g + x) entirely on workgroup ids = x mod 8, i.e. on one XCD (workgroups
     // are dealt to the 8 XCDs round-robin), blocks in ascending order.  The 4-byte stores of pass 2 that fill one posting
     // list then meet in a single L2, whose working set is one open cache line per list of the range.
@@ -156,13 +158,12 @@ __global__ __launch_bounds__(BR_THREADS) void build_range_kernel(QIndex qi, cons
     if (r >= R) return;
     const uint64_t j0 = (uint64_t)r * BR_RANGE;
     const uint32_t nj = (uint32_t)(qi.nq - j0 < (uint64_t)BR_RANGE ? qi.nq - j0 : (uint64_t)BR_RANGE);
-    if (MODE != 3)
+    if (MODE != 3 && !PART)
         for (int k = threadIdx.x; k < BR_RANGE / 2; k += BR_THREADS) s_slot[k] = 0;
     if (PART) {
-        for (int k = threadIdx.x; k < WAVES * BR_NSUB; k += BR_THREADS) { s_head[k / BR_NSUB][k % BR_NSUB] = 0; s_tail[k / BR_NSUB][k % BR_NSUB] = 0; }
-        if (threadIdx.x < BR_NSUB) {
-            s_gbase[threadIdx.x] = inter_off[((uint64_t)r * BR_NSUB + threadIdx.x) * B + b];
-            s_gcur[threadIdx.x] = 0;
+        for (int k = threadIdx.x; k < BR_NSUB; k += BR_THREADS) {
+            s_gbase[k] = inter_off[((uint64_t)r * BR_NSUB + k) * B + b];
+            s_gcur[k] = 0;
         }
     }
     __syncthreads();
@@ -212,38 +213,11 @@ __global__ __launch_bounds__(BR_THREADS) void build_range_kernel(QIndex qi, cons
             }
             const bool hit = j != NONE32;
             if (PART) {
-                // stage (row, list) in this wave's ring of the posting's sub-range; lane l flushes the full chunks of ring l
-                uint32_t* ring = s_slot + (uint32_t)wave * (BR_NSUB * BR_RING);
-                const uint32_t k = hit ? j - (uint32_t)j0 : 0u;
-                const uint32_t sub = k / BR_SUB;
-                const uint32_t entry = ((uint32_t)(dbase + (uint64_t)h) << 9) | (k % BR_SUB);
-                uint32_t slot = 0;
-                if (hit) slot = atomicAdd(&s_head[wave][sub], 1u);          // absolute slot in the ring's stream
-                bool pending = hit;
-                for (;;) {
-                    if (pending && slot - *(volatile uint32_t*)&s_tail[wave][sub] < (uint32_t)BR_RING) {
-                        ring[sub * BR_RING + slot % BR_RING] = entry;
-                        pending = false;
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");  // the ring stores are ordered before the reads below
-                    const uint32_t head = *(volatile uint32_t*)&s_head[wave][lane];
-                    uint32_t tail = *(volatile uint32_t*)&s_tail[wave][lane];
-                    const uint32_t written = head < tail + BR_RING ? head : tail + BR_RING;   // every slot below is stored by now
-                    const uint32_t nfl = (written - tail) / BR_CHUNK * BR_CHUNK;
-                    unsigned long long fm = __ballot(nfl > 0);
-                    while (fm) {
-                        const int bkt = __ffsll((long long)fm) - 1;
-                        fm &= fm - 1;
-                        const uint32_t n = (uint32_t)__shfl((int)nfl, bkt), t0r = (uint32_t)__shfl((int)tail, bkt);
-                        uint32_t gpos = 0;
-                        if (lane == 0) gpos = atomicAdd(&s_gcur[bkt], n);
-                        gpos = (uint32_t)__shfl((int)gpos, 0);
-                        if ((uint32_t)lane < n)
-                            inter[(uint64_t)s_gbase[bkt] + gpos + lane] = *(volatile uint32_t*)&ring[bkt * BR_RING + (t0r + lane) % BR_RING];
-                        if (lane == bkt) { tail += n; *(volatile uint32_t*)&s_tail[wave][bkt] = tail; }
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-                    if (!__any(pending)) break;
+                if (hit) {
+                    const uint32_t k = j - (uint32_t)j0;
+                    const uint32_t sub = k >> BR_SUB_BITS;
+                    const uint32_t at = atomicAdd(&s_gcur[sub], 1u);                 // rank within this workgroup's stream
+                    inter[(uint64_t)s_gbase[sub] + at] = ((uint32_t)(dbase + (uint64_t)h) << BR_SUB_BITS) | (k & (BR_SUB - 1));
                 }
             } else if (hit) {
                 const uint32_t k = j - (uint32_t)j0;                // < nj: the slice lies inside the range
@@ -269,81 +243,39 @@ __global__ __launch_bounds__(BR_THREADS) void build_range_kernel(QIndex qi, cons
         if (COUNT && lane < BR_EPW && row_hits) atomicAdd(&counters[d], (unsigned long long)row_hits);
     }
     if (FILL || MODE == 3) return;
-    if (PART) {
-        // what is left in this wave's rings (< one chunk each): lane l drains ring l
-        uint32_t* ring = s_slot + (uint32_t)wave * (BR_NSUB * BR_RING);
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        const uint32_t head = *(volatile uint32_t*)&s_head[wave][lane], tail = *(volatile uint32_t*)&s_tail[wave][lane];
-        const uint32_t rem = head - tail;
-        if (rem) {
-            const uint32_t gpos = atomicAdd(&s_gcur[lane], rem);
-            for (uint32_t i = 0; i < rem; ++i)
-                inter[(uint64_t)s_gbase[lane] + gpos + i] = *(volatile uint32_t*)&ring[lane * BR_RING + (tail + i) % BR_RING];
-        }
-        return;
-    }
+    if (PART) return;
     __syncthreads();
     uint32_t* out = partial + (uint64_t)b * qi.nq + j0;
     for (uint32_t k = threadIdx.x; k < nj; k += BR_THREADS) out[k] = (s_slot[k >> 1] >> (16u * (k & 1u))) & 0xffffu;
     if (subcnt) {
-        // postings this workgroup holds per sub-range: thread t sums 64 lists (32 words) of sub-range t / 8
-        const int sub = threadIdx.x >> 3, part = threadIdx.x & 7;
+        // postings this workgroup holds per sub-range: PARTS threads per sub-range, each sums its share of the words
+        constexpr int PARTS = BR_THREADS / BR_NSUB, WORDS = BR_SUB / 2 / PARTS;
+        static_assert(BR_THREADS % BR_NSUB == 0 && (BR_SUB / 2) % PARTS == 0 && PARTS <= 64 && (PARTS & (PARTS - 1)) == 0, "");
+        const int sub = threadIdx.x / PARTS, part = threadIdx.x % PARTS;
         uint32_t sum = 0;
-        for (int w = 0; w < 32; ++w) {
-            const uint32_t v = s_slot[sub * (BR_SUB / 2) + part * 32 + w];
+        for (int w = 0; w < WORDS; ++w) {
+            const uint32_t v = s_slot[sub * (BR_SUB / 2) + part * WORDS + w];
             sum += (v & 0xffffu) + (v >> 16);
         }
-        sum += __shfl_down(sum, 4, 8);
-        sum += __shfl_down(sum, 2, 8);
-        sum += __shfl_down(sum, 1, 8);
+        for (int off = PARTS / 2; off > 0; off >>= 1) sum += __shfl_down(sum, off, PARTS);
         if (part == 0) subcnt[((uint64_t)r * BR_NSUB + sub) * B + b] = sum;
     }
 }
 
-// intermediate layout of the two-level fill: region of (window w = range * 64 + sub-range, row block b) starts at
-// inter_off[w * B + b], regions padded to whole chunks so that chunk flushes stay 64-byte aligned.  One workgroup.
-__global__ __launch_bounds__(1024) void inter_layout_kernel(const uint32_t* __restrict__ subcnt, uint32_t n_windows, uint32_t B,
-                                                            uint32_t* __restrict__ inter_off) {
-    __shared__ uint32_t s_scan[1024];
-    __shared__ uint32_t s_carry;
-    if (threadIdx.x == 0) s_carry = 0;
-    __syncthreads();
-    for (uint32_t w0 = 0; w0 < n_windows; w0 += 1024) {
-        const uint32_t w = w0 + threadIdx.x;
-        uint32_t mine = 0;
-        if (w < n_windows)
-            for (uint32_t b = 0; b < B; ++b) mine += (subcnt[(uint64_t)w * B + b] + (BR_CHUNK - 1)) / BR_CHUNK * BR_CHUNK;
-        s_scan[threadIdx.x] = mine;
-        __syncthreads();
-        for (int off = 1; off < 1024; off <<= 1) {                  // inclusive scan (Hillis-Steele; runs once per 1024 windows)
-            const uint32_t v = threadIdx.x >= (unsigned)off ? s_scan[threadIdx.x - off] : 0u;
-            __syncthreads();
-            s_scan[threadIdx.x] += v;
-            __syncthreads();
-        }
-        uint32_t at = s_carry + s_scan[threadIdx.x] - mine;
-        if (w < n_windows)
-            for (uint32_t b = 0; b < B; ++b) {
-                inter_off[(uint64_t)w * B + b] = at;
-                at += (subcnt[(uint64_t)w * B + b] + (BR_CHUNK - 1)) / BR_CHUNK * BR_CHUNK;
-            }
-        __syncthreads();
-        if (threadIdx.x == 1023) s_carry += s_scan[1023];
-        __syncthreads();
-    }
-}
-
-// pass 2b: workgroup (window w, group g) scatters the entries of its row blocks into the window's lists through LDS
-// cursors that start at post_off[j] + (postings of j in earlier row blocks).  Windows w = x (mod 8) run on
-// workgroup ids = x (mod 8), i.e. on one XCD, the groups of a window next to each other: the runs the groups write
-// into a list are adjacent, and their shared edge lines meet in that XCD's L2.
-__global__ __launch_bounds__(256) void build_scatter_kernel(uint64_t nq, uint32_t n_windows, uint32_t B,
+// pass 2b: workgroup (window w, group g) counting-sorts the entries of its row blocks by list in LDS (at most
+// BR_SORT_CAP at a time) and writes every list's run with consecutive lanes at post_off[j] + (postings of j in earlier row
+// blocks) + (what earlier batches of this workgroup put there).  Windows w = x (mod 8) run on workgroup ids = x (mod 8),
+// i.e. on one XCD, the groups of a window next to each other: the runs that neighbouring groups write into a list are
+// adjacent, and the lines they share meet in that XCD's L2.
+__global__ __launch_bounds__(512) void build_scatter_kernel(uint64_t nq, uint32_t n_windows, uint32_t B,
                                                             const uint32_t* __restrict__ partial,
                                                             const uint64_t* __restrict__ post_off,
                                                             const uint32_t* __restrict__ subcnt,
                                                             const uint32_t* __restrict__ inter_off,
                                                             const uint32_t* __restrict__ inter, uint32_t* __restrict__ post_rows) {
-    __shared__ uint32_t s_cur[BR_SUB];
+    __shared__ uint32_t s_sorted[BR_SORT_CAP];
+    __shared__ uint32_t s_cnt[BR_SUB], s_start[BR_SUB], s_fill[BR_SUB], s_cur[BR_SUB];
+    __shared__ uint32_t s_pre[BR_GROUPS * 8 + 1], s_src[BR_GROUPS * 8];     // flat entry index -> region (at most 64 row blocks per group)
     const uint32_t q = blockIdx.x >> 3, x = blockIdx.x & 7u;
     const uint32_t w = (q / BR_GROUPS) * 8u + x, g = q % BR_GROUPS;
     if (w >= n_windows) return;
@@ -353,18 +285,66 @@ __global__ __launch_bounds__(256) void build_scatter_kernel(uint64_t nq, uint32_
     const uint32_t per = (B + BR_GROUPS - 1) / BR_GROUPS;
     const uint32_t b_lo = g * per, b_hi = b_lo + per < B ? b_lo + per : B;
     if (b_lo >= B) return;
+    const uint32_t nb = b_hi - b_lo;                                 // <= 64 (B <= 512 is enforced by the host)
     const uint64_t wbase = post_off[j0];
-    for (uint32_t k = threadIdx.x; k < nl; k += blockDim.x)
-        s_cur[k] = (uint32_t)(post_off[j0 + k] - wbase) + partial[(uint64_t)b_lo * nq + j0 + k];
-    __syncthreads();
-    for (uint32_t b = b_lo; b < b_hi; ++b) {
-        const uint32_t n = subcnt[(uint64_t)w * B + b];
-        const uint32_t* src = inter + inter_off[(uint64_t)w * B + b];
-        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
-            const uint32_t e = src[i];
-            const uint32_t slot = atomicAdd(&s_cur[e & (BR_SUB - 1)], 1u);
-            post_rows[wbase + slot] = e >> 9;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (uint32_t k = tid; k < (uint32_t)BR_SUB; k += blockDim.x)
+        s_cur[k] = k < nl ? (uint32_t)(post_off[j0 + k] - wbase) + partial[(uint64_t)b_lo * nq + j0 + k] : 0u;
+    if (tid == 0) {
+        uint32_t run = 0;
+        for (uint32_t i = 0; i < nb; ++i) {
+            s_pre[i] = run;
+            s_src[i] = inter_off[(uint64_t)w * B + b_lo + i];
+            run += subcnt[(uint64_t)w * B + b_lo + i];
         }
+        s_pre[nb] = run;
+    }
+    __syncthreads();
+    const uint32_t total = s_pre[nb];
+    for (uint32_t f0 = 0; f0 < total; f0 += BR_SORT_CAP) {
+        const uint32_t f1 = f0 + BR_SORT_CAP < total ? f0 + BR_SORT_CAP : total;
+        for (uint32_t k = tid; k < (uint32_t)BR_SUB; k += blockDim.x) s_cnt[k] = 0;
+        __syncthreads();
+        // histogram of the batch by list
+        uint32_t reg = 0;
+        for (uint32_t f = f0 + tid; f < f1; f += blockDim.x) {
+            while (f >= s_pre[reg + 1]) ++reg;
+            atomicAdd(&s_cnt[inter[(uint64_t)s_src[reg] + (f - s_pre[reg])] & (BR_SUB - 1)], 1u);
+        }
+        __syncthreads();
+        if (wave == 0) {                                            // exclusive scan of BR_SUB counts by one wave
+            uint32_t carry = 0;
+            for (int base = 0; base < BR_SUB; base += 64) {
+                const uint32_t v = s_cnt[base + lane];
+                uint32_t incl = v;
+#pragma unroll
+                for (int d = 1; d < 64; d <<= 1) {
+                    const uint32_t o = __shfl_up(incl, d);
+                    if (lane >= d) incl += o;
+                }
+                s_start[base + lane] = carry + incl - v;
+                s_fill[base + lane] = carry + incl - v;
+                carry += __shfl(incl, 63);
+            }
+        }
+        __syncthreads();
+        // placement (the batch is read again: it is still in L2)
+        reg = 0;
+        for (uint32_t f = f0 + tid; f < f1; f += blockDim.x) {
+            while (f >= s_pre[reg + 1]) ++reg;
+            const uint32_t e = inter[(uint64_t)s_src[reg] + (f - s_pre[reg])];
+            s_sorted[atomicAdd(&s_fill[e & (BR_SUB - 1)], 1u)] = e >> BR_SUB_BITS;
+        }
+        __syncthreads();
+        // every list's run goes out with consecutive lanes
+        for (uint32_t jl = wave; jl < nl; jl += blockDim.x >> 6) {
+            const uint32_t n = s_cnt[jl], from = s_start[jl];
+            const uint64_t to = wbase + s_cur[jl];
+            for (uint32_t i = lane; i < n; i += 64) post_rows[to + i] = s_sorted[from + i];
+        }
+        __syncthreads();
+        for (uint32_t k = tid; k < (uint32_t)BR_SUB; k += blockDim.x) s_cur[k] += s_cnt[k];
+        __syncthreads();
     }
 }
 
@@ -824,7 +804,7 @@ unsigned blocks_for_rows(uint64_t ndb) {
 
 }  // namespace
 
-static QIndex qindex_of(const GatherDev& g) { return QIndex{g.q_padded, g.nq, g.q_table, g.q_shift, g.q_max}; }
+static QIndex qindex_of(const GatherDev& g) { return QIndex{g.q_padded, g.nq, g.q_table, g.q_shift, g.q_max, g.q_rec}; }
 
 #define SMG_TRY(expr)                      \
     do {                                   \
@@ -833,7 +813,7 @@ static QIndex qindex_of(const GatherDev& g) { return QIndex{g.q_padded, g.nq, g.
     } while (0)
 
 void gather_destroy(GatherDev& g) {
-    void* owned[] = {g.q_padded, g.q_table, g.alive, g.post_off, g.post_rows, g.qpos, g.counters, g.state, g.partials, g.out_idx, g.out_isect,
+    void* owned[] = {g.q_padded, g.q_table, g.q_rec, g.alive, g.post_off, g.post_rows, g.qpos, g.counters, g.state, g.partials, g.out_idx, g.out_isect,
                      g.topk_sel, g.topk_partials, g.cmask, g.cand_count, g.cand_key, g.cand_len, g.cand_qpos, g.own_cands};
     for (void* p : owned)
         if (p) (void)hipFree(p);
@@ -875,6 +855,11 @@ hipError_t gather_build(GatherDev& g, hipStream_t stream) {
     hipLaunchKernelGGL(qtable_kernel, dim3((g.q_buckets + 256) / 256), dim3(256), 0, stream, g.Q, g.nq, g.q_shift,
                        g.q_buckets, g.q_table);
     SMG_TRY(hipGetLastError());
+    if (g.nq && !getenv("SMG_GATHER_NO_QREC")) {
+        SMG_TRY(hipMalloc(&g.q_rec, (uint64_t)g.q_buckets * sizeof(QRec)));
+        hipLaunchKernelGGL(qrec_kernel, dim3((g.q_buckets + 255) / 256), dim3(256), 0, stream, g.Q, g.q_table, g.q_buckets, g.q_rec);
+        SMG_TRY(hipGetLastError());
+    }
     if (g.ndb == 0 || total == 0 || g.nq == 0) {
         SMG_TRY(hipMemsetAsync(g.post_off, 0, nq1 * 8, stream));
         g.npairs = 0;
@@ -928,7 +913,7 @@ hipError_t gather_build(GatherDev& g, hipStream_t stream) {
         hipLaunchKernelGGL(build_bounds_kernel, dim3(blocks_for_rows(g.ndb)), dim3(256), 0, stream, g.Q, R, g.hashes,
                            g.offsets, g.ndb, bounds);
         SMG_TRY(hipGetLastError());
-        // two-level fill unless forced off or its packing does not apply (entries hold the row in 23 bits, offsets in 32)
+        // two-level fill unless forced off or its packing does not apply (entries hold the row in 24 bits, offsets in 32)
         const char* fill_env = getenv("SMG_GATHER_FILL");
         const uint32_t n_windows = R * BR_NSUB;
         bool staged = !(fill_env && !strcmp(fill_env, "direct")) && g.ndb < (1ull << BR_ROWBITS);
@@ -949,21 +934,25 @@ hipError_t gather_build(GatherDev& g, hipStream_t stream) {
         SMG_TRY(rocprim::exclusive_scan(scan_tmp, scan_bytes, (uint64_t*)post_cnt, g.post_off, (uint64_t)0, (size_t)nq1,
                                         rocprim::plus<uint64_t>(), stream));
         SMG_TRY(hipMemcpyAsync(&g.npairs, g.post_off + g.nq, 8, hipMemcpyDeviceToHost, stream));
+        void* lay_tmp = nullptr;
         if (staged) {
-            hipLaunchKernelGGL(inter_layout_kernel, dim3(1), dim3(1024), 0, stream, subcnt, n_windows, (uint32_t)B, inter_off);
-            SMG_TRY(hipGetLastError());
+            // region of (window, row block) in the intermediate buffer: exclusive scan of the exact counts, window-major
+            size_t lay_bytes = 0;
+            SMG_TRY(rocprim::exclusive_scan(nullptr, lay_bytes, subcnt, inter_off, 0u, (size_t)n_windows * B, rocprim::plus<uint32_t>(), stream));
+            SMG_TRY(hipMallocAsync(&lay_tmp, lay_bytes + 256, stream));
+            SMG_TRY(rocprim::exclusive_scan(lay_tmp, lay_bytes, subcnt, inter_off, 0u, (size_t)n_windows * B, rocprim::plus<uint32_t>(), stream));
         }
         SMG_TRY(hipStreamSynchronize(stream));
         SMG_TRY(hipMalloc(&g.post_rows, (g.npairs + 4) * 4));
-        const uint64_t inter_words = g.npairs + (uint64_t)n_windows * B * (BR_CHUNK - 1) + BR_CHUNK;
-        if (staged && inter_words >= 0xffffffffull) staged = false;
+        const uint64_t inter_words = g.npairs + 4;
+        if (staged && (inter_words >= 0xffffffffull || B > 512)) staged = false;
         if (staged) {
             SMG_TRY(hipMallocAsync((void**)&inter, inter_words * 4, stream));
             hipLaunchKernelGGL(build_range_kernel<2>, dim3(range_grid), dim3(BR_THREADS), 0, stream, qi, g.hashes, g.offsets,
                                g.ndb, bounds, R, (uint32_t)B, rows_per_block, partial, (const uint64_t*)nullptr, (uint32_t*)nullptr,
                                g.counters, g.qpos, (uint32_t*)nullptr, (const uint32_t*)inter_off, inter);
             SMG_TRY(hipGetLastError());
-            hipLaunchKernelGGL(build_scatter_kernel, dim3((unsigned)((n_windows + 7) / 8 * 8 * BR_GROUPS)), dim3(256), 0, stream, g.nq,
+            hipLaunchKernelGGL(build_scatter_kernel, dim3((unsigned)((n_windows + 7) / 8 * 8 * BR_GROUPS)), dim3(512), 0, stream, g.nq,
                                n_windows, (uint32_t)B, (const uint32_t*)partial, (const uint64_t*)g.post_off, (const uint32_t*)subcnt,
                                (const uint32_t*)inter_off, (const uint32_t*)inter, g.post_rows);
             SMG_TRY(hipGetLastError());
@@ -981,6 +970,7 @@ hipError_t gather_build(GatherDev& g, hipStream_t stream) {
                                (uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr);
             SMG_TRY(hipGetLastError());
         }
+        if (lay_tmp) SMG_TRY(hipFreeAsync(lay_tmp, stream));
         if (subcnt) SMG_TRY(hipFreeAsync(subcnt, stream));
         if (inter_off) SMG_TRY(hipFreeAsync(inter_off, stream));
         SMG_TRY(hipFreeAsync(bounds, stream));
@@ -1171,14 +1161,18 @@ hipError_t overlap_ranges_launch(const uint64_t* Q, uint64_t nq, const uint64_t*
     for (int i = 0; i < 4; ++i) SMG_TRY(hipMemcpyAsync(q_padded + nq + i, Q + nq - 1, 8, hipMemcpyDeviceToDevice, stream));
     SMG_TRY(hipMemsetAsync(cnt, 0, ndb * 8, stream));
     hipLaunchKernelGGL(qtable_kernel, dim3((buckets + 256) / 256), dim3(256), 0, stream, Q, nq, shift, buckets, table);
+    QRec* rec = nullptr;
+    SMG_TRY(hipMallocAsync((void**)&rec, (uint64_t)buckets * sizeof(QRec), stream));
+    hipLaunchKernelGGL(qrec_kernel, dim3((buckets + 255) / 256), dim3(256), 0, stream, Q, (const uint32_t*)table, buckets, rec);
     hipLaunchKernelGGL(build_bounds_kernel, dim3(blocks_for_rows(ndb)), dim3(256), 0, stream, Q, R, hashes, offsets, ndb, bounds);
-    const QIndex qi{q_padded, nq, table, shift, q_max};
+    const QIndex qi{q_padded, nq, table, shift, q_max, rec};
     hipLaunchKernelGGL(build_range_kernel<3>, dim3((unsigned)(((R + 7) / 8) * 8 * B)), dim3(BR_THREADS), 0, stream, qi, hashes, offsets,
                        ndb, (const uint32_t*)bounds, R, (uint32_t)B, rows_per_block, (uint32_t*)nullptr, (const uint64_t*)nullptr,
                        (uint32_t*)nullptr, cnt, (uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr);
     hipLaunchKernelGGL(overlap_finish_kernel, dim3((unsigned)((ndb + 255) / 256)), dim3(256), 0, stream, cnt, ndb, overlap, op);
     const hipError_t e = hipGetLastError();
     (void)hipFreeAsync(q_padded, stream);
+    (void)hipFreeAsync(rec, stream);
     (void)hipFreeAsync(table, stream);
     (void)hipFreeAsync(bounds, stream);
     (void)hipFreeAsync(cnt, stream);

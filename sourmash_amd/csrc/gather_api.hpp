@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>
+#include "qindex.hpp"
 
 namespace smg {
 
@@ -33,6 +34,7 @@ struct GatherDev {
     // owned
     uint64_t* q_padded = nullptr;       // copy of Q followed by 4 copies of its last element (lookups read 4 entries at once)
     uint32_t* q_table = nullptr;        // [q_buckets + 1] first-level table over Q: bucket b = x >> q_shift
+    QRec* q_rec = nullptr;              // [q_buckets] bucket records (position, count, first three hashes inline): lookups read these
     uint32_t q_shift = 0, q_buckets = 1;
     uint64_t q_max = 0;                 // Q[nq - 1]
     uint8_t* alive = nullptr;           // [nq] 1 while the query hash is uncovered

@@ -370,7 +370,10 @@ inline void sketch_file_with(IngestWorker& w, std::vector<KmerMinHash*>& mhs, co
             const size_t expect = std::min(slen, (size_t)((double)slen * frac * 1.5 + 8.0 * std::sqrt((double)slen * frac + 1.0)) + 4096);
             if (a.count > a.cap) throw err_internal("sketch output overflow while ingesting " + path);
             if (a.count && (mh.num != 0 || a.count + expect > FLUSH_AT)) flush(s);
-            const size_t need = (size_t)a.count + expect;
+            // Capacity covers the worst case -- every k-mer of the chunk kept (the count depends on multiplicity, not on
+            // distinct k-mers: deep amplicon reads, a long tandem repeat under max_hash) -- so a launch can never
+            // overflow; the statistical estimate above only decides when to flush.  8 bytes per chunk byte per sketch.
+            const size_t need = (size_t)a.count + std::max(expect, slen - (size_t)(k - 1));
             if (need > a.cap) {
                 const size_t ncap = std::max(need + need / 2, (size_t)1 << 16);
                 void* bigger = nullptr;
@@ -406,7 +409,8 @@ inline void sketch_file_into(std::vector<KmerMinHash*>& mhs, const std::string& 
                              uint64_t* n_bases) {
     DeviceCtx& ctx = DeviceCtx::get();
     std::lock_guard<std::mutex> g(ctx.mutex());
-    static IngestWorker shared;                     // guarded by the context mutex
+    static IngestWorker& shared = *new IngestWorker();   // guarded by the context mutex; leaked on purpose like the
+                                                         // context (its pinned buffers must not be freed after HIP is gone)
     shared.stream = ctx.stream();
     // 32 MiB chunks; SMG_INGEST_CHUNK (bytes) overrides it so tests can force many chunk boundaries
     size_t chunk = (size_t)32 << 20;

@@ -42,20 +42,23 @@ struct KmerMinHash {
     bool track_abundance = false;
     std::vector<uint64_t> mins;
     std::vector<uint64_t> abunds;   // parallel to mins iff track_abundance
+    // DNA records handed to add_sequence and not hashed yet (each followed by a '\n', which no k-mer may span): the C-ABI
+    // layer runs them through the sketch kernel in one launch when the state is next looked at (capi.cpp: settle)
+    mutable std::string pending;
 
     KmerMinHash() = default;
     // minhash.rs:186-221
     KmerMinHash(uint64_t scaled, uint32_t k, uint32_t hf, uint64_t seed_, bool track, uint32_t n)
         : num(n), ksize(k), hash_function(hf), seed(seed_), max_hash(max_hash_for_scaled(scaled)),
           track_abundance(track) {
-        mins.reserve(n > 0 ? n : 1000);
+        mins.reserve(n > 0 ? (n < (1u << 20) ? n : (1u << 20)) : 1000);   // a caller-chosen n must not decide an allocation
     }
 
     uint64_t scaled() const { return scaled_for_max_hash(max_hash); }
     size_t size() const { return mins.size(); }
     bool is_dna() const { return hash_function == HF_DNA; }
 
-    void clear() { mins.clear(); abunds.clear(); }   // minhash.rs:239-244
+    void clear() { mins.clear(); abunds.clear(); pending.clear(); }   // minhash.rs:239-244
 
     // minhash.rs:406-416
     void remove_hash(uint64_t h) {

@@ -109,6 +109,7 @@ __global__ __launch_bounds__(256) void qindex_setup_kernel(const uint64_t* __res
         h->qi.nq = nq;
         h->qi.T = reinterpret_cast<const uint32_t*>(pad + nq + 4);
         h->qi.qmax = qmax;
+        h->qi.rec = nullptr;                                        // this one-pass form keeps the two-level lookup
         qindex_geometry(nq, qmax, &h->qi.shift, &h->buckets);
     }
 }

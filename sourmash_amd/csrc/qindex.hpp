@@ -10,12 +10,22 @@ constexpr uint32_t NONE32 = 0xffffffffu;
 
 // first-level table over the sorted query: bucket b = x >> shift covers Q[T[b], T[b+1]).  Q must be followed by 4
 // readable entries (owners keep a padded copy), T has buckets + 1 entries, buckets = (qmax >> shift) + 1.
+// One 32-byte record per bucket: where the bucket starts in Q, how many query hashes it holds, and the first three of
+// them inline.  With about one hash per bucket a lookup is then ONE dependent step -- two independent 16-byte loads from
+// the same record -- instead of table entry -> query entries; fuller buckets (2 % at one hash per bucket on average)
+// finish with a binary search in Q.
+struct __attribute__((aligned(32))) QRec {
+    uint32_t pos, cnt;
+    uint64_t h[3];
+};
+
 struct QIndex {
     const uint64_t* Q;
     uint64_t nq;
     const uint32_t* T;
     uint32_t shift;
     uint64_t qmax;
+    const QRec* rec = nullptr;       // optional (owners that look up many times build it); q_find prefers it
 };
 
 // table geometry for nq hashes whose largest is q_max: about one hash per bucket (never more than 2 * nq + 1 buckets)
@@ -52,8 +62,31 @@ __device__ __forceinline__ void load_u64_quad(const uint64_t* p, uint64_t& a, ui
 // (table pair, two halves of the bucket): every lane of a lookup goes to a different cache line, and a CU serves such
 // loads at about one line per cycle, so the number of load INSTRUCTIONS is what a lookup costs.
 // Fuller buckets finish with a binary search.
+__device__ __forceinline__ uint32_t q_find_rec(const QIndex& qi, uint64_t x) {
+    const QRec* r = qi.rec + (x >> qi.shift);
+    u32x4_t v0, v1;
+    asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:16\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(v0), "=&v"(v1) : "v"(r) : "memory");
+    const uint32_t pos = v0.x, cnt = v0.y;
+    const uint64_t h0 = (uint64_t)v0.z | ((uint64_t)v0.w << 32), h1 = (uint64_t)v1.x | ((uint64_t)v1.y << 32),
+                   h2 = (uint64_t)v1.z | ((uint64_t)v1.w << 32);
+    if (cnt == 0) return NONE32;
+    if (h0 == x) return pos;
+    if (cnt > 1 && h1 == x) return pos + 1;
+    if (cnt > 2 && h2 == x) return pos + 2;
+    if (cnt <= 3) return NONE32;
+    uint32_t l = pos + 3, h = pos + cnt;
+    const uint32_t end = h;
+    while (l < h) {
+        const uint32_t mid = (l + h) >> 1;
+        if (qi.Q[mid] < x) l = mid + 1; else h = mid;
+    }
+    return (l < end && qi.Q[l] == x) ? l : NONE32;
+}
+
 __device__ __forceinline__ uint32_t q_find(const QIndex& qi, uint64_t x) {
     if (x > qi.qmax) return NONE32;
+    if (qi.rec) return q_find_rec(qi, x);
     uint32_t lo, hi;
     load_u32_pair(qi.T + (x >> qi.shift), lo, hi);
     if (lo == hi) return NONE32;
@@ -85,6 +118,18 @@ __device__ __forceinline__ void qindex_fill_bucket(const uint64_t* __restrict__ 
         if (Q[mid] < x) lo = mid + 1; else hi = mid;
     }
     T[b] = (uint32_t)lo;
+}
+
+// rec[b] from the finished table: bucket b covers Q[T[b], T[b+1])
+__device__ __forceinline__ void qindex_fill_record(const uint64_t* __restrict__ Q, const uint32_t* __restrict__ T,
+                                                   uint32_t n_buckets, QRec* __restrict__ rec, uint32_t b) {
+    if (b >= n_buckets) return;
+    const uint32_t pos = T[b], cnt = T[b + 1] - pos;
+    QRec r;
+    r.pos = pos;
+    r.cnt = cnt;
+    for (int i = 0; i < 3; ++i) r.h[i] = (uint32_t)i < cnt ? Q[pos + i] : 0ull;
+    rec[b] = r;
 }
 
 }  // namespace smg

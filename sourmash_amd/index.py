@@ -16,7 +16,6 @@ import ctypes as C
 import io
 import math
 import os
-import zipfile
 from collections import Counter, namedtuple
 
 import numpy as np
@@ -26,10 +25,8 @@ from .minhash import flatten_and_downsample_num, flatten_and_downsample_scaled, 
 from .search import calc_threshold_from_bp, make_containment_query, make_jaccard_search_query
 from .signature import SourmashSignature, load_signatures_from_json, save_signatures_to_json
 from .utils import RustObject, decode_str, rustcall
-from .manifest import CollectionManifest
 
-__all__ = ["IndexSearchResult", "Collection", "SketchSet", "select_signature", "Index", "LinearIndex", "LazyLinearIndex",
-           "ZipStorage", "ZipFileLinearIndex", "MultiIndex", "StandaloneManifestIndex", "CounterGather"]
+__all__ = ["IndexSearchResult", "Collection", "SketchSet", "select_signature", "Index", "LinearIndex", "CounterGather"]
 
 IndexSearchResult = namedtuple("Result", "score, signature, location")
 
@@ -516,470 +513,6 @@ class LinearIndex(Index):
         return self._packed[1], self._packed[2]
 
 
-class LazyLinearIndex(Index):
-    """Wraps another index: selection is remembered and applied only when signatures are asked for, and search is
-    always the linear (batched) `find` of the base class (index/__init__.py:456-526)."""
-
-    def __init__(self, db, selection_dict={}):
-        self.db = db
-        self.selection_dict = dict(selection_dict)
-
-    def signatures(self):
-        yield from self.db.select(**self.selection_dict).signatures()
-
-    def signatures_with_location(self):
-        yield from self.db.select(**self.selection_dict).signatures_with_location()
-
-    def __bool__(self):
-        return next(iter(self.signatures()), None) is not None
-
-    def __len__(self):
-        return len(self.db.select(**self.selection_dict))
-
-    def select(self, **kwargs):
-        _check_select_parameters(**kwargs)
-        merged = dict(self.selection_dict)
-        for k, v in kwargs.items():
-            if k in merged and merged[k] != v:
-                raise ValueError(f"cannot select on two different values for {k}")
-            merged[k] = v
-        return LazyLinearIndex(self.db, merged)
-
-
-class ZipStorage:
-    """Members of one zip file by name (the part of src/sourmash/sbt_storage.py:96-330 that collections of
-    signatures use).  mode 'r': read only.  mode 'w': create, or add to an existing file -- a member saved under a
-    name that already holds different content gets the next free `name_N`; replaced members (the manifest) take
-    effect when the storage is closed."""
-
-    def __init__(self, path, *, mode="r"):
-        self.path = os.path.abspath(path)
-        self.mode = mode
-        self._added = {}                                      # name -> (bytes, deflate?)  written at close()
-        if mode == "w" and not os.path.exists(self.path):
-            os.makedirs(os.path.dirname(self.path), exist_ok=True)
-            self._zf = None
-            names = []
-        else:
-            self._zf = zipfile.ZipFile(self.path, "r")
-            names = self._zf.namelist()
-        subdirs = [n for n in names if n.endswith("/")]
-        self.subdir = subdirs[0] if len(subdirs) == 1 else ""
-
-    @staticmethod
-    def can_open(location):
-        return zipfile.is_zipfile(location)
-
-    def _filenames(self):
-        names = self._zf.namelist() if self._zf is not None else []
-        return names + [n for n in self._added if n not in names]
-
-    def _read(self, name):
-        if name in self._added:
-            return self._added[name][0]
-        if self._zf is None:
-            raise KeyError(name)
-        return self._zf.read(name)
-
-    def load(self, path):
-        try:
-            return self._read(path)
-        except KeyError:
-            try:
-                return self._read(os.path.join(self.subdir, path))
-            except KeyError:
-                raise FileNotFoundError(path) from None
-
-    def save(self, path, content, *, overwrite=False, compress=False):
-        if self.mode != "w":
-            raise NotImplementedError("storage opened read-only")
-        name = path
-        if not overwrite:
-            n = 0
-            while True:
-                try:
-                    if self._read(name) == content:
-                        return name                         # same bytes already stored under this name
-                except KeyError:
-                    break
-                name = f"{path}_{n}"
-                n += 1
-        self._added[name] = (bytes(content), compress)
-        return name
-
-    def flush(self):
-        pass
-
-    def close(self):
-        if self.mode != "w" or not self._added:
-            if self._zf is not None:
-                self._zf.close()
-                self._zf = None
-            return
-        old = self._zf
-        tmp = self.path + ".tmp"
-        with zipfile.ZipFile(tmp, "w", compression=zipfile.ZIP_STORED) as out:
-            if old is not None:
-                for info in old.infolist():
-                    if info.filename not in self._added:
-                        out.writestr(info, old.read(info), compress_type=info.compress_type)
-            for name, (content, deflate) in self._added.items():
-                zi = zipfile.ZipInfo(name)
-                zi.external_attr = (0o755 if name.endswith("/") else 0o444) << 16
-                out.writestr(zi, content, compress_type=zipfile.ZIP_DEFLATED if deflate else zipfile.ZIP_STORED)
-        if old is not None:
-            old.close()
-        os.replace(tmp, self.path)
-        self._zf = zipfile.ZipFile(self.path, "r")
-        self._added = {}
-
-    def __enter__(self):
-        return self
-
-    def __exit__(self, *exc):
-        self.close()
-
-
-class ZipFileLinearIndex(Index):
-    """A read-only collection of signatures in a zip file, selected through its manifest when it has one and
-    loaded from the archive on demand (index/__init__.py:529-732)."""
-    is_database = True
-
-    def __init__(self, storage, *, selection_dict=None, traverse_yield_all=False, manifest=None, use_manifest=True):
-        self.storage = storage
-        self.selection_dict = selection_dict
-        self.traverse_yield_all = traverse_yield_all
-        self.use_manifest = use_manifest
-        self.manifest = None
-        if use_manifest:
-            self.manifest = manifest if manifest is not None else self._load_manifest()
-        if self.manifest is not None:
-            assert not self.selection_dict, self.selection_dict
-        if self.selection_dict:
-            assert self.manifest is None
-
-    def _load_manifest(self):
-        try:
-            data = self.storage.load("SOURMASH-MANIFEST.csv")
-        except (KeyError, FileNotFoundError):
-            return None
-        return CollectionManifest.load_from_csv(io.StringIO(data.decode("utf-8"), newline=""))
-
-    def __bool__(self):
-        return next(iter(self.signatures()), None) is not None
-
-    def __len__(self):
-        if self.manifest is not None:
-            return len(self.manifest)
-        return sum(1 for _ in self.signatures())
-
-    @property
-    def location(self):
-        return self.storage.path
-
-    @classmethod
-    def load(cls, location, traverse_yield_all=False, use_manifest=True):
-        if not os.path.exists(location):
-            raise FileNotFoundError(location)
-        return cls(ZipStorage(location), traverse_yield_all=traverse_yield_all, use_manifest=use_manifest)
-
-    def _member_names(self):
-        for name in self.storage._filenames():
-            if name.endswith(".sig") or name.endswith(".sig.gz") or self.traverse_yield_all:
-                yield name
-
-    def _signatures_with_internal(self):
-        for name in self._member_names():
-            for ss in load_signatures_from_json(self.storage.load(name)):
-                yield ss, name
-
-    def signatures(self):
-        if self.manifest is not None:
-            assert not self.selection_dict
-            for name in self.manifest.locations():
-                for ss in load_signatures_from_json(self.storage.load(name)):
-                    if ss in self.manifest:               # a member may hold more sketches than were selected
-                        yield ss
-            return
-        sel = self.selection_dict
-        for name in self._member_names():
-            for ss in load_signatures_from_json(self.storage.load(name)):
-                if not sel or select_signature(ss, **sel):
-                    yield ss
-
-    # ---- search: the archive goes to HBM once, signatures are materialised for the matches only --------------
-    _bulk_cache = None
-
-    def _bulk(self, query_mh):
-        """(SketchSet, sizes, rows per member) of the selected sketches, parsed by the native reader straight into one
-        CSR in HBM (no signature objects) and downsampled to the query's scaled; kept for the next query.  None when
-        the rows cannot share one CSR with this query (num sketches, a coarser scaled, another ksize or molecule
-        type) -- the per-signature walk of the base class handles, or rejects, those exactly like the reference."""
-        m = self.manifest
-        qs = query_mh.scaled
-        if m is None or not qs or not m.rows:
-            return None
-        ksize, moltype = query_mh.ksize, query_mh.moltype
-        for row in m.rows:
-            if row["num"] or not row["scaled"] or row["scaled"] > qs or row["ksize"] != ksize or row["moltype"] != moltype:
-                return None
-        if self._bulk_cache is None or self._bulk_cache[0] != (qs, ksize, moltype):
-            sset = SketchSet.load([self.storage.path], ksize=ksize, moltype=moltype, scaled=qs)
-            by_member = {}
-            for r, row in enumerate(sset.manifest):
-                by_member.setdefault(row["internal_location"], []).append(r)
-            # the order of signatures(): members as the manifest lists them, then the selected sketches within each
-            wanted = m._md5_set
-            walk = [r for member in m.locations() for r in by_member.get(member, ()) if sset.manifest[r]["md5"] in wanted]
-            self._bulk_cache = ((qs, ksize, moltype), sset, sset.sizes, np.asarray(walk, dtype=np.int64))
-        return self._bulk_cache[1:]
-
-    def find(self, search_fn, query, **kwargs):
-        search_fn.check_is_compatible(query)
-        query_mh = query.minhash
-        assert not query_mh.track_abundance
-        bulk = self._bulk(query_mh)
-        if bulk is None:
-            yield from Index.find(self, search_fn, query, **kwargs)
-            return
-        sset, sizes, walk = bulk
-        shared = sset.overlaps(query_mh)
-        q_size = len(query_mh)
-        if _zero_overlap_never_matches(search_fn, q_size):
-            walk = walk[shared[walk] > 0]                     # most of a large database: nothing to score, nothing to load
-        rows = sset.manifest
-        loaded_member, loaded = None, None
-        for r in walk.tolist():
-            n_shared, s_size = int(shared[r]), int(sizes[r])
-            score = search_fn.score_fn(q_size, n_shared, s_size, q_size + s_size - n_shared)
-            if not search_fn.passes(score):
-                continue
-            member, md5 = rows[r]["internal_location"], rows[r]["md5"]
-            if member != loaded_member:                      # signatures are materialised for the matches only
-                loaded = {ss.md5sum(): ss for ss in load_signatures_from_json(self.storage.load(member))}
-                loaded_member = member
-            if search_fn.collect(score, loaded[md5]):
-                yield IndexSearchResult(score, loaded[md5], self.location)
-
-    def counter_gather(self, query, threshold_bp, **kwargs):
-        """The reference prefetches and adds every match to a CounterGather, one signature object each
-        (index/__init__.py:302-320).  Here the prefetch is the overlap pass over the resident CSR, the matching rows are
-        gathered into their own CSR on the device, and the counter reads signatures from the archive only when a
-        round returns one."""
-        prefetch_query = query.to_mutable()
-        prefetch_query.minhash = prefetch_query.minhash.flatten()
-        bulk = self._bulk(prefetch_query.minhash)
-        if bulk is None:
-            return Index.counter_gather(self, query, threshold_bp, **kwargs)
-        if not self:
-            raise ValueError("no signatures to search")
-        sset, sizes, walk = bulk
-        query_mh = prefetch_query.minhash
-        search_fn = make_containment_query(query_mh, threshold_bp, best_only=kwargs.get("best_only", False))
-        search_fn.check_is_compatible(prefetch_query)
-        shared = sset.overlaps(query_mh)
-        q_size = len(query_mh)
-        walk = walk[shared[walk] > 0]
-        keep = [r for r in walk.tolist()
-                if search_fn.passes(search_fn.score_fn(q_size, int(shared[r]), int(sizes[r]), q_size + int(sizes[r]) - int(shared[r])))]
-        return _ArchiveCounterGather(prefetch_query, self, sset, keep)
-
-    def select(self, **kwargs):
-        _check_select_parameters(**kwargs)
-        if self.manifest is not None:
-            return ZipFileLinearIndex(self.storage, selection_dict=None, traverse_yield_all=self.traverse_yield_all,
-                                      manifest=self.manifest.select_to_manifest(**kwargs), use_manifest=True)
-        if self.selection_dict:
-            merged = dict(self.selection_dict)
-            for k, v in kwargs.items():
-                if k in merged and merged[k] is not None and merged[k] != v:
-                    raise ValueError(f"incompatible select on '{k}'")
-                merged[k] = v
-            kwargs = merged
-        return ZipFileLinearIndex(self.storage, selection_dict=kwargs, traverse_yield_all=self.traverse_yield_all,
-                                  manifest=None, use_manifest=False)
-
-
-def traverse_find_sigs(filenames, yield_all_files=False):
-    "every .sig / .sig.gz file in and beneath `filenames` (all files when asked); sourmash_args.py:275-295"
-    def wanted(name):
-        return yield_all_files or name.endswith((".sig", ".sig.gz"))
-    for filename in filenames:
-        if os.path.isfile(filename):
-            if wanted(filename):
-                yield filename
-        elif os.path.isdir(filename):
-            for root, _dirs, files in os.walk(filename):
-                for name in sorted(files):
-                    if wanted(os.path.join(root, name)):
-                        yield os.path.join(root, name)
-
-
-def load_pathlist_from_file(filename):
-    "a text file of paths, one per line, all of which must exist (sourmash_args.py:380-399)"
-    try:
-        with open(filename) as fp:
-            file_list = set(x.rstrip("\r\n") for x in fp)
-    except OSError:
-        raise ValueError(f"pathlist file '{filename}' does not exist")
-    except UnicodeDecodeError:
-        raise ValueError(f"cannot parse file '{filename}' as list of filenames")
-    if not file_list:
-        raise ValueError("pathlist is empty")
-    for checkfile in file_list:
-        if not os.path.exists(checkfile):
-            raise ValueError(f"file '{checkfile}' inside the pathlist does not exist")
-    return file_list
-
-
-class MultiIndex(Index):
-    """Signatures gathered from several indices or files, kept in memory inside a manifest that remembers where each
-    one came from (index/__init__.py:910-1125)."""
-
-    def __init__(self, manifest, parent, *, prepend_location=False):
-        if prepend_location and parent is None:
-            raise ValueError("must set 'parent' if 'prepend_location' is set")
-        self.manifest = manifest
-        self.parent = parent
-        self.prepend_location = prepend_location
-
-    @property
-    def location(self):
-        return self.parent
-
-    def signatures(self):
-        for row in self.manifest.rows:
-            yield row["signature"]
-
-    def signatures_with_location(self):
-        for row in self.manifest.rows:
-            loc = row["internal_location"]
-            yield row["signature"], (os.path.join(self.parent, loc) if self.prepend_location else loc)
-
-    def _signatures_with_internal(self):
-        for row in self.manifest.rows:
-            yield row["signature"], row["internal_location"]
-
-    def __len__(self):
-        return 0 if self.manifest is None else len(self.manifest)
-
-    _packed = None
-
-    def _subject_set(self, query_scaled, items):
-        "the manifest never changes after construction: keep the device CSR between queries of the same scaled"
-        key = (query_scaled, len(items))
-        if self._packed is None or self._packed[0] != key:
-            self._packed = (key,) + Index._subject_set(self, query_scaled, items)
-        return self._packed[1], self._packed[2]
-
-    @classmethod
-    def load(cls, index_list, source_list, parent, *, prepend_location=False):
-        "from loaded indices and as many sources; a source of None keeps the index's own location"
-        assert len(index_list) == len(source_list)
-
-        def sigloc_iter():
-            for idx, iloc in zip(index_list, source_list):
-                for ss in idx.signatures():
-                    yield ss, (idx.location if iloc is None else iloc)
-        return cls(CollectionManifest.create_manifest(sigloc_iter()), parent, prepend_location=prepend_location)
-
-    @classmethod
-    def load_from_directory(cls, pathname, *, force=False):
-        "every .sig / .sig.gz under a directory (every file with force, unreadable ones skipped)"
-        from .exceptions import SourmashError
-        if not os.path.isdir(pathname):
-            raise ValueError(f"'{pathname}' must be a directory.")
-        index_list, source_list = [], []
-        for thisfile in traverse_find_sigs([pathname], yield_all_files=force):
-            try:
-                index_list.append(LinearIndex.load(thisfile))
-                source_list.append(os.path.relpath(thisfile, pathname))
-            except (OSError, SourmashError, ValueError) as exc:
-                if not force:
-                    raise ValueError(exc)
-        if not index_list:
-            raise ValueError(f"no signatures to load under directory '{pathname}'")
-        return cls.load(index_list, source_list, pathname, prepend_location=True)
-
-    @classmethod
-    def load_from_path(cls, pathname, force=False):
-        from .exceptions import SourmashError
-        if not os.path.exists(pathname):
-            raise ValueError(f"'{pathname}' must exist.")
-        if os.path.isdir(pathname):
-            return cls.load_from_directory(pathname, force=force)
-        try:
-            idx = LinearIndex.load(pathname)
-        except (OSError, SourmashError, ValueError):
-            if not force:
-                raise ValueError(f"no signatures to load from '{pathname}'")
-            return None
-        return cls.load([idx], [pathname], pathname)
-
-    @classmethod
-    def load_from_pathlist(cls, filename):
-        from .save_load import load_file_as_index
-        idx_list, src_list = [], []
-        for fname in load_pathlist_from_file(filename):
-            idx_list.append(load_file_as_index(fname))
-            src_list.append(fname)
-        return cls.load(idx_list, src_list, filename)
-
-    def select(self, **kwargs):
-        _check_select_parameters(**kwargs)
-        return MultiIndex(self.manifest.select_to_manifest(**kwargs), self.parent, prepend_location=self.prepend_location)
-
-
-class StandaloneManifestIndex(Index):
-    """A manifest file on its own: selection works on its rows, signatures are loaded from the locations the rows
-    name only when asked for (relative paths are taken from the manifest's directory); index/__init__.py:1128-1226."""
-    is_database = True
-
-    def __init__(self, manifest, location, *, prefix=None):
-        assert manifest is not None
-        self.manifest = manifest
-        self._location = location
-        self.prefix = prefix
-
-    @classmethod
-    def load(cls, location, *, prefix=None):
-        if not os.path.isfile(location):
-            raise ValueError(f"provided manifest location '{location}' is not a file")
-        m = CollectionManifest.load_from_filename(location)
-        return cls(m, location, prefix=os.path.dirname(location) if prefix is None else prefix)
-
-    @property
-    def location(self):
-        return self._location
-
-    def signatures_with_location(self):
-        yield from self._signatures_with_internal()
-
-    def signatures(self):
-        for ss, _ in self._signatures_with_internal():
-            yield ss
-
-    def _signatures_with_internal(self):
-        "only the rows that survived selection -- the original manifest is not kept"
-        from .save_load import load_file_as_index
-        picklist = self.manifest.to_picklist()
-        for iloc in self.manifest.locations():
-            if not iloc.startswith("/") and self.prefix:
-                iloc = os.path.join(self.prefix, iloc)
-            for ss in load_file_as_index(iloc).select(picklist=picklist).signatures():
-                yield ss, iloc
-
-    def __len__(self):
-        return len(self.manifest)
-
-    def __bool__(self):
-        return bool(self.manifest)
-
-    def select(self, **kwargs):
-        _check_select_parameters(**kwargs)
-        return StandaloneManifestIndex(self.manifest.select_to_manifest(**kwargs), self._location, prefix=self.prefix)
-
-
 class CounterGather:
     """Track overlaps between a query and candidate matches for min-set-cover gather.
 
@@ -1142,89 +675,3 @@ class CounterGather:
             query_mh = query_mh.downsample(scaled=scaled).to_mutable() if scaled != query_mh.scaled else query_mh
             query_mh.remove_many(sr.signature.minhash.downsample(scaled=scaled).flatten())
         return out
-
-
-class _LazySignatures:
-    "md5 -> signature for rows of an archive-backed set, read from the archive on first use (insertion ordered)"
-
-    def __init__(self, index, rows):
-        self._index = index
-        self._rows = {row["md5"]: row for row in rows}      # first row wins, like the md5-keyed dict of the reference
-        self._loaded = {}
-
-    def __len__(self):
-        return len(self._rows)
-
-    def __bool__(self):
-        return bool(self._rows)
-
-    def __iter__(self):
-        return iter(self._rows)
-
-    def __contains__(self, md5):
-        return md5 in self._rows
-
-    def __getitem__(self, md5):
-        if md5 not in self._loaded:
-            member = self._rows[md5]["internal_location"]
-            for ss in load_signatures_from_json(self._index.storage.load(member)):
-                self._loaded.setdefault(ss.md5sum(), ss)
-        return self._loaded[md5]
-
-    def keys(self):
-        return self._rows.keys()
-
-    def values(self):
-        return (self[md5] for md5 in self._rows)
-
-    def items(self):
-        return ((md5, self[md5]) for md5 in self._rows)
-
-
-class _ArchiveCounterGather(CounterGather):
-    """CounterGather over rows of a collection that is already in HBM: same protocol, same decisions; the candidate
-    rows are gathered into their own CSR on the device instead of being added one signature object at a time."""
-
-    def __init__(self, query, index, sset, rows):
-        CounterGather.__init__(self, query)
-        # one entry per md5, first occurrence wins (CounterGather keys by md5)
-        seen, first = set(), []
-        for r in rows:
-            md5 = sset.manifest[r]["md5"]
-            if md5 not in seen:
-                seen.add(md5)
-                first.append(r)
-        self._cand = sset.subset(first) if first else None
-        man = self._cand.manifest if first else []
-        self.siglist = _LazySignatures(index, man)
-        self.locations = {row["md5"]: index.location for row in man}
-        for row in man:                                      # every candidate has the collection's scaled after loading
-            self.downsample(row["scaled"])
-        self.downsample(sset.params[3])
-
-    def add(self, *args, **kwargs):
-        raise ValueError("this counter was built from a resident collection; candidates cannot be added")
-
-    add_many = add
-
-    def _device(self):
-        if self._dev is None:
-            self._dev = (_DeviceCounter(self._cand, self.orig_query_mh), list(self.siglist))
-        return self._dev
-
-    @property
-    def union_found(self):
-        found_mh = self.orig_query_mh.copy_and_clear()
-        for i in range(len(self._cand) if self._cand is not None else 0):
-            found_mh.add_many(flatten_and_intersect_scaled(self._cand.minhash(i), self.orig_query_mh))
-        return found_mh
-
-    def gather_all(self, threshold_bp=0):
-        if not self.siglist:
-            return []
-        self.query_started = 1
-        dev, order = self._device()
-        scaled = self.orig_query_mh.scaled
-        thr = math.ceil(float(threshold_bp) / scaled) if threshold_bp else 0
-        idx, isect = dev.gather(thr)
-        return [(order[int(i)], int(c)) for i, c in zip(idx, isect)]

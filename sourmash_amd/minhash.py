@@ -101,6 +101,15 @@ def flatten_and_intersect_scaled(mh1, mh2):
     return mh1.flatten().downsample(scaled=scaled) & mh2.flatten().downsample(scaled=scaled)
 
 
+_add_sequence_rc = lib.smgpu_minhash_add_sequence_rc
+
+
+def _raise_last(code):
+    from .exceptions import SourmashError, exceptions_by_code
+    from .utils import decode_str
+    raise exceptions_by_code.get(code, SourmashError)(decode_str(lib.sourmash_err_get_last_message()))
+
+
 class _HashesWrapper(Mapping):
     "Read-only {hash: abundance} view."
 
@@ -211,8 +220,14 @@ class MinHash(RustObject):
 
     # ---- adding -------------------------------------------------------------------------------
     def add_sequence(self, sequence, force=False):
-        "Add every k-mer of a DNA sequence (GPU)."
-        self._methodcall(lib.kmerminhash_add_sequence, to_bytes(sequence), force)
+        """Add every k-mer of a DNA sequence (GPU).  The record is validated and queued; the library hashes the queue in
+        one kernel launch when it is large or when the sketch is next looked at, so a loop over reads costs one C call
+        per read and no launch.  Invalid DNA with force=False raises here, after the k-mers in front of the bad one
+        were queued -- the reference's streaming order (signature.rs:48-54)."""
+        b = to_bytes(sequence)
+        code = _add_sequence_rc(self._get_objptr(), b, len(b), force)
+        if code:
+            _raise_last(code)
 
     def add_sequence_buffer(self, buf, force=True):
         """Batch extension: sketch a whole buffer in one call.  Records are separated

@@ -5,7 +5,7 @@ import sys
 import sourmash_amd as _impl
 
 for _name in ("minhash", "signature", "sketchcomparison", "search", "index", "compare", "distance_utils",
-              "exceptions", "utils", "_lowlevel", "sketch", "manifest", "picklist", "save_load"):
+              "exceptions", "utils", "_lowlevel", "sketch"):
     _mod = importlib.import_module("sourmash_amd." + _name)
     sys.modules[__name__ + "." + _name] = _mod
     globals()[_name] = _mod
@@ -43,8 +43,6 @@ def save_signatures(*args, **kwargs):
     return save_signatures_to_json(*args, **kwargs)
 
 
-from sourmash_amd.save_load import load_file_as_index as _load_index, load_file_as_signatures  # noqa: E402,F401
-
 
 # ---- everything outside the hot path: importable, skips the test when touched -------------------
 import types as _types                                      # noqa: E402
@@ -69,18 +67,13 @@ class _OutOfScope(_types.ModuleType):
 
 
 for _name in ("sbt", "sbtmh", "lca", "lca.lca_db", "lca.lca_utils", "index.sqlite_index", "index.revindex",
-              "sourmash_args", "tax", "nodegraph", "hll", "cli", "cli.utils", "commands", "sig", "plugins", "sbt_storage", "logging"):
+              "sourmash_args", "tax", "nodegraph", "hll", "cli", "cli.utils", "commands", "sig", "plugins", "sbt_storage", "logging",
+              "manifest", "picklist", "save_load"):
     _mod = _OutOfScope(__name__ + "." + _name)
     sys.modules[_mod.__name__] = _mod
     if "." not in _name:
         globals()[_name] = _mod
 sys.modules[__name__ + ".lca"].lca_db = sys.modules[__name__ + ".lca.lca_db"]
-# the loaders of sourmash_args that the engine has; its command-line helpers stay out of scope
-for _name in ("traverse_find_sigs", "load_pathlist_from_file"):
-    setattr(sourmash_args, _name, getattr(index, _name))    # noqa: F821
-sourmash_args.load_file_as_signatures = load_file_as_signatures     # noqa: F821
-sourmash_args.SaveSignaturesToLocation = save_load.SaveSignaturesToLocation   # noqa: F821
-
 for _name in ("ZipFileLinearIndex", "LazyLinearIndex", "MultiIndex", "StandaloneManifestIndex"):
     if not hasattr(index, _name):                           # noqa: F821  (bound by the loop at the top)
         setattr(index, _name, _Skips("sourmash.index." + _name, (), {}))   # noqa: F821
@@ -89,14 +82,6 @@ load_sbt_index = _Skips("sourmash.load_sbt_index", (), {})
 search_sbt_index = _Skips("sourmash.search_sbt_index", (), {})
 
 
-def load_file_as_index(filename, *args, **kwargs):
-    "SBT / LCA / SQLite databases are outside the hot path: skip; everything else through the engine's loader."
-    name = _os.path.basename(_os.fspath(filename))
-    if any(tag in name for tag in (".sbt.", ".lca.json", ".sqldb")) or name.endswith(".sbt"):
-        import pytest
-        pytest.skip("index format outside the hot path (SURVEY.md section 8)")
-    return _load_index(filename, *args, **kwargs)
-
-
-save_load.load_file_as_index = load_file_as_index           # noqa: F821  (nested loads -- manifests, path lists -- skip too)
-sourmash_args.load_file_as_index = load_file_as_index       # noqa: F821
+# collection loaders (zip / directory / manifest / path list -> Index objects) are the reference's control plane
+load_file_as_index = _Skips("sourmash.load_file_as_index", (), {})
+load_file_as_signatures = _Skips("sourmash.load_file_as_signatures", (), {})

@@ -1,0 +1,160 @@
+"""The per-record API with deferred hashing (capi.cpp: add_sequence queues, accessors settle): the observable behaviour
+must stay that of the reference's streaming add_sequence (src/core/src/signature.rs:38-58) -- same sketch whatever
+the interleaving with other calls, InvalidDNA raised by the offending call after the k-mers in front of the bad one were
+added (tests/test_minhash.py:711-719,2594-2602 of the reference).  Run with -m gpu."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def sm():
+    import torch  # noqa: F401
+    import sourmash_amd
+    assert sourmash_amd.gpu_available()
+    return sourmash_amd
+
+
+def _pending(mh):
+    from sourmash_amd._lowlevel import lib
+    return int(lib.smgpu_minhash_pending_bytes(mh._objptr))
+
+
+def _records(n, length, seed=3):
+    rng = np.random.default_rng(seed)
+    return [bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), length)).decode() for _ in range(n)]
+
+
+def test_queue_settles_on_access_and_equals_streaming(sm):
+    recs = _records(300, 180) + ["ACGT" * 3, "A" * 30, "", "acgtacgtacgtacgtacgtacgtacgtacgtacgtacgt"]
+    mh = sm.MinHash(0, 31, scaled=20)
+    want = oracle.OracleMinHash(0, 31, scaled=20)
+    for r in recs:
+        mh.add_sequence(r)
+        want.add_sequence(r.encode())
+    assert _pending(mh) > 0                                       # nothing has been hashed yet
+    assert len(mh) == len(want)                                   # the size getter settles
+    assert _pending(mh) == 0
+    assert np.array_equal(mh._mins_array(), want.mins)
+    assert mh.md5sum() == want.md5sum()
+
+
+def test_invalid_dna_raises_from_the_offending_call_with_the_prefix_added(sm):
+    good1, good2 = _records(2, 200, seed=9)
+    bad = good1[:70] + "R" + good2[:50]                           # k-mers 0..39 are fine, k-mer 40 covers the R
+    mh = sm.MinHash(0, 31, scaled=1)
+    want = oracle.OracleMinHash(0, 31, scaled=1)
+    mh.add_sequence(good1)
+    want.add_sequence(good1.encode())
+    with pytest.raises(ValueError) as err:
+        mh.add_sequence(bad)                                      # raised here, not when the queue is settled
+    assert "invalid DNA character in input k-mer: " + bad[40:71].upper() in str(err.value)
+    with pytest.raises(oracle.InvalidDNA):
+        want.add_sequence(bad.encode())
+    mh.add_sequence(good2)
+    want.add_sequence(good2.encode())
+    assert np.array_equal(mh._mins_array(), want.mins)            # includes the 40 k-mers in front of the bad one
+    forced = sm.MinHash(0, 31, scaled=1)
+    forced.add_sequence(bad, force=True)
+    ow = oracle.OracleMinHash(0, 31, scaled=1)
+    ow.add_sequence(bad.encode(), force=True)
+    assert np.array_equal(forced._mins_array(), ow.mins) and len(forced) == len(bad) - 30 - 31
+    short = sm.MinHash(0, 31, scaled=1)
+    short.add_sequence("ACGTNNNN")                                # shorter than k: silently nothing (signature.rs:206-210)
+    assert len(short) == 0
+
+
+def test_operations_that_do_not_commute_settle_first(sm):
+    a, b, c = _records(3, 400, seed=21)
+    def fresh(**kw):
+        return sm.MinHash(0, 21, scaled=1, **kw)
+    ha = oracle.OracleMinHash(0, 21, scaled=1)
+    ha.add_sequence(a.encode())
+    hb = oracle.OracleMinHash(0, 21, scaled=1)
+    hb.add_sequence(b.encode())
+    # remove after add
+    mh = fresh()
+    mh.add_sequence(a)
+    mh.remove_many(ha.mins[:50].tolist())
+    assert np.array_equal(mh._mins_array(), ha.mins[50:])
+    # clear drops what is queued
+    mh = fresh()
+    mh.add_sequence(a)
+    mh.clear()
+    mh.add_sequence(b)
+    assert np.array_equal(mh._mins_array(), hb.mins)
+    # add_hash in between commutes
+    mh = fresh()
+    mh.add_sequence(a)
+    mh.add_hash(7)
+    mh.add_sequence(b)
+    assert np.array_equal(mh._mins_array(), np.union1d(np.union1d(ha.mins, hb.mins), np.array([7], dtype=np.uint64)))
+    # merge / copy / count_common with queues on both sides
+    x, y = fresh(), fresh()
+    x.add_sequence(a)
+    y.add_sequence(b)
+    y.add_sequence(a[:100])
+    z = x.copy()
+    assert np.array_equal(z._mins_array(), ha.mins)
+    assert x.count_common(y) == len(np.intersect1d(ha.mins, y._mins_array()))
+    x.merge(y)
+    assert np.array_equal(x._mins_array(), np.union1d(ha.mins, y._mins_array()))
+    # abundances add up across queued records and across settles
+    w = fresh(track_abundance=True)
+    w.add_sequence(a)
+    w.add_sequence(a)
+    assert set(w.hashes.values()) >= {2}
+    w.add_sequence(a)
+    ow = oracle.OracleMinHash(0, 21, scaled=1, track_abundance=True)
+    for _ in range(3):
+        ow.add_sequence(a.encode())
+    assert w.hashes == dict(zip(ow.mins.tolist(), ow.abunds.tolist()))
+    # bottom-k
+    n = sm.MinHash(50, 21)
+    on = oracle.OracleMinHash(50, 21)
+    for r in (a, b, c):
+        n.add_sequence(r)
+        on.add_sequence(r.encode())
+    assert np.array_equal(n._mins_array(), on.mins) and len(n) == 50
+
+
+def test_queue_flushes_itself_when_it_is_large(sm):
+    recs = _records(90, 500_000, seed=4)                           # 45 MB of records: crosses the 32 MiB threshold once
+    mh = sm.MinHash(0, 31, scaled=1000)
+    seen_small = False
+    for r in recs:
+        before = _pending(mh)
+        mh.add_sequence(r, True)
+        if _pending(mh) < before:
+            seen_small = True
+    assert seen_small
+    whole = sm.MinHash(0, 31, scaled=1000)
+    whole.add_sequence_buffer("\n".join(recs).encode())
+    assert mh == whole and len(mh) > 40_000
+
+
+def test_signature_fan_out_and_c_string_semantics(sm):
+    from sourmash_amd._lowlevel import lib
+    recs = _records(40, 300, seed=13)
+    sig_mhs = [sm.MinHash(0, k, scaled=10) for k in (21, 31, 51)]
+    sigs = [sm.SourmashSignature(mh, name="x") for mh in sig_mhs]
+    for r in recs:
+        for s in sigs:
+            s.add_sequence(r)
+    for s, k in zip(sigs, (21, 31, 51)):
+        ow = oracle.OracleMinHash(0, k, scaled=10)
+        for r in recs:
+            ow.add_sequence(r.encode())
+        assert np.array_equal(s.minhash._mins_array(), ow.mins)
+    # a NUL ends the record (ffi/minhash.rs:53-59 takes a C string)
+    mh = sm.MinHash(0, 21, scaled=1)
+    raw = (recs[0][:100] + "\0" + recs[1]).encode()
+    assert lib.smgpu_minhash_add_sequence_rc(mh._objptr, raw, len(raw), False) == 0
+    ow = oracle.OracleMinHash(0, 21, scaled=1)
+    ow.add_sequence(recs[0][:100].encode())
+    assert np.array_equal(mh._mins_array(), ow.mins)

@@ -1,29 +1,58 @@
 #!/usr/bin/env python3
-"""Latency of the per-call object API (what a Python loop over records pays): MinHash.add_sequence for short and
-medium sequences, count_common / jaccard of two sketches, seq_to_hashes.   python tools/bench_small_calls.py"""
+"""Cost of the per-record object API -- what a drop-in user who keeps the reference's loop pays
+(src/sourmash/command_sketch.py:746-768: one add_sequence per record):
+  * a Python loop of MinHash.add_sequence calls (ctypes call overhead included), sketch read at the end;
+  * the same loop in C against the C-ABI (tools/small_calls_loop.c, compiled here with gcc): kmerminhash_add_sequence
+    per record, kmerminhash_get_mins_size at the end -- what a cffi / Rust / C caller sees;
+  * count_common / jaccard / len / copy of 5,000-hash sketches.
+python tools/bench_small_calls.py"""
+import ctypes as C
 import json
 import os
+import subprocess
 import sys
+import tempfile
 import time
 
 import numpy as np
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def native_loop(lib_path, length, calls):
+    "-> (seconds, hashes) of `calls` kmerminhash_add_sequence calls of `length` bases + one size read, from C"
+    src = os.path.join(ROOT, "tools", "small_calls_loop.c")
+    exe = os.path.join(tempfile.gettempdir(), "smg_small_calls_loop")
+    if not os.path.exists(exe) or os.path.getmtime(exe) < os.path.getmtime(src):
+        subprocess.check_call(["gcc", "-O2", "-o", exe, src, "-ldl"])
+    out = subprocess.check_output([exe, lib_path, str(length), str(calls)], text=True)
+    sec, n = out.split()
+    return float(sec), int(n)
 
 
 def main():
     import sourmash_amd as sm
+    from sourmash_amd._lowlevel import LIBPATH
     rng = np.random.default_rng(5)
     out = {}
-    for length, calls in ((150, 2000), (10_000, 1000), (1_000_000, 50)):
+    for length, calls in ((150, 200_000), (10_000, 20_000), (1_000_000, 200)):
         seqs = [bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), length)).decode() for _ in range(min(calls, 200))]
         mh = sm.MinHash(0, 31, scaled=1000)
         mh.add_sequence(seqs[0])
-        t0 = time.perf_counter()
-        for i in range(calls):
-            mh.add_sequence(seqs[i % len(seqs)], True)
-        dt = time.perf_counter() - t0
-        out[f"add_sequence_{length}bp"] = {"us_per_call": round(dt / calls * 1e6, 1), "Mbase_per_s": round(length * calls / dt / 1e6, 1)}
+        len(mh)
+        for force in (False, True):
+            mh = sm.MinHash(0, 31, scaled=1000)
+            t0 = time.perf_counter()
+            for i in range(calls):
+                mh.add_sequence(seqs[i % len(seqs)], force)
+            n = len(mh)                                            # settles the queued records: in the timed region
+            dt = time.perf_counter() - t0
+            out[f"python_add_sequence_{length}bp_force_{force}"] = {
+                "calls": calls, "us_per_call": round(dt / calls * 1e6, 2), "Mbase_per_s": round(length * calls / dt / 1e6, 1), "hashes": n}
+        sec, n = native_loop(LIBPATH, length, calls)
+        out[f"c_abi_add_sequence_{length}bp"] = {"calls": calls, "us_per_call": round(sec / calls * 1e6, 3),
+                                                 "Mbase_per_s": round(length * calls / sec / 1e6, 1), "hashes": n}
     a, b = sm.MinHash(0, 31, scaled=1000), sm.MinHash(0, 31, scaled=1000)
     a.add_many(range(1, 10_001, 2))
     b.add_many(range(1, 10_001, 3))

@@ -6,7 +6,7 @@
 set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 REF=/root/reference/tests
-MODS=${@:-test_minhash.py test__minhash_hypothesis.py test_jaccard.py test_signature.py test_sketchcomparison.py test_search.py test_distance_utils.py test_compare.py test_index_protocol.py test_index.py test_api.py test_prefetch.py test_bugs.py test_deprecated.py test_manifest.py test_picklist.py test_manifest_protocol.py test_sourmash_sketch.py test_sourmash_args.py}
+MODS=${@:-test_minhash.py test__minhash_hypothesis.py test_jaccard.py test_signature.py test_sketchcomparison.py test_search.py test_distance_utils.py test_compare.py test_index_protocol.py test_index.py test_api.py test_prefetch.py test_bugs.py test_deprecated.py test_sourmash_sketch.py}
 rm -rf "$ROOT/_refrun"; mkdir -p "$ROOT/_refrun"
 cp -r "$ROOT"/tests/refcompat/shim/* "$ROOT/_refrun/"
 cp -r "$REF/test-data" "$ROOT/_refrun/test-data"
