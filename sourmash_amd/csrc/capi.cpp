@@ -136,7 +136,21 @@ size_t first_invalid_byte(const uint8_t* seq, size_t len) {
         uint8_t bad[256];
         Table() { memset(bad, 1, sizeof(bad)); for (const char* c = "ACGTacgt"; *c; ++c) bad[(uint8_t)*c] = 0; }
     } t;
-    for (size_t i = 0; i < len; ++i)
+    size_t i = 0;
+    // eight bytes at a time: fold the case bit away, then a byte is fine iff it equals one of A C G T.  `zero(v)` marks
+    // exactly the bytes of v that are 0 (the carry-free form; the shorter (v - 0x01..) & ~v & 0x80.. marks false
+    // positives next to a true zero).  A byte >= 0x80 is never valid.
+    const uint64_t L = 0x0101010101010101ull, H = 0x8080808080808080ull;
+    for (; i + 8 <= len; i += 8) {
+        uint64_t w;
+        memcpy(&w, seq + i, 8);
+        const uint64_t hi = w & H;                                  // bytes >= 0x80: invalid
+        const uint64_t x = w & 0x5f5f5f5f5f5f5f5full;               // case folded, top bit cleared
+        auto zero = [&](uint64_t v) { return ~((((v & ~H) + ~H) | v) | ~H); };   // 0x80 where the byte is 0; no carry crosses a byte
+        const uint64_t ok = zero(x ^ (L * 'A')) | zero(x ^ (L * 'C')) | zero(x ^ (L * 'G')) | zero(x ^ (L * 'T'));
+        if ((ok & ~hi) != H) break;                                 // some byte of this word is not ACGTacgt: find it below
+    }
+    for (; i < len; ++i)
         if (t.bad[seq[i]]) return i;
     return SIZE_MAX;
 }

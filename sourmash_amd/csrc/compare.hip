@@ -27,6 +27,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <string.h>
 #include "device_api.hpp"
 
 namespace smg {
@@ -55,17 +56,18 @@ struct WorkItem { uint32_t ty, cb, z, zt; };
 __global__ __launch_bounds__(256) void compare_plan_kernel(
     const uint64_t* __restrict__ offsets, uint32_t n, uint32_t row_lo, uint32_t row_hi, int symmetric,
     uint32_t rb_first, uint32_t rb_stride, uint32_t n_row_tiles, uint32_t n_col_tiles, uint32_t slice_len,
-    WorkItem* __restrict__ heavy, WorkItem* __restrict__ light, unsigned int* __restrict__ counters) {
+    WorkItem* __restrict__ heavy, WorkItem* __restrict__ light, unsigned int* __restrict__ counters, uint32_t ctc) {
+    // ctc: columns per tile (CT for the walk kernel, HC for the hash kernel); rows per tile are CT for both
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_row_tiles * n_col_tiles) return;
     const uint32_t ty = t / n_col_tiles, cb = t % n_col_tiles;
     const uint32_t rb = rb_first + ty * rb_stride;
-    const uint32_t row0 = row_lo + rb * CT, col0 = cb * CT;
-    if (symmetric && col0 + CT <= row0) return;              // strictly below the diagonal
+    const uint32_t row0 = row_lo + rb * CT, col0 = cb * ctc;
+    if (symmetric && col0 + ctc <= row0) return;             // strictly below the diagonal
     uint64_t best = 0;
-    for (int i = 0; i < CT; ++i) {
+    for (uint32_t i = 0; i < ctc; ++i) {
         const uint32_t r = row0 + i, c = col0 + i;
-        if (r < row_hi) { const uint64_t l = offsets[r + 1] - offsets[r]; best = l > best ? l : best; }
+        if (i < (uint32_t)CT && r < row_hi) { const uint64_t l = offsets[r + 1] - offsets[r]; best = l > best ? l : best; }
         if (c < n) { const uint64_t l = offsets[c + 1] - offsets[c]; best = l > best ? l : best; }
     }
     if (best == 0) return;                                    // nothing can intersect
@@ -223,6 +225,200 @@ __global__ __launch_bounds__(CMP_BLOCK) void compare_tile_kernel(
     }
 }
 
+// ---- hash-table form of the tile (the default) ---------------------------------------------------------------------
+// The walk above spends one step per element of BOTH lists for EVERY pair (256 pairs x (n_i + n_j) steps per tile,
+// 13 VALU instructions a step): at C4 it is bound by instruction issue, not by LDS or memory.  The same slab structure
+// admits a formulation whose work grows with the ELEMENTS of a tile instead: per round, the <= 64 staged hashes of each
+// of the 16 ROW sketches are inserted into an LDS hash table (key = hash, value = 16-bit mask of the rows holding it),
+// then every staged hash of the 32 COLUMN sketches is looked up once and adds 1 to the counters of (row, column) for the
+// rows in its mask.  Rounds are cut at the same data-driven bound `hi` as the walk (every sketch's hashes <= hi are among
+// its staged ones), so the counts are the walk's counts: |A_r ∩ B_c| summed over disjoint hash ranges.
+// Per round: 1,024 inserts + 2,048 lookups + one LDS add per common hash, for 512 pairs -- about 6x fewer instructions than
+// 512 walks of ~100 steps.  LDS accesses are hash-addressed (random banks), so the bank-conflict RATIO stays high while
+// the absolute LDS cycles drop with the work.
+constexpr int HR = CT;                // row sketches of a tile (inserted)
+constexpr int HC = 32;                // column sketches of a tile (looked up)
+constexpr int HSEG = 64;              // hashes staged per sketch and round: one per lane
+constexpr int HT = 2048;              // table slots: rows put in at most 16 x 64 = 1024 distinct hashes per round
+constexpr unsigned long long H_EMPTY = ~0ull;   // never a key: a staged hash equal to 2^64 - 1 is counted out of band
+constexpr int HPW = (HR + HC) / 4;    // sketches per wave (4 waves): sketch s = i * 4 + wave, so every wave holds HR / 4 rows
+
+__device__ __forceinline__ uint32_t hash_slot(uint64_t v) {
+    const uint32_t x = ((uint32_t)v ^ (uint32_t)(v >> 32)) * 0x9E3779B1u;   // slabs share their top bits: mix before cutting
+    return x >> (32 - 11);
+}
+static_assert(HT == (1 << 11), "hash_slot cuts 11 bits");
+
+__global__ __launch_bounds__(CMP_BLOCK, 4) void compare_hash_kernel(
+    const uint64_t* __restrict__ hashes, const uint64_t* __restrict__ offsets, uint32_t n,
+    uint32_t row_lo, uint32_t row_hi, uint32_t* __restrict__ common, int symmetric,
+    uint32_t rb_first, uint32_t rb_stride, const WorkItem* __restrict__ heavy,
+    const WorkItem* __restrict__ light, unsigned int* __restrict__ counters) {
+    // same contract as compare_tile_kernel (symmetric modes, work lists, output rows), tiles of HR rows x HC columns
+    __shared__ unsigned long long s_key[HT];
+    __shared__ uint32_t s_mask[HT];
+    __shared__ uint32_t s_cnt[HR * HC];
+    __shared__ uint64_t s_pos[HR + HC], s_end[HR + HC];
+    __shared__ unsigned long long s_hi;
+    __shared__ uint32_t s_live[2], s_top[2];      // s_top: rows / columns whose staged part holds the hash 2^64 - 1
+    __shared__ uint64_t s_piv[2];
+    __shared__ WorkItem s_item;
+    __shared__ int s_have;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int k = tid; k < HT; k += CMP_BLOCK) { s_key[k] = H_EMPTY; s_mask[k] = 0; }
+
+    for (;;) {
+        __syncthreads();                                   // previous item fully done (LDS reuse)
+        if (tid == 0) {
+            int have = 0;
+            unsigned int i = atomicAdd(&counters[2], 1u);
+            if (i < counters[0]) { s_item = heavy[i]; have = 1; }
+            else {
+                i = atomicAdd(&counters[3], 1u);
+                if (i < counters[1]) { s_item = light[i]; have = 1; }
+            }
+            s_have = have;
+        }
+        for (int k = tid; k < HR * HC; k += CMP_BLOCK) s_cnt[k] = 0;
+        __syncthreads();
+        if (!s_have) return;
+        const WorkItem it = s_item;
+        const uint32_t rb = rb_first + it.ty * rb_stride;
+        const uint32_t row0 = row_lo + rb * HR, col0 = it.cb * HC;
+        if (tid < HR + HC) {
+            const uint32_t s = tid < HR ? row0 + tid : col0 + (tid - HR);
+            const bool ok = tid < HR ? (s < row_hi) : (s < n);
+            s_pos[tid] = ok ? offsets[s] : 0;
+            s_end[tid] = ok ? offsets[s + 1] : 0;
+        }
+        __syncthreads();
+        if (it.zt > 1) {                                   // hash-range slice of a heavy tile, as in the walk kernel
+            if (tid == 0) {
+                uint64_t best_len = 0, best_pos = 0;
+                for (int i = 0; i < HR + HC; ++i) {
+                    const uint64_t len = s_end[i] - s_pos[i];
+                    if (len > best_len) { best_len = len; best_pos = s_pos[i]; }
+                }
+                s_piv[0] = it.z == 0 ? 0ull : hashes[best_pos + (uint64_t)it.z * best_len / it.zt];
+                s_piv[1] = it.z + 1 == it.zt ? ~0ull : hashes[best_pos + (uint64_t)(it.z + 1) * best_len / it.zt];
+            }
+            __syncthreads();
+            if (tid < HR + HC) {
+                const uint64_t lo = s_pos[tid], hi = s_end[tid];
+                const uint64_t a = it.z == 0 ? lo : lower_bound_row(hashes, lo, hi, s_piv[0]);
+                const uint64_t b = it.z + 1 == it.zt ? hi : lower_bound_row(hashes, a, hi, s_piv[1]);
+                s_pos[tid] = a;
+                s_end[tid] = b;
+            }
+            __syncthreads();
+        }
+        if (tid == 0) { s_top[0] = 0; s_top[1] = 0; }
+
+        for (;;) {
+            if (tid == 0) { s_hi = ~0ull; s_live[0] = 0; s_live[1] = 0; }
+            __syncthreads();
+            // ---- stage: lane l takes the l-th of the next <= 64 hashes of each of this wave's sketches ----
+            uint64_t e[HPW];
+            uint32_t valid = 0, more = 0;                   // bit i: this lane holds a staged hash of sketch i * 4 + wave /
+                                                            // that sketch has more than this round stages
+#pragma unroll
+            for (int i = 0; i < HPW; ++i) {
+                const int s = i * 4 + wave;
+                const uint64_t pos = s_pos[s], left = s_end[s] - pos;
+                const bool ok = (uint64_t)lane < left;      // lane < min(left, 64)
+                valid |= (uint32_t)ok << i;
+                more |= (uint32_t)(left > (uint64_t)HSEG) << i;
+                e[i] = ok ? hashes[pos + lane] : ~0ull;
+            }
+#pragma unroll
+            for (int i = 0; i < HPW; ++i) {                 // (after all twelve loads are in flight)
+                const int s = i * 4 + wave;
+                if (lane == HSEG - 1 && ((more >> i) & 1u)) atomicMin(&s_hi, (unsigned long long)e[i]);
+                if (lane == 0 && (valid & (1u << i))) atomicOr(&s_live[s < HR ? 0 : 1], 1u);
+            }
+            __syncthreads();
+            if (s_live[0] == 0 || s_live[1] == 0) break;   // every row or every column exhausted
+            const uint64_t hi = s_hi;
+            // ---- rows: insert the staged hashes <= hi; advance every sketch by what this round consumes ----
+            uint32_t slot_of[HR / 4];
+#pragma unroll
+            for (int i = 0; i < HPW; ++i) {
+                const int s = i * 4 + wave;
+                const bool in = ((valid >> i) & 1u) && e[i] <= hi;
+                const uint32_t take = (uint32_t)__popcll(__ballot(in));
+                if (lane == 0) s_pos[s] += take;
+                if (i < HR / 4) {                          // sketch s = i * 4 + wave < HR: a row
+                    slot_of[i] = HT;
+                    if (in) {
+                        if (e[i] == H_EMPTY) {
+                            atomicOr(&s_top[0], 1u << s);
+                        } else {
+                            uint32_t slot = hash_slot(e[i]);
+                            for (;;) {
+                                const unsigned long long old = atomicCAS(&s_key[slot], H_EMPTY, (unsigned long long)e[i]);
+                                if (old == H_EMPTY || old == e[i]) break;
+                                slot = (slot + 1) & (HT - 1);
+                            }
+                            atomicOr(&s_mask[slot], 1u << s);
+                            slot_of[i] = slot;
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            // ---- columns: one lookup per staged hash <= hi, one LDS add per row that holds it ----
+#pragma unroll
+            for (int i = HR / 4; i < HPW; ++i) {
+                const int c = i * 4 + wave - HR;
+                if (((valid >> i) & 1u) && e[i] <= hi) {
+                    if (e[i] == H_EMPTY) {
+                        atomicOr(&s_top[1], 1u << c);
+                    } else {
+                        uint32_t slot = hash_slot(e[i]), m = 0;
+                        for (;;) {
+                            const unsigned long long k = s_key[slot];
+                            if (k == e[i]) { m = s_mask[slot]; break; }
+                            if (k == H_EMPTY) break;
+                            slot = (slot + 1) & (HT - 1);
+                        }
+                        while (m) {
+                            atomicAdd(&s_cnt[(__ffs((int)m) - 1) * HC + c], 1u);
+                            m &= m - 1;
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            // ---- the table goes back to empty: every inserter clears the slot it ended up in ----
+#pragma unroll
+            for (int i = 0; i < HR / 4; ++i)
+                if (slot_of[i] < (uint32_t)HT) { s_key[slot_of[i]] = H_EMPTY; s_mask[slot_of[i]] = 0; }
+            // the barrier at the top of the loop orders the clears before the next round's inserts
+        }
+
+        // the hash 2^64 - 1 (possible with scaled = 1) never went through the table
+        for (int k = tid; k < HR * HC; k += CMP_BLOCK)
+            if (((s_top[0] >> (k / HC)) & 1u) && ((s_top[1] >> (k % HC)) & 1u)) s_cnt[k] += 1;
+        __syncthreads();
+        for (int k = tid; k < HR * HC; k += CMP_BLOCK) {
+            const uint32_t cnt = s_cnt[k];
+            const uint32_t r = (uint32_t)k / HC, c = (uint32_t)k % HC;
+            const uint32_t row = row0 + r, col = col0 + c;
+            if (row < row_hi && col < n && cnt) {
+                const uint64_t idx = (uint64_t)(it.ty * HR + r) * n + col;
+                if (!symmetric) {
+                    atomicAdd(&common[idx], cnt);
+                } else if (col >= row) {
+                    atomicAdd(&common[idx], cnt);
+                    if (symmetric == 1 && col != row) atomicAdd(&common[(uint64_t)(col - row_lo) * n + row], cnt);
+                }
+            }
+        }
+    }
+}
+
+
 __global__ __launch_bounds__(256) void jaccard_from_counts_kernel(const uint32_t* __restrict__ common,
                                                                   const uint64_t* __restrict__ offsets, uint32_t n,
                                                                   uint32_t row_lo, uint32_t row_hi,
@@ -257,10 +453,17 @@ size_t compare_workspace_bytes(uint32_t n_row_tiles, uint32_t n_col_tiles) {
     return 256 + tiles * sizeof(WorkItem) * (CMP_ZMAX + 1);        // heavy (x ZMAX) + light (x 1) lists
 }
 
+static bool use_walk_kernel() {
+    static const bool walk = [] { const char* e = getenv("SMG_COMPARE_KERNEL"); return e && !strcmp(e, "walk"); }();
+    return walk;
+}
+
 static hipError_t compare_launch(const uint64_t* d_hashes, const uint64_t* d_offsets, uint32_t n, uint32_t row_lo,
                                  uint32_t row_hi, int symmetric, uint32_t rb_first, uint32_t rb_stride,
                                  uint32_t n_row_tiles, uint32_t* d_common, hipStream_t stream) {
-    const uint32_t n_col_tiles = (n + CT - 1) / CT;
+    const bool walk = use_walk_kernel();
+    const uint32_t ctc = walk ? CT : HC;                              // columns per tile
+    const uint32_t n_col_tiles = (n + ctc - 1) / ctc;
     const size_t tiles = (size_t)n_row_tiles * n_col_tiles;
     hipError_t e = hipMemsetAsync(d_common, 0, (size_t)n_row_tiles * CT * n * sizeof(uint32_t), stream);
     if (e != hipSuccess) return e;
@@ -275,14 +478,19 @@ static hipError_t compare_launch(const uint64_t* d_hashes, const uint64_t* d_off
         const uint64_t work_tiles = tiles / (symmetric ? 2 : 1);
         hipLaunchKernelGGL(compare_plan_kernel, dim3((unsigned)((tiles + 255) / 256)), dim3(256), 0, stream, d_offsets, n,
                            row_lo, row_hi, symmetric, rb_first, rb_stride, n_row_tiles, n_col_tiles,
-                           pick_slice_len(work_tiles), heavy, light, counters);
-        // 64 hashes per sketch and round: 17 KiB of LDS per workgroup, 8 workgroups (= 8 waves per SIMD) per CU.
-        // The walk is a dependent LDS round trip per step; twice the resident waves hide it better than longer
-        // rounds amortise the barriers (measured: +33 % pairs/s over 128 hashes per round at 5,000-hash sketches).
-        const uint64_t cap = 256ull * 8;
+                           pick_slice_len(work_tiles), heavy, light, counters, ctc);
+        const uint64_t cap = 256ull * (walk ? 8 : 5);
         const unsigned grid0 = (unsigned)(work_tiles + 1 < cap ? work_tiles + 1 : cap);
-        hipLaunchKernelGGL((compare_tile_kernel<64>), dim3(grid0 < 1 ? 1 : grid0), dim3(CMP_BLOCK), 0, stream, d_hashes,
-                           d_offsets, n, row_lo, row_hi, d_common, symmetric, rb_first, rb_stride, heavy, light, counters);
+        if (walk)
+            // 64 hashes per sketch and round: 17 KiB of LDS per workgroup, 8 workgroups (= 8 waves per SIMD) per CU.
+            // The walk is a dependent LDS round trip per step; twice the resident waves hide it better than longer
+            // rounds amortise the barriers (measured: +33 % pairs/s over 128 hashes per round at 5,000-hash sketches).
+            hipLaunchKernelGGL((compare_tile_kernel<64>), dim3(grid0 < 1 ? 1 : grid0), dim3(CMP_BLOCK), 0, stream, d_hashes,
+                               d_offsets, n, row_lo, row_hi, d_common, symmetric, rb_first, rb_stride, heavy, light, counters);
+        else
+            // 27 KiB of LDS per workgroup (table 24 KiB + counters 2 KiB): 5 workgroups per CU
+            hipLaunchKernelGGL(compare_hash_kernel, dim3(grid0 < 1 ? 1 : grid0), dim3(CMP_BLOCK), 0, stream, d_hashes,
+                               d_offsets, n, row_lo, row_hi, d_common, symmetric, rb_first, rb_stride, heavy, light, counters);
         e = hipGetLastError();
     }
     const hipError_t e2 = hipFreeAsync(ws, stream);

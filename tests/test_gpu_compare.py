@@ -394,3 +394,53 @@ def test_mixed_scaled_and_mixed_abundance_follow_the_per_pair_rule(sm):
                 assert sims[a, b] == mixed[a].similarity(mixed[b], ignore_abundance=False)
     assert sims[1, 3] == mixed[1].minhash.angular_similarity(mixed[3].minhash) != mixed[1].jaccard(mixed[3])
     assert np.array_equal(compare_serial(mixed, True), compare_serial(_sigs_from_arrays(sm, sk[:5]), True))
+
+
+def test_compare_extreme_hash_values_and_both_tile_kernels():
+    """The hash-table tile kernel keeps 2^64 - 1 (possible with scaled = 1) out of its table and counts it out of band;
+    0 is an ordinary key.  Ragged collection with those values planted, more rows than one tile, vs the oracle -- for the
+    default (hash-table) kernel here and for the walk kernel in a subprocess (SMG_COMPARE_KERNEL is read once)."""
+    import json, os, subprocess, sys
+    import torch
+    from conftest import ROOT
+    from sourmash_amd import device as smd
+    rng = np.random.default_rng(11)
+    top = np.uint64(2**64 - 1)
+    pool = np.unique(rng.integers(0, 2**63, 4000, dtype=np.int64).astype(np.uint64) * np.uint64(2) + np.uint64(1))
+    sk = []
+    for i in range(70):
+        n = int(rng.integers(0, 900)) if i % 7 else int(rng.integers(0, 3))
+        row = set(rng.choice(pool, size=min(n, len(pool)), replace=False).tolist())
+        if i % 3 == 0:
+            row.add(int(top))
+        if i % 4 == 0:
+            row.add(0)
+        sk.append(np.array(sorted(row), dtype=np.uint64))
+    sk[5] = np.array([int(top)], dtype=np.uint64)
+    sk[6] = np.array([0], dtype=np.uint64)
+    sk[8] = np.unique(np.concatenate([pool, np.array([0, int(top)], dtype=np.uint64)]))      # 4,000+ hashes: many rounds
+    wc, wj = oracle.compare_all_pairs(*oracle.make_csr(sk), nthreads=4)
+    h, off = smd.pack_csr(sk)
+    c, j = smd.compare_rows(h, off)
+    torch.cuda.synchronize()
+    assert np.array_equal(c.cpu().numpy().view(np.uint32), wc)
+    assert np.array_equal(j.cpu().numpy().view(np.uint64), wj.view(np.uint64))
+    for lo, hi in ((0, 16), (16, 70), (3, 41)):                    # row blocks (the unsymmetric launch)
+        cb, _ = smd.compare_rows(h, off, lo, hi)
+        torch.cuda.synchronize()
+        assert np.array_equal(cb.cpu().numpy().view(np.uint32), wc[lo:hi])
+    code = ("import sys, json, numpy as np, torch; sys.path.insert(0, %r)\n"
+            "from sourmash_amd import device as smd\n"
+            "sk = [np.array(r, dtype=np.uint64) for r in json.load(open(sys.argv[1]))]\n"
+            "h, off = smd.pack_csr(sk)\n"
+            "c, j = smd.compare_rows(h, off)\n"
+            "torch.cuda.synchronize()\n"
+            "np.save(sys.argv[2], c.cpu().numpy())\n" % ROOT)
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        src, dst = os.path.join(tmp, "sk.json"), os.path.join(tmp, "c.npy")
+        json.dump([r.tolist() for r in sk], open(src, "w"))
+        p = subprocess.run([sys.executable, "-c", code, src, dst], env=dict(os.environ, SMG_COMPARE_KERNEL="walk"),
+                           capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        assert np.array_equal(np.load(dst).view(np.uint32), wc)
