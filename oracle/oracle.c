@@ -699,7 +699,7 @@ static void u64vec_push(u64vec *v, uint64_t x) {
 static void sketch_slice(const uint8_t *seq, uint64_t len, uint64_t kmer_lo, uint64_t kmer_hi,
                          uint32_t k, uint64_t seed, uint64_t max_hash, u64vec *out) {
     /* k-mers with start index in [kmer_lo, kmer_hi) */
-    uint8_t fwd[64], rev[64];
+    uint8_t fwd[256], rev[256];
     (void)len;
     for (uint64_t i = kmer_lo; i < kmer_hi; ++i) {
         int bad = 0;
@@ -719,7 +719,7 @@ static void sketch_slice(const uint8_t *seq, uint64_t len, uint64_t kmer_lo, uin
 ORC_API uint64_t orc_sketch_dna_bulk(const uint8_t *seq, uint64_t len, uint32_t k, uint64_t seed,
                                      uint64_t max_hash, int nthreads, uint64_t **out) {
     *out = NULL;
-    if (len < k || k == 0 || k > 64) return 0;
+    if (len < k || k == 0 || k > 256) return 0;
     uint64_t nk = len - k + 1;
     if (nthreads < 1) nthreads = 1;
     u64vec *parts = (u64vec *)calloc((size_t)nthreads, sizeof(u64vec));

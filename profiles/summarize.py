@@ -29,7 +29,8 @@ def main():
                            "from kernels group by name order by sum(duration) desc").fetchall()
         tot = sum(r[2] for r in rows) or 1
         print(f"{'kernel':<62} {'calls':>5} {'total_ms':>10} {'avg_us':>11} {'min_us':>10} {'max_us':>10} {'%':>6} vgpr sgpr lds grid wg")
-        for r in rows[:14]:
+        shown = rows[:14] + [r for r in rows[14:] if "smg::" in r[0]]        # the top of the list, and every kernel of this library
+        for r in shown:
             print(f"{short(r[0]):<62} {r[1]:>5} {r[2]/1e6:>10.3f} {r[3]/1e3:>11.2f} {r[4]/1e3:>10.2f} {r[5]/1e3:>10.2f} "
                   f"{100*r[2]/tot:>6.2f} {r[6]} {r[7]} {r[8]} {r[9]} {r[10]}")
         try:
@@ -48,10 +49,10 @@ def main():
             except sqlite3.Error as e:
                 print("  (no counters:", e, ")")
         if pm:
-            print(f"  {'kernel':<50} {'counter':<22} {'dispatches':>10} {'avg/dispatch':>16}")
+            print(f"  {'kernel':<50} {'counter':<22} {'dispatches':>10} {'avg/dispatch':>16} {'sum':>18}")
             for k, c, n, avg, tot_ in pm:
                 if "smg::" in k:
-                    print(f"  {short(k):<50} {c:<22} {n:>10} {avg:>16.1f}")
+                    print(f"  {short(k):<50} {c:<22} {n:>10} {avg:>16.1f} {tot_:>18.1f}")
         print()
 
 

@@ -7,6 +7,7 @@
 #include <hip/hip_runtime_api.h>
 #include <stdio.h>
 #include <string.h>
+#include <chrono>
 #include <cmath>
 #include <fstream>
 #include <memory>
@@ -1024,12 +1025,19 @@ static bool gather_use_replay() {
 static uint64_t gather_drain(GatherDev& g, uint64_t* out_idx, uint64_t* out_isect, uint64_t cap, hipStream_t st) {
     unsigned long long head[GS_SLOTS];
     const bool replay = gather_use_replay() && g.ndb > 0 && g.nq > 0;
+    static const bool trace = getenv("SMG_GATHER_TRACE") != nullptr;   // per batch: time to enqueue, time until the GPU is through
     unsigned batch = 32;
     for (;;) {
+        const auto t0 = std::chrono::steady_clock::now();
         if (replay) hip_check(gather_enqueue_replay(g, (batch + GATHER_TOPK_MAX - 1) / GATHER_TOPK_MAX, st), "gather rounds");
         else hip_check(gather_enqueue_rounds(g, batch, st), "gather rounds");
+        const auto t1 = std::chrono::steady_clock::now();
         hip_check(hipMemcpyAsync(head, g.state, sizeof(head), hipMemcpyDeviceToHost, st), "D2H");
         hip_check(hipStreamSynchronize(st), "sync");
+        if (trace)
+            fprintf(stderr, "[gather] batch of %u rounds: enqueue %.1f us, then %.1f us until done (rounds so far %llu)\n", batch,
+                    std::chrono::duration<double, std::micro>(t1 - t0).count(),
+                    std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t1).count(), head[GS_ROUNDS]);
         if (head[GS_DONE]) break;
         if (batch < 512) batch *= 2;
     }

@@ -241,7 +241,15 @@ constexpr int HC = 32;                // column sketches of a tile (looked up)
 constexpr int HSEG = 64;              // hashes staged per sketch and round: one per lane
 constexpr int HT = 2048;              // table slots: rows put in at most 16 x 64 = 1024 distinct hashes per round
 constexpr unsigned long long H_EMPTY = ~0ull;   // never a key: a staged hash equal to 2^64 - 1 is counted out of band
-constexpr int HPW = (HR + HC) / 4;    // sketches per wave (4 waves): sketch s = i * 4 + wave, so every wave holds HR / 4 rows
+constexpr int HWAVES = 8;             // waves per workgroup: sketch s = i * HWAVES + wave, so every wave holds HR / 8 rows
+constexpr int HBLOCK = HWAVES * 64;
+constexpr int HPW = (HR + HC) / HWAVES;   // sketches per wave
+static_assert(HR % HWAVES == 0 && HC % HWAVES == 0, "");
+
+__device__ __forceinline__ uint64_t uniform64(uint64_t v) {          // a wave-uniform value into scalar registers
+    return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32) |
+           (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+}
 
 __device__ __forceinline__ uint32_t hash_slot(uint64_t v) {
     const uint32_t x = ((uint32_t)v ^ (uint32_t)(v >> 32)) * 0x9E3779B1u;   // slabs share their top bits: mix before cutting
@@ -249,7 +257,8 @@ __device__ __forceinline__ uint32_t hash_slot(uint64_t v) {
 }
 static_assert(HT == (1 << 11), "hash_slot cuts 11 bits");
 
-__global__ __launch_bounds__(CMP_BLOCK, 4) void compare_hash_kernel(
+template <int MINW>
+__global__ __launch_bounds__(HBLOCK, MINW) void compare_hash_kernel(
     const uint64_t* __restrict__ hashes, const uint64_t* __restrict__ offsets, uint32_t n,
     uint32_t row_lo, uint32_t row_hi, uint32_t* __restrict__ common, int symmetric,
     uint32_t rb_first, uint32_t rb_stride, const WorkItem* __restrict__ heavy,
@@ -259,14 +268,14 @@ __global__ __launch_bounds__(CMP_BLOCK, 4) void compare_hash_kernel(
     __shared__ uint32_t s_mask[HT];
     __shared__ uint32_t s_cnt[HR * HC];
     __shared__ uint64_t s_pos[HR + HC], s_end[HR + HC];
-    __shared__ unsigned long long s_hi;
-    __shared__ uint32_t s_live[2], s_top[2];      // s_top: rows / columns whose staged part holds the hash 2^64 - 1
-    __shared__ uint64_t s_piv[2];
+    __shared__ unsigned long long s_hi2[2];        // the round's bound, one cell per round parity
+    __shared__ uint32_t s_live2[2], s_top[2];      // s_live2: bit 0 rows / bit 1 columns with data left; s_top: rows / columns
+    __shared__ uint64_t s_piv[2];                  // whose staged part holds the hash 2^64 - 1
     __shared__ WorkItem s_item;
     __shared__ int s_have;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int k = tid; k < HT; k += CMP_BLOCK) { s_key[k] = H_EMPTY; s_mask[k] = 0; }
+    for (int k = tid; k < HT; k += HBLOCK) { s_key[k] = H_EMPTY; s_mask[k] = 0; }
 
     for (;;) {
         __syncthreads();                                   // previous item fully done (LDS reuse)
@@ -280,7 +289,7 @@ __global__ __launch_bounds__(CMP_BLOCK, 4) void compare_hash_kernel(
             }
             s_have = have;
         }
-        for (int k = tid; k < HR * HC; k += CMP_BLOCK) s_cnt[k] = 0;
+        for (int k = tid; k < HR * HC; k += HBLOCK) s_cnt[k] = 0;
         __syncthreads();
         if (!s_have) return;
         const WorkItem it = s_item;
@@ -313,95 +322,144 @@ __global__ __launch_bounds__(CMP_BLOCK, 4) void compare_hash_kernel(
             }
             __syncthreads();
         }
-        if (tid == 0) { s_top[0] = 0; s_top[1] = 0; }
-
-        for (;;) {
-            if (tid == 0) { s_hi = ~0ull; s_live[0] = 0; s_live[1] = 0; }
-            __syncthreads();
-            // ---- stage: lane l takes the l-th of the next <= 64 hashes of each of this wave's sketches ----
-            uint64_t e[HPW];
-            uint32_t valid = 0, more = 0;                   // bit i: this lane holds a staged hash of sketch i * 4 + wave /
-                                                            // that sketch has more than this round stages
+        if (tid == 0) { s_top[0] = 0; s_top[1] = 0; s_hi2[0] = ~0ull; s_hi2[1] = ~0ull; s_live2[0] = 0; s_live2[1] = 0; }
+        // this wave's sketches: s = i * HWAVES + wave; positions are wave-uniform and live in scalar registers
+        const uint64_t* at[HPW];                           // next unread hash of sketch i
+        uint32_t left[HPW];                                // hashes still unread (a slice of a sketch is < 2^32 long)
 #pragma unroll
-            for (int i = 0; i < HPW; ++i) {
-                const int s = i * 4 + wave;
-                const uint64_t pos = s_pos[s], left = s_end[s] - pos;
-                const bool ok = (uint64_t)lane < left;      // lane < min(left, 64)
-                valid |= (uint32_t)ok << i;
-                more |= (uint32_t)(left > (uint64_t)HSEG) << i;
-                e[i] = ok ? hashes[pos + lane] : ~0ull;
-            }
-#pragma unroll
-            for (int i = 0; i < HPW; ++i) {                 // (after all twelve loads are in flight)
-                const int s = i * 4 + wave;
-                if (lane == HSEG - 1 && ((more >> i) & 1u)) atomicMin(&s_hi, (unsigned long long)e[i]);
-                if (lane == 0 && (valid & (1u << i))) atomicOr(&s_live[s < HR ? 0 : 1], 1u);
-            }
-            __syncthreads();
-            if (s_live[0] == 0 || s_live[1] == 0) break;   // every row or every column exhausted
-            const uint64_t hi = s_hi;
-            // ---- rows: insert the staged hashes <= hi; advance every sketch by what this round consumes ----
-            uint32_t slot_of[HR / 4];
-#pragma unroll
-            for (int i = 0; i < HPW; ++i) {
-                const int s = i * 4 + wave;
-                const bool in = ((valid >> i) & 1u) && e[i] <= hi;
-                const uint32_t take = (uint32_t)__popcll(__ballot(in));
-                if (lane == 0) s_pos[s] += take;
-                if (i < HR / 4) {                          // sketch s = i * 4 + wave < HR: a row
-                    slot_of[i] = HT;
-                    if (in) {
-                        if (e[i] == H_EMPTY) {
-                            atomicOr(&s_top[0], 1u << s);
-                        } else {
-                            uint32_t slot = hash_slot(e[i]);
-                            for (;;) {
-                                const unsigned long long old = atomicCAS(&s_key[slot], H_EMPTY, (unsigned long long)e[i]);
-                                if (old == H_EMPTY || old == e[i]) break;
-                                slot = (slot + 1) & (HT - 1);
-                            }
-                            atomicOr(&s_mask[slot], 1u << s);
-                            slot_of[i] = slot;
-                        }
-                    }
-                }
-            }
-            __syncthreads();
-            // ---- columns: one lookup per staged hash <= hi, one LDS add per row that holds it ----
-#pragma unroll
-            for (int i = HR / 4; i < HPW; ++i) {
-                const int c = i * 4 + wave - HR;
-                if (((valid >> i) & 1u) && e[i] <= hi) {
-                    if (e[i] == H_EMPTY) {
-                        atomicOr(&s_top[1], 1u << c);
-                    } else {
-                        uint32_t slot = hash_slot(e[i]), m = 0;
-                        for (;;) {
-                            const unsigned long long k = s_key[slot];
-                            if (k == e[i]) { m = s_mask[slot]; break; }
-                            if (k == H_EMPTY) break;
-                            slot = (slot + 1) & (HT - 1);
-                        }
-                        while (m) {
-                            atomicAdd(&s_cnt[(__ffs((int)m) - 1) * HC + c], 1u);
-                            m &= m - 1;
-                        }
-                    }
-                }
-            }
-            __syncthreads();
-            // ---- the table goes back to empty: every inserter clears the slot it ended up in ----
-#pragma unroll
-            for (int i = 0; i < HR / 4; ++i)
-                if (slot_of[i] < (uint32_t)HT) { s_key[slot_of[i]] = H_EMPTY; s_mask[slot_of[i]] = 0; }
-            // the barrier at the top of the loop orders the clears before the next round's inserts
+        for (int i = 0; i < HPW; ++i) {
+            const uint64_t p0 = uniform64(s_pos[i * HWAVES + wave]), p1 = uniform64(s_end[i * HWAVES + wave]);
+            at[i] = hashes + p0;
+            left[i] = (uint32_t)(p1 - p0);
+        }
+        __syncthreads();                                   // s_top / s_hi2 / s_live2 are set before anyone's atomics
+        uint64_t e[HPW];
+        uint32_t valid = 0, more = 0;                      // bit i: this lane holds a staged hash of sketch i / that sketch has
+#pragma unroll                                             // more than this round stages
+        for (int i = 0; i < HPW; ++i) {
+            const bool ok = (uint32_t)lane < left[i];
+            valid |= (uint32_t)ok << i;
+            more |= (uint32_t)(left[i] > (uint32_t)HSEG) << i;
+            e[i] = ok ? at[i][lane] : ~0ull;
         }
 
+        for (uint32_t round = 0;; ++round) {
+            const uint32_t par = round & 1u;
+            // ---- the round's bound: smallest 64th staged hash among sketches with more to come ----
+#pragma unroll
+            for (int i = 0; i < HPW; ++i) {
+                const int s = i * HWAVES + wave;
+                if (lane == HSEG - 1 && ((more >> i) & 1u)) atomicMin(&s_hi2[par], (unsigned long long)e[i]);
+                if (lane == 0 && (valid & (1u << i))) atomicOr(&s_live2[par], s < HR ? 1u : 2u);
+            }
+            __syncthreads();
+            if (s_live2[par] != 3u) break;                 // every row or every column exhausted
+            const uint64_t hi = s_hi2[par];
+            if (tid == 0) { s_hi2[par ^ 1u] = ~0ull; s_live2[par ^ 1u] = 0; }     // next round's cells (not touched before its atomics)
+            // ---- what this round consumes; the next round's hashes start loading now ----
+            uint32_t in = 0;
+#pragma unroll
+            for (int i = 0; i < HPW; ++i) {
+                const bool mine = ((valid >> i) & 1u) && e[i] <= hi;
+                in |= (uint32_t)mine << i;
+                const uint32_t take = (uint32_t)__popcll(__ballot(mine));
+                at[i] += take;
+                left[i] -= take;
+            }
+            uint64_t en[HPW];
+            uint32_t nvalid = 0, nmore = 0;
+#pragma unroll
+            for (int i = 0; i < HPW; ++i) {
+                const bool ok = (uint32_t)lane < left[i];
+                nvalid |= (uint32_t)ok << i;
+                nmore |= (uint32_t)(left[i] > (uint32_t)HSEG) << i;
+                en[i] = ok ? at[i][lane] : ~0ull;
+            }
+            // ---- rows: insert; the probes of this lane's (up to) four hashes go out together ----
+            constexpr int NR = HR / HWAVES;
+            uint32_t slot[HPW], pend = 0, mine_slot[NR];
+#pragma unroll
+            for (int i = 0; i < NR; ++i) {
+                mine_slot[i] = HT;
+                slot[i] = hash_slot(e[i]);
+                if ((in >> i) & 1u) {
+                    if (e[i] == H_EMPTY) atomicOr(&s_top[0], 1u << (i * HWAVES + wave));
+                    else pend |= 1u << i;
+                }
+            }
+            while (__any(pend != 0)) {
+                unsigned long long old[NR];
+#pragma unroll
+                for (int i = 0; i < NR; ++i)
+                    if ((pend >> i) & 1u) old[i] = atomicCAS(&s_key[slot[i]], H_EMPTY, (unsigned long long)e[i]);
+#pragma unroll
+                for (int i = 0; i < NR; ++i)
+                    if ((pend >> i) & 1u) {
+                        if (old[i] == H_EMPTY || old[i] == e[i]) {
+                            atomicOr(&s_mask[slot[i]], 1u << (i * HWAVES + wave));
+                            mine_slot[i] = slot[i];
+                            pend &= ~(1u << i);
+                        } else {
+                            slot[i] = (slot[i] + 1) & (HT - 1);
+                        }
+                    }
+            }
+            __syncthreads();
+            // ---- columns: one lookup per hash, probes of the lane's (up to) eight hashes together, then the row masks,
+            //      then one LDS add per (row, column) that shares the hash ----
+            uint32_t found = 0;
+            pend = 0;
+#pragma unroll
+            for (int i = NR; i < HPW; ++i) {
+                slot[i] = hash_slot(e[i]);
+                if ((in >> i) & 1u) {
+                    if (e[i] == H_EMPTY) atomicOr(&s_top[1], 1u << (i * HWAVES + wave - HR));
+                    else pend |= 1u << i;
+                }
+            }
+            while (__any(pend != 0)) {
+                unsigned long long k[HPW];
+#pragma unroll
+                for (int i = NR; i < HPW; ++i)
+                    if ((pend >> i) & 1u) k[i] = s_key[slot[i]];
+#pragma unroll
+                for (int i = NR; i < HPW; ++i)
+                    if ((pend >> i) & 1u) {
+                        if (k[i] == e[i]) { found |= 1u << i; pend &= ~(1u << i); }
+                        else if (k[i] == H_EMPTY) pend &= ~(1u << i);
+                        else slot[i] = (slot[i] + 1) & (HT - 1);
+                    }
+            }
+            uint32_t m[HPW];
+#pragma unroll
+            for (int i = NR; i < HPW; ++i) m[i] = ((found >> i) & 1u) ? s_mask[slot[i]] : 0u;
+#pragma unroll
+            for (int i = NR; i < HPW; ++i) {
+                const int c = i * HWAVES + wave - HR;
+                uint32_t mm = m[i];
+                while (mm) {
+                    atomicAdd(&s_cnt[(__ffs((int)mm) - 1) * HC + c], 1u);
+                    mm &= mm - 1;
+                }
+            }
+            __syncthreads();
+            // ---- the table goes back to empty: every inserter clears the slot it ended up in (ordered before the
+            //      next round's inserts by the barrier after its bound) ----
+#pragma unroll
+            for (int i = 0; i < NR; ++i)
+                if (mine_slot[i] < (uint32_t)HT) { s_key[mine_slot[i]] = H_EMPTY; s_mask[mine_slot[i]] = 0; }
+#pragma unroll
+            for (int i = 0; i < HPW; ++i) e[i] = en[i];
+            valid = nvalid;
+            more = nmore;
+        }
+        __syncthreads();
+
         // the hash 2^64 - 1 (possible with scaled = 1) never went through the table
-        for (int k = tid; k < HR * HC; k += CMP_BLOCK)
+        for (int k = tid; k < HR * HC; k += HBLOCK)
             if (((s_top[0] >> (k / HC)) & 1u) && ((s_top[1] >> (k % HC)) & 1u)) s_cnt[k] += 1;
         __syncthreads();
-        for (int k = tid; k < HR * HC; k += CMP_BLOCK) {
+        for (int k = tid; k < HR * HC; k += HBLOCK) {
             const uint32_t cnt = s_cnt[k];
             const uint32_t r = (uint32_t)k / HC, c = (uint32_t)k % HC;
             const uint32_t row = row0 + r, col = col0 + c;
@@ -458,6 +516,11 @@ static bool use_walk_kernel() {
     return walk;
 }
 
+static bool hash_occ6() {
+    static const bool v = [] { const char* e = getenv("SMG_COMPARE_OCC"); return e && !strcmp(e, "6"); }();
+    return v;
+}
+
 static hipError_t compare_launch(const uint64_t* d_hashes, const uint64_t* d_offsets, uint32_t n, uint32_t row_lo,
                                  uint32_t row_hi, int symmetric, uint32_t rb_first, uint32_t rb_stride,
                                  uint32_t n_row_tiles, uint32_t* d_common, hipStream_t stream) {
@@ -479,7 +542,7 @@ static hipError_t compare_launch(const uint64_t* d_hashes, const uint64_t* d_off
         hipLaunchKernelGGL(compare_plan_kernel, dim3((unsigned)((tiles + 255) / 256)), dim3(256), 0, stream, d_offsets, n,
                            row_lo, row_hi, symmetric, rb_first, rb_stride, n_row_tiles, n_col_tiles,
                            pick_slice_len(work_tiles), heavy, light, counters, ctc);
-        const uint64_t cap = 256ull * (walk ? 8 : 5);
+        const uint64_t cap = 256ull * (walk ? 8 : 3);
         const unsigned grid0 = (unsigned)(work_tiles + 1 < cap ? work_tiles + 1 : cap);
         if (walk)
             // 64 hashes per sketch and round: 17 KiB of LDS per workgroup, 8 workgroups (= 8 waves per SIMD) per CU.
@@ -488,9 +551,15 @@ static hipError_t compare_launch(const uint64_t* d_hashes, const uint64_t* d_off
             hipLaunchKernelGGL((compare_tile_kernel<64>), dim3(grid0 < 1 ? 1 : grid0), dim3(CMP_BLOCK), 0, stream, d_hashes,
                                d_offsets, n, row_lo, row_hi, d_common, symmetric, rb_first, rb_stride, heavy, light, counters);
         else
-            // 27 KiB of LDS per workgroup (table 24 KiB + counters 2 KiB): 5 workgroups per CU
-            hipLaunchKernelGGL(compare_hash_kernel, dim3(grid0 < 1 ? 1 : grid0), dim3(CMP_BLOCK), 0, stream, d_hashes,
-                               d_offsets, n, row_lo, row_hi, d_common, symmetric, rb_first, rb_stride, heavy, light, counters);
+            // 27 KiB of LDS per workgroup (table 24 KiB + counters 2 KiB), 8 waves each
+            // two register budgets of the same kernel: 96 VGPRs (2 workgroups = 16 waves per CU, nothing spilled; default)
+            // and 80 VGPRs (3 workgroups, 44 bytes per lane spilled); SMG_COMPARE_OCC=6 picks the second
+            if (hash_occ6())
+                hipLaunchKernelGGL(compare_hash_kernel<6>, dim3(grid0 < 1 ? 1 : grid0), dim3(HBLOCK), 0, stream, d_hashes,
+                                   d_offsets, n, row_lo, row_hi, d_common, symmetric, rb_first, rb_stride, heavy, light, counters);
+            else
+                hipLaunchKernelGGL(compare_hash_kernel<5>, dim3(grid0 < 1 ? 1 : grid0), dim3(HBLOCK), 0, stream, d_hashes,
+                                   d_offsets, n, row_lo, row_hi, d_common, symmetric, rb_first, rb_stride, heavy, light, counters);
         e = hipGetLastError();
     }
     const hipError_t e2 = hipFreeAsync(ws, stream);

@@ -17,6 +17,8 @@
 // bound by VALU integer issue (12 64-bit multiplies per k-mer), not by HBM.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
+#include <utility>
 #include "kmer_core.hpp"
 #include "device_api.hpp"
 
@@ -209,11 +211,41 @@ static hipError_t launch_k(const uint8_t* d_seq, uint64_t len, uint64_t seed, ui
     return hipGetLastError();
 }
 
+// The register-window kernel is instantiated for EVERY ksize 1 .. 64 (the reference treats all k alike,
+// signature.rs:246-306; tests/test_kmer_core_cpu.py checks each instantiation against the oracle on the host): the
+// table below is what sketch_dna_launch dispatches through.  Longer k-mers take the byte-wise generic kernel.
+constexpr int FAST_MAX_K = 64;
+typedef hipError_t (*launch_fn)(const uint8_t*, uint64_t, uint64_t, uint64_t, uint64_t*, unsigned long long*, uint64_t, bool,
+                                hipStream_t);
+template <int K>
+static hipError_t launch_sparse_k(const uint8_t* d_seq, uint64_t len, uint64_t seed, uint64_t thr, uint64_t* d_out,
+                                  unsigned long long* d_count, uint64_t cap, bool, hipStream_t stream) {
+    constexpr uint64_t TILE = (uint64_t)SK_BLOCK * 16;
+    const uint32_t skip = (uint32_t)((uintptr_t)d_seq & 15);
+    d_seq -= skip;
+    len += skip;
+    const uint64_t n_tiles = (len + TILE - 1) / TILE;
+    if (n_tiles == 0) return hipSuccess;
+    const uint64_t max_blocks = 256ull * 8;
+    const unsigned grid = (unsigned)(n_tiles < max_blocks ? n_tiles : max_blocks);
+    hipLaunchKernelGGL((sketch_dna_kernel<K, 16, false>), dim3(grid), dim3(SK_BLOCK), 0, stream, d_seq, len, seed, thr, d_out,
+                       d_count, cap, n_tiles, skip);
+    return hipGetLastError();
+}
+template <int... KS>
+static launch_fn sparse_launcher(uint32_t k, std::integer_sequence<int, KS...>) {
+    static const launch_fn table[] = {&launch_sparse_k<KS + 1>...};
+    return table[k - 1];
+}
+
 static hipError_t sketch_any(const uint8_t* d_seq, uint64_t len, uint32_t k, uint64_t seed, uint64_t thr,
                              uint64_t* d_out, unsigned long long* d_count, uint64_t cap, bool dense,
                              hipStream_t stream) {
     if (len < k || k == 0) return hipSuccess;
-    switch (k) {
+    static const bool generic_only = [] { const char* e = getenv("SMG_SKETCH_GENERIC"); return e && *e == '1'; }();
+    if (!dense && k <= (uint32_t)FAST_MAX_K && !generic_only)
+        return sparse_launcher(k, std::make_integer_sequence<int, FAST_MAX_K>())(d_seq, len, seed, thr, d_out, d_count, cap, false, stream);
+    if (!generic_only) switch (k) {                                    // per-position output (seq_to_hashes): the usual ksizes
     case 21: return launch_k<21, 16>(d_seq, len, seed, thr, d_out, d_count, cap, dense, stream);
     case 31: return launch_k<31, 16>(d_seq, len, seed, thr, d_out, d_count, cap, dense, stream);
     case 51: return launch_k<51, 16>(d_seq, len, seed, thr, d_out, d_count, cap, dense, stream);

@@ -6,6 +6,7 @@
 #include <cstring>
 #include <vector>
 #include <algorithm>
+#include <utility>
 #include "../../sourmash_amd/csrc/kmer_core.hpp"
 
 template <int K, int P>
@@ -24,11 +25,22 @@ static uint64_t run(const uint8_t* seq, uint64_t len, uint64_t seed, uint64_t th
     return n;
 }
 
+// every ksize the GPU dispatch instantiates (sketch.hip: K = 1 .. 64 at P = 16) plus a few other lane widths
+typedef uint64_t (*run_fn)(const uint8_t*, uint64_t, uint64_t, uint64_t, uint64_t*, uint64_t);
+template <int... KS>
+static run_fn pick16(uint32_t k, std::integer_sequence<int, KS...>) {
+    static const run_fn table[] = {&run<KS + 1, 16>...};
+    return k >= 1 && k <= sizeof...(KS) ? table[k - 1] : nullptr;
+}
+
 extern "C" uint64_t emul_sketch(const uint8_t* seq, uint64_t len, uint32_t k, uint32_t p, uint64_t seed,
                                 uint64_t thr, uint64_t* out, uint64_t cap) {
+    if (p == 16) {
+        const run_fn f = pick16(k, std::make_integer_sequence<int, 64>());
+        return f ? f(seq, len, seed, thr, out, cap) : ~0ull;
+    }
 #define CASE(KK, PP) if (k == KK && p == PP) return run<KK, PP>(seq, len, seed, thr, out, cap);
-    CASE(31, 16) CASE(31, 8) CASE(21, 16) CASE(51, 16) CASE(4, 16) CASE(3, 16) CASE(5, 16) CASE(10, 16)
-    CASE(16, 16) CASE(32, 16) CASE(17, 8) CASE(15, 4) CASE(33, 16) CASE(63, 16) CASE(1, 16) CASE(8, 16) CASE(9,16)
+    CASE(31, 8) CASE(17, 8) CASE(15, 4)
 #undef CASE
     return ~0ull;
 }

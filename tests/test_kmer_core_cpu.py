@@ -45,6 +45,15 @@ def _rand_dna(rng, n, alphabet=b"ACGT"):
     return bytes(rng.choice(np.frombuffer(alphabet, dtype=np.uint8), size=n))
 
 
+def test_every_dispatched_ksize_matches_oracle(emul):
+    "sketch.hip instantiates the register-window kernel for every k = 1 .. 64 (P = 16): each one against the oracle"
+    rng = np.random.default_rng(2024)
+    for k in range(1, 65):
+        for n in (k - 1, k, k + 17, 700):
+            s = _rand_dna(rng, n, alphabet=b"ACGTacgtN" if n == 700 else b"ACGT")
+            assert np.array_equal(emul(s, k, 16), _oracle_all(s, k)), (k, n)
+
+
 @pytest.mark.parametrize("k,p", [(31, 16), (31, 8), (21, 16), (51, 16), (4, 16), (3, 16), (5, 16), (10, 16),
                                  (16, 16), (32, 16), (17, 8), (15, 4), (33, 16), (63, 16), (1, 16), (8, 16), (9, 16)])
 def test_all_kmers_match_oracle(emul, k, p):
