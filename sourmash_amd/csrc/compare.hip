@@ -239,7 +239,7 @@ __global__ __launch_bounds__(CMP_BLOCK) void compare_tile_kernel(
 constexpr int HR = CT;                // row sketches of a tile (inserted)
 constexpr int HC = 32;                // column sketches of a tile (looked up)
 constexpr int HSEG = 64;              // hashes staged per sketch and round: one per lane
-constexpr int HT = 2048;              // table slots: rows put in at most 16 x 64 = 1024 distinct hashes per round
+// table slots: 2^LOGT (template parameter); rows put in at most 16 x 64 = 1024 distinct hashes per round
 constexpr unsigned long long H_EMPTY = ~0ull;   // never a key: a staged hash equal to 2^64 - 1 is counted out of band
 constexpr int HWAVES = 8;             // waves per workgroup: sketch s = i * HWAVES + wave, so every wave holds HR / 8 rows
 constexpr int HBLOCK = HWAVES * 64;
@@ -251,19 +251,20 @@ __device__ __forceinline__ uint64_t uniform64(uint64_t v) {          // a wave-u
            (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
 }
 
+template <int LOGT>
 __device__ __forceinline__ uint32_t hash_slot(uint64_t v) {
     const uint32_t x = ((uint32_t)v ^ (uint32_t)(v >> 32)) * 0x9E3779B1u;   // slabs share their top bits: mix before cutting
-    return x >> (32 - 11);
+    return x >> (32 - LOGT);
 }
-static_assert(HT == (1 << 11), "hash_slot cuts 11 bits");
 
-template <int MINW>
+template <int MINW, int LOGT>
 __global__ __launch_bounds__(HBLOCK, MINW) void compare_hash_kernel(
     const uint64_t* __restrict__ hashes, const uint64_t* __restrict__ offsets, uint32_t n,
     uint32_t row_lo, uint32_t row_hi, uint32_t* __restrict__ common, int symmetric,
     uint32_t rb_first, uint32_t rb_stride, const WorkItem* __restrict__ heavy,
     const WorkItem* __restrict__ light, unsigned int* __restrict__ counters) {
     // same contract as compare_tile_kernel (symmetric modes, work lists, output rows), tiles of HR rows x HC columns
+    constexpr int HT = 1 << LOGT;
     __shared__ unsigned long long s_key[HT];
     __shared__ uint32_t s_mask[HT];
     __shared__ uint32_t s_cnt[HR * HC];
@@ -381,7 +382,7 @@ __global__ __launch_bounds__(HBLOCK, MINW) void compare_hash_kernel(
 #pragma unroll
             for (int i = 0; i < NR; ++i) {
                 mine_slot[i] = HT;
-                slot[i] = hash_slot(e[i]);
+                slot[i] = hash_slot<LOGT>(e[i]);
                 if ((in >> i) & 1u) {
                     if (e[i] == H_EMPTY) atomicOr(&s_top[0], 1u << (i * HWAVES + wave));
                     else pend |= 1u << i;
@@ -411,7 +412,7 @@ __global__ __launch_bounds__(HBLOCK, MINW) void compare_hash_kernel(
             pend = 0;
 #pragma unroll
             for (int i = NR; i < HPW; ++i) {
-                slot[i] = hash_slot(e[i]);
+                slot[i] = hash_slot<LOGT>(e[i]);
                 if ((in >> i) & 1u) {
                     if (e[i] == H_EMPTY) atomicOr(&s_top[1], 1u << (i * HWAVES + wave - HR));
                     else pend |= 1u << i;
@@ -516,8 +517,8 @@ static bool use_walk_kernel() {
     return walk;
 }
 
-static bool hash_occ6() {
-    static const bool v = [] { const char* e = getenv("SMG_COMPARE_OCC"); return e && !strcmp(e, "6"); }();
+static int hash_variant() {       // SMG_COMPARE_VARIANT: tuning variants of the hash-table kernel (profiles/r02_compare_kernels.txt)
+    static const int v = [] { const char* e = getenv("SMG_COMPARE_VARIANT"); return e ? atoi(e) : 0; }();
     return v;
 }
 
@@ -550,16 +551,19 @@ static hipError_t compare_launch(const uint64_t* d_hashes, const uint64_t* d_off
             // rounds amortise the barriers (measured: +33 % pairs/s over 128 hashes per round at 5,000-hash sketches).
             hipLaunchKernelGGL((compare_tile_kernel<64>), dim3(grid0 < 1 ? 1 : grid0), dim3(CMP_BLOCK), 0, stream, d_hashes,
                                d_offsets, n, row_lo, row_hi, d_common, symmetric, rb_first, rb_stride, heavy, light, counters);
-        else
+        else {
             // 27 KiB of LDS per workgroup (table 24 KiB + counters 2 KiB), 8 waves each
             // two register budgets of the same kernel: 96 VGPRs (2 workgroups = 16 waves per CU, nothing spilled; default)
             // and 80 VGPRs (3 workgroups, 44 bytes per lane spilled); SMG_COMPARE_OCC=6 picks the second
-            if (hash_occ6())
-                hipLaunchKernelGGL(compare_hash_kernel<6>, dim3(grid0 < 1 ? 1 : grid0), dim3(HBLOCK), 0, stream, d_hashes,
-                                   d_offsets, n, row_lo, row_hi, d_common, symmetric, rb_first, rb_stride, heavy, light, counters);
-            else
-                hipLaunchKernelGGL(compare_hash_kernel<5>, dim3(grid0 < 1 ? 1 : grid0), dim3(HBLOCK), 0, stream, d_hashes,
-                                   d_offsets, n, row_lo, row_hi, d_common, symmetric, rb_first, rb_stride, heavy, light, counters);
+            const int variant = hash_variant();
+#define SMG_LAUNCH_HASH(MINW, LOGT)                                                                                              \
+    hipLaunchKernelGGL((compare_hash_kernel<MINW, LOGT>), dim3(grid0 < 1 ? 1 : grid0), dim3(HBLOCK), 0, stream, d_hashes, d_offsets, \
+                       n, row_lo, row_hi, d_common, symmetric, rb_first, rb_stride, heavy, light, counters)
+            if (variant == 1) SMG_LAUNCH_HASH(5, 11);           // 96 VGPRs, nothing spilled, 2 workgroups per CU
+            else if (variant == 2) SMG_LAUNCH_HASH(6, 12);      // 4,096 slots (load factor 1/4), 50 KiB of LDS
+            else SMG_LAUNCH_HASH(6, 11);                        // default: 80 VGPRs (44 bytes per lane spilled), 3 workgroups per CU
+#undef SMG_LAUNCH_HASH
+        }
         e = hipGetLastError();
     }
     const hipError_t e2 = hipFreeAsync(ws, stream);
