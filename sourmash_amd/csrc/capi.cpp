@@ -937,18 +937,19 @@ void smgpu_bitindex_compare_raw(const SmgpuBitIndex* p, uint32_t rb_first, uint3
 // n x n counts (+ Jaccard) of a device-resident CSR into host matrices; dense collections take the bit-row path
 static void compare_device_csr(const uint64_t* d_hashes, const uint64_t* d_offsets, uint64_t n, uint64_t total,
                                uint32_t* common_out, double* jaccard_out, hipStream_t st) {
-    DevBuf dc, dj;
-    struct Free { DevBuf& b; ~Free() { if (b.p) (void)hipFree(b.p); } } f3{dc}, f4{dj};
-    dc.reserve((size_t)((n + 15) / 16 * 16) * n * 4);
+    // result matrices from the stream-ordered pool (kept between calls): hipMalloc / hipFree of a gigabyte per call cost
+    // more than the comparison on hosts with a slow driver path
+    AsyncBuf dc((size_t)((n + 15) / 16 * 16) * n * 4, st);
     std::unique_ptr<BitIndex> bi(bitindex_build(d_hashes, d_offsets, (uint32_t)n, st, 0, true, total));
     if (bi)   // bit rows for the frequent hashes + inverted lists for the rare ones
         bitindex_compare(bi.get(), 0, 1, (uint32_t)((n + 15) / 16), dc.as<uint32_t>(), st);
     else      // LDS-tiled merge walk
         hip_check(compare_counts_launch(d_hashes, d_offsets, (uint32_t)n, 0, (uint32_t)n, dc.as<uint32_t>(), st), "compare");
+    std::unique_ptr<AsyncBuf> dj;
     if (jaccard_out) {
-        dj.reserve((size_t)n * n * 8);
-        hip_check(jaccard_from_counts_launch(dc.as<uint32_t>(), d_offsets, (uint32_t)n, 0, (uint32_t)n, dj.as<double>(), st), "jaccard");
-        hip_check(hipMemcpyAsync(jaccard_out, dj.p, (size_t)n * n * 8, hipMemcpyDeviceToHost, st), "D2H");
+        dj.reset(new AsyncBuf((size_t)n * n * 8, st));
+        hip_check(jaccard_from_counts_launch(dc.as<uint32_t>(), d_offsets, (uint32_t)n, 0, (uint32_t)n, dj->as<double>(), st), "jaccard");
+        hip_check(hipMemcpyAsync(jaccard_out, dj->p, (size_t)n * n * 8, hipMemcpyDeviceToHost, st), "D2H");
     }
     if (common_out) hip_check(hipMemcpyAsync(common_out, dc.p, (size_t)n * n * 4, hipMemcpyDeviceToHost, st), "D2H");
     hip_check(hipStreamSynchronize(st), "sync");
@@ -967,10 +968,7 @@ void smgpu_compare_all_pairs(const SourmashKmerMinHash* const* mhs, uintptr_t n,
         DeviceCtx& ctx = DeviceCtx::get();
         std::lock_guard<std::mutex> g(ctx.mutex());
         hipStream_t st = ctx.stream();
-        DevBuf dh, doff;
-        struct Free { DevBuf& b; ~Free() { if (b.p) (void)hipFree(b.p); } } f1{dh}, f2{doff};
-        dh.reserve(total * 8 + 16);
-        doff.reserve((n + 1) * 8);
+        AsyncBuf dh(total * 8 + 16, st), doff((n + 1) * 8, st);
         for (uintptr_t i = 0; i < n; ++i)
             if (MH(mhs[i])->size())
                 hip_check(hipMemcpyAsync(dh.as<uint64_t>() + offsets[i], MH(mhs[i])->mins.data(), MH(mhs[i])->size() * 8,

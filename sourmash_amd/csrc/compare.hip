@@ -552,16 +552,16 @@ static hipError_t compare_launch(const uint64_t* d_hashes, const uint64_t* d_off
             hipLaunchKernelGGL((compare_tile_kernel<64>), dim3(grid0 < 1 ? 1 : grid0), dim3(CMP_BLOCK), 0, stream, d_hashes,
                                d_offsets, n, row_lo, row_hi, d_common, symmetric, rb_first, rb_stride, heavy, light, counters);
         else {
-            // 27 KiB of LDS per workgroup (table 24 KiB + counters 2 KiB), 8 waves each
             // two register budgets of the same kernel: 96 VGPRs (2 workgroups = 16 waves per CU, nothing spilled; default)
             // and 80 VGPRs (3 workgroups, 44 bytes per lane spilled); SMG_COMPARE_OCC=6 picks the second
             const int variant = hash_variant();
 #define SMG_LAUNCH_HASH(MINW, LOGT)                                                                                              \
     hipLaunchKernelGGL((compare_hash_kernel<MINW, LOGT>), dim3(grid0 < 1 ? 1 : grid0), dim3(HBLOCK), 0, stream, d_hashes, d_offsets, \
                        n, row_lo, row_hi, d_common, symmetric, rb_first, rb_stride, heavy, light, counters)
-            if (variant == 1) SMG_LAUNCH_HASH(5, 11);           // 96 VGPRs, nothing spilled, 2 workgroups per CU
-            else if (variant == 2) SMG_LAUNCH_HASH(6, 12);      // 4,096 slots (load factor 1/4), 50 KiB of LDS
-            else SMG_LAUNCH_HASH(6, 11);                        // default: 80 VGPRs (44 bytes per lane spilled), 3 workgroups per CU
+            if (variant == 1) SMG_LAUNCH_HASH(5, 11);           // 2,048 slots, 96 VGPRs, nothing spilled, 2 workgroups per CU
+            else if (variant == 2) SMG_LAUNCH_HASH(6, 11);      // 2,048 slots (load factor 1/2), 80 VGPRs, 3 workgroups per CU
+            else SMG_LAUNCH_HASH(6, 12);                        // default: 4,096 slots (load factor 1/4: shorter probe chains), 50 KiB
+                                                                // of LDS, 80 VGPRs (44 bytes per lane spilled), 3 workgroups per CU
 #undef SMG_LAUNCH_HASH
         }
         e = hipGetLastError();

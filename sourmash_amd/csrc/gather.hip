@@ -88,7 +88,10 @@ __global__ __launch_bounds__(256) void build_fill_kernel(const uint32_t* __restr
 //   bounds   [R + 1][ndb]  first position of row d whose hash is >= Q[r * BR_RANGE]  (row length for r = R)
 //   partial  [B][nq]       pass 1: postings of query hash j contributed by block b; then its exclusive prefix over b
 // so that in pass 2 the slot of an element is post_off[j] + partial[b][j] + (LDS cursor of j in this workgroup).
-constexpr int BR_RANGE = 32768;      // query positions per range: row slices long enough (~1 KB) to read DRAM efficiently
+#ifndef SMG_BR_RANGE
+#define SMG_BR_RANGE 32768
+#endif
+constexpr int BR_RANGE = SMG_BR_RANGE;      // query positions per range: row slices long enough (~1 KB) to read DRAM efficiently
 constexpr int BR_EPW = 16;           // row slices a wave flattens per step (see apply_kernel)
 constexpr int BR_THREADS = 512;      // 64 KB of LDS per workgroup (u16 slots, two per word): 2 workgroups = 16 waves per CU
 // Two-level fill (the default): a 4-byte store per posting straight into its list leaves 32,768 lists x 8 lines open per
@@ -204,7 +207,11 @@ __global__ __launch_bounds__(BR_THREADS) void build_range_kernel(QIndex qi, cons
             const uint32_t first = (uint32_t)__shfl((int)excl, h);
             uint32_t j = NONE32;
             if (t < total) {
-                if (FILL || PART) {
+                if (PART) {
+                    // read once, never again: a streaming (non-temporal) load, so that the 2 GB of positions flowing through
+                    // do not push the partially written lines of the output streams out of the L2
+                    j = __builtin_nontemporal_load(&qpos[start + (t - first)]);
+                } else if (FILL) {
                     j = qpos[start + (t - first)];                  // pass 1 left it there
                 } else {
                     j = q_find(qi, hashes[start + (t - first)]);
@@ -812,23 +819,47 @@ static QIndex qindex_of(const GatherDev& g) { return QIndex{g.q_padded, g.nq, g.
         if (e_ != hipSuccess) return e_;   \
     } while (0)
 
+// Owned buffers come from the stream-ordered pool (its release threshold is raised in keep_pool()): a rebuilt index gets
+// its gigabytes back from the pool instead of from the driver, whose hipMalloc / hipFree of such sizes took 100+ ms on
+// some hosts (profiles/r02_gather_host_variance.txt).
+static void keep_pool() {
+    static const bool once = [] {
+        int dev = 0;
+        hipMemPool_t pool = nullptr;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess && pool) {
+            uint64_t keep = ~0ull;
+            (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+        }
+        return true;
+    }();
+    (void)once;
+}
+template <class T>
+static hipError_t own_alloc(GatherDev& g, T** p, size_t bytes, hipStream_t user = nullptr) {
+    keep_pool();
+    const hipError_t e = hipMallocAsync((void**)p, bytes, g.stream);
+    if (e != hipSuccess || user == nullptr || user == g.stream) return e;
+    return hipStreamSynchronize(g.stream);       // another stream is about to use the buffer: it must exist by then
+}
+
 void gather_destroy(GatherDev& g) {
     void* owned[] = {g.q_padded, g.q_table, g.q_rec, g.alive, g.post_off, g.post_rows, g.qpos, g.counters, g.state, g.partials, g.out_idx, g.out_isect,
                      g.topk_sel, g.topk_partials, g.cmask, g.cand_count, g.cand_key, g.cand_len, g.cand_qpos, g.own_cands};
     for (void* p : owned)
-        if (p) (void)hipFree(p);
+        if (p) (void)hipFreeAsync(p, g.stream);
     g = GatherDev();
 }
 
 hipError_t gather_build(GatherDev& g, hipStream_t stream) {
+    g.stream = stream;
     if (g.nq >= NONE32) return hipErrorInvalidValue;             // query positions are u32
     if (g.ndb >= NONE32) return hipErrorInvalidValue;            // row ids are u32
     const uint64_t nq1 = g.nq + 1;
-    SMG_TRY(hipMalloc(&g.state, GS_SLOTS * 8));
-    SMG_TRY(hipMalloc(&g.partials, GATHER_PICK_BLOCKS * 8));
-    SMG_TRY(hipMalloc(&g.counters, (g.ndb + 1) * 8));
-    SMG_TRY(hipMalloc(&g.alive, g.nq + 16));
-    SMG_TRY(hipMalloc(&g.post_off, nq1 * 8));
+    SMG_TRY(own_alloc(g, &g.state, GS_SLOTS * 8));
+    SMG_TRY(own_alloc(g, &g.partials, GATHER_PICK_BLOCKS * 8));
+    SMG_TRY(own_alloc(g, &g.counters, (g.ndb + 1) * 8));
+    SMG_TRY(own_alloc(g, &g.alive, g.nq + 16));
+    SMG_TRY(own_alloc(g, &g.post_off, nq1 * 8));
     SMG_TRY(hipMemsetAsync(g.state, 0, GS_SLOTS * 8, stream));
     SMG_TRY(hipMemsetAsync(g.counters, 0, (g.ndb + 1) * 8, stream));
     SMG_TRY(hipMemsetAsync(g.alive, 1, g.nq + 16, stream));
@@ -846,17 +877,17 @@ hipError_t gather_build(GatherDev& g, hipStream_t stream) {
     }
     if (g.nq) SMG_TRY(hipMemcpyAsync(&g.q_max, g.Q + g.nq - 1, 8, hipMemcpyDeviceToHost, stream));
     SMG_TRY(hipStreamSynchronize(stream));
-    SMG_TRY(hipMalloc(&g.q_padded, (g.nq + 4) * 8));
+    SMG_TRY(own_alloc(g, &g.q_padded, (g.nq + 4) * 8));
     if (g.nq) SMG_TRY(hipMemcpyAsync(g.q_padded, g.Q, g.nq * 8, hipMemcpyDeviceToDevice, stream));
     for (int i = 0; i < 4; ++i)                                   // &g.q_max outlives the copies: the stream is synchronised below
         SMG_TRY(hipMemcpyAsync(g.q_padded + g.nq + i, &g.q_max, 8, hipMemcpyHostToDevice, stream));
     qindex_geometry(g.nq, g.q_max, &g.q_shift, &g.q_buckets);
-    SMG_TRY(hipMalloc(&g.q_table, ((uint64_t)g.q_buckets + 1) * 4));
+    SMG_TRY(own_alloc(g, &g.q_table, ((uint64_t)g.q_buckets + 1) * 4));
     hipLaunchKernelGGL(qtable_kernel, dim3((g.q_buckets + 256) / 256), dim3(256), 0, stream, g.Q, g.nq, g.q_shift,
                        g.q_buckets, g.q_table);
     SMG_TRY(hipGetLastError());
     if (g.nq && !getenv("SMG_GATHER_NO_QREC")) {
-        SMG_TRY(hipMalloc(&g.q_rec, (uint64_t)g.q_buckets * sizeof(QRec)));
+        SMG_TRY(own_alloc(g, &g.q_rec, (uint64_t)g.q_buckets * sizeof(QRec)));
         hipLaunchKernelGGL(qrec_kernel, dim3((g.q_buckets + 255) / 256), dim3(256), 0, stream, g.Q, g.q_table, g.q_buckets, g.q_rec);
         SMG_TRY(hipGetLastError());
     }
@@ -873,7 +904,7 @@ hipError_t gather_build(GatherDev& g, hipStream_t stream) {
                                     rocprim::plus<uint64_t>(), stream));
     void* scan_tmp = nullptr;
     SMG_TRY(hipMallocAsync(&scan_tmp, scan_bytes + 256, stream));
-    SMG_TRY(hipMalloc(&g.qpos, (total + 4) * 4));                // kept: apply reads it instead of looking hashes up again
+    SMG_TRY(own_alloc(g, &g.qpos, (total + 4) * 4));                // kept: apply reads it instead of looking hashes up again
     // Small problems: one atomic per element is cheapest.  Large ones: range-partitioned, histogram and cursors in LDS.
     const char* force = getenv("SMG_GATHER_BUILD");
     bool ranges = force ? !strcmp(force, "ranges") : (total >= (8ull << 20) && g.ndb >= 256);
@@ -896,7 +927,7 @@ hipError_t gather_build(GatherDev& g, hipStream_t stream) {
         SMG_TRY(hipMemcpyAsync(&g.npairs, g.post_off + g.nq, 8, hipMemcpyDeviceToHost, stream));
         SMG_TRY(hipMemcpyAsync(post_cnt, g.post_off, nq1 * 8, hipMemcpyDeviceToDevice, stream));   // cursors
         SMG_TRY(hipStreamSynchronize(stream));
-        SMG_TRY(hipMalloc(&g.post_rows, (g.npairs + 4) * 4));
+        SMG_TRY(own_alloc(g, &g.post_rows, (g.npairs + 4) * 4));
         hipLaunchKernelGGL(build_fill_kernel, dim3(blocks_for_rows(g.ndb)), dim3(256), 0, stream, qpos, g.offsets, g.ndb,
                            post_cnt, g.post_rows);
         SMG_TRY(hipGetLastError());
@@ -943,7 +974,7 @@ hipError_t gather_build(GatherDev& g, hipStream_t stream) {
             SMG_TRY(rocprim::exclusive_scan(lay_tmp, lay_bytes, subcnt, inter_off, 0u, (size_t)n_windows * B, rocprim::plus<uint32_t>(), stream));
         }
         SMG_TRY(hipStreamSynchronize(stream));
-        SMG_TRY(hipMalloc(&g.post_rows, (g.npairs + 4) * 4));
+        SMG_TRY(own_alloc(g, &g.post_rows, (g.npairs + 4) * 4));
         const uint64_t inter_words = g.npairs + 4;
         if (staged && (inter_words >= 0xffffffffull || B > 512)) staged = false;
         if (staged) {
@@ -985,11 +1016,11 @@ hipError_t gather_begin(GatherDev& g, uint64_t thr_hashes, uint64_t max_rounds, 
     if (max_rounds == 0) max_rounds = 1;
     if (max_rounds > g.out_cap) {
         SMG_TRY(hipStreamSynchronize(stream));
-        if (g.out_idx) (void)hipFree(g.out_idx);
-        if (g.out_isect) (void)hipFree(g.out_isect);
+        if (g.out_idx) (void)hipFreeAsync(g.out_idx, stream);
+        if (g.out_isect) (void)hipFreeAsync(g.out_isect, stream);
         g.out_idx = g.out_isect = nullptr;
-        SMG_TRY(hipMalloc(&g.out_idx, max_rounds * 8));
-        SMG_TRY(hipMalloc(&g.out_isect, max_rounds * 8));
+        SMG_TRY(own_alloc(g, &g.out_idx, max_rounds * 8, stream));
+        SMG_TRY(own_alloc(g, &g.out_isect, max_rounds * 8, stream));
         g.out_cap = max_rounds;
     }
     // rounds restart at 0; the uncovered set, its size and the counters carry over
@@ -1039,12 +1070,12 @@ hipError_t gather_enqueue_rounds(GatherDev& g, unsigned rounds, hipStream_t stre
 // ---- candidate replay --------------------------------------------------------------------------------------------
 static hipError_t replay_buffers(GatherDev& g, hipStream_t stream) {
     if (g.cmask) return hipSuccess;
-    SMG_TRY(hipMalloc(&g.topk_sel, (GATHER_TOPK_MAX + 1) * 8));
-    SMG_TRY(hipMalloc(&g.topk_partials, (size_t)GATHER_PICK_BLOCKS * (GATHER_TOPK_MAX + 1) * 8));
-    SMG_TRY(hipMalloc(&g.cmask, (g.nq + 1) * 8));
-    SMG_TRY(hipMalloc(&g.cand_count, GATHER_CAND_MAX * 8));
-    SMG_TRY(hipMalloc(&g.cand_key, GATHER_CAND_MAX * 8));
-    SMG_TRY(hipMalloc(&g.cand_len, GATHER_CAND_MAX * 4));
+    SMG_TRY(own_alloc(g, &g.topk_sel, (GATHER_TOPK_MAX + 1) * 8, stream));
+    SMG_TRY(own_alloc(g, &g.topk_partials, (size_t)GATHER_PICK_BLOCKS * (GATHER_TOPK_MAX + 1) * 8, stream));
+    SMG_TRY(own_alloc(g, &g.cmask, (g.nq + 1) * 8, stream));
+    SMG_TRY(own_alloc(g, &g.cand_count, GATHER_CAND_MAX * 8, stream));
+    SMG_TRY(own_alloc(g, &g.cand_key, GATHER_CAND_MAX * 8, stream));
+    SMG_TRY(own_alloc(g, &g.cand_len, GATHER_CAND_MAX * 4, stream));
     SMG_TRY(hipMemsetAsync(g.cmask, 0, (g.nq + 1) * 8, stream));
     SMG_TRY(hipMemsetAsync(g.cand_count, 0, GATHER_CAND_MAX * 8, stream));
     SMG_TRY(hipMemsetAsync(g.cand_key, 0, GATHER_CAND_MAX * 8, stream));
@@ -1076,10 +1107,10 @@ hipError_t gather_cands_load(GatherDev& g, const uint64_t* d_cands, uint32_t n_c
                                g.cand_qstride);
             SMG_TRY(hipMemsetAsync(g.cand_len, 0, GATHER_CAND_MAX * 4, stream));
             SMG_TRY(hipStreamSynchronize(stream));
-            (void)hipFree(g.cand_qpos);
+            (void)hipFreeAsync(g.cand_qpos, stream);
             g.cand_qpos = nullptr;
         }
-        SMG_TRY(hipMalloc(&g.cand_qpos, (size_t)GATHER_CAND_MAX * stride * 4));
+        SMG_TRY(own_alloc(g, &g.cand_qpos, (size_t)GATHER_CAND_MAX * stride * 4, stream));
         g.cand_qstride = stride;
     }
     hipLaunchKernelGGL(cands_clear_kernel, dim3(GATHER_CAND_MAX), dim3(256), 0, stream, g.cmask, g.cand_len, g.cand_qpos,
@@ -1112,7 +1143,7 @@ hipError_t gather_enqueue_replay(GatherDev& g, unsigned exchanges, hipStream_t s
     const uint32_t K = GATHER_TOPK_MAX;
     if (!g.own_cands) {
         g.own_cands_words = (GATHER_CAND_HEAD + (g.longest_row ? g.longest_row : 1)) * K;
-        SMG_TRY(hipMalloc(&g.own_cands, g.own_cands_words * 8));
+        SMG_TRY(own_alloc(g, &g.own_cands, g.own_cands_words * 8, stream));
     }
     const uint64_t stride = g.own_cands_words / K;
     for (unsigned x = 0; x < exchanges; ++x) {
@@ -1121,6 +1152,106 @@ hipError_t gather_enqueue_replay(GatherDev& g, unsigned exchanges, hipStream_t s
         SMG_TRY(gather_replay_rounds(g, K, stream));
     }
     return hipSuccess;
+}
+
+// ---- streaming lookups: the query flows through LDS, the database is read once -----------------------------------
+// The range kernels above look every database hash up in structures that live in L2 (two dependent 16-byte loads per
+// element from lines nobody else in the wave touches): 5e8 lookups cost 5-6 ms at C5 whatever else the pass does.
+// Here a workgroup owns a block of rows and walks the QUERY in order: the hash space is cut at multiples of
+// SL_BUCKETS buckets of the first-level table (about SL_BUCKETS query hashes each, because there is about one hash per
+// bucket); for each such range the workgroup loads that slice of the table and of the query into LDS (32 KB), then
+// visits each of its rows once: a group of 16 lanes reads the row's next 16 hashes at the row's cursor, the ones below
+// the range's upper bound are looked up in LDS (table entry -> at most a few query hashes, compared in registers) and
+// consumed, the cursor moves on.  Rows are sorted, so a row's hashes inside a range are contiguous and every database
+// hash is read from HBM once, by consecutive lanes.  No per-(row, range) bounds are precomputed: the cursors carry over.
+// Workgroup (block b, group g) covers ranges [g * per, (g + 1) * per); its first cursors come from a binary search.
+constexpr int SL_BUCKETS = 2048;          // table buckets per range
+constexpr int SL_QCAP = 3072;             // query hashes a range may hold (uniform hashes: 2048 +- 45); else the caller falls back
+constexpr int SL_ROWS = 2048;             // rows per block (cursors and per-row hit counts live in LDS)
+constexpr int SL_THREADS = 512;
+constexpr int SL_GROUP = 16;              // lanes per row visit
+
+// largest number of query hashes in any range (the caller checks it against SL_QCAP)
+__global__ __launch_bounds__(256) void stream_range_max_kernel(const uint32_t* __restrict__ T, uint32_t n_buckets, uint32_t n_ranges,
+                                                              unsigned int* out) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_ranges) return;
+    const uint32_t b0 = r * SL_BUCKETS, b1 = b0 + SL_BUCKETS < n_buckets ? b0 + SL_BUCKETS : n_buckets;
+    atomicMax(out, T[b1] - T[b0]);
+}
+
+template <int MODE>    // 3: overlaps only (counters[d] += |Q ∩ row d|)
+__global__ __launch_bounds__(SL_THREADS) void stream_lookup_kernel(const uint64_t* __restrict__ Q, const uint32_t* __restrict__ T,
+                                                                   uint32_t n_buckets, uint32_t shift, uint64_t qmax,
+                                                                   const uint64_t* __restrict__ hashes,
+                                                                   const uint64_t* __restrict__ offsets, uint64_t ndb,
+                                                                   uint32_t n_blocks, uint32_t n_ranges, uint32_t ranges_per_group,
+                                                                   unsigned long long* __restrict__ counters) {
+    __shared__ __attribute__((aligned(16))) uint64_t s_q[SL_QCAP];
+    __shared__ __attribute__((aligned(16))) uint32_t s_t[SL_BUCKETS + 4];
+    __shared__ uint32_t s_cur[SL_ROWS], s_hits[SL_ROWS];
+    const uint32_t b = blockIdx.x % n_blocks, g = blockIdx.x / n_blocks;
+    const uint64_t d_lo = (uint64_t)b * SL_ROWS;
+    const uint32_t n_rows = (uint32_t)(ndb - d_lo < (uint64_t)SL_ROWS ? ndb - d_lo : (uint64_t)SL_ROWS);
+    const uint32_t r_lo = g * ranges_per_group;
+    const uint32_t r_hi = r_lo + ranges_per_group < n_ranges ? r_lo + ranges_per_group : n_ranges;
+    if (r_lo >= r_hi) return;
+    const int tid = threadIdx.x;
+    // first cursors: where the group's first range starts in every row
+    const uint64_t first_hash = ((uint64_t)r_lo * SL_BUCKETS) << shift;
+    for (uint32_t i = tid; i < n_rows; i += SL_THREADS) {
+        const uint64_t base = offsets[d_lo + i], len = offsets[d_lo + i + 1] - base;
+        uint64_t lo = 0, hi = len;
+        if (r_lo != 0)
+            while (lo < hi) {
+                const uint64_t mid = (lo + hi) >> 1;
+                if (hashes[base + mid] < first_hash) lo = mid + 1; else hi = mid;
+            }
+        else hi = 0;
+        s_cur[i] = (uint32_t)(r_lo != 0 ? lo : 0);
+        s_hits[i] = 0;
+    }
+    const int grp = tid / SL_GROUP, gl = tid % SL_GROUP;                 // 32 groups of 16 lanes
+    const int sh16 = (tid & 63) / SL_GROUP * SL_GROUP;                   // this group's bit offset inside the wave's ballot
+    for (uint32_t r = r_lo; r < r_hi; ++r) {
+        const uint32_t b0 = r * SL_BUCKETS, b1 = b0 + SL_BUCKETS < n_buckets ? b0 + SL_BUCKETS : n_buckets;
+        const uint32_t p0 = T[b0], p1 = T[b1];
+        const bool last = r + 1 == n_ranges;
+        // hashes below `upper` belong to this range or an earlier one (earlier ones are consumed already)
+        const uint64_t upper = last ? ~0ull : ((uint64_t)b1 << shift);
+        __syncthreads();                                                  // the previous range's readers are done
+        for (uint32_t i = tid; i < b1 - b0 + 1; i += SL_THREADS) s_t[i] = T[b0 + i] - p0;
+        for (uint32_t i = tid; i < p1 - p0; i += SL_THREADS) s_q[i] = Q[p0 + i];
+        __syncthreads();
+        for (uint32_t i = grp; i < n_rows; i += SL_THREADS / SL_GROUP) {
+            const uint64_t base = offsets[d_lo + i];
+            const uint32_t len = (uint32_t)(offsets[d_lo + i + 1] - base);
+            uint32_t c = s_cur[i], hits = 0;
+            for (;;) {
+                const bool have = c + gl < len;
+                const uint64_t e = have ? hashes[base + c + gl] : ~0ull;
+                const bool in = have && (last || e < upper);
+                const uint32_t taken = (uint32_t)__popc((uint32_t)((__ballot(in) >> sh16) & 0xffffu));
+                bool hit = false;
+                if (in && e <= qmax) {
+                    const uint32_t k = (uint32_t)(e >> shift) - b0;          // < SL_BUCKETS: the hash lies in this range
+                    const uint32_t t0 = s_t[k], t1 = s_t[k + 1];
+                    for (uint32_t t = t0; t < t1; ++t) {
+                        const uint64_t qv = s_q[t];
+                        if (qv == e) { hit = true; break; }
+                        if (qv > e) break;
+                    }
+                }
+                hits += (uint32_t)__popc((uint32_t)((__ballot(hit) >> sh16) & 0xffffu));
+                c += taken;
+                if (taken < (uint32_t)SL_GROUP) break;                    // the row's part of this range is through
+            }
+            if (gl == 0) { s_cur[i] = c; if (hits) s_hits[i] += hits; }
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < n_rows; i += SL_THREADS)
+        if (s_hits[i]) atomicAdd(&counters[d_lo + i], (unsigned long long)s_hits[i]);   // one add per (row, group of ranges)
 }
 
 // op 0: overlap[d] = cnt[d]; op 1: overlap[d] -= cnt[d], saturating (rows at 0 stay dropped, index/__init__.py:908-909)
@@ -1145,36 +1276,60 @@ hipError_t overlap_ranges_launch(const uint64_t* Q, uint64_t nq, const uint64_t*
     SMG_TRY(hipStreamSynchronize(stream));
     uint32_t shift = 0, buckets = 1;
     qindex_geometry(nq, q_max, &shift, &buckets);
-    const uint32_t R = (uint32_t)((nq + BR_RANGE - 1) / BR_RANGE);
-    uint64_t B = 64;
-    if (B > (ndb + 127) / 128) B = (ndb + 127) / 128;
-    if (B < 1) B = 1;
-    const uint64_t rows_per_block = (ndb + B - 1) / B;
-    uint64_t* q_padded = nullptr;
-    uint32_t *table = nullptr, *bounds = nullptr;
+    uint32_t* table = nullptr;
     unsigned long long* cnt = nullptr;
-    SMG_TRY(hipMallocAsync((void**)&q_padded, (nq + 4) * 8, stream));
-    SMG_TRY(hipMallocAsync((void**)&table, ((uint64_t)buckets + 1) * 4, stream));
-    SMG_TRY(hipMallocAsync((void**)&bounds, ((uint64_t)R + 1) * ndb * 4, stream));
-    SMG_TRY(hipMallocAsync((void**)&cnt, ndb * 8, stream));
-    SMG_TRY(hipMemcpyAsync(q_padded, Q, nq * 8, hipMemcpyDeviceToDevice, stream));
-    for (int i = 0; i < 4; ++i) SMG_TRY(hipMemcpyAsync(q_padded + nq + i, Q + nq - 1, 8, hipMemcpyDeviceToDevice, stream));
-    SMG_TRY(hipMemsetAsync(cnt, 0, ndb * 8, stream));
+    SMG_TRY(hipMallocAsync((void**)&table, ((uint64_t)buckets + 1) * 4 + 64, stream));
+    SMG_TRY(hipMallocAsync((void**)&cnt, ndb * 8 + 64, stream));
+    SMG_TRY(hipMemsetAsync(cnt, 0, ndb * 8 + 64, stream));
     hipLaunchKernelGGL(qtable_kernel, dim3((buckets + 256) / 256), dim3(256), 0, stream, Q, nq, shift, buckets, table);
-    QRec* rec = nullptr;
-    SMG_TRY(hipMallocAsync((void**)&rec, (uint64_t)buckets * sizeof(QRec), stream));
-    hipLaunchKernelGGL(qrec_kernel, dim3((buckets + 255) / 256), dim3(256), 0, stream, Q, (const uint32_t*)table, buckets, rec);
-    hipLaunchKernelGGL(build_bounds_kernel, dim3(blocks_for_rows(ndb)), dim3(256), 0, stream, Q, R, hashes, offsets, ndb, bounds);
-    const QIndex qi{q_padded, nq, table, shift, q_max, rec};
-    hipLaunchKernelGGL(build_range_kernel<3>, dim3((unsigned)(((R + 7) / 8) * 8 * B)), dim3(BR_THREADS), 0, stream, qi, hashes, offsets,
-                       ndb, (const uint32_t*)bounds, R, (uint32_t)B, rows_per_block, (uint32_t*)nullptr, (const uint64_t*)nullptr,
-                       (uint32_t*)nullptr, cnt, (uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr);
+    // streaming form (the query through LDS) unless a range of the table holds more query hashes than LDS has room for
+    static const bool no_stream = [] { const char* e = getenv("SMG_OVERLAP"); return e && !strcmp(e, "ranges"); }();
+    const uint32_t n_ranges = (buckets + SL_BUCKETS - 1) / SL_BUCKETS;
+    unsigned int widest = 0;
+    if (!no_stream) {
+        unsigned int* d_widest = (unsigned int*)(cnt + ndb);                // the 64 spare bytes, zeroed above
+        hipLaunchKernelGGL(stream_range_max_kernel, dim3((n_ranges + 255) / 256), dim3(256), 0, stream, (const uint32_t*)table, buckets,
+                           n_ranges, d_widest);
+        SMG_TRY(hipMemcpyAsync(&widest, d_widest, 4, hipMemcpyDeviceToHost, stream));
+        SMG_TRY(hipStreamSynchronize(stream));
+    }
+    hipError_t e = hipSuccess;
+    if (!no_stream && widest <= (unsigned)SL_QCAP) {
+        const uint32_t n_blocks = (uint32_t)((ndb + SL_ROWS - 1) / SL_ROWS);
+        uint32_t n_groups = (768 + n_blocks - 1) / n_blocks;                // about 3 workgroups per CU
+        if (n_groups > n_ranges) n_groups = n_ranges;
+        if (n_groups < 1) n_groups = 1;
+        const uint32_t per = (n_ranges + n_groups - 1) / n_groups;
+        n_groups = (n_ranges + per - 1) / per;
+        hipLaunchKernelGGL(stream_lookup_kernel<3>, dim3(n_blocks * n_groups), dim3(SL_THREADS), 0, stream, Q, (const uint32_t*)table, buckets,
+                           shift, q_max, hashes, offsets, ndb, n_blocks, n_ranges, per, cnt);
+    } else {
+        const uint32_t R = (uint32_t)((nq + BR_RANGE - 1) / BR_RANGE);
+        uint64_t B = 64;
+        if (B > (ndb + 127) / 128) B = (ndb + 127) / 128;
+        if (B < 1) B = 1;
+        const uint64_t rows_per_block = (ndb + B - 1) / B;
+        uint64_t* q_padded = nullptr;
+        uint32_t* bounds = nullptr;
+        QRec* rec = nullptr;
+        SMG_TRY(hipMallocAsync((void**)&q_padded, (nq + 4) * 8, stream));
+        SMG_TRY(hipMallocAsync((void**)&bounds, ((uint64_t)R + 1) * ndb * 4, stream));
+        SMG_TRY(hipMallocAsync((void**)&rec, (uint64_t)buckets * sizeof(QRec), stream));
+        SMG_TRY(hipMemcpyAsync(q_padded, Q, nq * 8, hipMemcpyDeviceToDevice, stream));
+        for (int i = 0; i < 4; ++i) SMG_TRY(hipMemcpyAsync(q_padded + nq + i, Q + nq - 1, 8, hipMemcpyDeviceToDevice, stream));
+        hipLaunchKernelGGL(qrec_kernel, dim3((buckets + 255) / 256), dim3(256), 0, stream, Q, (const uint32_t*)table, buckets, rec);
+        hipLaunchKernelGGL(build_bounds_kernel, dim3(blocks_for_rows(ndb)), dim3(256), 0, stream, Q, R, hashes, offsets, ndb, bounds);
+        const QIndex qi{q_padded, nq, table, shift, q_max, rec};
+        hipLaunchKernelGGL(build_range_kernel<3>, dim3((unsigned)(((R + 7) / 8) * 8 * B)), dim3(BR_THREADS), 0, stream, qi, hashes, offsets,
+                           ndb, (const uint32_t*)bounds, R, (uint32_t)B, rows_per_block, (uint32_t*)nullptr, (const uint64_t*)nullptr,
+                           (uint32_t*)nullptr, cnt, (uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr);
+        (void)hipFreeAsync(q_padded, stream);
+        (void)hipFreeAsync(rec, stream);
+        (void)hipFreeAsync(bounds, stream);
+    }
     hipLaunchKernelGGL(overlap_finish_kernel, dim3((unsigned)((ndb + 255) / 256)), dim3(256), 0, stream, cnt, ndb, overlap, op);
-    const hipError_t e = hipGetLastError();
-    (void)hipFreeAsync(q_padded, stream);
-    (void)hipFreeAsync(rec, stream);
+    e = hipGetLastError();
     (void)hipFreeAsync(table, stream);
-    (void)hipFreeAsync(bounds, stream);
     (void)hipFreeAsync(cnt, stream);
     return e;
 }

@@ -31,6 +31,7 @@ struct GatherDev {
     const uint64_t* hashes = nullptr;   // CSR database shard
     const uint64_t* offsets = nullptr;
     uint64_t ndb = 0, index_base = 0;
+    hipStream_t stream = nullptr;       // stream of the build: the owned buffers are stream-ordered pool allocations
     // owned
     uint64_t* q_padded = nullptr;       // copy of Q followed by 4 copies of its last element (lookups read 4 entries at once)
     uint32_t* q_table = nullptr;        // [q_buckets + 1] first-level table over Q: bucket b = x >> q_shift
