@@ -91,6 +91,19 @@ def main():
     first = first.cpu().numpy().view(np.uint64)
     checks["round0_is_argmax_lowest_index"] = bool(len(res) == 0 or (int(np.argmax(first)) == idx[0] and int(first.max()) == isect[0]))
 
+    # the overlap pass on its own (search / prefetch over the resident collection): |Q ∩ row| for every row
+    scratch = be.zeros((ndb,), torch.int64)
+    be.overlaps(q, nq, hashes, offsets, ndb, scratch, 0)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(3):
+        be.overlaps(q, nq, hashes, offsets, ndb, scratch, 0)
+    e1.record()
+    torch.cuda.synchronize()
+    overlap_ms = e0.elapsed_time(e1) / 3
+    checks["overlap_pass_equals_build_counters"] = bool(np.array_equal(scratch.cpu().numpy().view(np.uint64), first))
+
     out = {"config": {"query_hashes": nq, "datasets": ndb, "db_hashes": total, "db_bytes": total * 8,
                       "threshold_bp": args.threshold_bp, "scaled": 1000},
            "generate_s": round(gen_s, 3), "index_build_ms": round(build_s * 1e3, 2),
@@ -98,6 +111,7 @@ def main():
            "rounds": len(res), "loop_ms": round(run_s * 1e3, 2),
            "us_per_round": round(run_s * 1e6 / max(len(res), 1), 2),
            "total_ms": round((build_s + run_s) * 1e3, 2),
+           "overlap_pass_ms": round(overlap_ms, 3), "overlap_pass_GBps": round(total * 8 / overlap_ms / 1e6, 1),
            "streaming_equivalent_bytes": int(8 * (nq + total) * max(len(res), 1)),
            "first": res[:3], "last": res[-3:], "checks": checks}
     if args.stepwise:
