@@ -1167,9 +1167,12 @@ hipError_t gather_enqueue_replay(GatherDev& g, unsigned exchanges, hipStream_t s
 // Workgroup (block b, group g) covers ranges [g * per, (g + 1) * per); its first cursors come from a binary search.
 constexpr int SL_BUCKETS = 2048;          // table buckets per range
 constexpr int SL_QCAP = 3072;             // query hashes a range may hold (uniform hashes: 2048 +- 45); else the caller falls back
-constexpr int SL_ROWS = 2048;             // rows per block (cursors and per-row hit counts live in LDS)
+constexpr int SL_ROWS = 1024;             // rows per block (row starts, cursors and per-row hit counts live in LDS)
 constexpr int SL_THREADS = 512;
 constexpr int SL_GROUP = 16;              // lanes per row visit
+constexpr int SL_GROUPS = SL_THREADS / SL_GROUP;
+constexpr int SL_AHEAD = 4;               // row visits a group has in flight: a visit is one ~1 us load from HBM, and 51 million of
+                                          // them (rows x ranges at C5) must overlap
 
 // largest number of query hashes in any range (the caller checks it against SL_QCAP)
 __global__ __launch_bounds__(256) void stream_range_max_kernel(const uint32_t* __restrict__ T, uint32_t n_buckets, uint32_t n_ranges,
@@ -1189,6 +1192,7 @@ __global__ __launch_bounds__(SL_THREADS) void stream_lookup_kernel(const uint64_
                                                                    unsigned long long* __restrict__ counters) {
     __shared__ __attribute__((aligned(16))) uint64_t s_q[SL_QCAP];
     __shared__ __attribute__((aligned(16))) uint32_t s_t[SL_BUCKETS + 4];
+    __shared__ uint32_t s_base[SL_ROWS + 1];                             // row starts relative to the block's first hash
     __shared__ uint32_t s_cur[SL_ROWS], s_hits[SL_ROWS];
     const uint32_t b = blockIdx.x % n_blocks, g = blockIdx.x / n_blocks;
     const uint64_t d_lo = (uint64_t)b * SL_ROWS;
@@ -1197,21 +1201,27 @@ __global__ __launch_bounds__(SL_THREADS) void stream_lookup_kernel(const uint64_
     const uint32_t r_hi = r_lo + ranges_per_group < n_ranges ? r_lo + ranges_per_group : n_ranges;
     if (r_lo >= r_hi) return;
     const int tid = threadIdx.x;
+    const uint64_t block_base = offsets[d_lo];
+    const uint64_t* rows = hashes + block_base;
     // first cursors: where the group's first range starts in every row
     const uint64_t first_hash = ((uint64_t)r_lo * SL_BUCKETS) << shift;
+    for (uint32_t i = tid; i <= n_rows; i += SL_THREADS) s_base[i] = (uint32_t)(offsets[d_lo + i] - block_base);
+    __syncthreads();
     for (uint32_t i = tid; i < n_rows; i += SL_THREADS) {
-        const uint64_t base = offsets[d_lo + i], len = offsets[d_lo + i + 1] - base;
-        uint64_t lo = 0, hi = len;
-        if (r_lo != 0)
+        uint32_t lo = 0, hi = s_base[i + 1] - s_base[i];
+        const uint64_t* row = rows + s_base[i];
+        if (r_lo != 0) {
             while (lo < hi) {
-                const uint64_t mid = (lo + hi) >> 1;
-                if (hashes[base + mid] < first_hash) lo = mid + 1; else hi = mid;
+                const uint32_t mid = (lo + hi) >> 1;
+                if (row[mid] < first_hash) lo = mid + 1; else hi = mid;
             }
-        else hi = 0;
-        s_cur[i] = (uint32_t)(r_lo != 0 ? lo : 0);
+        } else {
+            lo = 0;
+        }
+        s_cur[i] = lo;
         s_hits[i] = 0;
     }
-    const int grp = tid / SL_GROUP, gl = tid % SL_GROUP;                 // 32 groups of 16 lanes
+    const int grp = tid / SL_GROUP, gl = tid % SL_GROUP;
     const int sh16 = (tid & 63) / SL_GROUP * SL_GROUP;                   // this group's bit offset inside the wave's ballot
     for (uint32_t r = r_lo; r < r_hi; ++r) {
         const uint32_t b0 = r * SL_BUCKETS, b1 = b0 + SL_BUCKETS < n_buckets ? b0 + SL_BUCKETS : n_buckets;
@@ -1223,30 +1233,45 @@ __global__ __launch_bounds__(SL_THREADS) void stream_lookup_kernel(const uint64_
         for (uint32_t i = tid; i < b1 - b0 + 1; i += SL_THREADS) s_t[i] = T[b0 + i] - p0;
         for (uint32_t i = tid; i < p1 - p0; i += SL_THREADS) s_q[i] = Q[p0 + i];
         __syncthreads();
-        for (uint32_t i = grp; i < n_rows; i += SL_THREADS / SL_GROUP) {
-            const uint64_t base = offsets[d_lo + i];
-            const uint32_t len = (uint32_t)(offsets[d_lo + i + 1] - base);
-            uint32_t c = s_cur[i], hits = 0;
-            for (;;) {
-                const bool have = c + gl < len;
-                const uint64_t e = have ? hashes[base + c + gl] : ~0ull;
-                const bool in = have && (last || e < upper);
-                const uint32_t taken = (uint32_t)__popc((uint32_t)((__ballot(in) >> sh16) & 0xffffu));
-                bool hit = false;
-                if (in && e <= qmax) {
-                    const uint32_t k = (uint32_t)(e >> shift) - b0;          // < SL_BUCKETS: the hash lies in this range
-                    const uint32_t t0 = s_t[k], t1 = s_t[k + 1];
-                    for (uint32_t t = t0; t < t1; ++t) {
-                        const uint64_t qv = s_q[t];
-                        if (qv == e) { hit = true; break; }
-                        if (qv > e) break;
-                    }
-                }
-                hits += (uint32_t)__popc((uint32_t)((__ballot(hit) >> sh16) & 0xffffu));
-                c += taken;
-                if (taken < (uint32_t)SL_GROUP) break;                    // the row's part of this range is through
+        // one group of 16 lanes per row; SL_AHEAD rows' loads are issued before the first of them is looked at
+        for (uint32_t i0 = grp; i0 < n_rows; i0 += SL_GROUPS * SL_AHEAD) {
+            uint64_t e[SL_AHEAD];
+            uint32_t c[SL_AHEAD], len[SL_AHEAD], rb[SL_AHEAD];
+#pragma unroll
+            for (int u = 0; u < SL_AHEAD; ++u) {
+                const uint32_t i = i0 + u * SL_GROUPS;
+                const bool row_ok = i < n_rows;
+                rb[u] = row_ok ? s_base[i] : 0u;
+                len[u] = row_ok ? s_base[i + 1] - rb[u] : 0u;
+                c[u] = row_ok ? s_cur[i] : 0u;
+                e[u] = c[u] + gl < len[u] ? rows[(uint64_t)rb[u] + c[u] + gl] : ~0ull;
             }
-            if (gl == 0) { s_cur[i] = c; if (hits) s_hits[i] += hits; }
+#pragma unroll
+            for (int u = 0; u < SL_AHEAD; ++u) {
+                const uint32_t i = i0 + u * SL_GROUPS;
+                uint32_t cur = c[u], hits = 0;
+                uint64_t ev = e[u];
+                for (;;) {
+                    const bool have = cur + gl < len[u];
+                    const bool in = have && (last || ev < upper);
+                    const uint32_t taken = (uint32_t)__popc((uint32_t)((__ballot(in) >> sh16) & 0xffffu));
+                    bool hit = false;
+                    if (in && ev <= qmax) {
+                        const uint32_t k = (uint32_t)(ev >> shift) - b0;         // < SL_BUCKETS: the hash lies in this range
+                        const uint32_t t0 = s_t[k], t1 = s_t[k + 1];
+                        for (uint32_t t = t0; t < t1; ++t) {
+                            const uint64_t qv = s_q[t];
+                            if (qv == ev) { hit = true; break; }
+                            if (qv > ev) break;
+                        }
+                    }
+                    hits += (uint32_t)__popc((uint32_t)((__ballot(hit) >> sh16) & 0xffffu));
+                    cur += taken;
+                    if (taken < (uint32_t)SL_GROUP) break;                // the row's part of this range is through
+                    ev = cur + gl < len[u] ? rows[(uint64_t)rb[u] + cur + gl] : ~0ull;   // a longer slice: keep reading
+                }
+                if (gl == 0 && i < n_rows) { s_cur[i] = cur; if (hits) s_hits[i] += hits; }
+            }
         }
     }
     __syncthreads();
