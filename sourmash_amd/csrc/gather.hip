@@ -1176,10 +1176,10 @@ constexpr int SL_AHEAD = 4;               // row visits a group has in flight: a
 
 // largest number of query hashes in any range (the caller checks it against SL_QCAP)
 __global__ __launch_bounds__(256) void stream_range_max_kernel(const uint32_t* __restrict__ T, uint32_t n_buckets, uint32_t n_ranges,
-                                                              unsigned int* out) {
+                                                              uint32_t bpr, unsigned int* out) {
     const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_ranges) return;
-    const uint32_t b0 = r * SL_BUCKETS, b1 = b0 + SL_BUCKETS < n_buckets ? b0 + SL_BUCKETS : n_buckets;
+    const uint32_t b0 = r * bpr, b1 = b0 + bpr < n_buckets ? b0 + bpr : n_buckets;
     atomicMax(out, T[b1] - T[b0]);
 }
 
@@ -1189,7 +1189,9 @@ __global__ __launch_bounds__(SL_THREADS) void stream_lookup_kernel(const uint64_
                                                                    const uint64_t* __restrict__ hashes,
                                                                    const uint64_t* __restrict__ offsets, uint64_t ndb,
                                                                    uint32_t n_blocks, uint32_t n_ranges, uint32_t ranges_per_group,
-                                                                   unsigned long long* __restrict__ counters) {
+                                                                   uint32_t bpr, unsigned long long* __restrict__ counters) {
+    // bpr: buckets per range (<= SL_BUCKETS): the table holds between one and two query hashes per bucket, the caller picks
+    // the power of two that puts about 2,000 of them into a range
     __shared__ __attribute__((aligned(16))) uint64_t s_q[SL_QCAP];
     __shared__ __attribute__((aligned(16))) uint32_t s_t[SL_BUCKETS + 4];
     __shared__ uint32_t s_base[SL_ROWS + 1];                             // row starts relative to the block's first hash
@@ -1204,7 +1206,7 @@ __global__ __launch_bounds__(SL_THREADS) void stream_lookup_kernel(const uint64_
     const uint64_t block_base = offsets[d_lo];
     const uint64_t* rows = hashes + block_base;
     // first cursors: where the group's first range starts in every row
-    const uint64_t first_hash = ((uint64_t)r_lo * SL_BUCKETS) << shift;
+    const uint64_t first_hash = ((uint64_t)r_lo * bpr) << shift;
     for (uint32_t i = tid; i <= n_rows; i += SL_THREADS) s_base[i] = (uint32_t)(offsets[d_lo + i] - block_base);
     __syncthreads();
     for (uint32_t i = tid; i < n_rows; i += SL_THREADS) {
@@ -1224,7 +1226,7 @@ __global__ __launch_bounds__(SL_THREADS) void stream_lookup_kernel(const uint64_
     const int grp = tid / SL_GROUP, gl = tid % SL_GROUP;
     const int sh16 = (tid & 63) / SL_GROUP * SL_GROUP;                   // this group's bit offset inside the wave's ballot
     for (uint32_t r = r_lo; r < r_hi; ++r) {
-        const uint32_t b0 = r * SL_BUCKETS, b1 = b0 + SL_BUCKETS < n_buckets ? b0 + SL_BUCKETS : n_buckets;
+        const uint32_t b0 = r * bpr, b1 = b0 + bpr < n_buckets ? b0 + bpr : n_buckets;
         const uint32_t p0 = T[b0], p1 = T[b1];
         const bool last = r + 1 == n_ranges;
         // hashes below `upper` belong to this range or an earlier one (earlier ones are consumed already)
@@ -1309,12 +1311,15 @@ hipError_t overlap_ranges_launch(const uint64_t* Q, uint64_t nq, const uint64_t*
     hipLaunchKernelGGL(qtable_kernel, dim3((buckets + 256) / 256), dim3(256), 0, stream, Q, nq, shift, buckets, table);
     // streaming form (the query through LDS) unless a range of the table holds more query hashes than LDS has room for
     static const bool no_stream = [] { const char* e = getenv("SMG_OVERLAP"); return e && !strcmp(e, "ranges"); }();
-    const uint32_t n_ranges = (buckets + SL_BUCKETS - 1) / SL_BUCKETS;
+    static const bool only_stream = [] { const char* e = getenv("SMG_OVERLAP"); return e && !strcmp(e, "stream"); }();   // tests: no fallback
+    uint32_t bpr = SL_BUCKETS;                                             // buckets per range: about 2,000 query hashes
+    while (bpr > 64 && (double)bpr * (double)nq / (double)buckets > 2200.0) bpr >>= 1;
+    const uint32_t n_ranges = (buckets + bpr - 1) / bpr;
     unsigned int widest = 0;
     if (!no_stream) {
         unsigned int* d_widest = (unsigned int*)(cnt + ndb);                // the 64 spare bytes, zeroed above
         hipLaunchKernelGGL(stream_range_max_kernel, dim3((n_ranges + 255) / 256), dim3(256), 0, stream, (const uint32_t*)table, buckets,
-                           n_ranges, d_widest);
+                           n_ranges, bpr, d_widest);
         SMG_TRY(hipMemcpyAsync(&widest, d_widest, 4, hipMemcpyDeviceToHost, stream));
         SMG_TRY(hipStreamSynchronize(stream));
     }
@@ -1327,7 +1332,11 @@ hipError_t overlap_ranges_launch(const uint64_t* Q, uint64_t nq, const uint64_t*
         const uint32_t per = (n_ranges + n_groups - 1) / n_groups;
         n_groups = (n_ranges + per - 1) / per;
         hipLaunchKernelGGL(stream_lookup_kernel<3>, dim3(n_blocks * n_groups), dim3(SL_THREADS), 0, stream, Q, (const uint32_t*)table, buckets,
-                           shift, q_max, hashes, offsets, ndb, n_blocks, n_ranges, per, cnt);
+                           shift, q_max, hashes, offsets, ndb, n_blocks, n_ranges, per, bpr, cnt);
+    } else if (only_stream) {
+        (void)hipFreeAsync(table, stream);
+        (void)hipFreeAsync(cnt, stream);
+        return hipErrorInvalidValue;
     } else {
         const uint32_t R = (uint32_t)((nq + BR_RANGE - 1) / BR_RANGE);
         uint64_t B = 64;

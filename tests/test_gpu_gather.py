@@ -196,14 +196,28 @@ def test_range_builder_postings_are_exact(fill, monkeypatch):
     assert not st.counters().any()
 
 
-def test_overlaps_of_a_large_query_take_the_range_partitioned_pass():
-    "smgpu_overlap_raw with a query of >= 4 ranges over >= 4096 rows (gather.hip: overlap_ranges_launch), both ops, vs the oracle"
+@pytest.mark.parametrize("form", ["stream", "ranges"])
+def test_overlaps_of_a_large_query_take_the_range_partitioned_pass(form):
+    """smgpu_overlap_raw with a large query over >= 4096 rows (gather.hip: overlap_ranges_launch), both ops, vs the oracle:
+    the streaming form (the query through LDS; SMG_OVERLAP=stream makes a fallback an error) and the range-partitioned
+    form it falls back to.  The switch is read once per process, so each form runs in its own interpreter."""
+    import os, subprocess, sys
+    from conftest import ROOT
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import test_gpu_gather as t\nt._overlaps_large_query()\nprint('ok')\n" % (ROOT, os.path.join(ROOT, "tests")))
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, SMG_OVERLAP=form))
+    assert p.returncode == 0 and p.stdout.strip().endswith("ok"), (p.stdout[-1500:], p.stderr[-1500:])
+
+
+def _overlaps_large_query():
     import torch
     from sourmash_amd import device as smd, parallel
     from sourmash_amd.synth import synth_gather
     qh, dbh = synth_gather(n_query=140_000, n_db=4200, db_size=90)
     dbh[10] = np.zeros(0, dtype=np.uint64)
-    dbh[11] = qh[1000:3000].copy()
+    dbh[11] = qh[1000:3000].copy()                                # a run of 2,000 consecutive query hashes: long slices
+    dbh[12] = np.unique(np.concatenate([qh[::3], np.array([1, 2, 2**64 - 1], dtype=np.uint64)]))   # 46k hashes, below / above the query
     be = parallel.DeviceBackend()
     h, off = smd.pack_csr(dbh)
     q = torch.from_numpy(qh.view(np.int64).copy()).cuda()
