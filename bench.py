@@ -380,7 +380,7 @@ def single_gpu_extras(extra, torch, np, dev, be, smd, synth_sketches, synth_gath
     extra["compare_1000x1000_merge"] = {
         "pairs_per_s": round(pairs / (ms_merge * 1e-3), 1), "ms": round(ms_merge, 3), "pairs": pairs,
         "roofline": merge_roofline(alg, ms_merge),
-        "kernel": "compare_tile_kernel (LDS-tiled merge walk; the general path)"}
+        "kernel": "compare_hash_kernel (LDS hash table per 16 x 32 tile and round; the general path, no index needed)"}
     build_ms = 0.0
     for _ in range(3):                                  # last build: memory pool warm
         idx = None
@@ -476,7 +476,7 @@ def single_gpu_extras(extra, torch, np, dev, be, smd, synth_sketches, synth_gath
     ms_ov = timed(lambda: be.overlaps(gq5, gq5.numel(), gh5, goff5, 100_000, cnt, 0), reps=3)
     extra["overlaps_1M_vs_100000"] = {"ms": round(ms_ov, 3), "sketches_per_s": round(100_000 / (ms_ov * 1e-3), 1),
                                       "roofline": hbm_roofline(db_bytes + 8 * int(gq5.numel()), ms_ov,
-                                                               "8 B per database hash + the query once; overlap_vector_kernel")}
+                                                               "8 B per database hash + the query once; stream_lookup_kernel (query slices through LDS, database read once)")}
 
 
 def hbm_roofline(alg_bytes, ms, what):
@@ -487,15 +487,18 @@ def hbm_roofline(alg_bytes, ms, what):
 
 
 def merge_roofline(alg_bytes, ms):
-    """The merge kernel re-uses every staged hash for 16 pairs out of LDS, so HBM is the wrong roof (the collection is
-    L2 / Infinity-Cache resident and the convention figure exceeds the HBM peak).  Each merge step reads one u64 from
-    each of two LDS segments: the LDS read rate is the roof."""
+    """The general compare path keeps a tile's hashes in LDS and serves 512 pairs from them, so HBM is the wrong roof (the
+    collection is L2 / Infinity-Cache resident and the SURVEY.md 8(d) convention figure exceeds the HBM peak).  The
+    convention bytes -- 8 B x (n_i + n_j) per pair, what one two-pointer walk per pair would read -- are priced against
+    the aggregate LDS read bandwidth; the hash-table kernel does less LDS work than that per pair (one insert or lookup
+    per hash of the TILE, not per pair), which is how it passes the walk kernel, and is bound by the latency of its
+    probe chains and by instruction issue (profiles/r02_compare_pmc.txt)."""
     achieved = alg_bytes / (ms * 1e-3) / 1e9
     return {"bound": "lds", "achieved": round(achieved, 1), "peak": LDS_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / LDS_PEAK_GBS, 4), "algorithmic_bytes": int(alg_bytes), "ms": round(ms, 3),
             "hbm_convention_frac": round(achieved / HBM_PEAK_GBS, 3),
-            "what": "8 B x (n_i + n_j) per pair = LDS bytes the walks read (SURVEY.md 8d convention); roof = aggregate LDS read "
-                    "bandwidth (~150 TB/s, MI355X_MICROARCH.md); HBM traffic is 1/16 of it by the tiling"}
+            "what": "8 B x (n_i + n_j) per pair (SURVEY.md 8d convention) against the aggregate LDS read bandwidth (~150 TB/s, "
+                    "MI355X_MICROARCH.md); HBM sees each hash of a tile once per round"}
 
 
 if __name__ == "__main__":

@@ -832,7 +832,7 @@ struct BitIndex {
 };
 
 // measured rates behind the cost model (1 x MI355X)
-constexpr double RATE_MERGE_STEPS = 2.5e12;   // merge steps / s   (compare_tile_kernel at C4)
+constexpr double RATE_MERGE_STEPS = 4.3e12;   // merge-step equivalents / s (compare_hash_kernel at C4: 431e6 pairs/s x 1e4 steps)
 constexpr double RATE_BIT_WORDS = 7.5e12;     // 32-bit AND+popcount / s (bitmatrix_kernel at C4)
 constexpr double RATE_PAIR_ATOMICS = 4.0e9;   // matrix increments / s (rare_pairs_kernel; two per pair)
 
