@@ -39,12 +39,17 @@ HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 T
 HBM_ACHIEVABLE_GBS = 6290.0  # same guide: 6.29 TB/s measured with a float4 copy
 LDS_PEAK_GBS = 150_000.0   # same guide, LDS: ~150 TB/s aggregate for ds_read_b64/b128 with every CU streaming
 # Counter readings of sketch_dna_kernel<31,16,false> on the default C2 batch, QUOTED from the committed PMC passes
-# (rocprofv3 --pmc, separate runs; profiles/README.md says which file belongs to which round).  They are constants of
-# a previous run of this same command, not measurements of the present one: the JSON labels them `*_quoted_from`.
-PMC_FILE = "profiles/r01_end_pmc.txt"
-PMC_C2_BYTES = 2 * 5_030_617 * 1024 + 78_545 * 1024      # 2 x FETCH_SIZE (gfx950 correction for 16 B/lane reads) + WRITE_SIZE
+# (rocprofv3 --pmc, one counter group per run, tools/prof_r02.sh; profiles/README.md).  They are constants of an earlier run
+# of this same command, not measurements of the present one: the JSON labels them `*_quoted_from`.
+PMC_FILE = "profiles/r02_pmc.txt"
+PMC_C2_BYTES = 2 * 5_030_614 * 1024 + 78_534 * 1024      # 2 x FETCH_SIZE (gfx950 correction for 16 B/lane reads) + WRITE_SIZE
 PMC_C2_INPUT_BYTES = 9_990_000_999
 PMC_C2_VALU_INSTS = 18_194_765_969                        # SQ_INSTS_VALU, wave-instructions per launch
+PMC_C2_WAVE_CYCLES = 61_685_605_951                       # SQ_WAVE_CYCLES (quad-cycles, summed over waves)
+PMC_C2_WAIT_INST_ANY = 30_083_529_866                     # ... of which: waiting to issue (pipe busy / dependency)
+PMC_C2_ACTIVE_INST_ANY = 19_160_554_067                   # ... of which: issuing
+PMC_C2_GUI_ACTIVE = 593_932_343                           # GRBM_GUI_ACTIVE summed over the 8 XCDs, per launch (31.8 ms)
+N_SIMDS = 1024
 
 
 def parse():
@@ -163,7 +168,14 @@ def main():
                     "traffic_quoted_from": PMC_FILE + " (PMC passes of this same command, an earlier run)" if quoted else None,
                     "kernel_ms": round(kern_ms, 3), "algorithmic_bytes": alg_bytes,
                     "valu": ({"insts_per_kmer": round(PMC_C2_VALU_INSTS * 64 / bases_per_step, 1),
-                              "quoted_from": PMC_FILE + " SQ_INSTS_VALU; measured VALU-busy fraction: DESIGN.md 4.1"}
+                              # counter-derived: VALU wave-instructions per SIMD and shader cycle (the ubenchmarked cost of this
+                              # kernel's mix is 2.4 cycles for and/or/xor/add/shift, 4.3 for multiplies, v_add3, permutes, selects)
+                              "valu_insts_per_simd_cycle": round(PMC_C2_VALU_INSTS / N_SIMDS / (PMC_C2_GUI_ACTIVE / 8), 4),
+                              "cycles_per_valu_inst_per_simd": round(N_SIMDS * (PMC_C2_GUI_ACTIVE / 8) / PMC_C2_VALU_INSTS, 2),
+                              "wave_cycles_issuing_frac": round(PMC_C2_ACTIVE_INST_ANY / PMC_C2_WAVE_CYCLES, 3),
+                              "wave_cycles_waiting_to_issue_frac": round(PMC_C2_WAIT_INST_ANY / PMC_C2_WAVE_CYCLES, 3),
+                              "quoted_from": PMC_FILE + " (SQ_INSTS_VALU, SQ_WAVE_CYCLES, SQ_WAIT_INST_ANY, SQ_ACTIVE_INST_ANY, "
+                                             "GRBM_GUI_ACTIVE; separate passes)"}
                              if quoted else None),
                     "note": "VALU-integer bound (12 x 64-bit multiplies per k-mer), see DESIGN.md; "
                             "kernel-only Gbase/s = %.1f" % (bases_per_step / (kern_ms * 1e-3) / 1e9)}

@@ -832,7 +832,8 @@ struct BitIndex {
 };
 
 // measured rates behind the cost model (1 x MI355X)
-constexpr double RATE_MERGE_STEPS = 4.3e12;   // merge-step equivalents / s (compare_hash_kernel at C4: 431e6 pairs/s x 1e4 steps)
+constexpr double RATE_MERGE_STEPS = 3.0e12;   // merge-step equivalents / s of compare_hash_kernel: 4.3e12 at C4 (431e6 pairs/s x 1e4 steps),
+                                              // 3.0e12 at C3 where 1,000 sketches do not fill the chip -- the smaller one decides small problems
 constexpr double RATE_BIT_WORDS = 7.5e12;     // 32-bit AND+popcount / s (bitmatrix_kernel at C4)
 constexpr double RATE_PAIR_ATOMICS = 4.0e9;   // matrix increments / s (rare_pairs_kernel; two per pair)
 
@@ -1024,19 +1025,26 @@ static uint64_t gather_drain(GatherDev& g, uint64_t* out_idx, uint64_t* out_isec
     unsigned long long head[GS_SLOTS];
     const bool replay = gather_use_replay() && g.ndb > 0 && g.nq > 0;
     static const bool trace = getenv("SMG_GATHER_TRACE") != nullptr;   // per batch: time to enqueue, time until the GPU is through
+    // SMG_GATHER_GRAPH: 0 eager launches only, 1 graph replays only, unset: eager until a batch shows the host cannot keep
+    // ahead (the GPU was through almost as soon as the last launch was issued), then graph replays of 64 rounds
+    static const int graph_mode = [] { const char* e = getenv("SMG_GATHER_GRAPH"); return e ? atoi(e) : -1; }();
+    bool use_graph = graph_mode == 1;
     unsigned batch = 32;
     for (;;) {
         const auto t0 = std::chrono::steady_clock::now();
         if (replay) hip_check(gather_enqueue_replay(g, (batch + GATHER_TOPK_MAX - 1) / GATHER_TOPK_MAX, st), "gather rounds");
+        else if (use_graph) hip_check(gather_enqueue_rounds_graph(g, batch, st), "gather rounds (graph)");
         else hip_check(gather_enqueue_rounds(g, batch, st), "gather rounds");
         const auto t1 = std::chrono::steady_clock::now();
         hip_check(hipMemcpyAsync(head, g.state, sizeof(head), hipMemcpyDeviceToHost, st), "D2H");
         hip_check(hipStreamSynchronize(st), "sync");
+        const double enqueue_us = std::chrono::duration<double, std::micro>(t1 - t0).count();
+        const double wait_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t1).count();
         if (trace)
-            fprintf(stderr, "[gather] batch of %u rounds: enqueue %.1f us, then %.1f us until done (rounds so far %llu)\n", batch,
-                    std::chrono::duration<double, std::micro>(t1 - t0).count(),
-                    std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t1).count(), head[GS_ROUNDS]);
+            fprintf(stderr, "[gather] batch of %u rounds (%s): enqueue %.1f us, then %.1f us until done (rounds so far %llu)\n", batch,
+                    replay ? "replay" : use_graph ? "graph" : "eager", enqueue_us, wait_us, head[GS_ROUNDS]);
         if (head[GS_DONE]) break;
+        if (!replay && !use_graph && graph_mode == -1 && batch >= 64 && wait_us < 0.2 * enqueue_us) use_graph = true;
         if (batch < 512) batch *= 2;
     }
     const uint64_t n = head[GS_ROUNDS];

@@ -269,6 +269,93 @@ __global__ __launch_bounds__(BR_THREADS) void build_range_kernel(QIndex qi, cons
     }
 }
 
+// pass 2a with staging (the default): the same walk as build_range_kernel<2>, but the workgroup moves through its rows in
+// chunks of 8 waves x 16 rows with all waves in step; an entry's final slot in its stream is reserved at once (an LDS
+// counter per stream), the entry itself waits in LDS -- stream k's entries of the chunk at s_stage[k][slot - chunk start]
+// -- and after the chunk every stream's part goes out with consecutive lanes (~80 entries = 330 bytes at C5).  An entry
+// that does not fit its stream's LDS row is stored directly at its slot.  What reaches the L2 are runs, not 4-byte
+// stores scattered over 128 open lines.
+constexpr int PA_CAPS = 128;                      // staged entries per stream and chunk: 128 x 128 x 4 B = 64 KB of LDS
+
+__global__ __launch_bounds__(BR_THREADS) void build_partition_kernel(uint64_t nq, const uint64_t* __restrict__ offsets,
+                                                                     uint64_t ndb, const uint32_t* __restrict__ bounds,
+                                                                     uint32_t R, uint32_t B, uint64_t rows_per_block,
+                                                                     const uint32_t* __restrict__ qpos,
+                                                                     const uint32_t* __restrict__ inter_off,
+                                                                     uint32_t* __restrict__ inter) {
+    constexpr int WAVES = BR_THREADS / 64;
+    __shared__ uint32_t s_stage[BR_NSUB][PA_CAPS];
+    __shared__ uint32_t s_gbase[BR_NSUB], s_gcur[BR_NSUB], s_cbase[BR_NSUB];
+    const uint32_t local = blockIdx.x % (8u * B);
+    const uint32_t r = (blockIdx.x / (8u * B)) * 8u + (local & 7u), b = local >> 3;
+    if (r >= R) return;
+    const uint64_t j0 = (uint64_t)r * BR_RANGE;
+    (void)nq;
+    for (int k = threadIdx.x; k < BR_NSUB; k += BR_THREADS) {
+        s_gbase[k] = inter_off[((uint64_t)r * BR_NSUB + k) * B + b];
+        s_gcur[k] = 0;
+    }
+    const uint64_t d_lo = (uint64_t)b * rows_per_block;
+    const uint64_t d_hi = d_lo + rows_per_block < ndb ? d_lo + rows_per_block : ndb;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const uint64_t n_chunks = d_hi > d_lo ? (d_hi - d_lo + (uint64_t)(WAVES * BR_EPW) - 1) / (WAVES * BR_EPW) : 0;
+    for (uint64_t chunk = 0; chunk < n_chunks; ++chunk) {
+        __syncthreads();                                            // the previous chunk is flushed (and, first time, s_gbase is set)
+        for (int k = threadIdx.x; k < BR_NSUB; k += BR_THREADS) s_cbase[k] = s_gcur[k];
+        __syncthreads();
+        const uint64_t dbase = d_lo + (chunk * WAVES + (uint64_t)wave) * BR_EPW;
+        if (dbase < d_hi) {
+            uint64_t lo = 0;
+            uint32_t n = 0;
+            const uint64_t d = dbase + lane;
+            if (lane < BR_EPW && d < d_hi) {
+                const uint32_t a = bounds[(uint64_t)r * ndb + d], e = bounds[(uint64_t)(r + 1) * ndb + d];
+                lo = offsets[d] + a;
+                n = e - a;
+            }
+            uint32_t incl = n;
+#pragma unroll
+            for (int sft = 1; sft < BR_EPW; sft <<= 1) {
+                const uint32_t v = __shfl_up(incl, sft);
+                if (lane >= sft) incl += v;
+            }
+            const uint32_t total = __shfl(incl, BR_EPW - 1);
+            uint32_t bound[BR_EPW - 1];
+#pragma unroll
+            for (int k = 0; k < BR_EPW - 1; ++k) bound[k] = __shfl(incl, k);
+            const uint32_t excl = incl - n;
+            const uint32_t lo_lo = (uint32_t)lo, lo_hi = (uint32_t)(lo >> 32);
+            for (uint32_t t0 = 0; t0 < total; t0 += 64) {
+                const uint32_t t = t0 + (uint32_t)lane;
+                int h = 0;
+#pragma unroll
+                for (int k = 0; k < BR_EPW - 1; ++k) h += t >= bound[k];
+                const uint64_t start = ((uint64_t)(uint32_t)__shfl((int)lo_hi, h) << 32) | (uint32_t)__shfl((int)lo_lo, h);
+                const uint32_t first = (uint32_t)__shfl((int)excl, h);
+                uint32_t j = NONE32;
+                if (t < total) j = __builtin_nontemporal_load(&qpos[start + (t - first)]);   // read once: streaming load
+                if (j != NONE32) {
+                    const uint32_t k = j - (uint32_t)j0;
+                    const uint32_t sub = k >> BR_SUB_BITS;
+                    const uint32_t entry = ((uint32_t)(dbase + (uint64_t)h) << BR_SUB_BITS) | (k & (BR_SUB - 1));
+                    const uint32_t at = atomicAdd(&s_gcur[sub], 1u);                       // final slot in this workgroup's stream
+                    const uint32_t in_chunk = at - s_cbase[sub];
+                    if (in_chunk < (uint32_t)PA_CAPS) s_stage[sub][in_chunk] = entry;
+                    else inter[(uint64_t)s_gbase[sub] + at] = entry;
+                }
+            }
+        }
+        __syncthreads();
+        for (int k = wave; k < BR_NSUB; k += WAVES) {               // stream k's part of the chunk, consecutive lanes
+            const uint32_t from = s_cbase[k];
+            uint32_t n = s_gcur[k] - from;
+            n = n < (uint32_t)PA_CAPS ? n : (uint32_t)PA_CAPS;
+            uint32_t* dst = inter + (uint64_t)s_gbase[k] + from;
+            for (uint32_t i = lane; i < n; i += 64) dst[i] = s_stage[k][i];
+        }
+    }
+}
+
 // pass 2b: workgroup (window w, group g) counting-sorts the entries of its row blocks by list in LDS (at most
 // BR_SORT_CAP at a time) and writes every list's run with consecutive lanes at post_off[j] + (postings of j in earlier row
 // blocks) + (what earlier batches of this workgroup put there).  Windows w = x (mod 8) run on workgroup ids = x (mod 8),
@@ -847,6 +934,7 @@ void gather_destroy(GatherDev& g) {
                      g.topk_sel, g.topk_partials, g.cmask, g.cand_count, g.cand_key, g.cand_len, g.cand_qpos, g.own_cands};
     for (void* p : owned)
         if (p) (void)hipFreeAsync(p, g.stream);
+    if (g.loop_graph) (void)hipGraphExecDestroy(g.loop_graph);
     g = GatherDev();
 }
 
@@ -979,9 +1067,14 @@ hipError_t gather_build(GatherDev& g, hipStream_t stream) {
         if (staged && (inter_words >= 0xffffffffull || B > 512)) staged = false;
         if (staged) {
             SMG_TRY(hipMallocAsync((void**)&inter, inter_words * 4, stream));
-            hipLaunchKernelGGL(build_range_kernel<2>, dim3(range_grid), dim3(BR_THREADS), 0, stream, qi, g.hashes, g.offsets,
-                               g.ndb, bounds, R, (uint32_t)B, rows_per_block, partial, (const uint64_t*)nullptr, (uint32_t*)nullptr,
-                               g.counters, g.qpos, (uint32_t*)nullptr, (const uint32_t*)inter_off, inter);
+            if (fill_env && !strcmp(fill_env, "streams"))       // pass 2a without staging: 4-byte stores into 128 open streams
+                hipLaunchKernelGGL(build_range_kernel<2>, dim3(range_grid), dim3(BR_THREADS), 0, stream, qi, g.hashes, g.offsets,
+                                   g.ndb, bounds, R, (uint32_t)B, rows_per_block, partial, (const uint64_t*)nullptr, (uint32_t*)nullptr,
+                                   g.counters, g.qpos, (uint32_t*)nullptr, (const uint32_t*)inter_off, inter);
+            else
+                hipLaunchKernelGGL(build_partition_kernel, dim3(range_grid), dim3(BR_THREADS), 0, stream, g.nq, g.offsets, g.ndb,
+                                   (const uint32_t*)bounds, R, (uint32_t)B, rows_per_block, (const uint32_t*)g.qpos,
+                                   (const uint32_t*)inter_off, inter);
             SMG_TRY(hipGetLastError());
             hipLaunchKernelGGL(build_scatter_kernel, dim3((unsigned)((n_windows + 7) / 8 * 8 * BR_GROUPS)), dim3(512), 0, stream, g.nq,
                                n_windows, (uint32_t)B, (const uint32_t*)partial, (const uint64_t*)g.post_off, (const uint32_t*)subcnt,
@@ -1064,6 +1157,22 @@ hipError_t gather_enqueue_rounds(GatherDev& g, unsigned rounds, hipStream_t stre
         SMG_TRY(gather_pick(g, nullptr, 1, stream));
         SMG_TRY(gather_apply(g, stream));
     }
+    return hipSuccess;
+}
+
+hipError_t gather_enqueue_rounds_graph(GatherDev& g, unsigned rounds, hipStream_t stream) {
+    if (!g.loop_graph) {
+        hipGraph_t graph = nullptr;
+        SMG_TRY(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+        const hipError_t e = gather_enqueue_rounds(g, GATHER_GRAPH_ROUNDS, stream);
+        const hipError_t e2 = hipStreamEndCapture(stream, &graph);
+        if (e != hipSuccess) { if (graph) (void)hipGraphDestroy(graph); return e; }
+        SMG_TRY(e2);
+        const hipError_t e3 = hipGraphInstantiate(&g.loop_graph, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        SMG_TRY(e3);
+    }
+    for (unsigned r = 0; r < rounds; r += GATHER_GRAPH_ROUNDS) SMG_TRY(hipGraphLaunch(g.loop_graph, stream));
     return hipSuccess;
 }
 

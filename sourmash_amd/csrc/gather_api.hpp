@@ -65,7 +65,10 @@ struct GatherDev {
     uint32_t n_cand = 0;
     uint64_t* own_cands = nullptr;      // single-GPU loop: this shard's own export buffer
     uint64_t own_cands_words = 0;
+    hipGraphExec_t loop_graph = nullptr;   // GATHER_GRAPH_ROUNDS rounds of pick + apply, captured once (hosts that launch slowly)
 };
+
+constexpr unsigned GATHER_GRAPH_ROUNDS = 64;
 
 constexpr unsigned GATHER_PICK_BLOCKS = 256;
 constexpr unsigned GATHER_TOPK_MAX = 16;     // candidates a rank can export per exchange
@@ -100,6 +103,10 @@ hipError_t gather_enqueue_replay(GatherDev& g, unsigned exchanges, hipStream_t s
 hipError_t gather_consume_list(GatherDev& g, const uint64_t* d_list, hipStream_t stream);
 // Enqueue `rounds` rounds of pick(check) + apply on one GPU (kernels are no-ops once GS_DONE is set).
 hipError_t gather_enqueue_rounds(GatherDev& g, unsigned rounds, hipStream_t stream);
+// The same rounds as replays of one captured graph of GATHER_GRAPH_ROUNDS rounds (rounded up): one host call per 64
+// rounds instead of 128 launches.  Slower than eager launches on a quiet host, faster when the host cannot keep the
+// queue ahead of the kernels (profiles/r02_gather_host_variance.txt); the caller decides.
+hipError_t gather_enqueue_rounds_graph(GatherDev& g, unsigned rounds, hipStream_t stream);
 
 // overlap[d] = |Q ∩ D_d| (op 0) or overlap[d] -= |Q ∩ D_d| saturating (op 1) with range-partitioned lookups: the form of
 // pair_api.hpp's overlap_vector_launch for queries of many ranges (synchronises the stream once)

@@ -143,13 +143,13 @@ def test_search_and_prefetch_vs_oracle(sm):
     assert db.best_containment(q).signature.name in ("s5", "s116")          # itself or its planted duplicate
 
 
-@pytest.mark.parametrize("build", ["atomic", "ranges", "ranges-direct"])
+@pytest.mark.parametrize("build", ["atomic", "ranges", "ranges-direct", "ranges-streams"])
 def test_synthetic_gather_vs_oracle(sm, build, monkeypatch):
     # the builders of the inverted index (csrc/gather.hip: one atomic per element / range-partitioned with the
     # histogram in LDS, postings filled through the two-level partition or by direct stores) -- the size heuristic
     # would pick "atomic" for a database this small
     monkeypatch.setenv("SMG_GATHER_BUILD", build.split("-")[0])
-    monkeypatch.setenv("SMG_GATHER_FILL", "direct" if build.endswith("direct") else "staged")
+    monkeypatch.setenv("SMG_GATHER_FILL", build.split("-")[1] if "-" in build else "staged")
     from sourmash_amd.index import CounterGather
     from sourmash_amd.synth import synth_gather
     qh, dbh = synth_gather(n_query=60_000, n_db=1500, db_size=600)
@@ -166,7 +166,7 @@ def test_synthetic_gather_vs_oracle(sm, build, monkeypatch):
         assert len(want) > 10 or thr_bp == 200_000
 
 
-@pytest.mark.parametrize("fill", ["staged", "direct"])
+@pytest.mark.parametrize("fill", ["staged", "streams", "direct"])
 def test_range_builder_postings_are_exact(fill, monkeypatch):
     """The postings themselves (not only the gather they drive): after the range-partitioned build every counter equals
     |Q ∩ row|, and consuming the whole query through the postings brings every counter to exactly zero -- which holds
