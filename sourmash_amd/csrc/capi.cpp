@@ -1030,19 +1030,22 @@ static uint64_t gather_drain(GatherDev& g, uint64_t* out_idx, uint64_t* out_isec
     static const int graph_mode = [] { const char* e = getenv("SMG_GATHER_GRAPH"); return e ? atoi(e) : -1; }();
     bool use_graph = graph_mode == 1;
     unsigned batch = 32;
+    const auto t_all = std::chrono::steady_clock::now();
     for (;;) {
         const auto t0 = std::chrono::steady_clock::now();
+        hipStream_t bs = st;                                           // the stream this batch runs on
         if (replay) hip_check(gather_enqueue_replay(g, (batch + GATHER_TOPK_MAX - 1) / GATHER_TOPK_MAX, st), "gather rounds");
-        else if (use_graph) hip_check(gather_enqueue_rounds_graph(g, batch, st), "gather rounds (graph)");
+        else if (use_graph) hip_check(gather_enqueue_rounds_graph(g, batch, &bs), "gather rounds (graph)");
         else hip_check(gather_enqueue_rounds(g, batch, st), "gather rounds");
         const auto t1 = std::chrono::steady_clock::now();
-        hip_check(hipMemcpyAsync(head, g.state, sizeof(head), hipMemcpyDeviceToHost, st), "D2H");
-        hip_check(hipStreamSynchronize(st), "sync");
+        hip_check(hipMemcpyAsync(head, g.state, sizeof(head), hipMemcpyDeviceToHost, bs), "D2H");
+        hip_check(hipStreamSynchronize(bs), "sync");
         const double enqueue_us = std::chrono::duration<double, std::micro>(t1 - t0).count();
         const double wait_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t1).count();
         if (trace)
-            fprintf(stderr, "[gather] batch of %u rounds (%s): enqueue %.1f us, then %.1f us until done (rounds so far %llu)\n", batch,
-                    replay ? "replay" : use_graph ? "graph" : "eager", enqueue_us, wait_us, head[GS_ROUNDS]);
+            fprintf(stderr, "[gather] batch of %u rounds (%s): enqueue %.1f us, then %.1f us until done (rounds so far %llu; %.1f us since the loop began)\n",
+                    batch, replay ? "replay" : use_graph ? "graph" : "eager", enqueue_us, wait_us, head[GS_ROUNDS],
+                    std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_all).count());
         if (head[GS_DONE]) break;
         if (!replay && !use_graph && graph_mode == -1 && batch >= 64 && wait_us < 0.2 * enqueue_us) use_graph = true;
         if (batch < 512) batch *= 2;

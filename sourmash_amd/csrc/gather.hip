@@ -935,6 +935,7 @@ void gather_destroy(GatherDev& g) {
     for (void* p : owned)
         if (p) (void)hipFreeAsync(p, g.stream);
     if (g.loop_graph) (void)hipGraphExecDestroy(g.loop_graph);
+    if (g.loop_stream) (void)hipStreamDestroy(g.loop_stream);
     g = GatherDev();
 }
 
@@ -1160,19 +1161,23 @@ hipError_t gather_enqueue_rounds(GatherDev& g, unsigned rounds, hipStream_t stre
     return hipSuccess;
 }
 
-hipError_t gather_enqueue_rounds_graph(GatherDev& g, unsigned rounds, hipStream_t stream) {
+hipError_t gather_enqueue_rounds_graph(GatherDev& g, unsigned rounds, hipStream_t* used) {
+    // Runs on the index's own stream: a caller's stream may be the legacy default stream, which cannot capture.  The
+    // caller has synchronised its stream before the first call and synchronises *used after every batch.
+    if (!g.loop_stream) SMG_TRY(hipStreamCreateWithFlags(&g.loop_stream, hipStreamNonBlocking));
     if (!g.loop_graph) {
         hipGraph_t graph = nullptr;
-        SMG_TRY(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
-        const hipError_t e = gather_enqueue_rounds(g, GATHER_GRAPH_ROUNDS, stream);
-        const hipError_t e2 = hipStreamEndCapture(stream, &graph);
+        SMG_TRY(hipStreamBeginCapture(g.loop_stream, hipStreamCaptureModeThreadLocal));
+        const hipError_t e = gather_enqueue_rounds(g, GATHER_GRAPH_ROUNDS, g.loop_stream);
+        const hipError_t e2 = hipStreamEndCapture(g.loop_stream, &graph);
         if (e != hipSuccess) { if (graph) (void)hipGraphDestroy(graph); return e; }
         SMG_TRY(e2);
         const hipError_t e3 = hipGraphInstantiate(&g.loop_graph, graph, nullptr, nullptr, 0);
         (void)hipGraphDestroy(graph);
         SMG_TRY(e3);
     }
-    for (unsigned r = 0; r < rounds; r += GATHER_GRAPH_ROUNDS) SMG_TRY(hipGraphLaunch(g.loop_graph, stream));
+    for (unsigned r = 0; r < rounds; r += GATHER_GRAPH_ROUNDS) SMG_TRY(hipGraphLaunch(g.loop_graph, g.loop_stream));
+    *used = g.loop_stream;
     return hipSuccess;
 }
 

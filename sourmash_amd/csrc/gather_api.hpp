@@ -66,6 +66,7 @@ struct GatherDev {
     uint64_t* own_cands = nullptr;      // single-GPU loop: this shard's own export buffer
     uint64_t own_cands_words = 0;
     hipGraphExec_t loop_graph = nullptr;   // GATHER_GRAPH_ROUNDS rounds of pick + apply, captured once (hosts that launch slowly)
+    hipStream_t loop_stream = nullptr;     // the graph's own stream (the legacy default stream cannot capture)
 };
 
 constexpr unsigned GATHER_GRAPH_ROUNDS = 64;
@@ -106,7 +107,7 @@ hipError_t gather_enqueue_rounds(GatherDev& g, unsigned rounds, hipStream_t stre
 // The same rounds as replays of one captured graph of GATHER_GRAPH_ROUNDS rounds (rounded up): one host call per 64
 // rounds instead of 128 launches.  Slower than eager launches on a quiet host, faster when the host cannot keep the
 // queue ahead of the kernels (profiles/r02_gather_host_variance.txt); the caller decides.
-hipError_t gather_enqueue_rounds_graph(GatherDev& g, unsigned rounds, hipStream_t stream);
+hipError_t gather_enqueue_rounds_graph(GatherDev& g, unsigned rounds, hipStream_t* used);
 
 // overlap[d] = |Q ∩ D_d| (op 0) or overlap[d] -= |Q ∩ D_d| saturating (op 1) with range-partitioned lookups: the form of
 // pair_api.hpp's overlap_vector_launch for queries of many ranges (synchronises the stream once)
