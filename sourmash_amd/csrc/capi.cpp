@@ -1055,6 +1055,9 @@ static uint64_t gather_drain(GatherDev& g, uint64_t* out_idx, uint64_t* out_isec
     if (m && out_idx) hip_check(hipMemcpyAsync(out_idx, g.out_idx, m * 8, hipMemcpyDeviceToHost, st), "D2H");
     if (m && out_isect) hip_check(hipMemcpyAsync(out_isect, g.out_isect, m * 8, hipMemcpyDeviceToHost, st), "D2H");
     hip_check(hipStreamSynchronize(st), "sync");
+    if (trace)
+        fprintf(stderr, "[gather] %llu rounds read back; %.1f us since the loop began\n", (unsigned long long)n,
+                std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_all).count());
     return n;
 }
 

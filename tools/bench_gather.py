@@ -59,6 +59,7 @@ def main():
     torch.cuda.synchronize()
     t = time.perf_counter()
     res = st.run()
+    t_back = time.perf_counter() - t
     torch.cuda.synchronize()
     run_s = time.perf_counter() - t
     idx = np.array([r[0] for r in res], dtype=np.int64)
@@ -108,7 +109,7 @@ def main():
                       "threshold_bp": args.threshold_bp, "scaled": 1000},
            "generate_s": round(gen_s, 3), "index_build_ms": round(build_s * 1e3, 2),
            "postings": int(be.lib.smgpu_gather_postings(st._ptr)),
-           "rounds": len(res), "loop_ms": round(run_s * 1e3, 2),
+           "rounds": len(res), "loop_ms": round(run_s * 1e3, 2), "loop_call_ms": round(t_back * 1e3, 2),
            "us_per_round": round(run_s * 1e6 / max(len(res), 1), 2),
            "total_ms": round((build_s + run_s) * 1e3, 2),
            "overlap_pass_ms": round(overlap_ms, 3), "overlap_pass_GBps": round(total * 8 / overlap_ms / 1e6, 1),
