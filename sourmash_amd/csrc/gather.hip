@@ -93,6 +93,7 @@ __global__ __launch_bounds__(256) void build_fill_kernel(const uint32_t* __restr
 #endif
 constexpr int BR_RANGE = SMG_BR_RANGE;      // query positions per range: row slices long enough (~1 KB) to read DRAM efficiently
 constexpr int BR_EPW = 16;           // row slices a wave flattens per step (see apply_kernel)
+constexpr int BR_AHEAD = 4;         // steps of 64 lookups a wave keeps in flight in pass 1 (see build_range_kernel)
 constexpr int BR_THREADS = 512;      // 64 KB of LDS per workgroup (u16 slots, two per word): 2 workgroups = 16 waves per CU
 // Two-level fill (the default): a 4-byte store per posting straight into its list leaves 32,768 lists x 8 lines open per
 // range -- far more than one L2 -- and partially filled lines were evicted and fetched back (8.1 GB written and 13.6 GB
@@ -198,6 +199,51 @@ __global__ __launch_bounds__(BR_THREADS) void build_range_kernel(QIndex qi, cons
         const uint32_t excl = incl - n;
         const uint32_t lo_lo = (uint32_t)lo, lo_hi = (uint32_t)(lo >> 32);
         uint32_t row_hits = 0;                                      // lane l < BR_EPW: hits of slice l
+        if (COUNT && qi.rec) {
+            // Lookups, BR_AHEAD steps of 64 elements at a time: a step is a chain of two loads (the hash from HBM, its
+            // record from L2, about 3 us together) and a wave that waits for each step in turn keeps 64 loads in flight --
+            // 16 waves per CU then bound the pass at ~100 G lookups/s whatever the bandwidth (6.0 ms at C5, measured).
+            // All hash loads of the steps are issued first, then all record loads, then the compares and outputs.
+            for (uint32_t t0 = 0; t0 < total; t0 += 64 * BR_AHEAD) {
+                uint64_t x[BR_AHEAD], at[BR_AHEAD];
+                bool ok[BR_AHEAD];
+#pragma unroll
+                for (int u = 0; u < BR_AHEAD; ++u) {
+                    const uint32_t t = t0 + 64u * (uint32_t)u + (uint32_t)lane;
+                    ok[u] = t < total;
+                    const uint32_t tt = ok[u] ? t : total - 1;      // lanes past the end re-read the last element
+                    int h = 0;
+#pragma unroll
+                    for (int k = 0; k < BR_EPW - 1; ++k) h += tt >= bound[k];
+                    const uint64_t start = ((uint64_t)(uint32_t)__shfl((int)lo_hi, h) << 32) | (uint32_t)__shfl((int)lo_lo, h);
+                    at[u] = start + (tt - (uint32_t)__shfl((int)excl, h));
+                    x[u] = hashes[at[u]];
+                }
+                __builtin_amdgcn_sched_barrier(0);                  // every hash load is out before the first one is waited for
+                QRecVal rv[BR_AHEAD];
+#pragma unroll
+                for (int u = 0; u < BR_AHEAD; ++u) rv[u] = q_rec_load(qi, x[u] <= qi.qmax ? x[u] : qi.qmax);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < BR_AHEAD; ++u) {
+                    uint32_t j = q_rec_match(qi, x[u], rv[u]);
+                    if (!ok[u] || x[u] > qi.qmax) j = NONE32;
+                    if (MODE == 0 && ok[u]) qpos[at[u]] = j;
+                    const bool hit = j != NONE32;
+                    if (MODE == 0 && hit) {
+                        const uint32_t k = j - (uint32_t)j0;        // < nj: the slice lies inside the range
+                        atomicAdd(&s_slot[k >> 1], 1u << (16u * (k & 1u)));
+                    }
+                    const uint32_t tb = t0 + 64u * (uint32_t)u;
+                    const unsigned long long hits = __ballot(hit);
+                    const uint32_t a = excl > tb ? (excl - tb < 64u ? excl - tb : 64u) : 0u;
+                    const uint32_t e = incl > tb ? (incl - tb < 64u ? incl - tb : 64u) : 0u;
+                    const unsigned long long upto_e = e >= 64u ? ~0ull : ((1ull << e) - 1ull);
+                    const unsigned long long upto_a = a >= 64u ? ~0ull : ((1ull << a) - 1ull);
+                    row_hits += (uint32_t)__popcll(hits & upto_e & ~upto_a);
+                }
+            }
+        } else
         for (uint32_t t0 = 0; t0 < total; t0 += 64) {               // wave-uniform trip count: the shuffles read lanes 0 .. 15
             const uint32_t t = t0 + (uint32_t)lane;
             int h = 0;
@@ -275,6 +321,7 @@ __global__ __launch_bounds__(BR_THREADS) void build_range_kernel(QIndex qi, cons
 // -- and after the chunk every stream's part goes out with consecutive lanes (~80 entries = 330 bytes at C5).  An entry
 // that does not fit its stream's LDS row is stored directly at its slot.  What reaches the L2 are runs, not 4-byte
 // stores scattered over 128 open lines.
+constexpr int PA_AHEAD = 4;                      // steps of 64 position loads a wave keeps in flight
 constexpr int PA_CAPS = 128;                      // staged entries per stream and chunk: 128 x 128 x 4 B = 64 KB of LDS
 
 __global__ __launch_bounds__(BR_THREADS) void build_partition_kernel(uint64_t nq, const uint64_t* __restrict__ offsets,
@@ -325,23 +372,35 @@ __global__ __launch_bounds__(BR_THREADS) void build_partition_kernel(uint64_t nq
             for (int k = 0; k < BR_EPW - 1; ++k) bound[k] = __shfl(incl, k);
             const uint32_t excl = incl - n;
             const uint32_t lo_lo = (uint32_t)lo, lo_hi = (uint32_t)(lo >> 32);
-            for (uint32_t t0 = 0; t0 < total; t0 += 64) {
-                const uint32_t t = t0 + (uint32_t)lane;
-                int h = 0;
+            for (uint32_t t0 = 0; t0 < total; t0 += 64 * PA_AHEAD) {   // PA_AHEAD steps of loads in flight (see pass 1)
+                uint32_t jv[PA_AHEAD];
+                int hv[PA_AHEAD];
 #pragma unroll
-                for (int k = 0; k < BR_EPW - 1; ++k) h += t >= bound[k];
-                const uint64_t start = ((uint64_t)(uint32_t)__shfl((int)lo_hi, h) << 32) | (uint32_t)__shfl((int)lo_lo, h);
-                const uint32_t first = (uint32_t)__shfl((int)excl, h);
-                uint32_t j = NONE32;
-                if (t < total) j = __builtin_nontemporal_load(&qpos[start + (t - first)]);   // read once: streaming load
-                if (j != NONE32) {
-                    const uint32_t k = j - (uint32_t)j0;
-                    const uint32_t sub = k >> BR_SUB_BITS;
-                    const uint32_t entry = ((uint32_t)(dbase + (uint64_t)h) << BR_SUB_BITS) | (k & (BR_SUB - 1));
-                    const uint32_t at = atomicAdd(&s_gcur[sub], 1u);                       // final slot in this workgroup's stream
-                    const uint32_t in_chunk = at - s_cbase[sub];
-                    if (in_chunk < (uint32_t)PA_CAPS) s_stage[sub][in_chunk] = entry;
-                    else inter[(uint64_t)s_gbase[sub] + at] = entry;
+                for (int u = 0; u < PA_AHEAD; ++u) {
+                    const uint32_t t = t0 + 64u * (uint32_t)u + (uint32_t)lane;
+                    const bool ok = t < total;
+                    const uint32_t tt = ok ? t : total - 1;
+                    int h = 0;
+#pragma unroll
+                    for (int k = 0; k < BR_EPW - 1; ++k) h += tt >= bound[k];
+                    const uint64_t start = ((uint64_t)(uint32_t)__shfl((int)lo_hi, h) << 32) | (uint32_t)__shfl((int)lo_lo, h);
+                    const uint32_t first = (uint32_t)__shfl((int)excl, h);
+                    hv[u] = ok ? h : -1;
+                    jv[u] = __builtin_nontemporal_load(&qpos[start + (tt - first)]);   // read once: streaming load
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < PA_AHEAD; ++u) {
+                    const uint32_t j = hv[u] >= 0 ? jv[u] : NONE32;
+                    if (j != NONE32) {
+                        const uint32_t k = j - (uint32_t)j0;
+                        const uint32_t sub = k >> BR_SUB_BITS;
+                        const uint32_t entry = ((uint32_t)(dbase + (uint64_t)hv[u]) << BR_SUB_BITS) | (k & (BR_SUB - 1));
+                        const uint32_t at = atomicAdd(&s_gcur[sub], 1u);                   // final slot in this workgroup's stream
+                        const uint32_t in_chunk = at - s_cbase[sub];
+                        if (in_chunk < (uint32_t)PA_CAPS) s_stage[sub][in_chunk] = entry;
+                        else inter[(uint64_t)s_gbase[sub] + at] = entry;
+                    }
                 }
             }
         }
@@ -399,12 +458,27 @@ __global__ __launch_bounds__(512) void build_scatter_kernel(uint64_t nq, uint32_
         const uint32_t f1 = f0 + BR_SORT_CAP < total ? f0 + BR_SORT_CAP : total;
         for (uint32_t k = tid; k < (uint32_t)BR_SUB; k += blockDim.x) s_cnt[k] = 0;
         __syncthreads();
-        // histogram of the batch by list
-        uint32_t reg = 0;
-        for (uint32_t f = f0 + tid; f < f1; f += blockDim.x) {
-            while (f >= s_pre[reg + 1]) ++reg;
-            atomicAdd(&s_cnt[inter[(uint64_t)s_src[reg] + (f - s_pre[reg])] & (BR_SUB - 1)], 1u);
+        // The batch is read ONCE, all of a thread's loads issued before the first is used (one load per step used to wait
+        // for the one before: 24 dependent trips to L2 / HBM per thread and phase, and the batch was read twice).
+        constexpr int PER = BR_SORT_CAP / 512;
+        static_assert(BR_SORT_CAP % 512 == 0, "");
+        uint32_t ent[PER];
+        {
+            uint32_t reg = 0;
+#pragma unroll
+            for (int i = 0; i < PER; ++i) {
+                const uint32_t f = f0 + (uint32_t)tid + (uint32_t)i * 512u;
+                ent[i] = 0;
+                if (f < f1) {
+                    while (f >= s_pre[reg + 1]) ++reg;
+                    ent[i] = __builtin_nontemporal_load(&inter[(uint64_t)s_src[reg] + (f - s_pre[reg])]);
+                }
+            }
         }
+        // histogram of the batch by list
+#pragma unroll
+        for (int i = 0; i < PER; ++i)
+            if (f0 + (uint32_t)tid + (uint32_t)i * 512u < f1) atomicAdd(&s_cnt[ent[i] & (BR_SUB - 1)], 1u);
         __syncthreads();
         if (wave == 0) {                                            // exclusive scan of BR_SUB counts by one wave
             uint32_t carry = 0;
@@ -422,13 +496,11 @@ __global__ __launch_bounds__(512) void build_scatter_kernel(uint64_t nq, uint32_
             }
         }
         __syncthreads();
-        // placement (the batch is read again: it is still in L2)
-        reg = 0;
-        for (uint32_t f = f0 + tid; f < f1; f += blockDim.x) {
-            while (f >= s_pre[reg + 1]) ++reg;
-            const uint32_t e = inter[(uint64_t)s_src[reg] + (f - s_pre[reg])];
-            s_sorted[atomicAdd(&s_fill[e & (BR_SUB - 1)], 1u)] = e >> BR_SUB_BITS;
-        }
+        // placement
+#pragma unroll
+        for (int i = 0; i < PER; ++i)
+            if (f0 + (uint32_t)tid + (uint32_t)i * 512u < f1)
+                s_sorted[atomicAdd(&s_fill[ent[i] & (BR_SUB - 1)], 1u)] = ent[i] >> BR_SUB_BITS;
         __syncthreads();
         // every list's run goes out with consecutive lanes
         for (uint32_t jl = wave; jl < nl; jl += blockDim.x >> 6) {
@@ -1280,7 +1352,8 @@ hipError_t gather_enqueue_replay(GatherDev& g, unsigned exchanges, hipStream_t s
 // hash is read from HBM once, by consecutive lanes.  No per-(row, range) bounds are precomputed: the cursors carry over.
 // Workgroup (block b, group g) covers ranges [g * per, (g + 1) * per); its first cursors come from a binary search.
 constexpr int SL_BUCKETS = 2048;          // table buckets per range
-constexpr int SL_QCAP = 3072;             // query hashes a range may hold (uniform hashes: 2048 +- 45); else the caller falls back
+constexpr int SL_QCAP = 2432;             // query hashes a range may hold (at most ~2,048 by construction, +- 45); else the caller falls back.
+                                          // 39.9 KB of LDS in all: four workgroups (32 waves) per CU
 constexpr int SL_ROWS = 1024;             // rows per block (row starts, cursors and per-row hit counts live in LDS)
 constexpr int SL_THREADS = 512;
 constexpr int SL_GROUP = 16;              // lanes per row visit
@@ -1440,7 +1513,12 @@ hipError_t overlap_ranges_launch(const uint64_t* Q, uint64_t nq, const uint64_t*
     hipError_t e = hipSuccess;
     if (!no_stream && widest <= (unsigned)SL_QCAP) {
         const uint32_t n_blocks = (uint32_t)((ndb + SL_ROWS - 1) / SL_ROWS);
-        uint32_t n_groups = (768 + n_blocks - 1) / n_blocks;                // about 3 workgroups per CU
+        // every workgroup resident at once (4 per CU by LDS and waves): with even a few more than fit, the kernel takes two
+        // rounds -- 784 workgroups on 768 slots ran 4.2 ms with the CUs idle 42 % of the wave-time (profiles/r02_gather_sq.txt)
+        int n_cu = 256;
+        { int dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev); }
+        const uint32_t slots = (uint32_t)n_cu * 4u;
+        uint32_t n_groups = slots / n_blocks;                                // floor: never one workgroup more than fits
         if (n_groups > n_ranges) n_groups = n_ranges;
         if (n_groups < 1) n_groups = 1;
         const uint32_t per = (n_ranges + n_groups - 1) / n_groups;

@@ -28,7 +28,7 @@ struct QIndex {
     const QRec* rec = nullptr;       // optional (owners that look up many times build it); q_find prefers it
 };
 
-// table geometry for nq hashes whose largest is q_max: about one hash per bucket (never more than 2 * nq + 1 buckets)
+// table geometry for nq hashes whose largest is q_max: at most about one hash per bucket (never more than 2 * nq + 1 buckets)
 __host__ __device__ inline void qindex_geometry(uint64_t nq, uint64_t q_max, uint32_t* shift, uint32_t* buckets) {
     uint32_t bucket_bits = 0;
     while (bucket_bits < 26 && (1ull << bucket_bits) < nq) ++bucket_bits;
@@ -36,6 +36,12 @@ __host__ __device__ inline void qindex_geometry(uint64_t nq, uint64_t q_max, uin
     while (value_bits < 64 && (q_max >> value_bits)) ++value_bits;
     *shift = value_bits > bucket_bits ? value_bits - bucket_bits : 0;
     *buckets = (uint32_t)(q_max >> *shift) + 1;
+    // between half a hash and one hash per bucket: with up to two, one bucket in eight held more than the three hashes a
+    // record carries inline (Poisson, mean 1.9) and sent its lookups into a second dependent load
+    if (*buckets < nq && *shift > 0 && bucket_bits < 26) {
+        --*shift;
+        *buckets = (uint32_t)(q_max >> *shift) + 1;
+    }
 }
 
 // Wide loads from addresses that are only 4- / 8-byte aligned.  The hardware takes them (global memory, dword
@@ -57,33 +63,56 @@ __device__ __forceinline__ void load_u64_quad(const uint64_t* p, uint64_t& a, ui
     c = (uint64_t)v1.x | ((uint64_t)v1.y << 32); d = (uint64_t)v1.z | ((uint64_t)v1.w << 32);
 }
 
+// The same lookup in two steps, for callers that keep several lookups in flight: q_rec_load issues the two 16-byte loads
+// of the record (plain loads: the compiler schedules the loads of independent lookups back to back and places the waits),
+// q_rec_match compares.  `x` must be <= qi.qmax (callers clamp, then discard the result of clamped lanes); qi.rec != null.
+struct QRecVal {
+    uint4 a, b;
+};
+__device__ __forceinline__ QRecVal q_rec_load(const QIndex& qi, uint64_t x) {
+    const uint4* p = reinterpret_cast<const uint4*>(qi.rec + (x >> qi.shift));
+    QRecVal v;
+    v.a = p[0];
+    v.b = p[1];
+    return v;
+}
+__device__ __forceinline__ uint32_t q_rec_match(const QIndex& qi, uint64_t x, const QRecVal& v) {
+    const uint32_t pos = v.a.x, cnt = v.a.y;
+    const uint64_t h0 = (uint64_t)v.a.z | ((uint64_t)v.a.w << 32), h1 = (uint64_t)v.b.x | ((uint64_t)v.b.y << 32),
+                   h2 = (uint64_t)v.b.z | ((uint64_t)v.b.w << 32);
+    uint32_t j = NONE32;
+    if (cnt > 2 && h2 == x) j = pos + 2;
+    if (cnt > 1 && h1 == x) j = pos + 1;
+    if (cnt > 0 && h0 == x) j = pos;
+    if (__builtin_expect(cnt > 3 && j == NONE32 && x > h2, 0)) {         // rare (1.5 % of the buckets hold more than three)
+        uint64_t q3, q4, q5, q6;
+        load_u64_quad(qi.Q + pos + 3, q3, q4, q5, q6);                   // one more step covers buckets of up to seven
+        if (q3 == x) j = pos + 3;
+        else if (cnt > 4 && q4 == x) j = pos + 4;
+        else if (cnt > 5 && q5 == x) j = pos + 5;
+        else if (cnt > 6 && q6 == x) j = pos + 6;
+        else if (cnt > 7 && x > q6) {
+            uint32_t l = pos + 7, h = pos + cnt;
+            const uint32_t end = h;
+            while (l < h) {
+                const uint32_t mid = (l + h) >> 1;
+                if (qi.Q[mid] < x) l = mid + 1; else h = mid;
+            }
+            if (l < end && qi.Q[l] == x) j = l;
+        }
+    }
+    return j;
+}
+
+__device__ __forceinline__ uint32_t q_find_rec(const QIndex& qi, uint64_t x) {
+    return q_rec_match(qi, x, q_rec_load(qi, x));
+}
+
 // Position of x in Q, or NONE32.  The table is sized for about one query hash per bucket, so a bucket almost always
 // holds <= 4: those are fetched with two 16-byte loads and compared in registers.  Three load instructions per lookup
 // (table pair, two halves of the bucket): every lane of a lookup goes to a different cache line, and a CU serves such
 // loads at about one line per cycle, so the number of load INSTRUCTIONS is what a lookup costs.
 // Fuller buckets finish with a binary search.
-__device__ __forceinline__ uint32_t q_find_rec(const QIndex& qi, uint64_t x) {
-    const QRec* r = qi.rec + (x >> qi.shift);
-    u32x4_t v0, v1;
-    asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %2, off offset:16\n\ts_waitcnt vmcnt(0)"
-                 : "=&v"(v0), "=&v"(v1) : "v"(r) : "memory");
-    const uint32_t pos = v0.x, cnt = v0.y;
-    const uint64_t h0 = (uint64_t)v0.z | ((uint64_t)v0.w << 32), h1 = (uint64_t)v1.x | ((uint64_t)v1.y << 32),
-                   h2 = (uint64_t)v1.z | ((uint64_t)v1.w << 32);
-    if (cnt == 0) return NONE32;
-    if (h0 == x) return pos;
-    if (cnt > 1 && h1 == x) return pos + 1;
-    if (cnt > 2 && h2 == x) return pos + 2;
-    if (cnt <= 3) return NONE32;
-    uint32_t l = pos + 3, h = pos + cnt;
-    const uint32_t end = h;
-    while (l < h) {
-        const uint32_t mid = (l + h) >> 1;
-        if (qi.Q[mid] < x) l = mid + 1; else h = mid;
-    }
-    return (l < end && qi.Q[l] == x) ? l : NONE32;
-}
-
 __device__ __forceinline__ uint32_t q_find(const QIndex& qi, uint64_t x) {
     if (x > qi.qmax) return NONE32;
     if (qi.rec) return q_find_rec(qi, x);
