@@ -310,6 +310,10 @@ void smgpu_bitindex_compare_raw(const SmgpuBitIndex *ptr, uint32_t rb_first, uin
  * pow(x[i], y[ny == 1 ? 0 : i]) with the host libm, i.e. the bits of the reference's per-pair Python `**`
  * (src/sourmash/minhash.py:832-834, src/sourmash/distance_utils.py:283).  n_threads = 0: every host core. */
 void smgpu_host_pow_f64(const double *x, const double *y, uintptr_t ny, double *out, uintptr_t n, uint32_t n_threads);
+/* Host helper of add_sequence(force = false): index of the first byte of seq[0, len) outside ACGTacgt (what makes a k-mer
+ * invalid: src/core/src/encodings.rs:370-377 after the upper-casing of src/core/src/signature.rs:214), or UINTPTR_MAX
+ * when there is none.  No device involved; exported so that the CPU test suite can pin the vectorised scan. */
+uintptr_t smgpu_first_invalid_dna_byte(const char *seq, uintptr_t len);
 /* Host convenience: n sketch handles -> n x n matrices on the host (either may be NULL). */
 void smgpu_compare_all_pairs(const SourmashKmerMinHash *const *mhs, uintptr_t n, uint32_t *common_out,
                              double *jaccard_out);

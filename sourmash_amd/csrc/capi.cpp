@@ -4,6 +4,7 @@
 // (src/core/src/ffi/{utils,mod,minhash,signature,cmd/compute}.rs) on top of the
 // host containers (minhash_host.hpp, signature_host.hpp) and the HIP kernels
 // (DeviceCtx / device_api.hpp).  Part 2 are the smgpu_* batch extensions.
+#include <emmintrin.h>
 #include <hip/hip_runtime_api.h>
 #include <stdio.h>
 #include <string.h>
@@ -138,18 +139,16 @@ size_t first_invalid_byte(const uint8_t* seq, size_t len) {
         Table() { memset(bad, 1, sizeof(bad)); for (const char* c = "ACGTacgt"; *c; ++c) bad[(uint8_t)*c] = 0; }
     } t;
     size_t i = 0;
-    // eight bytes at a time: fold the case bit away, then a byte is fine iff it equals one of A C G T.  `zero(v)` marks
-    // exactly the bytes of v that are 0 (the carry-free form; the shorter (v - 0x01..) & ~v & 0x80.. marks false
-    // positives next to a true zero).  A byte >= 0x80 is never valid.
-    const uint64_t L = 0x0101010101010101ull, H = 0x8080808080808080ull;
-    for (; i + 8 <= len; i += 8) {
-        uint64_t w;
-        memcpy(&w, seq + i, 8);
-        const uint64_t hi = w & H;                                  // bytes >= 0x80: invalid
-        const uint64_t x = w & 0x5f5f5f5f5f5f5f5full;               // case folded, top bit cleared
-        auto zero = [&](uint64_t v) { return ~((((v & ~H) + ~H) | v) | ~H); };   // 0x80 where the byte is 0; no carry crosses a byte
-        const uint64_t ok = zero(x ^ (L * 'A')) | zero(x ^ (L * 'C')) | zero(x ^ (L * 'G')) | zero(x ^ (L * 'T'));
-        if ((ok & ~hi) != H) break;                                 // some byte of this word is not ACGTacgt: find it below
+    // sixteen bytes at a time (SSE2, part of every x86-64): fold the case bit away, then a byte is fine iff it equals one
+    // of A C G T (a byte >= 0x80 keeps its top bit and equals none of them)
+    const __m128i fold = _mm_set1_epi8((char)0xdf), cA = _mm_set1_epi8('A'), cC = _mm_set1_epi8('C'), cG = _mm_set1_epi8('G'),
+                  cT = _mm_set1_epi8('T');
+    for (; i + 16 <= len; i += 16) {
+        const __m128i x = _mm_and_si128(_mm_loadu_si128(reinterpret_cast<const __m128i*>(seq + i)), fold);
+        const __m128i ok = _mm_or_si128(_mm_or_si128(_mm_cmpeq_epi8(x, cA), _mm_cmpeq_epi8(x, cC)),
+                                        _mm_or_si128(_mm_cmpeq_epi8(x, cG), _mm_cmpeq_epi8(x, cT)));
+        const unsigned m = (unsigned)_mm_movemask_epi8(ok);
+        if (m != 0xffffu) return i + (size_t)__builtin_ctz(~m & 0xffffu);
     }
     for (; i < len; ++i)
         if (t.bad[seq[i]]) return i;
@@ -158,19 +157,25 @@ size_t first_invalid_byte(const uint8_t* seq, size_t len) {
 
 void settle(KmerMinHash& mh) {
     if (mh.pending.empty()) return;
-    std::string buf;
-    buf.swap(mh.pending);                                           // whatever happens below, the records are consumed once
+    // whatever happens below, the records are consumed once; the queue keeps its storage (a fresh 32 MiB string per
+    // flush costs 8,192 page faults, which was a fifth of the per-record time of a loop over 150-bp reads)
+    struct Consume {
+        std::string& q;
+        ~Consume() { q.clear(); }
+    } consume{mh.pending};
     DeviceCtx& ctx = DeviceCtx::get();
     std::lock_guard<std::mutex> g(ctx.mutex());
     std::vector<uint64_t> hs, cs;
-    ctx.sketch_host((const uint8_t*)buf.data(), buf.size(), mh.ksize, mh.seed, keep_threshold(mh), mh.track_abundance, mh.num, hs, cs);
+    ctx.sketch_host((const uint8_t*)mh.pending.data(), mh.pending.size(), mh.ksize, mh.seed, keep_threshold(mh), mh.track_abundance,
+                    mh.num, hs, cs);
     mh.add_sorted_batch(hs.data(), mh.track_abundance ? cs.data() : nullptr, hs.size());
 }
 
 // The DNA add_sequence path (signature.rs:38-58 + :246-306).
 // force == false: the walk is streaming in the reference, so the hashes of every k-mer before the first offending
 // one are added before InvalidDNA is raised: the valid prefix is queued, then the error is raised from this call.
-void add_sequence_dna(KmerMinHash& mh, const uint8_t* seq, size_t len, bool force) {
+// `scanned`: the caller has run first_invalid_byte over seq[0, len) already and passes its result in `first_bad`
+void add_sequence_dna(KmerMinHash& mh, const uint8_t* seq, size_t len, bool force, bool scanned = false, size_t first_bad = SIZE_MAX) {
     if (!mh.is_dna()) { add_residue_kmers(mh, seq, len, false); return; }
     const uint32_t k = mh.ksize;
     if (len < k || k == 0) return;                                  // signature.rs:206-210
@@ -180,7 +185,7 @@ void add_sequence_dna(KmerMinHash& mh, const uint8_t* seq, size_t len, bool forc
     bool raise = false;
     size_t bad_kmer = 0;
     if (!force) {
-        const size_t p = first_invalid_byte(seq, len);
+        const size_t p = scanned ? first_bad : first_invalid_byte(seq, len);
         if (p != SIZE_MAX) {
             bad_kmer = p + 1 >= k ? p + 1 - k : 0;                  // first k-mer whose window covers byte p
             if (bad_kmer < len - k + 1) {
@@ -672,6 +677,12 @@ void smgpu_host_pow_f64(const double* x, const double* y, uintptr_t ny, double* 
     });
 }
 
+uintptr_t smgpu_first_invalid_dna_byte(const char* seq, uintptr_t len) {
+    if (!seq || !len) return UINTPTR_MAX;
+    const size_t p = first_invalid_byte((const uint8_t*)seq, len);
+    return p == SIZE_MAX ? UINTPTR_MAX : (uintptr_t)p;
+}
+
 int32_t smgpu_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
@@ -694,8 +705,20 @@ uint32_t smgpu_minhash_add_sequence_rc(SourmashKmerMinHash* p, const char* seque
     g_err_code = 0;
     landing_void([&] {
         if (!sequence && len) throw err_internal("null sequence");
-        const void* nul = len ? memchr(sequence, 0, len) : nullptr;             // C-string semantics of kmerminhash_add_sequence
-        add_sequence_dna(*RAW(p), (const uint8_t*)sequence, nul ? (size_t)((const char*)nul - sequence) : len, force);
+        // C-string semantics of kmerminhash_add_sequence: a NUL ends the record.  force = false scans the record anyway, and
+        // a NUL is an invalid byte like any other: one pass finds whichever comes first.
+        KmerMinHash& mh = *RAW(p);
+        const uint8_t* seq = (const uint8_t*)sequence;
+        if (!force && mh.is_dna()) {
+            const size_t bad = first_invalid_byte(seq, len);
+            if (bad == SIZE_MAX) { add_sequence_dna(mh, seq, len, false, true, SIZE_MAX); return; }
+            if (seq[bad] == 0) { add_sequence_dna(mh, seq, bad, false, true, SIZE_MAX); return; }   // clean up to the NUL
+            const void* nul = memchr(seq + bad, 0, len - bad);
+            add_sequence_dna(mh, seq, nul ? (size_t)((const uint8_t*)nul - seq) : len, false, true, bad);
+            return;
+        }
+        const void* nul = len ? memchr(sequence, 0, len) : nullptr;
+        add_sequence_dna(mh, seq, nul ? (size_t)((const char*)nul - sequence) : len, force);
     });
     return g_err_code;
 }

@@ -9,6 +9,7 @@ also offers batch helpers (``add_sequence_buffer``) that hand whole buffers to
 the GPU in one call.
 """
 import ctypes as C
+import os
 import warnings
 from collections.abc import Mapping
 
@@ -144,7 +145,35 @@ def _u64_array(values):
     return arr, arr.ctypes.data_as(C.POINTER(C.c_uint64)), arr.size
 
 
-class MinHash(RustObject):
+class _AddSequencePython:
+    "add_sequence through ctypes: what MinHash uses when the C-API entry (csrc/fastcall.c) has not been built."
+
+    def add_sequence(self, sequence, force=False):
+        """Add every k-mer of a DNA sequence (GPU).  The record is validated and queued; the library hashes the queue in
+        one kernel launch when it is large or when the sketch is next looked at, so a loop over reads costs one C call
+        per read and no launch.  Invalid DNA with force=False raises here, after the k-mers in front of the bad one
+        were queued -- the reference's streaming order (signature.rs:48-54)."""
+        b = to_bytes(sequence)
+        code = _add_sequence_rc(self._get_objptr(), b, len(b), force)
+        if code:
+            _raise_last(code)
+
+
+# The per-record call is the one place where the binding is the cost (ctypes: 0.65 us per 150-bp read, two thirds of it
+# argument conversion).  csrc/fastcall.c is the same call as a C method; it is bound to the entry point of the library
+# loaded above.  SMG_NO_FASTCALL=1 keeps the ctypes route (tests compare the two).
+try:
+    if os.environ.get("SMG_NO_FASTCALL") == "1":
+        raise ImportError("disabled")
+    from . import _fastcall
+    _fastcall.bind(C.cast(_add_sequence_rc, C.c_void_p).value, _raise_last)
+    _AddSequence = _fastcall.AddSequenceBase
+except ImportError:
+    _fastcall = None
+    _AddSequence = _AddSequencePython
+
+
+class MinHash(RustObject, _AddSequence):
     """The sketch object.
 
     ``MinHash(n, ksize, ...)`` builds a bottom-``n`` sketch, ``MinHash(0, ksize,
@@ -219,15 +248,7 @@ class MinHash(RustObject):
         return self.__getstate__() == other.__getstate__()
 
     # ---- adding -------------------------------------------------------------------------------
-    def add_sequence(self, sequence, force=False):
-        """Add every k-mer of a DNA sequence (GPU).  The record is validated and queued; the library hashes the queue in
-        one kernel launch when it is large or when the sketch is next looked at, so a loop over reads costs one C call
-        per read and no launch.  Invalid DNA with force=False raises here, after the k-mers in front of the bad one
-        were queued -- the reference's streaming order (signature.rs:48-54)."""
-        b = to_bytes(sequence)
-        code = _add_sequence_rc(self._get_objptr(), b, len(b), force)
-        if code:
-            _raise_last(code)
+    # add_sequence(sequence, force=False): inherited from _AddSequence (the C method, or its ctypes twin above)
 
     def add_sequence_buffer(self, buf, force=True):
         """Batch extension: sketch a whole buffer in one call.  Records are separated

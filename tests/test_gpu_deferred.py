@@ -158,3 +158,44 @@ def test_signature_fan_out_and_c_string_semantics(sm):
     ow = oracle.OracleMinHash(0, 21, scaled=1)
     ow.add_sequence(recs[0][:100].encode())
     assert np.array_equal(mh._mins_array(), ow.mins)
+
+
+def test_c_method_and_ctypes_binding_agree(sm):
+    """MinHash.add_sequence is the C method of csrc/fastcall.c; its ctypes twin (minhash.py: _AddSequencePython) must
+    see the same sketch and raise the same errors for every argument form the reference accepts (minhash.py:70-85)."""
+    from sourmash_amd import minhash as mhmod
+    assert mhmod._fastcall is not None, "sourmash_amd/_fastcall*.so is not built (make -C sourmash_amd/csrc)"
+    assert type(sm.MinHash.add_sequence).__name__ == "method_descriptor"
+    recs = _records(50, 170, seed=21)
+    forms = [lambda r: r, lambda r: r.encode(), lambda r: bytearray(r.encode()), lambda r: memoryview(r.encode()),
+             lambda r: r.lower(), lambda r: r[:60] + "\0" + r[60:]]          # the last one: a NUL ends the record
+    a, b = sm.MinHash(0, 21, scaled=5), sm.MinHash(0, 21, scaled=5)
+    want = oracle.OracleMinHash(0, 21, scaled=5)
+    for i, r in enumerate(recs):
+        arg = forms[i % len(forms)](r)
+        a.add_sequence(arg)
+        mhmod._AddSequencePython.add_sequence(b, arg)
+        raw = bytes(arg) if not isinstance(arg, str) else arg.encode()
+        want.add_sequence(raw.split(b"\0")[0])
+    a.add_sequence(sequence=recs[0], force=True)                  # keywords
+    mhmod._AddSequencePython.add_sequence(b, sequence=recs[0], force=True)
+    want.add_sequence(recs[0].encode(), force=True)
+    assert np.array_equal(a._mins_array(), want.mins) and np.array_equal(b._mins_array(), want.mins)
+    bad = recs[1][:40] + "N" + recs[2][:40]
+    for call in (a.add_sequence, lambda s, f=False: mhmod._AddSequencePython.add_sequence(b, s, f)):
+        with pytest.raises(ValueError) as err:
+            call(bad)
+        assert "invalid DNA character in input k-mer: " + bad[20:41].upper() in str(err.value)
+        call(bad, True)                                           # force: the k-mers over the N are skipped
+    want2 = oracle.OracleMinHash(0, 21, scaled=5)
+    with pytest.raises(oracle.InvalidDNA):
+        want2.add_sequence(bad.encode())
+    want2.add_sequence(bad.encode(), force=True)
+    want.merge(want2)
+    assert np.array_equal(a._mins_array(), want.mins) and np.array_equal(b._mins_array(), want.mins)
+    for wrong in (3.5, None, ["ACGT"]):
+        with pytest.raises(TypeError):
+            a.add_sequence(wrong)
+    frozen = a.to_frozen()
+    with pytest.raises(TypeError):
+        frozen.add_sequence("ACGT" * 10)                          # FrozenMinHash stays read-only

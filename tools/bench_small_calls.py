@@ -33,10 +33,12 @@ def native_loop(lib_path, length, calls):
 
 def main():
     import sourmash_amd as sm
+    from sourmash_amd import minhash as _mh
     from sourmash_amd._lowlevel import LIBPATH
     rng = np.random.default_rng(5)
-    out = {}
-    for length, calls in ((150, 200_000), (10_000, 20_000), (1_000_000, 200)):
+    python_only = "--python-only" in sys.argv                       # the add_sequence loops alone (the ctypes comparison run)
+    out = {"binding": "C method (csrc/fastcall.c)" if _mh._fastcall is not None else "ctypes"}
+    for length, calls in ((150, 1_000_000), (10_000, 20_000), (1_000_000, 200)):
         seqs = [bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), length)).decode() for _ in range(min(calls, 200))]
         mh = sm.MinHash(0, 31, scaled=1000)
         mh.add_sequence(seqs[0])
@@ -50,9 +52,18 @@ def main():
             dt = time.perf_counter() - t0
             out[f"python_add_sequence_{length}bp_force_{force}"] = {
                 "calls": calls, "us_per_call": round(dt / calls * 1e6, 2), "Mbase_per_s": round(length * calls / dt / 1e6, 1), "hashes": n}
+        if python_only:
+            continue
         sec, n = native_loop(LIBPATH, length, calls)
         out[f"c_abi_add_sequence_{length}bp"] = {"calls": calls, "us_per_call": round(sec / calls * 1e6, 3),
                                                  "Mbase_per_s": round(length * calls / sec / 1e6, 1), "hashes": n}
+    if python_only:
+        print(json.dumps(out))
+        return
+    if _mh._fastcall is not None:                                   # the same loops through the ctypes binding, in a fresh process
+        env = dict(os.environ, SMG_NO_FASTCALL="1")
+        txt = subprocess.check_output([sys.executable, os.path.abspath(__file__), "--python-only"], env=env, text=True)
+        out["through_ctypes"] = json.loads(txt.strip().splitlines()[-1])
     a, b = sm.MinHash(0, 31, scaled=1000), sm.MinHash(0, 31, scaled=1000)
     a.add_many(range(1, 10_001, 2))
     b.add_many(range(1, 10_001, 3))
