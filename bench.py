@@ -92,6 +92,14 @@ def main():
     from sourmash_amd import device as smd, parallel
     from sourmash_amd.synth import synth_sketches, synth_gather, synth_gather_device
 
+    # the interpreter's cyclic GC stays out of the timed regions: a full pass over torch's object graph costs 40-70 ms of
+    # host time wherever an allocation happens to trigger it (it showed up as "loop time" of a 42 ms gather,
+    # profiles/r02_gather_host_variance.txt); nothing below creates reference cycles worth collecting
+    import gc
+    gc.collect()
+    gc.freeze()
+    gc.disable()
+
     n_bases = int(args.bases)
     rec = args.record_len
     # per-rank slice of one global stream, aligned to whole records (record = rec bases + 1 separator)

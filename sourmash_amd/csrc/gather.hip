@@ -181,7 +181,9 @@ __global__ __launch_bounds__(BR_THREADS) void build_range_kernel(QIndex qi, cons
         uint32_t n = 0;
         const uint64_t d = dbase + lane;
         if (lane < BR_EPW && d < d_hi) {
-            const uint32_t a = bounds[(uint64_t)r * ndb + d], e = bounds[(uint64_t)(r + 1) * ndb + d];
+            // pass 1 starts its first range at the row's first element: what lies below Q[0] is looked up (and missed) like
+            // everything else, so that every element's query position is written and nobody has to pre-fill 2 GB of them
+            const uint32_t a = (MODE == 0 && r == 0) ? 0u : bounds[(uint64_t)r * ndb + d], e = bounds[(uint64_t)(r + 1) * ndb + d];
             lo = offsets[d] + a;
             n = e - a;
         }
@@ -1101,7 +1103,6 @@ hipError_t gather_build(GatherDev& g, hipStream_t stream) {
         uint32_t *bounds = nullptr, *partial = nullptr;
         SMG_TRY(hipMallocAsync((void**)&bounds, ((uint64_t)R + 1) * g.ndb * 4, stream));
         SMG_TRY(hipMallocAsync((void**)&partial, B * g.nq * 4, stream));
-        SMG_TRY(hipMemsetAsync(g.qpos, 0xff, total * 4, stream));   // elements below Q[0] lie in no range
         hipLaunchKernelGGL(build_bounds_kernel, dim3(blocks_for_rows(g.ndb)), dim3(256), 0, stream, g.Q, R, g.hashes,
                            g.offsets, g.ndb, bounds);
         SMG_TRY(hipGetLastError());

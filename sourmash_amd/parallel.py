@@ -122,7 +122,10 @@ class _DeviceGatherState:
         idx, isect = np.zeros(self._cap, dtype=np.uint64), np.zeros(self._cap, dtype=np.uint64)
         n = self.rustcall(fn, self._ptr, idx.ctypes.data_as(C.c_void_p), isect.ctypes.data_as(C.c_void_p), self._cap,
                           self.b._s())
-        return [(int(i), int(c)) for i, c in zip(idx[:n], isect[:n])]
+        # tolist(): plain ints in two C loops.  (Building the pairs from numpy scalars allocated enough objects to set
+        # off a full cyclic-GC pass over torch's object graph -- 40-70 ms of host time that looked like loop time in
+        # tools/bench_gather.py, profiles/r02_gather_host_variance.txt.)
+        return list(zip(idx[:n].tolist(), isect[:n].tolist()))
 
     def results(self):
         return self._fetch(self.lib.smgpu_gather_results)
