@@ -306,6 +306,11 @@ uint64_t smgpu_bitindex_universe(const SmgpuBitIndex *ptr);
 void smgpu_bitindex_stats(const SmgpuBitIndex *ptr, uint64_t *frequent_hashes, uint64_t *rare_pairs, uint32_t *threshold);
 void smgpu_bitindex_compare_raw(const SmgpuBitIndex *ptr, uint32_t rb_first, uint32_t rb_stride, uint32_t rb_count,
                                 uint32_t *d_common, void *stream);
+/* The same for callers that mirror the triangle afterwards (smgpu_symmetrize_raw, as the all-pairs drivers do): only the
+ * entries on or above the diagonal of the owned rows are computed (the counterpart of smgpu_compare_blocks_raw); what lies
+ * below is left as it was.  Half the tiles of a world-size-1 launch. */
+void smgpu_bitindex_compare_upper_raw(const SmgpuBitIndex *ptr, uint32_t rb_first, uint32_t rb_stride, uint32_t rb_count,
+                                      uint32_t *d_common, void *stream);
 /* Host float helper for the containment / ANI matrices of compare (src/sourmash/compare.py:67-187): out[i] =
  * pow(x[i], y[ny == 1 ? 0 : i]) with the host libm, i.e. the bits of the reference's per-pair Python `**`
  * (src/sourmash/minhash.py:832-834, src/sourmash/distance_utils.py:283).  n_threads = 0: every host core. */

@@ -51,7 +51,10 @@ __global__ __launch_bounds__(256) void bitmap_build_kernel(const uint64_t* __res
 // rb_first + rb_stride, ... (same dealing as compare.hip); four of them form one 64-row group.
 __global__ __launch_bounds__(256) void bitmatrix_kernel(const uint32_t* __restrict__ bits, uint32_t words_per_row,
                                                         uint32_t n, uint32_t rb_first, uint32_t rb_stride,
-                                                        uint32_t rb_count, uint32_t* __restrict__ common) {
+                                                        uint32_t rb_count, uint32_t* __restrict__ common, uint32_t upper_only) {
+    // upper_only: the caller mirrors the triangle afterwards (symmetrize_kernel), so a tile whose columns all lie left of
+    // the group's first row is never read: half of the launch at world size 1
+    if (upper_only && (blockIdx.x + 1) * BT <= (rb_first + blockIdx.y * 4 * rb_stride) * 16) return;
     __shared__ __attribute__((aligned(16))) uint32_t sA[BT * BSTRIDE];
     __shared__ __attribute__((aligned(16))) uint32_t sB[BT * BSTRIDE];
     const int tid = threadIdx.x;
@@ -129,11 +132,11 @@ hipError_t bitmap_build_launch(const uint64_t* d_hashes, const uint64_t* d_offse
 }
 
 hipError_t bitmatrix_launch(const uint32_t* d_bits, uint32_t words_per_row, uint32_t n, uint32_t rb_first,
-                            uint32_t rb_stride, uint32_t rb_count, uint32_t* d_common, hipStream_t stream) {
+                            uint32_t rb_stride, uint32_t rb_count, uint32_t* d_common, hipStream_t stream, bool upper_only) {
     if (n == 0 || rb_count == 0) return hipSuccess;
     dim3 grid((n + BT - 1) / BT, (rb_count + 3) / 4);
     hipLaunchKernelGGL(bitmatrix_kernel, grid, dim3(256), 0, stream, d_bits, words_per_row, n, rb_first, rb_stride,
-                       rb_count, d_common);
+                       rb_count, d_common, upper_only ? 1u : 0u);
     return hipGetLastError();
 }
 

@@ -921,13 +921,15 @@ static BitIndex* bitindex_build(const uint64_t* d_hashes, const uint64_t* d_offs
 }
 
 static void bitindex_compare(const BitIndex* bi, uint32_t rb_first, uint32_t rb_stride, uint32_t rb_count, uint32_t* d_common,
-                             hipStream_t st) {
+                             hipStream_t st, bool upper_only = false) {
     if (bi->bits)
-        hip_check(bitmatrix_launch(bi->bits, bi->words_per_row, bi->n, rb_first, rb_stride, rb_count, d_common, st), "bitmatrix");
+        hip_check(bitmatrix_launch(bi->bits, bi->words_per_row, bi->n, rb_first, rb_stride, rb_count, d_common, st, upper_only),
+                  "bitmatrix");
     else
         hip_check(hipMemsetAsync(d_common, 0, (size_t)rb_count * 16 * bi->n * 4, st), "memset");
     if (bi->run_end)
-        hip_check(rare_pairs_launch(bi->rows_sorted, bi->run_end, bi->total, bi->n, rb_first, rb_stride, rb_count, d_common, st),
+        hip_check(rare_pairs_launch(bi->rows_sorted, bi->run_end, bi->total, bi->n, rb_first, rb_stride, rb_count, d_common, st,
+                                    upper_only),
                   "rare pairs");
 }
 
@@ -957,6 +959,12 @@ void smgpu_bitindex_compare_raw(const SmgpuBitIndex* p, uint32_t rb_first, uint3
         bitindex_compare(reinterpret_cast<const BitIndex*>(p), rb_first, rb_stride, rb_count, d_common, (hipStream_t)stream);
     });
 }
+void smgpu_bitindex_compare_upper_raw(const SmgpuBitIndex* p, uint32_t rb_first, uint32_t rb_stride, uint32_t rb_count,
+                                      uint32_t* d_common, void* stream) {
+    landing_void([&] {
+        bitindex_compare(reinterpret_cast<const BitIndex*>(p), rb_first, rb_stride, rb_count, d_common, (hipStream_t)stream, true);
+    });
+}
 
 // n x n counts (+ Jaccard) of a device-resident CSR into host matrices; dense collections take the bit-row path
 static void compare_device_csr(const uint64_t* d_hashes, const uint64_t* d_offsets, uint64_t n, uint64_t total,
@@ -965,9 +973,10 @@ static void compare_device_csr(const uint64_t* d_hashes, const uint64_t* d_offse
     // more than the comparison on hosts with a slow driver path
     AsyncBuf dc((size_t)((n + 15) / 16 * 16) * n * 4, st);
     std::unique_ptr<BitIndex> bi(bitindex_build(d_hashes, d_offsets, (uint32_t)n, st, 0, true, total));
-    if (bi)   // bit rows for the frequent hashes + inverted lists for the rare ones
-        bitindex_compare(bi.get(), 0, 1, (uint32_t)((n + 15) / 16), dc.as<uint32_t>(), st);
-    else      // LDS-tiled merge walk
+    if (bi) { // bit rows for the frequent hashes + inverted lists for the rare ones: the triangle, then its mirror image
+        bitindex_compare(bi.get(), 0, 1, (uint32_t)((n + 15) / 16), dc.as<uint32_t>(), st, true);
+        hip_check(symmetrize_launch(dc.as<uint32_t>(), (uint32_t)n, st), "symmetrize");
+    } else    // LDS-tiled merge walk
         hip_check(compare_counts_launch(d_hashes, d_offsets, (uint32_t)n, 0, (uint32_t)n, dc.as<uint32_t>(), st), "compare");
     std::unique_ptr<AsyncBuf> dj;
     if (jaccard_out) {

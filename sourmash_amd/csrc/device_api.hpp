@@ -61,9 +61,10 @@ hipError_t jaccard_from_counts_launch(const uint32_t* d_common, const uint64_t* 
 // ---- bitindex.hip (dense compare path) ---------------------------------------------------------
 hipError_t bitmap_build_launch(const uint64_t* d_hashes, const uint64_t* d_offsets, uint32_t n, const uint64_t* d_dict,
                                uint64_t U, uint32_t* d_bits, uint32_t words_per_row, hipStream_t stream);
-// rows: 16-row tiles rb_first, rb_first + rb_stride, ... (rb_count); all columns; d_common [rb_count*16][n]
+// rows: 16-row tiles rb_first, rb_first + rb_stride, ... (rb_count); d_common [rb_count*16][n]; every column, or with
+// upper_only every entry on or above the diagonal (entries below it are left as they were: the caller mirrors)
 hipError_t bitmatrix_launch(const uint32_t* d_bits, uint32_t words_per_row, uint32_t n, uint32_t rb_first,
-                            uint32_t rb_stride, uint32_t rb_count, uint32_t* d_common, hipStream_t stream);
+                            uint32_t rb_stride, uint32_t rb_count, uint32_t* d_common, hipStream_t stream, bool upper_only = false);
 
 // ---- sparse_pairs.hip (inverted compare path) ---------------------------------------------------
 size_t inverted_temp_bytes(uint64_t total);
@@ -80,6 +81,7 @@ hipError_t inverted_apply_launch(const uint64_t* d_run_off, const uint32_t* d_fr
                                  uint32_t* d_bits, uint32_t words_per_row, hipStream_t stream);
 // common[local row][col] += rare-hash contributions, for the rows of the 16-row tiles rb_first, rb_first + rb_stride, ...
 hipError_t rare_pairs_launch(const uint32_t* d_rows_sorted, const uint32_t* d_run_end, uint64_t total, uint32_t n,
-                             uint32_t rb_first, uint32_t rb_stride, uint32_t rb_count, uint32_t* d_common, hipStream_t stream);
+                             uint32_t rb_first, uint32_t rb_stride, uint32_t rb_count, uint32_t* d_common, hipStream_t stream,
+                             bool upper_only = false);
 
 }  // namespace smg

@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void elements_apply_kernel(const uint64_t* __r
 // rows this launch owns (16-row tiles rb_first, rb_first + rb_stride, ...; output rows back to back)
 __global__ __launch_bounds__(256) void rare_pairs_kernel(const uint32_t* __restrict__ rows, const uint32_t* __restrict__ run_end,
                                                          uint64_t total, uint32_t n, uint32_t rb_first, uint32_t rb_stride,
-                                                         uint32_t rb_count, uint32_t* __restrict__ common) {
+                                                         uint32_t rb_count, uint32_t* __restrict__ common, uint32_t upper_only) {
     auto local_row = [&](uint32_t r) -> uint32_t {               // 0xffffffff if the row is not owned
         const uint32_t tile = r >> 4;
         if (tile < rb_first) return 0xffffffffu;
@@ -110,6 +110,12 @@ __global__ __launch_bounds__(256) void rare_pairs_kernel(const uint32_t* __restr
         if (lr != 0xffffffffu) atomicAdd(&common[(uint64_t)lr * n + r], 1u);
         for (uint64_t q = p + 1; q < e; ++q) {
             const uint32_t c = rows[q];
+            if (upper_only) {                                     // the caller mirrors: only the entry above the diagonal
+                const uint32_t lo = r < c ? r : c, hi = r < c ? c : r;
+                const uint32_t ll = lo == r ? lr : local_row(lo);
+                if (ll != 0xffffffffu) atomicAdd(&common[(uint64_t)ll * n + hi], 1u);
+                continue;
+            }
             if (lr != 0xffffffffu) atomicAdd(&common[(uint64_t)lr * n + c], 1u);
             const uint32_t lc = local_row(c);
             if (lc != 0xffffffffu) atomicAdd(&common[(uint64_t)lc * n + r], 1u);
@@ -200,10 +206,11 @@ hipError_t inverted_apply_launch(const uint64_t* d_run_off, const uint32_t* d_fr
 }
 
 hipError_t rare_pairs_launch(const uint32_t* d_rows_sorted, const uint32_t* d_run_end, uint64_t total, uint32_t n,
-                             uint32_t rb_first, uint32_t rb_stride, uint32_t rb_count, uint32_t* d_common, hipStream_t stream) {
+                             uint32_t rb_first, uint32_t rb_stride, uint32_t rb_count, uint32_t* d_common, hipStream_t stream,
+                             bool upper_only) {
     if (total == 0 || rb_count == 0) return hipSuccess;
     hipLaunchKernelGGL(rare_pairs_kernel, dim3(grid_for(total, 256, 16384)), dim3(256), 0, stream, d_rows_sorted, d_run_end, total,
-                       n, rb_first, rb_stride < 1 ? 1 : rb_stride, rb_count, d_common);
+                       n, rb_first, rb_stride < 1 ? 1 : rb_stride, rb_count, d_common, upper_only ? 1u : 0u);
     return hipGetLastError();
 }
 

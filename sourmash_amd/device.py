@@ -142,12 +142,14 @@ class BitIndex:
         lib.smgpu_bitindex_stats(self._ptr, C.byref(f), C.byref(r), C.byref(t))
         return f.value, r.value, t.value
 
-    def compare_tiles(self, first, stride, count, out=None):
-        "u32 counts for the 16-row tiles first, first+stride, ... (count of them), all columns"
+    def compare_tiles(self, first, stride, count, out=None, upper=False):
+        """u32 counts for the 16-row tiles first, first+stride, ... (count of them): all columns, or with upper=True only
+        the entries on or above the diagonal (for callers that mirror the triangle afterwards; the rest is left as it was)"""
         torch = _torch()
         if out is None:
             out = torch.empty((count * 16, self.n), dtype=torch.int32, device="cuda")
-        rustcall(lib.smgpu_bitindex_compare_raw, self._ptr, first, stride, count, _ptr(out), _stream(torch))
+        fn = lib.smgpu_bitindex_compare_upper_raw if upper else lib.smgpu_bitindex_compare_raw
+        rustcall(fn, self._ptr, first, stride, count, _ptr(out), _stream(torch))
         return out
 
     def __del__(self):
@@ -176,7 +178,11 @@ def compare_rows(hashes, offsets, row_lo=0, row_hi=None, want_jaccard=True, comm
         count = (rows + 15) // 16
         if common is None or common.shape[0] < count * 16:
             common = torch.empty((count * 16, n), dtype=torch.int32, device=hashes.device)
-        index.compare_tiles(row_lo // 16, 1, count, out=common)
+        if row_lo == 0 and row_hi == n:                         # the whole matrix: the triangle, then its mirror image
+            index.compare_tiles(0, 1, count, out=common, upper=True)
+            rustcall(lib.smgpu_symmetrize_raw, _ptr(common), n, _stream(torch))
+        else:
+            index.compare_tiles(row_lo // 16, 1, count, out=common)
         if want_jaccard:
             rustcall(lib.smgpu_jaccard_raw, _ptr(common), _ptr(offsets), n, row_lo, row_hi, _ptr(jaccard), _stream(torch))
         return common[:rows], (jaccard if want_jaccard else None)

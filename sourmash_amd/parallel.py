@@ -175,8 +175,8 @@ class DeviceBackend:
 
     # -- compare --
     def compare_tiles(self, hashes, offsets, n, first, stride, count, method="auto"):
-        """counts for the owned 16-row tiles.  method: "merge" (LDS-tiled merge walk, upper triangle),
-        "bits" (bit rows + popcount, all columns) or "auto" (bits when the collection is dense enough)."""
+        """counts for the owned 16-row tiles, entries on or above the diagonal (the driver mirrors them).  method: "merge"
+        (LDS hash-table tiles), "bits" (bit rows + popcount) or "auto" (bits when the collection is dense enough)."""
         out = self.zeros((count * TILE, n), self.torch.int32)
         index = None
         if method in ("auto", "bits"):
@@ -188,7 +188,7 @@ class DeviceBackend:
             if index is None and method == "bits":
                 raise ValueError("collection too sparse for the bit-row path")
         if index is not None:
-            index.compare_tiles(first, stride, count, out=out)
+            index.compare_tiles(first, stride, count, out=out, upper=True)
         else:
             self.rustcall(self.lib.smgpu_compare_blocks_raw, self._p(hashes), self._p(offsets), n, first, stride, count,
                           self._p(out), self._s())

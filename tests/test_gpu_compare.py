@@ -231,6 +231,12 @@ def test_compare_index_splits_frequent_and_rare_hashes(sm):
             lo = (first + t * stride) * 16
             hi = min(lo + 16, n)
             assert np.array_equal(out[t * 16:t * 16 + hi - lo], wc[lo:hi]), (first, stride, t)
+        # the triangle form (callers mirror afterwards): everything on or above the diagonal, whatever lies below
+        up = idx.compare_tiles(first, stride, count, upper=True).cpu().numpy().view(np.uint32)
+        for t in range(count):
+            lo = (first + t * stride) * 16
+            for r in range(lo, min(lo + 16, n)):
+                assert np.array_equal(up[t * 16 + r - lo, r:], wc[r, r:]), (first, stride, r)
     # the host convenience entry point picks the same path and the same numbers
     mhs = []
     for hs in sk[:60]:
