@@ -455,21 +455,28 @@ def single_gpu_extras(extra, torch, np, dev, be, smd, synth_sketches, synth_gath
     balg = 8 * int(bsizes.sum() * (bn - 1))
     bc, bj = smd.compare_rows(bh, boff)
     ms_big = timed(lambda: smd.compare_rows(bh, boff, common=bc, jaccard=bj), reps=1)
-    t0 = time.perf_counter()
-    ca, ja = smd.compare_rows(bh, boff, method="auto")
-    torch.cuda.synchronize()
-    auto_big = (time.perf_counter() - t0) * 1e3
+    auto_big = None
+    for _ in range(2):                                  # decide + build the index + matrix + Jaccard, every time; second call
+        t0 = time.perf_counter()
+        ca, ja = smd.compare_rows(bh, boff, method="auto")
+        torch.cuda.synchronize()
+        auto_big = (time.perf_counter() - t0) * 1e3
     extra["compare_10000x10000"] = {
         "pairs": bpairs, "merge_ms": round(ms_big, 2), "merge_pairs_per_s": round(bpairs / (ms_big * 1e-3), 1),
         "merge_roofline": merge_roofline(balg, ms_big),
         "auto_ms": round(auto_big, 2), "auto_pairs_per_s": round(bpairs / (auto_big * 1e-3), 1),
         "identical": bool((ca == bc).all().item() and (ja == bj).all().item()),
-        "note": "config C4 (pool-drawn sketches: the cost model picks bit columns); auto includes the index build"}
+        "note": "config C4 (pool-drawn sketches: the cost model picks bit columns); auto includes the index build; "
+                "bitmatrix_kernel is VALU-bound: 2.55 instructions per 32-bit AND+popcount against a floor of 2, every "
+                "SIMD issue slot used (profiles/r02_compare_pmc.txt), upper triangle + mirror"}
     del bc, bj, ca, ja, bh, boff
     torch.cuda.empty_cache()
     gq5, gh5, goff5 = synth_gather_device(1_000_000, 100_000, 5000, dev)
     torch.cuda.synchronize()
+    st5 = None
     for _ in range(2):
+        st5 = None                                      # the previous index goes back to the pool before the next is built
+        torch.cuda.synchronize()
         t0 = time.perf_counter()
         st5 = be.gather_state(gq5, gq5.numel(), gh5, goff5, 100_000, 0)
         torch.cuda.synchronize()
@@ -489,14 +496,17 @@ def single_gpu_extras(extra, torch, np, dev, be, smd, synth_sketches, synth_gath
         "us_per_round": round((t2 - t1) * 1e6 / max(len(res5), 1), 2),
         "index_build_roofline": hbm_roofline(build_alg, (t1 - t0) * 1e3,
                                              "8 B per database hash + 4 B per posting + 2 x 4 B query position per element; wall clock of smgpu_gather_new_raw"),
-        "loop_note": "a dependent chain of small kernels (latency, not bandwidth): %d rounds touch %.1f MB of postings in all"
+        "loop_floor_ms": round(postings / 23.0e9 * 1e3, 2),
+        "loop_note": "a dependent chain of small kernels (latency, not bandwidth): %d rounds touch %.1f MB of postings in all; "
+                     "one 64-bit counter decrement per posting, and the device does 23 G such atomics/s on 100,000 counters "
+                     "(profiles/r02_ubench_atomics.txt): loop_floor_ms; the rest is ~7 dependent memory trips per round"
                      % (len(res5), postings * 4 / 1e6)}
     # overlap pass (search / prefetch over the resident collection): |Q ∩ row| for every row
     cnt = be.zeros((100_000,), torch.int64)
     ms_ov = timed(lambda: be.overlaps(gq5, gq5.numel(), gh5, goff5, 100_000, cnt, 0), reps=3)
     extra["overlaps_1M_vs_100000"] = {"ms": round(ms_ov, 3), "sketches_per_s": round(100_000 / (ms_ov * 1e-3), 1),
                                       "roofline": hbm_roofline(db_bytes + 8 * int(gq5.numel()), ms_ov,
-                                                               "8 B per database hash + the query once; stream_lookup_kernel (query slices through LDS, database read once)")}
+                                                               "8 B per database hash + the query once; stream_lookup_kernel (query slices through LDS, every database hash looked at once)")}
 
 
 def hbm_roofline(alg_bytes, ms, what):

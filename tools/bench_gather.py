@@ -52,9 +52,10 @@ def main():
         return st, time.perf_counter() - t
 
     import gc
-    gc.collect()
-    gc.freeze()                                            # the interpreter's cyclic GC stays out of the timed regions:
-    gc.disable()                                           # a full pass over torch's object graph costs 40-70 ms
+    if os.environ.get("SMG_BENCH_GC") != "1":
+        gc.collect()
+        gc.freeze()                                        # the interpreter's cyclic GC stays out of the timed regions:
+        gc.disable()                                       # a full pass over torch's object graph costs 40-70 ms
     st, _ = timed_build()                                  # warm (allocator, code objects)
     del st
     st, build_s = timed_build()
