@@ -844,6 +844,8 @@ struct BitIndex {
     // inverted part (null for the pure bit-row index)
     uint32_t* rows_sorted = nullptr;       // row of every (hash, row) element, ordered by hash
     uint32_t* run_end = nullptr;           // end of the element's run if its hash is rare, else 0
+    uint64_t inv_total = 0;                // entries of rows_sorted / run_end (every element after the sort; the rare ones only
+                                           // from the sort-free builder)
     uint64_t frequent = 0, rare_pairs = 0;
     uint32_t threshold = 0;
     hipStream_t stream = nullptr;          // the arrays come from this stream's pool and go back to it, in order
@@ -870,6 +872,48 @@ static BitIndex* bitindex_build(const uint64_t* d_hashes, const uint64_t* d_offs
     }
     if (total == 0 || total > 0xffffffffull) return nullptr;
     const double t_merge = (double)n * (double)total / RATE_MERGE_STEPS;
+    // a hash held by m sketches costs m^2 increments as a rare hash, or one bit column (n^2/2 pairs x 1/32 word) as
+    // a frequent one: the two meet at m ~ n * sqrt(RATE_PAIR_ATOMICS / (64 * RATE_BIT_WORDS))
+    uint32_t threshold = (uint32_t)((double)n * std::sqrt(RATE_PAIR_ATOMICS / (64.0 * RATE_BIT_WORDS)));
+    if (threshold < 1) threshold = 1;
+    if (forced_threshold) threshold = forced_threshold;
+    const double pairs = 0.5 * (double)n * (double)n;
+    // The sort-free builder first (dictindex.hip): it serves collections whose distinct hashes fit its per-bucket tables
+    // (any collection with heavy sharing: C3 / C4 have 55,000 distinct hashes for 5e6 / 5e7 elements); a bucket that
+    // overflows sends the build to the sort below.  SMG_COMPARE_INDEX=sort skips it (tests run both).
+    static const bool sort_only = [] { const char* e = getenv("SMG_COMPARE_INDEX"); return e && !strcmp(e, "sort"); }();
+    // an index that serves ONE compare must also pay for its own build (~0.1 ms of launches + three passes over the elements)
+    if (!sort_only && !(one_shot && !forced_threshold && t_merge < 0.1e-3 + (double)total / 4.0e10)) {
+        std::unique_ptr<BitIndex> bi(new BitIndex());
+        bi->n = n; bi->total = total; bi->stream = st;
+        AsyncBuf scratch(dict_scratch_bytes(n), st), scal(64, st);
+        hip_check(hipMemsetAsync(scal.p, 0, 64, st), "memset");
+        hip_check(dict_count_launch(d_hashes, d_offsets, n, threshold, scratch.p, scal.as<unsigned long long>(), st), "dictionary pass 1");
+        unsigned long long out[5] = {0, 0, 0, 0, 0};
+        hip_check(hipMemcpyAsync(out, scal.p, sizeof(out), hipMemcpyDeviceToHost, st), "D2H");
+        hip_check(hipStreamSynchronize(st), "sync");
+        if (out[4] == 0) {
+            const uint64_t U = out[0], n_freq = out[1], rare_pairs = out[2], rare_elems = out[3];
+            bi->universe = U;
+            const uint32_t words = n_freq ? (uint32_t)(((n_freq + 31) / 32 + 31) / 32 * 32) : 0;     // whole 32-word k-steps
+            const double t_index = pairs * (double)words / RATE_BIT_WORDS + 2.0 * (double)rare_pairs / RATE_PAIR_ATOMICS +
+                                   (double)total / 2.0e10;
+            if ((t_index > t_merge && !forced_threshold) || (double)n * words * 4.0 > 8.0 * (1ull << 30)) return nullptr;
+            bi->frequent = n_freq; bi->rare_pairs = rare_pairs; bi->threshold = threshold; bi->words_per_row = words;
+            if (words) {
+                hip_check(hipMallocAsync((void**)&bi->bits, (size_t)n * words * 4, st), "hipMallocAsync");
+                hip_check(hipMemsetAsync(bi->bits, 0, (size_t)n * words * 4, st), "memset");
+            }
+            if (rare_elems) {
+                hip_check(hipMallocAsync((void**)&bi->rows_sorted, rare_elems * 4 + 16, st), "hipMallocAsync");
+                hip_check(hipMallocAsync((void**)&bi->run_end, rare_elems * 4 + 16, st), "hipMallocAsync");
+                bi->inv_total = rare_elems;
+            }
+            hip_check(dict_emit_launch(d_hashes, d_offsets, n, scratch.p, bi->bits, words, bi->rows_sorted, bi->run_end, st),
+                      "dictionary pass 2");
+            return bi.release();
+        }
+    }
     // an index that serves ONE compare must also pay for its own sort (~0.6 ms of fixed cost + total / 5e9 s measured)
     if (one_shot && !forced_threshold && t_merge < 0.6e-3 + (double)total / 5.0e9) return nullptr;
     // (hash, row) of the whole collection sorted by hash; runs = distinct hashes with their number of holders.
@@ -887,11 +931,6 @@ static BitIndex* bitindex_build(const uint64_t* d_hashes, const uint64_t* d_offs
     hip_check(inverted_sort_launch(d_hashes, d_offsets, n, total, keys_a.as<uint64_t>(), keys_b.as<uint64_t>(),
                                    rows_tmp.as<uint32_t>(), bi->rows_sorted, counts.as<uint32_t>(), d_n_runs, tmp.p, tb, st),
               "inverted sort");
-    // a hash held by m sketches costs m^2 increments as a rare hash, or one bit column (n^2/2 pairs x 1/32 word) as
-    // a frequent one: the two meet at m ~ n * sqrt(RATE_PAIR_ATOMICS / (64 * RATE_BIT_WORDS))
-    uint32_t threshold = (uint32_t)((double)n * std::sqrt(RATE_PAIR_ATOMICS / (64.0 * RATE_BIT_WORDS)));
-    if (threshold < 1) threshold = 1;
-    if (forced_threshold) threshold = forced_threshold;
     hip_check(inverted_classify_launch(counts.as<uint32_t>(), d_n_runs, total, threshold, flags.as<uint32_t>(),
                                        run_off.as<uint64_t>(), freq_rank.as<uint64_t>(), d_out, tmp.p, tb, st), "classify");
     unsigned long long out[3] = {0, 0, 0};
@@ -899,7 +938,7 @@ static BitIndex* bitindex_build(const uint64_t* d_hashes, const uint64_t* d_offs
     hip_check(hipStreamSynchronize(st), "sync");
     const uint64_t U = out[0], n_freq = out[1], rare_pairs = out[2];
     bi->universe = U;
-    const double pairs = 0.5 * (double)n * (double)n;
+    bi->inv_total = total;
     const uint32_t words = n_freq ? (uint32_t)(((n_freq + 31) / 32 + 31) / 32 * 32) : 0;     // whole 32-word k-steps
     const double t_index = pairs * (double)words / RATE_BIT_WORDS + 2.0 * (double)rare_pairs / RATE_PAIR_ATOMICS +
                            (double)total / 2.0e10;                                         // + one pass over the elements
@@ -928,7 +967,7 @@ static void bitindex_compare(const BitIndex* bi, uint32_t rb_first, uint32_t rb_
     else
         hip_check(hipMemsetAsync(d_common, 0, (size_t)rb_count * 16 * bi->n * 4, st), "memset");
     if (bi->run_end)
-        hip_check(rare_pairs_launch(bi->rows_sorted, bi->run_end, bi->total, bi->n, rb_first, rb_stride, rb_count, d_common, st,
+        hip_check(rare_pairs_launch(bi->rows_sorted, bi->run_end, bi->inv_total, bi->n, rb_first, rb_stride, rb_count, d_common, st,
                                     upper_only),
                   "rare pairs");
 }

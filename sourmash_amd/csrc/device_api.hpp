@@ -66,6 +66,18 @@ hipError_t bitmap_build_launch(const uint64_t* d_hashes, const uint64_t* d_offse
 hipError_t bitmatrix_launch(const uint32_t* d_bits, uint32_t words_per_row, uint32_t n, uint32_t rb_first,
                             uint32_t rb_stride, uint32_t rb_count, uint32_t* d_common, hipStream_t stream, bool upper_only = false);
 
+// ---- dictindex.hip (the compare index without a sort) -------------------------------------------
+constexpr int DICT_BUCKETS = 512;          // hash-space buckets, one workgroup each
+constexpr int DICT_MAX_DISTINCT = 1024;    // distinct hashes a bucket can hold; fuller collections use the sort below
+size_t dict_scratch_bytes(uint32_t n);
+// slice bounds, pass 1 (distinct hashes + holders per bucket, classified against `threshold`), scan.  d_out (5 values, zeroed
+// by the caller): distinct hashes, frequent ones, rare pair increments, rare elements, buckets that overflowed
+hipError_t dict_count_launch(const uint64_t* d_hashes, const uint64_t* d_offsets, uint32_t n, uint32_t threshold, void* d_scratch,
+                             unsigned long long* d_out, hipStream_t stream);
+// pass 2: bit rows (zeroed by the caller) and the rows of every rare hash (d_rare_end[p] = end of p's run)
+hipError_t dict_emit_launch(const uint64_t* d_hashes, const uint64_t* d_offsets, uint32_t n, void* d_scratch, uint32_t* d_bits,
+                            uint32_t words_per_row, uint32_t* d_rare_rows, uint32_t* d_rare_end, hipStream_t stream);
+
 // ---- sparse_pairs.hip (inverted compare path) ---------------------------------------------------
 size_t inverted_temp_bytes(uint64_t total);
 hipError_t inverted_sort_launch(const uint64_t* d_hashes, const uint64_t* d_offsets, uint32_t n, uint64_t total,

@@ -450,3 +450,63 @@ def test_compare_extreme_hash_values_and_both_tile_kernels():
                            capture_output=True, text=True, timeout=600)
         assert p.returncode == 0, p.stderr[-2000:]
         assert np.array_equal(np.load(dst).view(np.uint32), wc)
+
+
+def _index_builder_cases():
+    """Both builders of the compare index must give the oracle's matrix: the sort-free one (csrc/dictindex.hip: buckets of
+    the hash space, LDS tables) and the sort it falls back to (csrc/sparse_pairs.hip).  Run in a subprocess per builder."""
+    import torch
+    from sourmash_amd import device as smd
+    from sourmash_amd.synth import synth_sketches
+    rng = np.random.default_rng(23)
+    top = np.uint64(2**64 - 1)
+    pool = np.unique(rng.integers(0, 2**63, 3000, dtype=np.int64).astype(np.uint64) * np.uint64(2) + np.uint64(1))
+    sk = []
+    for i in range(150):                                          # more than one 128-row chunk of pass 2
+        n = int(rng.integers(0, 700)) if i % 7 else int(rng.integers(0, 3))
+        row = set(rng.choice(pool, size=n, replace=False).tolist())
+        if i % 3 == 0:
+            row.add(int(top))                                     # the tables' empty marker is a legal hash (scaled = 1)
+        if i % 4 == 0:
+            row.add(0)
+        sk.append(np.array(sorted(row), dtype=np.uint64))
+    sk[5] = np.array([int(top)], dtype=np.uint64)
+    sk[6] = np.array([0], dtype=np.uint64)
+    sk[9] = np.array([], dtype=np.uint64)
+    wc, wj = oracle.compare_all_pairs(*oracle.make_csr(sk), nthreads=4)
+    h, off = smd.pack_csr(sk)
+    for threshold in (1, 8, 60, 10_000):                          # 2^64 - 1 (50 holders) frequent or rare; all rare
+        idx = smd.BitIndex.build(h, off, threshold=threshold)
+        assert idx is not None
+        c, j = smd.compare_rows(h, off, index=idx)
+        torch.cuda.synchronize()
+        assert np.array_equal(c.cpu().numpy().view(np.uint32), wc), threshold
+        assert np.array_equal(j.cpu().numpy().view(np.uint64), wj.view(np.uint64)), threshold
+        cb, _ = smd.compare_rows(h, off, 16, 112, index=idx)      # a row block: every column, no mirror
+        torch.cuda.synchronize()
+        assert np.array_equal(cb.cpu().numpy().view(np.uint32), wc[16:112]), threshold
+    # a pool collection (every hash frequent) and one whose distinct hashes overflow the buckets' tables (-> the sort)
+    for sk2, thr in ((synth_sketches(300, pool_size=20_000, keep_one_in=8, planted=True), 0),
+                     (synth_sketches(260, pool_size=3_000_000, keep_one_in=600, planted=False), 300)):
+        wc2, _ = oracle.compare_all_pairs(*oracle.make_csr(sk2), nthreads=8)
+        h2, off2 = smd.pack_csr(sk2)
+        idx2 = smd.BitIndex.build(h2, off2, threshold=thr or None)
+        assert idx2 is not None
+        c2, _ = smd.compare_rows(h2, off2, index=idx2)
+        torch.cuda.synchronize()
+        assert np.array_equal(c2.cpu().numpy().view(np.uint32), wc2)
+        if thr:
+            assert idx2.universe > 512 * 1024                     # more distinct hashes than the tables hold: the fallback ran
+
+
+@pytest.mark.parametrize("builder", ["dict", "sort"])
+def test_compare_index_builders_agree(builder):
+    import os, subprocess, sys
+    from conftest import ROOT
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import test_gpu_compare as t\nt._index_builder_cases()\nprint('ok')\n" % (ROOT, os.path.join(ROOT, "tests")))
+    env = dict(os.environ)
+    if builder == "sort":
+        env["SMG_COMPARE_INDEX"] = "sort"
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=env)
+    assert p.returncode == 0 and p.stdout.strip().endswith("ok"), (p.stdout[-1500:], p.stderr[-3000:])
