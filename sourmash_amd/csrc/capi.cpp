@@ -859,8 +859,12 @@ struct BitIndex {
 // measured rates behind the cost model (1 x MI355X)
 constexpr double RATE_MERGE_STEPS = 3.0e12;   // merge-step equivalents / s of compare_hash_kernel: 4.3e12 at C4 (431e6 pairs/s x 1e4 steps),
                                               // 3.0e12 at C3 where 1,000 sketches do not fill the chip -- the smaller one decides small problems
-constexpr double RATE_BIT_WORDS = 7.5e12;     // 32-bit AND+popcount / s (bitmatrix_kernel at C4)
-constexpr double RATE_PAIR_ATOMICS = 4.0e9;   // matrix increments / s (rare_pairs_kernel; two per pair)
+constexpr double RATE_BIT_WORDS = 7.5e12;     // 32-bit AND+popcount / s (bitmatrix_kernel at C4: the VALU roof)
+constexpr double RATE_PAIR_ATOMICS = 4.0e9;   // matrix increments / s (rare_pairs_kernel)
+// the all-pairs callers compute the triangle and mirror it: a pair costs ONE visit of its tile / ONE increment, like the
+// n * total / 2 ... steps the merge rate is calibrated on.  (A bit column costs n^2/2 pairs x 1/32 word, a rare hash held by
+// m sketches m^2/2 increments: they meet at m = n * sqrt(RATE_PAIR_ATOMICS / (32 * 2 * RATE_BIT_WORDS)), the threshold below.)
+constexpr double TRIANGLE = 0.5;
 
 // Build the cheapest exact index for the collection, or return nullptr (no error) when the merge kernel is.
 static BitIndex* bitindex_build(const uint64_t* d_hashes, const uint64_t* d_offsets, uint32_t n, hipStream_t st,
@@ -886,17 +890,18 @@ static BitIndex* bitindex_build(const uint64_t* d_hashes, const uint64_t* d_offs
     if (!sort_only && !(one_shot && !forced_threshold && t_merge < 0.1e-3 + (double)total / 4.0e10)) {
         std::unique_ptr<BitIndex> bi(new BitIndex());
         bi->n = n; bi->total = total; bi->stream = st;
-        AsyncBuf scratch(dict_scratch_bytes(n), st), scal(64, st);
-        hip_check(hipMemsetAsync(scal.p, 0, 64, st), "memset");
-        hip_check(dict_count_launch(d_hashes, d_offsets, n, threshold, scratch.p, scal.as<unsigned long long>(), st), "dictionary pass 1");
+        AsyncBuf scratch(dict_scratch_bytes(n), st);
+        unsigned long long* d_out = reinterpret_cast<unsigned long long*>(scratch.as<char>() + 64);   // inside the zeroed header
+        hip_check(hipMemsetAsync(scratch.p, 0, 256, st), "memset");
+        hip_check(dict_count_launch(d_hashes, d_offsets, n, threshold, scratch.p, d_out, st), "dictionary pass 1");
         unsigned long long out[5] = {0, 0, 0, 0, 0};
-        hip_check(hipMemcpyAsync(out, scal.p, sizeof(out), hipMemcpyDeviceToHost, st), "D2H");
+        hip_check(hipMemcpyAsync(out, d_out, sizeof(out), hipMemcpyDeviceToHost, st), "D2H");
         hip_check(hipStreamSynchronize(st), "sync");
         if (out[4] == 0) {
             const uint64_t U = out[0], n_freq = out[1], rare_pairs = out[2], rare_elems = out[3];
             bi->universe = U;
             const uint32_t words = n_freq ? (uint32_t)(((n_freq + 31) / 32 + 31) / 32 * 32) : 0;     // whole 32-word k-steps
-            const double t_index = pairs * (double)words / RATE_BIT_WORDS + 2.0 * (double)rare_pairs / RATE_PAIR_ATOMICS +
+            const double t_index = TRIANGLE * (pairs * (double)words / RATE_BIT_WORDS + 2.0 * (double)rare_pairs / RATE_PAIR_ATOMICS) +
                                    (double)total / 2.0e10;
             if ((t_index > t_merge && !forced_threshold) || (double)n * words * 4.0 > 8.0 * (1ull << 30)) return nullptr;
             bi->frequent = n_freq; bi->rare_pairs = rare_pairs; bi->threshold = threshold; bi->words_per_row = words;
@@ -940,7 +945,7 @@ static BitIndex* bitindex_build(const uint64_t* d_hashes, const uint64_t* d_offs
     bi->universe = U;
     bi->inv_total = total;
     const uint32_t words = n_freq ? (uint32_t)(((n_freq + 31) / 32 + 31) / 32 * 32) : 0;     // whole 32-word k-steps
-    const double t_index = pairs * (double)words / RATE_BIT_WORDS + 2.0 * (double)rare_pairs / RATE_PAIR_ATOMICS +
+    const double t_index = TRIANGLE * (pairs * (double)words / RATE_BIT_WORDS + 2.0 * (double)rare_pairs / RATE_PAIR_ATOMICS) +
                            (double)total / 2.0e10;                                         // + one pass over the elements
     if ((t_index > t_merge && !forced_threshold) || (double)n * words * 4.0 > 8.0 * (1ull << 30))
         return nullptr;                                             // merge kernel wins / bitmap cap (~BitIndex frees)

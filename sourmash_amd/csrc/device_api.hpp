@@ -70,8 +70,9 @@ hipError_t bitmatrix_launch(const uint32_t* d_bits, uint32_t words_per_row, uint
 constexpr int DICT_BUCKETS = 512;          // hash-space buckets, one workgroup each
 constexpr int DICT_MAX_DISTINCT = 1024;    // distinct hashes a bucket can hold; fuller collections use the sort below
 size_t dict_scratch_bytes(uint32_t n);
-// slice bounds, pass 1 (distinct hashes + holders per bucket, classified against `threshold`), scan.  d_out (5 values, zeroed
-// by the caller): distinct hashes, frequent ones, rare pair increments, rare elements, buckets that overflowed
+// slice bounds, pass 1 (distinct hashes + holders per bucket, classified against `threshold`), scan.  The caller zeroes the
+// first 256 bytes of d_scratch (the builder's parameters live there; d_out may point at byte 64 of it).  d_out (5 values,
+// zero on entry): distinct hashes, frequent ones, rare pair increments, rare elements, buckets that overflowed
 hipError_t dict_count_launch(const uint64_t* d_hashes, const uint64_t* d_offsets, uint32_t n, uint32_t threshold, void* d_scratch,
                              unsigned long long* d_out, hipStream_t stream);
 // pass 2: bit rows (zeroed by the caller) and the rows of every rare hash (d_rare_end[p] = end of p's run)

@@ -38,6 +38,7 @@ constexpr int DX_MAXD = DICT_MAX_DISTINCT;        // distinct hashes per bucket 
 constexpr int DX_THREADS = 1024;                  // 16 waves per bucket: the passes are chains of dependent loads, waves are what overlaps them
 constexpr int DX_WAVES = DX_THREADS / 64;
 constexpr int DX_EPW = 16;                        // rows a wave flattens per step
+constexpr int DX_BSEG = 8;                        // segments a row is cut into for the bounds pass
 constexpr int DX_CHUNK = DX_WAVES * DX_EPW;       // rows per pass-2 chunk
 constexpr int DX_TILE_W = DX_MAXD / 32 + 2;       // words a bucket's bit columns can span
 constexpr uint64_t DX_EMPTY = ~0ull;
@@ -93,31 +94,38 @@ __global__ __launch_bounds__(256) void dx_bounds_kernel(const uint64_t* __restri
     const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
     const int lane = threadIdx.x & 63;
-    for (uint64_t r = wave; r < n; r += n_waves) {
+    // a wave takes one of DX_BSEG segments of a row: the walk is a chain of dependent rounds, and a thousand rows of 5,000
+    // hashes (C3) would otherwise be a thousand waves running 20 rounds each
+    for (uint64_t item = wave; item < (uint64_t)n * DX_BSEG; item += n_waves) {
+        const uint64_t r = item / DX_BSEG;
+        const uint32_t seg = (uint32_t)(item % DX_BSEG);
         const uint64_t lo = offsets[r];
         const uint32_t len = (uint32_t)(offsets[r + 1] - lo);
         uint32_t* out = bounds + r * (uint64_t)(DX_P + 1);
-        for (uint32_t i0 = 0; i0 < len; i0 += 256) {                 // four steps of loads in flight
+        const uint32_t s_lo = (uint32_t)((uint64_t)len * seg / DX_BSEG), s_hi = (uint32_t)((uint64_t)len * (seg + 1) / DX_BSEG);
+        for (uint32_t i0 = s_lo; i0 < s_hi; i0 += 256) {             // four steps of loads in flight
             uint64_t x[4], px[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const uint32_t i = i0 + 64u * (uint32_t)u + (uint32_t)lane;
-                const uint32_t ii = i < len ? i : len - 1;
+                const uint32_t ii = i < s_hi ? i : s_hi - 1;
                 x[u] = hashes[lo + ii];
                 px[u] = hashes[lo + (ii ? ii - 1 : 0)];
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const uint32_t i = i0 + 64u * (uint32_t)u + (uint32_t)lane;
-                if (i < len) {
+                if (i < s_hi) {
                     const uint32_t b = dx_bucket(x[u], shift);
                     const uint32_t first = i == 0 ? 0u : dx_bucket(px[u], shift) + 1u;
                     for (uint32_t bb = first; bb <= b; ++bb) out[bb] = i;
                 }
             }
         }
-        const uint32_t after = len ? dx_bucket(hashes[lo + len - 1], shift) + 1u : 0u;
-        for (uint32_t bb = after + (uint32_t)lane; bb <= (uint32_t)DX_P; bb += 64) out[bb] = len;
+        if (seg == DX_BSEG - 1) {
+            const uint32_t after = len ? dx_bucket(hashes[lo + len - 1], shift) + 1u : 0u;
+            for (uint32_t bb = after + (uint32_t)lane; bb <= (uint32_t)DX_P; bb += 64) out[bb] = len;
+        }
     }
 }
 
@@ -273,7 +281,7 @@ __global__ __launch_bounds__(DX_P) void dx_scan_kernel(const uint32_t* __restric
 constexpr int DX_ETHREADS = 512;
 constexpr int DX_EWAVES = DX_ETHREADS / 64;
 constexpr int DX_EROWS = DX_EWAVES * DX_EPW;      // 128 rows per workgroup
-constexpr int DX_BR = 32;                         // buckets per range
+constexpr int DX_BR = 32;                         // buckets per range, at most (a power of two; fewer for small collections: see dict_emit_launch)
 static_assert(DX_P % DX_BR == 0 && DX_ETHREADS == 4 * DX_EROWS, "");
 
 __global__ __launch_bounds__(DX_ETHREADS) void dx_emit_kernel(const uint64_t* __restrict__ hashes, const uint64_t* __restrict__ offsets,
@@ -282,7 +290,8 @@ __global__ __launch_bounds__(DX_ETHREADS) void dx_emit_kernel(const uint64_t* __
                                                              const uint32_t* __restrict__ dict_cnt, uint32_t* __restrict__ dict_cur,
                                                              const uint32_t* __restrict__ stats, const uint32_t* __restrict__ bases,
                                                              uint32_t* __restrict__ bits, uint32_t words_per_row,
-                                                             uint32_t* __restrict__ rare_rows, uint32_t* __restrict__ rare_end) {
+                                                             uint32_t* __restrict__ rare_rows, uint32_t* __restrict__ rare_end,
+                                                             uint32_t br) {
     __shared__ unsigned long long s_key[DX_CAP];
     __shared__ uint32_t s_val[DX_CAP], s_end[DX_CAP], s_ent[DX_CAP];
     __shared__ uint32_t s_tile[DX_EROWS][DX_TILE_W];
@@ -290,13 +299,13 @@ __global__ __launch_bounds__(DX_ETHREADS) void dx_emit_kernel(const uint64_t* __
     __shared__ uint32_t s_ones_val, s_ones_end, s_ones_ent;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const uint64_t chunk0 = (uint64_t)blockIdx.x * DX_EROWS;
-    const uint32_t b_lo = blockIdx.y * DX_BR;
+    const uint32_t b_lo = blockIdx.y * br;
     const uint32_t frr = (uint32_t)tid >> 2, fw = (uint32_t)tid & 3u;     // flush assignment: row of the chunk, word lane
     const uint64_t frow = chunk0 + frr;
     uint32_t carry_idx = 0xffffffffu;                                     // word the carry belongs to (uniform); none yet
     bool first_word_pending = true;                                       // the range's first word has not been stored yet
     int cb = 0;                                                           // carry buffer in use
-    for (uint32_t b = b_lo; b < b_lo + DX_BR; ++b) {
+    for (uint32_t b = b_lo; b < b_lo + br; ++b) {
         const uint32_t nd = stats[b * 4 + 0], nf = stats[b * 4 + 1];
         if (nd == 0) continue;                                            // uniform
         const uint32_t fbase = bases[b * 2 + 0], rbase = bases[b * 2 + 1];
@@ -424,10 +433,9 @@ hipError_t dict_count_launch(const uint64_t* d_hashes, const uint64_t* d_offsets
                              unsigned long long* d_out, hipStream_t stream) {
     if (n == 0) return hipErrorInvalidValue;
     const DxLayout l = dx_layout(d_scratch, n);
-    hipError_t e = hipMemsetAsync(l.prm, 0, sizeof(DxParams), stream);
-    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(dx_max_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, d_hashes, d_offsets, n, l.prm);
-    const unsigned rows_grid = (unsigned)(((uint64_t)n + 3) / 4 < 16384 ? ((uint64_t)n + 3) / 4 : 16384);
+    const uint64_t seg_blocks = ((uint64_t)n * DX_BSEG + 3) / 4;
+    const unsigned rows_grid = (unsigned)(seg_blocks < 32768 ? seg_blocks : 32768);
     hipLaunchKernelGGL(dx_bounds_kernel, dim3(rows_grid), dim3(256), 0, stream, d_hashes, d_offsets, n, (const DxParams*)l.prm, l.bounds);
     hipLaunchKernelGGL(dx_count_kernel, dim3(DX_P), dim3(DX_THREADS), 0, stream, d_hashes, d_offsets, n, (const DxParams*)l.prm,
                        (const uint32_t*)l.bounds, threshold, l.key, l.val, l.cnt, l.stats, d_out);
@@ -440,11 +448,18 @@ hipError_t dict_count_launch(const uint64_t* d_hashes, const uint64_t* d_offsets
 hipError_t dict_emit_launch(const uint64_t* d_hashes, const uint64_t* d_offsets, uint32_t n, void* d_scratch, uint32_t* d_bits,
                             uint32_t words_per_row, uint32_t* d_rare_rows, uint32_t* d_rare_end, hipStream_t stream) {
     const DxLayout l = dx_layout(d_scratch, n);
-    hipError_t e = hipMemsetAsync(l.cur, 0, (size_t)DX_P * (DX_MAXD + 1) * 4, stream);       // the rare lists' cursors
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(dx_emit_kernel, dim3((n + DX_EROWS - 1) / DX_EROWS, DX_P / DX_BR), dim3(DX_ETHREADS), 0, stream, d_hashes,
+    if (d_rare_rows) {                                                                        // the rare lists' cursors
+        const hipError_t e = hipMemsetAsync(l.cur, 0, (size_t)DX_P * (DX_MAXD + 1) * 4, stream);
+        if (e != hipSuccess) return e;
+    }
+    // a workgroup visits the buckets of its range one after the other (~7 us each): few row chunks -> shorter ranges, so that
+    // there are at least ~512 workgroups (two per CU) and the chain a workgroup runs stays short
+    const uint32_t n_chunks = (n + DX_EROWS - 1) / DX_EROWS;
+    uint32_t br = DX_BR;
+    while (br > 1 && (uint64_t)n_chunks * (DX_P / br) < 512) br >>= 1;
+    hipLaunchKernelGGL(dx_emit_kernel, dim3(n_chunks, DX_P / br), dim3(DX_ETHREADS), 0, stream, d_hashes,
                        d_offsets, n, (const uint32_t*)l.bounds, (const uint64_t*)l.key, (const uint32_t*)l.val, (const uint32_t*)l.cnt,
-                       l.cur, (const uint32_t*)l.stats, (const uint32_t*)l.bases, d_bits, words_per_row, d_rare_rows, d_rare_end);
+                       l.cur, (const uint32_t*)l.stats, (const uint32_t*)l.bases, d_bits, words_per_row, d_rare_rows, d_rare_end, br);
     return hipGetLastError();
 }
 
