@@ -187,10 +187,13 @@ __global__ __launch_bounds__(DX_THREADS) void dx_count_kernel(const uint64_t* __
     for (int k = tid; k < DX_CAP; k += DX_THREADS) { s_key[k] = DX_EMPTY; s_cnt[k] = 0; }
     if (tid == 0) { s_n = 0; s_ones = 0; s_over = 0; s_out = 0; s_nf = 0; s_rare = 0; }
     __syncthreads();
+    volatile uint32_t* over = &s_over;
     for (uint64_t row0 = (uint64_t)wave * DX_EPW; row0 < n; row0 += DX_CHUNK) {
+        if (*over) break;                                           // the bucket does not fit: stop at once, the sort takes over
         DxGroup g;
         dx_group_load(g, offsets, bounds, n, b, row0, lane);
         for (uint32_t t0 = 0; t0 < g.total; t0 += 64) {             // wave-uniform trip count (the shuffles read lanes 0 .. 15)
+            if (*over) break;                                       // (one LDS word read by all lanes: uniform)
             const uint32_t t = t0 + (uint32_t)lane;
             int h;
             const uint64_t at = dx_group_at(g, t < g.total ? t : g.total - 1, h);
@@ -199,7 +202,7 @@ __global__ __launch_bounds__(DX_THREADS) void dx_count_kernel(const uint64_t* __
             if (x == DX_EMPTY) { atomicAdd(&s_ones, 1u); continue; }   // the table's empty marker is a legal hash: counted apart
             uint32_t slot = dx_slot(x);
             bool placed = false;
-            for (int probe = 0; probe < DX_CAP; ++probe) {
+            for (int probe = 0; probe < 256; ++probe) {             // (a table this crowded has overflowed anyway)
                 const unsigned long long k = s_key[slot];
                 if (k == x) { placed = true; break; }
                 if (k == DX_EMPTY) {

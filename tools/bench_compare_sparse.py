@@ -12,7 +12,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from sourmash_amd import device as smd  # noqa: E402
-from bench_gather import splitmix63, MAX_HASH_1000  # noqa: E402
+from sourmash_amd.synth import splitmix63, MAX_HASH_1000  # noqa: E402
 
 
 def main():
