@@ -285,8 +285,9 @@ void smgpu_compare_blocks_raw(const uint64_t *d_hashes, const uint64_t *d_offset
 void smgpu_symmetrize_raw(uint32_t *d_common, uint32_t n, void *stream);
 void smgpu_jaccard_raw(const uint32_t *d_common, const uint64_t *d_offsets, uint32_t n, uint32_t row_lo,
                        uint32_t row_hi, double *d_jaccard, void *stream);
-/* Indexed paths of the same comparison.  smgpu_bitindex_new sorts every (hash, row) of the collection by hash
- * (synchronises the stream) and splits the hashes by how many sketches hold them: frequent ones become bit columns
+/* Indexed paths of the same comparison.  smgpu_bitindex_new groups every (hash, row) of the collection by hash (hash-space
+ * buckets with LDS tables, csrc/dictindex.hip; a radix sort when a bucket holds more than 1,024 distinct hashes;
+ * synchronises the stream once) and splits the hashes by how many sketches hold them: frequent ones become bit columns
  * (|A ∩ B| = popcount(A & B) over bit rows), rare ones inverted lists whose pairs are incremented directly.  A
  * collection drawn from one pool ends up all bit rows, a collection of unrelated genomes all inverted lists.
  * Returns NULL -- with no error set -- when the cost model prefers the merge kernel (smgpu_compare_*_raw).
