@@ -497,6 +497,30 @@ def _index_builder_cases():
         assert np.array_equal(c2.cpu().numpy().view(np.uint32), wc2)
         if thr:
             assert idx2.universe > 512 * 1024                     # more distinct hashes than the tables hold: the fallback ran
+    # corners of the bucketing: hashes below the number of buckets, one sketch, two identical sketches, only empty sketches,
+    # one crowded bucket (2,000 hashes that differ in their low bits only) next to a spread-out rest
+    crowded = np.uint64(1) << np.uint64(40)
+    corner_sets = [
+        [np.arange(0, 300, 3, dtype=np.uint64), np.arange(0, 300, 2, dtype=np.uint64), np.array([7], dtype=np.uint64)],
+        [np.unique(rng.integers(0, 2**62, 500, dtype=np.int64).astype(np.uint64))],
+        [np.arange(10, 4000, 7, dtype=np.uint64) * np.uint64(2**40)] * 2,
+        [np.array([], dtype=np.uint64)] * 3,
+        [np.concatenate([crowded + np.arange(2000, dtype=np.uint64), np.uint64(2**50) + np.arange(5, dtype=np.uint64) * np.uint64(2**45)]),
+         np.concatenate([crowded + np.arange(0, 2000, 2, dtype=np.uint64), np.array([2**55], dtype=np.uint64)])] * 3,
+    ]
+    for sk3 in corner_sets:
+        sk3 = [np.unique(r) for r in sk3]
+        wc3, wj3 = oracle.compare_all_pairs(*oracle.make_csr(sk3), nthreads=2)
+        h3, off3 = smd.pack_csr(sk3)
+        for threshold in (1, 2, 1000):
+            idx3 = smd.BitIndex.build(h3, off3, threshold=threshold)
+            if idx3 is None:                                      # nothing to index (no hashes at all)
+                assert sum(len(r) for r in sk3) == 0
+                continue
+            c3, j3 = smd.compare_rows(h3, off3, index=idx3)
+            torch.cuda.synchronize()
+            assert np.array_equal(c3.cpu().numpy().view(np.uint32), wc3), (len(sk3), threshold)
+            assert np.array_equal(j3.cpu().numpy().view(np.uint64), wj3.view(np.uint64)), (len(sk3), threshold)
 
 
 @pytest.mark.parametrize("builder", ["dict", "sort"])
