@@ -180,9 +180,10 @@ def main():
                               # kernel's mix is 2.4 cycles for and/or/xor/add/shift, 4.3 for multiplies, v_add3, permutes, selects)
                               "valu_insts_per_simd_cycle": round(PMC_C2_VALU_INSTS / N_SIMDS / (PMC_C2_GUI_ACTIVE / 8), 4),
                               "cycles_per_valu_inst_per_simd": round(N_SIMDS * (PMC_C2_GUI_ACTIVE / 8) / PMC_C2_VALU_INSTS, 2),
-                              # a SIMD issues a 64-wide vector instruction every 4 cycles at best (0.25 per cycle: what
-                              # bitmatrix_kernel, pure v_and + v_bcnt, reaches in profiles/r02_compare_pmc.txt)
-                              "valu_issue_slots_used_frac": round(PMC_C2_VALU_INSTS / N_SIMDS / (PMC_C2_GUI_ACTIVE / 8) / 0.25, 3),
+                              # the kernel's static mix (71 % multiplies / v_add3 / permutes / selects at 4.3 cycles, the rest at
+                              # 2.4: profiles/r01_ubench_valu.txt) averages 3.76 cycles per instruction: issue-busy fraction
+                              "mix_cycles_per_valu_inst": 3.76,
+                              "valu_issue_busy_frac": round(3.76 * PMC_C2_VALU_INSTS / N_SIMDS / (PMC_C2_GUI_ACTIVE / 8), 3),
                               "wave_cycles_issuing_frac": round(PMC_C2_ACTIVE_INST_ANY / PMC_C2_WAVE_CYCLES, 3),
                               "wave_cycles_waiting_to_issue_frac": round(PMC_C2_WAIT_INST_ANY / PMC_C2_WAVE_CYCLES, 3),
                               "quoted_from": PMC_FILE + " (SQ_INSTS_VALU, SQ_WAVE_CYCLES, SQ_WAIT_INST_ANY, SQ_ACTIVE_INST_ANY, "
