@@ -471,8 +471,9 @@ def single_gpu_extras(extra, torch, np, dev, be, smd, synth_sketches, synth_gath
         "auto_ms": round(auto_big, 2), "auto_pairs_per_s": round(bpairs / (auto_big * 1e-3), 1),
         "identical": bool((ca == bc).all().item() and (ja == bj).all().item()),
         "note": "config C4 (pool-drawn sketches: the cost model picks bit columns); auto includes the index build; "
-                "bitmatrix_kernel is VALU-bound: 2.55 instructions per 32-bit AND+popcount against a floor of 2, every "
-                "SIMD issue slot used (profiles/r02_compare_pmc.txt), upper triangle + mirror"}
+                "bitmatrix_kernel is VALU-bound: 2.55 instructions per 32-bit AND+popcount against a floor of 2, ~87 % "
+                "issue-busy at the measured instruction costs (profiles/r02_compare_pmc.txt), upper triangle + mirror; the "
+                "index is built without a sort (csrc/dictindex.hip)"}
     del bc, bj, ca, ja, bh, boff
     torch.cuda.empty_cache()
     gq5, gh5, goff5 = synth_gather_device(1_000_000, 100_000, 5000, dev)
