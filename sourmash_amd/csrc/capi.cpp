@@ -887,7 +887,8 @@ static BitIndex* bitindex_build(const uint64_t* d_hashes, const uint64_t* d_offs
     // overflows sends the build to the sort below.  SMG_COMPARE_INDEX=sort skips it (tests run both).
     static const bool sort_only = [] { const char* e = getenv("SMG_COMPARE_INDEX"); return e && !strcmp(e, "sort"); }();
     // an index that serves ONE compare must also pay for its own build (~0.1 ms of launches + three passes over the elements)
-    if (!sort_only && !(one_shot && !forced_threshold && t_merge < 0.1e-3 + (double)total / 4.0e10)) {
+    // (its slice bounds take 2 KB per sketch: past two million sketches the sort's scratch is the smaller one)
+    if (!sort_only && n <= (2u << 20) && !(one_shot && !forced_threshold && t_merge < 0.1e-3 + (double)total / 4.0e10)) {
         std::unique_ptr<BitIndex> bi(new BitIndex());
         bi->n = n; bi->total = total; bi->stream = st;
         AsyncBuf scratch(dict_scratch_bytes(n), st);

@@ -876,9 +876,12 @@ __global__ __launch_bounds__(256) void apply_kernel(QIndex qi, uint8_t* alive, c
     for (uint64_t base = wave * APPLY_EPW; base < len; base += n_waves * APPLY_EPW) {
         const uint64_t i = base + lane;
         uint32_t j = NONE32;
+        uint64_t list_lo = 0, list_hi = 0;                         // posting list of the hash: asked for together with its alive byte
         if (lane < APPLY_EPW && i < len) {
             j = row_pos ? row_pos[i] : q_find(qi, row[i]);
             if (j != NONE32) {
+                list_lo = post_off[j];
+                list_hi = post_off[j + 1];
                 // only hashes still uncovered count: they leave the set here, and counters[d] stays |row_d ∩ uncovered|
                 // whatever the caller hands to consume (the same intersect twice, hashes it never peeked)
                 if (alive[j]) alive[j] = 0;                    // row hashes are distinct: no two lanes share j
@@ -902,8 +905,8 @@ __global__ __launch_bounds__(256) void apply_kernel(QIndex qi, uint8_t* alive, c
         uint64_t lo = 0;
         uint32_t n = 0;
         if (j != NONE32) {
-            lo = post_off[j];
-            n = (uint32_t)(post_off[j + 1] - lo);
+            lo = list_lo;
+            n = (uint32_t)(list_hi - list_lo);
         }
         uint32_t incl = n;
 #pragma unroll
