@@ -46,6 +46,13 @@ __global__ __launch_bounds__(256) void bitmap_build_kernel(const uint64_t* __res
     }
 }
 
+// popcount(x) + acc in one instruction
+__device__ __forceinline__ uint32_t popc_acc(uint32_t x, uint32_t acc) {
+    uint32_t r;
+    asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(acc));
+    return r;
+}
+
 // common[local row][col] = popcount(bits[row] & bits[col]) for a 64 x 64 tile; lane (tr, tc) owns the
 // 4 x 4 pairs (tr + 16 i, tc + 16 j).  Rows of the launch are the 16-row tiles rb_first,
 // rb_first + rb_stride, ... (same dealing as compare.hip); four of them form one 64-row group.
@@ -101,8 +108,16 @@ __global__ __launch_bounds__(256) void bitmatrix_kernel(const uint32_t* __restri
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    acc[i][j] += __popc(a[i].x & b[j].x) + __popc(a[i].y & b[j].y) + __popc(a[i].z & b[j].z) +
-                                 __popc(a[i].w & b[j].w);
+                    // one v_and + one v_bcnt per word, the v_bcnt taking the running sum as its second operand.  Spelled as
+                    // an instruction: from `acc += popc(..) + popc(..) + ..` hipcc makes v_bcnt x, 0 plus a v_add3 per two
+                    // words -- 2.55 instructions per word instead of 2.05, and v_add3 is a half-rate instruction like v_bcnt
+                    // (profiles/r02_compare_pmc.txt, r01_ubench_valu.txt)
+                    uint32_t s = acc[i][j];
+                    s = popc_acc(a[i].x & b[j].x, s);
+                    s = popc_acc(a[i].y & b[j].y, s);
+                    s = popc_acc(a[i].z & b[j].z, s);
+                    s = popc_acc(a[i].w & b[j].w, s);
+                    acc[i][j] = s;
                 }
         }
     }

@@ -859,7 +859,7 @@ struct BitIndex {
 // measured rates behind the cost model (1 x MI355X)
 constexpr double RATE_MERGE_STEPS = 3.0e12;   // merge-step equivalents / s of compare_hash_kernel: 4.3e12 at C4 (431e6 pairs/s x 1e4 steps),
                                               // 3.0e12 at C3 where 1,000 sketches do not fill the chip -- the smaller one decides small problems
-constexpr double RATE_BIT_WORDS = 7.5e12;     // 32-bit AND+popcount / s (bitmatrix_kernel at C4: the VALU roof)
+constexpr double RATE_BIT_WORDS = 9.5e12;     // 32-bit AND+popcount / s (bitmatrix_kernel at C4: the VALU roof)
 constexpr double RATE_PAIR_ATOMICS = 4.0e9;   // matrix increments / s (rare_pairs_kernel)
 // the all-pairs callers compute the triangle and mirror it: a pair costs ONE visit of its tile / ONE increment, like the
 // n * total / 2 ... steps the merge rate is calibrated on.  (A bit column costs n^2/2 pairs x 1/32 word, a rare hash held by
