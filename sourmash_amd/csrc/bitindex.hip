@@ -81,22 +81,46 @@ __global__ __launch_bounds__(256) void bitmatrix_kernel(const uint32_t* __restri
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = 0;
 
-    // staging assignment: 64 rows x 8 chunks of 4 words = 512 chunks per operand, 2 per thread
+    // staging assignment: 64 rows x 8 chunks of 4 words = 512 chunks per operand, 2 per thread.  The words of step k0 + BKC
+    // are fetched into registers while step k0 is being computed from LDS, so the trip to L2 / HBM overlaps the popcounts
+    // instead of sitting between two barriers.
+    const uint32_t* srcA[2];
+    const uint32_t* srcB[2];
+    uint32_t dstS[2];
+    uint32_t mA[2], mB[2];                                           // all ones, or zero for a row past the end
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int chunk = tid + q * 256;
+        const int row = chunk >> 3, kc = (chunk & 7) * 4;
+        const uint32_t gr = global_row((uint32_t)row);
+        const uint32_t gc = col0 + (uint32_t)row;
+        mA[q] = gr < n ? 0xffffffffu : 0u;                              // rows past the end read row 0 and are masked out
+        mB[q] = gc < n ? 0xffffffffu : 0u;
+        srcA[q] = bits + (uint64_t)(gr < n ? gr : 0u) * words_per_row + kc;
+        srcB[q] = bits + (uint64_t)(gc < n ? gc : 0u) * words_per_row + kc;
+        dstS[q] = (uint32_t)(row * BSTRIDE + kc);
+    }
+    uint4 ra[2], rb[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        ra[q] = *reinterpret_cast<const uint4*>(srcA[q]);
+        rb[q] = *reinterpret_cast<const uint4*>(srcB[q]);
+    }
     for (uint32_t k0 = 0; k0 < words_per_row; k0 += BKC) {
-        __syncthreads();
+        __syncthreads();                                                // the previous step's readers are done
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            const int chunk = tid + q * 256;
-            const int row = chunk >> 3, kc = (chunk & 7) * 4;
-            const uint32_t gr = global_row((uint32_t)row);
-            uint4 va = make_uint4(0, 0, 0, 0), vb = make_uint4(0, 0, 0, 0);
-            if (gr < n) va = *reinterpret_cast<const uint4*>(bits + (uint64_t)gr * words_per_row + k0 + kc);
-            const uint32_t gc = col0 + (uint32_t)row;
-            if (gc < n) vb = *reinterpret_cast<const uint4*>(bits + (uint64_t)gc * words_per_row + k0 + kc);
-            *reinterpret_cast<uint4*>(&sA[row * BSTRIDE + kc]) = va;
-            *reinterpret_cast<uint4*>(&sB[row * BSTRIDE + kc]) = vb;
+            *reinterpret_cast<uint4*>(&sA[dstS[q]]) = make_uint4(ra[q].x & mA[q], ra[q].y & mA[q], ra[q].z & mA[q], ra[q].w & mA[q]);
+            *reinterpret_cast<uint4*>(&sB[dstS[q]]) = make_uint4(rb[q].x & mB[q], rb[q].y & mB[q], rb[q].z & mB[q], rb[q].w & mB[q]);
         }
         __syncthreads();
+        if (k0 + BKC < words_per_row) {                                 // next step's words: in flight during the compute below
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                ra[q] = *reinterpret_cast<const uint4*>(srcA[q] + k0 + BKC);
+                rb[q] = *reinterpret_cast<const uint4*>(srcB[q] + k0 + BKC);
+            }
+        }
 #pragma unroll
         for (int k4 = 0; k4 < BKC; k4 += 4) {
             uint4 a[4], b[4];
