@@ -529,7 +529,9 @@ static hipError_t compare_launch(const uint64_t* d_hashes, const uint64_t* d_off
     const uint32_t ctc = walk ? CT : HC;                              // columns per tile
     const uint32_t n_col_tiles = (n + ctc - 1) / ctc;
     const size_t tiles = (size_t)n_row_tiles * n_col_tiles;
-    hipError_t e = hipMemsetAsync(d_common, 0, (size_t)n_row_tiles * CT * n * sizeof(uint32_t), stream);
+    // the sharded form owns whole 16-row tiles ([n_row_tiles * 16][n]); the others own exactly rows [row_lo, row_hi)
+    const size_t out_rows = symmetric == 2 ? (size_t)n_row_tiles * CT : (size_t)(row_hi - row_lo);
+    hipError_t e = hipMemsetAsync(d_common, 0, out_rows * n * sizeof(uint32_t), stream);
     if (e != hipSuccess) return e;
     void* ws = nullptr;
     e = hipMallocAsync(&ws, compare_workspace_bytes(n_row_tiles, n_col_tiles), stream);   // stream-ordered scratch

@@ -534,3 +534,47 @@ def test_compare_index_builders_agree(builder):
         env["SMG_COMPARE_INDEX"] = "sort"
     p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=env)
     assert p.returncode == 0 and p.stdout.strip().endswith("ok"), (p.stdout[-1500:], p.stderr[-3000:])
+
+
+def test_compare_index_random_collections(sm):
+    """Random shapes through every compare path -- general kernel, indexed path with the threshold the cost model picks and
+    with forced ones (the sort-free builder's row chunks of 128, bucket ranges, carried words, rare lists), whole matrix
+    (triangle + mirror) and a row block (all columns) -- against the oracle, bit for bit."""
+    import torch
+    from sourmash_amd import device as smd
+    rng = np.random.default_rng(2024)
+    for case in range(24):
+        n = int(rng.choice([1, 2, 3, 15, 16, 17, 63, 127, 128, 129, 200, 300, 400]))
+        top_bits = int(rng.choice([9, 20, 40, 54, 63, 64]))        # hash range: from fewer values than buckets to all 64 bits
+        pool_size = int(rng.choice([50, 700, 5000, 40_000]))
+        hi = (1 << top_bits) - 1
+        pool = np.unique(rng.integers(0, hi, size=pool_size, dtype=np.uint64, endpoint=True))
+        sk = []
+        for _ in range(n):
+            size = int(rng.integers(0, min(len(pool), 900) + 1))
+            row = rng.choice(pool, size=size, replace=False)
+            if rng.random() < 0.3:                                  # private hashes: rare ones next to the shared pool
+                row = np.concatenate([row, rng.integers(0, hi, size=int(rng.integers(1, 50)), dtype=np.uint64, endpoint=True)])
+            sk.append(np.unique(row.astype(np.uint64)))
+        wc, wj = oracle.compare_all_pairs(*oracle.make_csr(sk), nthreads=4)
+        h, off = smd.pack_csr(sk)
+        c, j = smd.compare_rows(h, off)
+        torch.cuda.synchronize()
+        assert np.array_equal(c.cpu().numpy().view(np.uint32), wc), ("general", case, n)
+        if sum(len(r) for r in sk) == 0:
+            continue
+        for threshold in (None, 1, int(rng.integers(2, 40))):
+            idx = smd.BitIndex.build(h, off, threshold=threshold)
+            if idx is None:                                         # the cost model preferred the general kernel
+                assert threshold is None
+                continue
+            c2, j2 = smd.compare_rows(h, off, index=idx)
+            torch.cuda.synchronize()
+            assert np.array_equal(c2.cpu().numpy().view(np.uint32), wc), ("indexed", case, n, threshold)
+            assert np.array_equal(j2.cpu().numpy().view(np.uint64), wj.view(np.uint64)), ("indexed", case, n, threshold)
+            if n > 16:
+                lo = 16 * int(rng.integers(0, n // 16))
+                hi_row = int(rng.integers(lo + 1, n + 1))
+                cb, _ = smd.compare_rows(h, off, lo, hi_row, index=idx)
+                torch.cuda.synchronize()
+                assert np.array_equal(cb.cpu().numpy().view(np.uint32), wc[lo:hi_row]), ("block", case, n, threshold, lo, hi_row)
