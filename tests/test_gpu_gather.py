@@ -232,3 +232,49 @@ def _overlaps_large_query():
     sub = np.array([oracle.intersection_size(part, d)[0] for d in dbh], dtype=np.int64)
     want[7] = 1
     assert np.array_equal(cnt.cpu().numpy(), np.maximum(want - sub, 0))
+
+
+def test_gather_random_shapes_every_builder(monkeypatch):
+    """Random query / database shapes -- one row, empty rows, rows outside the query, duplicates of the winner, hash ranges
+    from a few hundred values to all 64 bits, queries shorter than one range and a few ranges long -- through both builders
+    of the index with every fill, the native loop and the exchange protocol on one rank, against the oracle's ordered picks
+    and against |Q ∩ row| for the counters and the overlap pass."""
+    import torch
+    from sourmash_amd import device as smd, parallel
+    rng = np.random.default_rng(77)
+    be = parallel.DeviceBackend()
+    for case in range(14):
+        top_bits = int(rng.choice([10, 24, 54, 64]))
+        hi = (1 << top_bits) - 1
+        nq = int(rng.choice([1, 40, 3000, 40_000, 70_000]))
+        ndb = int(rng.choice([1, 2, 17, 300, 900]))
+        qh = np.unique(rng.integers(0, hi, size=nq, dtype=np.uint64, endpoint=True))
+        dbh = []
+        for _ in range(ndb):
+            size = int(rng.integers(0, 700))
+            from_q = rng.choice(qh, size=min(len(qh), int(size * rng.random())), replace=False)
+            own = rng.integers(0, hi, size=size, dtype=np.uint64, endpoint=True)
+            dbh.append(np.unique(np.concatenate([from_q, own]).astype(np.uint64)))
+        if ndb > 5:
+            dbh[1] = dbh[0].copy()                                    # a tie: the lower index wins
+            dbh[2] = np.zeros(0, dtype=np.uint64)
+        h, off = smd.pack_csr(dbh)
+        fh, foff = oracle.make_csr(dbh)
+        q = torch.from_numpy(qh.view(np.int64).copy()).cuda()
+        want_cnt = np.array([oracle.intersection_size(qh, d)[0] for d in dbh], dtype=np.uint64)
+        cnt = be.zeros((ndb,), torch.int64)
+        be.overlaps(q, len(qh), h, off, ndb, cnt, 0)
+        torch.cuda.synchronize()
+        assert np.array_equal(cnt.cpu().numpy().view(np.uint64), want_cnt), ("overlaps", case)
+        thr_bp = int(rng.choice([0, 3000, 60_000]))
+        want = oracle.gather(qh, fh, foff, threshold_bp=thr_bp, scaled=1000)
+        for build, fill in (("atomic", "staged"), ("ranges", "staged"), ("ranges", "streams"), ("ranges", "direct")):
+            monkeypatch.setenv("SMG_GATHER_BUILD", build)
+            monkeypatch.setenv("SMG_GATHER_FILL", fill)
+            st = be.gather_state(q, len(qh), h, off, ndb, 0)
+            assert np.array_equal(st.counters(), want_cnt), ("counters", case, build, fill)
+            del st
+            got = parallel.gather_distributed(q, len(qh), h, off, ndb, 0, thr_bp, 1000, be)
+            assert got == want, ("loop", case, build, fill, thr_bp)
+        got = parallel.gather_distributed(q, len(qh), h, off, ndb, 0, thr_bp, 1000, be, stepwise=True)
+        assert got == want, ("exchange protocol", case, thr_bp)
