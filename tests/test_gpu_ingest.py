@@ -140,3 +140,29 @@ def test_many_files_in_parallel(sm, tmp_path):
     assert sketch_files([]) == []
     with pytest.raises(sm.exceptions.SourmashError):
         sketch_files([fa, "/nonexistent/file.fa"], params)
+
+
+def test_repeated_reads_keep_more_hashes_than_the_statistical_estimate(sm, tmp_path):
+    """The number of kept hashes a chunk produces depends on multiplicity, not on distinct k-mers: a deep amplicon whose one
+    k-mer falls under max_hash keeps a hash per READ.  The ingest path sizes its output for the positions of the chunk, so
+    this is ordinary input (round 1 sized it from slen / scaled and raised 'sketch output overflow': ADVICE.md)."""
+    from sourmash_amd.sketch import sketch_file
+    rng = np.random.default_rng(31)
+    read = None
+    for _ in range(200_000):                                      # a 31-mer that scaled=1000 keeps
+        cand = bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), size=31)).decode()
+        mh = oracle.OracleMinHash(0, 31, scaled=1000)
+        mh.add_sequence(cand.encode(), force=True)
+        if len(mh.mins):
+            read = cand
+            break
+    assert read is not None
+    copies = 60_000                                               # 1.9 MB of sequence: the estimate was ~7,000 kept hashes
+    fq = str(tmp_path / "amplicon.fastq")
+    with open(fq, "w") as fh:
+        fh.write(f"@r\n{read}\n+\n{'I' * 31}\n" * copies)
+    sig, = sketch_file(fq, "k=31,scaled=1000,abund")
+    mh = sig.minhash
+    assert len(mh) == 1 and list(mh.hashes.values()) == [copies]
+    sig, = sketch_file(fq, "k=31,scaled=1000")
+    assert len(sig.minhash) == 1
