@@ -69,6 +69,11 @@ def parse():
 
 def main():
     args = parse()
+    # stdout carries ONE line, the JSON of rank 0: everything else any library writes to file descriptor 1 while the bench runs
+    # (RCCL prints a version banner through C stdio) goes to stderr
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     import torch
     import torch.distributed as dist
     import numpy as np
@@ -254,15 +259,16 @@ def main():
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    # whatever sits in libc's or Python's buffers for descriptor 1 leaves (towards stderr) before stdout comes back
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.flush()
+    os.dup2(real_stdout, 1)
+    os.close(real_stdout)
     if out is not None:
-        # RCCL prints a version banner through C stdio, which sits in libc's buffer until exit when stdout is a file
-        # or a pipe: push it out first so that the JSON is the last line of rank 0's output
-        try:
-            import ctypes
-            ctypes.CDLL(None).fflush(None)
-        except Exception:
-            pass
-        sys.stdout.flush()
         print(json.dumps(out), flush=True)
 
 
