@@ -93,7 +93,10 @@ __global__ __launch_bounds__(256) void build_fill_kernel(const uint32_t* __restr
 #endif
 constexpr int BR_RANGE = SMG_BR_RANGE;      // query positions per range: row slices long enough (~1 KB) to read DRAM efficiently
 constexpr int BR_EPW = 16;           // row slices a wave flattens per step (see apply_kernel)
-constexpr int BR_AHEAD = 4;         // steps of 64 lookups a wave keeps in flight in pass 1 (see build_range_kernel)
+#ifndef SMG_BR_AHEAD
+#define SMG_BR_AHEAD 4
+#endif
+constexpr int BR_AHEAD = SMG_BR_AHEAD;   // steps of 64 lookups a wave keeps in flight in pass 1 (see build_range_kernel)
 constexpr int BR_THREADS = 512;      // 64 KB of LDS per workgroup (u16 slots, two per word): 2 workgroups = 16 waves per CU
 // Two-level fill (the default): a 4-byte store per posting straight into its list leaves 32,768 lists x 8 lines open per
 // range -- far more than one L2 -- and partially filled lines were evicted and fetched back (8.1 GB written and 13.6 GB
