@@ -524,7 +524,10 @@ def single_gpu_extras(extra, torch, np, dev, be, smd, synth_sketches, synth_gath
         "loop_ms": round((t2 - t1) * 1e3, 2), "total_ms": round((t2 - t0) * 1e3, 2),
         "us_per_round": round((t2 - t1) * 1e6 / max(len(res5), 1), 2),
         "index_build_roofline": hbm_roofline(build_alg, (t1 - t0) * 1e3,
-                                             "8 B per database hash + 4 B per posting + 2 x 4 B query position per element; wall clock of smgpu_gather_new_raw"),
+                                             "8 B per database hash + 4 B per posting + 2 x 4 B query position per element; wall clock of smgpu_gather_new_raw",
+                                             traffic=PMC_C5_BUILD_COUNTED if db_bytes == 3997497344 else None,
+                                             traffic_note="as counted (10.3 GB); with pass 1's read of the 4.0 GB database corrected for "
+                                                          "the counter's halving of coalesced reads: ~12.3 GB"),
         "loop_floor_ms": round(postings / 23.0e9 * 1e3, 2),
         "loop_note": "a dependent chain of small kernels (latency, not bandwidth): %d rounds touch %.1f MB of postings in all; "
                      "one 64-bit counter decrement per posting, and the device does 23 G such atomics/s on 100,000 counters "
@@ -535,14 +538,30 @@ def single_gpu_extras(extra, torch, np, dev, be, smd, synth_sketches, synth_gath
     ms_ov = timed(lambda: be.overlaps(gq5, gq5.numel(), gh5, goff5, 100_000, cnt, 0), reps=3)
     extra["overlaps_1M_vs_100000"] = {"ms": round(ms_ov, 3), "sketches_per_s": round(100_000 / (ms_ov * 1e-3), 1),
                                       "roofline": hbm_roofline(db_bytes + 8 * int(gq5.numel()), ms_ov,
-                                                               "8 B per database hash + the query once; stream_lookup_kernel (query slices through LDS, every database hash looked at once)")}
+                                                               "8 B per database hash + the query once; stream_lookup_kernel (query slices through LDS, every database hash looked at once)",
+                                                               traffic=PMC_C5_OVERLAP_COUNTED if db_bytes == 3997497344 else None,
+                                                               traffic_note="as counted (1.8x the database; up to 3.7x if its 8-byte-per-lane "
+                                                                            "reads are halved like pass 1's): lines a row visit stops in "
+                                                                            "are fetched again by the next range's visit (DESIGN.md 4.4)")}
 
 
-def hbm_roofline(alg_bytes, ms, what):
+# FETCH_SIZE + WRITE_SIZE per launch, in bytes, of the C5 kernels (profiles/r02_gather_pmc.txt, separate --pmc passes of
+# tools/bench_gather.py; KiB as counted).  FETCH_SIZE halves coalesced reads on gfx950 (MI355X_MICROARCH.md): pass 1 reads its
+# 4.0 GB of database and is counted with 2.37 GB, so the "corrected" figures add the database once per pass that reads it.
+PMC_C5_BUILD_COUNTED = int((985_497 + 125_005 + 1_269_823 + 511_293 + 2_309_879 + 29_153 + 257_813 + 1_133_146 + 975_447 + 2_456_248) * 1024)
+PMC_C5_OVERLAP_COUNTED = int((7_190_156 + 7_813) * 1024)
+PMC_C5_GATHER_FILE = "profiles/r02_gather_pmc.txt"
+
+
+def hbm_roofline(alg_bytes, ms, what, traffic=None, traffic_note=None):
     achieved = alg_bytes / (ms * 1e-3) / 1e9
-    return {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "frac_of_achievable": round(achieved / HBM_ACHIEVABLE_GBS, 4),
-            "algorithmic_bytes": int(alg_bytes), "ms": round(ms, 3), "traffic": None, "what": what}
+    out = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+           "frac": round(achieved / HBM_PEAK_GBS, 4), "frac_of_achievable": round(achieved / HBM_ACHIEVABLE_GBS, 4),
+           "algorithmic_bytes": int(alg_bytes), "ms": round(ms, 3), "traffic": traffic, "what": what}
+    if traffic is not None:
+        out["traffic_quoted_from"] = PMC_C5_GATHER_FILE + " (PMC passes of tools/bench_gather.py on the same configuration, an earlier run)"
+        out["traffic_note"] = traffic_note
+    return out
 
 
 def merge_roofline(alg_bytes, ms):
