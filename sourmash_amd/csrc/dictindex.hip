@@ -137,18 +137,28 @@ struct DxGroup {
     uint32_t lo_lo, lo_hi;          // lane l < DX_EPW: absolute index of the slice's first element
     uint32_t bound[DX_EPW - 1];     // wave-uniform: end of slices 0 .. 14
 };
-__device__ __forceinline__ void dx_group_load(DxGroup& g, const uint64_t* __restrict__ offsets, const uint32_t* __restrict__ bounds,
-                                              uint32_t n, uint32_t b, uint64_t row0, int lane) {
-    uint64_t lo = 0;
-    uint32_t cnt = 0;
-    const uint64_t r = row0 + (uint64_t)lane;
-    if (lane < DX_EPW && r < n) {
-        const uint32_t* bp = bounds + r * (uint64_t)(DX_P + 1) + b;
+// the loads of a group (issued early: the chain bounds -> hashes -> table is what a wave waits for) ...
+struct DxRaw {
+    uint64_t lo;                    // lane l < DX_EPW: absolute index of the first element of slice l
+    uint32_t cnt;                   // ... and its length
+};
+__device__ __forceinline__ DxRaw dx_group_fetch(const uint64_t* __restrict__ offsets, const uint32_t* __restrict__ bounds, uint32_t n,
+                                                uint32_t b, uint64_t row0, int lane) {
+    DxRaw r;
+    r.lo = 0;
+    r.cnt = 0;
+    const uint64_t row = row0 + (uint64_t)lane;
+    if (lane < DX_EPW && row < n) {
+        const uint32_t* bp = bounds + row * (uint64_t)(DX_P + 1) + b;
         const uint32_t a = bp[0], e = bp[1];
-        lo = offsets[r] + a;
-        cnt = e - a;
+        r.lo = offsets[row] + a;
+        r.cnt = e - a;
     }
-    uint32_t incl = cnt;
+    return r;
+}
+// ... and the prefix sums over them
+__device__ __forceinline__ void dx_group_build(DxGroup& g, const DxRaw& r, int lane) {
+    uint32_t incl = r.cnt;
 #pragma unroll
     for (int s = 1; s < DX_EPW; s <<= 1) {
         const uint32_t v = __shfl_up(incl, s);
@@ -158,9 +168,9 @@ __device__ __forceinline__ void dx_group_load(DxGroup& g, const uint64_t* __rest
 #pragma unroll
     for (int k = 0; k < DX_EPW - 1; ++k) g.bound[k] = __shfl(incl, k);
     g.incl = incl;
-    g.excl = incl - cnt;
-    g.lo_lo = (uint32_t)lo;
-    g.lo_hi = (uint32_t)(lo >> 32);
+    g.excl = incl - r.cnt;
+    g.lo_lo = (uint32_t)r.lo;
+    g.lo_hi = (uint32_t)(r.lo >> 32);
 }
 // flattened position t (< g.total) -> slice h and the element's absolute index
 __device__ __forceinline__ uint64_t dx_group_at(const DxGroup& g, uint32_t t, int& h) {
@@ -188,36 +198,49 @@ __global__ __launch_bounds__(DX_THREADS) void dx_count_kernel(const uint64_t* __
     if (tid == 0) { s_n = 0; s_ones = 0; s_over = 0; s_out = 0; s_nf = 0; s_rare = 0; }
     __syncthreads();
     volatile uint32_t* over = &s_over;
+    auto insert = [&](uint64_t x) {
+        if (x == DX_EMPTY) { atomicAdd(&s_ones, 1u); return; }         // the table's empty marker is a legal hash: counted apart
+        uint32_t slot = dx_slot(x);
+        bool placed = false;
+        for (int probe = 0; probe < 256; ++probe) {                     // (a table this crowded has overflowed anyway)
+            const unsigned long long k = s_key[slot];
+            if (k == x) { placed = true; break; }
+            if (k == DX_EMPTY) {
+                const unsigned long long prev = atomicCAS(&s_key[slot], DX_EMPTY, (unsigned long long)x);
+                if (prev == DX_EMPTY) {
+                    if (atomicAdd(&s_n, 1u) >= (uint32_t)DX_MAXD) s_over = 1;   // fuller than the dictionary has room for
+                    placed = true;
+                    break;
+                }
+                if (prev == x) { placed = true; break; }
+            }
+            slot = (slot + 1) & (DX_CAP - 1);
+        }
+        if (placed) atomicAdd(&s_cnt[slot], 1u);
+        else s_over = 1;                                                // table full
+    };
+    // the next group's bounds are asked for before this group is walked, and a group's hashes two steps at a time
+    DxRaw next = dx_group_fetch(offsets, bounds, n, b, (uint64_t)wave * DX_EPW, lane);
     for (uint64_t row0 = (uint64_t)wave * DX_EPW; row0 < n; row0 += DX_CHUNK) {
         if (*over) break;                                           // the bucket does not fit: stop at once, the sort takes over
+        const DxRaw cur = next;
+        next = dx_group_fetch(offsets, bounds, n, b, row0 + DX_CHUNK, lane);      // (rows past the end: nothing is loaded)
         DxGroup g;
-        dx_group_load(g, offsets, bounds, n, b, row0, lane);
-        for (uint32_t t0 = 0; t0 < g.total; t0 += 64) {             // wave-uniform trip count (the shuffles read lanes 0 .. 15)
+        dx_group_build(g, cur, lane);
+        for (uint32_t t0 = 0; t0 < g.total; t0 += 128) {            // wave-uniform trip count (the shuffles read lanes 0 .. 15)
             if (*over) break;                                       // (one LDS word read by all lanes: uniform)
-            const uint32_t t = t0 + (uint32_t)lane;
-            int h;
-            const uint64_t at = dx_group_at(g, t < g.total ? t : g.total - 1, h);
-            if (t >= g.total) continue;
-            const uint64_t x = hashes[at];
-            if (x == DX_EMPTY) { atomicAdd(&s_ones, 1u); continue; }   // the table's empty marker is a legal hash: counted apart
-            uint32_t slot = dx_slot(x);
-            bool placed = false;
-            for (int probe = 0; probe < 256; ++probe) {             // (a table this crowded has overflowed anyway)
-                const unsigned long long k = s_key[slot];
-                if (k == x) { placed = true; break; }
-                if (k == DX_EMPTY) {
-                    const unsigned long long prev = atomicCAS(&s_key[slot], DX_EMPTY, (unsigned long long)x);
-                    if (prev == DX_EMPTY) {
-                        if (atomicAdd(&s_n, 1u) >= (uint32_t)DX_MAXD) s_over = 1;   // fuller than the dictionary has room for
-                        placed = true;
-                        break;
-                    }
-                    if (prev == x) { placed = true; break; }
-                }
-                slot = (slot + 1) & (DX_CAP - 1);
+            uint64_t x[2];
+            bool ok[2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const uint32_t t = t0 + 64u * (uint32_t)u + (uint32_t)lane;
+                ok[u] = t < g.total;
+                int h;
+                x[u] = hashes[dx_group_at(g, ok[u] ? t : g.total - 1, h)];
             }
-            if (placed) atomicAdd(&s_cnt[slot], 1u);
-            else s_over = 1;                                          // table full
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+                if (ok[u]) insert(x[u]);
         }
     }
     __syncthreads();
@@ -314,10 +337,25 @@ __global__ __launch_bounds__(DX_ETHREADS) void dx_emit_kernel(const uint64_t* __
         const uint32_t fbase = bases[b * 2 + 0], rbase = bases[b * 2 + 1];
         const uint32_t w0 = fbase >> 5;
         const uint32_t W = nf ? ((fbase + nf - 1) >> 5) - w0 + 1 : 0u;    // <= DX_TILE_W
+        // this wave's slices of the bucket and their first 128 hashes are asked for now: nothing below depends on them until
+        // the table is built, two barriers later
+        const uint64_t row0 = chunk0 + (uint64_t)wave * DX_EPW;
+        const DxRaw raw = dx_group_fetch(offsets, bounds, n, b, row0 < n ? row0 : (uint64_t)n, lane);
         __syncthreads();                                                  // the previous bucket's flush is through
         for (int k = tid; k < DX_CAP; k += DX_ETHREADS) s_key[k] = DX_EMPTY;
         for (uint32_t w = fw; w < W; w += 4) s_tile[frr][w] = 0;
         if (tid == 0) { s_ones_val = 0; s_ones_end = 0; s_ones_ent = 0; }
+        DxGroup g;
+        dx_group_build(g, raw, lane);
+        uint64_t x0[2] = {0, 0};
+        int h0[2] = {0, 0};
+        if (g.total) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const uint32_t t = 64u * (uint32_t)u + (uint32_t)lane;
+                x0[u] = hashes[dx_group_at(g, t < g.total ? t : g.total - 1, h0[u])];
+            }
+        }
         __syncthreads();
         for (uint32_t i = tid; i < nd; i += DX_ETHREADS) {
             const uint64_t e = (uint64_t)b * (DX_MAXD + 1) + i;
@@ -336,15 +374,7 @@ __global__ __launch_bounds__(DX_ETHREADS) void dx_emit_kernel(const uint64_t* __
             s_ent[slot] = i;
         }
         __syncthreads();
-        DxGroup g;
-        const uint64_t row0 = chunk0 + (uint64_t)wave * DX_EPW;
-        dx_group_load(g, offsets, bounds, n, b, row0 < n ? row0 : (uint64_t)n, lane);
-        for (uint32_t t0 = 0; t0 < g.total; t0 += 64) {
-            const uint32_t t = t0 + (uint32_t)lane;
-            int h;
-            const uint64_t at = dx_group_at(g, t < g.total ? t : g.total - 1, h);
-            if (t >= g.total) continue;
-            const uint64_t x = hashes[at];
+        auto emit = [&](uint64_t x, int h) {
             uint32_t v, end, ent;
             if (x == DX_EMPTY) {
                 v = s_ones_val; end = s_ones_end; ent = s_ones_ent;
@@ -361,6 +391,16 @@ __global__ __launch_bounds__(DX_ETHREADS) void dx_emit_kernel(const uint64_t* __
                 rare_rows[(uint64_t)rbase + pos] = (uint32_t)(row0 + (uint64_t)h);
                 rare_end[(uint64_t)rbase + pos] = rbase + end;
             }
+        };
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+            if (64u * (uint32_t)u + (uint32_t)lane < g.total) emit(x0[u], h0[u]);
+        for (uint32_t t0 = 128; t0 < g.total; t0 += 64) {                 // longer groups: the rest, a step at a time
+            const uint32_t t = t0 + (uint32_t)lane;
+            int h;
+            const uint64_t at = dx_group_at(g, t < g.total ? t : g.total - 1, h);
+            if (t >= g.total) continue;
+            emit(hashes[at], h);
         }
         __syncthreads();
         if (W == 0) continue;
