@@ -359,7 +359,8 @@ def bench_compare_dist(torch, dist, np, dev, be, parallel, smd, synth_sketches, 
     out = {"ranks": world, "pairs": pairs, "ms": round(dt * 1e3, 2), "pairs_per_s": round(pairs / dt, 1),
            "tiles_ms_rank0": round(timing.get("tiles_ms", 0.0), 2), "allgather_ms": round(timing.get("allgather_ms", 0.0), 2),
            "mirror_and_jaccard_ms": round(timing.get("finish_ms", 0.0), 2), "collective": "all-gather (rccl)" if use_dist else "none",
-           "exchange_bytes": int(((n + 15) // 16 + world - 1) // world * world * 16 * n * 4) if use_dist else 0,
+           "exchange_bytes": int(((n + 15) // 16 + world - 1) // world * world * 16 * n * timing.get("exchange_bytes_per_entry", 4))
+           if use_dist else 0,
            "counts_checksum": checksum,
            "note": "wall clock from the resident CSR to the symmetric u32 matrix + f64 Jaccard on every rank: cost model + "
                    "compare-index build + owned row tiles + all-gather + mirror + Jaccard"}

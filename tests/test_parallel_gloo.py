@@ -172,6 +172,14 @@ def _worker(rank, world, port, ret):
         wc, wj = oracle.compare_all_pairs(*oracle.make_csr(sk))
         ok_cmp = np.array_equal(common.numpy().view(np.uint32), wc) and \
             np.array_equal(jac.numpy().view(np.uint64), wj.view(np.uint64))
+        # counts travel as 16-bit words unless a sketch could share 65,536 hashes or more: two sketches of 70,000 that share
+        # 66,000 take the 32-bit form (and a wrapped count would show)
+        wide = [np.arange(1, 70_001, dtype=np.uint64) * np.uint64(977), np.arange(4001, 74_001, dtype=np.uint64) * np.uint64(977)]
+        wide += [s for s in sk[:19]]
+        h2, off2 = _csr(wide)
+        common2, _ = parallel.compare_all_pairs_distributed(h2, off2, len(wide), be, want_jaccard=False)
+        wc2, _ = oracle.compare_all_pairs(*oracle.make_csr(wide))
+        ok_cmp = ok_cmp and int(wc2[0, 1]) == 66_000 and np.array_equal(common2.numpy().view(np.uint32), wc2)
         # ---- gather: database sharded by dataset, replicated query ----
         qh, dbh = synth_gather(n_query=4000, n_db=61, db_size=120)
         dbh[7] = dbh[3].copy()                                  # a tie across... the same shard
