@@ -241,6 +241,9 @@ def main():
         except Exception as e:
             extra["error"] = repr(e)
 
+    if rank == 0:
+        extra["arena"] = {**smd.arena_stats(), "what": "the library's device arena (csrc/arena.hpp) over the whole run: driver "
+                          "allocator calls, nanoseconds inside them, allocations served from cached blocks"}
     out = None
     if rank == 0:
         out = {
@@ -387,9 +390,12 @@ def bench_gather_dist(torch, np, dev, be, parallel, synth_gather_device, world, 
     out = {"ranks": world, "datasets": ndb, "datasets_per_rank": hi - lo, "query_hashes": int(q.numel()),
            "db_bytes_per_rank": int(gh.numel() * 8), "rounds": len(res), "total_ms": round(best * 1e3, 2),
            "us_per_round_incl_index_build": round(best * 1e6 / max(len(res), 1), 1),
+           "index_build_kernels_ms": stats.get("build_kernels_ms"), "index_build_host_ms": stats.get("build_host_ms"),
+           "index_build_driver_alloc_ms": stats.get("build_driver_alloc_ms"), "index_build_driver_allocs": stats.get("build_driver_allocs"),
+           "index_build_syncs": stats.get("build_syncs"), "loop_kernels_ms": stats.get("loop_gpu_ms"), "loop_host_ms": stats.get("loop_host_ms"),
            "exchanges": stats.get("exchanges"), "rounds_per_exchange": stats.get("rounds_per_exchange"),
            "records_per_rank": stats.get("records_per_rank"),
-           "exchange_bytes_per_rank": (stats["records_per_rank"] * stats["record_words"] * 8) if stats else None,
+           "exchange_bytes_per_rank": (stats["records_per_rank"] * stats["record_words"] * 8) if stats.get("records_per_rank") else None,
            "collective": "all-gather of candidate rows (rccl)" if use_dist else "none (native single-shard loop)",
            "overlaps_non_increasing": bool(all(a >= b for a, b in zip(iso, iso[1:]))),
            "first": res[:2], "last": res[-1:] if res else None,
@@ -454,7 +460,8 @@ def single_gpu_extras(extra, torch, np, dev, be, smd, synth_sketches, synth_gath
         res = state.run()                                # every round on the device
         torch.cuda.synchronize()
         t2 = time.perf_counter()
-    extra["gather_200k_vs_5000"] = {"rounds": len(res), "index_build_ms": round((t1 - t0) * 1e3, 2),
+    extra["gather_200k_vs_5000"] = {"rounds": len(res), **{k: v for k, v in state.stats().items() if k in ("build_kernels_ms", "loop_gpu_ms")},
+                                    "index_build_ms": round((t1 - t0) * 1e3, 2),
                                     "loop_ms": round((t2 - t1) * 1e3, 2),
                                     "us_per_round": round((t2 - t1) * 1e6 / max(len(res), 1), 1)}
     del state, gh, goff, gq
@@ -516,6 +523,7 @@ def single_gpu_extras(extra, torch, np, dev, be, smd, synth_sketches, synth_gath
         torch.cuda.synchronize()
         t2 = time.perf_counter()
     postings = int(be.lib.smgpu_gather_postings(st5._ptr))
+    st5_stats = st5.stats()                             # HIP events around the build's kernels and the loop's rounds
     db_bytes = int(gh5.numel() * 8)
     # index build: every database hash is read once (8 B), one u32 row id is written per posting, the per-element query
     # position (4 B) is written by pass 1 and read by pass 2
@@ -524,6 +532,10 @@ def single_gpu_extras(extra, torch, np, dev, be, smd, synth_sketches, synth_gath
         "db_bytes": db_bytes, "postings": postings, "rounds": len(res5), "index_build_ms": round((t1 - t0) * 1e3, 2),
         "loop_ms": round((t2 - t1) * 1e3, 2), "total_ms": round((t2 - t0) * 1e3, 2),
         "us_per_round": round((t2 - t1) * 1e6 / max(len(res5), 1), 2),
+        "index_build_kernels_ms": st5_stats["build_kernels_ms"], "index_build_host_ms": st5_stats["build_host_ms"],
+        "index_build_driver_alloc_ms": st5_stats["build_driver_alloc_ms"], "index_build_driver_allocs": st5_stats["build_driver_allocs"],
+        "index_build_syncs": st5_stats["build_syncs"], "index_build_sync_wait_ms": st5_stats["build_sync_wait_ms"],
+        "loop_kernels_ms": st5_stats["loop_gpu_ms"], "loop_host_ms": st5_stats["loop_host_ms"],
         "index_build_roofline": hbm_roofline(build_alg, (t1 - t0) * 1e3,
                                              "8 B per database hash + 4 B per posting + 2 x 4 B query position per element; wall clock of smgpu_gather_new_raw",
                                              traffic=PMC_C5_BUILD_COUNTED if db_bytes == 3997497344 else None,

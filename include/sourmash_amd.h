@@ -405,6 +405,17 @@ SmgpuGather *smgpu_gather_new_raw(const uint64_t *d_query, uint64_t nq, const ui
                                   const uint64_t *d_offsets, uint64_t ndb, uint64_t index_base, void *stream);
 void smgpu_gather_free(SmgpuGather *ptr);
 uint64_t smgpu_gather_postings(const SmgpuGather *ptr);
+/* What the build and the last smgpu_gather_run cost, so that one benchmark line separates kernels from host effects
+ * (waits for the build's kernels): out[0] build kernel span in ms (HIP events on the build's stream), out[1] build host
+ * wall clock ms (the smgpu_gather_new_raw call), out[2] ms inside the driver's allocator during the build (0 once the
+ * arena is warm), out[3] driver allocations made, out[4] host synchronisations of the build, out[5] ms the host waited in
+ * them, out[6] GPU span in ms of the last run's rounds (events around the loop), out[7] host wall clock ms of that run. */
+void smgpu_gather_stats(SmgpuGather *ptr, double *out8);
+/* The library's device arena (csrc/arena.hpp): every index / scratch block comes from it and is cached on release.
+ * out[0] driver allocations, out[1] driver frees, out[2] ns inside the driver, out[3] reuse hits, out[4] live bytes,
+ * out[5] cached bytes, out[6] peak bytes held, out[7] reuses that waited on another stream's event. */
+void smgpu_arena_stats(uint64_t *out8);
+void smgpu_arena_trim(uint64_t keep_bytes);     /* give cached blocks back to the driver (0: all of them) */
 void smgpu_gather_counters_get(const SmgpuGather *ptr, uint64_t *counts_out, void *stream);
 void smgpu_gather_begin(SmgpuGather *ptr, uint64_t threshold_hashes, uint64_t max_rounds, void *stream);
 uint64_t smgpu_gather_run(SmgpuGather *ptr, uint64_t *out_index, uint64_t *out_isect, uint64_t cap, void *stream);

@@ -72,7 +72,7 @@ SourmashStr make_str(const std::string& s) {
 // which settle first).  Results are those of immediate hashing: adding hashes to a sketch commutes (set union, counts
 // add, bottom-k keeps the smallest), and everything that does not commute with it settles first.
 constexpr size_t PENDING_FLUSH_BYTES = (size_t)32 << 20;
-void settle(KmerMinHash& mh);
+void settle(KmerMinHash& mh, bool streaming = false);
 
 inline KmerMinHash* RAW(SourmashKmerMinHash* p) { return reinterpret_cast<KmerMinHash*>(p); }
 inline const KmerMinHash* RAW(const SourmashKmerMinHash* p) { return reinterpret_cast<const KmerMinHash*>(p); }
@@ -123,7 +123,7 @@ void add_residue_kmers(KmerMinHash& mh, const uint8_t* seq, size_t len, bool is_
     if (mh.is_dna())                                                // signature.rs:367-384: no alphabet to map to
         throw Error(E_INVALID_HASH_FUNCTION, "Invalid hash function: \"DNA\"");
     DeviceCtx& ctx = DeviceCtx::get();
-    std::lock_guard<std::mutex> g(ctx.mutex());
+    std::lock_guard<std::recursive_mutex> g(ctx.mutex());
     std::vector<uint64_t> hs, cs;
     ctx.protein_sketch_host(seq, len, mh.ksize, mh.hash_function, mh.seed, is_protein, keep_threshold(mh),
                             mh.track_abundance, mh.num, hs, cs);
@@ -155,16 +155,26 @@ size_t first_invalid_byte(const uint8_t* seq, size_t len) {
     return SIZE_MAX;
 }
 
-void settle(KmerMinHash& mh) {
+void settle(KmerMinHash& mh, bool streaming) {
+    // Accessors that only read (get_mins, md5sum, similarity ...) come through here too, possibly from two threads on
+    // the same sketch (ctypes releases the GIL): one of them hashes the queue, the other finds it empty afterwards.
+    static std::recursive_mutex settle_mu;
+    std::lock_guard<std::recursive_mutex> sg(settle_mu);
     if (mh.pending.empty()) return;
-    // whatever happens below, the records are consumed once; the queue keeps its storage (a fresh 32 MiB string per
-    // flush costs 8,192 page faults, which was a fifth of the per-record time of a loop over 150-bp reads)
+    // whatever happens below, the records are consumed once.  A flush from inside the add_sequence loop (`streaming`)
+    // keeps the queue's storage (a fresh 32 MiB string per flush costs 8,192 page faults, which was a fifth of the
+    // per-record time of a loop over 150-bp reads); a flush because somebody looks at the sketch gives storage beyond
+    // 1 MiB back, or every sketch of a many-ksize signature would hold a copy of its longest record for life.
     struct Consume {
         std::string& q;
-        ~Consume() { q.clear(); }
-    } consume{mh.pending};
+        bool keep;
+        ~Consume() {
+            if (keep || q.capacity() <= ((size_t)1 << 20)) q.clear();
+            else std::string().swap(q);
+        }
+    } consume{mh.pending, streaming};
     DeviceCtx& ctx = DeviceCtx::get();
-    std::lock_guard<std::mutex> g(ctx.mutex());
+    std::lock_guard<std::recursive_mutex> g(ctx.mutex());
     std::vector<uint64_t> hs, cs;
     ctx.sketch_host((const uint8_t*)mh.pending.data(), mh.pending.size(), mh.ksize, mh.seed, keep_threshold(mh), mh.track_abundance,
                     mh.num, hs, cs);
@@ -197,7 +207,7 @@ void add_sequence_dna(KmerMinHash& mh, const uint8_t* seq, size_t len, bool forc
     if (use_len >= k) {
         mh.pending.append((const char*)seq, use_len);
         mh.pending.push_back('\n');                                 // records never share a k-mer
-        if (mh.pending.size() >= PENDING_FLUSH_BYTES) settle(mh);
+        if (mh.pending.size() >= PENDING_FLUSH_BYTES) settle(mh, true);
     }
     if (raise) throw err_invalid_dna(upper_ascii(seq + bad_kmer, k));   // errors.rs:49-50
 }
@@ -219,7 +229,7 @@ void align_scaled(const KmerMinHash& x, const KmerMinHash& y, bool downsample, D
 PairStats device_pair(const KmerMinHash& a, const KmerMinHash& b, bool want_abund, bool want_list, uint64_t num,
                       std::vector<uint64_t>* list) {
     DeviceCtx& ctx = DeviceCtx::get();
-    std::lock_guard<std::mutex> g(ctx.mutex());
+    std::lock_guard<std::recursive_mutex> g(ctx.mutex());
     return ctx.pair(a, b, want_abund, want_list, num, list);
 }
 
@@ -258,7 +268,7 @@ extern "C" {
 // ---------------------------------------------------------------------------------------------
 // library / errors
 // ---------------------------------------------------------------------------------------------
-void sourmash_init(void) { keep_pool_memory(); }   // stream-ordered scratch stays in the pool between calls
+void sourmash_init(void) {}
 void sourmash_err_clear(void) { g_err_code = 0; g_err_msg.clear(); }
 SourmashErrorCode sourmash_err_get_last_code(void) { return g_err_code; }
 SourmashStr sourmash_err_get_last_message(void) {
@@ -354,7 +364,7 @@ const uint64_t* kmerminhash_seq_to_hashes(SourmashKmerMinHash* p, const char* se
             std::vector<uint64_t> hs;
             {
                 DeviceCtx& ctx = DeviceCtx::get();
-                std::lock_guard<std::mutex> g(ctx.mutex());
+                std::lock_guard<std::recursive_mutex> g(ctx.mutex());
                 ctx.protein_hashes_host(seq, insize, mh.ksize, mh.hash_function, mh.seed, is_protein, hs);
             }
             const bool zeros = force && bad_kmers_as_zeroes;
@@ -368,7 +378,7 @@ const uint64_t* kmerminhash_seq_to_hashes(SourmashKmerMinHash* p, const char* se
         const uint32_t k = mh.ksize;
         if (insize >= k && k != 0) {
             DeviceCtx& ctx = DeviceCtx::get();
-            std::lock_guard<std::mutex> g(ctx.mutex());
+            std::lock_guard<std::recursive_mutex> g(ctx.mutex());
             ctx.kmer_hashes_host(seq, insize, k, mh.seed, out);       // 0 where a k-mer covers an invalid byte
             if (!force) {
                 // ffi/minhash.rs:76-96: the first bad k-mer aborts with InvalidDNA
@@ -850,9 +860,9 @@ struct BitIndex {
     uint32_t threshold = 0;
     hipStream_t stream = nullptr;          // the arrays come from this stream's pool and go back to it, in order
     ~BitIndex() {
-        if (bits) (void)hipFreeAsync(bits, stream);
-        if (rows_sorted) (void)hipFreeAsync(rows_sorted, stream);
-        if (run_end) (void)hipFreeAsync(run_end, stream);
+        if (bits) arena_free(bits, stream);
+        if (rows_sorted) arena_free(rows_sorted, stream);
+        if (run_end) arena_free(run_end, stream);
     }
 };
 
@@ -907,12 +917,12 @@ static BitIndex* bitindex_build(const uint64_t* d_hashes, const uint64_t* d_offs
             if ((t_index > t_merge && !forced_threshold) || (double)n * words * 4.0 > 8.0 * (1ull << 30)) return nullptr;
             bi->frequent = n_freq; bi->rare_pairs = rare_pairs; bi->threshold = threshold; bi->words_per_row = words;
             if (words) {
-                hip_check(hipMallocAsync((void**)&bi->bits, (size_t)n * words * 4, st), "hipMallocAsync");
+                hip_check(arena_alloc((void**)&bi->bits, (size_t)n * words * 4, st), "arena_alloc");
                 hip_check(hipMemsetAsync(bi->bits, 0, (size_t)n * words * 4, st), "memset");
             }
             if (rare_elems) {
-                hip_check(hipMallocAsync((void**)&bi->rows_sorted, rare_elems * 4 + 16, st), "hipMallocAsync");
-                hip_check(hipMallocAsync((void**)&bi->run_end, rare_elems * 4 + 16, st), "hipMallocAsync");
+                hip_check(arena_alloc((void**)&bi->rows_sorted, rare_elems * 4 + 16, st), "arena_alloc");
+                hip_check(arena_alloc((void**)&bi->run_end, rare_elems * 4 + 16, st), "arena_alloc");
                 bi->inv_total = rare_elems;
             }
             hip_check(dict_emit_launch(d_hashes, d_offsets, n, scratch.p, bi->bits, words, bi->rows_sorted, bi->run_end, st),
@@ -930,7 +940,7 @@ static BitIndex* bitindex_build(const uint64_t* d_hashes, const uint64_t* d_offs
     const size_t tb = inverted_temp_bytes(total);
     AsyncBuf keys_a(total * 8, st), keys_b(total * 8, st), rows_tmp(total * 4, st), counts((total + 2) * 4, st), tmp(tb, st),
         scal(64, st), flags((total + 2) * 4, st), run_off((total + 2) * 8, st), freq_rank((total + 2) * 8, st);
-    hip_check(hipMallocAsync((void**)&bi->rows_sorted, total * 4 + 16, st), "hipMallocAsync");
+    hip_check(arena_alloc((void**)&bi->rows_sorted, total * 4 + 16, st), "arena_alloc");
     hip_check(hipMemsetAsync(scal.p, 0, 64, st), "memset");
     uint64_t* d_n_runs = scal.as<uint64_t>();
     unsigned long long* d_out = scal.as<unsigned long long>() + 1;      // [runs, frequent, rare pair increments]
@@ -952,14 +962,14 @@ static BitIndex* bitindex_build(const uint64_t* d_hashes, const uint64_t* d_offs
         return nullptr;                                             // merge kernel wins / bitmap cap (~BitIndex frees)
     bi->frequent = n_freq; bi->rare_pairs = rare_pairs; bi->threshold = threshold; bi->words_per_row = words;
     if (words) {
-        hip_check(hipMallocAsync((void**)&bi->bits, (size_t)n * words * 4, st), "hipMallocAsync");
+        hip_check(arena_alloc((void**)&bi->bits, (size_t)n * words * 4, st), "arena_alloc");
         hip_check(hipMemsetAsync(bi->bits, 0, (size_t)n * words * 4, st), "memset");
     }
-    hip_check(hipMallocAsync((void**)&bi->run_end, total * 4 + 16, st), "hipMallocAsync");
+    hip_check(arena_alloc((void**)&bi->run_end, total * 4 + 16, st), "arena_alloc");
     hip_check(inverted_apply_launch(run_off.as<uint64_t>(), flags.as<uint32_t>(), freq_rank.as<uint64_t>(), U, total, bi->rows_sorted,
                                     bi->run_end, bi->bits, words, st), "inverted apply");
     if (rare_pairs == 0 && n_freq == U) {             // nothing is rare: plain bit rows, drop the inverted part
-        (void)hipFreeAsync(bi->rows_sorted, st); (void)hipFreeAsync(bi->run_end, st);
+        arena_free(bi->rows_sorted, st); arena_free(bi->run_end, st);
         bi->rows_sorted = bi->run_end = nullptr;
     }
     return bi.release();                              // stream-ordered: usable by later work on `st` without a sync
@@ -1044,7 +1054,7 @@ void smgpu_compare_all_pairs(const SourmashKmerMinHash* const* mhs, uintptr_t n,
         for (uintptr_t i = 0; i < n; ++i) offsets[i + 1] = offsets[i] + MH(mhs[i])->size();
         const uint64_t total = offsets[n];
         DeviceCtx& ctx = DeviceCtx::get();
-        std::lock_guard<std::mutex> g(ctx.mutex());
+        std::lock_guard<std::recursive_mutex> g(ctx.mutex());
         hipStream_t st = ctx.stream();
         AsyncBuf dh(total * 8 + 16, st), doff((n + 1) * 8, st);
         for (uintptr_t i = 0; i < n; ++i)
@@ -1108,15 +1118,28 @@ static uint64_t gather_drain(GatherDev& g, uint64_t* out_idx, uint64_t* out_isec
     bool use_graph = graph_mode == 1;
     unsigned batch = 32;
     const auto t_all = std::chrono::steady_clock::now();
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;                           // GPU span of the rounds (smgpu_gather_stats)
+    struct EvGuard { hipEvent_t &a, &b; ~EvGuard() { if (a) (void)hipEventDestroy(a); if (b) (void)hipEventDestroy(b); } } ev_guard{ev0, ev1};
+    hip_check(hipEventCreate(&ev0), "event");
+    hip_check(hipEventCreate(&ev1), "event");
+    hip_check(hipEventRecord(ev0, st), "event");
+    bool graph_synced = false;
+    double gpu_ms_graph = 0.0;
     for (;;) {
         const auto t0 = std::chrono::steady_clock::now();
         hipStream_t bs = st;                                           // the stream this batch runs on
+        if (use_graph && !graph_synced) {                              // the graph runs on the index's own stream: everything
+            hip_check(hipStreamSynchronize(st), "sync");               // enqueued on the caller's stream (begin, earlier batches) first
+            graph_synced = true;
+        }
         if (replay) hip_check(gather_enqueue_replay(g, (batch + GATHER_TOPK_MAX - 1) / GATHER_TOPK_MAX, st), "gather rounds");
         else if (use_graph) hip_check(gather_enqueue_rounds_graph(g, batch, &bs), "gather rounds (graph)");
         else hip_check(gather_enqueue_rounds(g, batch, st), "gather rounds");
         const auto t1 = std::chrono::steady_clock::now();
-        hip_check(hipMemcpyAsync(head, g.state, sizeof(head), hipMemcpyDeviceToHost, bs), "D2H");
+        hip_check(hipMemcpyAsync(g.pinned + 16, g.state, sizeof(head), hipMemcpyDeviceToHost, bs), "D2H");
         hip_check(hipStreamSynchronize(bs), "sync");
+        memcpy(head, g.pinned + 16, sizeof(head));
+        if (bs != st) gpu_ms_graph += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         const double enqueue_us = std::chrono::duration<double, std::micro>(t1 - t0).count();
         const double wait_us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t1).count();
         if (trace)
@@ -1129,9 +1152,14 @@ static uint64_t gather_drain(GatherDev& g, uint64_t* out_idx, uint64_t* out_isec
     }
     const uint64_t n = head[GS_ROUNDS];
     const uint64_t m = n < cap ? n : cap;
+    hip_check(hipEventRecord(ev1, st), "event");
     if (m && out_idx) hip_check(hipMemcpyAsync(out_idx, g.out_idx, m * 8, hipMemcpyDeviceToHost, st), "D2H");
     if (m && out_isect) hip_check(hipMemcpyAsync(out_isect, g.out_isect, m * 8, hipMemcpyDeviceToHost, st), "D2H");
     hip_check(hipStreamSynchronize(st), "sync");
+    float span = 0.f;
+    (void)hipEventElapsedTime(&span, ev0, ev1);
+    g.loop_gpu_ms = span + gpu_ms_graph;                               // graph batches run on another stream: their wall clock
+    g.loop_host_ns = (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_all).count();
     if (trace)
         fprintf(stderr, "[gather] %llu rounds read back; %.1f us since the loop began\n", (unsigned long long)n,
                 std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_all).count());
@@ -1140,8 +1168,9 @@ static uint64_t gather_drain(GatherDev& g, uint64_t* out_idx, uint64_t* out_isec
 
 SmgpuSketchSet* smgpu_sketchset_new(const SourmashKmerMinHash* const* mhs, uintptr_t n) {
     return landing<SmgpuSketchSet*>([&]() -> SmgpuSketchSet* {
+        for (uintptr_t i = 0; i < n; ++i) (void)MH(mhs[i]);          // queued records are hashed before the context is taken
         DeviceCtx& ctx = DeviceCtx::get();
-        std::lock_guard<std::mutex> g(ctx.mutex());
+        std::lock_guard<std::recursive_mutex> g(ctx.mutex());
         std::unique_ptr<SketchSet> s(new SketchSet());
         std::vector<uint64_t> off(n + 1, 0);
         for (uintptr_t i = 0; i < n; ++i) off[i + 1] = off[i] + MH(mhs[i])->size();
@@ -1198,7 +1227,7 @@ void smgpu_collection_params(const SmgpuCollection* p, uint32_t* ksize, uint32_t
 
 static SketchSet* upload_collection(LoadedCollection&& col) {
     DeviceCtx& ctx = DeviceCtx::get();
-    std::lock_guard<std::mutex> g(ctx.mutex());
+    std::lock_guard<std::recursive_mutex> g(ctx.mutex());
     hipStream_t st = ctx.stream();
     std::unique_ptr<SketchSet> s(new SketchSet());
     s->n = col.rows.size();
@@ -1246,7 +1275,7 @@ SmgpuSketchSet* smgpu_sketchset_subset(const SmgpuSketchSet* p, const uint64_t* 
         }
         out->total = out->host_offsets[n];
         DeviceCtx& ctx = DeviceCtx::get();
-        std::lock_guard<std::mutex> g(ctx.mutex());
+        std::lock_guard<std::recursive_mutex> g(ctx.mutex());
         hipStream_t st = ctx.stream();
         out->hashes.reserve((out->total + 1) * 8);
         out->offsets.reserve((n + 1) * 8);
@@ -1282,7 +1311,7 @@ void smgpu_sketchset_sizes(const SmgpuSketchSet* p, uint64_t* out) {
         }
         std::vector<uint64_t> off(s->n + 1);
         DeviceCtx& ctx = DeviceCtx::get();
-        std::lock_guard<std::mutex> g(ctx.mutex());
+        std::lock_guard<std::recursive_mutex> g(ctx.mutex());
         hip_check(hipMemcpyAsync(off.data(), s->offsets.p, (s->n + 1) * 8, hipMemcpyDeviceToHost, ctx.stream()), "D2H");
         hip_check(hipStreamSynchronize(ctx.stream()), "sync");
         for (uint64_t i = 0; i < s->n; ++i) out[i] = off[i + 1] - off[i];
@@ -1300,7 +1329,7 @@ SourmashKmerMinHash* smgpu_sketchset_get(const SmgpuSketchSet* p, uint64_t index
         mh->max_hash = s->max_hash;
         mh->mins.resize(len);
         DeviceCtx& ctx = DeviceCtx::get();
-        std::lock_guard<std::mutex> g(ctx.mutex());
+        std::lock_guard<std::recursive_mutex> g(ctx.mutex());
         if (len) hip_check(hipMemcpyAsync(mh->mins.data(), s->hashes.as<uint64_t>() + lo, len * 8, hipMemcpyDeviceToHost, ctx.stream()), "D2H");
         hip_check(hipStreamSynchronize(ctx.stream()), "sync");
         return reinterpret_cast<SourmashKmerMinHash*>(mh.release());
@@ -1318,7 +1347,7 @@ void smgpu_sketchset_overlaps(const SmgpuSketchSet* p, const SourmashKmerMinHash
         if (s->n == 0) return;
         const uint64_t nq = MH(query)->size();
         DeviceCtx& ctx = DeviceCtx::get();
-        std::lock_guard<std::mutex> g(ctx.mutex());
+        std::lock_guard<std::recursive_mutex> g(ctx.mutex());
         hipStream_t st = ctx.stream();
         AsyncBuf dq(nq * 8 + 16, st), dc(s->n * 8 + 16, st);
         if (nq) hip_check(hipMemcpyAsync(dq.p, MH(query)->mins.data(), nq * 8, hipMemcpyHostToDevice, st), "H2D");
@@ -1335,7 +1364,7 @@ void smgpu_sketchset_compare(const SmgpuSketchSet* p, uint32_t* common_out, doub
         if (s->n == 0) return;
         if (s->num != 0) throw err_internal("smgpu_sketchset_compare handles scaled sketches");
         DeviceCtx& ctx = DeviceCtx::get();
-        std::lock_guard<std::mutex> g(ctx.mutex());
+        std::lock_guard<std::recursive_mutex> g(ctx.mutex());
         compare_device_csr(s->hashes.as<uint64_t>(), s->offsets.as<uint64_t>(), s->n, s->total, common_out, jaccard_out, ctx.stream());
     });
 }
@@ -1343,8 +1372,9 @@ void smgpu_sketchset_compare(const SmgpuSketchSet* p, uint32_t* common_out, doub
 SmgpuCounter* smgpu_counter_new(const SmgpuSketchSet* set, const SourmashKmerMinHash* query) {
     return landing<SmgpuCounter*>([&]() -> SmgpuCounter* {
         const SketchSet* s = reinterpret_cast<const SketchSet*>(set);
+        (void)MH(query);                                              // queued records are hashed before the context is taken
         DeviceCtx& ctx = DeviceCtx::get();
-        std::lock_guard<std::mutex> g(ctx.mutex());
+        std::lock_guard<std::recursive_mutex> g(ctx.mutex());
         hipStream_t st = ctx.stream();
         std::unique_ptr<GatherCounter> c(new GatherCounter());
         c->set = s;
@@ -1368,7 +1398,7 @@ void smgpu_counter_get(const SmgpuCounter* p, uint64_t* out) {
     landing_void([&] {
         const GatherCounter* c = reinterpret_cast<const GatherCounter*>(p);
         DeviceCtx& ctx = DeviceCtx::get();
-        std::lock_guard<std::mutex> g(ctx.mutex());
+        std::lock_guard<std::recursive_mutex> g(ctx.mutex());
         if (c->set->n) hip_check(hipMemcpyAsync(out, c->g.counters, c->set->n * 8, hipMemcpyDeviceToHost, ctx.stream()), "D2H");
         hip_check(hipStreamSynchronize(ctx.stream()), "sync");
     });
@@ -1378,7 +1408,7 @@ void smgpu_counter_set(SmgpuCounter* p, uint64_t index, uint64_t value) {
         GatherCounter* c = reinterpret_cast<GatherCounter*>(p);
         if (index >= c->set->n) throw err_internal("counter index out of range");
         DeviceCtx& ctx = DeviceCtx::get();
-        std::lock_guard<std::mutex> g(ctx.mutex());
+        std::lock_guard<std::recursive_mutex> g(ctx.mutex());
         hip_check(hipMemcpyAsync(c->g.counters + index, &value, 8, hipMemcpyHostToDevice, ctx.stream()), "H2D");
         hip_check(hipStreamSynchronize(ctx.stream()), "sync");
     });
@@ -1387,7 +1417,7 @@ bool smgpu_counter_best(const SmgpuCounter* p, uint64_t* index, uint64_t* count)
     return landing<bool>([&]() -> bool {
         GatherCounter* c = const_cast<GatherCounter*>(reinterpret_cast<const GatherCounter*>(p));
         DeviceCtx& ctx = DeviceCtx::get();
-        std::lock_guard<std::mutex> g(ctx.mutex());
+        std::lock_guard<std::recursive_mutex> g(ctx.mutex());
         hipStream_t st = ctx.stream();
         unsigned long long* d_best = c->scal.as<unsigned long long>();
         hip_check(hipMemsetAsync(d_best, 0, 8, st), "memset");
@@ -1407,7 +1437,7 @@ void smgpu_counter_consume(SmgpuCounter* p, const SourmashKmerMinHash* intersect
         const uint64_t ni = MH(intersect)->size();
         if (ni == 0) return;
         DeviceCtx& ctx = DeviceCtx::get();
-        std::lock_guard<std::mutex> g(ctx.mutex());
+        std::lock_guard<std::recursive_mutex> g(ctx.mutex());
         hipStream_t st = ctx.stream();
         c->list.reserve((ni + 1) * 8 + 16);
         uint64_t* d_list = c->list.as<uint64_t>();
@@ -1434,7 +1464,7 @@ uint64_t smgpu_counter_gather(SmgpuCounter* p, uint64_t threshold_hashes, uint64
     return landing<uint64_t>([&]() -> uint64_t {
         GatherCounter* c = reinterpret_cast<GatherCounter*>(p);
         DeviceCtx& ctx = DeviceCtx::get();
-        std::lock_guard<std::mutex> g(ctx.mutex());
+        std::lock_guard<std::recursive_mutex> g(ctx.mutex());
         hipStream_t st = ctx.stream();
         hip_check(gather_begin(c->g, threshold_hashes, c->set->n ? c->set->n : 1, st), "gather arm");
         return gather_drain(c->g, out_index, out_isect, cap, st);
@@ -1458,6 +1488,27 @@ SmgpuGather* smgpu_gather_new_raw(const uint64_t* d_query, uint64_t nq, const ui
 }
 void smgpu_gather_free(SmgpuGather* p) { delete reinterpret_cast<GatherRaw*>(p); }
 uint64_t smgpu_gather_postings(const SmgpuGather* p) { return reinterpret_cast<const GatherRaw*>(p)->g.npairs; }
+void smgpu_gather_stats(SmgpuGather* p, double* out) {
+    landing_void([&] {
+        GatherDev& g = reinterpret_cast<GatherRaw*>(p)->g;
+        float ms = 0.f;
+        hip_check(gather_build_kernel_ms(g, &ms), "build events");
+        out[0] = ms;
+        out[1] = g.build_host_ns * 1e-6;
+        out[2] = g.build_driver_ns * 1e-6;
+        out[3] = (double)g.build_driver_allocs;
+        out[4] = (double)g.build_syncs;
+        out[5] = g.build_sync_wait_ns * 1e-6;
+        out[6] = g.loop_gpu_ms;
+        out[7] = g.loop_host_ns * 1e-6;
+    });
+}
+void smgpu_arena_stats(uint64_t* out) {
+    const ArenaStats a = arena_stats();
+    out[0] = a.driver_allocs; out[1] = a.driver_frees; out[2] = a.driver_ns; out[3] = a.reuse_hits;
+    out[4] = a.live_bytes; out[5] = a.cached_bytes; out[6] = a.peak_bytes; out[7] = a.cross_stream_waits;
+}
+void smgpu_arena_trim(uint64_t keep_bytes) { arena_trim(keep_bytes); }
 void smgpu_gather_counters_get(const SmgpuGather* p, uint64_t* out, void* stream) {
     landing_void([&] {
         const GatherDev& g = reinterpret_cast<const GatherRaw*>(p)->g;

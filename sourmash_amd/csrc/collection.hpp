@@ -116,7 +116,9 @@ class ZipReader {
             }
             const bool last_in = in_pos == comp.size();
             rc = inflate(&zs, last_in ? Z_FINISH : Z_NO_FLUSH);
-            if (rc == Z_BUF_ERROR && (in_pos < comp.size() || out_pos < out.size()) && (zs.avail_in == 0 || zs.avail_out == 0)) rc = Z_OK;
+            // no progress possible now: go round again only if the next pass really refills the side that ran dry
+            // (a corrupt stream can ask for input or output that does not exist -- it must fail, not spin)
+            if (rc == Z_BUF_ERROR && ((zs.avail_in == 0 && in_pos < comp.size()) || (zs.avail_out == 0 && out_pos < out.size()))) rc = Z_OK;
         }
         const bool ok = (rc == Z_STREAM_END) && (out_pos - zs.avail_out) == out.size() && in_pos == comp.size();
         inflateEnd(&zs);

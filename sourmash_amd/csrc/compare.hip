@@ -29,6 +29,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include "device_api.hpp"
+#include "arena.hpp"
 
 namespace smg {
 
@@ -534,7 +535,7 @@ static hipError_t compare_launch(const uint64_t* d_hashes, const uint64_t* d_off
     hipError_t e = hipMemsetAsync(d_common, 0, out_rows * n * sizeof(uint32_t), stream);
     if (e != hipSuccess) return e;
     void* ws = nullptr;
-    e = hipMallocAsync(&ws, compare_workspace_bytes(n_row_tiles, n_col_tiles), stream);   // stream-ordered scratch
+    e = arena_alloc(&ws, compare_workspace_bytes(n_row_tiles, n_col_tiles), stream);   // cached scratch, released in stream order
     if (e != hipSuccess) return e;
     unsigned int* counters = (unsigned int*)ws;
     WorkItem* heavy = (WorkItem*)((char*)ws + 256);
@@ -568,8 +569,8 @@ static hipError_t compare_launch(const uint64_t* d_hashes, const uint64_t* d_off
         }
         e = hipGetLastError();
     }
-    const hipError_t e2 = hipFreeAsync(ws, stream);
-    return e != hipSuccess ? e : e2;
+    arena_free(ws, stream);
+    return e;
 }
 
 hipError_t compare_counts_launch(const uint64_t* d_hashes, const uint64_t* d_offsets, uint32_t n, uint32_t row_lo,

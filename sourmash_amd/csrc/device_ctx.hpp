@@ -12,6 +12,7 @@
 #include <mutex>
 #include <string>
 #include <vector>
+#include "arena.hpp"
 #include "device_api.hpp"
 #include "minhash_host.hpp"
 #include "gather_api.hpp"
@@ -39,34 +40,18 @@ struct DevBuf {
     template <class T> T* as() const { return static_cast<T*>(p); }
 };
 
-// Stream-ordered scratch (hipMallocAsync pool): no device-wide synchronisation on allocation or release, which is
-// what plain hipMalloc / hipFree cost -- matters for index builds whose kernels take less time than that.
-// The default pool hands freed memory back to the driver at the next synchronisation unless told otherwise; scratch
-// that is allocated again and again (index builds, compare work lists) should stay in the pool.
-inline void keep_pool_memory() {
-    static const bool once = [] {
-        int dev = 0;
-        hipMemPool_t pool = nullptr;
-        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess && pool) {
-            uint64_t keep = ~0ull;
-            (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
-        }
-        return true;
-    }();
-    (void)once;
-}
-
+// Scratch and index blocks come from the library's arena (arena.hpp): cached driver blocks, reused in stream order, so that
+// an index build whose kernels take a millisecond does not spend a hundred in the driver's allocator.
 struct AsyncBuf {
     void* p = nullptr;
     hipStream_t st = nullptr;
     AsyncBuf() = default;
     AsyncBuf(size_t bytes, hipStream_t stream) : st(stream) {
-        keep_pool_memory();
-        hip_check(hipMallocAsync(&p, bytes + 256, stream), "hipMallocAsync");
+        hip_check(arena_alloc(&p, bytes + 256, stream), "arena_alloc");
     }
     AsyncBuf(const AsyncBuf&) = delete;
     AsyncBuf& operator=(const AsyncBuf&) = delete;
-    ~AsyncBuf() { if (p) (void)hipFreeAsync(p, st); }
+    ~AsyncBuf() { if (p) arena_free(p, st); }
     template <class T> T* as() const { return static_cast<T*>(p); }
 };
 
@@ -98,7 +83,9 @@ class DeviceCtx {
         return *ctx;
     }
 
-    std::mutex& mutex() { return mu_; }
+    // recursive: an entry point that holds the context may reach settle() of a sketch with queued records (capi.cpp), which
+    // takes it again on the same thread
+    std::recursive_mutex& mutex() { return mu_; }
     hipStream_t stream() const { return stream_; }
 
     // ---- sketch a host buffer: sorted unique kept hashes (+ multiplicities) -------------------
@@ -346,7 +333,7 @@ class DeviceCtx {
     }
 
     hipStream_t stream_ = nullptr;
-    std::mutex mu_;
+    std::recursive_mutex mu_;
     DevBuf seq_, aa_, out_, uniq_, temp_, scalars_, pair_, flags_;
 };
 

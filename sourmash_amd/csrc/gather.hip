@@ -24,6 +24,8 @@
 #include <stdlib.h>
 #include <rocprim/device/device_scan.hpp>
 #include "gather_api.hpp"
+#include "arena.hpp"
+#include <chrono>
 #include "qindex.hpp"
 
 namespace smg {
@@ -986,70 +988,98 @@ static QIndex qindex_of(const GatherDev& g) { return QIndex{g.q_padded, g.nq, g.
         if (e_ != hipSuccess) return e_;   \
     } while (0)
 
-// Owned buffers come from the stream-ordered pool (its release threshold is raised in keep_pool()): a rebuilt index gets
-// its gigabytes back from the pool instead of from the driver, whose hipMalloc / hipFree of such sizes took 100+ ms on
-// some hosts (profiles/r02_gather_host_variance.txt).
-static void keep_pool() {
-    static const bool once = [] {
-        int dev = 0;
-        hipMemPool_t pool = nullptr;
-        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess && pool) {
-            uint64_t keep = ~0ull;
-            (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
-        }
-        return true;
-    }();
-    (void)once;
-}
+// Owned buffers and build scratch come from the arena (arena.hpp): blocks the library keeps between builds, so that a
+// rebuild of the same shape makes no driver call.  (Round 2 used hipMallocAsync with a raised release threshold; on the
+// benchmark host that still cost 175 ms per build against 6.9 ms of kernels -- VERDICT r02.)
 template <class T>
 static hipError_t own_alloc(GatherDev& g, T** p, size_t bytes, hipStream_t user = nullptr) {
-    keep_pool();
-    const hipError_t e = hipMallocAsync((void**)p, bytes, g.stream);
-    if (e != hipSuccess || user == nullptr || user == g.stream) return e;
-    return hipStreamSynchronize(g.stream);       // another stream is about to use the buffer: it must exist by then
+    return arena_alloc((void**)p, bytes, user ? user : g.stream);
+}
+
+static uint64_t host_ns() {
+    return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+static hipError_t timed_sync(GatherDev& g, hipStream_t stream) {
+    const uint64_t t0 = host_ns();
+    const hipError_t e = hipStreamSynchronize(stream);
+    g.build_sync_wait_ns += host_ns() - t0;
+    g.build_syncs++;
+    return e;
 }
 
 void gather_destroy(GatherDev& g) {
     void* owned[] = {g.q_padded, g.q_table, g.q_rec, g.alive, g.post_off, g.post_rows, g.qpos, g.counters, g.state, g.partials, g.out_idx, g.out_isect,
                      g.topk_sel, g.topk_partials, g.cmask, g.cand_count, g.cand_key, g.cand_len, g.cand_qpos, g.own_cands};
+    if (g.loop_stream) (void)hipStreamSynchronize(g.loop_stream);   // graph replays ran there; the blocks go back tagged with g.stream
     for (void* p : owned)
-        if (p) (void)hipFreeAsync(p, g.stream);
+        if (p) arena_free(p, g.stream);
+    if (g.pinned) arena_pinned_free(g.pinned);
+    if (g.ev_build0) (void)hipEventDestroy(g.ev_build0);
+    if (g.ev_build1) (void)hipEventDestroy(g.ev_build1);
     if (g.loop_graph) (void)hipGraphExecDestroy(g.loop_graph);
     if (g.loop_stream) (void)hipStreamDestroy(g.loop_stream);
     g = GatherDev();
 }
 
+hipError_t gather_build_kernel_ms(GatherDev& g, float* ms) {
+    *ms = 0.f;
+    if (!g.ev_build0 || !g.ev_build1) return hipSuccess;
+    SMG_TRY(hipEventSynchronize(g.ev_build1));
+    return hipEventElapsedTime(ms, g.ev_build0, g.ev_build1);
+}
+
+static hipError_t gather_build_body(GatherDev& g, hipStream_t stream);
+
 hipError_t gather_build(GatherDev& g, hipStream_t stream) {
     g.stream = stream;
+    const ArenaStats a0 = arena_stats();
+    const uint64_t t0 = host_ns();
+    g.build_syncs = g.build_sync_wait_ns = 0;
+    const hipError_t e = gather_build_body(g, stream);
+    if (e == hipSuccess && g.ev_build1) (void)hipEventRecord(g.ev_build1, stream);
+    const ArenaStats a1 = arena_stats();
+    g.build_host_ns = host_ns() - t0;
+    g.build_driver_ns = a1.driver_ns - a0.driver_ns;
+    g.build_driver_allocs = a1.driver_allocs - a0.driver_allocs;
+    return e;
+}
+
+static hipError_t gather_build_body(GatherDev& g, hipStream_t stream) {
     if (g.nq >= NONE32) return hipErrorInvalidValue;             // query positions are u32
     if (g.ndb >= NONE32) return hipErrorInvalidValue;            // row ids are u32
     const uint64_t nq1 = g.nq + 1;
+    SMG_TRY(arena_pinned_alloc((void**)&g.pinned, 32 * 8));
+    SMG_TRY(hipEventCreate(&g.ev_build0));
+    SMG_TRY(hipEventCreate(&g.ev_build1));
     SMG_TRY(own_alloc(g, &g.state, GS_SLOTS * 8));
     SMG_TRY(own_alloc(g, &g.partials, GATHER_PICK_BLOCKS * 8));
     SMG_TRY(own_alloc(g, &g.counters, (g.ndb + 1) * 8));
     SMG_TRY(own_alloc(g, &g.alive, g.nq + 16));
     SMG_TRY(own_alloc(g, &g.post_off, nq1 * 8));
+    SMG_TRY(hipEventRecord(g.ev_build0, stream));
     SMG_TRY(hipMemsetAsync(g.state, 0, GS_SLOTS * 8, stream));
     SMG_TRY(hipMemsetAsync(g.counters, 0, (g.ndb + 1) * 8, stream));
     SMG_TRY(hipMemsetAsync(g.alive, 1, g.nq + 16, stream));
-    SMG_TRY(hipMemcpyAsync(&g.state[GS_QLEN], &g.nq, 8, hipMemcpyHostToDevice, stream));
-    // database size and the largest query hash decide the table geometry
-    uint64_t total = 0;
-    g.q_max = 0;
-    if (g.ndb) SMG_TRY(hipMemcpyAsync(&total, g.offsets + g.ndb, 8, hipMemcpyDeviceToHost, stream));
-    g.longest_row = 0;
+    g.pinned[3] = g.nq;
+    SMG_TRY(hipMemcpyAsync(&g.state[GS_QLEN], &g.pinned[3], 8, hipMemcpyHostToDevice, stream));
+    // database size and the largest query hash decide the table geometry: read back into pinned slots 0..2
+    g.pinned[0] = g.pinned[1] = g.pinned[2] = 0;
+    if (g.ndb) SMG_TRY(hipMemcpyAsync(&g.pinned[0], g.offsets + g.ndb, 8, hipMemcpyDeviceToHost, stream));
     if (g.ndb) {                                                  // state[GS_KEY] as scratch: zeroed above, zeroed again by begin
         hipLaunchKernelGGL(longest_row_kernel, dim3(blocks_for_rows(g.ndb) > 256 ? 256 : blocks_for_rows(g.ndb)), dim3(256), 0,
                            stream, g.offsets, g.ndb, &g.state[GS_KEY]);
-        SMG_TRY(hipMemcpyAsync(&g.longest_row, &g.state[GS_KEY], 8, hipMemcpyDeviceToHost, stream));
+        SMG_TRY(hipMemcpyAsync(&g.pinned[1], &g.state[GS_KEY], 8, hipMemcpyDeviceToHost, stream));
         SMG_TRY(hipMemsetAsync(&g.state[GS_KEY], 0, 8, stream));
     }
-    if (g.nq) SMG_TRY(hipMemcpyAsync(&g.q_max, g.Q + g.nq - 1, 8, hipMemcpyDeviceToHost, stream));
-    SMG_TRY(hipStreamSynchronize(stream));
+    if (g.nq) SMG_TRY(hipMemcpyAsync(&g.pinned[2], g.Q + g.nq - 1, 8, hipMemcpyDeviceToHost, stream));
+    SMG_TRY(timed_sync(g, stream));                               // synchronisation 1 of 2
+    const uint64_t total = g.pinned[0];
+    g.longest_row = g.pinned[1];
+    g.q_max = g.pinned[2];
     SMG_TRY(own_alloc(g, &g.q_padded, (g.nq + 4) * 8));
     if (g.nq) SMG_TRY(hipMemcpyAsync(g.q_padded, g.Q, g.nq * 8, hipMemcpyDeviceToDevice, stream));
-    for (int i = 0; i < 4; ++i)                                   // &g.q_max outlives the copies: the stream is synchronised below
-        SMG_TRY(hipMemcpyAsync(g.q_padded + g.nq + i, &g.q_max, 8, hipMemcpyHostToDevice, stream));
+    for (int i = 0; i < 4; ++i) g.pinned[4 + i] = g.q_max;        // pinned: stays valid until the object goes
+    SMG_TRY(hipMemcpyAsync(g.q_padded + g.nq, &g.pinned[4], 4 * 8, hipMemcpyHostToDevice, stream));
     qindex_geometry(g.nq, g.q_max, &g.q_shift, &g.q_buckets);
     SMG_TRY(own_alloc(g, &g.q_table, ((uint64_t)g.q_buckets + 1) * 4));
     hipLaunchKernelGGL(qtable_kernel, dim3((g.q_buckets + 256) / 256), dim3(256), 0, stream, g.Q, g.nq, g.q_shift,
@@ -1063,16 +1093,17 @@ hipError_t gather_build(GatherDev& g, hipStream_t stream) {
     if (g.ndb == 0 || total == 0 || g.nq == 0) {
         SMG_TRY(hipMemsetAsync(g.post_off, 0, nq1 * 8, stream));
         g.npairs = 0;
-        return hipStreamSynchronize(stream);
+        return hipSuccess;
     }
     const QIndex qi = qindex_of(g);
-    unsigned long long* post_cnt = nullptr;
-    SMG_TRY(hipMallocAsync((void**)&post_cnt, nq1 * 8, stream));
+    ArenaBuf post_cnt_b, scan_tmp_b, bounds_b, partial_b, subcnt_b, inter_off_b, lay_tmp_b, inter_b;
+    SMG_TRY(post_cnt_b.get(nq1 * 8, stream));
+    unsigned long long* post_cnt = post_cnt_b.as<unsigned long long>();
     size_t scan_bytes = 0;
     SMG_TRY(rocprim::exclusive_scan(nullptr, scan_bytes, (uint64_t*)post_cnt, g.post_off, (uint64_t)0, (size_t)nq1,
                                     rocprim::plus<uint64_t>(), stream));
-    void* scan_tmp = nullptr;
-    SMG_TRY(hipMallocAsync(&scan_tmp, scan_bytes + 256, stream));
+    SMG_TRY(scan_tmp_b.get(scan_bytes + 256, stream));
+    void* scan_tmp = scan_tmp_b.p;
     SMG_TRY(own_alloc(g, &g.qpos, (total + 4) * 4));                // kept: apply reads it instead of looking hashes up again
     // Small problems: one atomic per element is cheapest.  Large ones: range-partitioned, histogram and cursors in LDS.
     const char* force = getenv("SMG_GATHER_BUILD");
@@ -1093,9 +1124,10 @@ hipError_t gather_build(GatherDev& g, hipStream_t stream) {
         SMG_TRY(hipGetLastError());
         SMG_TRY(rocprim::exclusive_scan(scan_tmp, scan_bytes, (uint64_t*)post_cnt, g.post_off, (uint64_t)0, (size_t)nq1,
                                         rocprim::plus<uint64_t>(), stream));
-        SMG_TRY(hipMemcpyAsync(&g.npairs, g.post_off + g.nq, 8, hipMemcpyDeviceToHost, stream));
+        SMG_TRY(hipMemcpyAsync(&g.pinned[8], g.post_off + g.nq, 8, hipMemcpyDeviceToHost, stream));
         SMG_TRY(hipMemcpyAsync(post_cnt, g.post_off, nq1 * 8, hipMemcpyDeviceToDevice, stream));   // cursors
-        SMG_TRY(hipStreamSynchronize(stream));
+        SMG_TRY(timed_sync(g, stream));                           // synchronisation 2 of 2
+        g.npairs = g.pinned[8];
         SMG_TRY(own_alloc(g, &g.post_rows, (g.npairs + 4) * 4));
         hipLaunchKernelGGL(build_fill_kernel, dim3(blocks_for_rows(g.ndb)), dim3(256), 0, stream, qpos, g.offsets, g.ndb,
                            post_cnt, g.post_rows);
@@ -1106,9 +1138,9 @@ hipError_t gather_build(GatherDev& g, hipStream_t stream) {
         if (B < B_min) B = B_min;
         if (B < 1) B = 1;
         const uint64_t rows_per_block = (g.ndb + B - 1) / B;
-        uint32_t *bounds = nullptr, *partial = nullptr;
-        SMG_TRY(hipMallocAsync((void**)&bounds, ((uint64_t)R + 1) * g.ndb * 4, stream));
-        SMG_TRY(hipMallocAsync((void**)&partial, B * g.nq * 4, stream));
+        SMG_TRY(bounds_b.get(((uint64_t)R + 1) * g.ndb * 4, stream));
+        SMG_TRY(partial_b.get(B * g.nq * 4, stream));
+        uint32_t *bounds = bounds_b.as<uint32_t>(), *partial = partial_b.as<uint32_t>();
         hipLaunchKernelGGL(build_bounds_kernel, dim3(blocks_for_rows(g.ndb)), dim3(256), 0, stream, g.Q, R, g.hashes,
                            g.offsets, g.ndb, bounds);
         SMG_TRY(hipGetLastError());
@@ -1118,8 +1150,10 @@ hipError_t gather_build(GatherDev& g, hipStream_t stream) {
         bool staged = !(fill_env && !strcmp(fill_env, "direct")) && g.ndb < (1ull << BR_ROWBITS);
         uint32_t *subcnt = nullptr, *inter_off = nullptr, *inter = nullptr;
         if (staged) {
-            SMG_TRY(hipMallocAsync((void**)&subcnt, (uint64_t)n_windows * B * 4, stream));
-            SMG_TRY(hipMallocAsync((void**)&inter_off, (uint64_t)n_windows * B * 4, stream));
+            SMG_TRY(subcnt_b.get((uint64_t)n_windows * B * 4, stream));
+            SMG_TRY(inter_off_b.get((uint64_t)n_windows * B * 4, stream));
+            subcnt = subcnt_b.as<uint32_t>();
+            inter_off = inter_off_b.as<uint32_t>();
             SMG_TRY(hipMemsetAsync(subcnt, 0, (uint64_t)n_windows * B * 4, stream));   // ranges past R launch nothing
         }
         const unsigned range_grid = (unsigned)(((R + 7) / 8) * 8 * B);
@@ -1132,21 +1166,22 @@ hipError_t gather_build(GatherDev& g, hipStream_t stream) {
         SMG_TRY(hipGetLastError());
         SMG_TRY(rocprim::exclusive_scan(scan_tmp, scan_bytes, (uint64_t*)post_cnt, g.post_off, (uint64_t)0, (size_t)nq1,
                                         rocprim::plus<uint64_t>(), stream));
-        SMG_TRY(hipMemcpyAsync(&g.npairs, g.post_off + g.nq, 8, hipMemcpyDeviceToHost, stream));
-        void* lay_tmp = nullptr;
+        SMG_TRY(hipMemcpyAsync(&g.pinned[8], g.post_off + g.nq, 8, hipMemcpyDeviceToHost, stream));
         if (staged) {
             // region of (window, row block) in the intermediate buffer: exclusive scan of the exact counts, window-major
             size_t lay_bytes = 0;
             SMG_TRY(rocprim::exclusive_scan(nullptr, lay_bytes, subcnt, inter_off, 0u, (size_t)n_windows * B, rocprim::plus<uint32_t>(), stream));
-            SMG_TRY(hipMallocAsync(&lay_tmp, lay_bytes + 256, stream));
-            SMG_TRY(rocprim::exclusive_scan(lay_tmp, lay_bytes, subcnt, inter_off, 0u, (size_t)n_windows * B, rocprim::plus<uint32_t>(), stream));
+            SMG_TRY(lay_tmp_b.get(lay_bytes + 256, stream));
+            SMG_TRY(rocprim::exclusive_scan(lay_tmp_b.p, lay_bytes, subcnt, inter_off, 0u, (size_t)n_windows * B, rocprim::plus<uint32_t>(), stream));
         }
-        SMG_TRY(hipStreamSynchronize(stream));
+        SMG_TRY(timed_sync(g, stream));                           // synchronisation 2 of 2
+        g.npairs = g.pinned[8];
         SMG_TRY(own_alloc(g, &g.post_rows, (g.npairs + 4) * 4));
         const uint64_t inter_words = g.npairs + 4;
         if (staged && (inter_words >= 0xffffffffull || B > 512)) staged = false;
         if (staged) {
-            SMG_TRY(hipMallocAsync((void**)&inter, inter_words * 4, stream));
+            SMG_TRY(inter_b.get(inter_words * 4, stream));
+            inter = inter_b.as<uint32_t>();
             if (fill_env && !strcmp(fill_env, "streams"))       // pass 2a without staging: 4-byte stores into 128 open streams
                 hipLaunchKernelGGL(build_range_kernel<2>, dim3(range_grid), dim3(BR_THREADS), 0, stream, qi, g.hashes, g.offsets,
                                    g.ndb, bounds, R, (uint32_t)B, rows_per_block, partial, (const uint64_t*)nullptr, (uint32_t*)nullptr,
@@ -1160,7 +1195,6 @@ hipError_t gather_build(GatherDev& g, hipStream_t stream) {
                                n_windows, (uint32_t)B, (const uint32_t*)partial, (const uint64_t*)g.post_off, (const uint32_t*)subcnt,
                                (const uint32_t*)inter_off, (const uint32_t*)inter, g.post_rows);
             SMG_TRY(hipGetLastError());
-            SMG_TRY(hipFreeAsync(inter, stream));
         } else {
             const bool absolute = g.npairs < 0xffffffffull;
             if (absolute) {
@@ -1174,39 +1208,40 @@ hipError_t gather_build(GatherDev& g, hipStream_t stream) {
                                (uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr);
             SMG_TRY(hipGetLastError());
         }
-        if (lay_tmp) SMG_TRY(hipFreeAsync(lay_tmp, stream));
-        if (subcnt) SMG_TRY(hipFreeAsync(subcnt, stream));
-        if (inter_off) SMG_TRY(hipFreeAsync(inter_off, stream));
-        SMG_TRY(hipFreeAsync(bounds, stream));
-        SMG_TRY(hipFreeAsync(partial, stream));
     }
-    SMG_TRY(hipFreeAsync(scan_tmp, stream));
-    SMG_TRY(hipFreeAsync(post_cnt, stream));
-    return hipStreamSynchronize(stream);
+    return hipSuccess;       // scratch blocks go back to the arena tagged with `stream` (ArenaBuf destructors): no wait needed
+}
+
+// state block for a new loop: rounds restart at 0; the uncovered set, its size and the counters carry over
+__global__ void gather_begin_kernel(unsigned long long* state, unsigned long long thr, unsigned long long maxr) {
+    const int i = threadIdx.x;
+    if (i >= GS_SLOTS) return;
+    unsigned long long v = 0;
+    if (i == GS_QLEN) v = state[GS_QLEN];
+    else if (i == GS_THR) v = thr;
+    else if (i == GS_MAXR) v = maxr;
+    state[i] = v;
 }
 
 hipError_t gather_begin(GatherDev& g, uint64_t thr_hashes, uint64_t max_rounds, hipStream_t stream) {
     if (max_rounds == 0) max_rounds = 1;
     if (max_rounds > g.out_cap) {
-        SMG_TRY(hipStreamSynchronize(stream));
-        if (g.out_idx) (void)hipFreeAsync(g.out_idx, stream);
-        if (g.out_isect) (void)hipFreeAsync(g.out_isect, stream);
+        // a captured loop graph has the old result pointers baked into its nodes: it goes with them
+        if (g.loop_graph) {
+            if (g.loop_stream) SMG_TRY(hipStreamSynchronize(g.loop_stream));
+            (void)hipGraphExecDestroy(g.loop_graph);
+            g.loop_graph = nullptr;
+        }
+        if (g.out_idx) arena_free(g.out_idx, stream);
+        if (g.out_isect) arena_free(g.out_isect, stream);
         g.out_idx = g.out_isect = nullptr;
         SMG_TRY(own_alloc(g, &g.out_idx, max_rounds * 8, stream));
         SMG_TRY(own_alloc(g, &g.out_isect, max_rounds * 8, stream));
         g.out_cap = max_rounds;
     }
-    // rounds restart at 0; the uncovered set, its size and the counters carry over
-    unsigned long long head[GS_SLOTS] = {0};
-    SMG_TRY(hipMemcpyAsync(head, g.state, GS_SLOTS * 8, hipMemcpyDeviceToHost, stream));
-    SMG_TRY(hipStreamSynchronize(stream));
-    const unsigned long long qlen = head[GS_QLEN];
-    memset(head, 0, sizeof(head));
-    head[GS_QLEN] = qlen;
-    head[GS_THR] = thr_hashes;
-    head[GS_MAXR] = max_rounds;
-    SMG_TRY(hipMemcpyAsync(g.state, head, GS_SLOTS * 8, hipMemcpyHostToDevice, stream));
-    return hipStreamSynchronize(stream);                          // `head` is on this stack frame
+    hipLaunchKernelGGL(gather_begin_kernel, dim3(1), dim3(64), 0, stream, g.state, (unsigned long long)thr_hashes,
+                       (unsigned long long)max_rounds);
+    return hipGetLastError();
 }
 
 hipError_t gather_pick(GatherDev& g, unsigned long long* d_key_out, int check_stop, hipStream_t stream) {
@@ -1299,8 +1334,7 @@ hipError_t gather_cands_load(GatherDev& g, const uint64_t* d_cands, uint32_t n_c
             hipLaunchKernelGGL(cands_clear_kernel, dim3(GATHER_CAND_MAX), dim3(256), 0, stream, g.cmask, g.cand_len, g.cand_qpos,
                                g.cand_qstride);
             SMG_TRY(hipMemsetAsync(g.cand_len, 0, GATHER_CAND_MAX * 4, stream));
-            SMG_TRY(hipStreamSynchronize(stream));
-            (void)hipFreeAsync(g.cand_qpos, stream);
+            arena_free(g.cand_qpos, stream);
             g.cand_qpos = nullptr;
         }
         SMG_TRY(own_alloc(g, &g.cand_qpos, (size_t)GATHER_CAND_MAX * stride * 4, stream));
@@ -1492,15 +1526,21 @@ __global__ __launch_bounds__(256) void overlap_finish_kernel(const unsigned long
 hipError_t overlap_ranges_launch(const uint64_t* Q, uint64_t nq, const uint64_t* hashes, const uint64_t* offsets, uint64_t ndb,
                                  unsigned long long* overlap, int op, hipStream_t stream) {
     if (nq == 0 || ndb == 0 || nq >= NONE32 || ndb >= NONE32) return hipErrorInvalidValue;
-    uint64_t q_max = 0;
-    SMG_TRY(hipMemcpyAsync(&q_max, Q + nq - 1, 8, hipMemcpyDeviceToHost, stream));
+    struct Pinned {
+        unsigned long long* p = nullptr;
+        ~Pinned() { if (p) arena_pinned_free(p); }
+    } pin;
+    SMG_TRY(arena_pinned_alloc((void**)&pin.p, 64));
+    SMG_TRY(hipMemcpyAsync(&pin.p[0], Q + nq - 1, 8, hipMemcpyDeviceToHost, stream));
     SMG_TRY(hipStreamSynchronize(stream));
+    const uint64_t q_max = pin.p[0];
     uint32_t shift = 0, buckets = 1;
     qindex_geometry(nq, q_max, &shift, &buckets);
-    uint32_t* table = nullptr;
-    unsigned long long* cnt = nullptr;
-    SMG_TRY(hipMallocAsync((void**)&table, ((uint64_t)buckets + 1) * 4 + 64, stream));
-    SMG_TRY(hipMallocAsync((void**)&cnt, ndb * 8 + 64, stream));
+    ArenaBuf table_b, cnt_b, q_padded_b, bounds_b, rec_b;
+    SMG_TRY(table_b.get(((uint64_t)buckets + 1) * 4 + 64, stream));
+    SMG_TRY(cnt_b.get(ndb * 8 + 64, stream));
+    uint32_t* table = table_b.as<uint32_t>();
+    unsigned long long* cnt = cnt_b.as<unsigned long long>();
     SMG_TRY(hipMemsetAsync(cnt, 0, ndb * 8 + 64, stream));
     hipLaunchKernelGGL(qtable_kernel, dim3((buckets + 256) / 256), dim3(256), 0, stream, Q, nq, shift, buckets, table);
     // streaming form (the query through LDS) unless a range of the table holds more query hashes than LDS has room for
@@ -1514,8 +1554,9 @@ hipError_t overlap_ranges_launch(const uint64_t* Q, uint64_t nq, const uint64_t*
         unsigned int* d_widest = (unsigned int*)(cnt + ndb);                // the 64 spare bytes, zeroed above
         hipLaunchKernelGGL(stream_range_max_kernel, dim3((n_ranges + 255) / 256), dim3(256), 0, stream, (const uint32_t*)table, buckets,
                            n_ranges, bpr, d_widest);
-        SMG_TRY(hipMemcpyAsync(&widest, d_widest, 4, hipMemcpyDeviceToHost, stream));
+        SMG_TRY(hipMemcpyAsync(&pin.p[1], d_widest, 4, hipMemcpyDeviceToHost, stream));
         SMG_TRY(hipStreamSynchronize(stream));
+        widest = (unsigned int)(pin.p[1] & 0xffffffffull);
     }
     hipError_t e = hipSuccess;
     if (!no_stream && widest <= (unsigned)SL_QCAP) {
@@ -1533,8 +1574,6 @@ hipError_t overlap_ranges_launch(const uint64_t* Q, uint64_t nq, const uint64_t*
         hipLaunchKernelGGL(stream_lookup_kernel<3>, dim3(n_blocks * n_groups), dim3(SL_THREADS), 0, stream, Q, (const uint32_t*)table, buckets,
                            shift, q_max, hashes, offsets, ndb, n_blocks, n_ranges, per, bpr, cnt);
     } else if (only_stream) {
-        (void)hipFreeAsync(table, stream);
-        (void)hipFreeAsync(cnt, stream);
         return hipErrorInvalidValue;
     } else {
         const uint32_t R = (uint32_t)((nq + BR_RANGE - 1) / BR_RANGE);
@@ -1542,12 +1581,12 @@ hipError_t overlap_ranges_launch(const uint64_t* Q, uint64_t nq, const uint64_t*
         if (B > (ndb + 127) / 128) B = (ndb + 127) / 128;
         if (B < 1) B = 1;
         const uint64_t rows_per_block = (ndb + B - 1) / B;
-        uint64_t* q_padded = nullptr;
-        uint32_t* bounds = nullptr;
-        QRec* rec = nullptr;
-        SMG_TRY(hipMallocAsync((void**)&q_padded, (nq + 4) * 8, stream));
-        SMG_TRY(hipMallocAsync((void**)&bounds, ((uint64_t)R + 1) * ndb * 4, stream));
-        SMG_TRY(hipMallocAsync((void**)&rec, (uint64_t)buckets * sizeof(QRec), stream));
+        SMG_TRY(q_padded_b.get((nq + 4) * 8, stream));
+        SMG_TRY(bounds_b.get(((uint64_t)R + 1) * ndb * 4, stream));
+        SMG_TRY(rec_b.get((uint64_t)buckets * sizeof(QRec), stream));
+        uint64_t* q_padded = q_padded_b.as<uint64_t>();
+        uint32_t* bounds = bounds_b.as<uint32_t>();
+        QRec* rec = rec_b.as<QRec>();
         SMG_TRY(hipMemcpyAsync(q_padded, Q, nq * 8, hipMemcpyDeviceToDevice, stream));
         for (int i = 0; i < 4; ++i) SMG_TRY(hipMemcpyAsync(q_padded + nq + i, Q + nq - 1, 8, hipMemcpyDeviceToDevice, stream));
         hipLaunchKernelGGL(qrec_kernel, dim3((buckets + 255) / 256), dim3(256), 0, stream, Q, (const uint32_t*)table, buckets, rec);
@@ -1556,14 +1595,9 @@ hipError_t overlap_ranges_launch(const uint64_t* Q, uint64_t nq, const uint64_t*
         hipLaunchKernelGGL(build_range_kernel<3>, dim3((unsigned)(((R + 7) / 8) * 8 * B)), dim3(BR_THREADS), 0, stream, qi, hashes, offsets,
                            ndb, (const uint32_t*)bounds, R, (uint32_t)B, rows_per_block, (uint32_t*)nullptr, (const uint64_t*)nullptr,
                            (uint32_t*)nullptr, cnt, (uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr);
-        (void)hipFreeAsync(q_padded, stream);
-        (void)hipFreeAsync(rec, stream);
-        (void)hipFreeAsync(bounds, stream);
     }
     hipLaunchKernelGGL(overlap_finish_kernel, dim3((unsigned)((ndb + 255) / 256)), dim3(256), 0, stream, cnt, ndb, overlap, op);
     e = hipGetLastError();
-    (void)hipFreeAsync(table, stream);
-    (void)hipFreeAsync(cnt, stream);
     return e;
 }
 

@@ -31,7 +31,7 @@ struct GatherDev {
     const uint64_t* hashes = nullptr;   // CSR database shard
     const uint64_t* offsets = nullptr;
     uint64_t ndb = 0, index_base = 0;
-    hipStream_t stream = nullptr;       // stream of the build: the owned buffers are stream-ordered pool allocations
+    hipStream_t stream = nullptr;       // stream of the build: the owned buffers are arena blocks (arena.hpp) released on it
     // owned
     uint64_t* q_padded = nullptr;       // copy of Q followed by 4 copies of its last element (lookups read 4 entries at once)
     uint32_t* q_table = nullptr;        // [q_buckets + 1] first-level table over Q: bucket b = x >> q_shift
@@ -65,6 +65,13 @@ struct GatherDev {
     uint32_t n_cand = 0;
     uint64_t* own_cands = nullptr;      // single-GPU loop: this shard's own export buffer
     uint64_t own_cands_words = 0;
+    // what the build cost (smgpu_gather_build_stats): host wall clock, kernel span between two events on the build's stream,
+    // driver allocator calls made through the arena during the build, host synchronisations
+    unsigned long long* pinned = nullptr;  // 32 x u64 of pinned host memory: scalar read-backs land here
+    hipEvent_t ev_build0 = nullptr, ev_build1 = nullptr;
+    double loop_gpu_ms = 0.0;
+    uint64_t loop_host_ns = 0;
+    uint64_t build_host_ns = 0, build_driver_ns = 0, build_driver_allocs = 0, build_syncs = 0, build_sync_wait_ns = 0;
     hipGraphExec_t loop_graph = nullptr;   // GATHER_GRAPH_ROUNDS rounds of pick + apply, captured once (hosts that launch slowly)
     hipStream_t loop_stream = nullptr;     // the graph's own stream (the legacy default stream cannot capture)
 };
@@ -76,8 +83,12 @@ constexpr unsigned GATHER_TOPK_MAX = 16;     // candidates a rank can export per
 constexpr unsigned GATHER_CAND_MAX = 64;     // candidates of all ranks together (one bit each in cmask)
 constexpr unsigned GATHER_CAND_HEAD = 3;     // record header words: key, bound, len
 
-// Build the inverted index and the initial counters (one-off; synchronises the stream once to size the postings).
+// Build the inverted index and the initial counters.  Synchronises the stream twice (sizes of the table / of the
+// postings must reach the host to size buffers) and returns with the last kernels still in flight on `stream`.
+// Every buffer comes from the arena: a rebuild of the same shape makes no driver call.
 hipError_t gather_build(GatherDev& g, hipStream_t stream);
+// milliseconds between the first and the last kernel of the build (waits for the build to finish)
+hipError_t gather_build_kernel_ms(GatherDev& g, float* ms);
 void gather_destroy(GatherDev& g);
 // Arm the loop: thresholds, result capacity (reallocated if too small), state reset except alive/counters.
 hipError_t gather_begin(GatherDev& g, uint64_t thr_hashes, uint64_t max_rounds, hipStream_t stream);

@@ -253,15 +253,14 @@ inline void sketch_file_with(IngestWorker& w, std::vector<KmerMinHash*>& mhs, co
         size_t cap = 0;
         unsigned long long count = 0;  // host copy, exact after a sync
     };
-    keep_pool_memory();
     std::vector<Acc> acc(mhs.size());
     struct FreeAcc {
         std::vector<Acc>& v;
         hipStream_t st;
-        ~FreeAcc() { for (auto& a : v) { if (a.out.p) (void)hipFreeAsync(a.out.p, st); if (a.cnt.p) (void)hipFreeAsync(a.cnt.p, st); a.out.p = a.cnt.p = nullptr; } }
+        ~FreeAcc() { for (auto& a : v) { if (a.out.p) arena_free(a.out.p, st); if (a.cnt.p) arena_free(a.cnt.p, st); a.out.p = a.cnt.p = nullptr; } }
     } free_acc{acc, st};
     for (auto& a : acc) {
-        hip_check(hipMallocAsync(&a.cnt.p, 64, st), "hipMallocAsync");
+        hip_check(arena_alloc(&a.cnt.p, 64, st), "arena_alloc");
         hip_check(hipMemsetAsync(a.cnt.p, 0, 64, st), "memset");
     }
 
@@ -377,9 +376,9 @@ inline void sketch_file_with(IngestWorker& w, std::vector<KmerMinHash*>& mhs, co
             if (need > a.cap) {
                 const size_t ncap = std::max(need + need / 2, (size_t)1 << 16);
                 void* bigger = nullptr;
-                hip_check(hipMallocAsync(&bigger, ncap * 8, st), "hipMallocAsync");
+                hip_check(arena_alloc(&bigger, ncap * 8, st), "arena_alloc");
                 if (a.count) hip_check(hipMemcpyAsync(bigger, a.out.p, (size_t)a.count * 8, hipMemcpyDeviceToDevice, st), "D2D");
-                if (a.out.p) hip_check(hipFreeAsync(a.out.p, st), "hipFreeAsync");
+                if (a.out.p) arena_free(a.out.p, st);
                 a.out.p = bigger;
                 a.cap = ncap;
             }
@@ -408,7 +407,7 @@ inline void sketch_file_with(IngestWorker& w, std::vector<KmerMinHash*>& mhs, co
 inline void sketch_file_into(std::vector<KmerMinHash*>& mhs, const std::string& path, uint64_t* n_records,
                              uint64_t* n_bases) {
     DeviceCtx& ctx = DeviceCtx::get();
-    std::lock_guard<std::mutex> g(ctx.mutex());
+    std::lock_guard<std::recursive_mutex> g(ctx.mutex());
     static IngestWorker& shared = *new IngestWorker();   // guarded by the context mutex; leaked on purpose like the
                                                          // context (its pinned buffers must not be freed after HIP is gone)
     shared.stream = ctx.stream();

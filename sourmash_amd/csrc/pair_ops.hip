@@ -16,6 +16,7 @@
 #include <cstring>
 #include <rocprim/device/device_select.hpp>
 #include "device_api.hpp"
+#include "arena.hpp"
 #include "pair_api.hpp"
 #include "qindex.hpp"
 #include "gather_api.hpp"
@@ -217,7 +218,7 @@ hipError_t overlap_vector_launch(const uint64_t* Q, uint64_t nq, const uint64_t*
     // scratch: header, padded query, table of at most 2 * nq + 2 entries; allocated and released in stream order
     uint8_t* scratch = nullptr;
     const size_t bytes = QIH_BYTES + (nq + 4) * 8 + (2 * nq + 4) * 4;
-    hipError_t e = hipMallocAsync((void**)&scratch, bytes, stream);
+    hipError_t e = arena_alloc((void**)&scratch, bytes, stream);
     if (e != hipSuccess) return e;
     const uint64_t copy_blocks = (nq + 4 + 255) / 256;
     hipLaunchKernelGGL(qindex_setup_kernel, dim3((unsigned)(copy_blocks < 1024 ? copy_blocks : 1024)), dim3(256), 0, stream, Q,
@@ -227,8 +228,8 @@ hipError_t overlap_vector_launch(const uint64_t* Q, uint64_t nq, const uint64_t*
     hipLaunchKernelGGL(overlap_vector_kernel, dim3((unsigned)(blocks < 8192 ? blocks : 8192)), dim3(256), 0, stream,
                        reinterpret_cast<const QIndexHeader*>(scratch), hashes, offsets, ndb, overlap, op);
     e = hipGetLastError();
-    const hipError_t f = hipFreeAsync(scratch, stream);
-    return e != hipSuccess ? e : f;
+    arena_free(scratch, stream);
+    return e;
 }
 
 // one workgroup per destination row: dst[dst_off[i] ..) = src[src_off[rows[i]] ..), 8-byte coalesced copies

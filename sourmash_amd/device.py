@@ -34,6 +34,20 @@ def _u64(torch, n, device):
     return torch.empty(int(n), dtype=torch.int64, device=device)
 
 
+def arena_stats():
+    "the library's device arena (csrc/arena.hpp): driver calls, time in the driver, reuse hits, bytes live / cached"
+    out = (C.c_uint64 * 8)()
+    lib.smgpu_arena_stats(out)
+    keys = ("driver_allocs", "driver_frees", "driver_ns", "reuse_hits", "live_bytes", "cached_bytes", "peak_bytes",
+            "cross_stream_waits")
+    return dict(zip(keys, (int(v) for v in out)))
+
+
+def arena_trim(keep_bytes=0):
+    "give the arena's cached blocks back to the driver"
+    lib.smgpu_arena_trim(int(keep_bytes))
+
+
 def synth_dna(n, seed=42, record_len=0, start=0, device="cuda", out=None):
     "n bytes of the BASELINE C2 random-DNA stream generated in HBM (uint8 tensor)."
     torch = _torch()

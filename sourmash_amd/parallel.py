@@ -134,6 +134,15 @@ class _DeviceGatherState:
         "single GPU: every round enqueued back to back, the host only polls the done flag"
         return self._fetch(self.lib.smgpu_gather_run)
 
+    def stats(self):
+        """what the index build and the last run() cost (smgpu_gather_stats): kernel spans from HIP events next to the
+        host wall clocks, driver-allocator time and calls, host synchronisations -- localises host effects"""
+        out = (C.c_double * 8)()
+        self.rustcall(self.lib.smgpu_gather_stats, self._ptr, out)
+        keys = ("build_kernels_ms", "build_host_ms", "build_driver_alloc_ms", "build_driver_allocs", "build_syncs",
+                "build_sync_wait_ms", "loop_gpu_ms", "loop_host_ms")
+        return {k: round(float(v), 3) for k, v in zip(keys, out)}
+
     def counters(self):
         "remaining overlap of every local dataset (host copy)"
         import numpy as np
@@ -343,7 +352,10 @@ def gather_distributed(query, nq, shard_hashes, shard_offsets, n_shard, index_ba
     stride = CAND_HEAD + max(int(layout_max.item()), 1)
     state.begin(thr, min(max_rounds, total) if max_rounds is not None else total)
     if world == 1 and not stepwise and not force_collectives:
-        return state.run()
+        res = state.run()
+        if stats is not None and hasattr(state, "stats"):
+            stats.update(state.stats())
+        return res
     k, rounds = exchange_geometry(world)
     mine = backend.zeros((k, stride), torch.int64)
     everyone = backend.zeros((world * k, stride), torch.int64) if collect else mine
@@ -368,6 +380,8 @@ def gather_distributed(query, nq, shard_hashes, shard_offsets, n_shard, index_ba
     if stats is not None:
         stats.update(exchanges=exchanges, rounds_per_exchange=rounds, records_per_rank=k, record_words=stride,
                      rounds=len(state.results()))
+        if hasattr(state, "stats"):
+            stats.update(state.stats())
     return state.results()
 
 

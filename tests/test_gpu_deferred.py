@@ -199,3 +199,43 @@ def test_c_method_and_ctypes_binding_agree(sm):
     frozen = a.to_frozen()
     with pytest.raises(TypeError):
         frozen.add_sequence("ACGT" * 10)                          # FrozenMinHash stays read-only
+
+
+def test_pending_sketches_straight_into_sketchset_and_counter(sm):
+    """A sketch whose records are still queued handed to SketchSet / the gather counter: both entry points take the
+    device context themselves, and settling the queue needs it too (round-2 advisor finding: self-deadlock on a
+    non-recursive mutex).  Runs under a watchdog so that a regression fails instead of hanging the suite."""
+    import threading
+    from sourmash_amd.index import SketchSet, _DeviceCounter
+    recs = _records(40, 400, seed=21)
+    result = {}
+
+    def body():
+        rows, wants = [], []
+        for i in range(4):
+            mh = sm.MinHash(0, 21, scaled=5)
+            want = oracle.OracleMinHash(0, 21, scaled=5)
+            for r in recs[i * 8:(i + 1) * 8 + 4]:
+                mh.add_sequence(r)
+                want.add_sequence(r.encode())
+            assert _pending(mh) > 0
+            rows.append(mh)
+            wants.append(want)
+        sset = SketchSet(rows)                                    # settles every row on the way in
+        assert [int(x) for x in sset.sizes] == [len(w) for w in wants]
+        query = sm.MinHash(0, 21, scaled=5)
+        qwant = oracle.OracleMinHash(0, 21, scaled=5)
+        for r in recs[:30]:
+            query.add_sequence(r)
+            qwant.add_sequence(r.encode())
+        assert _pending(query) > 0
+        counter = _DeviceCounter(sset, query)                     # and the query
+        got = [int(x) for x in counter.values()]
+        result["got"] = got
+        result["want"] = [int(oracle.intersection_size(qwant.mins, w.mins)[0]) for w in wants]
+
+    t = threading.Thread(target=body, daemon=True)
+    t.start()
+    t.join(120)
+    assert not t.is_alive(), "deadlock: SketchSet / counter construction from a sketch with queued records"
+    assert result["got"] == result["want"] and max(result["want"]) > 0

@@ -278,3 +278,47 @@ def test_gather_random_shapes_every_builder(monkeypatch):
             assert got == want, ("loop", case, build, fill, thr_bp)
         got = parallel.gather_distributed(q, len(qh), h, off, ndb, 0, thr_bp, 1000, be, stepwise=True)
         assert got == want, ("exchange protocol", case, thr_bp)
+
+
+def test_rebegin_with_more_rounds_after_graph_replay():
+    """A gather state that replayed its rounds as a captured hipGraph, armed again with a larger round cap: the result
+    arrays are reallocated, and the graph (whose nodes hold the old pointers) has to go with them (round-2 advisor finding:
+    use-after-free).  SMG_GATHER_GRAPH is read once per process, so this runs in its own interpreter."""
+    import os, subprocess, sys
+    from conftest import ROOT
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import test_gpu_gather as t\nt._rebegin_after_graph()\nprint('ok')\n" % (ROOT, os.path.join(ROOT, "tests")))
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, SMG_GATHER_GRAPH="1"))
+    assert p.returncode == 0 and p.stdout.strip().endswith("ok"), (p.stdout[-1500:], p.stderr[-1500:])
+
+
+def _rebegin_after_graph():
+    import torch
+    from sourmash_amd import device as smd, parallel
+    from sourmash_amd.synth import synth_gather
+    qh, dbh = synth_gather(n_query=50_000, n_db=900, db_size=500)
+    be = parallel.DeviceBackend()
+    h, off = smd.pack_csr(dbh)
+    q = torch.from_numpy(qh.view(np.int64).copy()).cuda()
+    want = oracle.gather(qh, *oracle.make_csr(dbh), threshold_bp=0, scaled=1000)
+    assert len(want) > 70
+    st = be.gather_state(q, len(qh), h, off, len(dbh), 0)
+    st.begin(0, 5)                                                # small cap: 5 rounds through the graph, then stop
+    assert st.run() == want[:5]
+    st.begin(0, len(dbh))                                         # larger cap: new result arrays, the loop carries on
+    got = st.run()
+    assert got == want[5:], (len(got), len(want))
+    # the arena served the rebuilt arrays; a second state of the same shape makes no driver call at all
+    a0 = smd.arena_stats()
+    st2 = be.gather_state(q, len(qh), h, off, len(dbh), 0)
+    st2.begin(0, 5)
+    assert st2.run() == want[:5]
+    del st2
+    st3 = be.gather_state(q, len(qh), h, off, len(dbh), 0)
+    st3.begin(0, len(dbh))
+    assert st3.run() == want
+    a1 = smd.arena_stats()
+    s = st3.stats()
+    assert s["build_driver_allocs"] == 0 and s["build_syncs"] == 2, s
+    assert a1["reuse_hits"] > a0["reuse_hits"]
