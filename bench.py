@@ -38,17 +38,16 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0      # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
 HBM_ACHIEVABLE_GBS = 6290.0  # same guide: 6.29 TB/s measured with a float4 copy
 LDS_PEAK_GBS = 150_000.0   # same guide, LDS: ~150 TB/s aggregate for ds_read_b64/b128 with every CU streaming
-# Counter readings of sketch_dna_kernel<31,16,false> on the default C2 batch, QUOTED from the committed PMC passes
-# (rocprofv3 --pmc, one counter group per run, tools/prof_r02.sh; profiles/README.md).  They are constants of an earlier run
-# of this same command, not measurements of the present one: the JSON labels them `*_quoted_from`.
-PMC_FILE = "profiles/r02_pmc.txt"
-PMC_C2_BYTES = 2 * 5_030_614 * 1024 + 78_534 * 1024      # 2 x FETCH_SIZE (gfx950 correction for 16 B/lane reads) + WRITE_SIZE
-PMC_C2_INPUT_BYTES = 9_990_000_999
-PMC_C2_VALU_INSTS = 18_194_765_969                        # SQ_INSTS_VALU, wave-instructions per launch
-PMC_C2_WAVE_CYCLES = 61_685_605_951                       # SQ_WAVE_CYCLES (quad-cycles, summed over waves)
-PMC_C2_WAIT_INST_ANY = 30_083_529_866                     # ... of which: waiting to issue (pipe busy / dependency)
-PMC_C2_ACTIVE_INST_ANY = 19_160_554_067                   # ... of which: issuing
-PMC_C2_GUI_ACTIVE = 593_932_343                           # GRBM_GUI_ACTIVE summed over the 8 XCDs, per launch (31.8 ms)
+# Counter readings (HBM traffic, SQ counters) are READ from the committed rocprofv3 --pmc summaries under profiles/ through
+# profiles/pmcfile.py, which also refuses them (null + note) when the kernel's source files have changed since the
+# profile was taken -- bench.py itself cannot run counters (they need their own rocprofv3 passes, tools/prof_r03.sh).
+sys.path.insert(0, os.path.join(ROOT, "profiles"))
+from pmcfile import PmcFile  # noqa: E402
+PMC_FILE = "profiles/r03_pmc.txt"
+PMC_GATHER_FILE = "profiles/r03_gather_pmc.txt"
+SKETCH_SOURCES = ["sketch.hip", "kmer_core.hpp", "murmur3.hpp"]
+GATHER_SOURCES = ["gather.hip", "qindex.hpp"]
+PMC_C2_INPUT_BYTES = 9_990_000_999                        # the launch the sketch counters were taken on (default C2 batch)
 N_SIMDS = 1024
 
 
@@ -174,26 +173,10 @@ def main():
         kept = int(cnt[0].item())
         alg_bytes = n_bytes + 8 * kept                      # 1 B/base in + 8 B per kept hash out
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
-        quoted = n_bytes == PMC_C2_INPUT_BYTES and args.ksize == 31
         roofline = {"bound": "hbm", "kernel": "sketch_dna_kernel<31,16>", "achieved": round(achieved, 2),
                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                    "traffic": PMC_C2_BYTES if quoted else None,
-                    "traffic_quoted_from": PMC_FILE + " (PMC passes of this same command, an earlier run)" if quoted else None,
                     "kernel_ms": round(kern_ms, 3), "algorithmic_bytes": alg_bytes,
-                    "valu": ({"insts_per_kmer": round(PMC_C2_VALU_INSTS * 64 / bases_per_step, 1),
-                              # counter-derived: VALU wave-instructions per SIMD and shader cycle (the ubenchmarked cost of this
-                              # kernel's mix is 2.4 cycles for and/or/xor/add/shift, 4.3 for multiplies, v_add3, permutes, selects)
-                              "valu_insts_per_simd_cycle": round(PMC_C2_VALU_INSTS / N_SIMDS / (PMC_C2_GUI_ACTIVE / 8), 4),
-                              "cycles_per_valu_inst_per_simd": round(N_SIMDS * (PMC_C2_GUI_ACTIVE / 8) / PMC_C2_VALU_INSTS, 2),
-                              # the kernel's static mix (71 % multiplies / v_add3 / permutes / selects at 4.3 cycles, the rest at
-                              # 2.4: profiles/r01_ubench_valu.txt) averages 3.76 cycles per instruction: issue-busy fraction
-                              "mix_cycles_per_valu_inst": 3.76,
-                              "valu_issue_busy_frac": round(3.76 * PMC_C2_VALU_INSTS / N_SIMDS / (PMC_C2_GUI_ACTIVE / 8), 3),
-                              "wave_cycles_issuing_frac": round(PMC_C2_ACTIVE_INST_ANY / PMC_C2_WAVE_CYCLES, 3),
-                              "wave_cycles_waiting_to_issue_frac": round(PMC_C2_WAIT_INST_ANY / PMC_C2_WAVE_CYCLES, 3),
-                              "quoted_from": PMC_FILE + " (SQ_INSTS_VALU, SQ_WAVE_CYCLES, SQ_WAIT_INST_ANY, SQ_ACTIVE_INST_ANY, "
-                                             "GRBM_GUI_ACTIVE; separate passes)"}
-                             if quoted else None),
+                    **sketch_counters(n_bytes, args.ksize, bases_per_step),
                     "note": "VALU-integer bound (12 x 64-bit multiplies per k-mer), see DESIGN.md; "
                             "kernel-only Gbase/s = %.1f" % (bases_per_step / (kern_ms * 1e-3) / 1e9)}
         del raw, cnt
@@ -273,6 +256,61 @@ def main():
     os.close(real_stdout)
     if out is not None:
         print(json.dumps(out), flush=True)
+
+
+def sketch_counters(n_bytes, ksize, bases_per_step):
+    """traffic + VALU counters of sketch_dna_kernel<31,16,false> from the committed PMC summary of this same command, or
+    nulls with the reason when they cannot be quoted (other input size, no summary, kernel sources changed since)"""
+    pmc = PmcFile(PMC_FILE)
+    why = None
+    if n_bytes != PMC_C2_INPUT_BYTES or ksize != 31:
+        why = "counters were taken on the default C2 batch only"
+    else:
+        why = pmc.stale(SKETCH_SOURCES)
+    K = "sketch_dna_kernel<31, 16, false>"
+    fetch, write = (pmc.get(K, "FETCH_SIZE"), pmc.get(K, "WRITE_SIZE")) if not why else (None, None)
+    if why or fetch is None or write is None:
+        return {"traffic": None, "traffic_note": why or f"{PMC_FILE} has no FETCH_SIZE / WRITE_SIZE rows for {K}", "valu": None}
+    out = {"traffic": int((2 * fetch + write) * 1024),
+           "traffic_from": PMC_FILE + ": 2 x FETCH_SIZE (gfx950 counts half of a 16 B/lane coalesced read, MI355X_MICROARCH.md) + "
+                           "WRITE_SIZE, KiB per dispatch, separate --pmc passes of `bench.py --steps 1 --warmup 0 --no-cpu-baseline "
+                           "--no-compare`; source hashes of " + ", ".join(SKETCH_SOURCES) + " match the present tree"}
+    g = {c: pmc.get(K, c) for c in ("SQ_INSTS_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "GRBM_GUI_ACTIVE")}
+    if all(v for v in g.values()):
+        gui = g["GRBM_GUI_ACTIVE"] / 8                     # summed over the 8 XCDs
+        out["valu"] = {"insts_per_kmer": round(g["SQ_INSTS_VALU"] * 64 / bases_per_step, 1),
+                       # VALU wave-instructions per SIMD and shader cycle (the ubenchmarked cost of this kernel's mix is 2.4
+                       # cycles for and/or/xor/add/shift, 4.3 for multiplies, v_add3, permutes, selects: r01_ubench_valu.txt)
+                       "valu_insts_per_simd_cycle": round(g["SQ_INSTS_VALU"] / N_SIMDS / gui, 4),
+                       "cycles_per_valu_inst_per_simd": round(N_SIMDS * gui / g["SQ_INSTS_VALU"], 2),
+                       "mix_cycles_per_valu_inst": 3.76,
+                       "valu_issue_busy_frac": round(3.76 * g["SQ_INSTS_VALU"] / N_SIMDS / gui, 3),
+                       "wave_cycles_issuing_frac": round(g["SQ_ACTIVE_INST_ANY"] / g["SQ_WAVE_CYCLES"], 3),
+                       "wave_cycles_waiting_to_issue_frac": round(g["SQ_WAIT_INST_ANY"] / g["SQ_WAVE_CYCLES"], 3),
+                       "from": PMC_FILE + " (SQ_INSTS_VALU, SQ_WAVE_CYCLES, SQ_WAIT_INST_ANY, SQ_ACTIVE_INST_ANY, GRBM_GUI_ACTIVE)"}
+    else:
+        out["valu"] = None
+    return out
+
+
+def gather_counters(db_bytes):
+    "(build traffic, overlap traffic, note): FETCH_SIZE + WRITE_SIZE per build / per overlap pass from the committed C5 PMC summary"
+    pmc = PmcFile(PMC_GATHER_FILE)
+    why = pmc.stale(GATHER_SOURCES) if db_bytes == 3997497344 else "counters were taken on config C5 only"
+    if why:
+        return None, None, why
+    build = 0.0
+    for k in ("build_bounds_kernel", "build_range_kernel<0>", "build_merge_counts_kernel", "build_partition_kernel", "build_scatter_kernel",
+              "qtable_kernel", "qrec_kernel"):
+        f, w = pmc.get(k, "FETCH_SIZE"), pmc.get(k, "WRITE_SIZE")
+        if f is None or w is None:
+            return None, None, f"{PMC_GATHER_FILE} has no rows for {k}"
+        build += f + w
+    fo, wo = pmc.get("stream_lookup_kernel<3>", "FETCH_SIZE"), pmc.get("stream_lookup_kernel<3>", "WRITE_SIZE")
+    over = None if fo is None or wo is None else int((fo + wo) * 1024)
+    return int(build * 1024), over, (PMC_GATHER_FILE + ": FETCH_SIZE + WRITE_SIZE as counted (KiB per dispatch, tools/bench_gather.py under separate "
+                                     "--pmc passes); FETCH_SIZE counts half of the bytes of wide coalesced reads on gfx950, so reads of the "
+                                     "database proper are under-counted by up to 2x")
 
 
 def cpu_baseline(args, seq, n_bytes, sk, np):
@@ -523,7 +561,8 @@ def single_gpu_extras(extra, torch, np, dev, be, smd, synth_sketches, synth_gath
         torch.cuda.synchronize()
         t2 = time.perf_counter()
     postings = int(be.lib.smgpu_gather_postings(st5._ptr))
-    st5_stats = st5.stats()                             # HIP events around the build's kernels and the loop's rounds
+    st5_stats = st5.stats()
+    pmc_build, pmc_overlap, pmc_note = gather_counters(int(gh5.numel() * 8))                             # HIP events around the build's kernels and the loop's rounds
     db_bytes = int(gh5.numel() * 8)
     # index build: every database hash is read once (8 B), one u32 row id is written per posting, the per-element query
     # position (4 B) is written by pass 1 and read by pass 2
@@ -538,9 +577,7 @@ def single_gpu_extras(extra, torch, np, dev, be, smd, synth_sketches, synth_gath
         "loop_kernels_ms": st5_stats["loop_gpu_ms"], "loop_host_ms": st5_stats["loop_host_ms"],
         "index_build_roofline": hbm_roofline(build_alg, (t1 - t0) * 1e3,
                                              "8 B per database hash + 4 B per posting + 2 x 4 B query position per element; wall clock of smgpu_gather_new_raw",
-                                             traffic=PMC_C5_BUILD_COUNTED if db_bytes == 3997497344 else None,
-                                             traffic_note="as counted (10.3 GB); with pass 1's read of the 4.0 GB database corrected for "
-                                                          "the counter's halving of coalesced reads: ~12.3 GB"),
+                                             traffic=pmc_build, traffic_note=pmc_note, kernels_ms=st5_stats["build_kernels_ms"]),
         "loop_floor_ms": round(postings / 23.0e9 * 1e3, 2),
         "loop_note": "a dependent chain of small kernels (latency, not bandwidth): %d rounds touch %.1f MB of postings in all; "
                      "one 64-bit counter decrement per posting, and the device does 23 G such atomics/s on 100,000 counters "
@@ -552,27 +589,18 @@ def single_gpu_extras(extra, torch, np, dev, be, smd, synth_sketches, synth_gath
     extra["overlaps_1M_vs_100000"] = {"ms": round(ms_ov, 3), "sketches_per_s": round(100_000 / (ms_ov * 1e-3), 1),
                                       "roofline": hbm_roofline(db_bytes + 8 * int(gq5.numel()), ms_ov,
                                                                "8 B per database hash + the query once; stream_lookup_kernel (query slices through LDS, every database hash looked at once)",
-                                                               traffic=PMC_C5_OVERLAP_COUNTED if db_bytes == 3997497344 else None,
-                                                               traffic_note="as counted (1.8x the database; up to 3.7x if its 8-byte-per-lane "
-                                                                            "reads are halved like pass 1's): lines a row visit stops in "
-                                                                            "are fetched again by the next range's visit (DESIGN.md 4.4)")}
+                                                               traffic=pmc_overlap, traffic_note=pmc_note)}
 
 
-# FETCH_SIZE + WRITE_SIZE per launch, in bytes, of the C5 kernels (profiles/r02_gather_pmc.txt, separate --pmc passes of
-# tools/bench_gather.py; KiB as counted).  FETCH_SIZE halves coalesced reads on gfx950 (MI355X_MICROARCH.md): pass 1 reads its
-# 4.0 GB of database and is counted with 2.37 GB, so the "corrected" figures add the database once per pass that reads it.
-PMC_C5_BUILD_COUNTED = int((985_497 + 125_005 + 1_269_823 + 511_293 + 2_309_879 + 29_153 + 257_813 + 1_133_146 + 975_447 + 2_456_248) * 1024)
-PMC_C5_OVERLAP_COUNTED = int((7_190_156 + 7_813) * 1024)
-PMC_C5_GATHER_FILE = "profiles/r02_gather_pmc.txt"
-
-
-def hbm_roofline(alg_bytes, ms, what, traffic=None, traffic_note=None):
-    achieved = alg_bytes / (ms * 1e-3) / 1e9
+def hbm_roofline(alg_bytes, ms, what, traffic=None, traffic_note=None, kernels_ms=None):
+    "ms: wall clock of the call; kernels_ms (HIP events around the kernels, when the library reports them) prices `achieved`"
+    use = kernels_ms if kernels_ms else ms
+    achieved = alg_bytes / (use * 1e-3) / 1e9
     out = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
            "frac": round(achieved / HBM_PEAK_GBS, 4), "frac_of_achievable": round(achieved / HBM_ACHIEVABLE_GBS, 4),
-           "algorithmic_bytes": int(alg_bytes), "ms": round(ms, 3), "traffic": traffic, "what": what}
-    if traffic is not None:
-        out["traffic_quoted_from"] = PMC_C5_GATHER_FILE + " (PMC passes of tools/bench_gather.py on the same configuration, an earlier run)"
+           "algorithmic_bytes": int(alg_bytes), "ms": round(use, 3), "wall_ms": round(ms, 3),
+           "frac_wall": round(alg_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "traffic": traffic, "what": what}
+    if traffic_note:
         out["traffic_note"] = traffic_note
     return out
 

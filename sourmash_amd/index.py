@@ -95,6 +95,34 @@ class Collection(RustObject):
         return SketchSet._from_objptr(self._methodcall(lib.smgpu_sketchset_from_collection))
 
 
+def rank_search_hits(shared, sizes, n_query, *, threshold=0.0, do_containment=False, do_max_containment=False, best_only=False):
+    """[(score, row)] best first from one overlap pass: shared[r] = |query ∩ row r|, sizes[r] = |row r|.  Jaccard by default,
+    query containment or max containment on request -- the scores of JaccardSearch (search.py:88-160); rows scoring below
+    the threshold or sharing nothing are dropped (index/__init__.py:115-170).  Shared by SketchSet.search (one GPU) and
+    parallel.search_distributed (database sharded over the ranks)."""
+    shared = np.asarray(shared).astype(np.float64)
+    sizes = np.asarray(sizes).astype(np.float64)
+    nq = float(n_query)
+    if do_containment:
+        score = shared / nq if nq else np.zeros_like(shared)
+    elif do_max_containment:
+        score = np.divide(shared, np.minimum(sizes, nq), out=np.zeros_like(shared), where=np.minimum(sizes, nq) > 0)
+    else:
+        union = sizes + nq - shared
+        score = np.divide(shared, union, out=np.zeros_like(shared), where=union > 0)
+    keep = np.flatnonzero((score >= threshold) & (score > 0))
+    order = keep[np.argsort(-score[keep], kind="stable")]
+    hits = [(float(score[r]), int(r)) for r in order]
+    return hits[:1] if best_only else hits
+
+
+def prefetch_rows(shared, threshold_bp, scaled):
+    "[(row, |intersect|)] in row order for the rows sharing at least threshold_bp with the query (search.py:956-976)"
+    shared = np.asarray(shared)
+    need = float(threshold_bp) / scaled if threshold_bp else 0.0
+    return [(int(r), int(shared[r])) for r in np.flatnonzero((shared >= need) & (shared > 0))]
+
+
 class SketchSet(RustObject):
     """n flat sketches packed as one device-resident CSR (smgpu_sketchset_*).
 
@@ -182,29 +210,15 @@ class SketchSet(RustObject):
             raise TypeError("'do_containment' and 'do_max_containment' cannot both be True")
         if (do_containment or do_max_containment) and not query_mh.scaled:
             raise TypeError("this search requires a scaled signature")
-        shared = self.overlaps(query_mh).astype(np.float64)
-        sizes = self.sizes.astype(np.float64)
-        nq = float(len(query_mh))
-        if do_containment:
-            score = shared / nq if nq else np.zeros_like(shared)
-        elif do_max_containment:
-            score = np.divide(shared, np.minimum(sizes, nq), out=np.zeros_like(shared), where=np.minimum(sizes, nq) > 0)
-        else:
-            union = sizes + nq - shared
-            score = np.divide(shared, union, out=np.zeros_like(shared), where=union > 0)
-        keep = np.flatnonzero((score >= threshold) & (score > 0))
-        order = keep[np.argsort(-score[keep], kind="stable")]
-        hits = [(float(score[r]), int(r)) for r in order]
-        return hits[:1] if best_only else hits
+        return rank_search_hits(self.overlaps(query_mh), self.sizes, len(query_mh), threshold=threshold,
+                                do_containment=do_containment, do_max_containment=do_max_containment, best_only=best_only)
 
     def prefetch(self, query_mh, threshold_bp=0):
         "Rows sharing at least threshold_bp with the query -> [(row, |intersect|)] in row order (search.py:956-976)."
         scaled = query_mh.scaled
         if not scaled:
             raise ValueError("prefetch requires scaled signatures")
-        shared = self.overlaps(query_mh)
-        need = float(threshold_bp) / scaled if threshold_bp else 0.0
-        return [(int(r), int(shared[r])) for r in np.flatnonzero((shared >= need) & (shared > 0))]
+        return prefetch_rows(self.overlaps(query_mh), threshold_bp, scaled)
 
     def gather(self, query_mh, threshold_bp=0):
         """Min-set-cover of the query by the rows of this set -> [(row, |intersect|)] in rank order; the whole

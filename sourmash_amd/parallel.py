@@ -385,6 +385,85 @@ def gather_distributed(query, nq, shard_hashes, shard_offsets, n_shard, index_ba
     return state.results()
 
 
+# ---------------------------------------------------------------------------------------------------
+# search / prefetch over a dataset-sharded database (index/__init__.py:115-170,241-256,
+# src/core/src/index/linear.rs:52-113): every rank runs ONE overlap pass over its shard, one all-gather hands everyone the
+# (|query ∩ row|, |row|) pairs of all rows -- 16 bytes per dataset where the dataset itself is ~40 KB -- and the
+# scoring / thresholding / ordering is the single-GPU code on the assembled vectors.
+
+def local_overlaps(query, nq, shard_hashes, shard_offsets, n_shard, backend):
+    "this rank's part: int64 [n_shard, 2] = (|query ∩ row|, |row|) for its rows, from one overlap pass"
+    torch = backend.torch
+    pairs = backend.zeros((max(n_shard, 1), 2), torch.int64)
+    if n_shard:
+        counts = backend.zeros((n_shard,), torch.int64)
+        backend.overlaps(query, nq, shard_hashes, shard_offsets, n_shard, counts, 0)
+        pairs[:n_shard, 0] = counts
+        pairs[:n_shard, 1] = shard_offsets[1:n_shard + 1] - shard_offsets[:n_shard]
+    return pairs[:n_shard]
+
+
+def assemble_overlaps(pieces, shard_rows):
+    "pieces[r]: rank r's padded [longest, 2] block; shard_rows[r]: its number of rows -> [total, 2] in global row order"
+    torch = __import__("torch")
+    return torch.cat([p[:n] for p, n in zip(pieces, shard_rows)]) if pieces else None
+
+
+def overlaps_distributed(query, nq, shard_hashes, shard_offsets, n_shard, index_base, backend, group=None,
+                         force_collectives=False):
+    "-> (shared, sizes): numpy u64 vectors over ALL datasets in global index order, identical on every rank"
+    return _overlaps_all(query, nq, shard_hashes, shard_offsets, n_shard, index_base, backend, group, force_collectives)[:2]
+
+
+def _overlaps_all(query, nq, shard_hashes, shard_offsets, n_shard, index_base, backend, group, force_collectives):
+    """-> (shared, sizes, first): `first` = the global index of row 0 of the assembled vectors.
+    Shards must be contiguous in the global numbering and ordered by rank (rank r holds [index_base, index_base + n_shard)),
+    as bench.py and gather_distributed lay them out; that layout is checked."""
+    import numpy as np
+    dist = _dist()
+    rank, world = world_info(group)
+    torch = backend.torch
+    mine = local_overlaps(query, nq, shard_hashes, shard_offsets, n_shard, backend)
+    if world == 1 and not force_collectives:
+        both = mine.cpu().numpy().view(np.uint64)
+        return both[:, 0].copy(), both[:, 1].copy(), int(index_base)
+    layout = backend.zeros((world, 2), torch.int64)
+    me = backend.zeros((1, 2), torch.int64)
+    me[0, 0], me[0, 1] = int(n_shard), int(index_base)
+    _all_gather_rows(dist, layout, me, world, group)                       # who holds what (16 bytes per rank)
+    rows = [int(x) for x in layout[:, 0].tolist()]
+    bases = [int(x) for x in layout[:, 1].tolist()]
+    if any(bases[r] != bases[0] + sum(rows[:r]) for r in range(world)):
+        raise ValueError("overlaps_distributed needs contiguous shards in rank order: bases %r, rows %r" % (bases, rows))
+    longest = max(max(rows), 1)
+    pad = backend.zeros((longest, 2), torch.int64)
+    pad[:n_shard] = mine
+    everyone = backend.zeros((world * longest, 2), torch.int64)
+    _all_gather_rows(dist, everyone, pad, world, group)                     # the ONE data collective
+    full = assemble_overlaps([everyone[r * longest:(r + 1) * longest] for r in range(world)], rows)
+    both = full.cpu().numpy().view(np.uint64)
+    return both[:, 0].copy(), both[:, 1].copy(), bases[0]
+
+
+def prefetch_distributed(query, nq, shard_hashes, shard_offsets, n_shard, index_base, threshold_bp, scaled, backend,
+                         group=None, force_collectives=False):
+    "[(global index, |intersect|)] in index order: datasets sharing >= threshold_bp with the query (search.py:956-976)"
+    from .index import prefetch_rows
+    shared, _, first = _overlaps_all(query, nq, shard_hashes, shard_offsets, n_shard, index_base, backend, group, force_collectives)
+    return [(first + r, c) for r, c in prefetch_rows(shared, threshold_bp, scaled)]
+
+
+def search_distributed(query, nq, shard_hashes, shard_offsets, n_shard, index_base, backend, group=None, threshold=0.0,
+                       do_containment=False, do_max_containment=False, best_only=False, force_collectives=False):
+    "[(score, global index)] best first (ties: lowest index) -- the scores of JaccardSearch (search.py:88-160)"
+    from .index import rank_search_hits
+    shared, sizes, first = _overlaps_all(query, nq, shard_hashes, shard_offsets, n_shard, index_base, backend, group,
+                                         force_collectives)
+    hits = rank_search_hits(shared, sizes, nq, threshold=threshold, do_containment=do_containment,
+                            do_max_containment=do_max_containment, best_only=best_only)
+    return [(s, first + r) for s, r in hits]
+
+
 def _all_gather_rows(dist, out, mine, world, group):
     "out[r * k : (r + 1) * k] = rank r's `mine`"
     if hasattr(dist, "all_gather_into_tensor") and out.is_cuda:

@@ -151,3 +151,51 @@ def test_gather_native_loops_agree(be, monkeypatch):
     dbh[11] = dbh[5].copy()
     want = oracle.gather(qh, *oracle.make_csr(dbh), threshold_bp=20_000, scaled=1000, nthreads=8)
     assert outs["scan"] == want and outs["replay"] == want
+
+
+def test_search_and_prefetch_over_emulated_shards(be):
+    """the database sharded by dataset, one overlap pass per shard (the streaming kernel for this query
+    size), the (count, size) pairs assembled in global order -- the all-gather replaced by the list of per-shard blocks --
+    then the single-GPU scoring.  World 1 end to end through search_distributed / prefetch_distributed as well."""
+    import torch
+    from sourmash_amd import device as smd, parallel
+    from sourmash_amd.index import rank_search_hits, prefetch_rows
+    from sourmash_amd.synth import synth_gather
+    qh, dbh = synth_gather(n_query=140_000, n_db=4500, db_size=300)
+    dbh[9] = np.zeros(0, dtype=np.uint64)
+    dbh[2000] = dbh[4].copy()                                    # identical rows in different shards: the lowest index ranks first
+    dbh[4400] = qh[::5].copy()                                   # fully contained in the query
+    q = torch.from_numpy(qh.view(np.int64).copy()).cuda()
+    want_shared = np.array([oracle.intersection_size(qh, d)[0] for d in dbh], dtype=np.uint64)
+    want_sizes = np.array([len(d) for d in dbh], dtype=np.uint64)
+    h, off = smd.pack_csr(dbh)
+    shared, sizes = parallel.overlaps_distributed(q, len(qh), h, off, len(dbh), 0, be)
+    assert np.array_equal(shared, want_shared) and np.array_equal(sizes, want_sizes)
+    for world in (2, 3, 8):
+        cuts = [len(dbh) * r // world for r in range(world + 1)]
+        pieces, rows = [], []
+        for lo, hi in zip(cuts, cuts[1:]):
+            sh, so = smd.pack_csr(dbh[lo:hi])
+            pieces.append(parallel.local_overlaps(q, len(qh), sh, so, hi - lo, be))
+            rows.append(hi - lo)
+        full = parallel.assemble_overlaps(pieces, rows).cpu().numpy().view(np.uint64)
+        assert np.array_equal(full[:, 0], want_shared) and np.array_equal(full[:, 1], want_sizes), world
+    # scoring on the assembled vectors = the reference's per-dataset scores (search.py:88-160), ties by lowest index
+    for mode in ({}, {"do_containment": True}, {"do_max_containment": True}):
+        hits = parallel.search_distributed(q, len(qh), h, off, len(dbh), 0, be, threshold=0.05, **mode)
+        ref = []
+        for i, d in enumerate(dbh):
+            c, u = oracle.intersection_size(qh, d)
+            if not c:
+                continue
+            sc = c / len(qh) if "do_containment" in mode else c / min(len(d), len(qh)) if "do_max_containment" in mode else c / u
+            if sc >= 0.05:
+                ref.append((sc, i))
+        ref.sort(key=lambda t: (-t[0], t[1]))
+        assert hits == ref and len(ref) > 1, mode
+    assert parallel.search_distributed(q, len(qh), h, off, len(dbh), 0, be, do_max_containment=True, best_only=True)[0][1] == 4400
+    pf = parallel.prefetch_distributed(q, len(qh), h, off, len(dbh), 0, 100_000, 1000, be)
+    assert pf == [(i, int(c)) for i, c in enumerate(want_shared) if c >= 100] and len(pf) > 2
+    assert pf == prefetch_rows(want_shared, 100_000, 1000)
+    assert rank_search_hits(want_shared, want_sizes, len(qh), best_only=True) == \
+        parallel.search_distributed(q, len(qh), h, off, len(dbh), 0, be, best_only=True)

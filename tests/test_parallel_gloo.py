@@ -65,6 +65,12 @@ class OracleBackend:
         np.fill_diagonal(j, 1.0)
         return torch.from_numpy(j)
 
+    def overlaps(self, query, nq, hashes, offsets, ndb, counters, op):
+        q, h, off = self._u64(query, nq), self._u64(hashes), self._u64(offsets)
+        assert op == 0
+        for d in range(ndb):
+            counters[d] = int(oracle.intersection_size(q, h[off[d]:off[d + 1]])[0])
+
     def gather_state(self, query, nq, hashes, offsets, ndb, index_base):
         return OracleGatherState(self._u64(query, nq), self._u64(hashes), self._u64(offsets), ndb, index_base)
 
@@ -192,6 +198,25 @@ def _worker(rank, world, port, ret):
             res[thr] = parallel.gather_distributed(q, len(qh), sh, soff, hi - lo, lo, thr, 1000, be)
         fh, foff = oracle.make_csr(dbh)
         ok_g = all(res[thr] == oracle.gather(qh, fh, foff, threshold_bp=thr, scaled=1000) for thr in res)
+        # ---- search / prefetch: one overlap pass per shard, one all-gather of (count, size) pairs ----
+        shared, sizes = parallel.overlaps_distributed(q, len(qh), sh, soff, hi - lo, lo, be)
+        want_shared = np.array([oracle.intersection_size(qh, d)[0] for d in dbh], dtype=np.uint64)
+        ok_o = np.array_equal(shared, want_shared) and np.array_equal(sizes, np.array([len(d) for d in dbh], dtype=np.uint64))
+        pf = parallel.prefetch_distributed(q, len(qh), sh, soff, hi - lo, lo, 30_000, 1000, be)
+        ok_o = ok_o and pf == [(i, int(c)) for i, c in enumerate(want_shared) if c >= 30 and c > 0] and len(pf) > 3
+        for mode in ({"do_containment": True}, {"do_max_containment": True}, {}):
+            hits = parallel.search_distributed(q, len(qh), sh, soff, hi - lo, lo, be, threshold=0.01, **mode)
+            ref = []
+            for i, d in enumerate(dbh):
+                c, u = oracle.intersection_size(qh, d)
+                sc = (c / len(qh) if "do_containment" in mode else c / min(len(d), len(qh)) if "do_max_containment" in mode
+                      else c / u) if c else 0.0
+                if sc >= 0.01 and sc > 0:
+                    ref.append((sc, i))
+            ref.sort(key=lambda t: (-t[0], t[1]))
+            ok_o = ok_o and hits == ref and len(hits) > 3
+        best = parallel.search_distributed(q, len(qh), sh, soff, hi - lo, lo, be, best_only=True)
+        ok_o = ok_o and best == ref[:1]                             # equal scores (rows 3, 7 and 40 are identical): the lowest index
         # ---- sketch: records dealt to the ranks, one all-gather of the kept hashes, union = sketch of everything ----
         seq = oracle.synth_dna(0, 600_000, seed=42, record_len=50_000)           # 11 records + separators
         bounds = [0, 6 * 50_001, len(seq)]                                       # whole records per rank
@@ -202,7 +227,7 @@ def _worker(rank, world, port, ret):
         big = torch.tensor([5, -3, -1, 7], dtype=torch.int64) if rank == 0 else torch.tensor([-2, 5], dtype=torch.int64)
         ordered = parallel.allgather_union(big).numpy().view(np.uint64)          # u64 order with the top bit set (scaled = 1)
         ok_s = ok_s and list(ordered) == sorted({5, 7, 2**64 - 3, 2**64 - 1, 2**64 - 2})
-        ret[rank] = (bool(ok_cmp), bool(ok_g), len(res[0]), bool(ok_s))
+        ret[rank] = (bool(ok_cmp), bool(ok_g), len(res[0]), bool(ok_s), bool(ok_o))
     finally:
         dist.destroy_process_group()
 
@@ -215,7 +240,8 @@ def test_two_rank_compare_and_gather_over_gloo():
     mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
     assert set(ret.keys()) == {0, 1}
     for r in range(world):
-        ok_cmp, ok_g, rounds, ok_s = ret[r]
+        ok_cmp, ok_g, rounds, ok_s, ok_o = ret[r]
+        assert ok_o, f"rank {r}: distributed overlaps / prefetch / search differ from the oracle"
         assert ok_s, f"rank {r}: all-gathered sketch union differs from the oracle's sketch of the whole input"
         assert ok_cmp, f"rank {r}: distributed compare differs from the oracle"
         assert ok_g, f"rank {r}: distributed gather differs from the oracle"
