@@ -1125,7 +1125,19 @@ static uint64_t gather_drain(GatherDev& g, uint64_t* out_idx, uint64_t* out_isec
     hip_check(hipEventRecord(ev0, st), "event");
     bool graph_synced = false;
     double gpu_ms_graph = 0.0;
-    for (;;) {
+    // the whole loop as one resident kernel when the index allows it (gather.hip: gather_loop_kernel)
+    bool persistent = false;
+    if (!replay && graph_mode != 1) hip_check(gather_run_persistent(g, st, &persistent), "gather loop (persistent)");
+    if (persistent) {
+        hip_check(hipMemcpyAsync(g.pinned + 16, g.state, sizeof(head), hipMemcpyDeviceToHost, st), "D2H");
+        hip_check(hipStreamSynchronize(st), "sync");
+        memcpy(head, g.pinned + 16, sizeof(head));
+        if (head[GS_ERR]) throw err_internal("gather loop: a workgroup waited too long for its peers (the device was shared?)");
+        if (trace)
+            fprintf(stderr, "[gather] persistent loop: %llu rounds, %.1f us\n", head[GS_ROUNDS],
+                    std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_all).count());
+    }
+    for (; !persistent;) {
         const auto t0 = std::chrono::steady_clock::now();
         hipStream_t bs = st;                                           // the stream this batch runs on
         if (use_graph && !graph_synced) {                              // the graph runs on the index's own stream: everything
@@ -1409,6 +1421,7 @@ void smgpu_counter_set(SmgpuCounter* p, uint64_t index, uint64_t value) {
         if (index >= c->set->n) throw err_internal("counter index out of range");
         DeviceCtx& ctx = DeviceCtx::get();
         std::lock_guard<std::recursive_mutex> g(ctx.mutex());
+        c->g.counters_touched = true;
         hip_check(hipMemcpyAsync(c->g.counters + index, &value, 8, hipMemcpyHostToDevice, ctx.stream()), "H2D");
         hip_check(hipStreamSynchronize(ctx.stream()), "sync");
     });

@@ -20,6 +20,7 @@
 // candidate -- provably the global arg-max while its key is not below any kept-back key (counters only decrease) --
 // and rounds run back to back with no exchange until that test fails.  See sourmash_amd/parallel.py.
 #include <hip/hip_runtime.h>
+#include <cstdio>
 #include <cstring>
 #include <stdlib.h>
 #include <rocprim/device/device_scan.hpp>
@@ -427,15 +428,23 @@ __global__ __launch_bounds__(BR_THREADS) void build_partition_kernel(uint64_t nq
 // blocks) + (what earlier batches of this workgroup put there).  Windows w = x (mod 8) run on workgroup ids = x (mod 8),
 // i.e. on one XCD, the groups of a window next to each other: the runs that neighbouring groups write into a list are
 // adjacent, and the lines they share meet in that XCD's L2.
+// ORDERED (row blocks per group <= BR_ORD_NB): the sort key is (list, row block), so that inside a list the entries of a
+// row block are contiguous and blocks ascend -- the run of block b in list j is then exactly
+// [post_off[j] + partial[b][j], post_off[j] + partial[b + 1][j]), which is what lets a workgroup of the persistent gather
+// loop read only ITS rows' part of a list.
+constexpr int BR_ORD_NB = 8;
+template <bool ORDERED>
 __global__ __launch_bounds__(512) void build_scatter_kernel(uint64_t nq, uint32_t n_windows, uint32_t B,
                                                             const uint32_t* __restrict__ partial,
                                                             const uint64_t* __restrict__ post_off,
                                                             const uint32_t* __restrict__ subcnt,
                                                             const uint32_t* __restrict__ inter_off,
                                                             const uint32_t* __restrict__ inter, uint32_t* __restrict__ post_rows) {
+    constexpr int NK = ORDERED ? BR_SUB * BR_ORD_NB : BR_SUB;        // sort keys
     __shared__ uint32_t s_sorted[BR_SORT_CAP];
-    __shared__ uint32_t s_cnt[BR_SUB], s_start[BR_SUB], s_fill[BR_SUB], s_cur[BR_SUB];
+    __shared__ uint32_t s_cnt[NK], s_start[NK + 1], s_fill[NK], s_cur[BR_SUB];
     __shared__ uint32_t s_pre[BR_GROUPS * 8 + 1], s_src[BR_GROUPS * 8];     // flat entry index -> region (at most 64 row blocks per group)
+    __shared__ uint32_t s_wsum[8];
     const uint32_t q = blockIdx.x >> 3, x = blockIdx.x & 7u;
     const uint32_t w = (q / BR_GROUPS) * 8u + x, g = q % BR_GROUPS;
     if (w >= n_windows) return;
@@ -463,31 +472,58 @@ __global__ __launch_bounds__(512) void build_scatter_kernel(uint64_t nq, uint32_
     const uint32_t total = s_pre[nb];
     for (uint32_t f0 = 0; f0 < total; f0 += BR_SORT_CAP) {
         const uint32_t f1 = f0 + BR_SORT_CAP < total ? f0 + BR_SORT_CAP : total;
-        for (uint32_t k = tid; k < (uint32_t)BR_SUB; k += blockDim.x) s_cnt[k] = 0;
+        for (uint32_t k = tid; k < (uint32_t)NK; k += blockDim.x) s_cnt[k] = 0;
         __syncthreads();
         // The batch is read ONCE, all of a thread's loads issued before the first is used (one load per step used to wait
         // for the one before: 24 dependent trips to L2 / HBM per thread and phase, and the batch was read twice).
         constexpr int PER = BR_SORT_CAP / 512;
         static_assert(BR_SORT_CAP % 512 == 0, "");
         uint32_t ent[PER];
+        uint32_t key[PER];
         {
             uint32_t reg = 0;
 #pragma unroll
             for (int i = 0; i < PER; ++i) {
                 const uint32_t f = f0 + (uint32_t)tid + (uint32_t)i * 512u;
                 ent[i] = 0;
+                key[i] = 0;
                 if (f < f1) {
                     while (f >= s_pre[reg + 1]) ++reg;
                     ent[i] = __builtin_nontemporal_load(&inter[(uint64_t)s_src[reg] + (f - s_pre[reg])]);
+                    key[i] = reg;
                 }
             }
         }
-        // histogram of the batch by list
+        // histogram of the batch by sort key
 #pragma unroll
         for (int i = 0; i < PER; ++i)
-            if (f0 + (uint32_t)tid + (uint32_t)i * 512u < f1) atomicAdd(&s_cnt[ent[i] & (BR_SUB - 1)], 1u);
+            if (f0 + (uint32_t)tid + (uint32_t)i * 512u < f1) {
+                key[i] = ORDERED ? (ent[i] & (BR_SUB - 1)) * BR_ORD_NB + key[i] : (ent[i] & (BR_SUB - 1));
+                atomicAdd(&s_cnt[key[i]], 1u);
+            }
         __syncthreads();
-        if (wave == 0) {                                            // exclusive scan of BR_SUB counts by one wave
+        if (ORDERED) {
+            // exclusive scan of NK = 2,048 counts: four consecutive keys per thread, wave scan, 8 wave totals
+            static_assert(!ORDERED || NK == 4 * 512, "");
+            const uint32_t c0 = s_cnt[4 * tid], c1 = s_cnt[4 * tid + 1], c2 = s_cnt[4 * tid + 2], c3 = s_cnt[4 * tid + 3];
+            const uint32_t mine = c0 + c1 + c2 + c3;
+            uint32_t incl = mine;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t o = __shfl_up(incl, d);
+                if (lane >= d) incl += o;
+            }
+            if (lane == 63) s_wsum[wave] = incl;
+            __syncthreads();
+            uint32_t before = 0;
+            for (int v = 0; v < wave; ++v) before += s_wsum[v];
+            const uint32_t e0 = before + incl - mine;
+            s_start[4 * tid] = e0;           s_fill[4 * tid] = e0;
+            s_start[4 * tid + 1] = e0 + c0;  s_fill[4 * tid + 1] = e0 + c0;
+            s_start[4 * tid + 2] = e0 + c0 + c1;  s_fill[4 * tid + 2] = e0 + c0 + c1;
+            s_start[4 * tid + 3] = e0 + c0 + c1 + c2;  s_fill[4 * tid + 3] = e0 + c0 + c1 + c2;
+            if (tid == 511) s_start[NK] = e0 + mine;
+        } else if (wave == 0) {                                     // exclusive scan of BR_SUB counts by one wave
             uint32_t carry = 0;
             for (int base = 0; base < BR_SUB; base += 64) {
                 const uint32_t v = s_cnt[base + lane];
@@ -501,22 +537,25 @@ __global__ __launch_bounds__(512) void build_scatter_kernel(uint64_t nq, uint32_
                 s_fill[base + lane] = carry + incl - v;
                 carry += __shfl(incl, 63);
             }
+            if (lane == 0) s_start[NK] = carry;
         }
         __syncthreads();
         // placement
 #pragma unroll
         for (int i = 0; i < PER; ++i)
             if (f0 + (uint32_t)tid + (uint32_t)i * 512u < f1)
-                s_sorted[atomicAdd(&s_fill[ent[i] & (BR_SUB - 1)], 1u)] = ent[i] >> BR_SUB_BITS;
+                s_sorted[atomicAdd(&s_fill[key[i]], 1u)] = ent[i] >> BR_SUB_BITS;
         __syncthreads();
         // every list's run goes out with consecutive lanes
+        constexpr uint32_t KPL = ORDERED ? BR_ORD_NB : 1;            // sort keys per list
         for (uint32_t jl = wave; jl < nl; jl += blockDim.x >> 6) {
-            const uint32_t n = s_cnt[jl], from = s_start[jl];
+            const uint32_t from = s_start[jl * KPL], n = s_start[(jl + 1) * KPL] - from;
             const uint64_t to = wbase + s_cur[jl];
             for (uint32_t i = lane; i < n; i += 64) post_rows[to + i] = s_sorted[from + i];
         }
         __syncthreads();
-        for (uint32_t k = tid; k < (uint32_t)BR_SUB; k += blockDim.x) s_cur[k] += s_cnt[k];
+        for (uint32_t k = tid; k < (uint32_t)BR_SUB; k += blockDim.x)
+            if (k < nl) s_cur[k] += s_start[(k + 1) * KPL] - s_start[k * KPL];
         __syncthreads();
     }
 }
@@ -962,6 +1001,321 @@ __global__ __launch_bounds__(256) void apply_kernel(QIndex qi, uint8_t* alive, c
     }
 }
 
+// ---- persistent loop: every round of the gather inside ONE launch --------------------------------------------------
+// The two-kernel round above is a chain of dependent trips to memory (winner key -> row offset -> positions -> alive ->
+// post_off -> postings -> counters, then the arg-max over all counters through a ticket) plus one device-scope atomic
+// per posting: 28.7 us per round at C5, of which 7.5 are the atomics at the device's rate (profiles/r02_gather_loops.txt).
+// Here one workgroup per CU stays resident for the whole loop and OWNS a contiguous range of rows:
+//   * its rows' counters live in LDS (plain LDS atomics; nobody else touches them), so a round has no device-scope
+//     atomic at all and the local arg-max needs no pass over global memory;
+//   * the uncovered set of the query is replicated as a bitmap in every workgroup's LDS (10^6 hashes = 125 KB of the
+//     160): test-and-clear is an LDS atomicAnd, deterministic and identical everywhere, so the set is never exchanged;
+//   * every workgroup walks the whole winning row (its query positions, written by the build's pass 1) and, for each
+//     newly covered hash, only the slice of the posting list that can hold ITS rows: pass 2b of the build writes a
+//     list as consecutive runs, one per row block in ascending order, whose boundaries are the per-block prefixes of pass 1;
+//   * the only exchange per round is an all-gather of one 32-byte record per workgroup -- local best key, start and
+//     length of that row -- as four 8-byte {epoch, value} granules written by ONE write-through store each and swept
+//     by every workgroup until all tags carry the round's epoch: barrier and data in one hop (MI355X_MICROARCH.md,
+//     "allgather" / R2 granules; no fence needed because nothing else mutable is shared: counters and bitmap are
+//     private, postings / positions / offsets are immutable during the loop).
+// Rounds, stop rules (search.py:15-37) and bookkeeping are replicated arithmetic on replicated values, so every
+// workgroup leaves the loop in the same round; workgroup 0 records the results.  At exit the counters and the bitmap
+// go back to the global arrays, so that the protocol entry points (peek / consume, counters_get, a second begin + run)
+// carry on from the same state.
+constexpr int PL_THREADS = 1024;
+constexpr int PL_ROW_PER = 4;                  // row elements per thread and chunk (chunk <= PL_ROW_PER * PL_THREADS)
+constexpr int PL_LANES = 2;                    // lanes per newly covered position when its row block's run is read (2 x 2 x 4 entries;
+                                               // a run is about 4 entries at C5: 250 per list over 64 row blocks)
+constexpr int PL_STEPS = 3;                    // positions per lane group whose loads are in flight together (3 x 512 per batch)
+constexpr uint32_t PL_SPIN_LIMIT = 1u << 22;   // sweeps before a workgroup gives up (a peer is not resident): seconds, not forever
+
+struct LoopArgs {
+    const uint64_t* offsets;
+    const uint32_t* qpos;
+    const uint32_t* post_rows;
+    const uint32_t* block_pre;          // [B][nq] start of row block b's run in list j, relative to post_off[j]
+    const uint64_t* post_off;
+    unsigned long long* counters;
+    uint8_t* alive;
+    unsigned long long* state;
+    uint64_t* out_idx;
+    uint64_t* out_isect;
+    unsigned long long* xchg;           // [2][n_wg * 4] granules, zeroed before the launch
+    uint64_t ndb, nq, index_base;
+    uint32_t rows_per_wg, block_rows, B, chunk, bitmap_words;
+    unsigned long long* dbg;            // SMG_GATHER_TRACE: [8] phase times of workgroup 0 in 10 ns ticks (null: not collected)
+};
+
+__device__ __forceinline__ unsigned long long gran_load(const unsigned long long* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void gran_store(unsigned long long* p, unsigned long long v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ __launch_bounds__(PL_THREADS) void gather_loop_kernel(LoopArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t pl_lds[];
+    uint32_t* s_bits = pl_lds;                                   // [bitmap_words] bit p set: query hash p is uncovered
+    uint32_t* s_cnt = s_bits + a.bitmap_words;                   // [rows_per_wg] |row ∩ uncovered| of the owned rows
+    uint32_t* s_off = s_cnt + a.rows_per_wg;                     // [rows_per_wg + 1] element offsets of the owned rows
+    uint32_t* s_I = s_off + a.rows_per_wg + 1;                   // [chunk] newly covered query positions of the chunk in flight
+    __shared__ unsigned long long s_red[PL_THREADS / 64];
+    __shared__ uint32_t s_nI, s_wstart, s_wlen;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t wg = blockIdx.x, n_wg = gridDim.x;
+    // Which rows a workgroup owns: consecutive ranges go to workgroups on the SAME XCD (workgroup b runs on XCD b % 8 --
+    // an observation that only buys speed): the 32 workgroups that read a group's runs then share one L2.
+    const uint32_t own = (n_wg % 8u == 0u) ? (wg % 8u) * (n_wg / 8u) + wg / 8u : wg;
+    const uint64_t r0 = (uint64_t)own * a.rows_per_wg < a.ndb ? (uint64_t)own * a.rows_per_wg : a.ndb;
+    const uint64_t r1 = r0 + a.rows_per_wg < a.ndb ? r0 + a.rows_per_wg : a.ndb;
+    const uint32_t n_own = (uint32_t)(r1 - r0);
+    // the row blocks whose runs hold rows r0 .. r1 - 1 (one block when the ranges are aligned, else two)
+    const uint32_t b0 = n_own ? (uint32_t)(r0 / a.block_rows) : 0u;
+    const uint32_t b1 = n_own ? (uint32_t)((r1 - 1) / a.block_rows) : 0u;
+    const bool to_list_end = b1 + 1 >= a.B;                       // the run ends where the list ends
+    // ---- load the state this loop starts from ----
+    for (uint32_t w = tid; w < a.bitmap_words; w += PL_THREADS) {
+        uint32_t bits = 0;
+        const uint64_t p0 = (uint64_t)w * 32;
+        if (p0 + 32 <= a.nq) {
+            const uint4 lo = *reinterpret_cast<const uint4*>(a.alive + p0), hi = *reinterpret_cast<const uint4*>(a.alive + p0 + 16);
+            const uint32_t v[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) bits |= ((v[k] >> (8 * b)) & 0xffu ? 1u : 0u) << (4 * k + b);
+        } else {
+            for (uint32_t b = 0; b < 32 && p0 + b < a.nq; ++b) bits |= (a.alive[p0 + b] ? 1u : 0u) << b;
+        }
+        s_bits[w] = bits;
+    }
+    for (uint32_t i = tid; i < a.rows_per_wg; i += PL_THREADS) s_cnt[i] = i < n_own ? (uint32_t)a.counters[r0 + i] : 0u;
+    for (uint32_t i = tid; i <= a.rows_per_wg; i += PL_THREADS) s_off[i] = (uint32_t)a.offsets[r0 + (i <= n_own ? i : n_own)];
+    unsigned long long qlen = a.state[GS_QLEN], rounds = a.state[GS_ROUNDS];
+    const unsigned long long thr = a.state[GS_THR], maxr = a.state[GS_MAXR];
+    unsigned long long last_key = 0;
+    bool failed = false;
+    __syncthreads();
+    const bool timing = a.dbg != nullptr && wg == 0 && tid == 0;
+    unsigned long long t_mark = timing ? wall_clock64() : 0, t_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+#define PL_WAITLAP(slot) do { if (a.dbg != nullptr && wg == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); PL_LAP(slot); } } while (0)
+#define PL_LAP(slot) do { if (timing) { const unsigned long long t_ = wall_clock64(); t_acc[slot] += t_ - t_mark; t_mark = t_; } } while (0)
+    if (timing) a.dbg[6] = t_mark;
+    for (uint32_t epoch = 1;; ++epoch) {
+        // ---- local best of the owned rows -> this workgroup's record of the epoch ----
+        unsigned long long k = 0;
+        for (uint32_t i = tid; i < n_own; i += PL_THREADS) {
+            const unsigned long long c = s_cnt[i];
+            if (c) {
+                const unsigned long long key = (c << 32) | (0xffffffffull & ~(unsigned long long)(a.index_base + r0 + i));
+                k = key > k ? key : k;
+            }
+        }
+        k = wave_max(k);
+        if (lane == 0) s_red[wave] = k;
+        __syncthreads();
+        if (tid == 0) {
+            for (int w = 1; w < PL_THREADS / 64; ++w) k = s_red[w] > k ? s_red[w] : k;
+            uint32_t start = 0, len = 0;
+            if (k) {
+                const uint32_t i = (uint32_t)((0xffffffffull & ~k) - a.index_base - r0);
+                start = s_off[i];
+                len = s_off[i + 1] - start;
+            }
+            unsigned long long* rec = a.xchg + (uint64_t)(epoch & 1u) * n_wg * 4 + (uint64_t)wg * 4;
+            const unsigned long long tag = (unsigned long long)epoch << 32;
+            gran_store(rec + 0, tag | (k >> 32));
+            gran_store(rec + 1, tag | (k & 0xffffffffull));
+            gran_store(rec + 2, tag | start);
+            gran_store(rec + 3, tag | len);
+            s_wstart = start;                                        // (reused below once the winner is known)
+            s_wlen = len;
+        }
+        __syncthreads();
+        // While the records travel: touch the positions of this workgroup's own best row, one lane per 64-byte line.  The
+        // round's winner is one of these rows, so its slice is in the memory-side cache (and one XCD's L2) when everybody asks.
+        {
+            const uint32_t ps = s_wstart, pl = s_wlen;
+            for (uint32_t i = (uint32_t)tid * 16u; i < pl; i += PL_THREADS * 16u)
+                (void)*reinterpret_cast<const volatile uint32_t*>(a.qpos + (uint64_t)ps + i);   // volatile: issued, its value unused
+        }
+        PL_LAP(0);                                                   // local arg-max + publish
+        // ---- sweep everyone's records until all of them carry this epoch: the winner of the round ----
+        const unsigned long long* all = a.xchg + (uint64_t)(epoch & 1u) * n_wg * 4;
+        unsigned long long best = 0;
+        uint32_t b_start = 0, b_len = 0;
+        for (uint32_t spins = 0;; ++spins) {
+            bool ok = true;
+            best = 0;
+            for (uint32_t sidx = tid; sidx < n_wg; sidx += PL_THREADS) {
+                const unsigned long long x0 = gran_load(all + (uint64_t)sidx * 4 + 0), x1 = gran_load(all + (uint64_t)sidx * 4 + 1),
+                                         x2 = gran_load(all + (uint64_t)sidx * 4 + 2), x3 = gran_load(all + (uint64_t)sidx * 4 + 3);
+                ok = ok && (x0 >> 32) == epoch && (x1 >> 32) == epoch && (x2 >> 32) == epoch && (x3 >> 32) == epoch;
+                const unsigned long long key = ((x0 & 0xffffffffull) << 32) | (x1 & 0xffffffffull);
+                if (key > best) { best = key; b_start = (uint32_t)x2; b_len = (uint32_t)x3; }
+            }
+            if (__syncthreads_and(ok ? 1 : 0)) break;
+            if (spins >= PL_SPIN_LIMIT) { failed = true; break; }        // uniform: every thread counts the same sweeps
+            __builtin_amdgcn_s_sleep(1);
+            if (timing) t_acc[5] += 1;                                  // sweeps that found a record missing
+        }
+        if (failed) break;
+        PL_LAP(1);                                                   // sweep
+        const unsigned long long mine = best;
+        best = wave_max(best);
+        best = __shfl(best, 0);
+        if (lane == 0) s_red[wave] = best;
+        __syncthreads();
+        unsigned long long top = 0;
+        for (int w = 0; w < PL_THREADS / 64; ++w) top = s_red[w] > top ? s_red[w] : top;
+        if (top != 0 && mine == top) { s_wstart = b_start; s_wlen = b_len; }   // keys are distinct: one writer
+        __syncthreads();
+        // ---- stop rules on the round's winner (search.py:15-37; the same values in every workgroup) ----
+        last_key = top;
+        if (top == 0 || qlen == 0 || qlen < thr || (top >> 32) < thr) break;
+        const uint32_t wstart = s_wstart, wlen = s_wlen;
+        // ---- apply: I = row ∩ uncovered leaves the set; the owned rows holding a hash of I lose it ----
+        uint32_t isect = 0;
+        // a thread's positions of a chunk are asked for together, and the NEXT chunk's before this chunk's postings are walked
+        uint32_t pos[PL_ROW_PER];
+#pragma unroll
+        for (int u = 0; u < PL_ROW_PER; ++u) {
+            const uint32_t i = (uint32_t)u * PL_THREADS + (uint32_t)tid;
+            pos[u] = i < wlen && i < a.chunk ? a.qpos[(uint64_t)wstart + i] : NONE32;
+        }
+        const uint32_t grp = (uint32_t)tid / PL_LANES, gl = (uint32_t)tid % PL_LANES;
+        constexpr uint32_t GROUPS = PL_THREADS / PL_LANES;
+        for (uint32_t c0 = 0; c0 < wlen; c0 += a.chunk) {
+            if (tid == 0) s_nI = 0;
+            __syncthreads();
+            PL_WAITLAP(6);                                           // (trace) waiting for the row's positions
+#pragma unroll
+            for (int u = 0; u < PL_ROW_PER; ++u) {
+                bool fresh = false;
+                if (pos[u] != NONE32) {
+                    const uint32_t bit = 1u << (pos[u] & 31u);
+                    fresh = (atomicAnd(&s_bits[pos[u] >> 5], ~bit) & bit) != 0;      // row hashes are distinct: no two lanes share a bit
+                }
+                const unsigned long long m = __ballot(fresh);
+                uint32_t base = 0;
+                if (lane == 0 && m) base = atomicAdd(&s_nI, (uint32_t)__popcll(m));  // one LDS atomic per wave, not per hit
+                base = __shfl(base, 0);
+                if (fresh) s_I[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = pos[u];
+            }
+            {
+                const uint32_t n0 = c0 + a.chunk, n1 = n0 + a.chunk < wlen ? n0 + a.chunk : wlen;
+#pragma unroll
+                for (int u = 0; u < PL_ROW_PER; ++u) {
+                    const uint32_t i = n0 + (uint32_t)u * PL_THREADS + (uint32_t)tid;
+                    pos[u] = i < n1 ? a.qpos[(uint64_t)wstart + i] : NONE32;
+                }
+            }
+            __syncthreads();
+            PL_LAP(2);                                               // row scan: positions + bitmap
+            const uint32_t nI = s_nI;
+            isect += nI;
+            if (n_own && nI) {
+                // PL_LANES lanes per newly covered position: the run of this workgroup's row block in that posting list is
+                // read as 16-byte pieces, two per lane.  PL_STEPS positions per lane group
+                // form a batch whose loads are in flight together; the bounds of the next batch are asked for before this
+                // batch's entries are used, so a further batch costs one trip to memory, not two.
+                uint32_t lo[PL_STEPS], hi[PL_STEPS];
+#pragma unroll
+                for (int st = 0; st < PL_STEPS; ++st) {
+                    const uint32_t k = (uint32_t)st * GROUPS + grp;
+                    lo[st] = hi[st] = 0;
+                    if (k < nI) {
+                        const uint64_t p = s_I[k];
+                        const uint32_t base = (uint32_t)a.post_off[p];
+                        const uint32_t rel_lo = a.block_pre[(uint64_t)b0 * a.nq + p];
+                        const uint32_t end = to_list_end ? (uint32_t)a.post_off[p + 1] : base + a.block_pre[(uint64_t)(b1 + 1) * a.nq + p];
+                        lo[st] = base + rel_lo;
+                        hi[st] = end;
+                    }
+                }
+                PL_WAITLAP(7);                                       // (trace) waiting for the first batch's run bounds
+                for (uint32_t k0 = 0; k0 < nI; k0 += GROUPS * PL_STEPS) {
+                    uint4 ent[PL_STEPS][2];
+#pragma unroll
+                    for (int st = 0; st < PL_STEPS; ++st)
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const uint32_t idx = lo[st] + ((uint32_t)h * PL_LANES + gl) * 4u;
+                            ent[st][h] = make_uint4(NONE32, NONE32, NONE32, NONE32);
+                            if (idx < hi[st]) __builtin_memcpy(&ent[st][h], a.post_rows + idx, 16);   // 4-byte aligned: one dwordx4 load
+                        }
+                    uint32_t lo_n[PL_STEPS], hi_n[PL_STEPS];
+#pragma unroll
+                    for (int st = 0; st < PL_STEPS; ++st) {
+                        const uint32_t k = k0 + GROUPS * PL_STEPS + (uint32_t)st * GROUPS + grp;
+                        lo_n[st] = hi_n[st] = 0;
+                        if (k < nI) {
+                            const uint64_t p = s_I[k];
+                            const uint32_t base = (uint32_t)a.post_off[p];
+                            const uint32_t rel_lo = a.block_pre[(uint64_t)b0 * a.nq + p];
+                            const uint32_t end = to_list_end ? (uint32_t)a.post_off[p + 1] : base + a.block_pre[(uint64_t)(b1 + 1) * a.nq + p];
+                            lo_n[st] = base + rel_lo;
+                            hi_n[st] = end;
+                        }
+                    }
+                    PL_WAITLAP(8);                                   // (trace) waiting for the batch's entries (+ next bounds)
+#pragma unroll
+                    for (int st = 0; st < PL_STEPS; ++st) {
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            const uint32_t idx = lo[st] + ((uint32_t)h * PL_LANES + gl) * 4u;
+                            const uint32_t r[4] = {ent[st][h].x, ent[st][h].y, ent[st][h].z, ent[st][h].w};
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (idx + (uint32_t)e < hi[st] && r[e] >= (uint32_t)r0 && r[e] < (uint32_t)r1)
+                                    atomicSub(&s_cnt[r[e] - (uint32_t)r0], 1u);
+                        }
+                        // runs longer than 2 x 4 x PL_LANES entries (rare): the rest, one entry per lane and step
+                        for (uint32_t idx = lo[st] + 8u * PL_LANES + gl; idx < hi[st]; idx += PL_LANES) {   // (8 = 2 pieces x 4 entries)
+                            const uint32_t r = a.post_rows[idx];
+                            if (r >= (uint32_t)r0 && r < (uint32_t)r1) atomicSub(&s_cnt[r - (uint32_t)r0], 1u);
+                        }
+                    }
+#pragma unroll
+                    for (int st = 0; st < PL_STEPS; ++st) { lo[st] = lo_n[st]; hi[st] = hi_n[st]; }
+                }
+            }
+            __syncthreads();
+            PL_LAP(3);                                               // run bounds + postings + LDS decrements
+        }
+        // ---- bookkeeping (pick_kernel's record_pending) ----
+        if (wg == 0 && tid == 0) {
+            a.out_idx[rounds] = 0xffffffffull & ~top;
+            a.out_isect[rounds] = isect;
+        }
+        qlen -= isect;
+        rounds += 1;
+        if (rounds >= maxr) break;
+    }
+    // ---- hand the state back ----
+    __syncthreads();
+    if (timing) {
+        a.dbg[7] = wall_clock64() - a.dbg[6];
+        for (int i = 0; i < 6; ++i) a.dbg[i] = t_acc[i];
+        for (int i = 6; i < 12; ++i) a.dbg[8 + i - 6] = t_acc[i];
+    }
+    for (uint32_t i = tid; i < n_own; i += PL_THREADS) a.counters[r0 + i] = s_cnt[i];
+    {   // the alive bytes of this workgroup's slice of the query
+        const uint64_t per = (a.nq + n_wg - 1) / n_wg;
+        const uint64_t p_lo = (uint64_t)wg * per < a.nq ? (uint64_t)wg * per : a.nq, p_hi = p_lo + per < a.nq ? p_lo + per : a.nq;
+        for (uint64_t p = p_lo + tid; p < p_hi; p += PL_THREADS) a.alive[p] = (uint8_t)((s_bits[p >> 5] >> (p & 31u)) & 1u);
+    }
+    if (wg == 0 && tid == 0) {
+        a.state[GS_KEY] = last_key;
+        a.state[GS_ROUNDS] = rounds;
+        a.state[GS_QLEN] = qlen;
+        a.state[GS_ACC] = 0;
+        a.state[GS_PENDING] = 0;
+        a.state[GS_DONE] = 1;
+    }
+    if (failed && tid == 0) a.state[GS_ERR] = 1;
+}
+
 __global__ __launch_bounds__(256) void longest_row_kernel(const uint64_t* __restrict__ offsets, uint64_t ndb,
                                                          unsigned long long* out) {
     unsigned long long m = 0;
@@ -1009,7 +1363,7 @@ static hipError_t timed_sync(GatherDev& g, hipStream_t stream) {
 
 void gather_destroy(GatherDev& g) {
     void* owned[] = {g.q_padded, g.q_table, g.q_rec, g.alive, g.post_off, g.post_rows, g.qpos, g.counters, g.state, g.partials, g.out_idx, g.out_isect,
-                     g.topk_sel, g.topk_partials, g.cmask, g.cand_count, g.cand_key, g.cand_len, g.cand_qpos, g.own_cands};
+                     g.topk_sel, g.topk_partials, g.cmask, g.cand_count, g.cand_key, g.cand_len, g.cand_qpos, g.own_cands, g.block_pre, g.loop_xchg};
     if (g.loop_stream) (void)hipStreamSynchronize(g.loop_stream);   // graph replays ran there; the blocks go back tagged with g.stream
     for (void* p : owned)
         if (p) arena_free(p, g.stream);
@@ -1191,10 +1545,24 @@ static hipError_t gather_build_body(GatherDev& g, hipStream_t stream) {
                                    (const uint32_t*)bounds, R, (uint32_t)B, rows_per_block, (const uint32_t*)g.qpos,
                                    (const uint32_t*)inter_off, inter);
             SMG_TRY(hipGetLastError());
-            hipLaunchKernelGGL(build_scatter_kernel, dim3((unsigned)((n_windows + 7) / 8 * 8 * BR_GROUPS)), dim3(512), 0, stream, g.nq,
-                               n_windows, (uint32_t)B, (const uint32_t*)partial, (const uint64_t*)g.post_off, (const uint32_t*)subcnt,
-                               (const uint32_t*)inter_off, (const uint32_t*)inter, g.post_rows);
+            const uint32_t per = (uint32_t)((B + BR_GROUPS - 1) / BR_GROUPS);
+            const bool ordered = per <= (uint32_t)BR_ORD_NB;            // row-block runs inside every list (persistent loop)
+            if (ordered)
+                hipLaunchKernelGGL(build_scatter_kernel<true>, dim3((unsigned)((n_windows + 7) / 8 * 8 * BR_GROUPS)), dim3(512), 0, stream, g.nq,
+                                   n_windows, (uint32_t)B, (const uint32_t*)partial, (const uint64_t*)g.post_off, (const uint32_t*)subcnt,
+                                   (const uint32_t*)inter_off, (const uint32_t*)inter, g.post_rows);
+            else
+                hipLaunchKernelGGL(build_scatter_kernel<false>, dim3((unsigned)((n_windows + 7) / 8 * 8 * BR_GROUPS)), dim3(512), 0, stream, g.nq,
+                                   n_windows, (uint32_t)B, (const uint32_t*)partial, (const uint64_t*)g.post_off, (const uint32_t*)subcnt,
+                                   (const uint32_t*)inter_off, (const uint32_t*)inter, g.post_rows);
             SMG_TRY(hipGetLastError());
+            if (ordered && g.npairs < 0xffffffffull) {
+                // the per-block prefixes stay with the index: [B][nq] starts of every row block's run inside every list
+                g.block_pre = partial;
+                partial_b.p = nullptr;                                  // ownership moves to the index (freed by gather_destroy)
+                g.block_B = (uint32_t)B;
+                g.block_rows = (uint32_t)rows_per_block;
+            }
         } else {
             const bool absolute = g.npairs < 0xffffffffull;
             if (absolute) {
@@ -1265,6 +1633,65 @@ hipError_t gather_consume_list(GatherDev& g, const uint64_t* d_list, hipStream_t
     hipLaunchKernelGGL(apply_kernel<false>, dim3(128), dim3(256), 0, stream, qindex_of(g), g.alive, g.post_off,
                        g.post_rows, g.counters, g.state, d_list, g.hashes, g.offsets, g.index_base, g.qpos, no_cands());
     return hipGetLastError();
+}
+
+hipError_t gather_run_persistent(GatherDev& g, hipStream_t stream, bool* ran) {
+    *ran = false;
+    static const bool off = [] { const char* e = getenv("SMG_GATHER_LOOP"); return e && strcmp(e, "persistent") != 0; }();
+    if (off || !g.block_pre || g.counters_touched || g.ndb == 0 || g.nq == 0 || !g.out_idx) return hipSuccess;
+    int dev = 0, n_cu = 0;
+    SMG_TRY(hipGetDevice(&dev));
+    SMG_TRY(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+    if (n_cu <= 0) return hipSuccess;
+    const int lds_max = 160 * 1024;                                // gfx950: 160 KiB per CU, one workgroup per CU here
+    // element offsets travel as 32-bit granule payloads
+    if (g.pinned[0] >= 0xffffffffull) return hipSuccess;           // pinned[0]: the shard's element count, read by the build
+    LoopArgs a;
+    a.offsets = g.offsets; a.qpos = g.qpos; a.post_rows = g.post_rows; a.block_pre = g.block_pre; a.post_off = g.post_off;
+    a.counters = g.counters; a.alive = g.alive; a.state = g.state; a.out_idx = g.out_idx; a.out_isect = g.out_isect;
+    a.ndb = g.ndb; a.nq = g.nq; a.index_base = g.index_base;
+    a.rows_per_wg = (uint32_t)((g.ndb + (uint64_t)n_cu - 1) / (uint64_t)n_cu);
+    a.block_rows = g.block_rows;
+    a.B = g.block_B;
+    a.bitmap_words = (uint32_t)((g.nq + 31) / 32);
+    const size_t fixed = ((size_t)a.bitmap_words + 2 * (size_t)a.rows_per_wg + 1) * 4;
+    const size_t budget = (size_t)lds_max - 1024;                  // the kernel's static scalars
+    a.chunk = 4096;
+    while (a.chunk > 512 && fixed + (size_t)a.chunk * 4 > budget) a.chunk >>= 1;
+    if (fixed + (size_t)a.chunk * 4 > budget) return hipSuccess;    // query or rows too large for LDS: the two-kernel rounds
+    const size_t lds = fixed + (size_t)a.chunk * 4;
+    static int attr_state = 0;                                     // 1: set, -1: the runtime refused (no persistent loop)
+    if (attr_state == 0) {
+        const hipError_t e = hipFuncSetAttribute((const void*)gather_loop_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)budget);
+        attr_state = e == hipSuccess ? 1 : -1;
+        if (e != hipSuccess) (void)hipGetLastError();
+    }
+    if (attr_state < 0) return hipSuccess;
+    if (!g.loop_xchg || g.loop_wgs != (uint32_t)n_cu) {
+        if (g.loop_xchg) arena_free(g.loop_xchg, stream);
+        g.loop_xchg = nullptr;
+        SMG_TRY(own_alloc(g, &g.loop_xchg, ((size_t)2 * n_cu * 4 + 16) * 8, stream));
+        g.loop_wgs = (uint32_t)n_cu;
+    }
+    a.xchg = g.loop_xchg;
+    static const bool trace = getenv("SMG_GATHER_TRACE") != nullptr;
+    a.dbg = trace ? g.loop_xchg + (size_t)2 * n_cu * 4 : nullptr;           // 8 words behind the granules
+    SMG_TRY(hipMemsetAsync(g.loop_xchg, 0, ((size_t)2 * n_cu * 4 + 16) * 8, stream));   // epochs count from 1 within a launch
+    void* params[] = {&a};
+    // cooperative: the runtime refuses a grid that cannot be resident at once (the loop's sweeps wait for every workgroup)
+    SMG_TRY(hipLaunchCooperativeKernel((const void*)gather_loop_kernel, dim3((unsigned)n_cu), dim3(PL_THREADS), params, (unsigned)lds, stream));
+    *ran = true;
+    if (trace) {
+        unsigned long long d[16];
+        SMG_TRY(hipMemcpyAsync(d, a.dbg, sizeof(d), hipMemcpyDeviceToHost, stream));
+        SMG_TRY(hipStreamSynchronize(stream));
+        fprintf(stderr, "[gather] persistent loop, workgroup 0 (us): argmax+publish %.1f, sweep %.1f (%llu empty sweeps), row scan %.1f, "
+                        "postings %.1f, whole loop %.1f; lds %zu B, chunk %u, rows/wg %u, row blocks %u\n",
+                d[0] * 0.01, d[1] * 0.01, d[5], d[2] * 0.01, d[3] * 0.01, d[7] * 0.01, lds, a.chunk, a.rows_per_wg, a.B);
+        fprintf(stderr, "[gather]   of which waiting for: row positions %.1f, first run bounds %.1f, entries %.1f\n", d[8] * 0.01, d[9] * 0.01,
+                d[10] * 0.01);
+    }
+    return hipSuccess;
 }
 
 hipError_t gather_enqueue_rounds(GatherDev& g, unsigned rounds, hipStream_t stream) {

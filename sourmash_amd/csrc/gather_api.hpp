@@ -21,6 +21,7 @@ enum GatherSlot {
     GS_NEEDX = 9,    // replay: the best candidate fell below what a rank kept back -> the next exchange decides
     GS_WSLOT = 10,   // replay: candidate slot of the round's winner
     GS_BOUND = 11,   // replay: largest key any rank kept back at the last exchange (0: nothing kept back)
+    GS_ERR = 12,     // persistent loop: a workgroup gave up waiting for its peers (not all resident)
     GS_SLOTS = 16
 };
 
@@ -43,6 +44,13 @@ struct GatherDev {
     uint32_t* post_rows = nullptr;      // local row ids
     uint32_t* qpos = nullptr;           // [database elements] position in Q of every element of the shard (NONE32: not in Q):
                                         // a round applied from the local CSR skips the lookup (two dependent loads)
+    uint32_t* block_pre = nullptr;      // [block_B][nq] start of row block b's run inside posting list j, relative to post_off[j]
+                                        // (staged range build with block-ordered lists only): the persistent loop's workgroups
+                                        // read only their rows' part of a list
+    uint32_t block_B = 0, block_rows = 0;
+    unsigned long long* loop_xchg = nullptr;   // persistent loop: [2][workgroups][4] record granules
+    uint32_t loop_wgs = 0;
+    bool counters_touched = false;      // a caller overwrote counters (smgpu_counter_set): the fused loops keep to saturating steps
     uint64_t npairs = 0;
     uint64_t longest_row = 0;           // hashes in the shard's longest row (sizes the candidate records)
     unsigned long long* counters = nullptr;   // [ndb] |row_d ∩ uncovered query|
@@ -113,6 +121,10 @@ hipError_t gather_enqueue_replay(GatherDev& g, unsigned exchanges, hipStream_t s
 // CounterGather.consume for a caller-provided list ([len, hashes...] on device, every hash a member of Q):
 // counters[d] -= |list ∩ row_d| (saturating at 0), and the hashes leave the uncovered set.
 hipError_t gather_consume_list(GatherDev& g, const uint64_t* d_list, hipStream_t stream);
+// The whole armed loop as ONE resident kernel (gather.hip: gather_loop_kernel), when the index was built by the staged
+// range builder and the query's bitmap + a workgroup's rows fit LDS; *ran = false (and nothing launched) otherwise.
+// The caller synchronises the stream and reads the state block as after any batch of rounds.
+hipError_t gather_run_persistent(GatherDev& g, hipStream_t stream, bool* ran);
 // Enqueue `rounds` rounds of pick(check) + apply on one GPU (kernels are no-ops once GS_DONE is set).
 hipError_t gather_enqueue_rounds(GatherDev& g, unsigned rounds, hipStream_t stream);
 // The same rounds as replays of one captured graph of GATHER_GRAPH_ROUNDS rounds (rounded up): one host call per 64

@@ -322,3 +322,57 @@ def _rebegin_after_graph():
     s = st3.stats()
     assert s["build_driver_allocs"] == 0 and s["build_syncs"] == 2, s
     assert a1["reuse_hits"] > a0["reuse_hits"]
+
+
+def test_persistent_loop_equals_two_kernel_rounds():
+    """The resident one-launch loop (gather.hip: gather_loop_kernel; taken when the staged range builder made the index) and
+    the two-kernel rounds (SMG_GATHER_LOOP=scan) give the oracle's ordered picks, the same final counters, and a state a
+    second begin + run carries on from.  The switch is read once per process: one interpreter per loop form."""
+    import os, subprocess, sys, json
+    from conftest import ROOT
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import test_gpu_gather as t\nt._loop_forms()\n" % (ROOT, os.path.join(ROOT, "tests")))
+    outs = {}
+    for form in ("persistent", "scan"):
+        p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900,
+                           env=dict(os.environ, SMG_GATHER_LOOP=form, SMG_GATHER_BUILD="ranges"))
+        assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-1500:])
+        outs[form] = json.loads(p.stdout.strip().splitlines()[-1])
+    assert outs["persistent"] == outs["scan"]
+
+
+def _loop_forms():
+    import json
+    import torch
+    from sourmash_amd import device as smd, parallel
+    from sourmash_amd.synth import synth_gather
+    be = parallel.DeviceBackend()
+    digest = []
+    for nq, ndb, size, base in ((70_000, 3000, 400, 0), (40_000, 300, 900, 1000), (33_000, 5, 2000, 7), (100_000, 9000, 120, 0)):
+        qh, dbh = synth_gather(n_query=nq, n_db=ndb, db_size=size)
+        if ndb > 20:
+            dbh[11] = dbh[5].copy()                               # a tie: the lower index wins
+            dbh[3] = np.zeros(0, dtype=np.uint64)
+            dbh[4] = np.array([1, 2, 3], dtype=np.uint64)
+        h, off = smd.pack_csr(dbh)
+        q = torch.from_numpy(qh.view(np.int64).copy()).cuda()
+        fh, foff = oracle.make_csr(dbh)
+        for thr_bp in (0, 40_000):
+            want = [(base + i, c) for i, c in oracle.gather(qh, fh, foff, threshold_bp=thr_bp, scaled=1000, nthreads=8)]
+            st = be.gather_state(q, len(qh), h, off, len(dbh), base)
+            st.begin(int(np.ceil(thr_bp / 1000)), 7)               # stop after 7 rounds ...
+            first = st.run()
+            assert first == want[:7], (nq, ndb, thr_bp, first[:3], want[:3])
+            mid = st.counters().copy()
+            st.begin(int(np.ceil(thr_bp / 1000)), len(dbh))        # ... and carry on from the state that loop left
+            rest = st.run()
+            assert rest == want[7:], (nq, ndb, thr_bp, len(rest), len(want))
+            # what is left of every counter = |row ∩ still-uncovered query|
+            covered = set()
+            for gi, _ in want:
+                covered.update(int(x) for x in dbh[gi - base])
+            left = np.array([x for x in qh if int(x) not in covered], dtype=np.uint64)
+            want_left = np.array([oracle.intersection_size(left, d)[0] for d in dbh], dtype=np.uint64)
+            assert np.array_equal(st.counters(), want_left), (nq, ndb, thr_bp)
+            digest.append([len(want), int(mid.sum()), int(want_left.sum())])
+    print(json.dumps(digest))
