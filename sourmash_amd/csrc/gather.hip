@@ -1677,9 +1677,22 @@ hipError_t gather_run_persistent(GatherDev& g, hipStream_t stream, bool* ran) {
     static const bool trace = getenv("SMG_GATHER_TRACE") != nullptr;
     a.dbg = trace ? g.loop_xchg + (size_t)2 * n_cu * 4 : nullptr;           // 8 words behind the granules
     SMG_TRY(hipMemsetAsync(g.loop_xchg, 0, ((size_t)2 * n_cu * 4 + 16) * 8, stream));   // epochs count from 1 within a launch
-    void* params[] = {&a};
-    // cooperative: the runtime refuses a grid that cannot be resident at once (the loop's sweeps wait for every workgroup)
-    SMG_TRY(hipLaunchCooperativeKernel((const void*)gather_loop_kernel, dim3((unsigned)n_cu), dim3(PL_THREADS), params, (unsigned)lds, stream));
+    // One workgroup per CU: all of them must be resident at once (the sweeps wait for every workgroup).  A plain launch has
+    // the same residency as a cooperative one (MI355X_MICROARCH.md) without its 15-19 us and without the cooperative
+    // interception that crashes rocprofv3 here; the occupancy query is the check the cooperative launch would make, and a
+    // workgroup that waits too long for a peer gives up (GS_ERR) instead of hanging.
+    {
+        static int blocks_per_cu = -1;
+        if (blocks_per_cu < 0) {
+            int nb = 0;
+            const hipError_t eo = hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void*)gather_loop_kernel, PL_THREADS, budget);
+            blocks_per_cu = eo == hipSuccess ? nb : 0;
+            if (eo != hipSuccess) (void)hipGetLastError();
+        }
+        if (blocks_per_cu < 1) return hipSuccess;
+    }
+    hipLaunchKernelGGL(gather_loop_kernel, dim3((unsigned)n_cu), dim3(PL_THREADS), lds, stream, a);
+    SMG_TRY(hipGetLastError());
     *ran = true;
     if (trace) {
         unsigned long long d[16];
@@ -1936,6 +1949,179 @@ __global__ __launch_bounds__(SL_THREADS) void stream_lookup_kernel(const uint64_
         if (s_hits[i]) atomicAdd(&counters[d_lo + i], (unsigned long long)s_hits[i]);   // one add per (row, group of ranges)
 }
 
+// ---- the wide form: one workgroup per CU, a wave per row visit ------------------------------------------------------
+// stream_lookup_kernel above spends 118 lane-instructions per database hash (profiles/r02_gather_sq.txt: VALU issue 55 % busy
+// for 5e8 lookups): with ~2,000 query hashes per range a row's part of a range is ~10 hashes, so 51 million visits each pay
+// cursor / ballot / bounds bookkeeping for ten useful lanes of sixteen, and every visit's 128-byte read overlaps the next
+// one's (FETCH_SIZE 1.84 x the database).  Here a workgroup takes the whole LDS of a CU: ranges of ~10,000 query hashes
+// (88 KB) and 8,192 table buckets (32 KB), so that a row's part of a range is ~50 hashes and ONE wave reads it as one
+// 512-byte load: six times fewer visits, most lanes busy, and a row's boundary line is re-read by 1 visit in 5 lines
+// instead of 1 in 1.  A workgroup owns a contiguous block of rows and walks every range over them (cursors in LDS), so
+// every row is counted by exactly one workgroup: plain stores, no atomics.
+constexpr int OW_THREADS = 1024;
+constexpr int OW_WAVES = OW_THREADS / 64;
+constexpr int OW_AHEAD = 4;               // row visits a wave has in flight
+constexpr int OW_BUCKETS = 8192;          // table buckets per range (at most)
+constexpr int OW_QCAP = 11264;            // query hashes a range may hold (88 KB); the caller checks the widest range
+constexpr int OW_ROWS = 1024;             // rows per workgroup (at most)
+constexpr size_t OW_LDS = (size_t)OW_QCAP * 8 + ((size_t)OW_BUCKETS + 4) * 4 + ((size_t)3 * OW_ROWS + 8) * 4;
+
+__global__ __launch_bounds__(OW_THREADS) void overlap_wide_kernel(const uint64_t* __restrict__ Q, const uint32_t* __restrict__ T,
+                                                                  uint32_t n_buckets, uint32_t shift, uint64_t qmax,
+                                                                  const uint64_t* __restrict__ hashes,
+                                                                  const uint64_t* __restrict__ offsets, uint64_t ndb,
+                                                                  uint32_t rows_per_wg, uint32_t n_ranges, uint32_t bpr,
+                                                                  unsigned long long* __restrict__ counts) {
+    extern __shared__ __attribute__((aligned(16))) uint64_t ow_lds[];
+    uint64_t* s_q = ow_lds;
+    uint32_t* s_t = reinterpret_cast<uint32_t*>(s_q + OW_QCAP);
+    uint32_t* s_base = s_t + OW_BUCKETS + 4;                          // row starts relative to the block's first hash
+    uint32_t* s_cur = s_base + OW_ROWS + 2;
+    uint32_t* s_hits = s_cur + OW_ROWS + 1;
+    const uint64_t d_lo = (uint64_t)blockIdx.x * rows_per_wg;
+    if (d_lo >= ndb) return;
+    const uint32_t n_rows = (uint32_t)(ndb - d_lo < (uint64_t)rows_per_wg ? ndb - d_lo : (uint64_t)rows_per_wg);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint64_t block_base = offsets[d_lo];
+    const uint64_t* rows = hashes + block_base;
+    for (uint32_t i = tid; i <= n_rows + 1; i += OW_THREADS)          // entry n_rows + 1 closes an empty row behind the last one
+        s_base[i] = (uint32_t)(offsets[d_lo + (i <= n_rows ? i : n_rows)] - block_base);
+    for (uint32_t i = tid; i <= n_rows; i += OW_THREADS) { s_cur[i] = 0; s_hits[i] = 0; }
+    // The slice of the table and of the query for range r + 1 is asked for (into registers) before range r is walked, and
+    // goes to LDS when r is through: the fill's trip to L2 hides behind a range's worth of row visits.
+    constexpr int QPER = (OW_QCAP + OW_THREADS - 1) / OW_THREADS, TPER = (OW_BUCKETS + 1 + OW_THREADS - 1) / OW_THREADS;
+    uint64_t nq_reg[QPER];
+    uint32_t nt_reg[TPER];
+    uint32_t n_p0 = 0, n_cnt_q = 0, n_cnt_t = 0;
+    auto fetch = [&](uint32_t r) {
+        const uint32_t b0 = r * bpr, b1 = b0 + bpr < n_buckets ? b0 + bpr : n_buckets;
+        const uint32_t p0 = T[b0], p1 = T[b1];
+        n_p0 = p0; n_cnt_q = p1 - p0; n_cnt_t = b1 - b0 + 1;
+#pragma unroll
+        for (int u = 0; u < TPER; ++u) {
+            const uint32_t i = (uint32_t)tid + (uint32_t)u * OW_THREADS;
+            nt_reg[u] = i < n_cnt_t ? T[b0 + i] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < QPER; ++u) {
+            const uint32_t i = (uint32_t)tid + (uint32_t)u * OW_THREADS;
+            nq_reg[u] = i < n_cnt_q ? Q[p0 + i] : 0ull;
+        }
+    };
+    fetch(0);
+    for (uint32_t r = 0; r < n_ranges; ++r) {
+        const uint32_t b0 = r * bpr, b1 = b0 + bpr < n_buckets ? b0 + bpr : n_buckets;
+        const bool last = r + 1 == n_ranges;
+        const uint64_t upper = last ? ~0ull : ((uint64_t)b1 << shift);    // hashes below it belong to this range (earlier ones are consumed)
+        __syncthreads();                                                  // the previous range's readers are done
+#pragma unroll
+        for (int u = 0; u < TPER; ++u) {
+            const uint32_t i = (uint32_t)tid + (uint32_t)u * OW_THREADS;
+            if (i < n_cnt_t) s_t[i] = nt_reg[u] - n_p0;
+        }
+#pragma unroll
+        for (int u = 0; u < QPER; ++u) {
+            const uint32_t i = (uint32_t)tid + (uint32_t)u * OW_THREADS;
+            if (i < n_cnt_q) s_q[i] = nq_reg[u];
+        }
+        if (tid < 2) s_t[bpr + 1 + tid] = n_cnt_q;                       // padding: lanes without a hash of the range read an empty bucket
+        if (tid >= 64 && tid < 64 + 3 && n_cnt_t + (uint32_t)(tid - 64) <= bpr) s_t[n_cnt_t + (uint32_t)(tid - 64)] = n_cnt_q;   // a short last range
+        __syncthreads();
+        if (!last) fetch(r + 1);
+        // software pipeline over the wave's row visits: the loads of the NEXT OW_AHEAD rows are in flight while the present
+        // ones are looked up (row starts and cursors are read from LDS again at that point: registers hold only the data)
+        uint64_t e[OW_AHEAD], e_next[OW_AHEAD];
+        auto issue = [&](uint32_t i0, uint64_t (&dst)[OW_AHEAD]) {
+#pragma unroll
+            for (int u = 0; u < OW_AHEAD; ++u) {
+                const uint32_t i = i0 + (uint32_t)u * OW_WAVES;
+                dst[u] = ~0ull;
+                if (i < n_rows) {
+                    const uint32_t rb = s_base[i], len = s_base[i + 1] - rb, c = s_cur[i];
+                    if (c + lane < len) dst[u] = rows[(uint64_t)rb + c + lane];
+                }
+            }
+        };
+        issue((uint32_t)wave, e);
+        for (uint32_t i0 = wave; i0 < n_rows; i0 += OW_WAVES * OW_AHEAD) {
+            issue(i0 + OW_WAVES * OW_AHEAD, e_next);
+            uint32_t c[OW_AHEAD], len[OW_AHEAD], rb[OW_AHEAD];
+#pragma unroll
+            for (int u = 0; u < OW_AHEAD; ++u) {
+                const uint32_t i = i0 + (uint32_t)u * OW_WAVES;
+                const bool row_ok = i < n_rows;
+                rb[u] = row_ok ? s_base[i] : 0u;
+                len[u] = row_ok ? s_base[i + 1] - rb[u] : 0u;
+                c[u] = row_ok ? s_cur[i] : 0u;
+            }
+            // The visits' lookups run side by side and branch-free: every lane reads its bucket's two table entries and the
+            // bucket's first two query hashes whether or not it holds a hash of this range (indices clamped into the arrays;
+            // the compares decide).  Measured on the first form of this kernel (profiles/r03_overlap_pmc.txt): 74 VALU + 53
+            // scalar instructions per visit, most of them the exec-mask bookkeeping of per-lane conditionals -- the kernel was
+            // bound by instruction issue, not by memory.  Buckets of more than two hashes and slices of more than 64 hashes
+            // (both rare) take the slow paths, one visit at a time.
+            bool in[OW_AHEAD], lk[OW_AHEAD];
+            uint32_t t0[OW_AHEAD], nb[OW_AHEAD];
+#pragma unroll
+            for (int u = 0; u < OW_AHEAD; ++u) {
+                in[u] = c[u] + lane < len[u] && (last || e[u] < upper);
+                lk[u] = in[u] && e[u] <= qmax;
+                uint32_t k = (uint32_t)(e[u] >> shift) - b0;                 // < bpr when lk: the hash lies in this range
+                k = k < bpr ? k : bpr;                                       // other lanes: the padding entries behind the slice
+                t0[u] = s_t[k];
+                nb[u] = s_t[k + 1] - t0[u];
+            }
+            uint64_t qa[OW_AHEAD], qb[OW_AHEAD];
+#pragma unroll
+            for (int u = 0; u < OW_AHEAD; ++u) {
+                const uint32_t ta = t0[u] < (uint32_t)(OW_QCAP - 2) ? t0[u] : (uint32_t)(OW_QCAP - 2);
+                qa[u] = s_q[ta];
+                qb[u] = s_q[ta + 1];
+            }
+#pragma unroll
+            for (int u = 0; u < OW_AHEAD; ++u) {
+                const uint32_t i = i0 + (uint32_t)u * OW_WAVES;
+                bool hit = lk[u] & ((nb[u] >= 1u & qa[u] == e[u]) | (nb[u] >= 2u & qb[u] == e[u]));
+                const bool deep = lk[u] & !hit & nb[u] > 2u & qb[u] < e[u];  // the bucket goes on and has not passed the hash yet
+                if (__builtin_expect(__ballot(deep) != 0ull, 0)) {
+                    if (deep)
+                        for (uint32_t t = t0[u] + 2; t < t0[u] + nb[u]; ++t) {
+                            const uint64_t qv = s_q[t];
+                            if (qv == e[u]) { hit = true; break; }
+                            if (qv > e[u]) break;
+                        }
+                }
+                uint32_t taken = (uint32_t)__popcll(__ballot(in[u]));
+                uint32_t hits = (uint32_t)__popcll(__ballot(hit));
+                uint32_t cur = c[u] + taken;
+                if (__builtin_expect(taken == 64u, 0)) {
+                    while (taken == 64u) {                                   // a longer slice (rare): keep reading, one load at a time
+                        const uint64_t ev = cur + lane < len[u] ? rows[(uint64_t)rb[u] + cur + lane] : ~0ull;
+                        const bool more = cur + lane < len[u] && (last || ev < upper);
+                        bool h2 = false;
+                        if (more && ev <= qmax) {
+                            const uint32_t k = (uint32_t)(ev >> shift) - b0;
+                            for (uint32_t t = s_t[k], te = s_t[k + 1]; t < te; ++t) {
+                                const uint64_t qv = s_q[t];
+                                if (qv == ev) { h2 = true; break; }
+                                if (qv > ev) break;
+                            }
+                        }
+                        taken = (uint32_t)__popcll(__ballot(more));
+                        hits += (uint32_t)__popcll(__ballot(h2));
+                        cur += taken;
+                    }
+                }
+                if (lane == 0 && i < n_rows) { s_cur[i] = cur; s_hits[i] += hits; }
+            }
+#pragma unroll
+            for (int u = 0; u < OW_AHEAD; ++u) e[u] = e_next[u];
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < n_rows; i += OW_THREADS) counts[d_lo + i] = s_hits[i];
+}
+
 // op 0: overlap[d] = cnt[d]; op 1: overlap[d] -= cnt[d], saturating (rows at 0 stay dropped, index/__init__.py:908-909)
 __global__ __launch_bounds__(256) void overlap_finish_kernel(const unsigned long long* __restrict__ cnt, uint64_t ndb,
                                                              unsigned long long* __restrict__ overlap, int op) {
@@ -1976,17 +2162,55 @@ hipError_t overlap_ranges_launch(const uint64_t* Q, uint64_t nq, const uint64_t*
     uint32_t bpr = SL_BUCKETS;                                             // buckets per range: about 2,000 query hashes
     while (bpr > 64 && (double)bpr * (double)nq / (double)buckets > 2200.0) bpr >>= 1;
     const uint32_t n_ranges = (buckets + bpr - 1) / bpr;
-    unsigned int widest = 0;
-    if (!no_stream) {
+    // the wide form for databases large enough to give every CU a few hundred rows; SMG_OVERLAP=wide makes a fallback an error
+    static const bool no_wide = [] { const char* e = getenv("SMG_OVERLAP"); return e && strcmp(e, "wide") != 0; }();
+    static const bool only_wide = [] { const char* e = getenv("SMG_OVERLAP"); return e && !strcmp(e, "wide"); }();
+    int n_cu_w = 256;
+    { int dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n_cu_w, hipDeviceAttributeMultiprocessorCount, dev); }
+    const bool try_wide = !no_wide && (only_wide || ndb >= (uint64_t)n_cu_w * 64);
+    uint32_t wbpr = OW_BUCKETS;                                            // buckets per range of the wide form: about 10,000 query hashes
+    while (wbpr > 64 && (double)wbpr * (double)nq / (double)buckets > 10000.0) wbpr >>= 1;
+    const uint32_t w_ranges = (buckets + wbpr - 1) / wbpr;
+    // the widest range of either partition decides whether its LDS has room: both maxima come back with one synchronisation
+    unsigned int widest = 0, w_widest = 0;
+    {
         unsigned int* d_widest = (unsigned int*)(cnt + ndb);                // the 64 spare bytes, zeroed above
-        hipLaunchKernelGGL(stream_range_max_kernel, dim3((n_ranges + 255) / 256), dim3(256), 0, stream, (const uint32_t*)table, buckets,
-                           n_ranges, bpr, d_widest);
-        SMG_TRY(hipMemcpyAsync(&pin.p[1], d_widest, 4, hipMemcpyDeviceToHost, stream));
-        SMG_TRY(hipStreamSynchronize(stream));
-        widest = (unsigned int)(pin.p[1] & 0xffffffffull);
+        if (!no_stream)
+            hipLaunchKernelGGL(stream_range_max_kernel, dim3((n_ranges + 255) / 256), dim3(256), 0, stream, (const uint32_t*)table, buckets,
+                               n_ranges, bpr, d_widest);
+        if (try_wide)
+            hipLaunchKernelGGL(stream_range_max_kernel, dim3((w_ranges + 255) / 256), dim3(256), 0, stream, (const uint32_t*)table, buckets,
+                               w_ranges, wbpr, d_widest + 1);
+        if (!no_stream || try_wide) {
+            SMG_TRY(hipMemcpyAsync(&pin.p[1], d_widest, 8, hipMemcpyDeviceToHost, stream));
+            SMG_TRY(hipStreamSynchronize(stream));
+            widest = (unsigned int)(pin.p[1] & 0xffffffffull);
+            w_widest = (unsigned int)(pin.p[1] >> 32);
+        }
     }
     hipError_t e = hipSuccess;
-    if (!no_stream && widest <= (unsigned)SL_QCAP) {
+    bool wide_done = false;
+    if (try_wide) {
+        static int attr_state = 0;
+        if (attr_state == 0) {
+            const hipError_t ea = hipFuncSetAttribute((const void*)overlap_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)OW_LDS);
+            attr_state = ea == hipSuccess ? 1 : -1;
+            if (ea != hipSuccess) (void)hipGetLastError();
+        }
+        if (attr_state > 0 && w_widest <= (unsigned)OW_QCAP) {
+            uint64_t rpw = (ndb + (uint64_t)n_cu_w - 1) / (uint64_t)n_cu_w;
+            if (rpw > (uint64_t)OW_ROWS) rpw = OW_ROWS;
+            if (rpw < 1) rpw = 1;
+            const uint64_t n_wg = (ndb + rpw - 1) / rpw;
+            hipLaunchKernelGGL(overlap_wide_kernel, dim3((unsigned)n_wg), dim3(OW_THREADS), OW_LDS, stream, Q, (const uint32_t*)table, buckets,
+                               shift, q_max, hashes, offsets, ndb, (uint32_t)rpw, w_ranges, wbpr, cnt);
+            wide_done = true;
+        } else if (only_wide) {
+            return hipErrorInvalidValue;
+        }
+    }
+    if (wide_done) {
+    } else if (!no_stream && widest <= (unsigned)SL_QCAP) {
         const uint32_t n_blocks = (uint32_t)((ndb + SL_ROWS - 1) / SL_ROWS);
         // every workgroup resident at once (4 per CU by LDS and waves): with even a few more than fit, the kernel takes two
         // rounds -- 784 workgroups on 768 slots ran 4.2 ms with the CUs idle 42 % of the wave-time (profiles/r02_gather_sq.txt)

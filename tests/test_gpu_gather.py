@@ -196,7 +196,7 @@ def test_range_builder_postings_are_exact(fill, monkeypatch):
     assert not st.counters().any()
 
 
-@pytest.mark.parametrize("form", ["stream", "ranges"])
+@pytest.mark.parametrize("form", ["wide", "stream", "ranges"])
 def test_overlaps_of_a_large_query_take_the_range_partitioned_pass(form):
     """smgpu_overlap_raw with a large query over >= 4096 rows (gather.hip: overlap_ranges_launch), both ops, vs the oracle:
     the streaming form (the query through LDS; SMG_OVERLAP=stream makes a fallback an error) and the range-partitioned
