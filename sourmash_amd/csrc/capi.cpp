@@ -487,8 +487,8 @@ SourmashKmerMinHash* kmerminhash_intersection(const SourmashKmerMinHash* p, cons
             if (uni > a.num) {
                 // the num-th smallest of the union bounds the kept intersection
                 KmerMinHash u = a;
-                u.track_abundance = false; u.abunds.clear();
-                KmerMinHash bb = b; bb.track_abundance = false; bb.abunds.clear();
+                u.disable_abundance();
+                KmerMinHash bb = b; bb.disable_abundance();
                 u.merge(bb);
                 const uint64_t cutoff = u.mins.empty() ? 0 : u.mins.back();
                 while (!list.empty() && list.back() > cutoff) list.pop_back();
@@ -1340,6 +1340,7 @@ SourmashKmerMinHash* smgpu_sketchset_get(const SmgpuSketchSet* p, uint64_t index
                                                         s->seed, false, (uint32_t)s->num));
         mh->max_hash = s->max_hash;
         mh->mins.resize(len);
+        mh->touch();
         DeviceCtx& ctx = DeviceCtx::get();
         std::lock_guard<std::recursive_mutex> g(ctx.mutex());
         if (len) hip_check(hipMemcpyAsync(mh->mins.data(), s->hashes.as<uint64_t>() + lo, len * 8, hipMemcpyDeviceToHost, ctx.stream()), "D2H");

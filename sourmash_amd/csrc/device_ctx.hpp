@@ -12,6 +12,9 @@
 #include <mutex>
 #include <string>
 #include <vector>
+#include <list>
+#include <unordered_map>
+#include <chrono>
 #include "arena.hpp"
 #include "device_api.hpp"
 #include "minhash_host.hpp"
@@ -140,32 +143,114 @@ class DeviceCtx {
 
     // ---- pair statistics of two sorted sketches -------------------------------------------------
     // want_list: also return the sorted intersection.  num != 0: apply the bottom-k rule.
+    // ---- device mirrors of sketches (per-pair API) ---------------------------------------------------
+    // The reference's per-pair entry points (ffi/minhash.rs:409-457) are called in loops over the same sketches
+    // (compare.py:36-54, index/__init__.py:115-170): uploading both sketches on every call made a pair cost 54-59 us
+    // where the two-pointer walk on a host core takes 7 (profiles/r02_small_calls.json).  A sketch's hashes (and
+    // abundances) stay on the device under its content generation (minhash_host.hpp: gen), least recently used first out.
+    struct Mirror {
+        uint64_t* mins = nullptr;
+        uint64_t* abunds = nullptr;
+        size_t n = 0;
+        uint64_t first = 0, last = 0;
+        std::list<uint64_t>::iterator lru;
+    };
+    static constexpr size_t MIRROR_BYTES_MAX = (size_t)512 << 20;
+    static constexpr size_t MIRROR_ENTRIES_MAX = 4096;
+
+    Mirror& mirror_of(const KmerMinHash& m, bool want_abund) {
+        auto it = mirrors_.find(m.gen);
+        if (it != mirrors_.end()) {
+            Mirror& mr = it->second;
+            // (size and end hashes are checked as well: a writer that forgot touch() costs a re-upload, not a wrong answer)
+            if (mr.n == m.size() && (mr.n == 0 || (mr.first == m.mins.front() && mr.last == m.mins.back()))) {
+                lru_.splice(lru_.begin(), lru_, mr.lru);
+                if (want_abund && !mr.abunds && mr.n) upload(&mr.abunds, m.abunds.data(), mr.n);
+                return mr;
+            }
+            drop_mirror(it);
+        }
+        // (the most recently used mirror stays: it may be the other operand of the call being served)
+        while (lru_.size() > 1 && (mirror_bytes_ + m.size() * 16 > MIRROR_BYTES_MAX || mirrors_.size() >= MIRROR_ENTRIES_MAX))
+            drop_mirror(mirrors_.find(lru_.back()));
+        Mirror mr;
+        mr.n = m.size();
+        if (mr.n) {
+            mr.first = m.mins.front(); mr.last = m.mins.back();
+            upload(&mr.mins, m.mins.data(), mr.n);
+            if (want_abund) upload(&mr.abunds, m.abunds.data(), mr.n);
+        }
+        lru_.push_front(m.gen);
+        mr.lru = lru_.begin();
+        return mirrors_.emplace(m.gen, mr).first->second;
+    }
+    void upload(uint64_t** dst, const uint64_t* src, size_t n) {
+        hip_check(arena_alloc((void**)dst, n * 8 + 64, stream_), "arena_alloc");
+        hip_check(hipMemcpyAsync(*dst, src, n * 8, hipMemcpyHostToDevice, stream_), "H2D");
+        mirror_bytes_ += n * 8;
+    }
+    void drop_mirror(std::unordered_map<uint64_t, Mirror>::iterator it) {
+        if (it == mirrors_.end()) return;
+        Mirror& mr = it->second;
+        if (mr.mins) { arena_free(mr.mins, stream_); mirror_bytes_ -= mr.n * 8; }
+        if (mr.abunds) { arena_free(mr.abunds, stream_); mirror_bytes_ -= mr.n * 8; }
+        lru_.erase(mr.lru);
+        mirrors_.erase(it);
+    }
+
+    // |a ∩ b| through the one-launch kernel with the result polled from a pinned slot; false: not applicable here
+    bool pair_count_fast(const KmerMinHash& a, const KmerMinHash& b, uint64_t* common) {
+        const KmerMinHash& A = a.size() <= b.size() ? a : b;
+        const KmerMinHash& B = a.size() <= b.size() ? b : a;
+        if (A.size() == 0) { *common = 0; return true; }
+        if (B.size() > PAIR_SMALL_MAX) return false;
+        if (!slot_) {
+            if (hipHostMalloc((void**)&slot_, 256, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); slot_ = nullptr; return false; }
+            slot_[0] = slot_[1] = 0;
+        }
+        const uint64_t* dA = mirror_of(A, false).mins;
+        const uint64_t* dB = mirror_of(B, false).mins;
+        const unsigned long long seq = ++slot_seq_;
+        volatile unsigned long long* vs = slot_;
+        hip_check(pair_count_small_launch(dA, A.size(), dB, B.size(), slot_, seq, stream_), "pair_count");
+        // the kernel stores the count, then the sequence number (system-scope release): poll, with a synchronise as the way out
+        const auto t0 = std::chrono::steady_clock::now();
+        for (unsigned spins = 0; vs[0] != seq; ++spins) {
+            __builtin_ia32_pause();
+            if ((spins & 1023u) == 1023u &&
+                std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() > 2000.0) {
+                hip_check(hipStreamSynchronize(stream_), "sync");
+                break;
+            }
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+        if (vs[0] != seq) throw err_internal("pair kernel did not publish its result");
+        *common = vs[1];
+        return true;
+    }
+
     PairStats pair(const KmerMinHash& a, const KmerMinHash& b, bool want_abund, bool want_list, uint64_t num,
                    std::vector<uint64_t>* list) {
         PairStats st;
         if (list) list->clear();
+        if (!want_abund && !want_list && num == 0 && pair_count_fast(a, b, &st.common)) return st;
         // search the shorter list's hashes in the longer one (minhash.rs:550-554 swaps likewise)
         const KmerMinHash& A = a.size() <= b.size() ? a : b;
         const KmerMinHash& B = a.size() <= b.size() ? b : a;
         const size_t na = A.size(), nb = B.size();
         const bool ab = want_abund && a.track_abundance && b.track_abundance;
-        // device layout: [A mins][B mins][A abunds][B abunds][I list]
-        const size_t words = 2 * (na + nb) + na + 16;
-        pair_.reserve(words * 8);
-        uint64_t* dA = pair_.as<uint64_t>();
-        uint64_t* dB = dA + na;
-        uint64_t* dAa = dB + nb;
-        uint64_t* dBa = dAa + na;
-        uint64_t* dI = dBa + nb;
+        // the sketches come from their device mirrors (uploaded on first use, kept until the sketch changes); scratch: [I list]
+        pair_.reserve((na + 16) * 8);
+        Mirror& mA = mirror_of(A, ab);
+        const uint64_t* dA = mA.mins;
+        const uint64_t* dAa = mA.abunds;
+        Mirror& mB = mirror_of(B, ab);                                 // (never evicts A: A was just used)
+        const uint64_t* dB = mB.mins;
+        const uint64_t* dBa = mB.abunds;
+        uint64_t* dI = pair_.as<uint64_t>();
         flags_.reserve(na + 16);
         unsigned long long* sums = scalars_.as<unsigned long long>();   // [0..3] sums, [4] list size, [5] num count
         hip_check(hipMemsetAsync(sums, 0, 64, stream_), "memset");
-        if (na) hip_check(hipMemcpyAsync(dA, A.mins.data(), na * 8, hipMemcpyHostToDevice, stream_), "H2D");
-        if (nb) hip_check(hipMemcpyAsync(dB, B.mins.data(), nb * 8, hipMemcpyHostToDevice, stream_), "H2D");
-        if (ab) {
-            if (na) hip_check(hipMemcpyAsync(dAa, A.abunds.data(), na * 8, hipMemcpyHostToDevice, stream_), "H2D");
-            if (nb) hip_check(hipMemcpyAsync(dBa, B.abunds.data(), nb * 8, hipMemcpyHostToDevice, stream_), "H2D");
-        }
         const bool need_list = want_list || num != 0;
         hip_check(pair_match_launch(dA, na, dB, nb, ab ? dAa : nullptr, ab ? dBa : nullptr,
                                     need_list ? flags_.as<uint8_t>() : nullptr, sums, 0, stream_), "pair_match");
@@ -333,6 +418,11 @@ class DeviceCtx {
     }
 
     hipStream_t stream_ = nullptr;
+    std::unordered_map<uint64_t, Mirror> mirrors_;
+    std::list<uint64_t> lru_;
+    size_t mirror_bytes_ = 0;
+    unsigned long long* slot_ = nullptr;       // pinned host memory the one-launch pair kernel publishes into
+    unsigned long long slot_seq_ = 0;
     std::recursive_mutex mu_;
     DevBuf seq_, aa_, out_, uniq_, temp_, scalars_, pair_, flags_;
 };

@@ -11,6 +11,7 @@
 #pragma once
 #include <stdint.h>
 #include <algorithm>
+#include <atomic>
 #include <string>
 #include <vector>
 #include "md5.hpp"
@@ -45,6 +46,16 @@ struct KmerMinHash {
     // DNA records handed to add_sequence and not hashed yet (each followed by a '\n', which no k-mer may span): the C-ABI
     // layer runs them through the sketch kernel in one launch when the state is next looked at (capi.cpp: settle)
     mutable std::string pending;
+    // Content generation: a process-wide unique number taken at construction and again by every mutator.  Two objects with
+    // the same generation hold the same hashes (a copy keeps it until either side changes), which is what lets the device
+    // keep a mirror of a sketch's hashes between per-pair calls (device_ctx.hpp: mirror_of) and drop it the moment the
+    // sketch changes.  Code that writes mins / abunds directly calls touch().
+    uint64_t gen = next_gen();
+    static uint64_t next_gen() {
+        static std::atomic<uint64_t> g{1};
+        return g.fetch_add(1, std::memory_order_relaxed);
+    }
+    void touch() { gen = next_gen(); }
 
     KmerMinHash() = default;
     // minhash.rs:186-221
@@ -58,10 +69,11 @@ struct KmerMinHash {
     size_t size() const { return mins.size(); }
     bool is_dna() const { return hash_function == HF_DNA; }
 
-    void clear() { mins.clear(); abunds.clear(); pending.clear(); }   // minhash.rs:239-244
+    void clear() { touch(); mins.clear(); abunds.clear(); pending.clear(); }   // minhash.rs:239-244
 
     // minhash.rs:406-416
     void remove_hash(uint64_t h) {
+        touch();
         auto it = std::lower_bound(mins.begin(), mins.end(), h);
         if (it != mins.end() && *it == h) {
             const size_t pos = (size_t)(it - mins.begin());
@@ -73,6 +85,7 @@ struct KmerMinHash {
     // minhash.rs:418-430 remove_many / remove_from: same result as remove_hash per element, done as
     // one sorted set difference (the reference's Vec::remove per hash is quadratic on big queries).
     void remove_sorted(const uint64_t* hs, size_t n) {
+        touch();
         size_t i = 0, j = 0, w = 0;
         while (i < mins.size()) {
             while (j < n && hs[j] < mins[i]) ++j;
@@ -87,6 +100,7 @@ struct KmerMinHash {
 
     // minhash.rs:313-383
     void add_hash_with_abundance(uint64_t h, uint64_t abundance) {
+        touch();
         const uint64_t current_max = mins.empty() ? UINT64_MAX : mins.back();
         if (h > max_hash && max_hash != 0) return;           // keep rule is inclusive (:319)
         if (num == 0 && max_hash == 0) return;
@@ -121,6 +135,7 @@ struct KmerMinHash {
     // add_hash_with_abundance per element, in one linear merge.
     void add_sorted_batch(const uint64_t* hs, const uint64_t* counts, size_t n) {
         if (n == 0) return;
+        touch();
         if (num == 0 && max_hash == 0) return;
         if (mins.empty() && num == 0) {                        // first batch of a scaled sketch: it IS the sketch
             const size_t keep = (size_t)(std::upper_bound(hs, hs + n, max_hash) - hs);
@@ -163,6 +178,7 @@ struct KmerMinHash {
     // minhash.rs:432-516
     void merge(const KmerMinHash& o) {
         check_compatible(o);
+        touch();
         const bool both = track_abundance && o.track_abundance;
         std::vector<uint64_t> mm, ma;
         mm.reserve(mins.size() + o.mins.size());
@@ -186,7 +202,7 @@ struct KmerMinHash {
         const uint64_t cur = scaled();
         if (cur == new_scaled || cur == 0) return *this;
         if (cur > new_scaled) throw err_cannot_upsample();
-        KmerMinHash out(new_scaled, ksize, hash_function, seed, track_abundance, num);
+        KmerMinHash out(new_scaled, ksize, hash_function, seed, track_abundance, num);   // (a fresh generation)
         const size_t keep = (size_t)(std::upper_bound(mins.begin(), mins.end(), out.max_hash) - mins.begin());
         out.mins.assign(mins.begin(), mins.begin() + (long)keep);
         if (track_abundance) out.abunds.assign(abunds.begin(), abunds.begin() + (long)keep);
@@ -209,10 +225,11 @@ struct KmerMinHash {
     }
     void enable_abundance() {
         if (!mins.empty()) throw err_non_empty("track_abundance=True");
+        touch();
         track_abundance = true;
         abunds.clear();
     }
-    void disable_abundance() { track_abundance = false; abunds.clear(); }
+    void disable_abundance() { touch(); track_abundance = false; abunds.clear(); }
 };
 
 }  // namespace smg

@@ -11,6 +11,12 @@ namespace smg {
 hipError_t pair_match_launch(const uint64_t* A, uint64_t na, const uint64_t* B, uint64_t nb, const uint64_t* abA,
                              const uint64_t* abB, uint8_t* flags, unsigned long long* sums, int invert,
                              hipStream_t stream);  // invert: flag hashes of A NOT in B
+// |A ∩ B| of two device-resident sorted sketches in ONE small launch whose result goes straight to a host-visible slot:
+// slot[1] = count, then slot[0] = seq with system-scope release (the host polls slot[0]).  nb <= PAIR_SMALL_MAX: B is
+// staged in LDS and A's hashes are binary-searched there.
+constexpr uint64_t PAIR_SMALL_MAX = 8000;
+hipError_t pair_count_small_launch(const uint64_t* A, uint64_t na, const uint64_t* B, uint64_t nb,
+                                   unsigned long long* host_slot, unsigned long long seq, hipStream_t stream);
 hipError_t sumsq_launch(const uint64_t* a, uint64_t n, unsigned long long* dst, hipStream_t stream);
 hipError_t num_rank_launch(const uint64_t* I, uint64_t ni, const uint64_t* A, uint64_t na, const uint64_t* B,
                            uint64_t nb, uint64_t num, unsigned long long* dst, hipStream_t stream);

@@ -63,6 +63,46 @@ __global__ __launch_bounds__(256) void pair_match_kernel(const uint64_t* __restr
     }
 }
 
+// The per-pair calls of the reference API (count_common / jaccard / similarity on two ~5,000-hash sketches) are latency, not
+// work: one workgroup stages B in LDS (one coalesced trip), searches A's hashes there, reduces in LDS and publishes the
+// count to a pinned host slot, sequence number last with system-scope release -- no memset, no read-back copy, and the
+// host learns the result by polling that word instead of a stream synchronisation.
+__global__ __launch_bounds__(1024) void pair_count_small_kernel(const uint64_t* __restrict__ A, uint32_t na,
+                                                                const uint64_t* __restrict__ B, uint32_t nb,
+                                                                unsigned long long* host_slot, unsigned long long seq) {
+    extern __shared__ __attribute__((aligned(16))) uint64_t s_b[];
+    __shared__ uint32_t s_part[16];
+    for (uint32_t i = threadIdx.x; i < nb; i += 1024) s_b[i] = B[i];
+    __syncthreads();
+    uint32_t cnt = 0;
+    for (uint32_t i = threadIdx.x; i < na; i += 1024) {
+        const uint64_t x = A[i];
+        uint32_t lo = 0, hi = nb;
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (s_b[mid] < x) lo = mid + 1; else hi = mid;
+        }
+        cnt += lo < nb && s_b[lo] == x;
+    }
+    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_down(cnt, off);
+    if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long total = 0;
+        for (int w = 0; w < 16; ++w) total += s_part[w];
+        __hip_atomic_store(&host_slot[1], total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(&host_slot[0], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+hipError_t pair_count_small_launch(const uint64_t* A, uint64_t na, const uint64_t* B, uint64_t nb,
+                                   unsigned long long* host_slot, unsigned long long seq, hipStream_t stream) {
+    if (nb > PAIR_SMALL_MAX || na > 0xffffffffull) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(pair_count_small_kernel, dim3(1), dim3(1024), (size_t)nb * 8, stream, A, (uint32_t)na, B, (uint32_t)nb,
+                       host_slot, seq);
+    return hipGetLastError();
+}
+
 // sums[2] += sum a^2 ; sums[3] += sum b^2
 __global__ __launch_bounds__(256) void sumsq_kernel(const uint64_t* __restrict__ a, uint64_t n, unsigned long long* dst) {
     unsigned long long s = 0;

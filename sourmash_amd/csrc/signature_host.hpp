@@ -151,6 +151,7 @@ struct Signature {
         mh.mins.reserve(pairs.size());
         if (has_ab) mh.abunds.reserve(pairs.size());
         for (auto& p : pairs) { mh.mins.push_back(p.first); if (has_ab) mh.abunds.push_back(p.second); }
+        mh.touch();
         return mh;
     }
 

@@ -37,8 +37,9 @@ def main():
     from sourmash_amd._lowlevel import LIBPATH
     rng = np.random.default_rng(5)
     python_only = "--python-only" in sys.argv                       # the add_sequence loops alone (the ctypes comparison run)
+    pairs_only = "--pairs-only" in sys.argv                         # the per-pair calls alone
     out = {"binding": "C method (csrc/fastcall.c)" if _mh._fastcall is not None else "ctypes"}
-    for length, calls in ((150, 1_000_000), (10_000, 20_000), (1_000_000, 200)):
+    for length, calls in (() if pairs_only else ((150, 1_000_000), (10_000, 20_000), (1_000_000, 200))):
         seqs = [bytes(rng.choice(np.frombuffer(b"ACGT", dtype=np.uint8), length)).decode() for _ in range(min(calls, 200))]
         mh = sm.MinHash(0, 31, scaled=1000)
         mh.add_sequence(seqs[0])
@@ -60,7 +61,7 @@ def main():
     if python_only:
         print(json.dumps(out))
         return
-    if _mh._fastcall is not None:                                   # the same loops through the ctypes binding, in a fresh process
+    if _mh._fastcall is not None and not pairs_only:                # the same loops through the ctypes binding, in a fresh process
         env = dict(os.environ, SMG_NO_FASTCALL="1")
         txt = subprocess.check_output([sys.executable, os.path.abspath(__file__), "--python-only"], env=env, text=True)
         out["through_ctypes"] = json.loads(txt.strip().splitlines()[-1])
@@ -71,9 +72,23 @@ def main():
                      ("contained_by", lambda: a.contained_by(b)), ("len", lambda: len(a)), ("copy", lambda: a.copy())):
         fn()
         t0 = time.perf_counter()
-        for _ in range(500):
+        for _ in range(2000):
             fn()
-        out[name + "_5000_hashes"] = {"us_per_call": round((time.perf_counter() - t0) / 500 * 1e6, 1)}
+        out[name + "_5000_hashes"] = {"us_per_call": round((time.perf_counter() - t0) / 2000 * 1e6, 1)}
+    # the reference's compare loop (compare.py:36-54) over 60 sketches: every pair through the per-pair entry point
+    sk = []
+    for i in range(60):
+        m = sm.MinHash(0, 31, scaled=1000)
+        m.add_many(rng.integers(1, 2**40, size=5000).tolist())
+        sk.append(m)
+    sk[0].jaccard(sk[1])
+    t0 = time.perf_counter()
+    tot = 0.0
+    for i in range(60):
+        for j in range(i):
+            tot += sk[i].jaccard(sk[j])
+    dt = time.perf_counter() - t0
+    out["jaccard_loop_60_sketches"] = {"pairs": 60 * 59 // 2, "us_per_pair": round(dt / (60 * 59 // 2) * 1e6, 1)}
     print(json.dumps(out))
 
 
