@@ -548,3 +548,62 @@ def test_ani_on_real_sketches(sm):
     assert a.size_is_accurate() and not sm.MinHash(0, 31, scaled=1000, mins=[1, 2, 3]).size_is_accurate()
     tiny = sm.MinHash(0, 31, scaled=1000, mins=[1, 2, 3])
     assert tiny.containment_ani(tiny).ani is None                                    # size estimate not trustworthy
+
+
+def test_device_mirrors_follow_every_mutation(sm):
+    """The per-pair entry points keep a device copy of each sketch between calls (device_ctx.hpp: mirror_of, keyed by the
+    sketch's content generation).  Whatever changes a sketch -- add / remove / merge / clear / abundances / queued
+    sequence / downsample, on the object itself or on a copy -- the next count_common / jaccard / angular answers for the
+    NEW content, checked against the oracle's walk (minhash.rs:539-558,593-631)."""
+    import numpy as np
+    import oracle
+    rng = np.random.default_rng(12)
+    universe = rng.integers(1, 2**50, size=20_000, dtype=np.uint64)
+
+    def fresh(idx, abund=False):
+        mh = sm.MinHash(0, 31, scaled=1, track_abundance=abund)
+        mh.add_many([int(x) for x in universe[idx]])
+        return mh
+
+    def check(a, b):
+        ha, hb = np.array(sorted(a.hashes), dtype=np.uint64), np.array(sorted(b.hashes), dtype=np.uint64)
+        c, u = oracle.intersection_size(ha, hb)
+        assert a.count_common(b) == c and b.count_common(a) == c
+        assert a.jaccard(b) == (c / u if u else 0.0)
+
+    a, b = fresh(slice(0, 6000)), fresh(slice(3000, 9000))
+    check(a, b)
+    check(a, b)                                                    # second call: both mirrors are warm
+    a.add_hash(int(universe[8000])); check(a, b)
+    a.add_many([int(x) for x in universe[8500:8600]]); check(a, b)
+    a.remove_many([int(x) for x in universe[3000:3500]]); check(a, b)
+    b.merge(fresh(slice(0, 100))); check(a, b)
+    c = a.copy()                                                   # the copy shares a's content (and its mirror) ...
+    check(c, b)
+    c.add_many([int(x) for x in universe[9000:9500]])              # ... until one of them changes
+    check(c, b); check(a, b); check(a, c)
+    d = a.downsample(scaled=4); e = b.downsample(scaled=4)
+    check(d, e)
+    a.clear(); check(a, b)
+    a.add_many([int(x) for x in universe[100:200]]); check(a, b)
+    q = sm.MinHash(0, 21, scaled=1)
+    q2 = sm.MinHash(0, 21, scaled=1)
+    seq = "ACGTTGCAAGCTTGCATCGATCGGATCGATTAGCTAGCTAGGATCGATCGATTAGC" * 3
+    q.add_sequence(seq); q2.add_sequence(seq[:80])
+    assert q.count_common(q2) == len(q2)
+    q2.add_sequence(seq[40:])                                      # queued records settle on the next access: new content
+    assert q.count_common(q2) == len(q2) == len(q)
+    # abundances live in the mirror too: changing them changes the angular similarity
+    x, y = fresh(slice(0, 3000), abund=True), fresh(slice(1000, 4000), abund=True)
+    s0 = x.angular_similarity(y)
+    assert s0 == x.angular_similarity(y)
+    x.set_abundances({int(h): 7 for h in universe[1000:1500]}, clear=False)
+    s1 = x.angular_similarity(y)
+    hx = dict(x.hashes); hy = dict(y.hashes)
+    prod = sum(v * hy[k] for k, v in hx.items() if k in hy)
+    na, nb = math.sqrt(sum(v * v for v in hx.values())), math.sqrt(sum(v * v for v in hy.values()))
+    assert s1 != s0 and s1 == 1.0 - 2.0 * math.acos(min(prod / (na * nb), 1.0)) / math.pi
+    # many distinct sketches: more than the cache keeps would still be right (entries are evicted, least recently used first)
+    many = [fresh(slice(i * 37, i * 37 + 500)) for i in range(40)]
+    for i in range(0, 40, 3):
+        check(many[i], many[(i * 7 + 1) % 40])
