@@ -62,6 +62,7 @@ def parse():
     ap.add_argument("--scaled", type=int, default=1000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-compare", action="store_true", help="skip every secondary metric (compare / gather)")
+    ap.add_argument("--no-xl", action="store_true", help="skip the XL multi-GPU configurations (compare_xl_dist, gather_xl_dist)")
     ap.add_argument("--cpu-sample", type=float, default=0.0, help="bases for the N-thread CPU sketch leg (0 = auto)")
     return ap.parse_args()
 
@@ -215,6 +216,22 @@ def main():
                                                         use_dist, barrier, max_over_ranks)
         except Exception as e:
             extra["gather_c5_dist"] = {"error": repr(e)}
+        torch.cuda.empty_cache()
+
+    # ---- XL configurations for the scaling curve (every rank): C4 / C5 are over in milliseconds on one GPU ----
+    if not args.no_compare and not args.no_xl:
+        from sourmash_amd.synth import synth_sketches_device
+        try:
+            extra["compare_xl_dist"] = bench_compare_xl_dist(torch, dev, be, parallel, synth_sketches_device, world, rank, use_dist,
+                                                             barrier, max_over_ranks)
+        except Exception as e:
+            extra["compare_xl_dist"] = {"error": repr(e)}
+        torch.cuda.empty_cache()
+        try:
+            extra["gather_xl_dist"] = bench_gather_xl_dist(torch, dev, be, parallel, synth_gather_device, world, rank, use_dist,
+                                                           barrier, max_over_ranks)
+        except Exception as e:
+            extra["gather_xl_dist"] = {"error": repr(e)}
         torch.cuda.empty_cache()
 
     # ---- single-GPU secondary metrics (N = 1): config C3 and the kernels behind C4 / C5 one by one ----
@@ -440,6 +457,68 @@ def bench_gather_dist(torch, np, dev, be, parallel, synth_gather_device, world, 
            "note": "wall clock of index build + every round, threshold_bp 50,000; exact parity at this size: "
                    "tests/test_gpu_full_configs.py"}
     return out
+
+
+def bench_compare_xl_dist(torch, dev, be, parallel, synth_sketches_device, world, rank, use_dist, barrier, max_over_ranks):
+    """40,000 x 40,000 compare (8e8 pairs; 16 x C4) through the same distributed driver: the collection is generated in HBM,
+    identically on every rank; strong scaling (the matrix is fixed).  Checked through size-independent properties."""
+    n = 40_000
+    bh, boff = synth_sketches_device(n, dev)
+    torch.cuda.synchronize()
+    pairs = n * (n - 1) // 2
+    timing = {}
+    full, jac = parallel.compare_all_pairs_distributed(bh, boff, n, be, force_collectives=use_dist)   # warm
+    del full, jac
+    be._index, be._index_key = None, None
+    barrier()
+    t0 = time.perf_counter()
+    full, jac = parallel.compare_all_pairs_distributed(bh, boff, n, be, force_collectives=use_dist, timing=timing)
+    barrier()
+    dt = max_over_ranks(time.perf_counter() - t0)
+    sizes = (boff[1:] - boff[:-1])
+    idx = torch.randint(0, n, (4096,), device=dev)
+    jdx = torch.randint(0, n, (4096,), device=dev)
+    checks = {"diagonal_equals_sizes": bool((full.diagonal().to(torch.int64) == sizes).all().item()),
+              "symmetric_on_4096_samples": bool((full[idx, jdx] == full[jdx, idx]).all().item()),
+              "counts_at_most_smaller_sketch": bool((full[idx, jdx].to(torch.int64) <= torch.minimum(sizes[idx], sizes[jdx])).all().item()),
+              "jaccard_diagonal_is_one": bool((jac.diagonal() == 1.0).all().item())}
+    out = {"ranks": world, "sketches": n, "hashes": int(boff[-1].item()), "pairs": pairs, "ms": round(dt * 1e3, 2),
+           "pairs_per_s": round(pairs / dt, 1), "tiles_ms_rank0": round(timing.get("tiles_ms", 0.0), 2),
+           "allgather_ms": round(timing.get("allgather_ms", 0.0), 2), "mirror_and_jaccard_ms": round(timing.get("finish_ms", 0.0), 2),
+           "collective": "all-gather (rccl)" if use_dist else "none", "scaling": "strong", "checks": checks,
+           "counts_checksum": int(full.to(torch.int64).sum().item()),
+           "note": "cost model + compare-index build (replicated) + owned 16-row tiles + ONE all-gather of 16-bit counts (3.2 GB in all) "
+                   "+ mirror + Jaccard on every rank; what does not shard: the index build and the N x N finish"}
+    del full, jac, bh, boff
+    return out
+
+
+def bench_gather_xl_dist(torch, dev, be, parallel, synth_gather_device, world, rank, use_dist, barrier, max_over_ranks):
+    """Weak scaling of the gather: every rank holds 125,000 datasets (5 GB; 10^6 datasets = 40 GB on 8 ranks), the 10^6-hash
+    query is replicated.  What shards is the index build and the memory; the loop is a chain of dependent rounds."""
+    nq, per_rank, dbsize, thr_bp = 1_000_000, 125_000, 5000, 50_000
+    ndb = per_rank * world
+    lo, hi = per_rank * rank, per_rank * (rank + 1)
+    q, gh, goff = synth_gather_device(nq, ndb, dbsize, dev, row_lo=lo, row_hi=hi)
+    torch.cuda.synchronize()
+    best, stats, res = None, {}, []
+    for _ in range(2):
+        stats = {}
+        barrier()
+        t0 = time.perf_counter()
+        res = parallel.gather_distributed(q, q.numel(), gh, goff, hi - lo, lo, thr_bp, 1000, be, force_collectives=use_dist, stats=stats)
+        barrier()
+        best = max_over_ranks(time.perf_counter() - t0)
+    iso = [r[1] for r in res]
+    return {"ranks": world, "datasets": ndb, "datasets_per_rank": per_rank, "query_hashes": int(q.numel()),
+            "db_bytes_per_rank": int(gh.numel() * 8), "db_bytes_total": int(gh.numel() * 8) * world, "rounds": len(res),
+            "total_ms": round(best * 1e3, 2), "datasets_per_s": round(ndb / best, 1), "scaling": "weak",
+            "index_build_kernels_ms": stats.get("build_kernels_ms"), "loop_kernels_ms": stats.get("loop_gpu_ms"),
+            "exchanges": stats.get("exchanges"), "rounds_per_exchange": stats.get("rounds_per_exchange"),
+            "collective": "all-gather of candidate rows (rccl)" if use_dist else "none (native single-shard loop)",
+            "overlaps_non_increasing": bool(all(a >= b for a, b in zip(iso, iso[1:]))),
+            "winners_distinct": bool(len({r[0] for r in res}) == len(res)),
+            "first": res[:2], "last": res[-1:] if res else None}
 
 
 def single_gpu_extras(extra, torch, np, dev, be, smd, synth_sketches, synth_gather, synth_gather_device, timed):

@@ -302,6 +302,7 @@ SmgpuBitIndex *smgpu_bitindex_new_ex(const uint64_t *d_hashes, const uint64_t *d
                                      uint32_t threshold, bool one_shot, void *stream);
 void smgpu_bitindex_free(SmgpuBitIndex *ptr);
 uint64_t smgpu_bitindex_universe(const SmgpuBitIndex *ptr);
+uint32_t smgpu_bitindex_builder(const SmgpuBitIndex *ptr);   /* which builder made it: 1 sort-free dictionary passes, 2 radix sort (diagnostic) */
 /* how the index splits the collection: hashes held by more than `threshold` sketches are bit columns, the others
  * are inverted lists costing `rare_pairs` matrix increments per compare */
 void smgpu_bitindex_stats(const SmgpuBitIndex *ptr, uint64_t *frequent_hashes, uint64_t *rare_pairs, uint32_t *threshold);

@@ -858,6 +858,7 @@ struct BitIndex {
                                            // from the sort-free builder)
     uint64_t frequent = 0, rare_pairs = 0;
     uint32_t threshold = 0;
+    uint32_t builder = 0;                  // 1: sort-free dictionary builder (dictindex.hip), 2: radix sort of all (hash, row) pairs
     hipStream_t stream = nullptr;          // the arrays come from this stream's pool and go back to it, in order
     ~BitIndex() {
         if (bits) arena_free(bits, stream);
@@ -927,6 +928,7 @@ static BitIndex* bitindex_build(const uint64_t* d_hashes, const uint64_t* d_offs
             }
             hip_check(dict_emit_launch(d_hashes, d_offsets, n, scratch.p, bi->bits, words, bi->rows_sorted, bi->run_end, st),
                       "dictionary pass 2");
+            bi->builder = 1;
             return bi.release();
         }
     }
@@ -972,6 +974,7 @@ static BitIndex* bitindex_build(const uint64_t* d_hashes, const uint64_t* d_offs
         arena_free(bi->rows_sorted, st); arena_free(bi->run_end, st);
         bi->rows_sorted = bi->run_end = nullptr;
     }
+    bi->builder = 2;
     return bi.release();                              // stream-ordered: usable by later work on `st` without a sync
 }
 
@@ -1002,6 +1005,7 @@ SmgpuBitIndex* smgpu_bitindex_new_ex(const uint64_t* d_hashes, const uint64_t* d
 }
 void smgpu_bitindex_free(SmgpuBitIndex* p) { delete reinterpret_cast<BitIndex*>(p); }
 uint64_t smgpu_bitindex_universe(const SmgpuBitIndex* p) { return reinterpret_cast<const BitIndex*>(p)->universe; }
+uint32_t smgpu_bitindex_builder(const SmgpuBitIndex* p) { return reinterpret_cast<const BitIndex*>(p)->builder; }
 void smgpu_bitindex_stats(const SmgpuBitIndex* p, uint64_t* frequent_hashes, uint64_t* rare_pairs, uint32_t* threshold) {
     const BitIndex* bi = reinterpret_cast<const BitIndex*>(p);
     *frequent_hashes = bi->frequent ? bi->frequent : (bi->run_end ? 0 : bi->universe);

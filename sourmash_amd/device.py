@@ -150,6 +150,11 @@ class BitIndex:
         return lib.smgpu_bitindex_universe(self._ptr)
 
     @property
+    def builder(self):
+        "which builder made the index: 'dictionary' (sort-free passes, csrc/dictindex.hip) or 'sort' (radix sort of all pairs)"
+        return {1: "dictionary", 2: "sort"}.get(int(lib.smgpu_bitindex_builder(self._ptr)), "?")
+
+    @property
     def stats(self):
         "(frequent hashes = bit columns, matrix increments the rare hashes cost per compare, threshold)"
         f, r, t = C.c_uint64(), C.c_uint64(), C.c_uint32()

@@ -99,3 +99,22 @@ def synth_gather_device(nq, ndb, dbsize, dev, seed=777, chunk=10_000, row_lo=0, 
     if rows:
         offsets[1:] = torch.cumsum(torch.cat(lens), 0)
     return q, hashes, offsets
+
+
+def synth_sketches_device(n, dev, seed=1234, pool_size=50_000, keep_one_in=10, chunk=2000):
+    """(hashes, offsets) int64 tensors on `dev`: n sketches drawn from a shared pool like synth_sketches (every pool hash kept
+    with probability 1 / keep_one_in, decided by splitmix of (row, pool index)), generated in HBM -- for collections too large
+    to build on the host in a benchmark's time (40,000 sketches = 2e8 hashes).  Identical on every rank."""
+    import torch
+    pool = torch.unique(splitmix63(torch.arange(pool_size, device=dev, dtype=torch.int64) + seed) % MAX_HASH_1000 + 1)
+    jj = torch.arange(pool.numel(), device=dev, dtype=torch.int64)
+    rows, lens = [], []
+    for lo in range(0, n, chunk):
+        i = torch.arange(lo, min(lo + chunk, n), device=dev, dtype=torch.int64)[:, None]
+        sel = splitmix63((i << 32) ^ jj[None, :] ^ (seed * 2654435761 % (1 << 31))) % keep_one_in == 0
+        rows.append(pool[None, :].expand(sel.shape[0], -1)[sel])      # row-major: every row's hashes in pool (= sorted) order
+        lens.append(sel.sum(dim=1))
+    hashes = torch.cat(rows)
+    offsets = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    offsets[1:] = torch.cumsum(torch.cat(lens), 0)
+    return hashes, offsets
