@@ -417,6 +417,13 @@ void smgpu_gather_stats(SmgpuGather *ptr, double *out8);
  * out[5] cached bytes, out[6] peak bytes held, out[7] reuses that waited on another stream's event. */
 void smgpu_arena_stats(uint64_t *out8);
 void smgpu_arena_trim(uint64_t keep_bytes);     /* give cached blocks back to the driver (0: all of them) */
+/* The gzip reader of the ingest path on its own (host threads, no device): inflates `path`, returns the decompressed length,
+ * the CRC-32 of the bytes it produced and whether the many-thread form (csrc/pargz.hpp: block starts found by search,
+ * window references resolved afterwards) carried the whole file; up to `cap` bytes are copied to `out` (may be NULL).
+ * threads 0: the CPUs this process may use; span_bytes 0: 4 MiB of compressed data per work unit.
+ * Replaces the single zlib stream behind screed / niffler (src/sourmash/command_sketch.py:697, src/core/benches/compute.rs:35-38). */
+uint64_t smgpu_gunzip_file(const char *path, uint32_t threads, uint64_t span_bytes, uint8_t *out, uint64_t cap, uint32_t *crc32_out,
+                           bool *parallel_used);
 void smgpu_gather_counters_get(const SmgpuGather *ptr, uint64_t *counts_out, void *stream);
 void smgpu_gather_begin(SmgpuGather *ptr, uint64_t threshold_hashes, uint64_t max_rounds, void *stream);
 uint64_t smgpu_gather_run(SmgpuGather *ptr, uint64_t *out_index, uint64_t *out_isect, uint64_t cap, void *stream);

@@ -17,6 +17,7 @@
 #include "../../include/sourmash_amd.h"
 #include "collection.hpp"
 #include "device_ctx.hpp"
+#include "pargz.hpp"
 #include "ingest.hpp"
 #include "murmur3.hpp"
 #include "residues.hpp"
@@ -1527,6 +1528,29 @@ void smgpu_arena_stats(uint64_t* out) {
     out[4] = a.live_bytes; out[5] = a.cached_bytes; out[6] = a.peak_bytes; out[7] = a.cross_stream_waits;
 }
 void smgpu_arena_trim(uint64_t keep_bytes) { arena_trim(keep_bytes); }
+uint64_t smgpu_gunzip_file(const char* path, uint32_t threads, uint64_t span_bytes, uint8_t* out, uint64_t cap, uint32_t* crc_out,
+                           bool* parallel_used) {
+    return landing<uint64_t>([&]() -> uint64_t {
+        try {
+            ParallelGunzip pg(path, threads, span_bytes ? (size_t)span_bytes : ((size_t)4 << 20));
+            std::vector<uint8_t> buf((size_t)8 << 20);
+            uint64_t total = 0;
+            uint32_t crc = 0;
+            for (;;) {
+                const size_t n = pg.read(buf.data(), buf.size());
+                if (n == 0) break;
+                if (crc_out) crc = (uint32_t)crc32_z(crc, buf.data(), n);
+                if (out && total < cap) memcpy(out + total, buf.data(), (size_t)std::min<uint64_t>(n, cap - total));
+                total += n;
+            }
+            if (crc_out) *crc_out = crc;
+            if (parallel_used) *parallel_used = pg.parallel();
+            return total;
+        } catch (const std::runtime_error& e) {
+            throw Error(E_NIFFLER, e.what());
+        }
+    });
+}
 void smgpu_gather_counters_get(const SmgpuGather* p, uint64_t* out, void* stream) {
     landing_void([&] {
         const GatherDev& g = reinterpret_cast<const GatherRaw*>(p)->g;

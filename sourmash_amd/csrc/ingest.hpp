@@ -17,6 +17,8 @@
 #include <sys/stat.h>
 #include <unistd.h>
 #include <zlib.h>
+#include <memory>
+#include "pargz.hpp"
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -60,9 +62,14 @@ class RawChunkSource {
         gz_ = got == 2 && magic[0] == 0x1f && magic[1] == 0x8b;
         for (int s = 0; s < SLOTS; ++s) { owner_[s] = s; filled_[s] = -1; len_[s] = 0; }
         if (gz_) {
-            gzf_ = gzdopen(dup(fd_), "rb");
-            if (!gzf_) { ::close(fd_); throw Error(E_NIFFLER, "cannot initialise gzip reader for " + path); }
-            gzbuffer(gzf_, 1 << 20);
+            // one large member of text inflates on many host threads (pargz.hpp); a worker of the many-files pipeline
+            // (max_readers == 1) keeps to one thread: there the files run side by side
+            try {
+                pg_.reset(new ParallelGunzip(path, max_readers <= 1 ? 1u : 0u));
+            } catch (const std::runtime_error& e) {
+                ::close(fd_);
+                throw Error(E_NIFFLER, std::string("cannot initialise gzip reader for ") + path + ": " + e.what());
+            }
             threads_.emplace_back([this] { produce_gz(); });
         } else {
             const uint64_t n_chunks = (size_ + chunk_ - 1) / chunk_;
@@ -80,7 +87,7 @@ class RawChunkSource {
         }
         cv_.notify_all();
         for (auto& t : threads_) t.join();
-        if (gzf_) gzclose(gzf_);
+        pg_.reset();
         if (fd_ >= 0) ::close(fd_);
     }
 
@@ -146,11 +153,11 @@ class RawChunkSource {
         for (int64_t seq = 0;; ++seq) {
             if (!claim(seq)) return;
             size_t got = 0;
-            while (got < chunk_) {
-                const int r = gzread(gzf_, ring_[seq % SLOTS].p + got, (unsigned)std::min<size_t>(chunk_ - got, 1u << 30));
-                if (r < 0) { fail(E_NIFFLER, "error while reading sequence file " + path_); return; }
-                if (r == 0) break;
-                got += (size_t)r;
+            try {
+                got = pg_->read(ring_[seq % SLOTS].p, chunk_);            // short only at the end of the stream
+            } catch (const std::runtime_error& e) {
+                fail(E_NIFFLER, e.what());
+                return;
             }
             if (got) publish(seq, got);
             if (got < chunk_) {                     // end of stream
@@ -168,7 +175,7 @@ class RawChunkSource {
     size_t chunk_;
     PinnedBuf* ring_;
     int fd_ = -1;
-    gzFile gzf_ = nullptr;
+    std::unique_ptr<ParallelGunzip> pg_;
     uint64_t size_ = 0;
     bool gz_ = false;
     std::mutex mu_;

@@ -166,3 +166,45 @@ def test_repeated_reads_keep_more_hashes_than_the_statistical_estimate(sm, tmp_p
     assert len(mh) == 1 and list(mh.hashes.values()) == [copies]
     sig, = sketch_file(fq, "k=31,scaled=1000")
     assert len(sig.minhash) == 1
+
+
+def test_one_large_gzip_member_inflated_on_many_threads(sm, tmp_path):
+    """A single big .fna.gz: the reader cuts the deflate stream into spans, finds block starts by search, inflates the spans on
+    all host threads and fills window references in afterwards (csrc/pargz.hpp).  Same sketch as from the plain file and as the
+    oracle's; SMG_GUNZIP_SEQUENTIAL=1 (one zlib stream, what the reference does: command_sketch.py:697) agrees too."""
+    import ctypes as C
+    import zlib
+    from sourmash_amd._lowlevel import lib
+    from sourmash_amd.sketch import sketch_file
+    n = 48_000_000
+    seq = oracle.synth_dna(0, n, seed=77, record_len=3_999_999)            # 12 records + separators
+    recs = bytes(seq).split(b"\n")
+    plain = tmp_path / "big.fa"
+    with open(plain, "wb") as fh:
+        for i, r in enumerate(recs):
+            if not r:
+                continue
+            a = np.frombuffer(r, dtype=np.uint8)
+            full = (len(a) // 60) * 60
+            fh.write(b">big_%d\n" % i)
+            fh.write(np.concatenate([a[:full].reshape(-1, 60), np.full((full // 60, 1), 10, dtype=np.uint8)], axis=1).tobytes())
+            if len(a) > full:
+                fh.write(a[full:].tobytes() + b"\n")
+    gz = tmp_path / "big.fa.gz"
+    co = zlib.compressobj(1, zlib.DEFLATED, 31)
+    with open(plain, "rb") as fi, open(gz, "wb") as fo:
+        while True:
+            block = fi.read(8 << 20)
+            if not block:
+                break
+            fo.write(co.compress(block))
+        fo.write(co.flush())
+    par = C.c_bool(False)
+    total = lib.smgpu_gunzip_file(str(gz).encode(), 0, 1 << 20, None, 0, None, C.byref(par))
+    assert total == plain.stat().st_size and par.value, "the file should be large enough for the many-thread form"
+    want = oracle.sketch_dna_bulk(np.frombuffer(seq, dtype=np.uint8), 31, scaled=1000, nthreads=8)
+    sig_plain, = sketch_file(str(plain), "k=31,scaled=1000")
+    sig_gz, = sketch_file(str(gz), "k=31,scaled=1000")
+    assert np.array_equal(sig_plain.minhash._mins_array(), want)
+    assert np.array_equal(sig_gz.minhash._mins_array(), want)
+    assert sig_gz.md5sum() == sig_plain.md5sum()
