@@ -1461,7 +1461,9 @@ static hipError_t gather_build_body(GatherDev& g, hipStream_t stream) {
     SMG_TRY(own_alloc(g, &g.qpos, (total + 4) * 4));                // kept: apply reads it instead of looking hashes up again
     // Small problems: one atomic per element is cheapest.  Large ones: range-partitioned, histogram and cursors in LDS.
     const char* force = getenv("SMG_GATHER_BUILD");
-    bool ranges = force ? !strcmp(force, "ranges") : (total >= (8ull << 20) && g.ndb >= 256);
+    // (round 3: from 1 M elements up instead of 8 M -- the range builder also leaves the block-ordered lists the persistent loop
+    //  needs: 5,000 x 1,000 with a 2e5-hash query 0.41 + 11.8 ms -> 0.48 + 9.1 ms, a 12,500-row shard of C5 3.8 + 29 -> 1.9 + 20)
+    bool ranges = force ? !strcmp(force, "ranges") : (total >= (1ull << 20) && g.ndb >= 256);
     // scratch of the range-partitioned builder: B x nq per-block prefixes and (R + 1) x ndb slice bounds, 4 bytes each.
     // B can shrink to what the 16-bit LDS slots allow (< 65536 rows per block); past 8 GB the atomic builder is used.
     uint64_t B = 64;
