@@ -243,6 +243,7 @@ class ParallelGunzip {
     // cap the reader at one core's copy rate, a third of what sixteen inflating threads deliver.  Large copies go out in four pieces.
     static void big_copy(uint8_t* dst, const uint8_t* src, size_t n) {
         constexpr size_t PIECE = (size_t)2 << 20;
+        if (n == 0) return;                                          // (an empty span has no buffer at all)
         if (n < 2 * PIECE) { memcpy(dst, src, n); return; }
         const unsigned parts = 4;
         const size_t per = (n / parts + 63) & ~(size_t)63;
@@ -558,7 +559,7 @@ class ParallelGunzip {
                 tail.assign(WIN, 0);
                 const size_t keep = WIN - s.out.size();
                 if (!window.empty()) memcpy(tail.data(), window.data() + (WIN - keep), keep);
-                memcpy(tail.data() + keep, s.out.data(), s.out.size());
+                if (!s.out.empty()) memcpy(tail.data() + keep, s.out.data(), s.out.size());   // (an empty span: the tail is the window)
             }
         }
         {

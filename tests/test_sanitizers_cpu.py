@@ -31,7 +31,7 @@ def test_c_abi_host_side_under_asan_ubsan():
         pytest.skip("clang's shared ASan runtime is not installed")
     subprocess.check_call(["make", "-C", os.path.join(ROOT, "sourmash_amd", "csrc"), "-j8", "-s", "asan"])
     lib = os.path.join(ROOT, "sourmash_amd", "libsourmash_amd_asan.so")
-    out = _run(rt[0], {"SMG_LIBRARY": lib}, ["tests/test_capi_cpu.py", "tests/test_collection_cpu.py", "tests/test_fastcall_cpu.py"])
+    out = _run(rt[0], {"SMG_LIBRARY": lib}, ["tests/test_capi_cpu.py", "tests/test_collection_cpu.py", "tests/test_fastcall_cpu.py", "tests/test_pargz_cpu.py"])
     assert "failed" not in out
 
 
