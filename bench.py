@@ -318,12 +318,13 @@ def gather_counters(db_bytes):
         return None, None, why
     build = 0.0
     for k in ("build_bounds_kernel", "build_range_kernel<0>", "build_merge_counts_kernel", "build_partition_kernel", "build_scatter_kernel",
-              "qtable_kernel", "qrec_kernel"):
+              "qtable_kernel", "qrec_kernel"):        # (qtable_kernel also runs in front of every overlap pass: averaged per dispatch)
         f, w = pmc.get(k, "FETCH_SIZE"), pmc.get(k, "WRITE_SIZE")
         if f is None or w is None:
             return None, None, f"{PMC_GATHER_FILE} has no rows for {k}"
         build += f + w
-    fo, wo = pmc.get("stream_lookup_kernel<3>", "FETCH_SIZE"), pmc.get("stream_lookup_kernel<3>", "WRITE_SIZE")
+    ok = "overlap_wide_kernel" if pmc.get("overlap_wide_kernel", "FETCH_SIZE") is not None else "stream_lookup_kernel<3>"
+    fo, wo = pmc.get(ok, "FETCH_SIZE"), pmc.get(ok, "WRITE_SIZE")
     over = None if fo is None or wo is None else int((fo + wo) * 1024)
     return int(build * 1024), over, (PMC_GATHER_FILE + ": FETCH_SIZE + WRITE_SIZE as counted (KiB per dispatch, tools/bench_gather.py under separate "
                                      "--pmc passes); FETCH_SIZE counts half of the bytes of wide coalesced reads on gfx950, so reads of the "
@@ -667,7 +668,7 @@ def single_gpu_extras(extra, torch, np, dev, be, smd, synth_sketches, synth_gath
     ms_ov = timed(lambda: be.overlaps(gq5, gq5.numel(), gh5, goff5, 100_000, cnt, 0), reps=3)
     extra["overlaps_1M_vs_100000"] = {"ms": round(ms_ov, 3), "sketches_per_s": round(100_000 / (ms_ov * 1e-3), 1),
                                       "roofline": hbm_roofline(db_bytes + 8 * int(gq5.numel()), ms_ov,
-                                                               "8 B per database hash + the query once; stream_lookup_kernel (query slices through LDS, every database hash looked at once)",
+                                                               "8 B per database hash + the query once; overlap_wide_kernel (one workgroup per CU, ranges of ~10,000 query hashes in LDS, a wave per row visit)",
                                                                traffic=pmc_overlap, traffic_note=pmc_note)}
 
 
