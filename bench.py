@@ -452,7 +452,7 @@ def bench_gather_dist(torch, np, dev, be, parallel, synth_gather_device, world, 
            "exchanges": stats.get("exchanges"), "rounds_per_exchange": stats.get("rounds_per_exchange"),
            "records_per_rank": stats.get("records_per_rank"),
            "exchange_bytes_per_rank": (stats["records_per_rank"] * stats["record_words"] * 8) if stats.get("records_per_rank") else None,
-           "collective": "all-gather of candidate rows (rccl)" if use_dist else "none (native single-shard loop)",
+           "collective": (stats.get("protocol") or "all-gather of candidate rows (rccl)") if use_dist else "none (native single-shard loop)",
            "overlaps_non_increasing": bool(all(a >= b for a, b in zip(iso, iso[1:]))),
            "first": res[:2], "last": res[-1:] if res else None,
            "note": "wall clock of index build + every round, threshold_bp 50,000; exact parity at this size: "
@@ -516,7 +516,7 @@ def bench_gather_xl_dist(torch, dev, be, parallel, synth_gather_device, world, r
             "total_ms": round(best * 1e3, 2), "datasets_per_s": round(ndb / best, 1), "scaling": "weak",
             "index_build_kernels_ms": stats.get("build_kernels_ms"), "loop_kernels_ms": stats.get("loop_gpu_ms"),
             "exchanges": stats.get("exchanges"), "rounds_per_exchange": stats.get("rounds_per_exchange"),
-            "collective": "all-gather of candidate rows (rccl)" if use_dist else "none (native single-shard loop)",
+            "collective": (stats.get("protocol") or "all-gather of candidate rows (rccl)") if use_dist else "none (native single-shard loop)",
             "overlaps_non_increasing": bool(all(a >= b for a, b in zip(iso, iso[1:]))),
             "winners_distinct": bool(len({r[0] for r in res}) == len(res)),
             "first": res[:2], "last": res[-1:] if res else None}

@@ -427,6 +427,24 @@ uint64_t smgpu_gunzip_file(const char *path, uint32_t threads, uint64_t span_byt
 void smgpu_gather_counters_get(const SmgpuGather *ptr, uint64_t *counts_out, void *stream);
 void smgpu_gather_begin(SmgpuGather *ptr, uint64_t threshold_hashes, uint64_t max_rounds, void *stream);
 uint64_t smgpu_gather_run(SmgpuGather *ptr, uint64_t *out_index, uint64_t *out_isect, uint64_t cap, void *stream);
+/* Several ranks, one shard each, running the SAME rounds inside their resident loop kernels: the local winners meet in
+ * host-visible memory every rank can reach (POSIX shared memory registered with HIP when the ranks are processes on one node;
+ * private pinned memory when one process drives all of them), the best is the round's winner everywhere and its query
+ * positions travel through the same memory -- no host collective inside the loop.  xchg_new: shm_name NULL/"" = private
+ * memory; else rank 0 creates (create = true) and the others open it after a barrier.  rowcap >= the longest row of any shard
+ * (smgpu_gather_longest_row, MAX over ranks).  launch_shared enqueues the armed loop (after smgpu_gather_begin) and returns
+ * false when this index cannot run the resident loop (every rank must check smgpu_gather_loop_eligible first and all agree);
+ * run_id: the same on every rank, different from the previous run on this memory; n_wg: workgroups (0 = one per CU).
+ * smgpu_gather_results then waits and reads the picks (identical on every rank).  Replaces the per-round walk of
+ * CounterGather.peek / consume across shards, src/sourmash/index/__init__.py:817-909. */
+typedef struct SmgpuGatherXchg SmgpuGatherXchg;
+SmgpuGatherXchg *smgpu_gather_xchg_new(const char *shm_name, uint32_t world, uint64_t rowcap, bool create);
+void smgpu_gather_xchg_free(SmgpuGatherXchg *ptr);
+bool smgpu_gather_loop_eligible(const SmgpuGather *ptr, uint32_t n_wg);
+/* (one process driving several ranks: reserve every rank's loop memory BEFORE the first launch -- an allocation may synchronise
+ *  the device while a loop that already runs waits for its peers) */
+void smgpu_gather_loop_reserve(SmgpuGather *ptr, uint32_t n_wg, uint64_t rowcap, void *stream);
+bool smgpu_gather_launch_shared(SmgpuGather *ptr, SmgpuGatherXchg *xchg, uint32_t rank, uint32_t run_id, uint32_t n_wg, void *stream);
 uint64_t smgpu_gather_longest_row(const SmgpuGather *ptr);   /* hashes in the shard's longest row: stride >= 3 + the longest row of any shard */
 void smgpu_gather_topk_export_raw(SmgpuGather *ptr, uint64_t *d_records, uint32_t k, uint64_t stride, void *stream);
 void smgpu_gather_cands_load_raw(SmgpuGather *ptr, const uint64_t *d_records, uint32_t n_records, uint64_t stride,

@@ -34,7 +34,7 @@ _SCALARS = {
     "SourmashStr": SourmashStr,
 }
 _OPAQUE = {"SourmashKmerMinHash", "SourmashSignature", "SourmashComputeParameters", "SmgpuSketchSet", "SmgpuCounter", "SmgpuBitIndex",
-           "SmgpuGather", "SmgpuCollection"}
+           "SmgpuGather", "SmgpuCollection", "SmgpuGatherXchg"}
 
 
 def _ctype(decl, is_arg=False):

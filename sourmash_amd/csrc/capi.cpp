@@ -16,6 +16,10 @@
 #include <thread>
 #include "../../include/sourmash_amd.h"
 #include "collection.hpp"
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include "device_ctx.hpp"
 #include "pargz.hpp"
 #include "ingest.hpp"
@@ -1569,6 +1573,78 @@ uint64_t smgpu_gather_run(SmgpuGather* p, uint64_t* out_index, uint64_t* out_ise
         return gather_drain(reinterpret_cast<GatherRaw*>(p)->g, out_index, out_isect, cap, (hipStream_t)stream);
     });
 }
+// ---- several ranks running the same gather rounds through shared host memory (gather.hip: gather_launch_loop) ----
+struct GatherXchg {
+    unsigned long long* host = nullptr;      // the mapping in this process
+    unsigned long long* dev = nullptr;       // its device-visible address
+    size_t bytes = 0;
+    uint32_t world = 0;
+    uint64_t rowcap = 0;
+    std::string shm_name;                    // "" : private pinned memory (one process drives every rank)
+    bool creator = false, registered = false;
+    ~GatherXchg() {
+        if (!host) return;
+        if (shm_name.empty()) (void)hipHostFree(host);
+        else {
+            if (registered) (void)hipHostUnregister(host);
+            munmap(host, bytes);
+            if (creator) shm_unlink(shm_name.c_str());
+        }
+    }
+};
+SmgpuGatherXchg* smgpu_gather_xchg_new(const char* shm_name, uint32_t world, uint64_t rowcap, bool create) {
+    return landing<SmgpuGatherXchg*>([&]() -> SmgpuGatherXchg* {
+        if (world == 0 || world > 1024 || rowcap == 0) throw err_internal("gather exchange: bad geometry");
+        std::unique_ptr<GatherXchg> x(new GatherXchg());
+        x->world = world; x->rowcap = rowcap;
+        x->bytes = ((size_t)2 * world * 4 + (size_t)2 * world * rowcap) * 8;
+        x->bytes = (x->bytes + 4095) & ~(size_t)4095;
+        if (!shm_name || !*shm_name) {
+            hip_check(hipHostMalloc((void**)&x->host, x->bytes, hipHostMallocDefault), "hipHostMalloc");
+            memset(x->host, 0, x->bytes);
+            x->dev = x->host;
+        } else {
+            x->shm_name = shm_name;
+            x->creator = create;
+            const int fd = shm_open(shm_name, create ? (O_CREAT | O_EXCL | O_RDWR) : O_RDWR, 0600);
+            if (fd < 0) throw err_internal(std::string("gather exchange: shm_open(") + shm_name + ") failed");
+            if (create && ftruncate(fd, (off_t)x->bytes) != 0) { ::close(fd); shm_unlink(shm_name); throw err_internal("gather exchange: ftruncate failed"); }
+            void* m = mmap(nullptr, x->bytes, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+            ::close(fd);
+            if (m == MAP_FAILED) { if (create) shm_unlink(shm_name); throw err_internal("gather exchange: mmap failed"); }
+            x->host = (unsigned long long*)m;
+            if (create) memset(x->host, 0, x->bytes);
+            hip_check(hipHostRegister(x->host, x->bytes, hipHostRegisterPortable | hipHostRegisterMapped), "hipHostRegister");
+            x->registered = true;
+            void* d = nullptr;
+            hip_check(hipHostGetDevicePointer(&d, x->host, 0), "hipHostGetDevicePointer");
+            x->dev = (unsigned long long*)d;
+        }
+        return reinterpret_cast<SmgpuGatherXchg*>(x.release());
+    });
+}
+void smgpu_gather_xchg_free(SmgpuGatherXchg* p) { delete reinterpret_cast<GatherXchg*>(p); }
+bool smgpu_gather_loop_eligible(const SmgpuGather* p, uint32_t n_wg) {
+    return gather_loop_eligible(reinterpret_cast<const GatherRaw*>(p)->g, n_wg);
+}
+void smgpu_gather_loop_reserve(SmgpuGather* p, uint32_t n_wg, uint64_t rowcap, void* stream) {
+    landing_void([&] { hip_check(gather_loop_reserve(reinterpret_cast<GatherRaw*>(p)->g, (hipStream_t)stream, n_wg, rowcap), "loop memory"); });
+}
+// enqueue the armed loop of this rank's shard (nothing is waited for: smgpu_gather_results reads it back)
+bool smgpu_gather_launch_shared(SmgpuGather* p, SmgpuGatherXchg* xp, uint32_t rank, uint32_t run_id, uint32_t n_wg, void* stream) {
+    return landing<bool>([&]() -> bool {
+        GatherDev& g = reinterpret_cast<GatherRaw*>(p)->g;
+        GatherXchg* x = reinterpret_cast<GatherXchg*>(xp);
+        GatherShared sh;
+        sh.rec = x->dev;
+        sh.rows = x->dev + (size_t)2 * x->world * 4;
+        sh.W = x->world; sh.rank = rank; sh.rowcap = x->rowcap; sh.run_id = run_id;
+        if (g.longest_row > x->rowcap) throw err_internal("gather exchange: a row of this shard is longer than the exchange's slots");
+        bool ran = false;
+        hip_check(gather_launch_loop(g, (hipStream_t)stream, n_wg, &sh, &ran), "gather loop (shared)");
+        return ran;
+    });
+}
 uint64_t smgpu_gather_longest_row(const SmgpuGather* p) { return reinterpret_cast<const GatherRaw*>(p)->g.longest_row; }
 void smgpu_gather_topk_export_raw(SmgpuGather* p, uint64_t* d_records, uint32_t k, uint64_t stride, void* stream) {
     landing_void([&] {
@@ -1603,6 +1679,8 @@ uint64_t smgpu_gather_results(SmgpuGather* p, uint64_t* out_index, uint64_t* out
         unsigned long long head[GS_SLOTS];
         hip_check(hipMemcpyAsync(head, g.state, sizeof(head), hipMemcpyDeviceToHost, st), "D2H");
         hip_check(hipStreamSynchronize(st), "sync");
+        if (head[GS_ERR]) throw err_internal("gather loop: a workgroup or rank waited too long for its peers (code " + std::to_string(head[GS_ERR]) + ", epoch " +
+                                             std::to_string(head[13]) + ", workgroup " + std::to_string(head[14]) + ")");
         const uint64_t n = head[GS_ROUNDS], m = n < cap ? n : cap;
         if (m) {
             hip_check(hipMemcpyAsync(out_index, g.out_idx, m * 8, hipMemcpyDeviceToHost, st), "D2H");

@@ -1044,6 +1044,12 @@ struct LoopArgs {
     uint64_t ndb, nq, index_base;
     uint32_t rows_per_wg, block_rows, B, chunk, bitmap_words;
     unsigned long long* dbg;            // SMG_GATHER_TRACE: [8] phase times of workgroup 0 in 10 ns ticks (null: not collected)
+    // ---- several ranks, one database shard each (W > 0): the round's winner is agreed through host-visible memory ----
+    uint32_t W, rank, epoch_base, rowcap;   // ranks, this rank, tag offset of this run, granules per row slot
+    unsigned long long* x_rec;          // shared: [2][W][4] record granules {key hi, key lo, row length, -}
+    unsigned long long* x_rows;         // shared: [2][W][rowcap] {tag, query position} granules: every rank's local best row
+    unsigned long long* gwin;           // local:  [2][4] the global winner {key hi, key lo, length, owner rank}
+    unsigned long long* stage;          // local:  [2][rowcap] the winner's positions, copied in once per round by a few workgroups
 };
 
 __device__ __forceinline__ unsigned long long gran_load(const unsigned long long* p) {
@@ -1052,6 +1058,14 @@ __device__ __forceinline__ unsigned long long gran_load(const unsigned long long
 __device__ __forceinline__ void gran_store(unsigned long long* p, unsigned long long v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// the same across devices / processes: host-visible (pinned, coherent) memory, system scope
+__device__ __forceinline__ unsigned long long sys_load(const unsigned long long* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ void sys_store(unsigned long long* p, unsigned long long v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+constexpr uint32_t PL_STAGERS = 8;             // workgroups that copy a remote winner's row into local memory
 
 __global__ __launch_bounds__(PL_THREADS) void gather_loop_kernel(LoopArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t pl_lds[];
@@ -1095,6 +1109,7 @@ __global__ __launch_bounds__(PL_THREADS) void gather_loop_kernel(LoopArgs a) {
     const unsigned long long thr = a.state[GS_THR], maxr = a.state[GS_MAXR];
     unsigned long long last_key = 0;
     bool failed = false;
+    uint32_t fail_code = 1, fail_epoch = 0;
     __syncthreads();
     const bool timing = a.dbg != nullptr && wg == 0 && tid == 0;
     unsigned long long t_mark = timing ? wall_clock64() : 0, t_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -1102,6 +1117,7 @@ __global__ __launch_bounds__(PL_THREADS) void gather_loop_kernel(LoopArgs a) {
 #define PL_LAP(slot) do { if (timing) { const unsigned long long t_ = wall_clock64(); t_acc[slot] += t_ - t_mark; t_mark = t_; } } while (0)
     if (timing) a.dbg[6] = t_mark;
     for (uint32_t epoch = 1;; ++epoch) {
+        fail_epoch = epoch;
         // ---- local best of the owned rows -> this workgroup's record of the epoch ----
         unsigned long long k = 0;
         for (uint32_t i = tid; i < n_own; i += PL_THREADS) {
@@ -1155,7 +1171,7 @@ __global__ __launch_bounds__(PL_THREADS) void gather_loop_kernel(LoopArgs a) {
                 if (key > best) { best = key; b_start = (uint32_t)x2; b_len = (uint32_t)x3; }
             }
             if (__syncthreads_and(ok ? 1 : 0)) break;
-            if (spins >= PL_SPIN_LIMIT) { failed = true; break; }        // uniform: every thread counts the same sweeps
+            if (spins >= PL_SPIN_LIMIT) { failed = true; fail_code = 11; break; }        // uniform: every thread counts the same sweeps
             __builtin_amdgcn_s_sleep(1);
             if (timing) t_acc[5] += 1;                                  // sweeps that found a record missing
         }
@@ -1170,10 +1186,108 @@ __global__ __launch_bounds__(PL_THREADS) void gather_loop_kernel(LoopArgs a) {
         for (int w = 0; w < PL_THREADS / 64; ++w) top = s_red[w] > top ? s_red[w] : top;
         if (top != 0 && mine == top) { s_wstart = b_start; s_wlen = b_len; }   // keys are distinct: one writer
         __syncthreads();
+        // ---- several ranks: the local winners meet in shared memory; the best of them is the round's winner everywhere ----
+        const unsigned long long* stage_row = nullptr;             // non-null: the winner lives on another rank; its positions come from here
+        if (a.W > 0) {
+            const uint32_t par = epoch & 1u;
+            const unsigned long long gtag = (unsigned long long)(a.epoch_base + epoch) << 32, ltag = (unsigned long long)epoch << 32;
+            const uint32_t lstart = s_wstart, llen = top ? s_wlen : 0u;
+            if (llen > a.rowcap) { if (tid == 0) a.state[GS_ERR] = 4; failed = true; break; }   // (the host sized the slots from the longest row)
+            __syncthreads();                                        // (s_wstart / s_wlen are about to be reused)
+            // every rank pushes its own best row (query positions, tagged): whoever wins, its row is already on its way
+            unsigned long long* my_row = a.x_rows + ((uint64_t)par * a.W + a.rank) * a.rowcap;
+            for (uint32_t i = wg * PL_THREADS + (uint32_t)tid; i < llen; i += n_wg * PL_THREADS)
+                sys_store(my_row + i, gtag | a.qpos[(uint64_t)lstart + i]);
+            unsigned long long* gw = a.gwin + (uint64_t)par * 4;
+            if (wg == 0) {
+                if (tid == 0) {
+                    unsigned long long* rec = a.x_rec + ((uint64_t)par * a.W + a.rank) * 4;
+                    sys_store(rec + 0, gtag | (top >> 32));
+                    sys_store(rec + 1, gtag | (top & 0xffffffffull));
+                    sys_store(rec + 2, gtag | llen);
+                }
+                // one lane per rank polls that rank's record
+                unsigned long long rk = 0;
+                uint32_t rl = 0;
+                for (uint32_t spins = 0;; ++spins) {
+                    bool ok = true;
+                    if ((uint32_t)tid < a.W) {
+                        const unsigned long long* rec = a.x_rec + ((uint64_t)par * a.W + (uint32_t)tid) * 4;
+                        const unsigned long long x0 = sys_load(rec + 0), x1 = sys_load(rec + 1), x2 = sys_load(rec + 2);
+                        ok = (x0 >> 32) == (gtag >> 32) && (x1 >> 32) == (gtag >> 32) && (x2 >> 32) == (gtag >> 32);
+                        rk = ((x0 & 0xffffffffull) << 32) | (x1 & 0xffffffffull);
+                        rl = (uint32_t)x2;
+                    }
+                    if (__syncthreads_and(ok ? 1 : 0)) break;
+                    if (spins >= PL_SPIN_LIMIT) { failed = true; fail_code = 12; break; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                if (!failed) {
+                    // the best of at most 1024 ranks' keys (distinct: the global index is part of the key)
+                    unsigned long long m = (uint32_t)tid < a.W ? rk : 0ull;
+                    m = wave_max(m);
+                    m = __shfl(m, 0);
+                    if (lane == 0) s_red[wave] = m;
+                    __syncthreads();
+                    unsigned long long g = 0;
+                    for (int w = 0; w < PL_THREADS / 64; ++w) g = s_red[w] > g ? s_red[w] : g;
+                    if (g == 0 && tid == 0) {                        // nobody has anything left
+                        gran_store(gw + 0, ltag); gran_store(gw + 1, ltag); gran_store(gw + 2, ltag); gran_store(gw + 3, ltag);
+                    } else if ((uint32_t)tid < a.W && rk == g && g != 0) {
+                        gran_store(gw + 0, ltag | (g >> 32));
+                        gran_store(gw + 1, ltag | (g & 0xffffffffull));
+                        gran_store(gw + 2, ltag | rl);
+                        gran_store(gw + 3, ltag | (uint32_t)tid);
+                    }
+                }
+            }
+            // every workgroup learns the global winner from local memory
+            unsigned long long g0v = 0, g1v = 0, g2v = 0, g3v = 0;
+            if (!failed)
+                for (uint32_t spins = 0;; ++spins) {
+                    g0v = gran_load(gw + 0); g1v = gran_load(gw + 1); g2v = gran_load(gw + 2); g3v = gran_load(gw + 3);
+                    const bool ok = (g0v >> 32) == epoch && (g1v >> 32) == epoch && (g2v >> 32) == epoch && (g3v >> 32) == epoch;
+                    if (__syncthreads_and(ok ? 1 : 0)) break;
+                    if (spins >= PL_SPIN_LIMIT) { failed = true; fail_code = 13; break; }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+            if (failed) break;
+            top = ((g0v & 0xffffffffull) << 32) | (g1v & 0xffffffffull);
+            const uint32_t owner = (uint32_t)g3v, glen = (uint32_t)g2v;
+            if (tid == 0) { s_wlen = glen; if (owner == a.rank) s_wstart = lstart; }
+            __syncthreads();
+            if (top != 0 && owner != a.rank) {
+                // the winner's positions: copied out of shared memory ONCE per rank by a few workgroups, read locally by all
+                unsigned long long* st = a.stage + (uint64_t)par * a.rowcap;
+                const unsigned long long* src = a.x_rows + ((uint64_t)par * a.W + owner) * a.rowcap;
+                if (wg < PL_STAGERS)
+                    for (uint32_t i = wg * PL_THREADS + (uint32_t)tid; i < glen; i += PL_STAGERS * PL_THREADS) {
+                        unsigned long long x = sys_load(src + i);
+                        for (uint32_t spins = 0; (x >> 32) != (gtag >> 32) && spins < PL_SPIN_LIMIT; ++spins) {
+                            __builtin_amdgcn_s_sleep(1);
+                            x = sys_load(src + i);
+                        }
+                        if ((x >> 32) != (gtag >> 32)) a.state[GS_ERR] = 2;   // the owner's row never arrived: the run is void
+                        gran_store(st + i, (x >> 32) == (gtag >> 32) ? (ltag | (x & 0xffffffffull)) : (ltag | 0xffffffffull));
+                    }
+                stage_row = st;
+            }
+        }
         // ---- stop rules on the round's winner (search.py:15-37; the same values in every workgroup) ----
         last_key = top;
         if (top == 0 || qlen == 0 || qlen < thr || (top >> 32) < thr) break;
         const uint32_t wstart = s_wstart, wlen = s_wlen;
+        // a position of the winning row: from this rank's own index, or from the staged copy of another rank's row
+        auto row_pos = [&](uint32_t i) -> uint32_t {
+            if (!stage_row) return a.qpos[(uint64_t)wstart + i];
+            unsigned long long x = gran_load(stage_row + i);
+            for (uint32_t spins = 0; (x >> 32) != epoch && spins < PL_SPIN_LIMIT; ++spins) {
+                __builtin_amdgcn_s_sleep(1);
+                x = gran_load(stage_row + i);
+            }
+            if ((x >> 32) != epoch) a.state[GS_ERR] = 3;                // the staged copy never arrived: the run is void
+            return (x >> 32) == epoch ? (uint32_t)x : NONE32;
+        };
         // ---- apply: I = row ∩ uncovered leaves the set; the owned rows holding a hash of I lose it ----
         uint32_t isect = 0;
         // a thread's positions of a chunk are asked for together, and the NEXT chunk's before this chunk's postings are walked
@@ -1181,7 +1295,7 @@ __global__ __launch_bounds__(PL_THREADS) void gather_loop_kernel(LoopArgs a) {
 #pragma unroll
         for (int u = 0; u < PL_ROW_PER; ++u) {
             const uint32_t i = (uint32_t)u * PL_THREADS + (uint32_t)tid;
-            pos[u] = i < wlen && i < a.chunk ? a.qpos[(uint64_t)wstart + i] : NONE32;
+            pos[u] = i < wlen && i < a.chunk ? row_pos(i) : NONE32;
         }
         const uint32_t grp = (uint32_t)tid / PL_LANES, gl = (uint32_t)tid % PL_LANES;
         constexpr uint32_t GROUPS = PL_THREADS / PL_LANES;
@@ -1207,7 +1321,7 @@ __global__ __launch_bounds__(PL_THREADS) void gather_loop_kernel(LoopArgs a) {
 #pragma unroll
                 for (int u = 0; u < PL_ROW_PER; ++u) {
                     const uint32_t i = n0 + (uint32_t)u * PL_THREADS + (uint32_t)tid;
-                    pos[u] = i < n1 ? a.qpos[(uint64_t)wstart + i] : NONE32;
+                    pos[u] = i < n1 ? row_pos(i) : NONE32;
                 }
             }
             __syncthreads();
@@ -1313,7 +1427,7 @@ __global__ __launch_bounds__(PL_THREADS) void gather_loop_kernel(LoopArgs a) {
         a.state[GS_PENDING] = 0;
         a.state[GS_DONE] = 1;
     }
-    if (failed && tid == 0) a.state[GS_ERR] = 1;
+    if (failed && tid == 0) { a.state[GS_ERR] = fail_code; a.state[13] = fail_epoch; a.state[14] = wg; }
 }
 
 __global__ __launch_bounds__(256) void longest_row_kernel(const uint64_t* __restrict__ offsets, uint64_t ndb,
@@ -1637,31 +1751,76 @@ hipError_t gather_consume_list(GatherDev& g, const uint64_t* d_list, hipStream_t
     return hipGetLastError();
 }
 
-hipError_t gather_run_persistent(GatherDev& g, hipStream_t stream, bool* ran) {
-    *ran = false;
+// Geometry of the persistent loop for this index on `n_wg` workgroups; false: not applicable (the two-kernel rounds serve)
+static bool loop_geometry(const GatherDev& g, uint32_t n_wg, LoopArgs* a, size_t* lds, size_t* budget_out) {
     static const bool off = [] { const char* e = getenv("SMG_GATHER_LOOP"); return e && strcmp(e, "persistent") != 0; }();
-    if (off || !g.block_pre || g.counters_touched || g.ndb == 0 || g.nq == 0 || !g.out_idx) return hipSuccess;
+    if (off || !g.block_pre || g.counters_touched || g.ndb == 0 || g.nq == 0 || n_wg == 0) return false;
+    if (g.pinned[0] >= 0xffffffffull) return false;                // pinned[0]: the shard's element count (offsets travel as 32 bits)
+    const int lds_max = 160 * 1024;                                // gfx950: 160 KiB per CU, one workgroup per CU here
+    a->rows_per_wg = (uint32_t)((g.ndb + (uint64_t)n_wg - 1) / (uint64_t)n_wg);
+    a->block_rows = g.block_rows;
+    a->B = g.block_B;
+    a->bitmap_words = (uint32_t)((g.nq + 31) / 32);
+    const size_t fixed = ((size_t)a->bitmap_words + 2 * (size_t)a->rows_per_wg + 1) * 4;
+    const size_t budget = (size_t)lds_max - 1024;                  // the kernel's static scalars
+    a->chunk = 4096;
+    while (a->chunk > 512 && fixed + (size_t)a->chunk * 4 > budget) a->chunk >>= 1;
+    if (fixed + (size_t)a->chunk * 4 > budget) return false;       // query or rows too large for LDS
+    *lds = fixed + (size_t)a->chunk * 4;
+    *budget_out = budget;
+    return true;
+}
+
+bool gather_loop_eligible(const GatherDev& g, uint32_t n_wg) {
+    LoopArgs a;
+    size_t lds = 0, budget = 0;
+    if (n_wg == 0) {
+        int dev = 0, n_cu = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return false;
+        n_wg = (uint32_t)(n_cu > 0 ? n_cu : 0);
+    }
+    return loop_geometry(g, n_wg, &a, &lds, &budget);
+}
+
+// the loop's local exchange memory, (re)allocated only when the geometry grows.  A driver that launches several ranks' loops
+// from ONE process calls this for all of them first: an allocation may synchronise the device, and a loop kernel that is
+// already waiting for its peers would never see them start.
+hipError_t gather_loop_reserve(GatherDev& g, hipStream_t stream, uint32_t n_wg, uint64_t rowcap) {
+    if (n_wg == 0) {
+        int dev = 0, n_cu = 0;
+        SMG_TRY(hipGetDevice(&dev));
+        SMG_TRY(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+        n_wg = (uint32_t)n_cu;
+    }
+    const size_t words = (size_t)2 * n_wg * 4 + 16 + 8 + (size_t)2 * rowcap;
+    if (!g.loop_xchg || g.loop_wgs != n_wg || g.loop_words < words) {
+        if (g.loop_xchg) arena_free(g.loop_xchg, stream);
+        g.loop_xchg = nullptr;
+        SMG_TRY(own_alloc(g, &g.loop_xchg, words * 8, stream));
+        g.loop_wgs = n_wg;
+        g.loop_words = words;
+    }
+    return hipSuccess;
+}
+
+hipError_t gather_launch_loop(GatherDev& g, hipStream_t stream, uint32_t n_wg, const GatherShared* sh, bool* ran) {
+    *ran = false;
+    if (!g.out_idx) return hipSuccess;
     int dev = 0, n_cu = 0;
     SMG_TRY(hipGetDevice(&dev));
     SMG_TRY(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
     if (n_cu <= 0) return hipSuccess;
-    const int lds_max = 160 * 1024;                                // gfx950: 160 KiB per CU, one workgroup per CU here
-    // element offsets travel as 32-bit granule payloads
-    if (g.pinned[0] >= 0xffffffffull) return hipSuccess;           // pinned[0]: the shard's element count, read by the build
+    if (n_wg == 0 || n_wg > (uint32_t)n_cu) n_wg = (uint32_t)n_cu;
+    // Workgroup b runs on XCD b % 8 and a workgroup fills a CU (16 waves of 111 VGPRs): a grid that is a multiple of 8 puts the
+    // same number on every XCD.  (Three loops of 85 workgroups on one GPU put 33 on XCD 0, which has 32 CUs: one workgroup
+    // never became resident and its peers waited for it until they gave up.)
+    if (n_wg >= 8) n_wg -= n_wg % 8;
     LoopArgs a;
+    size_t lds = 0, budget = 0;
+    if (!loop_geometry(g, n_wg, &a, &lds, &budget)) return hipSuccess;
     a.offsets = g.offsets; a.qpos = g.qpos; a.post_rows = g.post_rows; a.block_pre = g.block_pre; a.post_off = g.post_off;
     a.counters = g.counters; a.alive = g.alive; a.state = g.state; a.out_idx = g.out_idx; a.out_isect = g.out_isect;
     a.ndb = g.ndb; a.nq = g.nq; a.index_base = g.index_base;
-    a.rows_per_wg = (uint32_t)((g.ndb + (uint64_t)n_cu - 1) / (uint64_t)n_cu);
-    a.block_rows = g.block_rows;
-    a.B = g.block_B;
-    a.bitmap_words = (uint32_t)((g.nq + 31) / 32);
-    const size_t fixed = ((size_t)a.bitmap_words + 2 * (size_t)a.rows_per_wg + 1) * 4;
-    const size_t budget = (size_t)lds_max - 1024;                  // the kernel's static scalars
-    a.chunk = 4096;
-    while (a.chunk > 512 && fixed + (size_t)a.chunk * 4 > budget) a.chunk >>= 1;
-    if (fixed + (size_t)a.chunk * 4 > budget) return hipSuccess;    // query or rows too large for LDS: the two-kernel rounds
-    const size_t lds = fixed + (size_t)a.chunk * 4;
     static int attr_state = 0;                                     // 1: set, -1: the runtime refused (no persistent loop)
     if (attr_state == 0) {
         const hipError_t e = hipFuncSetAttribute((const void*)gather_loop_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)budget);
@@ -1669,16 +1828,20 @@ hipError_t gather_run_persistent(GatherDev& g, hipStream_t stream, bool* ran) {
         if (e != hipSuccess) (void)hipGetLastError();
     }
     if (attr_state < 0) return hipSuccess;
-    if (!g.loop_xchg || g.loop_wgs != (uint32_t)n_cu) {
-        if (g.loop_xchg) arena_free(g.loop_xchg, stream);
-        g.loop_xchg = nullptr;
-        SMG_TRY(own_alloc(g, &g.loop_xchg, ((size_t)2 * n_cu * 4 + 16) * 8, stream));
-        g.loop_wgs = (uint32_t)n_cu;
-    }
+    // local exchange memory: [2][n_wg][4] workgroup records, 16 trace words, [2][4] global winner, [2][rowcap] staged row
+    const uint64_t rowcap = sh ? sh->rowcap : 0;
+    if (sh && (sh->W == 0 || sh->W > (uint32_t)PL_THREADS || sh->rank >= sh->W || rowcap == 0)) return hipErrorInvalidValue;
+    SMG_TRY(gather_loop_reserve(g, stream, n_wg, rowcap));
     a.xchg = g.loop_xchg;
     static const bool trace = getenv("SMG_GATHER_TRACE") != nullptr;
-    a.dbg = trace ? g.loop_xchg + (size_t)2 * n_cu * 4 : nullptr;           // 8 words behind the granules
-    SMG_TRY(hipMemsetAsync(g.loop_xchg, 0, ((size_t)2 * n_cu * 4 + 16) * 8, stream));   // epochs count from 1 within a launch
+    a.dbg = trace ? g.loop_xchg + (size_t)2 * n_wg * 4 : nullptr;           // 16 words behind the granules
+    a.gwin = g.loop_xchg + (size_t)2 * n_wg * 4 + 16;
+    a.stage = a.gwin + 8;
+    a.W = sh ? sh->W : 0; a.rank = sh ? sh->rank : 0; a.rowcap = (uint32_t)rowcap;
+    a.epoch_base = sh ? (sh->run_id & 0xfffu) << 20 : 0;                    // tags of the shared slots: unique per run, no zeroing between runs
+    a.x_rec = sh ? sh->rec : nullptr; a.x_rows = sh ? sh->rows : nullptr;
+    SMG_TRY(hipMemsetAsync(g.loop_xchg, 0, ((size_t)2 * n_wg * 4 + 16 + 8) * 8, stream));   // local epochs count from 1 within a launch
+    if (rowcap) SMG_TRY(hipMemsetAsync(a.stage, 0, (size_t)2 * rowcap * 8, stream));
     // One workgroup per CU: all of them must be resident at once (the sweeps wait for every workgroup).  A plain launch has
     // the same residency as a cooperative one (MI355X_MICROARCH.md) without its 15-19 us and without the cooperative
     // interception that crashes rocprofv3 here; the occupancy query is the check the cooperative launch would make, and a
@@ -1693,10 +1856,10 @@ hipError_t gather_run_persistent(GatherDev& g, hipStream_t stream, bool* ran) {
         }
         if (blocks_per_cu < 1) return hipSuccess;
     }
-    hipLaunchKernelGGL(gather_loop_kernel, dim3((unsigned)n_cu), dim3(PL_THREADS), lds, stream, a);
+    hipLaunchKernelGGL(gather_loop_kernel, dim3(n_wg), dim3(PL_THREADS), lds, stream, a);
     SMG_TRY(hipGetLastError());
     *ran = true;
-    if (trace) {
+    if (trace && !sh) {
         unsigned long long d[16];
         SMG_TRY(hipMemcpyAsync(d, a.dbg, sizeof(d), hipMemcpyDeviceToHost, stream));
         SMG_TRY(hipStreamSynchronize(stream));
@@ -1708,6 +1871,8 @@ hipError_t gather_run_persistent(GatherDev& g, hipStream_t stream, bool* ran) {
     }
     return hipSuccess;
 }
+
+hipError_t gather_run_persistent(GatherDev& g, hipStream_t stream, bool* ran) { return gather_launch_loop(g, stream, 0, nullptr, ran); }
 
 hipError_t gather_enqueue_rounds(GatherDev& g, unsigned rounds, hipStream_t stream) {
     for (unsigned r = 0; r < rounds; ++r) {

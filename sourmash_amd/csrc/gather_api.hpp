@@ -50,6 +50,7 @@ struct GatherDev {
     uint32_t block_B = 0, block_rows = 0;
     unsigned long long* loop_xchg = nullptr;   // persistent loop: [2][workgroups][4] record granules
     uint32_t loop_wgs = 0;
+    size_t loop_words = 0;
     bool counters_touched = false;      // a caller overwrote counters (smgpu_counter_set): the fused loops keep to saturating steps
     uint64_t npairs = 0;
     uint64_t longest_row = 0;           // hashes in the shard's longest row (sizes the candidate records)
@@ -125,6 +126,21 @@ hipError_t gather_consume_list(GatherDev& g, const uint64_t* d_list, hipStream_t
 // range builder and the query's bitmap + a workgroup's rows fit LDS; *ran = false (and nothing launched) otherwise.
 // The caller synchronises the stream and reads the state block as after any batch of rounds.
 hipError_t gather_run_persistent(GatherDev& g, hipStream_t stream, bool* ran);
+// Several ranks (one process and database shard each) running the SAME rounds: the local winners meet in host-visible memory
+// shared by all ranks (pinned; POSIX shared memory registered with HIP when the ranks are processes), the best of them is
+// the round's winner everywhere, and its query positions reach the other ranks through the same memory -- no host
+// collective inside the loop.  rec: [2][W][4] granules, rows: [2][W][rowcap] granules (device-visible addresses).
+struct GatherShared {
+    unsigned long long* rec;
+    unsigned long long* rows;
+    uint32_t W, rank;
+    uint64_t rowcap;              // >= the longest row of any rank's shard
+    uint32_t run_id;              // the same on every rank, different from the previous run on this memory
+};
+// the persistent loop on n_wg workgroups (0: one per CU), alone (sh == nullptr) or as rank sh->rank of sh->W
+hipError_t gather_launch_loop(GatherDev& g, hipStream_t stream, uint32_t n_wg, const GatherShared* sh, bool* ran);
+bool gather_loop_eligible(const GatherDev& g, uint32_t n_wg);
+hipError_t gather_loop_reserve(GatherDev& g, hipStream_t stream, uint32_t n_wg, uint64_t rowcap);
 // Enqueue `rounds` rounds of pick(check) + apply on one GPU (kernels are no-ops once GS_DONE is set).
 hipError_t gather_enqueue_rounds(GatherDev& g, unsigned rounds, hipStream_t stream);
 // The same rounds as replays of one captured graph of GATHER_GRAPH_ROUNDS rounds (rounded up): one host call per 64

@@ -134,6 +134,16 @@ class _DeviceGatherState:
         "single GPU: every round enqueued back to back, the host only polls the done flag"
         return self._fetch(self.lib.smgpu_gather_run)
 
+    def loop_eligible(self, n_wg=0):
+        "can this index run the resident loop kernel on n_wg workgroups (0: one per CU)?"
+        return bool(self.lib.smgpu_gather_loop_eligible(self._ptr, int(n_wg)))
+
+    def launch_shared(self, exchange, rank, run_id, n_wg=0, stream=None):
+        """enqueue the armed loop as rank `rank` of the exchange's world (every rank's loop kernel agrees on each round's winner
+        through the exchange's host-visible memory); results() waits for it.  -> False if the resident loop does not apply"""
+        s = C.c_void_p(stream.cuda_stream) if stream is not None else self.b._s()
+        return bool(self.rustcall(self.lib.smgpu_gather_launch_shared, self._ptr, exchange._ptr, int(rank), int(run_id), int(n_wg), s))
+
     def stats(self):
         """what the index build and the last run() cost (smgpu_gather_stats): kernel spans from HIP events next to the
         host wall clocks, driver-allocator time and calls, host synchronisations -- localises host effects"""
@@ -150,6 +160,21 @@ class _DeviceGatherState:
         out = np.zeros(max(ndb, 1), dtype=np.uint64)
         self.rustcall(self.lib.smgpu_gather_counters_get, self._ptr, out.ctypes.data_as(C.c_void_p), self.b._s())
         return out[:ndb]
+
+
+class GatherExchange:
+    """Host-visible memory through which the loop kernels of several ranks agree on every round's winner (smgpu_gather_xchg_*):
+    POSIX shared memory registered with HIP when the ranks are processes of one node, private pinned memory when one process
+    drives every rank (tests)."""
+
+    def __init__(self, lib, rustcall, world, rowcap, shm_name=None, create=True):
+        self.lib, self.world, self.rowcap, self.shm_name = lib, int(world), int(rowcap), shm_name
+        self._ptr = rustcall(lib.smgpu_gather_xchg_new, shm_name.encode() if shm_name else None, int(world), int(rowcap), bool(create))
+
+    def __del__(self):
+        if getattr(self, "_ptr", None) and self.lib is not None:
+            self.lib.smgpu_gather_xchg_free(self._ptr)
+            self._ptr = None
 
 
 class DeviceBackend:
@@ -212,6 +237,30 @@ class DeviceBackend:
         return out
 
     # -- gather --
+    def open_exchange(self, world, rank, rowcap, group=None):
+        """the shared exchange of this job's ranks (one node): rank 0 creates a POSIX shared-memory segment, the name travels
+        by broadcast, everybody maps and registers it; kept and reused while it is large enough.  run ids count up per use."""
+        cur = getattr(self, "_xchg", None)
+        if cur is None or cur.world != world or cur.rowcap < rowcap:
+            import os
+            dist = _dist()
+            name = None
+            if world > 1 or (dist.is_available() and dist.is_initialized()):
+                self._xchg_seq = getattr(self, "_xchg_seq", 0) + 1
+                box = ["/smg_gx_%d_%d" % (os.getpid(), self._xchg_seq)] if rank == 0 else [None]
+                dist.broadcast_object_list(box, src=0, group=group)
+                name = box[0]
+                self._xchg = GatherExchange(self.lib, self.rustcall, world, rowcap, name, create=True) if rank == 0 else None
+                dist.barrier(group=group)                                   # the segment exists and is zeroed
+                if rank != 0:
+                    self._xchg = GatherExchange(self.lib, self.rustcall, world, rowcap, name, create=False)
+                dist.barrier(group=group)                                   # everybody has it mapped
+            else:
+                self._xchg = GatherExchange(self.lib, self.rustcall, world, rowcap)
+            self._xchg_runs = 0
+        self._xchg_runs += 1
+        return self._xchg, self._xchg_runs
+
     def gather_state(self, query, nq, hashes, offsets, ndb, index_base):
         "Invert the shard against the query; -> step object (pick / export / apply / poll / results / run)."
         return _DeviceGatherState(self, query, nq, hashes, offsets, ndb, index_base)
@@ -356,6 +405,24 @@ def gather_distributed(query, nq, shard_hashes, shard_offsets, n_shard, index_ba
         if stats is not None and hasattr(state, "stats"):
             stats.update(state.stats())
         return res
+    # Ranks of one node whose indexes can run the resident loop: every rank's loop kernel runs all rounds, the local winners
+    # meet in shared host memory each round (csrc/gather.hip: gather_launch_loop) -- no host collective inside the loop.
+    # SMG_GATHER_EXCHANGE=records keeps the candidate-record protocol below (what ranks on different nodes would need).
+    import os
+    if hasattr(backend, "open_exchange") and hasattr(state, "launch_shared") and os.environ.get("SMG_GATHER_EXCHANGE", "shared") != "records":
+        ok = backend.zeros((1,), torch.int64)
+        ok[0] = 1 if state.loop_eligible(0) else 0
+        if collect and dist.is_available() and dist.is_initialized():
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+        if int(ok.item()) == 1:
+            xchg, run_id = backend.open_exchange(world, rank, stride - CAND_HEAD, group)
+            if state.launch_shared(xchg, rank, run_id):
+                res = state.results()
+                if stats is not None:
+                    stats.update(exchanges=0, rounds_per_exchange=None, records_per_rank=None, record_words=None, rounds=len(res),
+                                 protocol="resident loop kernels, winners agreed through shared host memory every round")
+                    stats.update(state.stats())
+                return res
     k, rounds = exchange_geometry(world)
     mine = backend.zeros((k, stride), torch.int64)
     everyone = backend.zeros((world * k, stride), torch.int64) if collect else mine
@@ -462,6 +529,49 @@ def search_distributed(query, nq, shard_hashes, shard_offsets, n_shard, index_ba
     hits = rank_search_hits(shared, sizes, nq, threshold=threshold, do_containment=do_containment,
                             do_max_containment=do_max_containment, best_only=best_only)
     return [(s, first + r) for s, r in hits]
+
+
+def gather_emulated_ranks(query, nq, shards, threshold_bp, scaled, backend, max_rounds=None):
+    """Diagnostic / test driver: the shared-exchange gather with every rank driven by THIS process on one GPU -- one loop kernel
+    per rank, each on its own stream with an equal share of the CUs, a private pinned exchange.  shards: [(hashes, offsets, n,
+    index_base)] in rank order.  -> the picks as every rank reports them (a list per rank; they must be identical)."""
+    torch = backend.torch
+    world = len(shards)
+    states = [backend.gather_state(query, nq, h, off, n, base) for h, off, n, base in shards]
+    total = sum(n for _, _, n, _ in shards)
+    rowcap = max(max(st.longest_row() for st in states), 1)
+    thr = math.ceil(float(threshold_bp) / scaled) if threshold_bp else 0
+    n_cu = torch.cuda.get_device_properties(backend.device).multi_processor_count
+    # a loop workgroup fills a CU and workgroup b lands on XCD b % 8: every rank gets a multiple of 8, and the ranks together leave
+    # CUs free (a grid that does not fit is not an error to the runtime -- the surplus workgroup just never starts)
+    per = max(8, min(64, (n_cu // world) // 8 * 8))
+    if not all(st.loop_eligible(per) for st in states):
+        return None
+    xchg = GatherExchange(backend.lib, backend.rustcall, world, rowcap)
+    backend._emu_runs = getattr(backend, "_emu_runs", 0) + 1
+    for st in states:
+        st.begin(thr, min(max_rounds, total) if max_rounds is not None else total)
+        backend.rustcall(backend.lib.smgpu_gather_loop_reserve, st._ptr, per, rowcap, backend._s())   # no allocation between the launches
+    torch.cuda.synchronize()
+    # one stream per rank, created once and kept: HIP multiplexes streams onto a few hardware queues, and two loops that land on
+    # the same queue run one after the other -- the first would wait for a peer that cannot start (seen with fresh streams
+    # on every call: the second call's pair shared a queue)
+    pool = backend.__dict__.setdefault("_emu_streams", [])
+    while len(pool) < world:
+        st_new = torch.cuda.Stream(device=backend.device)
+        with torch.cuda.stream(st_new):                      # first use creates the stream's hardware queue (~5 ms): not between launches
+            backend.zeros((1,), torch.int64).add_(1)
+        pool.append(st_new)
+    torch.cuda.synchronize()
+    streams = pool[:world]
+    for r, (st, stream) in enumerate(zip(states, streams)):
+        if not st.launch_shared(xchg, r, backend._emu_runs, per, stream=stream):
+            raise RuntimeError("the resident loop did not start for emulated rank %d" % r)
+    out = []
+    for st, stream in zip(states, streams):
+        with torch.cuda.stream(stream):
+            out.append(st.results())
+    return out
 
 
 def _all_gather_rows(dist, out, mine, world, group):

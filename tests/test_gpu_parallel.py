@@ -199,3 +199,62 @@ def test_search_and_prefetch_over_emulated_shards(be):
     assert pf == prefetch_rows(want_shared, 100_000, 1000)
     assert rank_search_hits(want_shared, want_sizes, len(qh), best_only=True) == \
         parallel.search_distributed(q, len(qh), h, off, len(dbh), 0, be, best_only=True)
+
+
+def test_gather_shared_exchange_emulated_ranks():
+    """The multi-rank form of the resident loop (csrc/gather.hip: gather_launch_loop with a GatherShared): every rank's loop kernel
+    runs all rounds, the local winners meet in host-visible memory each round, the winner's query positions travel through
+    the same memory.  One process drives 2 / 3 / 4 ranks here -- a kernel per rank on its own stream with its share of the CUs,
+    a private pinned exchange -- so the protocol itself (tags, double buffering, staging of a remote winner's row, replicated
+    stop rules, ties across ranks) runs for real; across processes only the memory is different (POSIX shared memory).
+    Own interpreter: the loops of all ranks must run AT THE SAME TIME, so every stream needs its own hardware queue
+    (GPU_MAX_HW_QUEUES, read when HIP starts; with the default of 4, two of the streams can share a queue and the second
+    loop would wait for the first to end -- a limit of driving several ranks from one process, not of the protocol)."""
+    import os, subprocess, sys
+    from conftest import ROOT
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import test_gpu_parallel as t\nt._shared_exchange_emulated()\nprint('ok')\n" % (ROOT, os.path.join(ROOT, "tests")))
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900,
+                       env=dict(os.environ, GPU_MAX_HW_QUEUES="8", SMG_GATHER_BUILD="ranges"))
+    assert p.returncode == 0 and p.stdout.strip().endswith("ok"), (p.stdout[-1500:], p.stderr[-1500:])
+
+
+def _shared_exchange_emulated():
+    import torch
+    from sourmash_amd import device as smd, parallel
+    from sourmash_amd.synth import synth_gather
+    be = parallel.DeviceBackend()
+    qh, dbh = synth_gather(n_query=60_000, n_db=2400, db_size=700)
+    dbh[1700] = dbh[3].copy()                                    # a tie across ranks: the lowest global index wins
+    dbh[17] = np.zeros(0, dtype=np.uint64)
+    dbh[2000] = np.unique(np.concatenate(dbh[1000:1030]))        # a long row (sizes the exchange slots) on a later rank
+    q = torch.from_numpy(qh.view(np.int64).copy()).cuda()
+    fh, foff = oracle.make_csr(dbh)
+    for world in (2, 3, 4):
+        cuts = [len(dbh) * r // world for r in range(world + 1)]
+        shards = []
+        for lo, hi in zip(cuts, cuts[1:]):
+            h, off = smd.pack_csr(dbh[lo:hi])
+            shards.append((h, off, hi - lo, lo))
+        for thr_bp, cap in ((0, None), (30_000, None), (0, 9)):
+            want = oracle.gather(qh, fh, foff, threshold_bp=thr_bp, scaled=1000, nthreads=8)
+            if cap:
+                want = want[:cap]
+            got = parallel.gather_emulated_ranks(q, len(qh), shards, thr_bp, 1000, be, max_rounds=cap)
+            assert got is not None, "the resident loop should apply to these shards"
+            for r, picks in enumerate(got):
+                assert picks == want, (world, thr_bp, cap, r, picks[:3], want[:3], len(picks), len(want))
+
+
+def test_gather_shared_exchange_two_processes_one_gpu():
+    """Two PROCESSES, one database shard each, their loop kernels sharing this one GPU and agreeing on every round through POSIX
+    shared memory that both registered with HIP (tools/shared_2proc.py): the cross-process path ranks on different GPUs of a
+    node take, minus the second device.  Both report the oracle's ordered picks."""
+    import os, subprocess, sys
+    from conftest import ROOT
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "shared_2proc.py")], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, GPU_MAX_HW_QUEUES="8"))
+    lines = [ln for ln in p.stdout.strip().splitlines() if ln[:1] in "01"]
+    assert p.returncode == 0 and len(lines) == 2, (p.stdout[-1500:], p.stderr[-1500:])
+    for rank, ln in enumerate(lines):
+        assert ln.startswith("%d True (True, " % rank), lines
