@@ -346,7 +346,18 @@ SourmashKmerMinHash* kmerminhash_new(uint64_t scaled, uint32_t k, HashFunctions 
         return reinterpret_cast<SourmashKmerMinHash*>(new KmerMinHash(scaled, k, hf, seed, track, n));
     });
 }
-void kmerminhash_free(SourmashKmerMinHash* p) { delete RAW(p); }
+void kmerminhash_free(SourmashKmerMinHash* p) {
+    KmerMinHash* m = RAW(p);
+    if (m) {
+        if (DeviceCtx* ctx = DeviceCtx::peek()) {                       // its device mirror goes with it
+            if (m->mirrored_gen) {
+                std::lock_guard<std::recursive_mutex> g(ctx->mutex());
+                ctx->forget(*m);
+            }
+        }
+    }
+    delete m;
+}
 void kmerminhash_slice_free(uint64_t* ptr, uintptr_t) { free(ptr); }
 
 void kmerminhash_add_sequence(SourmashKmerMinHash* p, const char* sequence, bool force) {

@@ -67,9 +67,12 @@ struct PairStats {
 
 class DeviceCtx {
   public:
+    // the context if one was ever made (freeing a sketch must not create one, nor fail without a device)
+    static DeviceCtx*& instance() { static DeviceCtx* ctx = nullptr; return ctx; }
+    static DeviceCtx* peek() { return instance(); }
     // One context per process (leaked on purpose: HIP may already be torn down at exit).
     static DeviceCtx& get() {
-        static DeviceCtx* ctx = nullptr;
+        DeviceCtx*& ctx = instance();
         static std::mutex mu;
         std::lock_guard<std::mutex> g(mu);
         if (!ctx) {
@@ -159,6 +162,8 @@ class DeviceCtx {
     static constexpr size_t MIRROR_ENTRIES_MAX = 4096;
 
     Mirror& mirror_of(const KmerMinHash& m, bool want_abund) {
+        if (m.mirrored_gen && m.mirrored_gen != m.gen) drop_mirror(mirrors_.find(m.mirrored_gen));   // the content it had before
+        m.mirrored_gen = m.gen;
         auto it = mirrors_.find(m.gen);
         if (it != mirrors_.end()) {
             Mirror& mr = it->second;
@@ -188,6 +193,10 @@ class DeviceCtx {
         hip_check(arena_alloc((void**)dst, n * 8 + 64, stream_), "arena_alloc");
         hip_check(hipMemcpyAsync(*dst, src, n * 8, hipMemcpyHostToDevice, stream_), "H2D");
         mirror_bytes_ += n * 8;
+    }
+    // a sketch is being freed: its mirror goes with it (a copy that shares the content re-uploads on its next use)
+    void forget(const KmerMinHash& m) {
+        if (m.mirrored_gen) drop_mirror(mirrors_.find(m.mirrored_gen));
     }
     void drop_mirror(std::unordered_map<uint64_t, Mirror>::iterator it) {
         if (it == mirrors_.end()) return;

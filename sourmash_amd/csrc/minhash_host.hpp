@@ -51,6 +51,8 @@ struct KmerMinHash {
     // keep a mirror of a sketch's hashes between per-pair calls (device_ctx.hpp: mirror_of) and drop it the moment the
     // sketch changes.  Code that writes mins / abunds directly calls touch().
     uint64_t gen = next_gen();
+    mutable uint64_t mirrored_gen = 0;   // the generation this object last had a device mirror made for (0: none): lets the device
+                                         // drop the mirror of the content this object no longer holds instead of waiting for LRU
     static uint64_t next_gen() {
         static std::atomic<uint64_t> g{1};
         return g.fetch_add(1, std::memory_order_relaxed);
@@ -58,6 +60,20 @@ struct KmerMinHash {
     void touch() { gen = next_gen(); }
 
     KmerMinHash() = default;
+    // a copy shares the content generation (same hashes -> same device mirror) but not the bookkeeping of who made that mirror:
+    // freeing or changing the copy must not take the original's mirror away
+    KmerMinHash(const KmerMinHash& o)
+        : num(o.num), ksize(o.ksize), hash_function(o.hash_function), seed(o.seed), max_hash(o.max_hash),
+          track_abundance(o.track_abundance), mins(o.mins), abunds(o.abunds), pending(o.pending), gen(o.gen), mirrored_gen(0) {}
+    KmerMinHash& operator=(const KmerMinHash& o) {
+        if (this != &o) {
+            num = o.num; ksize = o.ksize; hash_function = o.hash_function; seed = o.seed; max_hash = o.max_hash;
+            track_abundance = o.track_abundance; mins = o.mins; abunds = o.abunds; pending = o.pending; gen = o.gen;
+        }                                   // (mirrored_gen stays: the next device use drops the mirror of the old content)
+        return *this;
+    }
+    KmerMinHash(KmerMinHash&&) = default;
+    KmerMinHash& operator=(KmerMinHash&&) = default;
     // minhash.rs:186-221
     KmerMinHash(uint64_t scaled, uint32_t k, uint32_t hf, uint64_t seed_, bool track, uint32_t n)
         : num(n), ksize(k), hash_function(hf), seed(seed_), max_hash(max_hash_for_scaled(scaled)),
