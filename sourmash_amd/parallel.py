@@ -409,20 +409,47 @@ def gather_distributed(query, nq, shard_hashes, shard_offsets, n_shard, index_ba
     # meet in shared host memory each round (csrc/gather.hip: gather_launch_loop) -- no host collective inside the loop.
     # SMG_GATHER_EXCHANGE=records keeps the candidate-record protocol below (what ranks on different nodes would need).
     import os
-    if hasattr(backend, "open_exchange") and hasattr(state, "launch_shared") and os.environ.get("SMG_GATHER_EXCHANGE", "shared") != "records":
+    # (stepwise=True asks for the record protocol explicitly: tests, and the single-rank comparison of the two)
+    if (collect and not stepwise and hasattr(backend, "open_exchange") and hasattr(state, "launch_shared")
+            and os.environ.get("SMG_GATHER_EXCHANGE", "shared") != "records"):
         ok = backend.zeros((1,), torch.int64)
         ok[0] = 1 if state.loop_eligible(0) else 0
         if collect and dist.is_available() and dist.is_initialized():
             dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
         if int(ok.item()) == 1:
-            xchg, run_id = backend.open_exchange(world, rank, stride - CAND_HEAD, group)
-            if state.launch_shared(xchg, rank, run_id):
-                res = state.results()
-                if stats is not None:
-                    stats.update(exchanges=0, rounds_per_exchange=None, records_per_rank=None, record_words=None, rounds=len(res),
-                                 protocol="resident loop kernels, winners agreed through shared host memory every round")
-                    stats.update(state.stats())
-                return res
+            # Every step is agreed among the ranks before anybody acts on it: a rank that fell back to the record protocol on
+            # its own would sit in a collective the others never join.
+            def all_ok(flag):
+                t = backend.zeros((1,), torch.int64)
+                t[0] = 1 if flag else 0
+                if collect and dist.is_available() and dist.is_initialized():
+                    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+                return int(t.item()) == 1
+            res, good = None, False
+            try:
+                xchg, run_id = backend.open_exchange(world, rank, stride - CAND_HEAD, group)
+                opened = True
+            except Exception:                                   # (shared memory / registration not available here)
+                opened = False
+            if all_ok(opened):
+                launched = state.launch_shared(xchg, rank, run_id)
+                if launched:
+                    try:
+                        res = state.results()                   # waits for the loop; raises if a peer never showed up
+                        good = True
+                    except Exception:
+                        good = False
+                if all_ok(good):
+                    if stats is not None:
+                        stats.update(exchanges=0, rounds_per_exchange=None, records_per_rank=None, record_words=None, rounds=len(res),
+                                     protocol="resident loop kernels, winners agreed through shared host memory every round")
+                        stats.update(state.stats())
+                    return res
+            # the shared exchange did not work out on some rank: start over with a fresh index and the record protocol
+            state = backend.gather_state(query, nq, shard_hashes, shard_offsets, n_shard, index_base)
+            state.begin(thr, min(max_rounds, total) if max_rounds is not None else total)
+            if stats is not None:
+                stats["shared_exchange"] = "failed on some rank; record protocol used"
     k, rounds = exchange_geometry(world)
     mine = backend.zeros((k, stride), torch.int64)
     everyone = backend.zeros((world * k, stride), torch.int64) if collect else mine

@@ -258,3 +258,33 @@ def test_gather_shared_exchange_two_processes_one_gpu():
     assert p.returncode == 0 and len(lines) == 2, (p.stdout[-1500:], p.stderr[-1500:])
     for rank, ln in enumerate(lines):
         assert ln.startswith("%d True (True, " % rank), lines
+
+
+def test_gather_distributed_falls_back_when_the_shared_exchange_is_unavailable(be, monkeypatch):
+    """gather_distributed with the collectives' code path taken on one rank (force_collectives): the shared-memory exchange
+    by default; when opening it fails -- on any rank: the ranks agree before anybody acts -- a fresh index and the record
+    protocol take over.  Both give the oracle's picks."""
+    import torch
+    from sourmash_amd import device as smd, parallel
+    from sourmash_amd.synth import synth_gather
+    import os
+    import torch.distributed as dist
+    monkeypatch.setenv("SMG_GATHER_BUILD", "ranges")
+    qh, dbh = synth_gather(n_query=50_000, n_db=1300, db_size=600)
+    q = torch.from_numpy(qh.view(np.int64).copy()).cuda()
+    h, off = smd.pack_csr(dbh)
+    want = oracle.gather(qh, *oracle.make_csr(dbh), threshold_bp=20_000, scaled=1000, nthreads=8)
+    dist.init_process_group("nccl", rank=0, world_size=1, init_method="tcp://127.0.0.1:%d" % (29600 + os.getpid() % 300),
+                            device_id=torch.device("cuda", torch.cuda.current_device()))
+    try:
+        stats = {}
+        assert parallel.gather_distributed(q, len(qh), h, off, len(dbh), 0, 20_000, 1000, be, force_collectives=True, stats=stats) == want
+        assert "shared host memory" in stats.get("protocol", ""), stats
+        def broken(*a, **k):
+            raise OSError("no shared memory here")
+        monkeypatch.setattr(be, "open_exchange", broken)
+        stats = {}
+        assert parallel.gather_distributed(q, len(qh), h, off, len(dbh), 0, 20_000, 1000, be, force_collectives=True, stats=stats) == want
+        assert stats.get("shared_exchange", "").startswith("failed") and stats["exchanges"] > 0, stats
+    finally:
+        dist.destroy_process_group()
