@@ -420,7 +420,7 @@ void smgpu_arena_trim(uint64_t keep_bytes);     /* give cached blocks back to th
 /* The gzip reader of the ingest path on its own (host threads, no device): inflates `path`, returns the decompressed length,
  * the CRC-32 of the bytes it produced and whether the many-thread form (csrc/pargz.hpp: block starts found by search,
  * window references resolved afterwards) carried the whole file; up to `cap` bytes are copied to `out` (may be NULL).
- * threads 0: the CPUs this process may use; span_bytes 0: 4 MiB of compressed data per work unit.
+ * threads 0: the CPUs this process may use; span_bytes 0: 1 MiB of compressed data per work unit.
  * Replaces the single zlib stream behind screed / niffler (src/sourmash/command_sketch.py:697, src/core/benches/compute.rs:35-38). */
 uint64_t smgpu_gunzip_file(const char *path, uint32_t threads, uint64_t span_bytes, uint8_t *out, uint64_t cap, uint32_t *crc32_out,
                            bool *parallel_used);

@@ -1547,7 +1547,7 @@ uint64_t smgpu_gunzip_file(const char* path, uint32_t threads, uint64_t span_byt
                            bool* parallel_used) {
     return landing<uint64_t>([&]() -> uint64_t {
         try {
-            ParallelGunzip pg(path, threads, span_bytes ? (size_t)span_bytes : ((size_t)4 << 20));
+            ParallelGunzip pg(path, threads, span_bytes ? (size_t)span_bytes : ((size_t)1 << 20));
             std::vector<uint8_t> buf((size_t)8 << 20);
             uint64_t total = 0;
             uint32_t crc = 0;

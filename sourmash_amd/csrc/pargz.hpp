@@ -30,6 +30,7 @@
 #include <zlib.h>
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <functional>
 #include <mutex>
@@ -188,7 +189,7 @@ struct RawInflate {
 class ParallelGunzip {
   public:
     // span_bytes: compressed bytes per work unit; threads: 0 = hardware concurrency (at most 32)
-    explicit ParallelGunzip(const std::string& path, unsigned threads = 0, size_t span_bytes = (size_t)4 << 20)
+    explicit ParallelGunzip(const std::string& path, unsigned threads = 0, size_t span_bytes = (size_t)1 << 20)
         : path_(path), span_(span_bytes) {
         fd_ = ::open(path.c_str(), O_RDONLY);
         if (fd_ < 0) throw std::runtime_error("cannot open " + path);
@@ -209,6 +210,11 @@ class ParallelGunzip {
     }
     ~ParallelGunzip() {
         stop_workers();
+        if (parallel_ && getenv("SMG_GUNZIP_TRACE"))
+            fprintf(stderr, "[gunzip] %s: %u threads, %llu spans; worker ms: block search %.0f, first pass %.0f, second pass %.0f, waiting for "
+                            "the span in front %.0f, crc %.0f; consumer ms: waiting %.0f, copying %.0f\n", path_.c_str(), n_threads_,
+                    (unsigned long long)n_spans_, t_search_ * 1e-6, t_pass1_ * 1e-6, t_pass2_ * 1e-6, t_wait_tail_ * 1e-6, t_crc_ * 1e-6,
+                    t_consumer_wait_ * 1e-6, t_copy_ * 1e-6);
         for (Span* c : spans_) delete c;
         for (Span* c : free_spans_) delete c;
         if (gzf_) gzclose(gzf_);
@@ -232,7 +238,9 @@ class ParallelGunzip {
                 cur_off_ = 0;
             }
             const size_t k = std::min(want - got, cur_->out.size() - cur_off_);
+            const uint64_t tcp = now_ns();
             big_copy(dst + got, cur_->out.data() + cur_off_, k);
+            t_copy_ += now_ns() - tcp;
             got += k;
             cur_off_ += k;
             if (cur_off_ == cur_->out.size()) { recycle(cur_); cur_ = nullptr; }
@@ -349,7 +357,7 @@ class ParallelGunzip {
                                                                       // a short tail may hold nothing but the final block)
         tails_.assign(n_spans_, std::vector<uint8_t>());
         tail_state_.assign(n_spans_, 0);
-        in_flight_max_ = 2 * n_threads_ + 2;
+        in_flight_max_ = n_threads_ + 4;                             // (every span in flight is ~6 MB of freshly touched memory)
         static_dicts();
         for (unsigned t = 0; t < n_threads_; ++t) workers_.emplace_back([this] { work(); });
     }
@@ -409,7 +417,9 @@ class ParallelGunzip {
         // (a block of 16,384 symbols can be longer than a small span: look up to 256 KB ahead; two spans may then share a start,
         //  and the one in front is empty)
         const uint64_t look = std::max<uint64_t>(span_, 256u << 10) * 8;
+        const uint64_t ts = now_ns();
         uint64_t b = find_block(i * span_ * 8, look);
+        t_search_ += now_ns() - ts;
         // nothing up to the end of the stream: what is left holds no further (non-final) block start -- the span in front
         // runs to the end, and this one and the ones behind it are empty
         if (b == UINT64_MAX && i * span_ * 8 + look + 64 >= deflate_len_ * 8) b = AT_END;
@@ -449,6 +459,7 @@ class ParallelGunzip {
         if (s.out.size() < cap) s.out.resize(cap);                 // (a recycled span keeps its buffer: no zero-fill, no page faults)
         size_t produced = 0;
         bool reached = false;
+        const uint64_t t1 = now_ns();
         for (;;) {
             if (produced == s.out.size()) s.out.resize(s.out.size() * 2);
             ri.zs.next_out = s.out.data() + produced;
@@ -474,6 +485,7 @@ class ParallelGunzip {
             }
         }
         if (!reached) { s.why = "span did not end on a block boundary"; return; }
+        t_pass1_ += now_ns() - t1;
         s.out.resize(produced);
         s.marked_until = 0;
         s.lowbits.clear();
@@ -496,6 +508,7 @@ class ParallelGunzip {
                 }
             }
             s.marked_until = last;
+            const uint64_t t2 = now_ns();
             if (last) {
                 // second pass over that prefix with the low-bits dictionary
                 RawInflate r2;
@@ -513,15 +526,17 @@ class ParallelGunzip {
                     if (rc != Z_OK && !(rc == Z_BUF_ERROR && r2.zs.avail_out == 0)) { s.why = "second pass failed"; return; }
                 }
                 if (got < last) { s.why = "second pass came up short"; return; }
+                t_pass2_ += now_ns() - t2;
             }
         }
         s.ok = true;
     }
 
     // fill the marked bytes of s from the 32 KB in front of it (the resolved tail of the previous span)
-    static void resolve(Span& s, const std::vector<uint8_t>& window) {
+    static void resolve(Span& s, const std::vector<uint8_t>& window, size_t from, size_t to) {
         uint8_t* o = s.out.data();
-        for (size_t i = 0; i < (size_t)s.marked_until; ++i)
+        if (to > (size_t)s.marked_until) to = (size_t)s.marked_until;
+        for (size_t i = from; i < to; ++i)
             if (o[i] & 0x80u) {
                 const uint32_t pos = ((uint32_t)(o[i] & 0x7fu) << 8) | s.lowbits[i];
                 o[i] = window[pos];
@@ -534,14 +549,46 @@ class ParallelGunzip {
     void finish(Span& s) {
         using namespace pargz_detail;
         std::vector<uint8_t> window;
+        const uint64_t tw = now_ns();
         if (s.index > 0) {
             std::unique_lock<std::mutex> lk(tmu_);
             tcv_.wait(lk, [&] { return tail_state_[s.index - 1] != 0 || abort_ || failed_; });
             if (tail_state_[s.index - 1] != 1) s.ok = false;            // the span in front failed (or everything was called off)
             else window = tails_[s.index - 1];
         }
+        t_wait_tail_ += now_ns() - tw;
+        // The spans depend on each other only through their last 32 KB: those are filled in and published FIRST (a few
+        // microseconds per link of the chain); the rest of the span follows while the next span is already being resolved.
+        const size_t n_out = s.out.size();
+        const size_t tail_from = n_out >= WIN ? n_out - WIN : 0;
+        if (s.ok && s.index > 0) resolve(s, window, tail_from, n_out);
+        {
+            std::vector<uint8_t> tail;
+            bool tail_ok = s.ok;
+            if (tail_ok) {
+                uint64_t any = 0;
+                for (size_t i = tail_from; i < n_out; ++i) any |= s.out[i];
+                if (any & 0x80u) { s.ok = tail_ok = false; s.why = "the file holds bytes >= 0x80 (not 7-bit text)"; }
+            }
+            if (tail_ok) {
+                if (n_out >= WIN) tail.assign(s.out.end() - WIN, s.out.end());
+                else {
+                    tail.assign(WIN, 0);
+                    const size_t keep = WIN - n_out;
+                    if (!window.empty()) memcpy(tail.data(), window.data() + (WIN - keep), keep);
+                    if (n_out) memcpy(tail.data() + keep, s.out.data(), n_out);   // (an empty span: the tail is the window)
+                }
+            }
+            {
+                std::lock_guard<std::mutex> g(tmu_);
+                tails_[s.index].swap(tail);
+                tail_state_[s.index] = tail_ok ? 1 : 2;
+                if (s.index > 0) std::vector<uint8_t>().swap(tails_[s.index - 1]);   // nobody else needs it
+            }
+            tcv_.notify_all();
+        }
         if (s.ok) {
-            if (s.index > 0) resolve(s, window);
+            if (s.index > 0) resolve(s, window, 0, tail_from);
             // anything still >= 0x80 means the input is not 7-bit text and the marker scheme does not apply (span 0 is inflated
             // with its true history, so the whole of it is screened; later spans: the bytes that were marked)
             const uint8_t* o = s.out.data();
@@ -552,24 +599,9 @@ class ParallelGunzip {
             for (; i < n_check; ++i) any |= (uint64_t)o[i] << 0;
             if (any & 0x8080808080808080ull) { s.ok = false; s.why = "the file holds bytes >= 0x80 (not 7-bit text)"; }
         }
-        std::vector<uint8_t> tail;
-        if (s.ok) {
-            if (s.out.size() >= WIN) tail.assign(s.out.end() - WIN, s.out.end());
-            else {
-                tail.assign(WIN, 0);
-                const size_t keep = WIN - s.out.size();
-                if (!window.empty()) memcpy(tail.data(), window.data() + (WIN - keep), keep);
-                if (!s.out.empty()) memcpy(tail.data() + keep, s.out.data(), s.out.size());   // (an empty span: the tail is the window)
-            }
-        }
-        {
-            std::lock_guard<std::mutex> g(tmu_);
-            tails_[s.index].swap(tail);
-            tail_state_[s.index] = s.ok ? 1 : 2;
-            if (s.index > 0) std::vector<uint8_t>().swap(tails_[s.index - 1]);   // nobody else needs it
-        }
-        tcv_.notify_all();
+        const uint64_t tc = now_ns();
         if (s.ok) s.crc = (uint32_t)crc32_z(0, s.out.data(), s.out.size());
+        t_crc_ += now_ns() - tc;
     }
 
     void work() {
@@ -611,6 +643,7 @@ class ParallelGunzip {
     Span* next_ready() {
         if (finished_) return nullptr;
         Span* s = nullptr;
+        const uint64_t tcw = now_ns();
         {
             std::unique_lock<std::mutex> lk(mu_);
             cv_.wait(lk, [&] {
@@ -619,6 +652,7 @@ class ParallelGunzip {
                 return false;
             });
         }
+        t_consumer_wait_ += now_ns() - tcw;
         // a span must begin where the one in front ended (both found the same block start by themselves)
         if (!s->ok || (deliver_ > 0 && s->start_bit != prev_end_bit_)) {
             give_up(s->ok ? "span " + std::to_string(deliver_) + " does not begin where the one in front of it ended" : s->why);
@@ -689,6 +723,10 @@ class ParallelGunzip {
     std::vector<uint64_t> bounds_;
     std::vector<uint8_t> bstate_;               // 0 unknown, 1 being searched, 2 known
     std::atomic<bool> abort_{false}, failed_{false};
+    std::atomic<uint64_t> t_search_{0}, t_pass1_{0}, t_scan_{0}, t_pass2_{0}, t_wait_tail_{0}, t_crc_{0}, t_consumer_wait_{0}, t_copy_{0};
+    static uint64_t now_ns() {
+        return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+    }
     Span* cur_ = nullptr;
     size_t cur_off_ = 0;
 };
