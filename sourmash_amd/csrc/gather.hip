@@ -9,11 +9,14 @@
 // consume is the expensive line: the reference walks the whole database every round.  Here the database is
 // inverted once against the query (hash position -> rows containing it, a CSR of u32 row ids), so a round touches
 // only the postings of the hashes in I: total work over a whole gather is sum_d |Q ∩ D_d| counter decrements, the
-// same number the reference spends on round 0 alone.  One round = two small kernels (arg-max with stop rules and
-// bookkeeping in its last workgroup, apply); the host enqueues rounds in batches and only looks at a done flag,
-// so there is no host round trip per round.  Every kernel is a no-op once the flag is set.
+// same number the reference spends on round 0 alone.  Since round 3 the whole loop is ONE resident kernel where the index
+// allows it (gather_loop_kernel: a workgroup per CU owns a row range, counters and the uncovered set live in LDS, one granule
+// all-gather per round); otherwise one round = two small kernels (arg-max with stop rules and bookkeeping in its last
+// workgroup, apply), enqueued in batches by a host that only looks at a done flag.  Every kernel is a no-op once the flag is set.
 //
-// Multi-GPU (database sharded by dataset, query replicated): rounds are replayed from exchanged candidates.  Every
+// Multi-GPU (database sharded by dataset, query replicated): the ranks' resident loop kernels agree on every round's winner
+// through host-visible memory shared by the ranks (gather_launch_loop with a GatherShared; sourmash_amd/parallel.py).  The
+// older protocol, kept for indexes that cannot run the resident loop: rounds are replayed from exchanged candidates.  Every
 // shard exports its K best rows (packed key, hashes) plus the best key it keeps back; ONE all-gather hands all of
 // them to every rank, which inverts them against the query as well (one bit per candidate and query hash, cmask) so
 // that apply keeps the candidates' counters as exact as the local ones.  The winner of a round is then the best

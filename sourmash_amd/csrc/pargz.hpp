@@ -80,12 +80,10 @@ inline bool plausible_dynamic_header(const uint8_t* data, uint64_t n_bytes, uint
         memcpy(&w0, data + (bit >> 3), 8);
         memcpy(&w1, data + (bit >> 3) + 8, 8);
         const unsigned sh = (unsigned)(bit & 7);
-        uint64_t w = sh ? (w0 >> sh) | (w1 << (64 - sh)) : w0;
+        const uint64_t w = sh ? (w0 >> sh) | (w1 << (64 - sh)) : w0;
         if ((w & 7u) != 4u) return false;                       // BFINAL = 0, BTYPE = 10b (bits: 0, then 0 1)
         const unsigned hlit = (unsigned)((w >> 3) & 31u), hdist = (unsigned)((w >> 8) & 31u), hclen = (unsigned)((w >> 13) & 15u) + 4;
         if (hlit > 29 || hdist > 29) return false;
-        uint64_t cw = sh ? (w0 >> sh) | (w1 << (64 - sh)) : w0;  // 17 header bits, then 3 bits per code length: 17 + 57 = 74 bits
-        (void)cw;
         // Kraft sum over the code-length code (lengths 1..7): sum 2^(7 - len) must be exactly 128
         unsigned kraft = 0, nz = 0;
         uint64_t pos = bit + 17;
