@@ -1026,7 +1026,8 @@ __global__ __launch_bounds__(256) void apply_kernel(QIndex qi, uint8_t* alive, c
 // go back to the global arrays, so that the protocol entry points (peek / consume, counters_get, a second begin + run)
 // carry on from the same state.
 constexpr int PL_THREADS = 1024;
-constexpr int PL_ROW_PER = 4;                  // row elements per thread and chunk (chunk <= PL_ROW_PER * PL_THREADS)
+constexpr int PL_ROW_PER = 6;                  // row elements per thread and chunk (chunk <= PL_ROW_PER * PL_THREADS): a C5 row (~5,000
+                                               // hashes) is one chunk -- a second chunk costs another pair of barriers and LDS passes per round
 constexpr int PL_LANES = 2;                    // lanes per newly covered position when its row block's run is read (2 x 2 x 4 entries;
                                                // a run is about 4 entries at C5: 250 per list over 64 row blocks)
 constexpr int PL_STEPS = 3;                    // positions per lane group whose loads are in flight together (3 x 512 per batch)
@@ -1766,7 +1767,7 @@ static bool loop_geometry(const GatherDev& g, uint32_t n_wg, LoopArgs* a, size_t
     a->bitmap_words = (uint32_t)((g.nq + 31) / 32);
     const size_t fixed = ((size_t)a->bitmap_words + 2 * (size_t)a->rows_per_wg + 1) * 4;
     const size_t budget = (size_t)lds_max - 1024;                  // the kernel's static scalars
-    a->chunk = 4096;
+    a->chunk = (uint32_t)PL_ROW_PER * PL_THREADS;
     while (a->chunk > 512 && fixed + (size_t)a->chunk * 4 > budget) a->chunk >>= 1;
     if (fixed + (size_t)a->chunk * 4 > budget) return false;       // query or rows too large for LDS
     *lds = fixed + (size_t)a->chunk * 4;
