@@ -1037,7 +1037,7 @@ struct LoopArgs {
     const uint64_t* offsets;
     const uint32_t* qpos;
     const uint32_t* post_rows;
-    const uint32_t* block_pre;          // [B][nq] start of row block b's run in list j, relative to post_off[j]
+    const uint32_t* block_pre;          // [nq][B + 1] absolute start of row block b's run in list j (entry B: the list's end)
     const uint64_t* post_off;
     unsigned long long* counters;
     uint8_t* alive;
@@ -1090,7 +1090,6 @@ __global__ __launch_bounds__(PL_THREADS) void gather_loop_kernel(LoopArgs a) {
     // the row blocks whose runs hold rows r0 .. r1 - 1 (one block when the ranges are aligned, else two)
     const uint32_t b0 = n_own ? (uint32_t)(r0 / a.block_rows) : 0u;
     const uint32_t b1 = n_own ? (uint32_t)((r1 - 1) / a.block_rows) : 0u;
-    const bool to_list_end = b1 + 1 >= a.B;                       // the run ends where the list ends
     // ---- load the state this loop starts from ----
     for (uint32_t w = tid; w < a.bitmap_words; w += PL_THREADS) {
         uint32_t bits = 0;
@@ -1344,11 +1343,9 @@ __global__ __launch_bounds__(PL_THREADS) void gather_loop_kernel(LoopArgs a) {
                     lo[st] = hi[st] = 0;
                     if (k < nI) {
                         const uint64_t p = s_I[k];
-                        const uint32_t base = (uint32_t)a.post_off[p];
-                        const uint32_t rel_lo = a.block_pre[(uint64_t)b0 * a.nq + p];
-                        const uint32_t end = to_list_end ? (uint32_t)a.post_off[p + 1] : base + a.block_pre[(uint64_t)(b1 + 1) * a.nq + p];
-                        lo[st] = base + rel_lo;
-                        hi[st] = end;
+                        const uint32_t* bt = a.block_pre + p * (a.B + 1);             // one row of the table: lo and hi are neighbours
+                        lo[st] = bt[b0];
+                        hi[st] = bt[b1 + 1];
                     }
                 }
                 PL_WAITLAP(7);                                       // (trace) waiting for the first batch's run bounds
@@ -1369,11 +1366,9 @@ __global__ __launch_bounds__(PL_THREADS) void gather_loop_kernel(LoopArgs a) {
                         lo_n[st] = hi_n[st] = 0;
                         if (k < nI) {
                             const uint64_t p = s_I[k];
-                            const uint32_t base = (uint32_t)a.post_off[p];
-                            const uint32_t rel_lo = a.block_pre[(uint64_t)b0 * a.nq + p];
-                            const uint32_t end = to_list_end ? (uint32_t)a.post_off[p + 1] : base + a.block_pre[(uint64_t)(b1 + 1) * a.nq + p];
-                            lo_n[st] = base + rel_lo;
-                            hi_n[st] = end;
+                            const uint32_t* bt = a.block_pre + p * (a.B + 1);             // one row of the table: lo and hi are neighbours
+                            lo_n[st] = bt[b0];
+                            hi_n[st] = bt[b1 + 1];
                         }
                     }
                     PL_WAITLAP(8);                                   // (trace) waiting for the batch's entries (+ next bounds)
@@ -1432,6 +1427,31 @@ __global__ __launch_bounds__(PL_THREADS) void gather_loop_kernel(LoopArgs a) {
         a.state[GS_DONE] = 1;
     }
     if (failed && tid == 0) { a.state[GS_ERR] = fail_code; a.state[13] = fail_epoch; a.state[14] = wg; }
+}
+
+// bounds[j][b] = post_off[j] + partial[b][j] for b < B, bounds[j][B] = post_off[j + 1]: the run of row block b inside posting list j
+// as two neighbouring words (the resident loop asks for them once per newly covered hash and owned block; as partial[b][j],
+// partial[b + 1][j] and post_off[j] they were three loads from three distant arrays).  64 lists x B blocks per workgroup,
+// transposed through LDS so that reads run along j and writes along b.
+__global__ __launch_bounds__(256) void build_bounds_table_kernel(const uint32_t* __restrict__ partial, uint64_t nq, uint32_t B,
+                                                                 const uint64_t* __restrict__ post_off, uint32_t* __restrict__ bounds) {
+    __shared__ uint32_t tile[64][65];
+    const uint64_t j0 = (uint64_t)blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;             // 4 rows of 64 per step
+    for (uint32_t bb = 0; bb < B; bb += 64) {
+        for (int r = ty; r < 64; r += 4) {                              // r: block within the tile, tx: list
+            const uint32_t b = bb + (uint32_t)r;
+            tile[r][tx] = (b < B && j0 + tx < nq) ? partial[(uint64_t)b * nq + j0 + tx] : 0u;
+        }
+        __syncthreads();
+        for (int r = ty; r < 64; r += 4) {                              // r: list within the tile, tx: block
+            const uint64_t j = j0 + (uint64_t)r;
+            const uint32_t b = bb + (uint32_t)tx;
+            if (j < nq && b < B) bounds[j * (B + 1) + b] = (uint32_t)post_off[j] + tile[tx][r];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x < 64 && j0 + threadIdx.x < nq) bounds[(j0 + threadIdx.x) * (B + 1) + B] = (uint32_t)post_off[j0 + threadIdx.x + 1];
 }
 
 __global__ __launch_bounds__(256) void longest_row_kernel(const uint64_t* __restrict__ offsets, uint64_t ndb,
@@ -1677,9 +1697,11 @@ static hipError_t gather_build_body(GatherDev& g, hipStream_t stream) {
                                    (const uint32_t*)inter_off, (const uint32_t*)inter, g.post_rows);
             SMG_TRY(hipGetLastError());
             if (ordered && g.npairs < 0xffffffffull) {
-                // the per-block prefixes stay with the index: [B][nq] starts of every row block's run inside every list
-                g.block_pre = partial;
-                partial_b.p = nullptr;                                  // ownership moves to the index (freed by gather_destroy)
+                // where every row block's run begins and ends inside every list, for the resident loop: [nq][B + 1]
+                SMG_TRY(own_alloc(g, &g.block_pre, (g.nq * (B + 1) + 4) * 4));
+                hipLaunchKernelGGL(build_bounds_table_kernel, dim3((unsigned)((g.nq + 63) / 64)), dim3(256), 0, stream, (const uint32_t*)partial,
+                                   g.nq, (uint32_t)B, (const uint64_t*)g.post_off, g.block_pre);
+                SMG_TRY(hipGetLastError());
                 g.block_B = (uint32_t)B;
                 g.block_rows = (uint32_t)rows_per_block;
             }

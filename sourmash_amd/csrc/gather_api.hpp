@@ -44,7 +44,7 @@ struct GatherDev {
     uint32_t* post_rows = nullptr;      // local row ids
     uint32_t* qpos = nullptr;           // [database elements] position in Q of every element of the shard (NONE32: not in Q):
                                         // a round applied from the local CSR skips the lookup (two dependent loads)
-    uint32_t* block_pre = nullptr;      // [block_B][nq] start of row block b's run inside posting list j, relative to post_off[j]
+    uint32_t* block_pre = nullptr;      // [nq][block_B + 1] absolute start of row block b's run inside posting list j (last: the list's end)
                                         // (staged range build with block-ordered lists only): the persistent loop's workgroups
                                         // read only their rows' part of a list
     uint32_t block_B = 0, block_rows = 0;
