@@ -1046,7 +1046,7 @@ struct LoopArgs {
     uint64_t* out_isect;
     unsigned long long* xchg;           // [2][n_wg * 4] granules, zeroed before the launch
     uint64_t ndb, nq, index_base;
-    uint32_t rows_per_wg, block_rows, B, chunk, bitmap_words;
+    uint32_t rows_per_wg, block_rows, B, chunk, bitmap_words, prefetch;
     unsigned long long* dbg;            // SMG_GATHER_TRACE: [8] phase times of workgroup 0 in 10 ns ticks (null: not collected)
     // ---- several ranks, one database shard each (W > 0): the round's winner is agreed through host-visible memory ----
     uint32_t W, rank, epoch_base, rowcap;   // ranks, this rank, tag offset of this run, granules per row slot
@@ -1153,7 +1153,7 @@ __global__ __launch_bounds__(PL_THREADS) void gather_loop_kernel(LoopArgs a) {
         __syncthreads();
         // While the records travel: touch the positions of this workgroup's own best row, one lane per 64-byte line.  The
         // round's winner is one of these rows, so its slice is in the memory-side cache (and one XCD's L2) when everybody asks.
-        {
+        if (a.prefetch) {
             const uint32_t ps = s_wstart, pl = s_wlen;
             for (uint32_t i = (uint32_t)tid * 16u; i < pl; i += PL_THREADS * 16u)
                 (void)*reinterpret_cast<const volatile uint32_t*>(a.qpos + (uint64_t)ps + i);   // volatile: issued, its value unused
@@ -1859,6 +1859,8 @@ hipError_t gather_launch_loop(GatherDev& g, hipStream_t stream, uint32_t n_wg, c
     if (sh && (sh->W == 0 || sh->W > (uint32_t)PL_THREADS || sh->rank >= sh->W || rowcap == 0)) return hipErrorInvalidValue;
     SMG_TRY(gather_loop_reserve(g, stream, n_wg, rowcap));
     a.xchg = g.loop_xchg;
+    static const bool prefetch = [] { const char* e = getenv("SMG_GATHER_PREFETCH"); return !e || atoi(e) != 0; }();
+    a.prefetch = prefetch ? 1u : 0u;
     static const bool trace = getenv("SMG_GATHER_TRACE") != nullptr;
     a.dbg = trace ? g.loop_xchg + (size_t)2 * n_wg * 4 : nullptr;           // 16 words behind the granules
     a.gwin = g.loop_xchg + (size_t)2 * n_wg * 4 + 16;
