@@ -318,7 +318,7 @@ def gather_counters(db_bytes):
         return None, None, why
     build = 0.0
     for k in ("build_bounds_kernel", "build_range_kernel<0>", "build_merge_counts_kernel", "build_partition_kernel", "build_scatter_kernel",
-              "qtable_kernel", "qrec_kernel"):        # (qtable_kernel also runs in front of every overlap pass: averaged per dispatch)
+              "build_bounds_table_kernel", "qtable_kernel", "qrec_kernel"):        # (qtable_kernel also runs in front of every overlap pass: averaged per dispatch)
         f, w = pmc.get(k, "FETCH_SIZE"), pmc.get(k, "WRITE_SIZE")
         if f is None or w is None:
             return None, None, f"{PMC_GATHER_FILE} has no rows for {k}"
