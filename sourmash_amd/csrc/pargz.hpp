@@ -603,6 +603,21 @@ class ParallelGunzip {
     }
 
     void work() {
+        try {
+            work_loop();
+        } catch (...) {                                              // (out of memory in a worker: the consumer falls back or fails)
+            {
+                std::lock_guard<std::mutex> g(mu_);
+                failed_ = true;
+                for (Span* c : spans_)
+                    if (!c->done) { c->ok = false; c->why = "a worker thread failed"; c->done = true; }
+            }
+            cv_.notify_all();
+            tcv_.notify_all();
+            bcv_.notify_all();
+        }
+    }
+    void work_loop() {
         for (;;) {
             Span* s = nullptr;
             {
