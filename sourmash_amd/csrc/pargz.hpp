@@ -408,8 +408,9 @@ class ParallelGunzip {
         {
             std::unique_lock<std::mutex> lk(bmu_);
             if (bounds_.size() < n_spans_ + 1) { bounds_.assign(n_spans_ + 1, 0); bstate_.assign(n_spans_ + 1, 0); }
-            bcv_.wait(lk, [&] { return bstate_[i] != 1; });
+            bcv_.wait(lk, [&] { return bstate_[i] != 1 || failed_ || abort_; });
             if (bstate_[i] == 2) return bounds_[i];
+            if (bstate_[i] == 1) return UINT64_MAX;                  // the worker that was searching gave up: so does this span
             bstate_[i] = 1;
         }
         // (a block of 16,384 symbols can be longer than a small span: look up to 256 KB ahead; two spans may then share a start,
