@@ -252,10 +252,47 @@ __device__ __forceinline__ uint64_t uniform64(uint64_t v) {          // a wave-u
            (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
 }
 
+constexpr int NR = HR / HWAVES;       // row sketches per wave
+constexpr int NC = HC / HWAVES;       // column sketches per wave
+static_assert(HR == 16 && NC == 4 && HC == 32, "the packed counters below hold 16 rows x 4 columns per wave");
+
 template <int LOGT>
-__device__ __forceinline__ uint32_t hash_slot(uint64_t v) {
+__device__ __forceinline__ uint32_t pair_slot(uint64_t v) {           // the even slot a hash's probe sequence starts on
     const uint32_t x = ((uint32_t)v ^ (uint32_t)(v >> 32)) * 0x9E3779B1u;   // slabs share their top bits: mix before cutting
-    return x >> (32 - LOGT);
+    return (x >> (32 - (LOGT - 1))) << 1;
+}
+
+template <int CTRL>
+__device__ __forceinline__ uint32_t row_rotated(uint32_t x) {         // lane l of a 16-lane row <- lane (l + n) % 16: DPP row_ror:n
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, 0xf, 0xf, false);
+}
+
+// The per-lane 4-bit counters of a wave (see the kernel) go to the tile's LDS counters.  acc[p][k] nibble j counts bit
+// t = 4j + k of y_p = m[2p] | m[2p+1] << 16, i.e. row t & 15 of column j' = 2p + (t >> 4) of this wave (tile column
+// 8j' + wave).  Even and odd nibbles are split into byte lanes (<= 15 each), summed over the 16 lanes of a DPP row
+// (<= 240, still a byte), and lane b < 4 of each row adds byte b of every register to its counter.
+__device__ __forceinline__ void flush_nibble_counts(uint32_t (&acc)[NC / 2][4], uint32_t* s_cnt, int lane, int wave) {
+    const int b = lane & 3;
+    const bool pusher = (lane & 15) < 4;
+    uint32_t* const mine = s_cnt + (8 * (b & 1)) * HC + (b >> 1) * HWAVES + wave;
+    const uint32_t sh = 8u * (uint32_t)b;
+#pragma unroll
+    for (int p = 0; p < NC / 2; ++p)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            uint32_t part[2] = {acc[p][k] & 0x0f0f0f0fu, (acc[p][k] >> 4) & 0x0f0f0f0fu};
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                uint32_t x = part[h];
+                x += row_rotated<0x128>(x);
+                x += row_rotated<0x124>(x);
+                x += row_rotated<0x122>(x);
+                x += row_rotated<0x121>(x);
+                // byte b of (p, k, h): row 8 (b & 1) + 4 h + k, column 8 (2 p + (b >> 1)) + wave
+                if (pusher) atomicAdd(&mine[(4 * h + k) * HC + 2 * HWAVES * p], (x >> sh) & 0xffu);
+            }
+            acc[p][k] = 0;
+        }
 }
 
 template <int MINW, int LOGT>
@@ -266,8 +303,8 @@ __global__ __launch_bounds__(HBLOCK, MINW) void compare_hash_kernel(
     const WorkItem* __restrict__ light, unsigned int* __restrict__ counters) {
     // same contract as compare_tile_kernel (symmetric modes, work lists, output rows), tiles of HR rows x HC columns
     constexpr int HT = 1 << LOGT;
-    __shared__ unsigned long long s_key[HT];
-    __shared__ uint32_t s_mask[HT];
+    __shared__ __attribute__((aligned(16))) unsigned long long s_key[HT];     // pairs of slots are read as one 16-byte access
+    __shared__ uint32_t s_mask[HT / 2];            // 16-bit row masks of the slots, two to a word
     __shared__ uint32_t s_cnt[HR * HC];
     __shared__ uint64_t s_pos[HR + HC], s_end[HR + HC];
     __shared__ unsigned long long s_hi2[2];        // the round's bound, one cell per round parity
@@ -277,7 +314,7 @@ __global__ __launch_bounds__(HBLOCK, MINW) void compare_hash_kernel(
     __shared__ int s_have;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int k = tid; k < HT; k += HBLOCK) { s_key[k] = H_EMPTY; s_mask[k] = 0; }
+    for (int k = tid; k < HT; k += HBLOCK) { s_key[k] = H_EMPTY; if (k < HT / 2) s_mask[k] = 0; }
 
     for (;;) {
         __syncthreads();                                   // previous item fully done (LDS reuse)
@@ -335,126 +372,137 @@ __global__ __launch_bounds__(HBLOCK, MINW) void compare_hash_kernel(
             left[i] = (uint32_t)(p1 - p0);
         }
         __syncthreads();                                   // s_top / s_hi2 / s_live2 are set before anyone's atomics
-        uint64_t e[HPW];
-        uint32_t valid = 0, more = 0;                      // bit i: this lane holds a staged hash of sketch i / that sketch has
-#pragma unroll                                             // more than this round stages
-        for (int i = 0; i < HPW; ++i) {
-            const bool ok = (uint32_t)lane < left[i];
-            valid |= (uint32_t)ok << i;
-            more |= (uint32_t)(left[i] > (uint32_t)HSEG) << i;
-            e[i] = ok ? at[i][lane] : ~0ull;
-        }
+        uint64_t e[HPW];                                   // lane l: the l-th staged hash of sketch i (2^64 - 1 past its end)
+#pragma unroll
+        for (int i = 0; i < HPW; ++i) e[i] = (uint32_t)lane < left[i] ? at[i][lane] : ~0ull;
+        uint32_t acc[NC / 2][4];                           // this lane's share of the tile's counts, 4 bits per (row, column)
+#pragma unroll
+        for (int p = 0; p < NC / 2; ++p)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc[p][k] = 0;
+        uint32_t since = 0;                                // rounds added to acc since it last went to s_cnt (wave-uniform)
 
         for (uint32_t round = 0;; ++round) {
             const uint32_t par = round & 1u;
-            // ---- the round's bound: smallest 64th staged hash among sketches with more to come ----
+            // ---- the round's bound: smallest 64th staged hash among sketches with more to come.  `left` is wave-uniform,
+            //      so which sketches take part is decided in scalar code; lane 63 holds their 64th hashes ----
+            uint64_t wmin = ~0ull;
+            uint32_t live = 0;
 #pragma unroll
             for (int i = 0; i < HPW; ++i) {
-                const int s = i * HWAVES + wave;
-                if (lane == HSEG - 1 && ((more >> i) & 1u)) atomicMin(&s_hi2[par], (unsigned long long)e[i]);
-                if (lane == 0 && (valid & (1u << i))) atomicOr(&s_live2[par], s < HR ? 1u : 2u);
+                if (left[i] > (uint32_t)HSEG) wmin = e[i] < wmin ? e[i] : wmin;
+                if (left[i]) live |= i < NR ? 1u : 2u;
             }
+            if (lane == HSEG - 1 && wmin != ~0ull) atomicMin(&s_hi2[par], (unsigned long long)wmin);
+            if (lane == 0 && live) atomicOr(&s_live2[par], live);
             __syncthreads();
             if (s_live2[par] != 3u) break;                 // every row or every column exhausted
-            const uint64_t hi = s_hi2[par];
+            const uint64_t hi = uniform64(s_hi2[par]);
             if (tid == 0) { s_hi2[par ^ 1u] = ~0ull; s_live2[par ^ 1u] = 0; }     // next round's cells (not touched before its atomics)
-            // ---- what this round consumes; the next round's hashes start loading now ----
-            uint32_t in = 0;
+            // ---- what this round consumes (a prefix of every staged segment); the next round's hashes start loading now ----
+            bool mine[HPW];
 #pragma unroll
             for (int i = 0; i < HPW; ++i) {
-                const bool mine = ((valid >> i) & 1u) && e[i] <= hi;
-                in |= (uint32_t)mine << i;
-                const uint32_t take = (uint32_t)__popcll(__ballot(mine));
+                mine[i] = (uint32_t)lane < left[i] && e[i] <= hi;
+                const uint32_t take = (uint32_t)__popcll(__ballot(mine[i]));
                 at[i] += take;
                 left[i] -= take;
             }
             uint64_t en[HPW];
-            uint32_t nvalid = 0, nmore = 0;
 #pragma unroll
-            for (int i = 0; i < HPW; ++i) {
-                const bool ok = (uint32_t)lane < left[i];
-                nvalid |= (uint32_t)ok << i;
-                nmore |= (uint32_t)(left[i] > (uint32_t)HSEG) << i;
-                en[i] = ok ? at[i][lane] : ~0ull;
+            for (int i = 0; i < HPW; ++i) en[i] = (uint32_t)lane < left[i] ? at[i][lane] : ~0ull;
+            if (hi == ~0ull) {                             // only a round that consumes everything left can meet the hash
+#pragma unroll                                             // 2^64 - 1 (the empty-slot key): counted out of band
+                for (int i = 0; i < HPW; ++i)
+                    if (mine[i] && e[i] == H_EMPTY) {
+                        atomicOr(&s_top[i < NR ? 0 : 1], 1u << (i < NR ? i * HWAVES + wave : i * HWAVES + wave - HR));
+                        mine[i] = false;
+                    }
             }
-            // ---- rows: insert; the probes of this lane's (up to) four hashes go out together ----
-            constexpr int NR = HR / HWAVES;
-            uint32_t slot[HPW], pend = 0, mine_slot[NR];
+            // ---- rows: insert.  Probing starts on an even slot and goes up one slot at a time; the probes of the lane's
+            //      hashes go out together ----
+            uint32_t ro[NR];                               // byte offset into s_key of the slot being tried, then of the slot held
+            bool rp[NR];
 #pragma unroll
-            for (int i = 0; i < NR; ++i) {
-                mine_slot[i] = HT;
-                slot[i] = hash_slot<LOGT>(e[i]);
-                if ((in >> i) & 1u) {
-                    if (e[i] == H_EMPTY) atomicOr(&s_top[0], 1u << (i * HWAVES + wave));
-                    else pend |= 1u << i;
-                }
-            }
-            while (__any(pend != 0)) {
+            for (int i = 0; i < NR; ++i) { ro[i] = pair_slot<LOGT>(e[i]) * 8u; rp[i] = mine[i]; }
+            for (;;) {
+                bool any = false;
+#pragma unroll
+                for (int i = 0; i < NR; ++i) any |= rp[i];
+                if (!__any(any)) break;
                 unsigned long long old[NR];
 #pragma unroll
                 for (int i = 0; i < NR; ++i)
-                    if ((pend >> i) & 1u) old[i] = atomicCAS(&s_key[slot[i]], H_EMPTY, (unsigned long long)e[i]);
+                    if (rp[i]) old[i] = atomicCAS((unsigned long long*)((char*)s_key + ro[i]), H_EMPTY, (unsigned long long)e[i]);
 #pragma unroll
                 for (int i = 0; i < NR; ++i)
-                    if ((pend >> i) & 1u) {
+                    if (rp[i]) {
                         if (old[i] == H_EMPTY || old[i] == e[i]) {
-                            atomicOr(&s_mask[slot[i]], 1u << (i * HWAVES + wave));
-                            mine_slot[i] = slot[i];
-                            pend &= ~(1u << i);
+                            // 16-bit row masks, two to a word: slot s -> half (s & 1) of word s >> 1
+                            atomicOr(&s_mask[ro[i] >> 4], (1u << (i * HWAVES + wave)) << ((ro[i] & 8u) << 1));
+                            rp[i] = false;
                         } else {
-                            slot[i] = (slot[i] + 1) & (HT - 1);
+                            ro[i] = (ro[i] + 8u) & (uint32_t)(HT * 8 - 1);
                         }
                     }
             }
             __syncthreads();
-            // ---- columns: one lookup per hash, probes of the lane's (up to) eight hashes together, then the row masks,
-            //      then one LDS add per (row, column) that shares the hash ----
-            uint32_t found = 0;
-            pend = 0;
+            // ---- columns: one lookup per hash, a pair of slots per probe (the key sits before the first empty slot of its
+            //      probe sequence), probes of the lane's four hashes together; then the row masks ----
+            uint32_t co[NC];
+            bool cp[NC], fnd[NC];
 #pragma unroll
-            for (int i = NR; i < HPW; ++i) {
-                slot[i] = hash_slot<LOGT>(e[i]);
-                if ((in >> i) & 1u) {
-                    if (e[i] == H_EMPTY) atomicOr(&s_top[1], 1u << (i * HWAVES + wave - HR));
-                    else pend |= 1u << i;
-                }
-            }
-            while (__any(pend != 0)) {
-                unsigned long long k[HPW];
+            for (int j = 0; j < NC; ++j) { co[j] = pair_slot<LOGT>(e[NR + j]) * 8u; cp[j] = mine[NR + j]; fnd[j] = false; }
+            for (;;) {
+                bool any = false;
 #pragma unroll
-                for (int i = NR; i < HPW; ++i)
-                    if ((pend >> i) & 1u) k[i] = s_key[slot[i]];
+                for (int j = 0; j < NC; ++j) any |= cp[j];
+                if (!__any(any)) break;
+                ulonglong2 kk[NC];
 #pragma unroll
-                for (int i = NR; i < HPW; ++i)
-                    if ((pend >> i) & 1u) {
-                        if (k[i] == e[i]) { found |= 1u << i; pend &= ~(1u << i); }
-                        else if (k[i] == H_EMPTY) pend &= ~(1u << i);
-                        else slot[i] = (slot[i] + 1) & (HT - 1);
+                for (int j = 0; j < NC; ++j)
+                    if (cp[j]) kk[j] = *(const ulonglong2*)((const char*)s_key + co[j]);
+#pragma unroll
+                for (int j = 0; j < NC; ++j)
+                    if (cp[j]) {
+                        const bool h0 = kk[j].x == e[NR + j], h1 = kk[j].y == e[NR + j];
+                        if (h0 || h1) { fnd[j] = true; cp[j] = false; co[j] += h1 ? 8u : 0u; }
+                        else if (kk[j].x == H_EMPTY || kk[j].y == H_EMPTY) cp[j] = false;
+                        else co[j] = (co[j] + 16u) & (uint32_t)(HT * 8 - 1);
                     }
             }
-            uint32_t m[HPW];
+            bool hit = false;
+            uint32_t m[NC];
 #pragma unroll
-            for (int i = NR; i < HPW; ++i) m[i] = ((found >> i) & 1u) ? s_mask[slot[i]] : 0u;
+            for (int j = 0; j < NC; ++j) {
+                m[j] = fnd[j] ? (uint32_t)((const uint16_t*)s_mask)[co[j] >> 3] : 0u;
+                hit |= fnd[j];
+            }
+            // ---- counts: bit r of m[j] says row r shares the lane's hash of column j.  Every lane keeps 4-bit counters of
+            //      its own (16 rows x 4 columns in 8 registers: 3 instructions per 8 counters, nothing divergent, no LDS);
+            //      after 15 rounds they are summed over the lanes and added to s_cnt ----
+            if (__any(hit)) {
 #pragma unroll
-            for (int i = NR; i < HPW; ++i) {
-                const int c = i * HWAVES + wave - HR;
-                uint32_t mm = m[i];
-                while (mm) {
-                    atomicAdd(&s_cnt[(__ffs((int)mm) - 1) * HC + c], 1u);
-                    mm &= mm - 1;
+                for (int p = 0; p < NC / 2; ++p) {
+                    const uint32_t y = m[2 * p] | (m[2 * p + 1] << 16);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) acc[p][k] += (y >> k) & 0x11111111u;
                 }
+                if (++since == 15u) { flush_nibble_counts(acc, s_cnt, lane, wave); since = 0; }
             }
             __syncthreads();
-            // ---- the table goes back to empty: every inserter clears the slot it ended up in (ordered before the
-            //      next round's inserts by the barrier after its bound) ----
+            // ---- the table goes back to empty: every inserter clears the slot its hash is in (ordered before the next
+            //      round's inserts by the barrier after its bound) ----
 #pragma unroll
             for (int i = 0; i < NR; ++i)
-                if (mine_slot[i] < (uint32_t)HT) { s_key[mine_slot[i]] = H_EMPTY; s_mask[mine_slot[i]] = 0; }
+                if (mine[i]) {
+                    *(unsigned long long*)((char*)s_key + ro[i]) = H_EMPTY;
+                    ((uint16_t*)s_mask)[ro[i] >> 3] = 0;
+                }
 #pragma unroll
             for (int i = 0; i < HPW; ++i) e[i] = en[i];
-            valid = nvalid;
-            more = nmore;
         }
+        if (since) flush_nibble_counts(acc, s_cnt, lane, wave);
         __syncthreads();
 
         // the hash 2^64 - 1 (possible with scaled = 1) never went through the table
