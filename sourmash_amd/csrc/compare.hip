@@ -262,6 +262,16 @@ __device__ __forceinline__ uint32_t pair_slot(uint64_t v) {           // the eve
     return (x >> (32 - (LOGT - 1))) << 1;
 }
 
+__device__ __forceinline__ bool lanes_of(uint64_t wave_mask) {        // a wave mask held in scalar registers, as a lane predicate
+    return __builtin_amdgcn_inverse_ballot_w64(wave_mask);
+}
+__device__ __forceinline__ void opaque(unsigned long long& v) {       // the value as the registers hold it, whatever wrote it
+    asm volatile("" : "+v"(v));
+}
+__device__ __forceinline__ uint64_t mask_of(bool lane_pred) {         // and back (the compare's own result mask, no VALU work)
+    return __builtin_amdgcn_ballot_w64(lane_pred);
+}
+
 template <int CTRL>
 __device__ __forceinline__ uint32_t row_rotated(uint32_t x) {         // lane l of a 16-lane row <- lane (l + n) % 16: DPP row_ror:n
     return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, 0xf, 0xf, false);
@@ -399,89 +409,97 @@ __global__ __launch_bounds__(HBLOCK, MINW) void compare_hash_kernel(
             if (s_live2[par] != 3u) break;                 // every row or every column exhausted
             const uint64_t hi = uniform64(s_hi2[par]);
             if (tid == 0) { s_hi2[par ^ 1u] = ~0ull; s_live2[par ^ 1u] = 0; }     // next round's cells (not touched before its atomics)
-            // ---- what this round consumes (a prefix of every staged segment); the next round's hashes start loading now ----
+            // ---- what this round consumes (a prefix of every staged segment); the next round's hashes start loading now.
+            //      hi = 2^64 - 1 only when no sketch has more than it has staged: that round consumes everything left and is
+            //      the only one that can meet the hash 2^64 - 1 (the empty-slot key), which is counted out of band.  Lanes
+            //      past a segment's end hold 2^64 - 1 and fail `<= cut` by themselves ----
+            const bool last = hi == ~0ull;
+            const uint64_t cut = last ? ~0ull - 1 : hi;
             bool mine[HPW];
+            uint32_t take[HPW];
 #pragma unroll
             for (int i = 0; i < HPW; ++i) {
-                mine[i] = (uint32_t)lane < left[i] && e[i] <= hi;
-                const uint32_t take = (uint32_t)__popcll(__ballot(mine[i]));
-                at[i] += take;
-                left[i] -= take;
+                mine[i] = e[i] <= cut;
+                take[i] = last ? left[i] : (uint32_t)__popcll(mask_of(mine[i]));
+                at[i] += take[i];
+                left[i] -= take[i];
             }
             uint64_t en[HPW];
 #pragma unroll
             for (int i = 0; i < HPW; ++i) en[i] = (uint32_t)lane < left[i] ? at[i][lane] : ~0ull;
-            if (hi == ~0ull) {                             // only a round that consumes everything left can meet the hash
-#pragma unroll                                             // 2^64 - 1 (the empty-slot key): counted out of band
+            if (last) {
+#pragma unroll
                 for (int i = 0; i < HPW; ++i)
-                    if (mine[i] && e[i] == H_EMPTY) {
+                    if ((uint32_t)lane < take[i] && e[i] == H_EMPTY)
                         atomicOr(&s_top[i < NR ? 0 : 1], 1u << (i < NR ? i * HWAVES + wave : i * HWAVES + wave - HR));
-                        mine[i] = false;
-                    }
             }
             // ---- rows: insert.  Probing starts on an even slot and goes up one slot at a time; the probes of the lane's
-            //      hashes go out together ----
+            //      hashes go out together.  Which lanes are still probing is kept as wave masks in scalar registers ----
             uint32_t ro[NR];                               // byte offset into s_key of the slot being tried, then of the slot held
-            bool rp[NR];
+            uint64_t ron[NR];
 #pragma unroll
-            for (int i = 0; i < NR; ++i) { ro[i] = pair_slot<LOGT>(e[i]) * 8u; rp[i] = mine[i]; }
+            for (int i = 0; i < NR; ++i) { ro[i] = pair_slot<LOGT>(e[i]) * 8u; ron[i] = mask_of(mine[i]); }
             for (;;) {
-                bool any = false;
+                uint64_t any = 0;
 #pragma unroll
-                for (int i = 0; i < NR; ++i) any |= rp[i];
-                if (!__any(any)) break;
+                for (int i = 0; i < NR; ++i) any |= ron[i];
+                if (!any) break;
                 unsigned long long old[NR];
 #pragma unroll
                 for (int i = 0; i < NR; ++i)
-                    if (rp[i]) old[i] = atomicCAS((unsigned long long*)((char*)s_key + ro[i]), H_EMPTY, (unsigned long long)e[i]);
+                    if (lanes_of(ron[i])) old[i] = atomicCAS((unsigned long long*)((char*)s_key + ro[i]), H_EMPTY, (unsigned long long)e[i]);
 #pragma unroll
-                for (int i = 0; i < NR; ++i)
-                    if (rp[i]) {
-                        if (old[i] == H_EMPTY || old[i] == e[i]) {
-                            // 16-bit row masks, two to a word: slot s -> half (s & 1) of word s >> 1
-                            atomicOr(&s_mask[ro[i] >> 4], (1u << (i * HWAVES + wave)) << ((ro[i] & 8u) << 1));
-                            rp[i] = false;
-                        } else {
-                            ro[i] = (ro[i] + 8u) & (uint32_t)(HT * 8 - 1);
-                        }
-                    }
+                for (int i = 0; i < NR; ++i) {
+                    opaque(old[i]);                        // lanes outside ron[i] hold nothing; their compare bits are masked
+                    ron[i] &= mask_of(old[i] != H_EMPTY) & mask_of(old[i] != e[i]);     // slot taken by another hash
+                    if (lanes_of(ron[i])) ro[i] = (ro[i] + 8u) & (uint32_t)(HT * 8 - 1);
+                }
             }
+#pragma unroll
+            for (int i = 0; i < NR; ++i)                   // 16-bit row masks, two to a word: slot s -> half (s & 1) of word s >> 1
+                if (mine[i]) atomicOr(&s_mask[ro[i] >> 4], (1u << (i * HWAVES + wave)) << ((ro[i] & 8u) << 1));
             __syncthreads();
-            // ---- columns: one lookup per hash, a pair of slots per probe (the key sits before the first empty slot of its
-            //      probe sequence), probes of the lane's four hashes together; then the row masks ----
+            // ---- columns: one lookup per hash, a pair of slots per probe (a key sits before the first empty slot of its
+            //      probe sequence, and an odd slot is never filled before its even neighbour) ----
             uint32_t co[NC];
-            bool cp[NC], fnd[NC];
+            uint64_t con[NC], fnd[NC], odd[NC];            // lanes still probing / that found their hash / found it in the odd slot
 #pragma unroll
-            for (int j = 0; j < NC; ++j) { co[j] = pair_slot<LOGT>(e[NR + j]) * 8u; cp[j] = mine[NR + j]; fnd[j] = false; }
+            for (int j = 0; j < NC; ++j) {
+                co[j] = pair_slot<LOGT>(e[NR + j]) * 8u;
+                con[j] = mask_of(mine[NR + j]);
+                fnd[j] = 0;
+                odd[j] = 0;
+            }
             for (;;) {
-                bool any = false;
+                uint64_t any = 0;
 #pragma unroll
-                for (int j = 0; j < NC; ++j) any |= cp[j];
-                if (!__any(any)) break;
+                for (int j = 0; j < NC; ++j) any |= con[j];
+                if (!any) break;
                 ulonglong2 kk[NC];
 #pragma unroll
                 for (int j = 0; j < NC; ++j)
-                    if (cp[j]) kk[j] = *(const ulonglong2*)((const char*)s_key + co[j]);
+                    if (lanes_of(con[j])) kk[j] = *(const ulonglong2*)((const char*)s_key + co[j]);
 #pragma unroll
-                for (int j = 0; j < NC; ++j)
-                    if (cp[j]) {
-                        const bool h0 = kk[j].x == e[NR + j], h1 = kk[j].y == e[NR + j];
-                        if (h0 || h1) { fnd[j] = true; cp[j] = false; co[j] += h1 ? 8u : 0u; }
-                        else if (kk[j].x == H_EMPTY || kk[j].y == H_EMPTY) cp[j] = false;
-                        else co[j] = (co[j] + 16u) & (uint32_t)(HT * 8 - 1);
-                    }
+                for (int j = 0; j < NC; ++j) {
+                    opaque(kk[j].x);                       // lanes outside con[j] hold nothing; their compare bits are masked
+                    opaque(kk[j].y);
+                    const uint64_t b1 = mask_of(kk[j].y == e[NR + j]) & con[j];
+                    const uint64_t bh = (mask_of(kk[j].x == e[NR + j]) & con[j]) | b1;
+                    fnd[j] |= bh;
+                    odd[j] |= b1;
+                    con[j] &= mask_of(kk[j].y != H_EMPTY) & ~bh;
+                    if (lanes_of(con[j])) co[j] = (co[j] + 16u) & (uint32_t)(HT * 8 - 1);
+                }
             }
-            bool hit = false;
             uint32_t m[NC];
 #pragma unroll
-            for (int j = 0; j < NC; ++j) {
-                m[j] = fnd[j] ? (uint32_t)((const uint16_t*)s_mask)[co[j] >> 3] : 0u;
-                hit |= fnd[j];
-            }
+            for (int j = 0; j < NC; ++j)
+                m[j] = lanes_of(fnd[j]) ? (uint32_t)((const uint16_t*)s_mask)[(co[j] >> 3) + (lanes_of(odd[j]) ? 1u : 0u)] : 0u;
+            const bool hit = (fnd[0] | fnd[1] | fnd[2] | fnd[3]) != 0;
             // ---- counts: bit r of m[j] says row r shares the lane's hash of column j.  Every lane keeps 4-bit counters of
             //      its own (16 rows x 4 columns in 8 registers: 3 instructions per 8 counters, nothing divergent, no LDS);
             //      after 15 rounds they are summed over the lanes and added to s_cnt ----
-            if (__any(hit)) {
+            if (hit) {                                     // wave-uniform
 #pragma unroll
                 for (int p = 0; p < NC / 2; ++p) {
                     const uint32_t y = m[2 * p] | (m[2 * p + 1] << 16);
@@ -594,7 +612,7 @@ static hipError_t compare_launch(const uint64_t* d_hashes, const uint64_t* d_off
         hipLaunchKernelGGL(compare_plan_kernel, dim3((unsigned)((tiles + 255) / 256)), dim3(256), 0, stream, d_offsets, n,
                            row_lo, row_hi, symmetric, rb_first, rb_stride, n_row_tiles, n_col_tiles,
                            pick_slice_len(work_tiles), heavy, light, counters, ctc);
-        const uint64_t cap = 256ull * (walk ? 8 : 3);
+        const uint64_t cap = 256ull * (walk ? 8 : (hash_variant() == 3 ? 4 : 3));
         const unsigned grid0 = (unsigned)(work_tiles + 1 < cap ? work_tiles + 1 : cap);
         if (walk)
             // 64 hashes per sketch and round: 17 KiB of LDS per workgroup, 8 workgroups (= 8 waves per SIMD) per CU.
@@ -609,10 +627,12 @@ static hipError_t compare_launch(const uint64_t* d_hashes, const uint64_t* d_off
 #define SMG_LAUNCH_HASH(MINW, LOGT)                                                                                              \
     hipLaunchKernelGGL((compare_hash_kernel<MINW, LOGT>), dim3(grid0 < 1 ? 1 : grid0), dim3(HBLOCK), 0, stream, d_hashes, d_offsets, \
                        n, row_lo, row_hi, d_common, symmetric, rb_first, rb_stride, heavy, light, counters)
-            if (variant == 1) SMG_LAUNCH_HASH(5, 11);           // 2,048 slots, 96 VGPRs, nothing spilled, 2 workgroups per CU
+            if (variant == 1) SMG_LAUNCH_HASH(5, 11);           // 2,048 slots, 96 VGPRs, 2 workgroups per CU
             else if (variant == 2) SMG_LAUNCH_HASH(6, 11);      // 2,048 slots (load factor 1/2), 80 VGPRs, 3 workgroups per CU
-            else SMG_LAUNCH_HASH(6, 12);                        // default: 4,096 slots (load factor 1/4: shorter probe chains), 50 KiB
-                                                                // of LDS, 80 VGPRs (44 bytes per lane spilled), 3 workgroups per CU
+            else if (variant == 3) SMG_LAUNCH_HASH(8, 11);      // 2,048 slots, 64 VGPRs, 4 workgroups per CU
+            else if (variant == 4) SMG_LAUNCH_HASH(5, 12);      // 4,096 slots, 96 VGPRs, 2 workgroups per CU
+            else SMG_LAUNCH_HASH(6, 12);                        // default: 4,096 slots (load factor 1/4: shorter probe chains), 43 KiB
+                                                                // of LDS, 80 VGPRs, 3 workgroups per CU
 #undef SMG_LAUNCH_HASH
         }
         e = hipGetLastError();
