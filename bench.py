@@ -622,7 +622,7 @@ def single_gpu_extras(extra, torch, np, dev, be, smd, synth_sketches, synth_gath
         "identical": bool((ca == bc).all().item() and (ja == bj).all().item()),
         "note": "config C4 (pool-drawn sketches: the cost model picks bit columns); auto includes the index build; "
                 "bitmatrix_kernel is VALU-bound: 2.55 instructions per 32-bit AND+popcount against a floor of 2, ~87 % "
-                "issue-busy at the measured instruction costs (profiles/r02_compare_pmc.txt), upper triangle + mirror; the "
+                "issue-busy at the measured instruction costs (profiles/r03_compare_pmc.txt), upper triangle + mirror; the "
                 "index is built without a sort (csrc/dictindex.hip)"}
     del bc, bj, ca, ja, bh, boff
     torch.cuda.empty_cache()
@@ -690,8 +690,8 @@ def merge_roofline(alg_bytes, ms):
     collection is L2 / Infinity-Cache resident and the SURVEY.md 8(d) convention figure exceeds the HBM peak).  The
     convention bytes -- 8 B x (n_i + n_j) per pair, what one two-pointer walk per pair would read -- are priced against
     the aggregate LDS read bandwidth; the hash-table kernel does less LDS work than that per pair (one insert or lookup
-    per hash of the TILE, not per pair), which is how it passes the walk kernel, and is bound by the latency of its
-    probe chains and by instruction issue (profiles/r02_compare_pmc.txt)."""
+    per hash of the TILE, not per pair), which is how it passes the walk kernel; its time is shared between VALU issue,
+    LDS cycles and the three barriers of a round (profiles/r03_compare_pmc.txt)."""
     achieved = alg_bytes / (ms * 1e-3) / 1e9
     return {"bound": "lds", "achieved": round(achieved, 1), "peak": LDS_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / LDS_PEAK_GBS, 4), "algorithmic_bytes": int(alg_bytes), "ms": round(ms, 3),

@@ -30,6 +30,7 @@
 #include <string.h>
 #include "device_api.hpp"
 #include "arena.hpp"
+#include "wavemask.hpp"
 
 namespace smg {
 
@@ -231,12 +232,13 @@ __global__ __launch_bounds__(CMP_BLOCK) void compare_tile_kernel(
 // 13 VALU instructions a step): at C4 it is bound by instruction issue, not by LDS or memory.  The same slab structure
 // admits a formulation whose work grows with the ELEMENTS of a tile instead: per round, the <= 64 staged hashes of each
 // of the 16 ROW sketches are inserted into an LDS hash table (key = hash, value = 16-bit mask of the rows holding it),
-// then every staged hash of the 32 COLUMN sketches is looked up once and adds 1 to the counters of (row, column) for the
-// rows in its mask.  Rounds are cut at the same data-driven bound `hi` as the walk (every sketch's hashes <= hi are among
-// its staged ones), so the counts are the walk's counts: |A_r ∩ B_c| summed over disjoint hash ranges.
-// Per round: 1,024 inserts + 2,048 lookups + one LDS add per common hash, for 512 pairs -- about 6x fewer instructions than
-// 512 walks of ~100 steps.  LDS accesses are hash-addressed (random banks), so the bank-conflict RATIO stays high while
-// the absolute LDS cycles drop with the work.
+// then every staged hash of the 32 COLUMN sketches is looked up once; bit r of the mask it finds says row r shares it.
+// Rounds are cut at the same data-driven bound `hi` as the walk (every sketch's hashes <= hi are among its staged ones),
+// so the counts are the walk's counts: |A_r ∩ B_c| summed over disjoint hash ranges.
+// Per round: 1,024 inserts + 2,048 lookups for 512 pairs.  The loop is written around its VALU instruction count (it is
+// what bounded the first version): the masks are counted in per-lane 4-bit counters (3 instructions per 8
+// (row, column) cells, nothing divergent) that go to the tile's LDS counters every 15 rounds through a DPP row sum; a
+// probe reads an aligned pair of slots; the sets of lanes still probing live in scalar registers as wave masks.
 constexpr int HR = CT;                // row sketches of a tile (inserted)
 constexpr int HC = 32;                // column sketches of a tile (looked up)
 constexpr int HSEG = 64;              // hashes staged per sketch and round: one per lane
@@ -247,29 +249,17 @@ constexpr int HBLOCK = HWAVES * 64;
 constexpr int HPW = (HR + HC) / HWAVES;   // sketches per wave
 static_assert(HR % HWAVES == 0 && HC % HWAVES == 0, "");
 
-__device__ __forceinline__ uint64_t uniform64(uint64_t v) {          // a wave-uniform value into scalar registers
-    return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32) |
-           (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
-}
-
 constexpr int NR = HR / HWAVES;       // row sketches per wave
 constexpr int NC = HC / HWAVES;       // column sketches per wave
 static_assert(HR == 16 && NC == 4 && HC == 32, "the packed counters below hold 16 rows x 4 columns per wave");
 
 template <int LOGT>
 __device__ __forceinline__ uint32_t pair_slot(uint64_t v) {           // the even slot a hash's probe sequence starts on
-    const uint32_t x = ((uint32_t)v ^ (uint32_t)(v >> 32)) * 0x9E3779B1u;   // slabs share their top bits: mix before cutting
-    return (x >> (32 - (LOGT - 1))) << 1;
-}
-
-__device__ __forceinline__ bool lanes_of(uint64_t wave_mask) {        // a wave mask held in scalar registers, as a lane predicate
-    return __builtin_amdgcn_inverse_ballot_w64(wave_mask);
-}
-__device__ __forceinline__ void opaque(unsigned long long& v) {       // the value as the registers hold it, whatever wrote it
-    asm volatile("" : "+v"(v));
-}
-__device__ __forceinline__ uint64_t mask_of(bool lane_pred) {         // and back (the compare's own result mask, no VALU work)
-    return __builtin_amdgcn_ballot_w64(lane_pred);
+    // the hashes of a round share their top bits (a narrow value range), so the slot comes from the low word folded with
+    // the high one; shifts and xors only -- a 32-bit multiply costs four of them on this VALU
+    uint32_t x = (uint32_t)v ^ (uint32_t)(v >> 32);
+    x ^= x >> 15;
+    return (x & (uint32_t)((1 << (LOGT - 1)) - 1)) << 1;
 }
 
 template <int CTRL>

@@ -29,6 +29,7 @@
 #include <rocprim/device/device_scan.hpp>
 #include "gather_api.hpp"
 #include "arena.hpp"
+#include "wavemask.hpp"
 #include <chrono>
 #include "qindex.hpp"
 
@@ -2155,7 +2156,8 @@ __global__ __launch_bounds__(SL_THREADS) void stream_lookup_kernel(const uint64_
 // every row is counted by exactly one workgroup: plain stores, no atomics.
 constexpr int OW_THREADS = 1024;
 constexpr int OW_WAVES = OW_THREADS / 64;
-constexpr int OW_AHEAD = 4;               // row visits a wave has in flight
+constexpr int OW_AHEAD = 8;               // row visits a wave asks for at a time (as many again are being looked up)
+constexpr int OW_BATCH = 4;               // visits looked up side by side
 constexpr int OW_BUCKETS = 8192;          // table buckets per range (at most)
 constexpr int OW_QCAP = 11264;            // query hashes a range may hold (88 KB); the caller checks the widest range
 constexpr int OW_ROWS = 1024;             // rows per workgroup (at most)
@@ -2176,7 +2178,7 @@ __global__ __launch_bounds__(OW_THREADS) void overlap_wide_kernel(const uint64_t
     const uint64_t d_lo = (uint64_t)blockIdx.x * rows_per_wg;
     if (d_lo >= ndb) return;
     const uint32_t n_rows = (uint32_t)(ndb - d_lo < (uint64_t)rows_per_wg ? ndb - d_lo : (uint64_t)rows_per_wg);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint64_t block_base = offsets[d_lo];
     const uint64_t* rows = hashes + block_base;
     for (uint32_t i = tid; i <= n_rows + 1; i += OW_THREADS)          // entry n_rows + 1 closes an empty row behind the last one
@@ -2204,6 +2206,32 @@ __global__ __launch_bounds__(OW_THREADS) void overlap_wide_kernel(const uint64_t
         }
     };
     fetch(0);
+    // software pipeline over the wave's row visits: the loads of the NEXT OW_AHEAD rows are in flight while the present
+    // ones are looked up, OW_BATCH at a time.  The kernel waits on these loads more than on anything else (16 waves per
+    // CU, ~400 useful bytes per visit: profiles/r03_overlap_pmc.txt), so the number a wave keeps in flight is what sets
+    // its pace.  A visit's row is the same for all lanes: its start, length and cursor are read from LDS into SCALAR
+    // registers (one broadcast read, v_readfirstlane), the address of the 512-byte load is a scalar base plus lane * 8,
+    // and only the data and the count of hashes left in the row travel to the lookup.
+    uint64_t e[OW_AHEAD], e_next[OW_AHEAD];
+    uint32_t rem[OW_AHEAD], rem_next[OW_AHEAD];                         // hashes of the row behind its cursor (wave-uniform)
+    auto issue = [&](uint32_t i0, uint64_t (&dst)[OW_AHEAD], uint32_t (&rem_)[OW_AHEAD]) {
+#pragma unroll
+        for (int u = 0; u < OW_AHEAD; ++u) {
+            const uint32_t i = i0 + (uint32_t)u * OW_WAVES;                // wave-uniform
+            dst[u] = ~0ull;
+            rem_[u] = 0;
+            if (i < n_rows) {
+                const uint32_t rb = uniform32(s_base[i]), cur = uniform32(s_cur[i]);
+                rem_[u] = uniform32(s_base[i + 1]) - rb - cur;              // the cursor never passes the row's end
+                if ((uint32_t)lane < rem_[u]) dst[u] = (rows + rb + cur)[lane];
+            }
+        }
+    };
+    // The first visits of a range are asked for before the barrier that ends the previous one (their rows were the first
+    // this wave went over in that range, so their cursors are final): the loads fly while the workgroup waits, refills LDS
+    // and waits again -- a range would otherwise start with a full trip to memory and nothing to do.
+    __syncthreads();                                                      // row starts and cursors are in LDS
+    issue((uint32_t)wave, e, rem);
     for (uint32_t r = 0; r < n_ranges; ++r) {
         const uint32_t b0 = r * bpr, b1 = b0 + bpr < n_buckets ? b0 + bpr : n_buckets;
         const bool last = r + 1 == n_ranges;
@@ -2223,95 +2251,84 @@ __global__ __launch_bounds__(OW_THREADS) void overlap_wide_kernel(const uint64_t
         if (tid >= 64 && tid < 64 + 3 && n_cnt_t + (uint32_t)(tid - 64) <= bpr) s_t[n_cnt_t + (uint32_t)(tid - 64)] = n_cnt_q;   // a short last range
         __syncthreads();
         if (!last) fetch(r + 1);
-        // software pipeline over the wave's row visits: the loads of the NEXT OW_AHEAD rows are in flight while the present
-        // ones are looked up (row starts and cursors are read from LDS again at that point: registers hold only the data)
-        uint64_t e[OW_AHEAD], e_next[OW_AHEAD];
-        auto issue = [&](uint32_t i0, uint64_t (&dst)[OW_AHEAD]) {
-#pragma unroll
-            for (int u = 0; u < OW_AHEAD; ++u) {
-                const uint32_t i = i0 + (uint32_t)u * OW_WAVES;
-                dst[u] = ~0ull;
-                if (i < n_rows) {
-                    const uint32_t rb = s_base[i], len = s_base[i + 1] - rb, c = s_cur[i];
-                    if (c + lane < len) dst[u] = rows[(uint64_t)rb + c + lane];
-                }
-            }
-        };
-        issue((uint32_t)wave, e);
         for (uint32_t i0 = wave; i0 < n_rows; i0 += OW_WAVES * OW_AHEAD) {
-            issue(i0 + OW_WAVES * OW_AHEAD, e_next);
-            uint32_t c[OW_AHEAD], len[OW_AHEAD], rb[OW_AHEAD];
-#pragma unroll
-            for (int u = 0; u < OW_AHEAD; ++u) {
-                const uint32_t i = i0 + (uint32_t)u * OW_WAVES;
-                const bool row_ok = i < n_rows;
-                rb[u] = row_ok ? s_base[i] : 0u;
-                len[u] = row_ok ? s_base[i + 1] - rb[u] : 0u;
-                c[u] = row_ok ? s_cur[i] : 0u;
-            }
+            issue(i0 + OW_WAVES * OW_AHEAD, e_next, rem_next);
             // The visits' lookups run side by side and branch-free: every lane reads its bucket's two table entries and the
             // bucket's first two query hashes whether or not it holds a hash of this range (indices clamped into the arrays;
-            // the compares decide).  Measured on the first form of this kernel (profiles/r03_overlap_pmc.txt): 74 VALU + 53
-            // scalar instructions per visit, most of them the exec-mask bookkeeping of per-lane conditionals -- the kernel was
-            // bound by instruction issue, not by memory.  Buckets of more than two hashes and slices of more than 64 hashes
-            // (both rare) take the slow paths, one visit at a time.
-            bool in[OW_AHEAD], lk[OW_AHEAD];
-            uint32_t t0[OW_AHEAD], nb[OW_AHEAD];
+            // the compares decide).  Buckets of more than two hashes and slices of more than 64 hashes (both rare) take the
+            // slow paths, one visit at a time.  Which lanes hold a hash of this range / one that can be in the query / one
+            // that was found are wave masks in scalar registers, combined from the masks of plain compares (wavemask.hpp).
 #pragma unroll
-            for (int u = 0; u < OW_AHEAD; ++u) {
-                in[u] = c[u] + lane < len[u] && (last || e[u] < upper);
-                lk[u] = in[u] && e[u] <= qmax;
-                uint32_t k = (uint32_t)(e[u] >> shift) - b0;                 // < bpr when lk: the hash lies in this range
-                k = k < bpr ? k : bpr;                                       // other lanes: the padding entries behind the slice
-                t0[u] = s_t[k];
-                nb[u] = s_t[k + 1] - t0[u];
-            }
-            uint64_t qa[OW_AHEAD], qb[OW_AHEAD];
+            for (int v0 = 0; v0 < OW_AHEAD; v0 += OW_BATCH) {
+                uint64_t in[OW_BATCH], lk[OW_BATCH];
+                uint32_t t0[OW_BATCH], nb[OW_BATCH];
 #pragma unroll
-            for (int u = 0; u < OW_AHEAD; ++u) {
-                const uint32_t ta = t0[u] < (uint32_t)(OW_QCAP - 2) ? t0[u] : (uint32_t)(OW_QCAP - 2);
-                qa[u] = s_q[ta];
-                qb[u] = s_q[ta + 1];
-            }
-#pragma unroll
-            for (int u = 0; u < OW_AHEAD; ++u) {
-                const uint32_t i = i0 + (uint32_t)u * OW_WAVES;
-                bool hit = lk[u] & ((nb[u] >= 1u & qa[u] == e[u]) | (nb[u] >= 2u & qb[u] == e[u]));
-                const bool deep = lk[u] & !hit & nb[u] > 2u & qb[u] < e[u];  // the bucket goes on and has not passed the hash yet
-                if (__builtin_expect(__ballot(deep) != 0ull, 0)) {
-                    if (deep)
-                        for (uint32_t t = t0[u] + 2; t < t0[u] + nb[u]; ++t) {
-                            const uint64_t qv = s_q[t];
-                            if (qv == e[u]) { hit = true; break; }
-                            if (qv > e[u]) break;
-                        }
+                for (int w = 0; w < OW_BATCH; ++w) {
+                    const int u = v0 + w;
+                    // lanes past the row's end hold 2^64 - 1, which is not below any range's upper end but the last one's
+                    in[w] = last ? mask_of((uint32_t)lane < rem[u]) : mask_of(e[u] < upper);
+                    lk[w] = in[w] & mask_of(e[u] <= qmax);
+                    uint32_t k = (uint32_t)(e[u] >> shift) - b0;             // < bpr when lk: the hash lies in this range
+                    k = k < bpr ? k : bpr;                                   // other lanes: the padding entries behind the slice
+                    t0[w] = s_t[k];
+                    nb[w] = s_t[k + 1] - t0[w];
                 }
-                uint32_t taken = (uint32_t)__popcll(__ballot(in[u]));
-                uint32_t hits = (uint32_t)__popcll(__ballot(hit));
-                uint32_t cur = c[u] + taken;
-                if (__builtin_expect(taken == 64u, 0)) {
-                    while (taken == 64u) {                                   // a longer slice (rare): keep reading, one load at a time
-                        const uint64_t ev = cur + lane < len[u] ? rows[(uint64_t)rb[u] + cur + lane] : ~0ull;
-                        const bool more = cur + lane < len[u] && (last || ev < upper);
-                        bool h2 = false;
-                        if (more && ev <= qmax) {
-                            const uint32_t k = (uint32_t)(ev >> shift) - b0;
-                            for (uint32_t t = s_t[k], te = s_t[k + 1]; t < te; ++t) {
+                uint64_t qa[OW_BATCH], qb[OW_BATCH];
+#pragma unroll
+                for (int w = 0; w < OW_BATCH; ++w) {
+                    const uint32_t ta = t0[w] < (uint32_t)(OW_QCAP - 2) ? t0[w] : (uint32_t)(OW_QCAP - 2);
+                    qa[w] = s_q[ta];
+                    qb[w] = s_q[ta + 1];
+                }
+#pragma unroll
+                for (int w = 0; w < OW_BATCH; ++w) {
+                    const int u = v0 + w;
+                    const uint32_t i = i0 + (uint32_t)u * OW_WAVES;
+                    const uint64_t eq = (mask_of(nb[w] >= 1u) & mask_of(qa[w] == e[u])) | (mask_of(nb[w] >= 2u) & mask_of(qb[w] == e[u]));
+                    uint64_t found = lk[w] & eq;
+                    // the bucket goes on and has not passed the hash yet
+                    const uint64_t deep = lk[w] & ~eq & mask_of(nb[w] > 2u) & mask_of(qb[w] < e[u]);
+                    if (__builtin_expect(deep != 0ull, 0)) {
+                        bool hit = false;
+                        if (lanes_of(deep))
+                            for (uint32_t t = t0[w] + 2; t < t0[w] + nb[w]; ++t) {
                                 const uint64_t qv = s_q[t];
-                                if (qv == ev) { h2 = true; break; }
-                                if (qv > ev) break;
+                                if (qv == e[u]) { hit = true; break; }
+                                if (qv > e[u]) break;
                             }
-                        }
-                        taken = (uint32_t)__popcll(__ballot(more));
-                        hits += (uint32_t)__popcll(__ballot(h2));
-                        cur += taken;
+                        found |= mask_of(hit);
                     }
+                    uint32_t taken = (uint32_t)__popcll(in[w]);
+                    uint32_t hits = (uint32_t)__popcll(found);
+                    if (__builtin_expect(taken == 64u, 0)) {                 // a longer slice (rare): keep reading, one load at a time
+                        const uint32_t rb = uniform32(s_base[i]), len = uniform32(s_base[i + 1]) - rb;
+                        uint32_t cur = uniform32(s_cur[i]) + 64u, more_n = 64u;
+                        while (more_n == 64u) {
+                            const bool have = (uint32_t)lane < len - cur;
+                            const uint64_t ev = have ? (rows + rb + cur)[lane] : ~0ull;
+                            const bool more = have && (last || ev < upper);
+                            bool h2 = false;
+                            if (more && ev <= qmax) {
+                                const uint32_t k = (uint32_t)(ev >> shift) - b0;
+                                for (uint32_t t = s_t[k], te = s_t[k + 1]; t < te; ++t) {
+                                    const uint64_t qv = s_q[t];
+                                    if (qv == ev) { h2 = true; break; }
+                                    if (qv > ev) break;
+                                }
+                            }
+                            more_n = (uint32_t)__popcll(mask_of(more));
+                            hits += (uint32_t)__popcll(mask_of(h2));
+                            cur += more_n;
+                            taken += more_n;
+                        }
+                    }
+                    if (i < n_rows && lane == 0) { s_cur[i] += taken; s_hits[i] += hits; }
                 }
-                if (lane == 0 && i < n_rows) { s_cur[i] = cur; s_hits[i] += hits; }
             }
 #pragma unroll
-            for (int u = 0; u < OW_AHEAD; ++u) e[u] = e_next[u];
+            for (int u = 0; u < OW_AHEAD; ++u) { e[u] = e_next[u]; rem[u] = rem_next[u]; }
         }
+        if (!last) issue((uint32_t)wave, e, rem);
     }
     __syncthreads();
     for (uint32_t i = tid; i < n_rows; i += OW_THREADS) counts[d_lo + i] = s_hits[i];
@@ -2394,6 +2411,8 @@ hipError_t overlap_ranges_launch(const uint64_t* Q, uint64_t nq, const uint64_t*
         }
         if (attr_state > 0 && w_widest <= (unsigned)OW_QCAP) {
             uint64_t rpw = (ndb + (uint64_t)n_cu_w - 1) / (uint64_t)n_cu_w;
+            static const uint64_t rpw_env = [] { const char* e = getenv("SMG_OVERLAP_ROWS"); return e ? (uint64_t)atoll(e) : 0ull; }();
+            if (rpw_env) rpw = rpw_env;                                        // tuning: rows a workgroup owns
             if (rpw > (uint64_t)OW_ROWS) rpw = OW_ROWS;
             if (rpw < 1) rpw = 1;
             const uint64_t n_wg = (ndb + rpw - 1) / rpw;
