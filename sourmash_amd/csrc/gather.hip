@@ -2156,11 +2156,11 @@ __global__ __launch_bounds__(SL_THREADS) void stream_lookup_kernel(const uint64_
 // every row is counted by exactly one workgroup: plain stores, no atomics.
 constexpr int OW_THREADS = 1024;
 constexpr int OW_WAVES = OW_THREADS / 64;
-constexpr int OW_AHEAD = 8;               // row visits a wave asks for at a time (as many again are being looked up)
+constexpr int OW_SLOTS = 25;              // rows a wave owns, each with its next 64 hashes in (or on the way to) registers
 constexpr int OW_BATCH = 4;               // visits looked up side by side
 constexpr int OW_BUCKETS = 8192;          // table buckets per range (at most)
 constexpr int OW_QCAP = 11264;            // query hashes a range may hold (88 KB); the caller checks the widest range
-constexpr int OW_ROWS = 1024;             // rows per workgroup (at most)
+constexpr int OW_ROWS = OW_WAVES * OW_SLOTS;   // rows per workgroup (at most): 400
 constexpr size_t OW_LDS = (size_t)OW_QCAP * 8 + ((size_t)OW_BUCKETS + 4) * 4 + ((size_t)3 * OW_ROWS + 8) * 4;
 
 __global__ __launch_bounds__(OW_THREADS) void overlap_wide_kernel(const uint64_t* __restrict__ Q, const uint32_t* __restrict__ T,
@@ -2184,152 +2184,171 @@ __global__ __launch_bounds__(OW_THREADS) void overlap_wide_kernel(const uint64_t
     for (uint32_t i = tid; i <= n_rows + 1; i += OW_THREADS)          // entry n_rows + 1 closes an empty row behind the last one
         s_base[i] = (uint32_t)(offsets[d_lo + (i <= n_rows ? i : n_rows)] - block_base);
     for (uint32_t i = tid; i <= n_rows; i += OW_THREADS) { s_cur[i] = 0; s_hits[i] = 0; }
-    // The slice of the table and of the query for range r + 1 is asked for (into registers) before range r is walked, and
-    // goes to LDS when r is through: the fill's trip to L2 hides behind a range's worth of row visits.
+    // A range's slice of the table and of the query goes from L2 straight to LDS between the range's two barriers (20 loads
+    // per thread, one trip): staging it in registers a range ahead, as this kernel first did, costs 31 registers that the
+    // rows' data needs more.  Only the slice's bounds (two table entries the loads' addresses depend on) are asked for a
+    // range ahead.
     constexpr int QPER = (OW_QCAP + OW_THREADS - 1) / OW_THREADS, TPER = (OW_BUCKETS + 1 + OW_THREADS - 1) / OW_THREADS;
-    uint64_t nq_reg[QPER];
-    uint32_t nt_reg[TPER];
-    uint32_t n_p0 = 0, n_cnt_q = 0, n_cnt_t = 0;
-    auto fetch = [&](uint32_t r) {
-        const uint32_t b0 = r * bpr, b1 = b0 + bpr < n_buckets ? b0 + bpr : n_buckets;
-        const uint32_t p0 = T[b0], p1 = T[b1];
-        n_p0 = p0; n_cnt_q = p1 - p0; n_cnt_t = b1 - b0 + 1;
-#pragma unroll
-        for (int u = 0; u < TPER; ++u) {
-            const uint32_t i = (uint32_t)tid + (uint32_t)u * OW_THREADS;
-            nt_reg[u] = i < n_cnt_t ? T[b0 + i] : 0u;
-        }
-#pragma unroll
-        for (int u = 0; u < QPER; ++u) {
-            const uint32_t i = (uint32_t)tid + (uint32_t)u * OW_THREADS;
-            nq_reg[u] = i < n_cnt_q ? Q[p0 + i] : 0ull;
-        }
-    };
-    fetch(0);
-    // software pipeline over the wave's row visits: the loads of the NEXT OW_AHEAD rows are in flight while the present
-    // ones are looked up, OW_BATCH at a time.  The kernel waits on these loads more than on anything else (16 waves per
-    // CU, ~400 useful bytes per visit: profiles/r03_overlap_pmc.txt), so the number a wave keeps in flight is what sets
-    // its pace.  A visit's row is the same for all lanes: its start, length and cursor are read from LDS into SCALAR
-    // registers (one broadcast read, v_readfirstlane), the address of the 512-byte load is a scalar base plus lane * 8,
-    // and only the data and the count of hashes left in the row travel to the lookup.
-    uint64_t e[OW_AHEAD], e_next[OW_AHEAD];
-    uint32_t rem[OW_AHEAD], rem_next[OW_AHEAD];                         // hashes of the row behind its cursor (wave-uniform)
-    auto issue = [&](uint32_t i0, uint64_t (&dst)[OW_AHEAD], uint32_t (&rem_)[OW_AHEAD]) {
-#pragma unroll
-        for (int u = 0; u < OW_AHEAD; ++u) {
-            const uint32_t i = i0 + (uint32_t)u * OW_WAVES;                // wave-uniform
-            dst[u] = ~0ull;
-            rem_[u] = 0;
-            if (i < n_rows) {
-                const uint32_t rb = uniform32(s_base[i]), cur = uniform32(s_cur[i]);
-                rem_[u] = uniform32(s_base[i + 1]) - rb - cur;              // the cursor never passes the row's end
-                if ((uint32_t)lane < rem_[u]) dst[u] = (rows + rb + cur)[lane];
-            }
+    uint32_t n_p0 = T[0], n_p1 = T[bpr < n_buckets ? bpr : n_buckets];   // range 0's; every lane holds the same two values
+    // A wave owns the rows wave, wave + 16, ... of the block: OW_SLOTS of them at most, each with a register pair that holds
+    // the row's next 64 hashes.  A row is visited once per range, and the load for its NEXT visit is issued right after the
+    // present one (the cursor is known then), a whole range ahead: when a range starts, all of its data is in registers or
+    // on its way, and nothing in a range waits for a trip to memory that began in the same range.  (The two-stage pipeline
+    // this replaces kept 8-16 visits in flight and paid three dependent trips per range; with the barriers of a range that
+    // left it at 2.6 ms whatever the instruction count -- profiles/r03_overlap_pmc.txt.)
+    // A visit's row is the same for all lanes: its start, length and cursor are read from LDS into SCALAR registers (one
+    // broadcast read, v_readfirstlane) and the address of the 512-byte load is a scalar base plus lane * 8.
+    uint64_t e[OW_SLOTS];
+    auto ask = [&](int k) {                                                // the next 64 hashes of slot k's row
+        const uint32_t i = (uint32_t)wave + (uint32_t)k * OW_WAVES;          // wave-uniform
+        e[k] = ~0ull;
+        if (i < n_rows) {
+            const uint32_t rb = uniform32(s_base[i]), cur = uniform32(s_cur[i]);
+            const uint32_t left = uniform32(s_base[i + 1]) - rb - cur;       // the cursor never passes the row's end
+            if ((uint32_t)lane < left) e[k] = (rows + rb + cur)[lane];
         }
     };
-    // The first visits of a range are asked for before the barrier that ends the previous one (their rows were the first
-    // this wave went over in that range, so their cursors are final): the loads fly while the workgroup waits, refills LDS
-    // and waits again -- a range would otherwise start with a full trip to memory and nothing to do.
     __syncthreads();                                                      // row starts and cursors are in LDS
-    issue((uint32_t)wave, e, rem);
+#pragma unroll
+    for (int k = 0; k < OW_SLOTS; ++k) ask(k);
+#ifdef SMG_OW_TRACE
+    unsigned long long tr_b1 = 0, tr_fill = 0, tr_b2 = 0, tr_proc = 0, tr_t = __builtin_readcyclecounter();
+#define OW_MARK(acc) { const unsigned long long now_ = __builtin_readcyclecounter(); acc += now_ - tr_t; tr_t = now_; }
+#else
+#define OW_MARK(acc)
+#endif
     for (uint32_t r = 0; r < n_ranges; ++r) {
         const uint32_t b0 = r * bpr, b1 = b0 + bpr < n_buckets ? b0 + bpr : n_buckets;
         const bool last = r + 1 == n_ranges;
         const uint64_t upper = last ? ~0ull : ((uint64_t)b1 << shift);    // hashes below it belong to this range (earlier ones are consumed)
+        const uint32_t p0 = uniform32(n_p0), cnt_q = uniform32(n_p1) - p0, cnt_t = b1 - b0 + 1;
         __syncthreads();                                                  // the previous range's readers are done
+        OW_MARK(tr_b1)
+        {
+            uint32_t tv[TPER];
+            uint64_t qv[QPER];
 #pragma unroll
-        for (int u = 0; u < TPER; ++u) {
-            const uint32_t i = (uint32_t)tid + (uint32_t)u * OW_THREADS;
-            if (i < n_cnt_t) s_t[i] = nt_reg[u] - n_p0;
-        }
-#pragma unroll
-        for (int u = 0; u < QPER; ++u) {
-            const uint32_t i = (uint32_t)tid + (uint32_t)u * OW_THREADS;
-            if (i < n_cnt_q) s_q[i] = nq_reg[u];
-        }
-        if (tid < 2) s_t[bpr + 1 + tid] = n_cnt_q;                       // padding: lanes without a hash of the range read an empty bucket
-        if (tid >= 64 && tid < 64 + 3 && n_cnt_t + (uint32_t)(tid - 64) <= bpr) s_t[n_cnt_t + (uint32_t)(tid - 64)] = n_cnt_q;   // a short last range
-        __syncthreads();
-        if (!last) fetch(r + 1);
-        for (uint32_t i0 = wave; i0 < n_rows; i0 += OW_WAVES * OW_AHEAD) {
-            issue(i0 + OW_WAVES * OW_AHEAD, e_next, rem_next);
-            // The visits' lookups run side by side and branch-free: every lane reads its bucket's two table entries and the
-            // bucket's first two query hashes whether or not it holds a hash of this range (indices clamped into the arrays;
-            // the compares decide).  Buckets of more than two hashes and slices of more than 64 hashes (both rare) take the
-            // slow paths, one visit at a time.  Which lanes hold a hash of this range / one that can be in the query / one
-            // that was found are wave masks in scalar registers, combined from the masks of plain compares (wavemask.hpp).
-#pragma unroll
-            for (int v0 = 0; v0 < OW_AHEAD; v0 += OW_BATCH) {
-                uint64_t in[OW_BATCH], lk[OW_BATCH];
-                uint32_t t0[OW_BATCH], nb[OW_BATCH];
-#pragma unroll
-                for (int w = 0; w < OW_BATCH; ++w) {
-                    const int u = v0 + w;
-                    // lanes past the row's end hold 2^64 - 1, which is not below any range's upper end but the last one's
-                    in[w] = last ? mask_of((uint32_t)lane < rem[u]) : mask_of(e[u] < upper);
-                    lk[w] = in[w] & mask_of(e[u] <= qmax);
-                    uint32_t k = (uint32_t)(e[u] >> shift) - b0;             // < bpr when lk: the hash lies in this range
-                    k = k < bpr ? k : bpr;                                   // other lanes: the padding entries behind the slice
-                    t0[w] = s_t[k];
-                    nb[w] = s_t[k + 1] - t0[w];
-                }
-                uint64_t qa[OW_BATCH], qb[OW_BATCH];
-#pragma unroll
-                for (int w = 0; w < OW_BATCH; ++w) {
-                    const uint32_t ta = t0[w] < (uint32_t)(OW_QCAP - 2) ? t0[w] : (uint32_t)(OW_QCAP - 2);
-                    qa[w] = s_q[ta];
-                    qb[w] = s_q[ta + 1];
-                }
-#pragma unroll
-                for (int w = 0; w < OW_BATCH; ++w) {
-                    const int u = v0 + w;
-                    const uint32_t i = i0 + (uint32_t)u * OW_WAVES;
-                    const uint64_t eq = (mask_of(nb[w] >= 1u) & mask_of(qa[w] == e[u])) | (mask_of(nb[w] >= 2u) & mask_of(qb[w] == e[u]));
-                    uint64_t found = lk[w] & eq;
-                    // the bucket goes on and has not passed the hash yet
-                    const uint64_t deep = lk[w] & ~eq & mask_of(nb[w] > 2u) & mask_of(qb[w] < e[u]);
-                    if (__builtin_expect(deep != 0ull, 0)) {
-                        bool hit = false;
-                        if (lanes_of(deep))
-                            for (uint32_t t = t0[w] + 2; t < t0[w] + nb[w]; ++t) {
-                                const uint64_t qv = s_q[t];
-                                if (qv == e[u]) { hit = true; break; }
-                                if (qv > e[u]) break;
-                            }
-                        found |= mask_of(hit);
-                    }
-                    uint32_t taken = (uint32_t)__popcll(in[w]);
-                    uint32_t hits = (uint32_t)__popcll(found);
-                    if (__builtin_expect(taken == 64u, 0)) {                 // a longer slice (rare): keep reading, one load at a time
-                        const uint32_t rb = uniform32(s_base[i]), len = uniform32(s_base[i + 1]) - rb;
-                        uint32_t cur = uniform32(s_cur[i]) + 64u, more_n = 64u;
-                        while (more_n == 64u) {
-                            const bool have = (uint32_t)lane < len - cur;
-                            const uint64_t ev = have ? (rows + rb + cur)[lane] : ~0ull;
-                            const bool more = have && (last || ev < upper);
-                            bool h2 = false;
-                            if (more && ev <= qmax) {
-                                const uint32_t k = (uint32_t)(ev >> shift) - b0;
-                                for (uint32_t t = s_t[k], te = s_t[k + 1]; t < te; ++t) {
-                                    const uint64_t qv = s_q[t];
-                                    if (qv == ev) { h2 = true; break; }
-                                    if (qv > ev) break;
-                                }
-                            }
-                            more_n = (uint32_t)__popcll(mask_of(more));
-                            hits += (uint32_t)__popcll(mask_of(h2));
-                            cur += more_n;
-                            taken += more_n;
-                        }
-                    }
-                    if (i < n_rows && lane == 0) { s_cur[i] += taken; s_hits[i] += hits; }
-                }
+            for (int u = 0; u < TPER; ++u) {
+                const uint32_t i = (uint32_t)tid + (uint32_t)u * OW_THREADS;
+                tv[u] = i < cnt_t ? T[b0 + i] : 0u;
             }
 #pragma unroll
-            for (int u = 0; u < OW_AHEAD; ++u) { e[u] = e_next[u]; rem[u] = rem_next[u]; }
+            for (int u = 0; u < QPER; ++u) {
+                const uint32_t i = (uint32_t)tid + (uint32_t)u * OW_THREADS;
+                qv[u] = i < cnt_q ? Q[p0 + i] : 0ull;
+            }
+#pragma unroll
+            for (int u = 0; u < TPER; ++u) {
+                const uint32_t i = (uint32_t)tid + (uint32_t)u * OW_THREADS;
+                if (i < cnt_t) s_t[i] = tv[u] - p0;
+            }
+#pragma unroll
+            for (int u = 0; u < QPER; ++u) {
+                const uint32_t i = (uint32_t)tid + (uint32_t)u * OW_THREADS;
+                if (i < cnt_q) s_q[i] = qv[u];
+            }
         }
-        if (!last) issue((uint32_t)wave, e, rem);
+        if (tid < 2) s_t[bpr + 1 + tid] = cnt_q;                         // padding: lanes without a hash of the range read an empty bucket
+        if (tid >= 64 && tid < 64 + 3 && cnt_t + (uint32_t)(tid - 64) <= bpr) s_t[cnt_t + (uint32_t)(tid - 64)] = cnt_q;   // a short last range
+        OW_MARK(tr_fill)
+        __syncthreads();
+        OW_MARK(tr_b2)
+        if (!last) {                                                     // the next range's bounds
+            const uint32_t nb0 = b1, nb1 = nb0 + bpr < n_buckets ? nb0 + bpr : n_buckets;
+            n_p0 = T[nb0];
+            n_p1 = T[nb1];
+        }
+        // The visits' lookups run OW_BATCH side by side and branch-free: every lane reads its bucket's two table entries and
+        // the bucket's first two query hashes whether or not it holds a hash of this range (indices clamped into the arrays;
+        // the compares decide).  Buckets of more than two hashes and slices of more than 64 hashes (both rare) take the slow
+        // paths, one visit at a time.  Which lanes hold a hash of this range / one that can be in the query / one that was
+        // found are wave masks in scalar registers, combined from the masks of plain compares (wavemask.hpp).
+#pragma unroll
+        for (int v0 = 0; v0 < OW_SLOTS; v0 += OW_BATCH) {
+            if ((uint32_t)wave + (uint32_t)v0 * OW_WAVES >= n_rows) break;  // no rows in this batch or behind it (wave-uniform)
+            uint64_t in[OW_BATCH], lk[OW_BATCH];
+            uint32_t t0[OW_BATCH], nb[OW_BATCH];
+#pragma unroll
+            for (int w = 0; w < OW_BATCH; ++w) {
+                const int k = v0 + w;
+                if (k >= OW_SLOTS) continue;
+                if (last) {                                                  // 2^64 - 1 can be a hash here: count the lanes instead
+                    const uint32_t i = (uint32_t)wave + (uint32_t)k * OW_WAVES;
+                    uint32_t left = 0;
+                    if (i < n_rows) left = uniform32(s_base[i + 1]) - uniform32(s_base[i]) - uniform32(s_cur[i]);
+                    in[w] = mask_of((uint32_t)lane < left);
+                } else {
+                    in[w] = mask_of(e[k] < upper);                           // lanes past the row's end hold 2^64 - 1
+                }
+                lk[w] = in[w] & mask_of(e[k] <= qmax);
+                uint32_t kk = (uint32_t)(e[k] >> shift) - b0;                // < bpr when lk: the hash lies in this range
+                kk = kk < bpr ? kk : bpr;                                    // other lanes: the padding entries behind the slice
+                t0[w] = s_t[kk];
+                nb[w] = s_t[kk + 1] - t0[w];
+            }
+            uint64_t qa[OW_BATCH], qb[OW_BATCH];
+#pragma unroll
+            for (int w = 0; w < OW_BATCH; ++w) {
+                if (v0 + w >= OW_SLOTS) continue;
+                const uint32_t ta = t0[w] < (uint32_t)(OW_QCAP - 2) ? t0[w] : (uint32_t)(OW_QCAP - 2);
+                qa[w] = s_q[ta];
+                qb[w] = s_q[ta + 1];
+            }
+#pragma unroll
+            for (int w = 0; w < OW_BATCH; ++w) {
+                const int k = v0 + w;
+                if (k >= OW_SLOTS) continue;
+                const uint32_t i = (uint32_t)wave + (uint32_t)k * OW_WAVES;
+                const uint64_t eq = (mask_of(nb[w] >= 1u) & mask_of(qa[w] == e[k])) | (mask_of(nb[w] >= 2u) & mask_of(qb[w] == e[k]));
+                uint64_t found = lk[w] & eq;
+                // the bucket goes on and has not passed the hash yet
+                const uint64_t deep = lk[w] & ~eq & mask_of(nb[w] > 2u) & mask_of(qb[w] < e[k]);
+                if (__builtin_expect(deep != 0ull, 0)) {
+                    bool hit = false;
+                    if (lanes_of(deep))
+                        for (uint32_t t = t0[w] + 2; t < t0[w] + nb[w]; ++t) {
+                            const uint64_t qv = s_q[t];
+                            if (qv == e[k]) { hit = true; break; }
+                            if (qv > e[k]) break;
+                        }
+                    found |= mask_of(hit);
+                }
+                uint32_t taken = (uint32_t)__popcll(in[w]);
+                uint32_t hits = (uint32_t)__popcll(found);
+                if (__builtin_expect(taken == 64u, 0)) {                     // a longer slice (rare): keep reading, one load at a time
+                    const uint32_t rb = uniform32(s_base[i]), len = uniform32(s_base[i + 1]) - rb;
+                    uint32_t cur = uniform32(s_cur[i]) + 64u, more_n = 64u;
+                    while (more_n == 64u) {
+                        const bool have = (uint32_t)lane < len - cur;
+                        const uint64_t ev = have ? (rows + rb + cur)[lane] : ~0ull;
+                        const bool more = have && (last || ev < upper);
+                        bool h2 = false;
+                        if (more && ev <= qmax) {
+                            const uint32_t k2 = (uint32_t)(ev >> shift) - b0;
+                            for (uint32_t t = s_t[k2], te = s_t[k2 + 1]; t < te; ++t) {
+                                const uint64_t qv = s_q[t];
+                                if (qv == ev) { h2 = true; break; }
+                                if (qv > ev) break;
+                            }
+                        }
+                        more_n = (uint32_t)__popcll(mask_of(more));
+                        hits += (uint32_t)__popcll(mask_of(h2));
+                        cur += more_n;
+                        taken += more_n;
+                    }
+                }
+                if (i < n_rows) {
+                    if (lane == 0) { s_cur[i] += taken; s_hits[i] += hits; }
+                    if (!last) ask(k);                                       // the row's part of the next range, a range ahead
+                }
+            }
+        }
+        OW_MARK(tr_proc)
     }
+#ifdef SMG_OW_TRACE
+    if (blockIdx.x < 2 && lane == 0)
+        printf("wg %u wave %d: barrier1 %llu fill %llu barrier2 %llu rows %llu (cycles of s_memtime, %u ranges, %u rows)\n", blockIdx.x, wave, tr_b1, tr_fill, tr_b2, tr_proc, n_ranges, n_rows);
+#endif
     __syncthreads();
     for (uint32_t i = tid; i < n_rows; i += OW_THREADS) counts[d_lo + i] = s_hits[i];
 }
