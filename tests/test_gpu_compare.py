@@ -452,6 +452,64 @@ def test_compare_extreme_hash_values_and_both_tile_kernels():
         assert np.array_equal(np.load(dst).view(np.uint32), wc)
 
 
+def _slot_of_table_kernel(v, log_slots=12):
+    "the even slot compare.hip's pair_slot starts a hash's probe sequence on (white box: the collision cases below aim at it)"
+    x = (v & np.uint64(0xffffffff)) ^ (v >> np.uint64(32))
+    x = x ^ (x >> np.uint64(15))
+    return (x & np.uint64((1 << (log_slots - 1)) - 1)) << np.uint64(1)
+
+
+def test_compare_table_kernel_counters_and_probe_chains():
+    """The corners of the hash-table tile kernel's round (csrc/compare.hip), against the oracle's per-pair walk
+    (minhash.rs:915-953):
+    * 48 identical sketches -- every lookup finds all 16 rows, so every lane's 4-bit counters go up every round and are
+      flushed at exactly 15, many times over (2,000 hashes = 32 rounds; and 120 hashes: no flush before the last round);
+    * rows that differ in one hash each at the front / the back / the 64th and 65th place (round boundaries);
+    * hashes that all start their probe sequence on the SAME slot (chains hundreds of slots long, wrapping the table),
+      alone and mixed with ordinary ones, shared by some rows and not by others;
+    * a full tile next to a ragged one (50 rows, 37 columns' worth) so row and column padding is exercised."""
+    import torch
+    from sourmash_amd import device as smd
+    rng = np.random.default_rng(77)
+
+    def check(sk, what):
+        sk = [np.unique(np.asarray(r, dtype=np.uint64)) for r in sk]
+        wc, wj = oracle.compare_all_pairs(*oracle.make_csr(sk), nthreads=4)
+        h, off = smd.pack_csr(sk)
+        c, j = smd.compare_rows(h, off)                                    # no index: the tile kernel
+        torch.cuda.synchronize()
+        assert np.array_equal(c.cpu().numpy().view(np.uint32), wc), what
+        assert np.array_equal(j.cpu().numpy().view(np.uint64), wj.view(np.uint64)), what
+
+    base = np.unique(rng.integers(1, 2**62, 2000, dtype=np.int64).astype(np.uint64))
+    check([base] * 48, "identical, 32 rounds")
+    check([base[:120]] * 50, "identical, 2 rounds, ragged tile")
+    check([base[:960]] * 16 + [base[:961]] * 16 + [base[1:960]] * 18, "identical up to the ends, 15 rounds + 1")
+    variants = []
+    for i in range(50):
+        r = base.copy()
+        r = np.delete(r, [i, 63 + (i % 3), 1999 - i])                    # holes at the front, around the first round's end, at the back
+        if i % 5 == 0:
+            r = np.append(r, np.uint64(2**64 - 1))                       # the empty-slot key as a hash
+        if i % 7 == 0:
+            r = np.append(r, np.uint64(0))
+        variants.append(r)
+    check(variants, "one-hash differences")
+    # hashes whose probe sequences all start on one slot
+    cand = rng.integers(1, 2**63, 6_000_000, dtype=np.int64).astype(np.uint64)
+    same = np.unique(cand[_slot_of_table_kernel(cand) == np.uint64(2 * 1000)])
+    assert len(same) >= 2000
+    same = same[:2000]
+    check([same[:700]] * 20 + [same[200:1500]] * 20 + [same[::2]] * 10, "one slot: chains of hundreds of slots")
+    near_end = np.unique(cand[_slot_of_table_kernel(cand) >= np.uint64(4096 - 6)])[:1500]      # chains that wrap around the table
+    mixed = []
+    for i in range(48):
+        part = rng.choice(near_end, size=int(rng.integers(0, 1200)), replace=False)
+        rest = rng.choice(base, size=int(rng.integers(0, 1500)), replace=False)
+        mixed.append(np.concatenate([part, rest, same[: (i * 37) % 900]]))
+    check(mixed, "wrapping chains mixed with ordinary hashes")
+
+
 def _index_builder_cases():
     """Both builders of the compare index must give the oracle's matrix: the sort-free one (csrc/dictindex.hip: buckets of
     the hash space, LDS tables) and the sort it falls back to (csrc/sparse_pairs.hip).  Run in a subprocess per builder."""
