@@ -2193,9 +2193,9 @@ __global__ __launch_bounds__(OW_THREADS) void overlap_wide_kernel(const uint64_t
     // A wave owns the rows wave, wave + 16, ... of the block: OW_SLOTS of them at most, each with a register pair that holds
     // the row's next 64 hashes.  A row is visited once per range, and the load for its NEXT visit is issued right after the
     // present one (the cursor is known then), a whole range ahead: when a range starts, all of its data is in registers or
-    // on its way, and nothing in a range waits for a trip to memory that began in the same range.  (The two-stage pipeline
-    // this replaces kept 8-16 visits in flight and paid three dependent trips per range; with the barriers of a range that
-    // left it at 2.6 ms whatever the instruction count -- profiles/r03_overlap_pmc.txt.)
+    // on its way, and nothing in a range waits for a trip to memory that began in the same range.  (2.62 -> 2.44 ms against the
+    // two-stage pipeline this replaces.  What is left is each wave's own instruction stream -- ~200 instructions of all kinds
+    // per visit with four waves on a SIMD: DESIGN.md 4.4, profiles/r03_overlap_stages.txt.)
     // A visit's row is the same for all lanes: its start, length and cursor are read from LDS into SCALAR registers (one
     // broadcast read, v_readfirstlane) and the address of the 512-byte load is a scalar base plus lane * 8.
     uint64_t e[OW_SLOTS];
@@ -2430,6 +2430,13 @@ hipError_t overlap_ranges_launch(const uint64_t* Q, uint64_t nq, const uint64_t*
         }
         if (attr_state > 0 && w_widest <= (unsigned)OW_QCAP) {
             uint64_t rpw = (ndb + (uint64_t)n_cu_w - 1) / (uint64_t)n_cu_w;
+            if (rpw > (uint64_t)OW_ROWS) {
+                // more rows than one round of workgroups holds: as many rounds as that takes, all of them full (a last round
+                // of a few workgroups would cost a whole pass over the query for a fraction of the rows)
+                const uint64_t per_round = (uint64_t)OW_ROWS * (uint64_t)n_cu_w;
+                const uint64_t slots = ((ndb + per_round - 1) / per_round) * (uint64_t)n_cu_w;
+                rpw = (ndb + slots - 1) / slots;
+            }
             static const uint64_t rpw_env = [] { const char* e = getenv("SMG_OVERLAP_ROWS"); return e ? (uint64_t)atoll(e) : 0ull; }();
             if (rpw_env) rpw = rpw_env;                                        // tuning: rows a workgroup owns
             if (rpw > (uint64_t)OW_ROWS) rpw = OW_ROWS;

@@ -234,6 +234,39 @@ def _overlaps_large_query():
     assert np.array_equal(cnt.cpu().numpy(), np.maximum(want - sub, 0))
 
 
+def test_overlaps_wide_form_with_more_rows_than_one_round_of_workgroups():
+    """103,000 rows: more than 400 per CU, so the wide form's grid is cut into full rounds (gather.hip: overlap_ranges_launch);
+    and the same collection with 3 rows per workgroup (thousands of workgroups, most waves without a row).  Counts against
+    numpy's |Q ∩ row| (linear.rs:52-113 per row)."""
+    import os, subprocess, sys
+    from conftest import ROOT
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import test_gpu_gather as t\nt._overlaps_many_rows()\nprint('ok')\n" % (ROOT, os.path.join(ROOT, "tests")))
+    for extra in ({}, {"SMG_OVERLAP_ROWS": "3"}):
+        p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600,
+                           env=dict(os.environ, SMG_OVERLAP="wide", **extra))
+        assert p.returncode == 0 and p.stdout.strip().endswith("ok"), (extra, p.stdout[-1500:], p.stderr[-1500:])
+
+
+def _overlaps_many_rows():
+    import torch
+    from sourmash_amd import device as smd, parallel
+    from sourmash_amd.synth import synth_gather
+    qh, dbh = synth_gather(n_query=140_000, n_db=103_000, db_size=40)
+    dbh[5] = np.zeros(0, dtype=np.uint64)
+    dbh[102_999] = qh[500:900].copy()                             # the last row of the last workgroup: a long slice
+    be = parallel.DeviceBackend()
+    h, off = smd.pack_csr(dbh)
+    q = torch.from_numpy(qh.view(np.int64).copy()).cuda()
+    cnt = be.zeros((len(dbh),), torch.int64)
+    be.overlaps(q, len(qh), h, off, len(dbh), cnt, 0)
+    flat = np.concatenate(dbh)
+    ends = np.cumsum([len(d) for d in dbh])
+    hits = np.concatenate([[0], np.cumsum(np.isin(flat, qh).astype(np.int64))])
+    want = hits[ends] - hits[np.concatenate([[0], ends[:-1]])]
+    assert np.array_equal(cnt.cpu().numpy(), want)
+
+
 def test_gather_random_shapes_every_builder(monkeypatch):
     """Random query / database shapes -- one row, empty rows, rows outside the query, duplicates of the winner, hash ranges
     from a few hundred values to all 64 bits, queries shorter than one range and a few ranges long -- through both builders
