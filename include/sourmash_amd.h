@@ -424,6 +424,9 @@ void smgpu_arena_trim(uint64_t keep_bytes);     /* give cached blocks back to th
  * Replaces the single zlib stream behind screed / niffler (src/sourmash/command_sketch.py:697, src/core/benches/compute.rs:35-38). */
 uint64_t smgpu_gunzip_file(const char *path, uint32_t threads, uint64_t span_bytes, uint8_t *out, uint64_t cap, uint32_t *crc32_out,
                            bool *parallel_used);
+/* The 15-bit code the reader's marker bytes carry for window position `p` (an involution on 0..32767): the 128 codes whose two
+ * marker bytes coincide -- and so read like a data byte >= 0x80 -- belong to positions 0..127 (tests/test_pargz_cpu.py). */
+uint32_t smgpu_gunzip_position_code(uint32_t p);
 void smgpu_gather_counters_get(const SmgpuGather *ptr, uint64_t *counts_out, void *stream);
 void smgpu_gather_begin(SmgpuGather *ptr, uint64_t threshold_hashes, uint64_t max_rounds, void *stream);
 uint64_t smgpu_gather_run(SmgpuGather *ptr, uint64_t *out_index, uint64_t *out_isect, uint64_t cap, void *stream);

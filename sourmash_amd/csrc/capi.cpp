@@ -1566,6 +1566,7 @@ uint64_t smgpu_gunzip_file(const char* path, uint32_t threads, uint64_t span_byt
         }
     });
 }
+uint32_t smgpu_gunzip_position_code(uint32_t p) { return ParallelGunzip::position_code(p & 32767u); }
 void smgpu_gather_counters_get(const SmgpuGather* p, uint64_t* out, void* stream) {
     landing_void([&] {
         const GatherDev& g = reinterpret_cast<const GatherRaw*>(p)->g;

@@ -198,14 +198,30 @@ class DeviceCtx {
     void forget(const KmerMinHash& m) {
         if (m.mirrored_gen) drop_mirror(mirrors_.find(m.mirrored_gen));
     }
+    // Copies share a content generation (a clone of a mirrored sketch finds the same mirror), so the "stale" mirror one operand
+    // lets go of can be the very block the other operand of the same call was just handed: its blocks are then parked until the
+    // call's kernels are on the stream (a block freed and re-allocated on one stream would be overwritten by the second upload
+    // in front of the launch).  `hold_gen_` is the generation the call in progress already holds pointers of.
     void drop_mirror(std::unordered_map<uint64_t, Mirror>::iterator it) {
         if (it == mirrors_.end()) return;
         Mirror& mr = it->second;
-        if (mr.mins) { arena_free(mr.mins, stream_); mirror_bytes_ -= mr.n * 8; }
-        if (mr.abunds) { arena_free(mr.abunds, stream_); mirror_bytes_ -= mr.n * 8; }
+        const bool park = hold_gen_ != 0 && it->first == hold_gen_;
+        if (mr.mins) { if (park) parked_.push_back(mr.mins); else arena_free(mr.mins, stream_); mirror_bytes_ -= mr.n * 8; }
+        if (mr.abunds) { if (park) parked_.push_back(mr.abunds); else arena_free(mr.abunds, stream_); mirror_bytes_ -= mr.n * 8; }
         lru_.erase(mr.lru);
         mirrors_.erase(it);
     }
+    // the previous call's kernels are on the stream: what it parked can go back to the arena (stream-ordered reuse)
+    void release_parked() {
+        for (void* p : parked_) arena_free(p, stream_);
+        parked_.clear();
+        hold_gen_ = 0;
+    }
+    struct HoldScope {                      // a pair call: parked blocks of the call before go first, the hold ends with the call
+        DeviceCtx& c;
+        explicit HoldScope(DeviceCtx& ctx) : c(ctx) { c.release_parked(); }
+        ~HoldScope() { c.hold_gen_ = 0; }
+    };
 
     // |a ∩ b| through the one-launch kernel with the result polled from a pinned slot; false: not applicable here
     bool pair_count_fast(const KmerMinHash& a, const KmerMinHash& b, uint64_t* common) {
@@ -217,7 +233,9 @@ class DeviceCtx {
             if (hipHostMalloc((void**)&slot_, 256, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); slot_ = nullptr; return false; }
             slot_[0] = slot_[1] = 0;
         }
+        HoldScope hold(*this);
         const uint64_t* dA = mirror_of(A, false).mins;
+        hold_gen_ = A.gen;                                             // B may share, or have shared, A's generation
         const uint64_t* dB = mirror_of(B, false).mins;
         const unsigned long long seq = ++slot_seq_;
         volatile unsigned long long* vs = slot_;
@@ -250,9 +268,11 @@ class DeviceCtx {
         const bool ab = want_abund && a.track_abundance && b.track_abundance;
         // the sketches come from their device mirrors (uploaded on first use, kept until the sketch changes); scratch: [I list]
         pair_.reserve((na + 16) * 8);
+        HoldScope hold(*this);
         Mirror& mA = mirror_of(A, ab);
         const uint64_t* dA = mA.mins;
         const uint64_t* dAa = mA.abunds;
+        hold_gen_ = A.gen;                                             // B may share, or have shared, A's generation: A's blocks stay
         Mirror& mB = mirror_of(B, ab);                                 // (never evicts A: A was just used)
         const uint64_t* dB = mB.mins;
         const uint64_t* dBa = mB.abunds;
@@ -430,6 +450,8 @@ class DeviceCtx {
     std::unordered_map<uint64_t, Mirror> mirrors_;
     std::list<uint64_t> lru_;
     size_t mirror_bytes_ = 0;
+    uint64_t hold_gen_ = 0;
+    std::vector<void*> parked_;
     unsigned long long* slot_ = nullptr;       // pinned host memory the one-launch pair kernel publishes into
     unsigned long long slot_seq_ = 0;
     std::recursive_mutex mu_;

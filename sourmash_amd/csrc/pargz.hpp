@@ -9,7 +9,12 @@
 //     is inflated (zlib, raw mode, inflatePrime for the bit offset) against a preset dictionary whose bytes all have the top
 //     bit set and encode bits 8..14 of their own position -- FASTA / FASTQ text has no byte >= 0x80, so exactly the output
 //     bytes copied (directly or through later copies) out of the unknown window come out >= 0x80 -- and once more, as far
-//     as such bytes reach, against a dictionary encoding bits 0..7: together the window position each of them stands for;
+//     as such bytes reach, against a dictionary encoding bits 0..7: together the window position each of them stands for.
+//     A DATA byte >= 0x80 (a UTF-8 header, a binary file) reads the same in both passes, and so do the markers of 128 window
+//     positions (one per value of the high bits); the position code is permuted so that these are the OLDEST 128 bytes of the
+//     window -- distances zlib-family encoders never emit (MAX_DIST = 32768 - 262) -- and a span that does hold such a byte
+//     is inflated a third time against an all-zero dictionary, where a marker reads 0 and a data byte reads itself: a span
+//     with a data byte >= 0x80 is refused BEFORE any of it is delivered, and the reader falls back;
 //   * when the span in front is finished, its last 32 KB are the window and the marked bytes are filled in.
 // Every span must end exactly on the bit where the next one begins (zlib's Z_BLOCK reports block ends), and the member's
 // CRC-32 and length (gzip trailer) are checked over the assembled output: an input that is not pure 7-bit text, a
@@ -209,9 +214,9 @@ class ParallelGunzip {
     ~ParallelGunzip() {
         stop_workers();
         if (parallel_ && getenv("SMG_GUNZIP_TRACE"))
-            fprintf(stderr, "[gunzip] %s: %u threads, %llu spans; worker ms: block search %.0f, first pass %.0f, second pass %.0f, waiting for "
+            fprintf(stderr, "[gunzip] %s: %u threads, %llu spans; worker ms: block search %.0f, first pass %.0f, second pass %.0f, third pass %.0f, waiting for "
                             "the span in front %.0f, crc %.0f; consumer ms: waiting %.0f, copying %.0f\n", path_.c_str(), n_threads_,
-                    (unsigned long long)n_spans_, t_search_ * 1e-6, t_pass1_ * 1e-6, t_pass2_ * 1e-6, t_wait_tail_ * 1e-6, t_crc_ * 1e-6,
+                    (unsigned long long)n_spans_, t_search_ * 1e-6, t_pass1_ * 1e-6, t_pass2_ * 1e-6, t_pass3_ * 1e-6, t_wait_tail_ * 1e-6, t_crc_ * 1e-6,
                     t_consumer_wait_ * 1e-6, t_copy_ * 1e-6);
         for (Span* c : spans_) delete c;
         for (Span* c : free_spans_) delete c;
@@ -307,13 +312,18 @@ class ParallelGunzip {
     }
     size_t read_sequential(uint8_t* dst, size_t want) {
         if (!gzf_) open_sequential();
-        if (seq_skip_) {                                             // bytes the parallel form already delivered
-            std::vector<uint8_t> tmp(1 << 20);
+        if (seq_skip_) {                                             // bytes the parallel form already delivered: read past them,
+            std::vector<uint8_t> tmp(1 << 20);                       // and make sure they ARE what was delivered
+            uint32_t crc = 0;
             while (seq_skip_) {
                 const int r = gzread(gzf_, tmp.data(), (unsigned)std::min<uint64_t>(tmp.size(), seq_skip_));
                 if (r <= 0) throw std::runtime_error("error while reading sequence file " + path_);
+                crc = (uint32_t)crc32_z(crc, tmp.data(), (size_t)r);
                 seq_skip_ -= (uint64_t)r;
             }
+            if (crc != crc_)
+                throw std::runtime_error("gzip reader: the bytes already delivered from " + path_ + " differ from the sequential stream "
+                                         "(set SMG_GUNZIP_SEQUENTIAL=1)");
         }
         size_t got = 0;
         while (got < want) {
@@ -373,11 +383,25 @@ class ParallelGunzip {
     void static_dicts() {
         dict_hi_.resize(pargz_detail::WIN);
         dict_lo_.resize(pargz_detail::WIN);
+        dict_zero_.assign(pargz_detail::WIN, 0);
         for (uint32_t i = 0; i < pargz_detail::WIN; ++i) {
-            dict_hi_[i] = (uint8_t)(0x80u | (i >> 8));               // top bit: "from the unknown window"; bits 8..14 of the position
-            dict_lo_[i] = (uint8_t)(i & 0xffu);
+            const uint32_t c = position_code(i);
+            dict_hi_[i] = (uint8_t)(0x80u | (c >> 8));               // top bit: "from the unknown window"; bits 8..14 of the code
+            dict_lo_[i] = (uint8_t)(c & 0xffu);
         }
     }
+    // Window position <-> 15-bit code (an involution).  The two marker bytes of code c are 0x80 | c >> 8 and c & 0xff; they are
+    // EQUAL -- like the two readings of a data byte >= 0x80 -- for the 128 codes h << 8 | 0x80 | h.  Those codes go to window
+    // positions 0..127, the oldest bytes of the window, which only a match at the very start of a span with a distance above
+    // 32,640 can reach (zlib, pigz, bgzip never look back further than 32,506); every other position keeps its own number.
+  public:
+    static uint32_t position_code(uint32_t p) {
+        if (p < 128u) return (p << 8) | 0x80u | p;
+        const uint32_t h = p >> 8;
+        if ((p & 0xffu) == (0x80u | h)) return h;
+        return p;
+    }
+  private:
 
     // first confirmed block start at or after `bit` (searching at most `limit_bits` further); UINT64_MAX if none
     uint64_t find_block(uint64_t bit, uint64_t limit_bits) {
@@ -526,6 +550,35 @@ class ParallelGunzip {
                 }
                 if (got < last) { s.why = "second pass came up short"; return; }
                 t_pass2_ += now_ns() - t2;
+                // A byte that reads the same (>= 0x80) in both passes is either a data byte of the file or the marker of one
+                // of the 128 oldest window positions: a third pass against zeros tells them apart (marker -> 0, data -> itself).
+                size_t amb_end = 0;
+                for (size_t i = last; i > 0; --i)
+                    if ((o[i - 1] & 0x80u) && s.lowbits[i - 1] == o[i - 1]) { amb_end = i; break; }
+                if (amb_end) {
+                    const uint64_t t3 = now_ns();
+                    RawInflate r3;
+                    if (!r3.open(deflate_, deflate_len_, s.start_bit, dict_zero_.data())) { s.why = "inflate init"; return; }
+                    std::vector<uint8_t> plain(amb_end);
+                    size_t got3 = 0;
+                    while (got3 < amb_end) {
+                        r3.zs.next_out = plain.data() + got3;
+                        r3.zs.avail_out = (uInt)std::min<size_t>(amb_end - got3, 1u << 30);
+                        r3.feed();
+                        const size_t before = r3.zs.avail_out;
+                        const int rc = inflate(&r3.zs, Z_NO_FLUSH);
+                        got3 += before - r3.zs.avail_out;
+                        if (rc == Z_STREAM_END) break;
+                        if (rc != Z_OK && !(rc == Z_BUF_ERROR && r3.zs.avail_out == 0)) { s.why = "third pass failed"; return; }
+                    }
+                    if (got3 < amb_end) { s.why = "third pass came up short"; return; }
+                    for (size_t i = 0; i < amb_end; ++i)
+                        if ((o[i] & 0x80u) && s.lowbits[i] == o[i] && plain[i] != 0) {
+                            s.why = "the file holds bytes >= 0x80 (not 7-bit text)";
+                            return;
+                        }
+                    t_pass3_ += now_ns() - t3;
+                }
             }
         }
         s.ok = true;
@@ -537,7 +590,7 @@ class ParallelGunzip {
         if (to > (size_t)s.marked_until) to = (size_t)s.marked_until;
         for (size_t i = from; i < to; ++i)
             if (o[i] & 0x80u) {
-                const uint32_t pos = ((uint32_t)(o[i] & 0x7fu) << 8) | s.lowbits[i];
+                const uint32_t pos = position_code(((uint32_t)(o[i] & 0x7fu) << 8) | s.lowbits[i]);
                 o[i] = window[pos];
             }
     }
@@ -725,7 +778,7 @@ class ParallelGunzip {
     uint32_t want_crc_ = 0, want_isize_ = 0, crc_ = 0;
     uint64_t total_out_ = 0, seq_skip_ = 0;
     gzFile gzf_ = nullptr;
-    std::vector<uint8_t> dict_hi_, dict_lo_, window_;
+    std::vector<uint8_t> dict_hi_, dict_lo_, dict_zero_, window_;
     uint64_t n_spans_ = 0, next_span_ = 0, deliver_ = 0, prev_end_bit_ = 0;
     unsigned in_flight_ = 0, in_flight_max_ = 4;
     std::vector<Span*> spans_, free_spans_;
@@ -737,7 +790,7 @@ class ParallelGunzip {
     std::vector<uint64_t> bounds_;
     std::vector<uint8_t> bstate_;               // 0 unknown, 1 being searched, 2 known
     std::atomic<bool> abort_{false}, failed_{false};
-    std::atomic<uint64_t> t_search_{0}, t_pass1_{0}, t_scan_{0}, t_pass2_{0}, t_wait_tail_{0}, t_crc_{0}, t_consumer_wait_{0}, t_copy_{0};
+    std::atomic<uint64_t> t_search_{0}, t_pass1_{0}, t_scan_{0}, t_pass2_{0}, t_pass3_{0}, t_wait_tail_{0}, t_crc_{0}, t_consumer_wait_{0}, t_copy_{0};
     static uint64_t now_ns() {
         return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
     }

@@ -607,3 +607,42 @@ def test_device_mirrors_follow_every_mutation(sm):
     many = [fresh(slice(i * 37, i * 37 + 500)) for i in range(40)]
     for i in range(0, 40, 3):
         check(many[i], many[(i * 7 + 1) % 40])
+
+
+def test_native_copies_share_a_generation_without_sharing_a_fate(sm):
+    """Copies made inside the library (signature_set_mh / signature_first_mh copy-construct, so the copy keeps the
+    original's content generation and finds its device mirror) must not lose that mirror to the ORIGINAL's next change in
+    the middle of a call: f = sig.minhash; mh changes; f.count_common(mh) first takes f's (shared) mirror, then sees mh let go
+    of that very generation (device_ctx.hpp: drop_mirror parks the blocks until the call's kernels are on the stream).
+    Counts against the oracle's walk (minhash.rs:539-558)."""
+    import numpy as np
+    import oracle
+    rng = np.random.default_rng(99)
+    universe = rng.integers(1, 2**50, size=12_000, dtype=np.uint64)
+
+    def want(a, b):
+        ha, hb = np.array(sorted(a.hashes), dtype=np.uint64), np.array(sorted(b.hashes), dtype=np.uint64)
+        return oracle.intersection_size(ha, hb)[0]
+
+    for with_abund in (False, True):
+        mh = sm.MinHash(0, 31, scaled=1, track_abundance=with_abund)
+        mh.add_many([int(x) for x in universe[:5000]])
+        other = sm.MinHash(0, 31, scaled=1, track_abundance=with_abund)
+        other.add_many([int(x) for x in universe[2500:7000]])
+        assert mh.count_common(other) == want(mh, other)           # mh is mirrored now
+        sig = sm.SourmashSignature(mh)
+        f = sig.minhash                                            # native copy: same generation as mh
+        mh.remove_many([int(x) for x in universe[:2000]])          # mh is no superset of f any more ...
+        mh.add_many([int(x) for x in universe[8000:9000]])         # ... and not a subset either
+        c = want(f, mh)
+        assert c == 3000
+        assert f.count_common(mh) == c                             # f's mirror first, then mh drops "its" old generation
+        assert mh.count_common(f) == c
+        g = sig.minhash
+        mh.add_many([int(x) for x in universe[9000:9100]])
+        assert g.jaccard(mh) == c / (len(g) + len(mh) - c)
+        if with_abund:
+            h = sig.minhash
+            mh.add_many([int(x) for x in universe[9100:9200]])
+            assert h.angular_similarity(mh) == mh.angular_similarity(h)
+            assert len(h.intersection(mh)) == c if hasattr(h, "intersection") else True

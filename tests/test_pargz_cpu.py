@@ -106,11 +106,48 @@ def test_input_that_is_not_7_bit_text_is_still_right(tmp_path):
         with gzip.open(p, "wb", compresslevel=6) as f:
             f.write(data)
         n, out, crc, par, code = _gunzip(p, span=128 << 10)
-        if code == 0:
-            assert out == data and not par, name           # the reader noticed and fell back to the plain stream in time
-        else:
-            assert name == "late"                           # marked bytes and data bytes cannot be told apart deep inside a span:
-                                                            # the member's CRC-32 catches it and the call FAILS (never wrong bytes quietly)
+        # the reader notices BEFORE it delivers the span that holds such a byte (a data byte >= 0x80 reads alike in both marker
+        # passes; the third pass against zeros tells it from a marker) and carries on with the plain stream: never an error,
+        # never other bytes -- the reference reads such files through one zlib stream without complaint
+        assert code == 0 and out == data and not par and crc == zlib.crc32(data), name
+
+
+def test_utf8_in_a_late_header_followed_by_stored_blocks(tmp_path):
+    """text, two UTF-8 bytes three megabytes in, text, 900 KB of stored blocks (no block start to be found there),
+    text.  Round 3 delivered 'caf' + the window's bytes for the two data bytes, met the structural fallback afterwards and
+    skipped the delivered prefix unchecked: return code 0 and wrong bytes.  Now the span with the data bytes is refused before
+    delivery and a skipped prefix is CRC-checked against what was delivered."""
+    rng = np.random.default_rng(21)
+    text = _fasta(3_000_000, 31)
+    co = zlib.compressobj(6, zlib.DEFLATED, 31)
+    raw = co.compress(text + b">caf" + bytes([0xC3, 0xA9]) + b" strain\n" + _fasta(1_500_000, 32))
+    raw += co.flush(zlib.Z_FULL_FLUSH)
+    noise = bytes(rng.integers(0, 128, 900_000, dtype=np.uint8))        # incompressible 7-bit bytes: zlib stores them
+    raw += co.compress(noise)
+    raw += co.flush(zlib.Z_FULL_FLUSH)
+    tail = _fasta(2_000_000, 33)
+    raw += co.compress(tail) + co.flush()
+    data = gzip.decompress(raw)
+    assert bytes([0xC3, 0xA9]) in data
+    p = tmp_path / "cafe.gz"
+    p.write_bytes(raw)
+    for threads, span in ((8, 128 << 10), (4, 300 << 10), (8, 1 << 20)):
+        if os.path.getsize(p) < 4 * span:
+            continue
+        n, out, crc, par, code = _gunzip(p, threads=threads, span=span)
+        assert code == 0 and n == len(data) and out == data and crc == zlib.crc32(data), (threads, span)
+        assert not par
+
+
+def test_position_code_keeps_the_ambiguous_markers_out_of_reach():
+    """The two marker bytes of a window position are 0x80 | code >> 8 and code & 0xff.  They coincide for 128 codes; the code is
+    an involution on 0..32767 that hands exactly those codes to window positions 0..127 -- further back than zlib-family
+    encoders ever reach (32768 - 262) -- so that text files never need the third pass."""
+    codes = [lib.smgpu_gunzip_position_code(p) for p in range(32768)]
+    assert sorted(codes) == list(range(32768))
+    assert all(codes[codes[p]] == p for p in range(32768))
+    ambiguous = [p for p in range(32768) if (0x80 | (codes[p] >> 8)) == (codes[p] & 0xff)]
+    assert ambiguous == list(range(128))
 
 
 def test_corrupt_and_truncated_files_fail(tmp_path):
