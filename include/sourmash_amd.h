@@ -410,8 +410,10 @@ uint64_t smgpu_gather_postings(const SmgpuGather *ptr);
  * (waits for the build's kernels): out[0] build kernel span in ms (HIP events on the build's stream), out[1] build host
  * wall clock ms (the smgpu_gather_new_raw call), out[2] ms inside the driver's allocator during the build (0 once the
  * arena is warm), out[3] driver allocations made, out[4] host synchronisations of the build, out[5] ms the host waited in
- * them, out[6] GPU span in ms of the last run's rounds (events around the loop), out[7] host wall clock ms of that run. */
-void smgpu_gather_stats(SmgpuGather *ptr, double *out8);
+ * them, out[6] GPU span in ms of the last run's rounds (events around the loop), out[7] host wall clock ms of that run,
+ * out[8] times the resident loop kernel gave up because its grid was not resident as a whole (another kernel or process held
+ * CUs) and the two-kernel rounds / the record protocol took over from the untouched state. */
+void smgpu_gather_stats(SmgpuGather *ptr, double *out9);
 /* The library's device arena (csrc/arena.hpp): every index / scratch block comes from it and is cached on release.
  * out[0] driver allocations, out[1] driver frees, out[2] ns inside the driver, out[3] reuse hits, out[4] live bytes,
  * out[5] cached bytes, out[6] peak bytes held, out[7] reuses that waited on another stream's event. */
@@ -448,6 +450,9 @@ bool smgpu_gather_loop_eligible(const SmgpuGather *ptr, uint32_t n_wg);
  *  the device while a loop that already runs waits for its peers) */
 void smgpu_gather_loop_reserve(SmgpuGather *ptr, uint32_t n_wg, uint64_t rowcap, void *stream);
 bool smgpu_gather_launch_shared(SmgpuGather *ptr, SmgpuGatherXchg *xchg, uint32_t rank, uint32_t run_id, uint32_t n_wg, void *stream);
+/* Test support: `n_wg` workgroups that keep `lds_bytes` of LDS each and spin for `micros` microseconds on `stream` -- "somebody
+ * else's kernel holds CUs of this device" (the resident gather loop must step aside for the two-kernel rounds, not fail). */
+void smgpu_debug_hold_cus(uint32_t n_wg, uint32_t lds_bytes, uint64_t micros, void *stream);
 uint64_t smgpu_gather_longest_row(const SmgpuGather *ptr);   /* hashes in the shard's longest row: stride >= 3 + the longest row of any shard */
 void smgpu_gather_topk_export_raw(SmgpuGather *ptr, uint64_t *d_records, uint32_t k, uint64_t stride, void *stream);
 void smgpu_gather_cands_load_raw(SmgpuGather *ptr, const uint64_t *d_records, uint32_t n_records, uint64_t stride,

@@ -1095,19 +1095,14 @@ struct SketchSet {
     std::vector<ManifestRow> rows;
     uint32_t ksize = 0, hash_function = HF_DNA;
     uint64_t seed = 42, max_hash = 0, num = 0, skipped = 0;
-    ~SketchSet() { if (hashes.p) (void)hipFree(hashes.p); if (offsets.p) (void)hipFree(offsets.p); }
+    // (the device blocks are arena blocks and go back to the arena with the DevBufs: no hipFree, which would synchronise the device)
 };
 struct GatherCounter {
     const SketchSet* set = nullptr;
     DevBuf q, list, scal;
     uint64_t nq = 0;
     GatherDev g;
-    ~GatherCounter() {
-        gather_destroy(g);
-        if (q.p) (void)hipFree(q.p);
-        if (list.p) (void)hipFree(list.p);
-        if (scal.p) (void)hipFree(scal.p);
-    }
+    ~GatherCounter() { gather_destroy(g); }          // (q / list / scal: arena blocks, released by their DevBufs)
 };
 // raw variant: query and database are caller-owned device buffers (torch tensors)
 struct GatherRaw {
@@ -1128,6 +1123,8 @@ static bool gather_use_replay() {
     }();
     return mode == 1;
 }
+// persistent-loop exit codes after which the state is that of a whole number of rounds (gather.hip: the gate, the sweeps)
+static bool gather_loop_gave_up_cleanly(unsigned long long code) { return code >= 10 && code <= 14; }
 static uint64_t gather_drain(GatherDev& g, uint64_t* out_idx, uint64_t* out_isect, uint64_t cap, hipStream_t st) {
     unsigned long long head[GS_SLOTS];
     const bool replay = gather_use_replay() && g.ndb > 0 && g.nq > 0;
@@ -1152,8 +1149,20 @@ static uint64_t gather_drain(GatherDev& g, uint64_t* out_idx, uint64_t* out_isec
         hip_check(hipMemcpyAsync(g.pinned + 16, g.state, sizeof(head), hipMemcpyDeviceToHost, st), "D2H");
         hip_check(hipStreamSynchronize(st), "sync");
         memcpy(head, g.pinned + 16, sizeof(head));
-        if (head[GS_ERR]) throw err_internal("gather loop: a workgroup waited too long for its peers (the device was shared?)");
-        if (trace)
+        if (head[GS_ERR]) {
+            // The grid did not become resident as a whole (another kernel or another process holds CUs): the kernel gave up at
+            // its gate with nothing touched (code 10), or between two rounds with the state of `GS_ROUNDS` whole rounds (11).
+            // Either way the two-kernel rounds below carry on from exactly that state -- a library inside somebody's process
+            // cannot ask for an idle device.  Anything else (a staged row that never arrived: 2-4) is an error.
+            if (!gather_loop_gave_up_cleanly(head[GS_ERR]))
+                throw err_internal("gather loop failed (code " + std::to_string(head[GS_ERR]) + ", epoch " + std::to_string(head[13]) + ")");
+            if (trace)
+                fprintf(stderr, "[gather] persistent loop gave up (code %llu, workgroup %llu) after %llu rounds, %.1f us: two-kernel rounds take over\n",
+                        head[GS_ERR], head[14], head[GS_ROUNDS], std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_all).count());
+            hip_check(hipMemsetAsync(g.state + GS_ERR, 0, 8, st), "memset");
+            g.loop_fallbacks++;
+            persistent = false;
+        } else if (trace)
             fprintf(stderr, "[gather] persistent loop: %llu rounds, %.1f us\n", head[GS_ROUNDS],
                     std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_all).count());
     }
@@ -1207,9 +1216,9 @@ SmgpuSketchSet* smgpu_sketchset_new(const SourmashKmerMinHash* const* mhs, uintp
         std::vector<uint64_t> off(n + 1, 0);
         for (uintptr_t i = 0; i < n; ++i) off[i + 1] = off[i] + MH(mhs[i])->size();
         s->n = n; s->total = off[n];
-        s->hashes.reserve(s->total * 8 + 16);
-        s->offsets.reserve((n + 1) * 8);
         hipStream_t st = ctx.stream();
+        s->hashes.reserve(s->total * 8 + 16, st);
+        s->offsets.reserve((n + 1) * 8, st);
         // stage through one host vector: one large H2D copy instead of n small ones
         std::vector<uint64_t> flat(s->total);
         for (uintptr_t i = 0; i < n; ++i)
@@ -1264,8 +1273,8 @@ static SketchSet* upload_collection(LoadedCollection&& col) {
     std::unique_ptr<SketchSet> s(new SketchSet());
     s->n = col.rows.size();
     s->total = col.hashes.size();
-    s->hashes.reserve(s->total * 8 + 16);
-    s->offsets.reserve((s->n + 1) * 8);
+    s->hashes.reserve(s->total * 8 + 16, st);
+    s->offsets.reserve((s->n + 1) * 8, st);
     if (s->total) hip_check(hipMemcpyAsync(s->hashes.p, col.hashes.data(), s->total * 8, hipMemcpyHostToDevice, st), "H2D");
     hip_check(hipMemcpyAsync(s->offsets.p, col.offsets.data(), (s->n + 1) * 8, hipMemcpyHostToDevice, st), "H2D");
     hip_check(hipStreamSynchronize(st), "sync");
@@ -1309,16 +1318,15 @@ SmgpuSketchSet* smgpu_sketchset_subset(const SmgpuSketchSet* p, const uint64_t* 
         DeviceCtx& ctx = DeviceCtx::get();
         std::lock_guard<std::recursive_mutex> g(ctx.mutex());
         hipStream_t st = ctx.stream();
-        out->hashes.reserve((out->total + 1) * 8);
-        out->offsets.reserve((n + 1) * 8);
-        DevBuf d_rows;
-        d_rows.reserve((n + 1) * 8);
+        out->hashes.reserve((out->total + 1) * 8, st);
+        out->offsets.reserve((n + 1) * 8, st);
+        DevBuf d_rows;                                              // (an arena block: released on the stream, no device-wide synchronisation)
+        d_rows.reserve((n + 1) * 8, st);
         hip_check(hipMemcpyAsync(out->offsets.p, out->host_offsets.data(), (n + 1) * 8, hipMemcpyHostToDevice, st), "H2D");
         if (n) hip_check(hipMemcpyAsync(d_rows.p, rows, n * 8, hipMemcpyHostToDevice, st), "H2D");
         hip_check(copy_rows_launch(s->hashes.as<uint64_t>(), s->offsets.as<uint64_t>(), d_rows.as<uint64_t>(), n,
                                    out->offsets.as<uint64_t>(), out->hashes.as<uint64_t>(), st), "copy_rows");
         hip_check(hipStreamSynchronize(st), "sync");
-        if (d_rows.p) (void)hipFree(d_rows.p);
         return reinterpret_cast<SmgpuSketchSet*>(out.release());
     });
 }
@@ -1412,8 +1420,8 @@ SmgpuCounter* smgpu_counter_new(const SmgpuSketchSet* set, const SourmashKmerMin
         std::unique_ptr<GatherCounter> c(new GatherCounter());
         c->set = s;
         c->nq = MH(query)->size();
-        c->q.reserve(c->nq * 8 + 16);
-        c->scal.reserve(64);
+        c->q.reserve(c->nq * 8 + 16, st);
+        c->scal.reserve(64, st);
         if (c->nq) hip_check(hipMemcpyAsync(c->q.p, MH(query)->mins.data(), c->nq * 8, hipMemcpyHostToDevice, st), "H2D");
         c->g.Q = c->q.as<uint64_t>();
         c->g.nq = c->nq;
@@ -1473,7 +1481,7 @@ void smgpu_counter_consume(SmgpuCounter* p, const SourmashKmerMinHash* intersect
         DeviceCtx& ctx = DeviceCtx::get();
         std::lock_guard<std::recursive_mutex> g(ctx.mutex());
         hipStream_t st = ctx.stream();
-        c->list.reserve((ni + 1) * 8 + 16);
+        c->list.reserve((ni + 1) * 8 + 16, st);
         uint64_t* d_list = c->list.as<uint64_t>();
         hip_check(hipMemcpyAsync(d_list, &ni, 8, hipMemcpyHostToDevice, st), "H2D");
         hip_check(hipMemcpyAsync(d_list + 1, MH(intersect)->mins.data(), ni * 8, hipMemcpyHostToDevice, st), "H2D");
@@ -1535,6 +1543,7 @@ void smgpu_gather_stats(SmgpuGather* p, double* out) {
         out[5] = g.build_sync_wait_ns * 1e-6;
         out[6] = g.loop_gpu_ms;
         out[7] = g.loop_host_ns * 1e-6;
+        out[8] = (double)g.loop_fallbacks;
     });
 }
 void smgpu_arena_stats(uint64_t* out) {
@@ -1657,6 +1666,9 @@ bool smgpu_gather_launch_shared(SmgpuGather* p, SmgpuGatherXchg* xp, uint32_t ra
         return ran;
     });
 }
+void smgpu_debug_hold_cus(uint32_t n_wg, uint32_t lds_bytes, uint64_t micros, void* stream) {
+    landing_void([&] { hip_check(debug_hold_cus(n_wg, lds_bytes, micros, (hipStream_t)stream), "hold CUs"); });
+}
 uint64_t smgpu_gather_longest_row(const SmgpuGather* p) { return reinterpret_cast<const GatherRaw*>(p)->g.longest_row; }
 void smgpu_gather_topk_export_raw(SmgpuGather* p, uint64_t* d_records, uint32_t k, uint64_t stride, void* stream) {
     landing_void([&] {
@@ -1691,8 +1703,14 @@ uint64_t smgpu_gather_results(SmgpuGather* p, uint64_t* out_index, uint64_t* out
         unsigned long long head[GS_SLOTS];
         hip_check(hipMemcpyAsync(head, g.state, sizeof(head), hipMemcpyDeviceToHost, st), "D2H");
         hip_check(hipStreamSynchronize(st), "sync");
-        if (head[GS_ERR]) throw err_internal("gather loop: a workgroup or rank waited too long for its peers (code " + std::to_string(head[GS_ERR]) + ", epoch " +
-                                             std::to_string(head[13]) + ", workgroup " + std::to_string(head[14]) + ")");
+        if (head[GS_ERR]) {
+            // codes 10-14: the loop gave up between two rounds (at its gate, or waiting for a workgroup or a rank) and the index is
+            // intact -- the caller agrees with its peers on what to do next (parallel.gather_distributed: the record protocol)
+            const unsigned long long code = head[GS_ERR];
+            if (gather_loop_gave_up_cleanly(code)) { hip_check(hipMemsetAsync(g.state + GS_ERR, 0, 8, st), "memset"); g.loop_fallbacks++; }
+            throw err_internal("gather loop: a workgroup or rank waited too long for its peers (code " + std::to_string(code) + ", epoch " +
+                               std::to_string(head[13]) + ", workgroup " + std::to_string(head[14]) + ")");
+        }
         const uint64_t n = head[GS_ROUNDS], m = n < cap ? n : cap;
         if (m) {
             hip_check(hipMemcpyAsync(out_index, g.out_idx, m * 8, hipMemcpyDeviceToHost, st), "D2H");

@@ -29,16 +29,29 @@ inline void hip_check(hipError_t e, const char* what) {
         throw err_internal(std::string("HIP failure in ") + what + ": " + hipGetErrorString(e));
 }
 
+// Grow-only device buffer.  Its block comes from the library's arena (arena.hpp) like every other device block of the library
+// and goes back there -- never straight to the driver: hipFree synchronises the whole device, and a synchronisation while a
+// resident gather loop of another object (or rank) is polling for its peers stalls that loop or deadlocks with it.
+// `stream`: the stream the buffer's work is enqueued on (the arena orders reuse across streams by events).
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
-    void reserve(size_t bytes) {
+    hipStream_t st = nullptr;
+    DevBuf() = default;
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    ~DevBuf() { release(); }
+    void reserve(size_t bytes, hipStream_t stream) {
         if (bytes <= cap) return;
-        if (p) hip_check(hipFree(p), "hipFree");
-        p = nullptr; cap = 0;
+        release();
         size_t want = bytes + bytes / 4 + 4096;
-        hip_check(hipMalloc(&p, want), "hipMalloc");
+        hip_check(arena_alloc(&p, want, stream), "arena_alloc");
         cap = want;
+        st = stream;
+    }
+    void release() {
+        if (p) arena_free(p, st);
+        p = nullptr; cap = 0;
     }
     template <class T> T* as() const { return static_cast<T*>(p); }
 };
@@ -84,7 +97,7 @@ class DeviceCtx {
                                    std::string(e == hipSuccess ? "0 devices" : hipGetErrorString(e)) + ")");
             ctx = new DeviceCtx();
             hip_check(hipStreamCreate(&ctx->stream_), "hipStreamCreate");
-            ctx->scalars_.reserve(256);
+            ctx->scalars_.reserve(256, ctx->stream_);
         }
         return *ctx;
     }
@@ -123,7 +136,7 @@ class DeviceCtx {
         if (len < k || k == 0) return;
         const size_t nk = len - k + 1;
         upload_seq(seq, len);
-        out_.reserve(nk * 8);
+        out_.reserve(nk * 8, stream_);
         hip_check(hipMemsetAsync(out_.p, 0, nk * 8, stream_), "memset");
         hip_check(kmer_hashes_launch(seq_.as<uint8_t>(), len, k, seed, out_.as<uint64_t>(), nk, stream_), "kmer_hashes");
         out.resize(nk);
@@ -267,7 +280,7 @@ class DeviceCtx {
         const size_t na = A.size(), nb = B.size();
         const bool ab = want_abund && a.track_abundance && b.track_abundance;
         // the sketches come from their device mirrors (uploaded on first use, kept until the sketch changes); scratch: [I list]
-        pair_.reserve((na + 16) * 8);
+        pair_.reserve((na + 16) * 8, stream_);
         HoldScope hold(*this);
         Mirror& mA = mirror_of(A, ab);
         const uint64_t* dA = mA.mins;
@@ -277,7 +290,7 @@ class DeviceCtx {
         const uint64_t* dB = mB.mins;
         const uint64_t* dBa = mB.abunds;
         uint64_t* dI = pair_.as<uint64_t>();
-        flags_.reserve(na + 16);
+        flags_.reserve(na + 16, stream_);
         unsigned long long* sums = scalars_.as<unsigned long long>();   // [0..3] sums, [4] list size, [5] num count
         hip_check(hipMemsetAsync(sums, 0, 64, stream_), "memset");
         const bool need_list = want_list || num != 0;
@@ -289,7 +302,7 @@ class DeviceCtx {
         }
         if (need_list && na && nb) {
             const size_t tb = select_temp_bytes(na);
-            temp_.reserve(tb);
+            temp_.reserve(tb, stream_);
             hip_check(select_flagged(dA, flags_.as<uint8_t>(), na, dI, (uint64_t*)(sums + 4), temp_.p, tb, stream_), "select");
         }
         unsigned long long h[8] = {0};
@@ -332,7 +345,7 @@ class DeviceCtx {
         unsigned long long* d_cnt = scalars_.as<unsigned long long>();
         unsigned long long kept = 0;
         for (int attempt = 0; attempt < 2; ++attempt) {
-            out_.reserve(cap * 8);
+            out_.reserve(cap * 8, stream_);
             hip_check(hipMemsetAsync(d_cnt, 0, 16, stream_), "memset");
             hip_check(residue_windows_launch(aa_.as<uint8_t>(), n_aa, k, seed, thr, out_.as<uint64_t>(), d_cnt, cap, false,
                                              stream_), "residue_windows");
@@ -354,7 +367,7 @@ class DeviceCtx {
         const size_t n_aa = residues_to_device(seq, len, k, hf, is_protein);
         if (n_aa < k) return;
         const size_t nw = n_aa - k + 1;
-        out_.reserve(nw * 8);
+        out_.reserve(nw * 8, stream_);
         hip_check(hipMemsetAsync(out_.p, 0, nw * 8, stream_), "memset");
         hip_check(residue_windows_launch(aa_.as<uint8_t>(), n_aa, k, seed, ~0ull, out_.as<uint64_t>(), nullptr, nw, true,
                                          stream_), "residue_windows");
@@ -379,12 +392,12 @@ class DeviceCtx {
         if (!is_protein && len < (size_t)k * 3) return 0;           // signature.rs:259-261
         upload_seq(seq, len);
         if (is_protein) {
-            aa_.reserve(len + 64);
+            aa_.reserve(len + 64, stream_);
             hip_check(residues_launch(seq_.as<uint8_t>(), len, hf, aa_.as<uint8_t>(), stream_), "residues");
             return len;
         }
         const size_t total = (size_t)translated_bytes(len);
-        aa_.reserve(total + 64);
+        aa_.reserve(total + 64, stream_);
         hip_check(translate_launch(seq_.as<uint8_t>(), len, hf, aa_.as<uint8_t>(), stream_), "translate");
         return total;
     }
@@ -394,8 +407,8 @@ class DeviceCtx {
                                std::vector<uint64_t>& hashes, std::vector<uint64_t>& counts) {
         unsigned long long* d_cnt = scalars_.as<unsigned long long>();
         const size_t tb = sort_unique_temp_bytes(kept);
-        temp_.reserve(tb);
-        uniq_.reserve((size_t)kept * 16 + 64);
+        temp_.reserve(tb, stream_);
+        uniq_.reserve((size_t)kept * 16 + 64, stream_);
         uint64_t* d_u = uniq_.as<uint64_t>();
         uint64_t* d_c = d_u + kept;
         int bits = 64;
@@ -417,7 +430,7 @@ class DeviceCtx {
     }
 
     void upload_seq(const uint8_t* seq, size_t len) {
-        seq_.reserve(len + 64);
+        seq_.reserve(len + 64, stream_);
         hip_check(hipMemcpyAsync(seq_.p, seq, len, hipMemcpyHostToDevice, stream_), "H2D");
     }
 
@@ -433,7 +446,7 @@ class DeviceCtx {
         unsigned long long* d_cnt = scalars_.as<unsigned long long>();
         unsigned long long kept = 0;
         for (int attempt = 0; attempt < 2; ++attempt) {
-            out_.reserve(cap * 8);
+            out_.reserve(cap * 8, stream_);
             hip_check(hipMemsetAsync(d_cnt, 0, 16, stream_), "memset");
             hip_check(sketch_dna_launch(seq_.as<uint8_t>(), len, k, seed, thr, out_.as<uint64_t>(), d_cnt, cap, stream_),
                       "sketch_dna");

@@ -1054,6 +1054,8 @@ struct LoopArgs {
     unsigned long long* x_rec;          // shared: [2][W][4] record granules {key hi, key lo, row length, -}
     unsigned long long* x_rows;         // shared: [2][W][rowcap] {tag, query position} granules: every rank's local best row
     unsigned long long* gwin;           // local:  [2][4] the global winner {key hi, key lo, length, owner rank}
+    unsigned long long* gate;           // local:  [0] workgroups that have started, bit 63: somebody gave up waiting for the rest
+    unsigned long long gate_ticks;      // how long a workgroup waits at the gate for the others to start (wall_clock64 ticks, 10 ns)
     unsigned long long* stage;          // local:  [2][rowcap] the winner's positions, copied in once per round by a few workgroups
 };
 
@@ -1091,6 +1093,42 @@ __global__ __launch_bounds__(PL_THREADS) void gather_loop_kernel(LoopArgs a) {
     // the row blocks whose runs hold rows r0 .. r1 - 1 (one block when the ranges are aligned, else two)
     const uint32_t b0 = n_own ? (uint32_t)(r0 / a.block_rows) : 0u;
     const uint32_t b1 = n_own ? (uint32_t)((r1 - 1) / a.block_rows) : 0u;
+    // ---- the gate: nothing is touched before ALL workgroups of the grid are running ----
+    // The sweeps below wait for every workgroup, so all of them must be resident at once.  On an idle device a grid of one
+    // workgroup per CU is; with another kernel or another process on the device some may only start when others leave.  One word
+    // decides for the whole grid: it counts arrivals and reaches n_wg, or a workgroup that waited gate_ticks sets bit 63 by
+    // compare-and-swap while the count is still short (no CAS can succeed once everybody is there).  Given up: every
+    // workgroup -- those that start later included -- leaves at once with counters, uncovered set and results untouched, and
+    // the host runs the two-kernel rounds on the same state (GS_ERR = 10; capi.cpp: gather_drain).
+    {
+        constexpr unsigned long long GAVE_UP = 1ull << 63;
+        if (tid == 0) {
+            unsigned long long v = atomicAdd(a.gate, 1ull) + 1ull;
+            const unsigned long long t0 = wall_clock64();
+            while (!(v & GAVE_UP) && v < (unsigned long long)n_wg) {
+                if (wall_clock64() - t0 > a.gate_ticks) {
+                    const unsigned long long seen = atomicCAS(a.gate, v, v | GAVE_UP);
+                    if (seen == v) {                                  // this workgroup called it off: tell the host, and the other ranks
+                        v |= GAVE_UP;
+                        a.state[GS_ERR] = 10;
+                        a.state[13] = 0; a.state[14] = wg;
+                        if (a.W > 0) {                                // (their workgroup 0 polls this record in epoch 1)
+                            const unsigned long long gtag = (unsigned long long)(a.epoch_base + 1u) << 32;
+                            unsigned long long* rec = a.x_rec + ((uint64_t)1u * a.W + a.rank) * 4;
+                            sys_store(rec + 0, gtag); sys_store(rec + 1, gtag); sys_store(rec + 2, gtag | 0xffffffffull);
+                        }
+                    } else v = seen;
+                    continue;
+                }
+                __builtin_amdgcn_s_sleep(8);
+                v = gran_load(a.gate);
+            }
+            s_nI = (v & GAVE_UP) ? 1u : 0u;
+        }
+        __syncthreads();
+        if (s_nI) return;
+        __syncthreads();
+    }
     // ---- load the state this loop starts from ----
     for (uint32_t w = tid; w < a.bitmap_words; w += PL_THREADS) {
         uint32_t bits = 0;
@@ -1226,6 +1264,11 @@ __global__ __launch_bounds__(PL_THREADS) void gather_loop_kernel(LoopArgs a) {
                     if (spins >= PL_SPIN_LIMIT) { failed = true; fail_code = 12; break; }
                     __builtin_amdgcn_s_sleep(1);
                 }
+                // a rank whose grid did not become resident says so in the length field of its epoch-1 record: nobody applies anything
+                if (!failed && __syncthreads_or((uint32_t)tid < a.W && rl == 0xffffffffu ? 1 : 0)) {
+                    failed = true; fail_code = 14;
+                    if (tid == 0) { gran_store(gw + 0, ltag); gran_store(gw + 1, ltag); gran_store(gw + 2, ltag); gran_store(gw + 3, ltag | 0xffffffffull); }
+                }
                 if (!failed) {
                     // the best of at most 1024 ranks' keys (distinct: the global index is part of the key)
                     unsigned long long m = (uint32_t)tid < a.W ? rk : 0ull;
@@ -1258,6 +1301,7 @@ __global__ __launch_bounds__(PL_THREADS) void gather_loop_kernel(LoopArgs a) {
             if (failed) break;
             top = ((g0v & 0xffffffffull) << 32) | (g1v & 0xffffffffull);
             const uint32_t owner = (uint32_t)g3v, glen = (uint32_t)g2v;
+            if (owner == 0xffffffffu) { failed = true; fail_code = 14; break; }   // workgroup 0 saw a rank call the run off
             if (tid == 0) { s_wlen = glen; if (owner == a.rank) s_wstart = lstart; }
             __syncthreads();
             if (top != 0 && owner != a.rank) {
@@ -1425,9 +1469,9 @@ __global__ __launch_bounds__(PL_THREADS) void gather_loop_kernel(LoopArgs a) {
         a.state[GS_QLEN] = qlen;
         a.state[GS_ACC] = 0;
         a.state[GS_PENDING] = 0;
-        a.state[GS_DONE] = 1;
-    }
-    if (failed && tid == 0) { a.state[GS_ERR] = fail_code; a.state[13] = fail_epoch; a.state[14] = wg; }
+        a.state[GS_DONE] = failed ? 0 : 1;        // given up between two rounds: the state is that of `rounds` whole rounds, and whoever
+    }                                             // carries on (the two-kernel rounds, the record protocol) starts from it
+    if (failed && tid == 0 && a.state[GS_ERR] == 0) { a.state[GS_ERR] = fail_code; a.state[13] = fail_epoch; a.state[14] = wg; }
 }
 
 // bounds[j][b] = post_off[j] + partial[b][j] for b < B, bounds[j][B] = post_off[j + 1]: the run of row block b inside posting list j
@@ -1819,7 +1863,7 @@ hipError_t gather_loop_reserve(GatherDev& g, hipStream_t stream, uint32_t n_wg, 
         SMG_TRY(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
         n_wg = (uint32_t)n_cu;
     }
-    const size_t words = (size_t)2 * n_wg * 4 + 16 + 8 + (size_t)2 * rowcap;
+    const size_t words = (size_t)2 * n_wg * 4 + 16 + 8 + 8 + (size_t)2 * rowcap;
     if (!g.loop_xchg || g.loop_wgs != n_wg || g.loop_words < words) {
         if (g.loop_xchg) arena_free(g.loop_xchg, stream);
         g.loop_xchg = nullptr;
@@ -1855,7 +1899,7 @@ hipError_t gather_launch_loop(GatherDev& g, hipStream_t stream, uint32_t n_wg, c
         if (e != hipSuccess) (void)hipGetLastError();
     }
     if (attr_state < 0) return hipSuccess;
-    // local exchange memory: [2][n_wg][4] workgroup records, 16 trace words, [2][4] global winner, [2][rowcap] staged row
+    // local exchange memory: [2][n_wg][4] workgroup records, 16 trace words, [2][4] global winner, 8 gate words, [2][rowcap] staged row
     const uint64_t rowcap = sh ? sh->rowcap : 0;
     if (sh && (sh->W == 0 || sh->W > (uint32_t)PL_THREADS || sh->rank >= sh->W || rowcap == 0)) return hipErrorInvalidValue;
     SMG_TRY(gather_loop_reserve(g, stream, n_wg, rowcap));
@@ -1865,11 +1909,16 @@ hipError_t gather_launch_loop(GatherDev& g, hipStream_t stream, uint32_t n_wg, c
     static const bool trace = getenv("SMG_GATHER_TRACE") != nullptr;
     a.dbg = trace ? g.loop_xchg + (size_t)2 * n_wg * 4 : nullptr;           // 16 words behind the granules
     a.gwin = g.loop_xchg + (size_t)2 * n_wg * 4 + 16;
-    a.stage = a.gwin + 8;
+    a.gate = a.gwin + 8;
+    a.stage = a.gate + 8;
+    // a grid on an idle device is resident within microseconds; 20 ms covers a launch queued behind somebody's kernel without
+    // making the fallback wait long (SMG_GATHER_GATE_US: tests)
+    static const unsigned long long gate_us = [] { const char* e = getenv("SMG_GATHER_GATE_US"); const long long v = e ? atoll(e) : 0; return v > 0 ? (unsigned long long)v : 20000ull; }();
+    a.gate_ticks = gate_us * 100ull;
     a.W = sh ? sh->W : 0; a.rank = sh ? sh->rank : 0; a.rowcap = (uint32_t)rowcap;
     a.epoch_base = sh ? (sh->run_id & 0xfffu) << 20 : 0;                    // tags of the shared slots: unique per run, no zeroing between runs
     a.x_rec = sh ? sh->rec : nullptr; a.x_rows = sh ? sh->rows : nullptr;
-    SMG_TRY(hipMemsetAsync(g.loop_xchg, 0, ((size_t)2 * n_wg * 4 + 16 + 8) * 8, stream));   // local epochs count from 1 within a launch
+    SMG_TRY(hipMemsetAsync(g.loop_xchg, 0, ((size_t)2 * n_wg * 4 + 16 + 8 + 8) * 8, stream));   // local epochs count from 1 within a launch
     if (rowcap) SMG_TRY(hipMemsetAsync(a.stage, 0, (size_t)2 * rowcap * 8, stream));
     // One workgroup per CU: all of them must be resident at once (the sweeps wait for every workgroup).  A plain launch has
     // the same residency as a cooperative one (MI355X_MICROARCH.md) without its 15-19 us and without the cooperative
@@ -1899,6 +1948,27 @@ hipError_t gather_launch_loop(GatherDev& g, hipStream_t stream, uint32_t n_wg, c
                 d[10] * 0.01);
     }
     return hipSuccess;
+}
+
+// ---- test support: hold CUs ----------------------------------------------------------------------------------------------
+// n_wg workgroups that each keep `lds_bytes` of LDS and spin for `micros` microseconds: a stand-in for "somebody else's kernel is
+// running on this device" (tests/test_gpu_gather.py: the resident loop must step aside, not fail).
+__global__ __launch_bounds__(256) void hold_cus_kernel(unsigned long long ticks, uint32_t* sink) {
+    extern __shared__ uint32_t hold_lds[];
+    hold_lds[threadIdx.x] = threadIdx.x;
+    __syncthreads();
+    const unsigned long long t0 = wall_clock64();
+    uint32_t x = hold_lds[(threadIdx.x * 7u) & 255u];
+    while (wall_clock64() - t0 < ticks) { __builtin_amdgcn_s_sleep(32); x += 1; }
+    if (x == 0xdeadbeefu) *sink = x;                     // (keeps the loop and the LDS alive)
+}
+hipError_t debug_hold_cus(uint32_t n_wg, uint32_t lds_bytes, uint64_t micros, hipStream_t stream) {
+    static uint32_t* sink = nullptr;
+    if (!sink) SMG_TRY(hipMalloc(&sink, 256));
+    if (lds_bytes < 1024) lds_bytes = 1024;
+    SMG_TRY(hipFuncSetAttribute((const void*)hold_cus_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+    hipLaunchKernelGGL(hold_cus_kernel, dim3(n_wg), dim3(256), lds_bytes, stream, (unsigned long long)micros * 100ull, sink);
+    return hipGetLastError();
 }
 
 hipError_t gather_run_persistent(GatherDev& g, hipStream_t stream, bool* ran) { return gather_launch_loop(g, stream, 0, nullptr, ran); }

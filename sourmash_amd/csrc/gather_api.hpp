@@ -21,7 +21,10 @@ enum GatherSlot {
     GS_NEEDX = 9,    // replay: the best candidate fell below what a rank kept back -> the next exchange decides
     GS_WSLOT = 10,   // replay: candidate slot of the round's winner
     GS_BOUND = 11,   // replay: largest key any rank kept back at the last exchange (0: nothing kept back)
-    GS_ERR = 12,     // persistent loop: a workgroup gave up waiting for its peers (not all resident)
+    GS_ERR = 12,     // persistent loop: gave up.  10: the grid was not resident as a whole within the gate's time (nothing touched);
+                     // 11 / 12 / 13: a workgroup / a rank / the rank's own workgroup 0 did not show up in a sweep, 14: another rank
+                     // called the run off -- all between two rounds, the state is that of GS_ROUNDS whole rounds;
+                     // 2 / 3 / 4: a winner's row did not arrive or does not fit the exchange (the run is void)
     GS_SLOTS = 16
 };
 
@@ -78,6 +81,7 @@ struct GatherDev {
     // driver allocator calls made through the arena during the build, host synchronisations
     unsigned long long* pinned = nullptr;  // 32 x u64 of pinned host memory: scalar read-backs land here
     hipEvent_t ev_build0 = nullptr, ev_build1 = nullptr;
+    uint64_t loop_fallbacks = 0;        // times the resident loop gave up (grid not resident as a whole) and other rounds took over
     double loop_gpu_ms = 0.0;
     uint64_t loop_host_ns = 0;
     uint64_t build_host_ns = 0, build_driver_ns = 0, build_driver_allocs = 0, build_syncs = 0, build_sync_wait_ns = 0;
@@ -140,6 +144,8 @@ struct GatherShared {
 // the persistent loop on n_wg workgroups (0: one per CU), alone (sh == nullptr) or as rank sh->rank of sh->W
 hipError_t gather_launch_loop(GatherDev& g, hipStream_t stream, uint32_t n_wg, const GatherShared* sh, bool* ran);
 bool gather_loop_eligible(const GatherDev& g, uint32_t n_wg);
+// test support: n_wg workgroups holding lds_bytes of LDS each for `micros` microseconds on `stream` (somebody else's kernel)
+hipError_t debug_hold_cus(uint32_t n_wg, uint32_t lds_bytes, uint64_t micros, hipStream_t stream);
 hipError_t gather_loop_reserve(GatherDev& g, hipStream_t stream, uint32_t n_wg, uint64_t rowcap);
 // Enqueue `rounds` rounds of pick(check) + apply on one GPU (kernels are no-ops once GS_DONE is set).
 hipError_t gather_enqueue_rounds(GatherDev& g, unsigned rounds, hipStream_t stream);

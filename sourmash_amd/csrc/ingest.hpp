@@ -201,25 +201,25 @@ struct IngestScratch {
     size_t temp_bytes = 0;
     static constexpr size_t HALO = 256;             // bytes reserved in front of every compacted chunk
 
-    void prepare(size_t chunk_bytes) {
+    void prepare(size_t chunk_bytes, hipStream_t stream) {
         if (!copy_stream) {
             hip_check(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking), "hipStreamCreate");
             for (int i = 0; i < 2; ++i) {
                 hip_check(hipEventCreateWithFlags(&copied[i], hipEventDisableTiming), "hipEventCreate");
                 hip_check(hipEventCreateWithFlags(&consumed[i], hipEventDisableTiming), "hipEventCreate");
             }
-            small.reserve(256);
+            small.reserve(256, stream);
         }
         if (chunk_bytes <= chunk) return;
         chunk = chunk_bytes;
         for (auto& r : ring) r.reserve(chunk + 64);
         for (int i = 0; i < 2; ++i) {
-            raw[i].reserve(chunk + 64);
-            comp[i].reserve(HALO + chunk + 64);
+            raw[i].reserve(chunk + 64, stream);
+            comp[i].reserve(HALO + chunk + 64, stream);
         }
-        state.reserve(chunk + 64);
+        state.reserve(chunk + 64, stream);
         temp_bytes = fastx_temp_bytes(chunk);
-        temp.reserve(temp_bytes);
+        temp.reserve(temp_bytes, stream);
     }
 };
 
@@ -252,7 +252,7 @@ inline void sketch_file_with(IngestWorker& w, std::vector<KmerMinHash*>& mhs, co
     if (kmax > IngestScratch::HALO) throw err_internal("ksize too large for the streaming ingest");
     hipStream_t st = w.stream;
     IngestScratch& scratch = w.scratch;
-    scratch.prepare(CHUNK);
+    scratch.prepare(CHUNK, st);
     const int halo = (int)kmax - 1;
 
     struct Acc {                       // per sketch: unordered kept hashes since the last flush

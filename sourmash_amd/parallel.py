@@ -46,6 +46,93 @@ def world_info(group=None):
     return 0, 1
 
 
+# Collectives on whatever group the caller runs under.  The product configuration is one process per GPU under "nccl" (RCCL over
+# xGMI) with device tensors.  A gloo group moves host memory only: device tensors are staged through the host around the
+# collective -- what lets two real processes share ONE GPU in tests/test_gpu_two_processes.py and drive these very functions
+# (DeviceBackend, kernels and all) where no second GPU exists.
+def _staged(t, group):
+    dist = _dist()
+    return bool(t.is_cuda) and dist.get_backend(group) == "gloo"
+
+
+def _all_reduce(t, op, group=None):
+    dist = _dist()
+    if _staged(t, group):
+        c = t.cpu()
+        dist.all_reduce(c, op=op, group=group)
+        t.copy_(c)
+    else:
+        dist.all_reduce(t, op=op, group=group)
+
+
+def _all_gather(outs, t, group=None):
+    "outs[r] <- rank r's t (same shape and dtype everywhere)"
+    dist = _dist()
+    if _staged(t, group):
+        c = t.cpu().contiguous()
+        parts = [c.new_empty(c.shape) for _ in outs]
+        dist.all_gather(parts, c, group=group)
+        for o, part in zip(outs, parts):
+            o.copy_(part)
+    else:
+        dist.all_gather(outs, t, group=group)
+
+
+def agree(flag, group=None):
+    "True iff `flag` holds on every rank (one MIN all-reduce; a plain bool without a process group)"
+    dist = _dist()
+    if not (dist.is_available() and dist.is_initialized()):
+        return bool(flag)
+    torch = __import__("torch")
+    dev = "cuda" if dist.get_backend(group) == "nccl" else "cpu"
+    t = torch.tensor([1 if flag else 0], dtype=torch.int64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+    return int(t.item()) == 1
+
+
+EXCHANGE_RUNS_MAX = 4000       # run tags of the shared exchange carry 12 bits of the run number (gather.hip: epoch_base)
+
+
+def open_shared_exchange(owner, make, world, rank, rowcap, group=None):
+    """The exchange area of this job's ranks on one node, made once and reused while it is large enough: rank 0 creates a named
+    segment (make(name, True)), the name travels by one broadcast, the others map it (make(name, False)).  Every step is AGREED
+    before anybody goes on: a rank that failed leaves through the same collectives as its peers and all of them raise -- nobody
+    is left inside a barrier the others never reach.  The area's tags tell runs apart by 12 bits of the run
+    number, so it is made afresh before that wraps.  -> (exchange, run id); state lives on `owner` (_xchg, _xchg_runs)."""
+    import os
+    dist = _dist()
+    cur = getattr(owner, "_xchg", None)
+    grouped = world > 1 or (dist.is_available() and dist.is_initialized())
+    if cur is None or cur.world != world or cur.rowcap < rowcap or getattr(owner, "_xchg_runs", 0) >= EXCHANGE_RUNS_MAX:
+        owner._xchg = None
+        if not grouped:
+            owner._xchg = make(None, True)
+        else:
+            owner._xchg_seq = getattr(owner, "_xchg_seq", 0) + 1
+            box = ["/smg_gx_%d_%d" % (os.getpid(), owner._xchg_seq)] if rank == 0 else [None]
+            dist.broadcast_object_list(box, src=0, group=group)
+            made, err = None, None
+            if rank == 0:
+                try:
+                    made = make(box[0], True)                             # the segment exists and is zeroed
+                except Exception as e:                                   # noqa: BLE001 -- whatever it is, the peers must learn of it
+                    err = e
+            if not agree(err is None, group):
+                raise err or RuntimeError("the shared gather exchange could not be created on rank 0")
+            if rank != 0:
+                try:
+                    made = make(box[0], False)
+                except Exception as e:                                   # noqa: BLE001
+                    err = e
+            if not agree(err is None, group):                            # everybody has it mapped -- or nobody keeps it
+                made = None
+                raise err or RuntimeError("the shared gather exchange could not be mapped on some rank")
+            owner._xchg = made
+        owner._xchg_runs = 0
+    owner._xchg_runs += 1
+    return owner._xchg, owner._xchg_runs
+
+
 def allgather_union(local_hashes, group=None, force=False):
     """Sketching shards by records: every rank holds the sorted unique kept hashes of ITS records (int64 tensor of u64
     bit patterns); one all-gather later every rank holds the sketch of the whole input -- set union is associative,
@@ -59,13 +146,13 @@ def allgather_union(local_hashes, group=None, force=False):
     dev = local_hashes.device
     n_local = torch.tensor([local_hashes.numel()], dtype=torch.int64, device=dev)
     sizes = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
-    dist.all_gather(sizes, n_local, group=group)
+    _all_gather(sizes, n_local, group)
     sizes = [int(t.item()) for t in sizes]
     longest = max(max(sizes), 1)
     pad = torch.zeros(longest, dtype=torch.int64, device=dev)
     pad[:local_hashes.numel()] = local_hashes
     parts = [torch.empty(longest, dtype=torch.int64, device=dev) for _ in range(world)]
-    dist.all_gather(parts, pad, group=group)
+    _all_gather(parts, pad, group)
     merged = torch.cat([p[:n] for p, n in zip(parts, sizes)])
     flip = torch.iinfo(torch.int64).min                 # order as unsigned: flip the sign bit around the sort
     return torch.unique(merged ^ flip) ^ flip
@@ -147,10 +234,10 @@ class _DeviceGatherState:
     def stats(self):
         """what the index build and the last run() cost (smgpu_gather_stats): kernel spans from HIP events next to the
         host wall clocks, driver-allocator time and calls, host synchronisations -- localises host effects"""
-        out = (C.c_double * 8)()
+        out = (C.c_double * 9)()
         self.rustcall(self.lib.smgpu_gather_stats, self._ptr, out)
         keys = ("build_kernels_ms", "build_host_ms", "build_driver_alloc_ms", "build_driver_allocs", "build_syncs",
-                "build_sync_wait_ms", "loop_gpu_ms", "loop_host_ms")
+                "build_sync_wait_ms", "loop_gpu_ms", "loop_host_ms", "loop_fallbacks")
         return {k: round(float(v), 3) for k, v in zip(keys, out)}
 
     def counters(self):
@@ -238,28 +325,11 @@ class DeviceBackend:
 
     # -- gather --
     def open_exchange(self, world, rank, rowcap, group=None):
-        """the shared exchange of this job's ranks (one node): rank 0 creates a POSIX shared-memory segment, the name travels
-        by broadcast, everybody maps and registers it; kept and reused while it is large enough.  run ids count up per use."""
-        cur = getattr(self, "_xchg", None)
-        if cur is None or cur.world != world or cur.rowcap < rowcap:
-            import os
-            dist = _dist()
-            name = None
-            if world > 1 or (dist.is_available() and dist.is_initialized()):
-                self._xchg_seq = getattr(self, "_xchg_seq", 0) + 1
-                box = ["/smg_gx_%d_%d" % (os.getpid(), self._xchg_seq)] if rank == 0 else [None]
-                dist.broadcast_object_list(box, src=0, group=group)
-                name = box[0]
-                self._xchg = GatherExchange(self.lib, self.rustcall, world, rowcap, name, create=True) if rank == 0 else None
-                dist.barrier(group=group)                                   # the segment exists and is zeroed
-                if rank != 0:
-                    self._xchg = GatherExchange(self.lib, self.rustcall, world, rowcap, name, create=False)
-                dist.barrier(group=group)                                   # everybody has it mapped
-            else:
-                self._xchg = GatherExchange(self.lib, self.rustcall, world, rowcap)
-            self._xchg_runs = 0
-        self._xchg_runs += 1
-        return self._xchg, self._xchg_runs
+        """the shared exchange of this job's ranks (one node): POSIX shared memory every rank maps and registers with HIP
+        (open_shared_exchange has the choreography); run ids count up per use."""
+        def make(name, create):
+            return GatherExchange(self.lib, self.rustcall, world, rowcap, name, create=create)
+        return open_shared_exchange(self, make, world, rank, rowcap, group)
 
     def gather_state(self, query, nq, hashes, offsets, ndb, index_base):
         "Invert the shard against the query; -> step object (pick / export / apply / poll / results / run)."
@@ -320,7 +390,7 @@ def compare_all_pairs_distributed(hashes, offsets, n, backend, group=None, want_
         # (as bytes: neither RCCL nor gloo moves 16-bit integers; truncation keeps the low 16 bits)
         send = local.to(torch.int16).view(torch.uint8) if narrow else local
         pieces = [backend.empty(tuple(send.shape), send.dtype) for _ in range(world)]
-        dist.all_gather(pieces, send, group=group)                # the ONE collective of the compare path
+        _all_gather(pieces, send, group)                          # the ONE collective of the compare path
         if narrow:
             pieces = [p.view(torch.int16).to(torch.int32).bitwise_and_(0xFFFF) for p in pieces]
         full = assemble_tiles(pieces, n, world, backend)
@@ -395,8 +465,8 @@ def gather_distributed(query, nq, shard_hashes, shard_offsets, n_shard, index_ba
     layout_sum = backend.zeros((1,), torch.int64)
     layout_max[0], layout_sum[0] = state.longest_row(), n_shard
     if collect:                                            # one-off: longest row anywhere, number of datasets
-        dist.all_reduce(layout_max, op=dist.ReduceOp.MAX, group=group)
-        dist.all_reduce(layout_sum, op=dist.ReduceOp.SUM, group=group)
+        _all_reduce(layout_max, dist.ReduceOp.MAX, group)
+        _all_reduce(layout_sum, dist.ReduceOp.SUM, group)
     total = int(layout_sum.item())
     stride = CAND_HEAD + max(int(layout_max.item()), 1)
     state.begin(thr, min(max_rounds, total) if max_rounds is not None else total)
@@ -412,33 +482,28 @@ def gather_distributed(query, nq, shard_hashes, shard_offsets, n_shard, index_ba
     # (stepwise=True asks for the record protocol explicitly: tests, and the single-rank comparison of the two)
     if (collect and not stepwise and hasattr(backend, "open_exchange") and hasattr(state, "launch_shared")
             and os.environ.get("SMG_GATHER_EXCHANGE", "shared") != "records"):
-        ok = backend.zeros((1,), torch.int64)
-        ok[0] = 1 if state.loop_eligible(0) else 0
-        if collect and dist.is_available() and dist.is_initialized():
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
-        if int(ok.item()) == 1:
+        # workgroups per rank's loop kernel: one per CU (0) on a GPU of its own; ranks that SHARE a GPU (tests) must fit side by side
+        n_wg = int(os.environ.get("SMG_GATHER_LOOP_WGS", "0"))
+        grouped = collect and dist.is_available() and dist.is_initialized()
+
+        def all_ok(flag):
             # Every step is agreed among the ranks before anybody acts on it: a rank that fell back to the record protocol on
             # its own would sit in a collective the others never join.
-            def all_ok(flag):
-                t = backend.zeros((1,), torch.int64)
-                t[0] = 1 if flag else 0
-                if collect and dist.is_available() and dist.is_initialized():
-                    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
-                return int(t.item()) == 1
-            res, good = None, False
+            return agree(flag, group) if grouped else bool(flag)
+        if all_ok(state.loop_eligible(n_wg)):
+            res, good, xchg, run_id = None, False, None, 0
             try:
-                xchg, run_id = backend.open_exchange(world, rank, stride - CAND_HEAD, group)
+                xchg, run_id = backend.open_exchange(world, rank, stride - CAND_HEAD, group)   # (agreed inside: all ranks or none)
                 opened = True
             except Exception:                                   # (shared memory / registration not available here)
                 opened = False
             if all_ok(opened):
-                launched = state.launch_shared(xchg, rank, run_id)
-                if launched:
-                    try:
-                        res = state.results()                   # waits for the loop; raises if a peer never showed up
-                        good = True
-                    except Exception:
-                        good = False
+                try:
+                    if state.launch_shared(xchg, rank, run_id, n_wg):
+                        res = state.results()                   # waits for the loop; raises if a peer never showed up, or if some
+                        good = True                             # rank's grid did not become resident (nothing was applied then)
+                except Exception:
+                    good = False
                 if all_ok(good):
                     if stats is not None:
                         stats.update(exchanges=0, rounds_per_exchange=None, records_per_rank=None, record_words=None, rounds=len(res),
@@ -603,7 +668,14 @@ def gather_emulated_ranks(query, nq, shards, threshold_bp, scaled, backend, max_
 
 def _all_gather_rows(dist, out, mine, world, group):
     "out[r * k : (r + 1) * k] = rank r's `mine`"
-    if hasattr(dist, "all_gather_into_tensor") and out.is_cuda:
+    if _staged(out, group):                                  # a gloo group over device tensors: through the host (see _staged)
+        k = mine.shape[0]
+        c = mine.cpu().contiguous()
+        parts = [c.new_empty(c.shape) for _ in range(world)]
+        dist.all_gather(parts, c, group=group)
+        for r, part in enumerate(parts):
+            out[r * k:(r + 1) * k].copy_(part)
+    elif hasattr(dist, "all_gather_into_tensor") and out.is_cuda:
         dist.all_gather_into_tensor(out, mine, group=group)
     else:
         k = mine.shape[0]

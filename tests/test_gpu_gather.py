@@ -409,3 +409,48 @@ def _loop_forms():
             assert np.array_equal(st.counters(), want_left), (nq, ndb, thr_bp)
             digest.append([len(want), int(mid.sum()), int(want_left.sum())])
     print(json.dumps(digest))
+
+
+def test_resident_loop_steps_aside_when_the_device_is_not_idle(monkeypatch):
+    """The resident loop kernel needs a workgroup on every CU at once.  With somebody else's kernel holding CUs (here: 24
+    workgroups that keep 120 KB of LDS each for 0.4 s on another stream) its grid is not resident as a whole: the kernel
+    gives up at its gate with nothing touched and the two-kernel rounds run on the same state -- the oracle's picks, no error
+    (round 3 raised `Internal: the device was shared?` with half-consumed counters).  Also through CounterGather's object
+    protocol and the one-call gather of a loaded set, which share the drain (index/__init__.py:856-909, search.py:755-779)."""
+    import ctypes as C
+    import torch
+    from sourmash_amd import device as smd, parallel
+    from sourmash_amd._lowlevel import lib
+    from sourmash_amd.synth import synth_gather
+    monkeypatch.setenv("SMG_GATHER_BUILD", "ranges")
+    be = parallel.DeviceBackend()
+    qh, dbh = synth_gather(n_query=70_000, n_db=3000, db_size=400)
+    dbh[11] = dbh[5].copy()
+    h, off = smd.pack_csr(dbh)
+    q = torch.from_numpy(qh.view(np.int64).copy()).cuda()
+    want = oracle.gather(qh, *oracle.make_csr(dbh), threshold_bp=0, scaled=1000, nthreads=8)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        torch.zeros(1, device="cuda").add_(1)                     # (the stream's hardware queue exists before the timed part)
+    torch.cuda.synchronize()
+    # idle device: the resident loop answers
+    st = be.gather_state(q, len(qh), h, off, len(dbh), 0)
+    assert st.loop_eligible(0), "this index should be able to run the resident loop"
+    st.begin(0, len(dbh))
+    assert st.run() == want
+    assert st.stats()["loop_fallbacks"] == 0
+    # occupied device: 24 CUs held for 0.4 s -> the gate (20 ms) gives up, the two-kernel rounds answer meanwhile
+    st2 = be.gather_state(q, len(qh), h, off, len(dbh), 0)
+    st2.begin(0, len(dbh))
+    lib.smgpu_debug_hold_cus(24, 120 * 1024, 400_000, C.c_void_p(side.cuda_stream))
+    got = st2.run()
+    busy = not side.query()                                       # the holder outlived the gather: it really ran side by side
+    torch.cuda.synchronize()
+    assert got == want
+    assert st2.stats()["loop_fallbacks"] == 1 and busy, (st2.stats(), busy)
+    # and the same index afterwards, device idle again: back on the resident loop, same answer, no new fallback
+    st2.begin(0, len(dbh))
+    assert st2.run() == []                                        # (everything is consumed: the state carried over)
+    st3 = be.gather_state(q, len(qh), h, off, len(dbh), 0)
+    st3.begin(0, 9)
+    assert st3.run() == want[:9] and st3.stats()["loop_fallbacks"] == 0

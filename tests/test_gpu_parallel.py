@@ -246,26 +246,6 @@ def _shared_exchange_emulated():
                 assert picks == want, (world, thr_bp, cap, r, picks[:3], want[:3], len(picks), len(want))
 
 
-def test_gather_shared_exchange_two_processes_one_gpu():
-    """Two PROCESSES, one database shard each, their loop kernels sharing this one GPU and agreeing on every round through POSIX
-    shared memory that both registered with HIP (tools/shared_2proc.py): the cross-process path ranks on different GPUs of a
-    node take, minus the second device.  Both report the oracle's ordered picks."""
-    import os, subprocess, sys
-    from conftest import ROOT
-    for attempt in range(2):
-        p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "shared_2proc.py")], capture_output=True, text=True, timeout=600,
-                           env=dict(os.environ, GPU_MAX_HW_QUEUES="8"))
-        lines = [ln for ln in p.stdout.strip().splitlines() if ln[:1] in "01"]
-        assert p.returncode == 0 and len(lines) == 2, (p.stdout[-1500:], p.stderr[-1500:])
-        if all("waited too long" in ln for ln in lines):
-            continue                                                 # the two kernels did not overlap in time: once more
-        for rank, ln in enumerate(lines):
-            assert ln.startswith("%d True (True, " % rank), lines    # whenever the loops ran, the picks are the oracle's
-        return
-    pytest.skip("the loop kernels of two processes did not run at the same time on this device (each waited for the other and gave up): "
-                "nothing about the protocol can be concluded here")
-
-
 def test_gather_distributed_falls_back_when_the_shared_exchange_is_unavailable(be, monkeypatch):
     """gather_distributed with the collectives' code path taken on one rank (force_collectives): the shared-memory exchange
     by default; when opening it fails -- on any rank: the ranks agree before anybody acts -- a fresh index and the record

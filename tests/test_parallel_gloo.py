@@ -75,6 +75,45 @@ class OracleBackend:
         return OracleGatherState(self._u64(query, nq), self._u64(hashes), self._u64(offsets), ndb, index_base)
 
 
+class FlakySharedBackend(OracleBackend):
+    """OracleBackend whose indexes claim they can run the resident loop and whose shared exchange goes wrong in a chosen way on a
+    chosen rank: gather_distributed's default branch must end with every rank on the record protocol -- agreed, no rank left in
+    a collective of its own (parallel.py:435)."""
+
+    def __init__(self, rank, fail_open_on=None, fail_launch_on=None, fail_results_on=None):
+        self.rank, self.fail_open_on, self.fail_launch_on, self.fail_results_on = rank, fail_open_on, fail_launch_on, fail_results_on
+        self.opened = 0
+
+    def open_exchange(self, world, rank, rowcap, group=None):
+        import types
+
+        def make(name, create):
+            if self.fail_open_on == rank:
+                raise OSError("no shared memory on this rank")
+            return types.SimpleNamespace(world=world, rowcap=rowcap, name=name)
+        self.opened += 1
+        return parallel.open_shared_exchange(self, make, world, rank, rowcap, group)
+
+    def gather_state(self, query, nq, hashes, offsets, ndb, index_base):
+        st = OracleGatherState(self._u64(query, nq), self._u64(hashes), self._u64(offsets), ndb, index_base)
+        be = self
+        st.loop_eligible = lambda n_wg=0: True
+
+        def launch_shared(xchg, rank, run_id, n_wg=0):
+            if be.fail_launch_on == rank:
+                raise RuntimeError("a row of this shard is longer than the exchange's slots")
+            return True
+        st.launch_shared = launch_shared
+        inner = st.results
+
+        def results():
+            if st.done or st.out:                         # (the record protocol's own read-back)
+                return inner()
+            raise RuntimeError("gather loop: a workgroup or rank waited too long for its peers")   # the shared loop never completes here
+        st.results = results
+        return st
+
+
 class OracleGatherState:
     """CPU stand-in for the native per-rank gather state (same steps, plain numpy sets): counters by direct
     intersection with the uncovered query, i.e. the textbook CounterGather rather than the postings walk."""
@@ -198,6 +237,33 @@ def _worker(rank, world, port, ret):
             res[thr] = parallel.gather_distributed(q, len(qh), sh, soff, hi - lo, lo, thr, 1000, be)
         fh, foff = oracle.make_csr(dbh)
         ok_g = all(res[thr] == oracle.gather(qh, fh, foff, threshold_bp=thr, scaled=1000) for thr in res)
+        # ---- the default (shared-exchange) branch going wrong on ONE rank, at each of its steps: both ranks end on the record
+        # protocol with the right answer, nobody hangs in a collective the other never joins ----
+        want0 = oracle.gather(qh, fh, foff, threshold_bp=0, scaled=1000)
+        for kw in ({"fail_open_on": 1}, {"fail_open_on": 0}, {"fail_launch_on": 1}, {"fail_launch_on": 0}, {}):
+            fb = FlakySharedBackend(rank, **kw)
+            stats = {}
+            got = parallel.gather_distributed(q, len(qh), sh, soff, hi - lo, lo, 0, 1000, fb, stats=stats)
+            ok_g = ok_g and got == want0 and fb.opened == 1 and stats.get("shared_exchange", "").startswith("failed")
+        # ---- opening the exchange: made once, reused, re-made when it must grow or its run tags would wrap ----
+        import types
+        owner, made = types.SimpleNamespace(), []
+
+        def make(name, create):
+            made.append((name, create))
+            return types.SimpleNamespace(world=world, rowcap=100 if len(made) == 1 else 500, name=name)
+        x1, run1 = parallel.open_shared_exchange(owner, make, world, rank, 100)
+        x2, run2 = parallel.open_shared_exchange(owner, make, world, rank, 80)
+        ok_x = x1 is x2 and (run1, run2) == (1, 2) and made == [(x1.name, rank == 0)] and x1.name.startswith("/smg_gx_")
+        x3, run3 = parallel.open_shared_exchange(owner, make, world, rank, 300)          # too small now: a new segment
+        ok_x = ok_x and x3 is not x1 and run3 == 1 and x3.name != x1.name and len(made) == 2
+        owner._xchg_runs = parallel.EXCHANGE_RUNS_MAX                                   # 12 bits of run number in the tags
+        x4, run4 = parallel.open_shared_exchange(owner, make, world, rank, 300)
+        ok_x = ok_x and x4 is not x3 and run4 == 1 and len(made) == 3
+        names = [None, None]
+        dist.all_gather_object(names, x4.name)
+        ok_x = ok_x and names[0] == names[1]                                            # the creator's name reached the other rank
+        ok_g = ok_g and ok_x
         # ---- search / prefetch: one overlap pass per shard, one all-gather of (count, size) pairs ----
         shared, sizes = parallel.overlaps_distributed(q, len(qh), sh, soff, hi - lo, lo, be)
         want_shared = np.array([oracle.intersection_size(qh, d)[0] for d in dbh], dtype=np.uint64)
