@@ -324,6 +324,27 @@ uintptr_t smgpu_first_invalid_dna_byte(const char *seq, uintptr_t len);
 /* Host convenience: n sketch handles -> n x n matrices on the host (either may be NULL). */
 void smgpu_compare_all_pairs(const SourmashKmerMinHash *const *mhs, uintptr_t n, uint32_t *common_out,
                              double *jaccard_out);
+/* All pairs of BOTTOM-K (num) sketches in one launch (csrc/compare_ext.hip) -- what src/sourmash/compare.py:36-54 asks
+ * kmerminhash_similarity for pair by pair: common_out[i][j] = |A ∩ B ∩ merged|, union_out[i][j] = |merged| with merged = the
+ * num smallest hashes of A ∪ B, num taken from the sketch with the lower index (src/core/src/sketch/minhash.rs:593-621: the
+ * merged sketch is built with self.num), jaccard_out = common / max(1, union) (minhash.rs:624-631), 1.0 on the diagonal.  n x n
+ * host matrices, any may be NULL.  Errors: the compatibility error of the first sketch that does not match sketch 0. */
+void smgpu_compare_num_all_pairs(const SourmashKmerMinHash *const *mhs, uintptr_t n, uint32_t *common_out, uint32_t *union_out,
+                                 double *jaccard_out);
+/* All pairs of ABUNDANCE-TRACKING sketches: sims_out[i][j] = angular similarity 1 - 2 acos(min(sum a_i b_j / (|a| |b|), 1)) / pi
+ * (src/core/src/sketch/minhash.rs:635-680; 0 when a norm is 0; 1.0 on the diagonal as compare.py:33 has it).  The integer sums
+ * come from one launch (prod_out[i][j] = sum over the common hashes of abund_i x abund_j, sumsq_out[i] = sum of squares; u64,
+ * wrapping; optional), sqrt / acos from the host's libm.  Errors: compatibility as above; NeedsAbundanceTracking. */
+void smgpu_compare_angular_all_pairs(const SourmashKmerMinHash *const *mhs, uintptr_t n, double *sims_out, uint64_t *prod_out,
+                                     uint64_t *sumsq_out);
+/* the host half of the above on its own: prod [n][n], sumsq [n] -> out [n][n] (n_threads 0: every host core) */
+void smgpu_host_angular_f64(const uint64_t *prod, const uint64_t *sumsq, uintptr_t n, double *out, uint32_t n_threads);
+/* The same kernels on caller-owned device buffers (CSR of sorted rows; d_nums[i] = num of sketch i; d_abunds parallel to
+ * d_hashes; narrow = every abundance fits 32 bits).  Full n x n device matrices; d_union / d_jaccard may be NULL. */
+void smgpu_compare_num_raw(const uint64_t *d_hashes, const uint64_t *d_offsets, const uint32_t *d_nums, uint32_t n,
+                           uint32_t *d_common, uint32_t *d_union, double *d_jaccard, void *stream);
+void smgpu_compare_abund_raw(const uint64_t *d_hashes, const uint64_t *d_abunds, const uint64_t *d_offsets, uint32_t n, bool narrow,
+                             uint32_t *d_common, uint64_t *d_prod, uint64_t *d_sumsq, void *stream);
 
 /* Device-resident sketch collection + gather counters: the batched form of CounterGather
  * (src/sourmash/index/__init__.py:735-909).  A SketchSet is a CSR of n sorted sketches in HBM;

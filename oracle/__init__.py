@@ -90,6 +90,8 @@ def lib():
         "orc_max_containment": (C.c_double, [u64, u64, u64, u64]),
         "orc_avg_containment": (C.c_double, [u64, u64, u64, u64]),
         "orc_containment_to_distance_point": (C.c_double, [C.c_double, C.c_uint32]),
+        "orc_similarity_matrix": (None, [vp, u64, C.c_int, C.c_int, vp, C.POINTER(C.c_uint32), C.c_int]),
+        "orc_jaccard_to_distance": (C.c_double, [C.c_double, C.c_uint32, u64, C.POINTER(C.c_double), C.POINTER(C.c_int)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
@@ -298,6 +300,27 @@ def avg_containment(common, n_self, n_other, scaled):
 def containment_to_distance_point(containment, ksize):
     "distance_utils.py:276-283: the point estimate of containment_to_distance"
     return float(lib().orc_containment_to_distance_point(float(containment), int(ksize)))
+
+
+def jaccard_to_distance(jaccard, ksize, n_unique_kmers):
+    "distance_utils.py:349-407: (point estimate, lower bound of the approximation error); ValueError where the reference raises"
+    err, bad = C.c_double(0.0), C.c_int(0)
+    d = lib().orc_jaccard_to_distance(float(jaccard), int(ksize), int(n_unique_kmers), C.byref(err), C.byref(bad))
+    if bad.value:
+        raise ValueError("Error: varN <0.0!")
+    return float(d), float(err.value)
+
+
+def similarity_matrix(mhs, ignore_abundance=False, downsample=False, nthreads=1):
+    "compare.py:14-64 over OracleMinHash objects (num rule, angular similarity, per-pair downsampling) -> f64 [n][n]"
+    n = len(mhs)
+    out = np.zeros((n, n), dtype=np.float64)
+    ptrs = (C.c_void_p * max(n, 1))(*[m._p for m in mhs])
+    e = C.c_uint32(0)
+    lib().orc_similarity_matrix(ptrs, n, int(ignore_abundance), int(downsample), _ptr(out), C.byref(e), nthreads)
+    if e.value:
+        raise OracleError(e.value)
+    return out
 
 
 # --------------------------------------------------------------------------- #

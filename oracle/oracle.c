@@ -966,3 +966,61 @@ ORC_API double orc_containment_to_distance_point(double containment, uint32_t ks
     if (containment == 1.0) return 0.0;
     return 1.0 - pow(containment, 1.0 / (double)ksize);
 }
+
+/* ------------------------------------------------------------------------ */
+/* compare_serial over sketch OBJECTS (bottom-k sketches, abundance-tracking */
+/* sketches, mixed scaled values): src/sourmash/compare.py:14-64 -- ones on  */
+/* the diagonal, out[i][j] = out[j][i] = siglist[i].similarity(siglist[j],   */
+/* ignore_abundance, downsample) for every i < j -- with similarity =         */
+/* orc_mh_similarity above (minhash.rs:682-702: downsample the finer sketch,  */
+/* then jaccard incl. the num rule of :593-621, or angular :635-680).         */
+/* *err = code of the first failing pair in the loop's order (0: none).       */
+/* ------------------------------------------------------------------------ */
+ORC_API void orc_similarity_matrix(const orc_mh *const *mhs, uint64_t n, int ignore_abundance, int downsample,
+                                   double *out, uint32_t *err, int nthreads) {
+    if (nthreads < 1) nthreads = 1;
+    *err = 0;
+    uint32_t *row_err = (uint32_t *)calloc(n ? n : 1, sizeof(uint32_t));
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(nthreads) schedule(dynamic, 1)
+#endif
+    for (uint64_t i = 0; i < n; ++i) {
+        out[i * n + i] = 1.0;
+        for (uint64_t j = i + 1; j < n; ++j) {
+            uint32_t e = 0;
+            double s = orc_mh_similarity(mhs[i], mhs[j], ignore_abundance, downsample, &e);
+            if (e && !row_err[i]) row_err[i] = e;
+            out[i * n + j] = s; out[j * n + i] = s;
+        }
+    }
+    for (uint64_t i = 0; i < n && !*err; ++i) *err = row_err[i];
+    free(row_err);
+}
+
+/* ------------------------------------------------------------------------ */
+/* Jaccard -> distance: src/sourmash/distance_utils.py:349-407                */
+/* (jaccard_to_distance) with r1_to_q :128-131, var_n_mutated :134-152,       */
+/* exp_n_mutated :155-157, in the reference's operation order (Python floats; */
+/* `**` on floats is libm pow).  Returns the point estimate, *err_lower_bound */
+/* = the approximation error the reference compares with 1e-4                 */
+/* (jaccardANIResult: ani is None when it is exceeded).  *bad = 1 when the    */
+/* reference would raise "varN <0.0".                                         */
+/* ------------------------------------------------------------------------ */
+ORC_API double orc_jaccard_to_distance(double jaccard, uint32_t ksize, uint64_t n_unique_kmers, double *err_lower_bound, int *bad) {
+    *bad = 0;
+    if (jaccard == 0.0) { *err_lower_bound = 0.0; return 1.0; }
+    if (jaccard == 1.0) { *err_lower_bound = 0.0; return 0.0; }
+    const double k = (double)ksize, L = (double)n_unique_kmers;
+    const double r1 = 1.0 - pow(2.0 * jaccard / (1.0 + jaccard), 1.0 / k);
+    const double q = 1.0 - pow(1.0 - r1, k);                               /* r1_to_q */
+    const double exp_n_mut = L * q;                                        /* exp_n_mutated */
+    double varN = 0.0;
+    if (r1 != 0.0) {                                                       /* var_n_mutated */
+        varN = L * (1.0 - q) * (q * (2.0 * k + (2.0 / r1) - 1.0) - 2.0 * k)
+             + k * (k - 1.0) * pow(1.0 - q, 2.0)
+             + (2.0 * (1.0 - q) / pow(r1, 2.0)) * ((1.0 + (k - 1.0) * (1.0 - q)) * r1 - q);
+        if (varN < 0.0) { *bad = 1; varN = 0.0; }
+    }
+    *err_lower_bound = 1.0 * L * varN / pow(L + exp_n_mut, 3.0);
+    return r1;
+}

@@ -10,8 +10,10 @@ and Jaccard / containment / ANI are derived from it on whole arrays:
     jaccard[i][j]      = common / max(1, n_i + n_j - common)     (one IEEE divide, on the GPU)
     containment[i][j]  = debias(common, n_j)  with the host formula of minhash.py:819-841
     ani[i][j]          = 1 - (1 - containment^(1/k))             (host libm pow, distance_utils.py:276-283)
-Abundance-weighted (angular) pairs, num sketches and collections with mixed scaled
-values go through the per-pair GPU entry points, like the reference's loop.
+Bottom-k (num) sketches and abundance-weighted (angular) similarity have tile kernels of their own (csrc/compare_ext.hip);
+collections with several scaled values are served one launch per value (every pair at ITS coarser scaled, like
+similarity(downsample=True)); Jaccard-derived ANI is whole-array arithmetic on the Jaccard matrix.  Only the containment
+variants of mixed-scaled collections still walk the pairs.
 """
 import ctypes as C
 import itertools
@@ -22,7 +24,8 @@ from ._lowlevel import lib
 from .utils import rustcall
 
 __all__ = ["compare_all_pairs", "compare_serial", "compare_parallel", "compare_serial_containment",
-           "compare_serial_max_containment", "compare_serial_avg_containment", "common_matrix"]
+           "compare_serial_max_containment", "compare_serial_avg_containment", "common_matrix", "num_matrix", "angular_matrix",
+           "jaccard_ani_values"]
 
 
 def _uniform(mhs):
@@ -61,30 +64,164 @@ def _pow(x, y):
     return out
 
 
+def num_matrix(mhs, want_counts=False):
+    """Jaccard of every pair of flat BOTTOM-K sketches in one launch (smgpu_compare_num_all_pairs, csrc/compare_ext.hip): the
+    intersection is taken against the merged sketch truncated to `num` (minhash.rs:593-621), num being that of the sketch
+    with the lower index, as in compare.py:39 `siglist[i].similarity(siglist[j])`.  -> f64 [n][n] (and u32 common, union)."""
+    n = len(mhs)
+    jac = np.ones((n, n), dtype=np.float64)
+    common = np.zeros((n, n), dtype=np.uint32) if want_counts else None
+    union = np.zeros((n, n), dtype=np.uint32) if want_counts else None
+    if n:
+        ptrs = (C.c_void_p * n)(*[mh._get_objptr() for mh in mhs])
+        rustcall(lib.smgpu_compare_num_all_pairs, ptrs, n,
+                 common.ctypes.data_as(C.POINTER(C.c_uint32)) if want_counts else None,
+                 union.ctypes.data_as(C.POINTER(C.c_uint32)) if want_counts else None,
+                 jac.ctypes.data_as(C.POINTER(C.c_double)))
+    return (jac, common, union) if want_counts else jac
+
+
+def angular_matrix(mhs):
+    """Angular similarity of every pair of abundance-tracking sketches (minhash.rs:635-680): the integer sums -- sum over
+    the common hashes of abund x abund, per sketch the sum of squares -- from one launch (csrc/compare_ext.hip), sqrt / acos
+    from the host's libm in the reference's operation order (smgpu_compare_angular_all_pairs).  -> f64 [n][n], diagonal 1.0."""
+    n = len(mhs)
+    sims = np.ones((n, n), dtype=np.float64)
+    if n:
+        ptrs = (C.c_void_p * n)(*[mh._get_objptr() for mh in mhs])
+        rustcall(lib.smgpu_compare_angular_all_pairs, ptrs, n, sims.ctypes.data_as(C.POINTER(C.c_double)), None, None)
+    return sims
+
+
+def _compat_key(mh):
+    "what check_compatible looks at besides the threshold (minhash.rs:886-912): ksize, hash function, seed"
+    return (mh.ksize, mh.moltype, mh.seed)
+
+
+def _batchable(mhs, downsample):
+    """Can the pairs of this list be served by batched launches with the per-pair semantics intact?  Yes when every sketch
+    is mutually compatible with every other: one (ksize, molecule, seed), and either all bottom-k, or all scaled with one
+    scaled value -- or several, if the caller asked for downsampling (every pair is then compared at ITS coarser scaled,
+    minhash.rs:688-696).  Otherwise some pair raises in the reference's loop, and the caller lets that very pair raise."""
+    if len({_compat_key(mh) for mh in mhs}) > 1:
+        return False
+    if all(mh.num for mh in mhs):
+        return True
+    if any(mh.num for mh in mhs) or not all(mh.scaled for mh in mhs):
+        return False
+    return downsample or len({mh.scaled for mh in mhs}) == 1
+
+
+def _by_scaled(mhs, downsample, block):
+    """f64 [n][n], diagonal 1.0, assembled from one `block(sketches, scaled) -> matrix` call per distinct scaled value s of the
+    list: the sketches with scaled <= s, downsampled to s (a prefix of their hashes, minhash.rs:777-798), give the entries of
+    the pairs whose coarser scaled is s -- what similarity(downsample=True) does pair by pair (minhash.rs:688-696).  One
+    value (or bottom-k sketches: scaled 0): one call on the sketches as they are."""
+    n = len(mhs)
+    scaleds = sorted({mh.scaled for mh in mhs})
+    if len(scaleds) == 1:
+        return block(mhs, scaleds[0])
+    assert downsample
+    sc = np.array([mh.scaled for mh in mhs], dtype=np.int64)
+    out = np.ones((n, n), dtype=np.float64)
+    for s in scaleds:
+        idx = np.flatnonzero(sc <= s)
+        if len(idx) < 2 or not (sc[idx] == s).any():
+            continue
+        sub = [mhs[i] if sc[i] == s else mhs[i].downsample(scaled=int(s)) for i in idx]
+        m = block(sub, int(s))
+        here = np.maximum(sc[idx][:, None], sc[idx][None, :]) == s
+        view = out[np.ix_(idx, idx)]
+        view[here] = m[here]
+        out[np.ix_(idx, idx)] = view
+    out[np.arange(n), np.arange(n)] = 1.0
+    return out
+
+
+def _jaccard_block(flat, scaled):
+    if scaled == 0:                                    # bottom-k sketches
+        return num_matrix(flat)
+    return common_matrix(flat, want_jaccard=True)[1]
+
+
+def _raise_like_the_loop(siglist, call):
+    "the reference's loop meets an incompatible pair and raises: find the first one in its order and let it raise"
+    for i, j in itertools.combinations(range(len(siglist)), 2):
+        call(siglist[i], siglist[j])
+    raise AssertionError("every pair went through, but the list did not look batchable")
+
+
+def jaccard_ani_values(jaccard, ksize, n_unique_kmers, err_threshold=1e-4):
+    """ANI point estimates from Jaccard on whole arrays: jaccard_to_distance (distance_utils.py:349-407) with r1_to_q,
+    exp_n_mutated and var_n_mutated (:128-157) in the reference's operation order -- IEEE multiplies / divides / adds on
+    arrays, every `**` through the host libm's pow (what CPython's float ** ends in; pow(x, 2.0) is NOT always x * x), so
+    the bits are those of the per-pair Python floats.  -> (ani, withheld): ani = 1 - dist; withheld where the
+    approximation-error bound exceeds err_threshold (jaccardANIResult.ani is None there).  ValueError like the reference
+    when var_n_mutated turns negative."""
+    j = np.ascontiguousarray(jaccard, dtype=np.float64)
+    shape = j.shape
+    j = j.reshape(-1)
+    L = np.ascontiguousarray(n_unique_kmers, dtype=np.float64).reshape(-1)
+    k = float(ksize)
+    mid = (j != 0) & (j != 1)
+    jm, Lm = j[mid], L[mid]
+    r1 = 1.0 - _pow(2.0 * jm / (1 + jm), 1.0 / k)
+    q = 1 - _pow(1 - r1, k)
+    exp_n_mut = Lm * q
+    with np.errstate(divide="ignore", invalid="ignore"):
+        var_n = (Lm * (1 - q) * (q * (2 * k + (2 / r1) - 1) - 2 * k)
+                 + k * (k - 1) * _pow(1 - q, 2.0)
+                 + (2 * (1 - q) / _pow(r1, 2.0)) * ((1 + (k - 1) * (1 - q)) * r1 - q))
+    var_n = np.where(r1 == 0, 0.0, var_n)
+    if (var_n < 0.0).any():
+        raise ValueError("Error: varN <0.0!")
+    err = 1.0 * Lm * var_n / _pow(Lm + exp_n_mut, 3.0)
+    dist = np.where(j == 0, 1.0, 0.0)
+    dist[mid] = r1
+    withheld = np.zeros(j.shape, dtype=bool)
+    withheld[mid] = err > err_threshold
+    return (1 - dist).reshape(shape), withheld.reshape(shape)
+
+
+def _jaccard_ani_block(flat, scaled):
+    "jaccard_ani of every pair of flat scaled sketches of ONE scaled value (minhash.py:749-785) -> f64 matrix, 0.0 = withheld"
+    n = len(flat)
+    jac = common_matrix(flat, want_jaccard=True)[1]
+    sizes = np.array([len(mh) for mh in flat], dtype=np.float64)
+    n_kmers = np.rint((sizes[:, None] + sizes[None, :]) / 2 * scaled)       # round(avg_sketch_kmers * scaled): half to even, both
+    ani, withheld = jaccard_ani_values(jac, flat[0].ksize, n_kmers)
+    out = np.where(withheld, 0.0, ani)
+    out[np.arange(n), np.arange(n)] = 1.0
+    return out
+
+
 def compare_serial(siglist, ignore_abundance, *, downsample=False, return_ani=False):
-    """Similarity matrix (compare.py:14-64): Jaccard, or angular similarity for the pairs whose two sketches both track
-    abundance when it is not ignored."""
+    """Similarity matrix (compare.py:14-64).  Per pair the reference computes: Jaccard-derived ANI (return_ani); else the
+    angular similarity when both sketches track abundance and it is not ignored, else Jaccard -- with the bottom-k rule for
+    num sketches, and at the pair's coarser scaled when downsampling (minhash.rs:682-702).  Here every one of these is a
+    batched launch over the whole list (or over the sketches sharing a scaled value); lists in which some pair is
+    incompatible raise what the reference's loop raises, from the same pair."""
     n = len(siglist)
     mhs = [s.minhash for s in siglist]
-    if return_ani or not _uniform(mhs):
-        # per-pair semantics as they are: bottom-k sketches, mixed scaled values (each pair is compared at ITS coarser
-        # scaled when downsample is set, and fails with MismatchScaled otherwise), Jaccard ANI
-        sims = np.ones((n, n))
-        for i, j in itertools.combinations(range(n), 2):
-            if return_ani:
-                ani = siglist[i].jaccard_ani(siglist[j], downsample=downsample).ani
-                sims[i][j] = sims[j][i] = 0.0 if ani is None else ani
-            else:
-                sims[i][j] = sims[j][i] = siglist[i].similarity(siglist[j], ignore_abundance=ignore_abundance,
-                                                                downsample=downsample)
-        return sims
+    if n < 2:
+        return np.ones((n, n))
+    if return_ani:
+        if not all(mh.scaled for mh in mhs) or not _batchable(mhs, downsample):
+            _raise_like_the_loop(siglist, lambda a, b: a.jaccard_ani(b, downsample=downsample))
+        out = _by_scaled([mh.flatten() for mh in mhs], downsample, _jaccard_ani_block)
+        trusted = np.array([mh.size_is_accurate() for mh in mhs], dtype=bool)   # of the sketches as given (minhash.py:783)
+        out = np.where(trusted[:, None] & trusted[None, :], out, 0.0)
+        out[np.arange(n), np.arange(n)] = 1.0
+        return out
+    if not _batchable(mhs, downsample):
+        _raise_like_the_loop(siglist, lambda a, b: a.similarity(b, ignore_abundance=ignore_abundance, downsample=downsample))
     weighted = [] if ignore_abundance else [i for i, mh in enumerate(mhs) if mh.track_abundance]
-    if len(weighted) == n and n > 1:
-        sims = np.ones((n, n))
-    else:
-        _, sims = common_matrix([mh.flatten() for mh in mhs], want_jaccard=True)
-    for i, j in itertools.combinations(weighted, 2):           # minhash.rs:682-702 decides per pair
-        sims[i][j] = sims[j][i] = siglist[i].similarity(siglist[j], ignore_abundance=False, downsample=downsample)
+    if len(weighted) == n:
+        return _by_scaled(mhs, downsample, lambda sub, s: angular_matrix(sub))
+    sims = _by_scaled([mh.flatten() for mh in mhs], downsample, _jaccard_block)
+    if len(weighted) > 1:                                         # minhash.rs:697-701 decides per pair: both track abundance
+        w = np.array(weighted)
+        sims[np.ix_(w, w)] = _by_scaled([mhs[i] for i in weighted], downsample, lambda sub, s: angular_matrix(sub))
     return sims
 
 

@@ -1086,6 +1086,139 @@ void smgpu_compare_all_pairs(const SourmashKmerMinHash* const* mhs, uintptr_t n,
     });
 }
 
+// ---- all pairs of bottom-k / abundance-tracking sketches (compare_ext.hip) ------------------------------------------
+// The reference's compare loop calls similarity() per pair (compare.py:36-54); for num sketches that is the merged-and-
+// truncated union rule (minhash.rs:593-621), for sketches that track abundance the angular similarity (minhash.rs:635-702).
+static void pack_collection(const SourmashKmerMinHash* const* mhs, uintptr_t n, bool with_abund, std::vector<uint64_t>& offsets,
+                            AsyncBuf& dh, AsyncBuf& da, AsyncBuf& doff, bool* narrow, hipStream_t st) {
+    offsets.assign(n + 1, 0);
+    for (uintptr_t i = 0; i < n; ++i) offsets[i + 1] = offsets[i] + MH(mhs[i])->size();
+    const uint64_t total = offsets[n];
+    dh.reset(total * 8 + 16, st);
+    doff.reset((n + 1) * 8, st);
+    if (with_abund) da.reset(total * 8 + 16, st);
+    bool small = true;
+    for (uintptr_t i = 0; i < n; ++i) {
+        const KmerMinHash* m = MH(mhs[i]);
+        if (!m->size()) continue;
+        hip_check(hipMemcpyAsync(dh.as<uint64_t>() + offsets[i], m->mins.data(), m->size() * 8, hipMemcpyHostToDevice, st), "H2D");
+        if (with_abund) {
+            hip_check(hipMemcpyAsync(da.as<uint64_t>() + offsets[i], m->abunds.data(), m->size() * 8, hipMemcpyHostToDevice, st), "H2D");
+            for (uint64_t a : m->abunds) small = small && a <= 0xffffffffull;
+        }
+    }
+    hip_check(hipMemcpyAsync(doff.p, offsets.data(), (n + 1) * 8, hipMemcpyHostToDevice, st), "H2D");
+    if (narrow) *narrow = small;
+}
+
+void smgpu_compare_num_all_pairs(const SourmashKmerMinHash* const* mhs, uintptr_t n, uint32_t* common_out, uint32_t* union_out,
+                                 double* jaccard_out) {
+    landing_void([&] {
+        if (n == 0) return;
+        if (n > 0xffffffffu) throw err_internal("too many sketches");
+        for (uintptr_t i = 1; i < n; ++i) MH(mhs[0])->check_compatible(*MH(mhs[i]));
+        std::vector<uint32_t> nums(n);
+        for (uintptr_t i = 0; i < n; ++i) {
+            nums[i] = MH(mhs[i])->num;
+            if (nums[i] == 0) throw err_internal("smgpu_compare_num_all_pairs takes bottom-k (num) sketches; scaled sketches go to smgpu_compare_all_pairs");
+        }
+        DeviceCtx& ctx = DeviceCtx::get();
+        std::lock_guard<std::recursive_mutex> g(ctx.mutex());
+        hipStream_t st = ctx.stream();
+        std::vector<uint64_t> offsets;
+        AsyncBuf dh, da, doff;
+        pack_collection(mhs, n, false, offsets, dh, da, doff, nullptr, st);
+        AsyncBuf dn(n * 4, st), dc((size_t)n * n * 4, st), du((size_t)n * n * 4, st), dj((size_t)n * n * 8, st);
+        hip_check(hipMemcpyAsync(dn.p, nums.data(), n * 4, hipMemcpyHostToDevice, st), "H2D");
+        hip_check(hipMemsetAsync(dc.p, 0, (size_t)n * n * 4, st), "memset");
+        hip_check(compare_num_launch(dh.as<uint64_t>(), doff.as<uint64_t>(), dn.as<uint32_t>(), (uint32_t)n, dc.as<uint32_t>(),
+                                     du.as<uint32_t>(), dj.as<double>(), st), "compare (num)");
+        if (common_out) hip_check(hipMemcpyAsync(common_out, dc.p, (size_t)n * n * 4, hipMemcpyDeviceToHost, st), "D2H");
+        if (union_out) hip_check(hipMemcpyAsync(union_out, du.p, (size_t)n * n * 4, hipMemcpyDeviceToHost, st), "D2H");
+        if (jaccard_out) hip_check(hipMemcpyAsync(jaccard_out, dj.p, (size_t)n * n * 8, hipMemcpyDeviceToHost, st), "D2H");
+        hip_check(hipStreamSynchronize(st), "sync");
+    });
+}
+
+// out[i][j] = 1 - 2 acos(min(prod / (sqrt(sq_i) sqrt(sq_j)), 1)) / pi, 0 when a norm is 0 (minhash.rs:662-679); the host's libm
+// like the reference's f64::sqrt / f64::acos; the diagonal is 1.0 (compare.py:33)
+void smgpu_host_angular_f64(const uint64_t* prod, const uint64_t* sumsq, uintptr_t n, double* out, uint32_t n_threads) {
+    landing_void([&] {
+        if (n == 0) return;
+        if (!prod || !sumsq || !out) throw err_internal("null pointer");
+        size_t t = n_threads ? n_threads : std::thread::hardware_concurrency();
+        if (t > 64) t = 64;
+        if (t < 1 || n < 256) t = 1;
+        std::vector<double> norm(n);
+        for (uintptr_t i = 0; i < n; ++i) norm[i] = std::sqrt((double)sumsq[i]);
+        auto work = [&](size_t lo, size_t hi) {
+            for (size_t i = lo; i < hi; ++i)
+                for (size_t j = 0; j < n; ++j) {
+                    double v;
+                    if (i == j) v = 1.0;
+                    else if (norm[i] == 0.0 || norm[j] == 0.0) v = 0.0;
+                    else {
+                        // the pair is evaluated as similarity(lower index, higher index): norm_a belongs to the lower one
+                        const double na = i < j ? norm[i] : norm[j], nb = i < j ? norm[j] : norm[i];
+                        double p = (double)prod[i * n + j] / (na * nb);
+                        if (p > 1.0) p = 1.0;
+                        v = 1.0 - 2.0 * std::acos(p) / 3.14159265358979323846264338327950288;
+                    }
+                    out[i * n + j] = v;
+                }
+        };
+        if (t == 1) { work(0, n); return; }
+        std::vector<std::thread> pool;
+        for (size_t k = 0; k < t; ++k) pool.emplace_back(work, n * k / t, n * (k + 1) / t);
+        for (auto& th : pool) th.join();
+    });
+}
+
+void smgpu_compare_angular_all_pairs(const SourmashKmerMinHash* const* mhs, uintptr_t n, double* sims_out, uint64_t* prod_out,
+                                     uint64_t* sumsq_out) {
+    landing_void([&] {
+        if (n == 0) return;
+        if (n > 0xffffffffu) throw err_internal("too many sketches");
+        for (uintptr_t i = 1; i < n; ++i) MH(mhs[0])->check_compatible(*MH(mhs[i]));
+        for (uintptr_t i = 0; i < n; ++i)
+            if (!MH(mhs[i])->track_abundance) throw Error(E_NEEDS_ABUNDANCE_TRACKING, "sketch needs abundance for this operation");
+        std::vector<uint64_t> prod((size_t)n * n), sq(n);
+        {
+            DeviceCtx& ctx = DeviceCtx::get();
+            std::lock_guard<std::recursive_mutex> g(ctx.mutex());
+            hipStream_t st = ctx.stream();
+            std::vector<uint64_t> offsets;
+            AsyncBuf dh, da, doff;
+            bool narrow = true;
+            pack_collection(mhs, n, true, offsets, dh, da, doff, &narrow, st);
+            AsyncBuf dc((size_t)n * n * 4, st), dp((size_t)n * n * 8, st), ds(n * 8, st);
+            hip_check(hipMemsetAsync(dc.p, 0, (size_t)n * n * 4, st), "memset");
+            hip_check(hipMemsetAsync(dp.p, 0, (size_t)n * n * 8, st), "memset");
+            hip_check(compare_abund_launch(dh.as<uint64_t>(), da.as<uint64_t>(), doff.as<uint64_t>(), (uint32_t)n, narrow,
+                                           dc.as<uint32_t>(), dp.as<unsigned long long>(), ds.as<unsigned long long>(), st), "compare (abundance)");
+            hip_check(hipMemcpyAsync(prod.data(), dp.p, (size_t)n * n * 8, hipMemcpyDeviceToHost, st), "D2H");
+            hip_check(hipMemcpyAsync(sq.data(), ds.p, n * 8, hipMemcpyDeviceToHost, st), "D2H");
+            hip_check(hipStreamSynchronize(st), "sync");
+        }
+        if (prod_out) memcpy(prod_out, prod.data(), (size_t)n * n * 8);
+        if (sumsq_out) memcpy(sumsq_out, sq.data(), n * 8);
+        if (sims_out) smgpu_host_angular_f64(prod.data(), sq.data(), n, sims_out, 0);
+    });
+}
+
+// the same kernels on caller-owned device buffers (torch tensors): benchmarks, and callers that keep collections resident
+void smgpu_compare_num_raw(const uint64_t* d_hashes, const uint64_t* d_offsets, const uint32_t* d_nums, uint32_t n, uint32_t* d_common,
+                           uint32_t* d_union, double* d_jaccard, void* stream) {
+    landing_void([&] { hip_check(compare_num_launch(d_hashes, d_offsets, d_nums, n, d_common, d_union, d_jaccard, (hipStream_t)stream), "compare (num)"); });
+}
+void smgpu_compare_abund_raw(const uint64_t* d_hashes, const uint64_t* d_abunds, const uint64_t* d_offsets, uint32_t n, bool narrow,
+                             uint32_t* d_common, uint64_t* d_prod, uint64_t* d_sumsq, void* stream) {
+    landing_void([&] {
+        hip_check(compare_abund_launch(d_hashes, d_abunds, d_offsets, n, narrow, d_common, (unsigned long long*)d_prod,
+                                       (unsigned long long*)d_sumsq, (hipStream_t)stream), "compare (abundance)");
+    });
+}
+
 // ---- device-resident sketch collections and gather counters ------------------------------------
 struct SketchSet {
     DevBuf hashes, offsets;

@@ -58,6 +58,19 @@ hipError_t symmetrize_launch(uint32_t* d_common, uint32_t n, hipStream_t stream)
 hipError_t jaccard_from_counts_launch(const uint32_t* d_common, const uint64_t* d_offsets, uint32_t n,
                                       uint32_t row_lo, uint32_t row_hi, double* d_out, hipStream_t stream);
 
+// ---- compare_ext.hip (bottom-k and abundance-weighted all-pairs) --------------------------------
+// Bottom-k sketches (CSR of sorted rows, d_nums[i] = num of sketch i): d_common[i][j] = |A ∩ B ∩ bottom_num(A ∪ B)| with num of
+// the lower index (minhash.rs:593-621; the diagonal holds the row sizes), d_union[i][j] = |bottom_num(A ∪ B)| and
+// d_jaccard = common / max(1, union) with 1.0 on the diagonal (either may be null).  Full n x n matrices.
+hipError_t compare_num_launch(const uint64_t* d_hashes, const uint64_t* d_offsets, const uint32_t* d_nums, uint32_t n,
+                              uint32_t* d_common, uint32_t* d_union, double* d_jaccard, hipStream_t stream);
+// Abundance-tracking sketches: d_prod[i][j] = sum over common hashes of abund_i * abund_j (u64, wrapping; the diagonal holds the
+// row's sum of squares), d_sumsq[i] the same sums of squares, d_common the plain intersection sizes (minhash.rs:635-680).
+// narrow: every abundance fits 32 bits (one v_mad_u64_u32 per common hash instead of a 64 x 64 product).
+hipError_t compare_abund_launch(const uint64_t* d_hashes, const uint64_t* d_abunds, const uint64_t* d_offsets, uint32_t n,
+                                bool narrow, uint32_t* d_common, unsigned long long* d_prod, unsigned long long* d_sumsq,
+                                hipStream_t stream);
+
 // ---- bitindex.hip (dense compare path) ---------------------------------------------------------
 hipError_t bitmap_build_launch(const uint64_t* d_hashes, const uint64_t* d_offsets, uint32_t n, const uint64_t* d_dict,
                                uint64_t U, uint32_t* d_bits, uint32_t words_per_row, hipStream_t stream);

@@ -68,6 +68,11 @@ struct AsyncBuf {
     AsyncBuf(const AsyncBuf&) = delete;
     AsyncBuf& operator=(const AsyncBuf&) = delete;
     ~AsyncBuf() { if (p) arena_free(p, st); }
+    void reset(size_t bytes, hipStream_t stream) {
+        if (p) arena_free(p, st);
+        p = nullptr; st = stream;
+        hip_check(arena_alloc(&p, bytes + 256, stream), "arena_alloc");
+    }
     template <class T> T* as() const { return static_cast<T*>(p); }
 };
 

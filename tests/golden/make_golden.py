@@ -71,7 +71,48 @@ FILES.append(("tests/test-data/prot/all.zip", "zips/all.zip",
               "(DNA x2, protein/dayhoff/hp x2 each)"))
 
 
+def reference_distance_utils():
+    """the reference's src/sourmash/distance_utils.py imported on its own: it is plain Python + scipy and its one package import
+    is `.logging.notify`, so it runs in this container without the Rust core (the rest of the package does not)"""
+    import importlib.util
+    import types
+    pkg = types.ModuleType("sourmash")
+    pkg.__path__ = []
+    sys.modules["sourmash"] = pkg
+    lg = types.ModuleType("sourmash.logging")
+    lg.notify = lambda *a, **k: None
+    sys.modules["sourmash.logging"] = lg
+    spec = importlib.util.spec_from_file_location("sourmash.distance_utils", os.path.join(REF, "src/sourmash/distance_utils.py"))
+    m = importlib.util.module_from_spec(spec)
+    sys.modules["sourmash.distance_utils"] = m
+    spec.loader.exec_module(m)
+    return m
+
+
+def jaccard_to_distance_vectors():
+    """tests/golden/jaccard_to_distance.json: outputs of the REFERENCE's jaccard_to_distance (distance_utils.py:349-407) on 400 seeded
+    inputs, floats as hex -- pins the oracle's restatement and the batched ANI matrix of compare (compare.py:14-64 return_ani)."""
+    import random
+    m = reference_distance_utils()
+    random.seed(5)
+    cases = []
+    for _ in range(400):
+        j = random.random() ** random.choice([1, 2, 4])
+        k = random.choice([21, 31, 51, 7, 10])
+        n = random.choice([100, 5000, 50000, 5_000_000, 12345678])
+        try:
+            r = m.jaccard_to_distance(j, k, 1000, n_unique_kmers=n)
+            cases.append([j.hex(), k, n, [r.dist.hex(), r.jaccard_error.hex(), r.ani is None]])
+        except ValueError:
+            cases.append([j.hex(), k, n, None])
+    doc = {"source": "src/sourmash/distance_utils.py:349-407 jaccard_to_distance(j, ksize, 1000, n_unique_kmers=n): [jaccard hex, "
+                     "ksize, n, [dist hex, jaccard_error hex, ani is None] or null where it raises]", "cases": cases}
+    with open(os.path.join(HERE, "jaccard_to_distance.json"), "w") as fh:
+        json.dump(doc, fh)
+
+
 def main():
+    jaccard_to_distance_vectors()
     manifest = []
     for src, dst, why in FILES:
         s = os.path.join(REF, src)

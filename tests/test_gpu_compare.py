@@ -636,3 +636,147 @@ def test_compare_index_random_collections(sm):
                 cb, _ = smd.compare_rows(h, off, lo, hi_row, index=idx)
                 torch.cuda.synchronize()
                 assert np.array_equal(cb.cpu().numpy().view(np.uint32), wc[lo:hi_row]), ("block", case, n, threshold, lo, hi_row)
+
+
+# ---- batched launches for what used to be a per-pair loop: bottom-k, abundance, mixed scaled, Jaccard ANI ----------------
+def _oracle_sketch(hashes, ksize=31, num=0, scaled=0, abunds=None):
+    mh = oracle.OracleMinHash(num, ksize, scaled=scaled, track_abundance=abunds is not None)
+    if abunds is not None:
+        for h, a in zip(hashes, abunds):
+            mh.add_hash_with_abundance(int(h), int(a))
+    else:
+        mh.add_many(np.asarray(hashes, dtype=np.uint64))
+    return mh
+
+
+def _bottom_k_collection(n, num, seed, pool_size=20_000, draw=2000):
+    "n bottom-k sketches over a common pool: sketch i = the `num` smallest of its own random draw (fewer when the draw is small)"
+    rng = np.random.default_rng(seed)
+    pool = np.unique(rng.integers(1, 2**62, pool_size, dtype=np.int64).astype(np.uint64))
+    out = []
+    for i in range(n):
+        k = draw if i % 17 else int(rng.integers(0, num))              # some sketches hold fewer than num hashes
+        out.append(np.sort(rng.choice(pool, size=min(k, len(pool)), replace=False))[:num])
+    out[3] = out[2].copy()                                             # identical sketches
+    out[5] = np.zeros(0, dtype=np.uint64)                              # an empty one
+    out[7] = out[6][: num // 3].copy()                                 # a prefix of another
+    return out
+
+
+def test_num_all_pairs_batched_vs_oracle(sm):
+    """Bottom-k collections in ONE launch (csrc/compare_ext.hip): |A ∩ B ∩ merged|, |merged| and Jaccard of every pair
+    == the oracle's literal restatement of minhash.rs:593-631 (merge both into a sketch truncated to num, intersect),
+    f64 bit for bit; `num` is the lower-indexed sketch's where they differ.  The reference's golden 7 x 7 demo matrix
+    (tests/test_compare.py:48-63) through the same path, counts included."""
+    from sourmash_amd.compare import compare_all_pairs, num_matrix
+    sigs = [s for f in sorted(glob.glob(golden("demo", "*.sig"))) for s in _load(sm, f)]
+    jac, common, union = num_matrix([s.minhash for s in sigs], want_counts=True)
+    omh = [_omh(oracle.read_sig_json(f)[0]) for f in sorted(glob.glob(golden("demo", "*.sig")))]
+    for i in range(7):
+        for j in range(i + 1, 7):
+            assert (int(common[i, j]), int(union[i, j])) == omh[i].intersection_and_union_size(omh[j])
+            assert common[j, i] == common[i, j] and union[j, i] == union[i, j]
+    assert np.array_equal(jac, compare_all_pairs(sigs, ignore_abundance=True)) and jac[0, 1] == 0.356
+    # config-C3-shaped: 1,000 sketches of num = 500 (ragged: short, empty, identical, prefix sketches planted)
+    arrays = _bottom_k_collection(1000, 500, seed=3)
+    mhs = []
+    for i, a in enumerate(arrays):
+        mh = sm.MinHash(500 if i % 5 else 300, 31)                     # two different num values in one list
+        mh.add_many(a)
+        mhs.append(mh)
+    want = oracle.similarity_matrix([_oracle_sketch(np.asarray(mh._mins_array()), num=mh.num) for mh in mhs], ignore_abundance=True,
+                                    nthreads=oracle.usable_cpus())
+    got = compare_all_pairs([sm.SourmashSignature(mh, name=str(i)) for i, mh in enumerate(mhs)], ignore_abundance=False)
+    assert np.array_equal(got.view(np.uint64), want.view(np.uint64))
+    assert got[2, 3] == 1.0 and (got[5] == np.eye(1000)[5]).all() and 0 < got[10, 11] < 1
+    # per-pair API and batch agree (the pair kernel of pair_ops.hip is the round-1 form of the same rule)
+    for i, j in ((0, 1), (6, 7), (2, 3), (17, 34), (4, 5), (10, 995)):
+        assert got[i, j] == mhs[i].similarity(mhs[j])
+
+
+def test_angular_all_pairs_batched_vs_oracle(sm):
+    """Abundance-tracking collections in ONE launch: the u64 sums of the common hashes' abundance products and the sums of
+    squares (csrc/compare_ext.hip), sqrt / acos on the host -- == the oracle's restatement of minhash.rs:635-680 for every
+    pair, f64 bit for bit; abundances beyond 32 bits take the wide multiply."""
+    from sourmash_amd.compare import compare_all_pairs, angular_matrix
+    from sourmash_amd.synth import synth_sketches
+    sk = synth_sketches(1000, seed=99, pool_size=20_000, keep_one_in=8)         # ~2,500 hashes each, planted edge rows
+    def abund(h):
+        return 1 + (h % np.uint64(7)) * (h % np.uint64(11))
+    mhs, omhs = [], []
+    for i, a in enumerate(sk):
+        mh = sm.MinHash(0, 31, scaled=1000, track_abundance=True)
+        ab = abund(a)
+        mh.set_abundances(dict(zip(a.tolist(), ab.tolist())))
+        mhs.append(mh)
+        omhs.append(_oracle_sketch(a, scaled=1000, abunds=ab))
+    want = oracle.similarity_matrix(omhs, ignore_abundance=False, nthreads=oracle.usable_cpus())
+    got = compare_all_pairs([sm.SourmashSignature(mh, name=str(i)) for i, mh in enumerate(mhs)], ignore_abundance=False)
+    assert np.array_equal(got.view(np.uint64), want.view(np.uint64))
+    assert np.array_equal(got, angular_matrix(mhs))
+    for i, j in ((0, 1), (5, 700), (998, 999)):
+        assert got[i, j] == mhs[i].angular_similarity(mhs[j]) == mhs[j].similarity(mhs[i])
+    # ignore_abundance: the flat Jaccard matrix of the same hashes
+    flat = compare_all_pairs([sm.SourmashSignature(mh, name=str(i)) for i, mh in enumerate(mhs[:200])], ignore_abundance=True)
+    wc, wj = oracle.compare_all_pairs(*oracle.make_csr(sk[:200]), nthreads=4)
+    assert np.array_equal(flat.view(np.uint64), wj.view(np.uint64))
+    # abundances that do not fit 32 bits: products wrap in u64 like the reference's (release build) arithmetic
+    big, obig = [], []
+    for i, a in enumerate(sk[:40]):
+        ab = (abund(a) << np.uint64(29 + i % 5)) + np.uint64(i)
+        mh = sm.MinHash(0, 31, scaled=1000, track_abundance=True)
+        mh.set_abundances(dict(zip(a.tolist(), ab.tolist())))
+        big.append(mh)
+        obig.append(_oracle_sketch(a, scaled=1000, abunds=ab))
+    assert max(int(v) for v in big[4].hashes.values()) >= 2**32
+    w2 = oracle.similarity_matrix(obig, ignore_abundance=False, nthreads=4)
+    assert np.array_equal(angular_matrix(big).view(np.uint64), w2.view(np.uint64))
+
+
+def test_mixed_scaled_and_jaccard_ani_batched_vs_oracle(sm):
+    """compare.py:14-64 on a list with three scaled values: every pair at ITS coarser scaled (minhash.rs:688-696), served
+    by one launch per scaled value; and return_ani: jaccard_ani (minhash.py:749-785) on whole arrays.  Both == the oracle
+    pair by pair, f64 bit for bit (the ANI through the oracle's restatement of distance_utils.py:349-407, itself pinned to
+    the reference module's outputs in tests/test_distance_utils.py)."""
+    from sourmash_amd.compare import compare_serial
+    from sourmash_amd.synth import synth_sketches
+    sk = synth_sketches(120, seed=5, pool_size=40_000, keep_one_in=4, planted=False)      # ~10,000 hashes at scaled 1000
+    sigs, omhs = [], []
+    for i, a in enumerate(sk):
+        s = (1000, 2000, 4000)[i % 3]
+        mh = sm.MinHash(0, 31, scaled=1000)
+        mh.add_many(a)
+        if s != 1000:
+            mh = mh.downsample(scaled=s)
+        sigs.append(sm.SourmashSignature(mh, name=str(i)))
+        omhs.append(_oracle_sketch(np.asarray(mh._mins_array()), scaled=s))
+    with pytest.raises(ValueError) as e:
+        compare_serial(sigs, True)
+    assert "mismatch in scaled" in str(e.value)
+    got = compare_serial(sigs, True, downsample=True)
+    want = oracle.similarity_matrix(omhs, ignore_abundance=True, downsample=True, nthreads=oracle.usable_cpus())
+    assert np.array_equal(got.view(np.uint64), want.view(np.uint64))
+    assert got[0, 3] == sigs[0].jaccard(sigs[3]) and got[0, 1] == sigs[0].minhash.downsample(scaled=2000).jaccard(sigs[1].minhash)
+    # Jaccard ANI, mixed scaled
+    ani = compare_serial(sigs, True, downsample=True, return_ani=True)
+    trusted = [s.minhash.size_is_accurate() for s in sigs]
+    for i in range(len(sigs)):
+        for j in range(i + 1, len(sigs)):
+            s = max(sigs[i].minhash.scaled, sigs[j].minhash.scaled)
+            a, b = omhs[i].downsample_scaled(s), omhs[j].downsample_scaled(s)
+            jac = a.similarity(b, ignore_abundance=True)
+            n_kmers = round((len(a) + len(b)) / 2 * s)
+            dist, err = oracle.jaccard_to_distance(jac, 31, n_kmers)
+            w = 0.0 if (err > 1e-4 or not (trusted[i] and trusted[j])) else 1 - dist
+            assert ani[i, j] == w == ani[j, i], (i, j)
+    assert (np.diag(ani) == 1.0).all() and (ani > 0.9).sum() > 100
+    # and the same entries through the object API on a sample
+    for i, j in ((0, 1), (2, 119), (50, 51), (7, 8)):
+        r = sigs[i].jaccard_ani(sigs[j], downsample=True).ani
+        assert ani[i, j] == (0.0 if r is None else r)
+    # one scaled value: a single launch + array arithmetic
+    same = [s for i, s in enumerate(sigs) if i % 3 == 0]
+    a1 = compare_serial(same, True, return_ani=True)
+    for i, j in ((0, 1), (5, 30), (38, 39)):
+        r = same[i].jaccard_ani(same[j]).ani
+        assert a1[i, j] == (0.0 if r is None else r)
