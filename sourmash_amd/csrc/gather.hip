@@ -2226,23 +2226,41 @@ __global__ __launch_bounds__(SL_THREADS) void stream_lookup_kernel(const uint64_
 // every row is counted by exactly one workgroup: plain stores, no atomics.
 constexpr int OW_THREADS = 1024;
 constexpr int OW_WAVES = OW_THREADS / 64;
-constexpr int OW_SLOTS = 25;              // rows a wave owns, each with its next 64 hashes in (or on the way to) registers
-constexpr int OW_BATCH = 4;               // visits looked up side by side
-constexpr int OW_BUCKETS = 8192;          // table buckets per range (at most)
-constexpr int OW_QCAP = 11264;            // query hashes a range may hold (88 KB); the caller checks the widest range
-constexpr int OW_ROWS = OW_WAVES * OW_SLOTS;   // rows per workgroup (at most): 400
-constexpr size_t OW_LDS = (size_t)OW_QCAP * 8 + ((size_t)OW_BUCKETS + 4) * 4 + ((size_t)3 * OW_ROWS + 8) * 4;
+// Two geometries of the same kernel (round 4).  `One`: a workgroup takes the whole LDS of a CU -- the round-3 form, 4 waves per
+// SIMD.  `Two`: TWO workgroups share a CU (8 waves per SIMD; the kernel needs 60 VGPRs, 64 are to be had): the table slice as
+// 16-bit offsets (a range holds < 65,536 query hashes by construction), ~6,800 query hashes per range instead of ~10,000,
+// half the rows per workgroup.  The round-3 phase trace said what the One form waits for: with one 1,024-thread workgroup
+// per CU nothing runs while its 16 waves stand at a range's two barriers or wait out a lookup's two dependent LDS trips.
+template <int SLOTS_, int BUCKETS_, int QCAP_, typename TT_, int WAVES_PER_EU_, int BATCH_>
+struct OwGeom {
+    static constexpr int BATCH = BATCH_;          // visits looked up side by side
+    static constexpr int SLOTS = SLOTS_;          // rows a wave owns, each with its next 64 hashes in (or on the way to) registers
+    static constexpr int BUCKETS = BUCKETS_;      // table buckets per range (at most)
+    static constexpr int QCAP = QCAP_;            // query hashes a range may hold; the caller checks the widest range
+    using TT = TT_;                               // a table entry in LDS: offset of the bucket's first query hash within the slice
+    static constexpr int ROWS = OW_WAVES * SLOTS_; // rows per workgroup (at most)
+    static constexpr size_t T_BYTES = (((size_t)BUCKETS_ + 4) * sizeof(TT_) + 7) & ~(size_t)7;
+    static constexpr size_t LDS = (size_t)QCAP_ * 8 + T_BYTES + ((size_t)3 * ROWS + 8) * 4;
+    static constexpr int WAVES_PER_EU = WAVES_PER_EU_;
+};
+using OwOne = OwGeom<25, 8192, 11264, uint32_t, 4, 4>;    // 88 KB + 32 KB + 4.7 KB = 127.7 KB: one workgroup per CU
+using OwTwo = OwGeom<13, 8192, 7680, uint16_t, 8, 2>;     // 60 KB + 16 KB + 2.5 KB = 78.5 KB: two workgroups per CU
+constexpr int OW_BUCKETS = OwOne::BUCKETS;
 
-__global__ __launch_bounds__(OW_THREADS) void overlap_wide_kernel(const uint64_t* __restrict__ Q, const uint32_t* __restrict__ T,
+template <class G>
+__global__ __launch_bounds__(OW_THREADS) __attribute__((amdgpu_waves_per_eu(G::WAVES_PER_EU, G::WAVES_PER_EU)))
+void overlap_wide_kernel(const uint64_t* __restrict__ Q, const uint32_t* __restrict__ T,
                                                                   uint32_t n_buckets, uint32_t shift, uint64_t qmax,
                                                                   const uint64_t* __restrict__ hashes,
                                                                   const uint64_t* __restrict__ offsets, uint64_t ndb,
                                                                   uint32_t rows_per_wg, uint32_t n_ranges, uint32_t bpr,
                                                                   unsigned long long* __restrict__ counts) {
+    constexpr int OW_SLOTS = G::SLOTS, OW_BUCKETS = G::BUCKETS, OW_QCAP = G::QCAP, OW_ROWS = G::ROWS, OW_BATCH = G::BATCH;
+    using TT = typename G::TT;
     extern __shared__ __attribute__((aligned(16))) uint64_t ow_lds[];
     uint64_t* s_q = ow_lds;
-    uint32_t* s_t = reinterpret_cast<uint32_t*>(s_q + OW_QCAP);
-    uint32_t* s_base = s_t + OW_BUCKETS + 4;                          // row starts relative to the block's first hash
+    TT* s_t = reinterpret_cast<TT*>(s_q + OW_QCAP);
+    uint32_t* s_base = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(s_t) + G::T_BYTES);   // row starts relative to the block's first hash
     uint32_t* s_cur = s_base + OW_ROWS + 2;
     uint32_t* s_hits = s_cur + OW_ROWS + 1;
     const uint64_t d_lo = (uint64_t)blockIdx.x * rows_per_wg;
@@ -2294,32 +2312,39 @@ __global__ __launch_bounds__(OW_THREADS) void overlap_wide_kernel(const uint64_t
         const uint32_t p0 = uniform32(n_p0), cnt_q = uniform32(n_p1) - p0, cnt_t = b1 - b0 + 1;
         __syncthreads();                                                  // the previous range's readers are done
         OW_MARK(tr_b1)
-        {
-            uint32_t tv[TPER];
-            uint64_t qv[QPER];
+        {   // (in pieces of FILL_STEP loads per thread: all of a piece's loads are in flight together; the Two form has 64 registers)
+            constexpr int FILL_STEP = G::WAVES_PER_EU > 4 ? 4 : 16;
 #pragma unroll
-            for (int u = 0; u < TPER; ++u) {
-                const uint32_t i = (uint32_t)tid + (uint32_t)u * OW_THREADS;
-                tv[u] = i < cnt_t ? T[b0 + i] : 0u;
+            for (int u0 = 0; u0 < TPER; u0 += FILL_STEP) {
+                uint32_t tv[FILL_STEP];
+#pragma unroll
+                for (int u = 0; u < FILL_STEP; ++u) {
+                    const uint32_t i = (uint32_t)tid + (uint32_t)(u0 + u) * OW_THREADS;
+                    tv[u] = (u0 + u < TPER && i < cnt_t) ? T[b0 + i] : 0u;
+                }
+#pragma unroll
+                for (int u = 0; u < FILL_STEP; ++u) {
+                    const uint32_t i = (uint32_t)tid + (uint32_t)(u0 + u) * OW_THREADS;
+                    if (u0 + u < TPER && i < cnt_t) s_t[i] = (TT)(tv[u] - p0);
+                }
             }
 #pragma unroll
-            for (int u = 0; u < QPER; ++u) {
-                const uint32_t i = (uint32_t)tid + (uint32_t)u * OW_THREADS;
-                qv[u] = i < cnt_q ? Q[p0 + i] : 0ull;
-            }
+            for (int u0 = 0; u0 < QPER; u0 += FILL_STEP) {
+                uint64_t qv[FILL_STEP];
 #pragma unroll
-            for (int u = 0; u < TPER; ++u) {
-                const uint32_t i = (uint32_t)tid + (uint32_t)u * OW_THREADS;
-                if (i < cnt_t) s_t[i] = tv[u] - p0;
-            }
+                for (int u = 0; u < FILL_STEP; ++u) {
+                    const uint32_t i = (uint32_t)tid + (uint32_t)(u0 + u) * OW_THREADS;
+                    qv[u] = (u0 + u < QPER && i < cnt_q) ? Q[p0 + i] : 0ull;
+                }
 #pragma unroll
-            for (int u = 0; u < QPER; ++u) {
-                const uint32_t i = (uint32_t)tid + (uint32_t)u * OW_THREADS;
-                if (i < cnt_q) s_q[i] = qv[u];
+                for (int u = 0; u < FILL_STEP; ++u) {
+                    const uint32_t i = (uint32_t)tid + (uint32_t)(u0 + u) * OW_THREADS;
+                    if (u0 + u < QPER && i < cnt_q) s_q[i] = qv[u];
+                }
             }
         }
-        if (tid < 2) s_t[bpr + 1 + tid] = cnt_q;                         // padding: lanes without a hash of the range read an empty bucket
-        if (tid >= 64 && tid < 64 + 3 && cnt_t + (uint32_t)(tid - 64) <= bpr) s_t[cnt_t + (uint32_t)(tid - 64)] = cnt_q;   // a short last range
+        if (tid < 2) s_t[bpr + 1 + tid] = (TT)cnt_q;                     // padding: lanes without a hash of the range read an empty bucket
+        if (tid >= 64 && tid < 64 + 3 && cnt_t + (uint32_t)(tid - 64) <= bpr) s_t[cnt_t + (uint32_t)(tid - 64)] = (TT)cnt_q;   // a short last range
         OW_MARK(tr_fill)
         __syncthreads();
         OW_MARK(tr_b2)
@@ -2353,8 +2378,8 @@ __global__ __launch_bounds__(OW_THREADS) void overlap_wide_kernel(const uint64_t
                 lk[w] = in[w] & mask_of(e[k] <= qmax);
                 uint32_t kk = (uint32_t)(e[k] >> shift) - b0;                // < bpr when lk: the hash lies in this range
                 kk = kk < bpr ? kk : bpr;                                    // other lanes: the padding entries behind the slice
-                t0[w] = s_t[kk];
-                nb[w] = s_t[kk + 1] - t0[w];
+                t0[w] = (uint32_t)s_t[kk];
+                nb[w] = (uint32_t)s_t[kk + 1] - t0[w];
             }
             uint64_t qa[OW_BATCH], qb[OW_BATCH];
 #pragma unroll
@@ -2395,7 +2420,7 @@ __global__ __launch_bounds__(OW_THREADS) void overlap_wide_kernel(const uint64_t
                         bool h2 = false;
                         if (more && ev <= qmax) {
                             const uint32_t k2 = (uint32_t)(ev >> shift) - b0;
-                            for (uint32_t t = s_t[k2], te = s_t[k2 + 1]; t < te; ++t) {
+                            for (uint32_t t = (uint32_t)s_t[k2], te = (uint32_t)s_t[k2 + 1]; t < te; ++t) {
                                 const uint64_t qv = s_q[t];
                                 if (qv == ev) { h2 = true; break; }
                                 if (qv > ev) break;
@@ -2421,6 +2446,179 @@ __global__ __launch_bounds__(OW_THREADS) void overlap_wide_kernel(const uint64_t
 #endif
     __syncthreads();
     for (uint32_t i = tid; i < n_rows; i += OW_THREADS) counts[d_lo + i] = s_hits[i];
+}
+
+// ---- the wide form, lean visits (round 4) -----------------------------------------------------------------------------
+// Counters of the kernel above at C5 (profiles/r03_overlap_pmc.txt): 0.65e9 vector + 0.72e9 scalar + 0.13e9 LDS wave-instructions
+// per pass for 13 million visits -- ~115 instructions a visit, of which the lookup proper needs ~35 -- and its waves spend 57 % of
+// their cycles in s_waitcnt.  Twice the waves per SIMD (OwTwo) bought 3 %: it is the length of a visit's own dependent chain.
+// Where the instructions and the waits went: a row's start, end and cursor lived in LDS and were read back through
+// v_readfirstlane three to five times per visit (each a trip to LDS in FRONT of the load or the compare that needs it), hits
+// went to LDS counters, the last range's special cases (2^64 - 1 as a hash, hashes above the query) were tested in every range.
+// Here
+//   * a slot's row state is two scalars that never leave registers: pos[k] / end[k], element offsets of the row's next
+//     unconsumed hash and of its end -- the next load's address is scalar arithmetic on them;
+//   * hits are a scalar per slot as well (population count of the found mask); the compiler parks scalars it has no
+//     register for in lanes of a vector register (one v_readlane / v_writelane), which is far cheaper than an LDS counter;
+//   * "which lanes hold a hash of this range" is ONE compare (e < upper; lanes past the row's end hold 2^64 - 1), "found" is
+//     two compares: a bucket's first two query hashes are read whatever its size -- for a bucket of fewer the words behind it
+//     belong to later buckets and cannot equal a hash that falls into this one;
+//   * no clamp on the way to the query slice (two spare words behind it), no test against the largest query hash (hashes above
+//     it fall into padding buckets); a query that holds 2^64 - 1 itself takes the kernel above.
+template <class G>
+__global__ __launch_bounds__(OW_THREADS) __attribute__((amdgpu_waves_per_eu(G::WAVES_PER_EU, G::WAVES_PER_EU)))
+void overlap_lean_kernel(const uint64_t* __restrict__ Q, const uint32_t* __restrict__ T, uint32_t n_buckets, uint32_t shift,
+                         const uint64_t* __restrict__ hashes, const uint64_t* __restrict__ offsets, uint64_t ndb,
+                         uint32_t rows_per_wg, uint32_t n_ranges, uint32_t bpr, unsigned long long* __restrict__ counts) {
+    constexpr int SLOTS = G::SLOTS, BUCKETS = G::BUCKETS, QCAP = G::QCAP, BATCH = G::BATCH;
+    using TT = typename G::TT;
+    extern __shared__ __attribute__((aligned(16))) uint64_t ow_lds[];
+    uint64_t* s_q = ow_lds;                                              // [QCAP + 2]
+    TT* s_t = reinterpret_cast<TT*>(s_q + QCAP + 2);                     // [BUCKETS + 4]
+    const uint64_t d_lo = (uint64_t)blockIdx.x * rows_per_wg;
+    if (d_lo >= ndb) return;
+    const uint32_t n_rows = (uint32_t)(ndb - d_lo < (uint64_t)rows_per_wg ? ndb - d_lo : (uint64_t)rows_per_wg);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint64_t block_base = offsets[d_lo];
+    const uint64_t* rows = hashes + block_base;
+    uint32_t pos[SLOTS], end[SLOTS], hv[SLOTS];
+    uint64_t e[SLOTS];
+#pragma unroll
+    for (int k = 0; k < SLOTS; ++k) {
+        const uint32_t i = (uint32_t)wave + (uint32_t)k * OW_WAVES;          // wave-uniform: the loads below are scalar
+        pos[k] = end[k] = 0;
+        hv[k] = 0;
+        if (i < n_rows) {
+            pos[k] = uniform32((uint32_t)(offsets[d_lo + i] - block_base));
+            end[k] = uniform32((uint32_t)(offsets[d_lo + i + 1] - block_base));
+        }
+    }
+    auto ask = [&](int k) {                                                // the next 64 hashes of slot k's row
+        const uint32_t left = end[k] - pos[k];
+        e[k] = ~0ull;
+        if ((uint32_t)lane < left) e[k] = (rows + pos[k])[lane];
+    };
+#pragma unroll
+    for (int k = 0; k < SLOTS; ++k) ask(k);
+    constexpr int QPER = (QCAP + OW_THREADS - 1) / OW_THREADS, TPER = (BUCKETS + 1 + OW_THREADS - 1) / OW_THREADS;
+    uint32_t n_p0 = T[0], n_p1 = T[bpr < n_buckets ? bpr : n_buckets];
+    for (uint32_t r = 0; r < n_ranges; ++r) {
+        const uint32_t b0 = r * bpr, b1 = b0 + bpr < n_buckets ? b0 + bpr : n_buckets;
+        const bool last = r + 1 == n_ranges;
+        const uint64_t upper = last ? ~0ull : ((uint64_t)b1 << shift);
+        const uint32_t p0 = uniform32(n_p0), cnt_q = uniform32(n_p1) - p0, cnt_t = b1 - b0 + 1;
+        __syncthreads();                                                  // the previous range's readers are done
+        {
+            constexpr int FILL_STEP = 4;                                  // (registers: 25 slots x (2 + 1) stay live across the fill)
+#pragma unroll
+            for (int u0 = 0; u0 < TPER; u0 += FILL_STEP) {
+                uint32_t tv[FILL_STEP];
+#pragma unroll
+                for (int u = 0; u < FILL_STEP; ++u) {
+                    const uint32_t i = (uint32_t)tid + (uint32_t)(u0 + u) * OW_THREADS;
+                    tv[u] = (u0 + u < TPER && i < cnt_t) ? T[b0 + i] : 0u;
+                }
+#pragma unroll
+                for (int u = 0; u < FILL_STEP; ++u) {
+                    const uint32_t i = (uint32_t)tid + (uint32_t)(u0 + u) * OW_THREADS;
+                    if (u0 + u < TPER && i < cnt_t) s_t[i] = (TT)(tv[u] - p0);
+                }
+            }
+#pragma unroll
+            for (int u0 = 0; u0 < QPER; u0 += FILL_STEP) {
+                uint64_t qv[FILL_STEP];
+#pragma unroll
+                for (int u = 0; u < FILL_STEP; ++u) {
+                    const uint32_t i = (uint32_t)tid + (uint32_t)(u0 + u) * OW_THREADS;
+                    qv[u] = (u0 + u < QPER && i < cnt_q) ? Q[p0 + i] : 0ull;
+                }
+#pragma unroll
+                for (int u = 0; u < FILL_STEP; ++u) {
+                    const uint32_t i = (uint32_t)tid + (uint32_t)(u0 + u) * OW_THREADS;
+                    if (u0 + u < QPER && i < cnt_q) s_q[i] = qv[u];
+                }
+            }
+        }
+        // padding buckets behind the table slice; two words of 2^64 - 1 behind the query slice: a lookup reads the two query
+        // hashes at its bucket's start whatever the bucket holds, and scans on while they are below its hash -- the slice is
+        // sorted, so what follows a bucket is larger than any hash that falls into it, and the padding ends every scan
+        if (tid < 2) { s_t[bpr + 1 + tid] = (TT)cnt_q; s_q[cnt_q + tid] = ~0ull; }
+        if (tid >= 64 && tid < 64 + 3 && cnt_t + (uint32_t)(tid - 64) <= bpr) s_t[cnt_t + (uint32_t)(tid - 64)] = (TT)cnt_q;   // a short last range
+        __syncthreads();
+        if (!last) {                                                     // the next range's bounds
+            const uint32_t nb0 = b1, nb1 = nb0 + bpr < n_buckets ? nb0 + bpr : n_buckets;
+            n_p0 = T[nb0];
+            n_p1 = T[nb1];
+        }
+#pragma unroll
+        for (int v0 = 0; v0 < SLOTS; v0 += BATCH) {
+            if ((uint32_t)wave + (uint32_t)v0 * OW_WAVES >= n_rows) break;  // no rows in this batch or behind it (wave-uniform)
+            uint64_t in[BATCH];
+            uint32_t t0[BATCH], t1[BATCH];
+#pragma unroll
+            for (int w = 0; w < BATCH; ++w) {
+                const int k = v0 + w;
+                if (k >= SLOTS) continue;
+                in[w] = mask_of(e[k] < upper);                               // lanes past the row's end hold 2^64 - 1
+                uint32_t kk = (uint32_t)(e[k] >> shift) - b0;                // < bpr for the lanes of `in`
+                kk = kk < bpr ? kk : bpr;                                    // the others: the padding buckets behind the slice
+                t0[w] = (uint32_t)s_t[kk];
+                t1[w] = (uint32_t)s_t[kk + 1];
+            }
+            uint64_t qa[BATCH], qb[BATCH];
+#pragma unroll
+            for (int w = 0; w < BATCH; ++w) {
+                if (v0 + w >= SLOTS) continue;
+                qa[w] = s_q[t0[w]];
+                qb[w] = s_q[t0[w] + 1];
+            }
+#pragma unroll
+            for (int w = 0; w < BATCH; ++w) {
+                const int k = v0 + w;
+                if (k >= SLOTS) continue;
+                uint64_t found = in[w] & (mask_of(qa[w] == e[k]) | mask_of(qb[w] == e[k]));
+                // a bucket of three or more whose second hash is still below the lane's hash (rare: ~1 visit in 3 has such a
+                // lane, and a scan is a divergent loop over LDS): scan on.  (Without the size test every hash ABOVE both hashes of
+                // a bucket of two came here too -- 3 % of the lookups, three visits in four: 2.46 -> 3.44 ms.)
+                const uint64_t deep = mask_of(t1[w] > t0[w] + 2u) & mask_of(qb[w] < e[k]);
+                if (__builtin_expect(deep != 0ull, 0)) {
+                    bool hit = false;
+                    if (lanes_of(deep))
+                        for (uint32_t t = t0[w] + 2;; ++t) {
+                            const uint64_t qv = s_q[t];
+                            if (qv >= e[k]) { hit = qv == e[k]; break; }
+                        }
+                    found |= in[w] & mask_of(hit);
+                }
+                hv[k] += (uint32_t)__popcll(found);
+                uint32_t taken = (uint32_t)__popcll(in[w]);
+                pos[k] += taken;
+                while (__builtin_expect(taken == 64u, 0)) {                  // the row's part of this range goes on (rare): block by block
+                    const uint32_t left = end[k] - pos[k];
+                    const uint64_t ev = (uint32_t)lane < left ? (rows + pos[k])[lane] : ~0ull;
+                    const bool more = ev < upper;
+                    bool h2 = false;
+                    if (more) {
+                        uint32_t k2 = (uint32_t)(ev >> shift) - b0;
+                        k2 = k2 < bpr ? k2 : bpr;
+                        for (uint32_t t = (uint32_t)s_t[k2];; ++t) {
+                            const uint64_t qv = s_q[t];
+                            if (qv >= ev) { h2 = qv == ev; break; }
+                        }
+                    }
+                    hv[k] += (uint32_t)__popcll(mask_of(h2));
+                    taken = (uint32_t)__popcll(mask_of(more));
+                    pos[k] += taken;
+                }
+                if (!last) ask(k);                                           // the row's part of the next range, a range ahead
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < SLOTS; ++k) {
+        const uint32_t i = (uint32_t)wave + (uint32_t)k * OW_WAVES;
+        if (lane == 0 && i < n_rows) counts[d_lo + i] = hv[k];
+    }
 }
 
 // op 0: overlap[d] = cnt[d]; op 1: overlap[d] -= cnt[d], saturating (rows at 0 stay dropped, index/__init__.py:908-909)
@@ -2472,47 +2670,82 @@ hipError_t overlap_ranges_launch(const uint64_t* Q, uint64_t nq, const uint64_t*
     uint32_t wbpr = OW_BUCKETS;                                            // buckets per range of the wide form: about 10,000 query hashes
     while (wbpr > 64 && (double)wbpr * (double)nq / (double)buckets > 10000.0) wbpr >>= 1;
     const uint32_t w_ranges = (buckets + wbpr - 1) / wbpr;
-    // the widest range of either partition decides whether its LDS has room: both maxima come back with one synchronisation
-    unsigned int widest = 0, w_widest = 0;
+    // the Two form: about 6,800 query hashes per range, any number of buckets up to its table's room (not a power of two)
+    uint32_t w2bpr = (uint32_t)(6800.0 * (double)buckets / (double)nq);
+    if (w2bpr > (uint32_t)OwTwo::BUCKETS) w2bpr = OwTwo::BUCKETS;
+    if (w2bpr < 64) w2bpr = 64;
+    const uint32_t w2_ranges = (buckets + w2bpr - 1) / w2bpr;
+    // the widest range of either partition decides whether its LDS has room: all maxima come back with one synchronisation
+    unsigned int widest = 0, w_widest = 0, w2_widest = 0;
     {
         unsigned int* d_widest = (unsigned int*)(cnt + ndb);                // the 64 spare bytes, zeroed above
         if (!no_stream)
             hipLaunchKernelGGL(stream_range_max_kernel, dim3((n_ranges + 255) / 256), dim3(256), 0, stream, (const uint32_t*)table, buckets,
                                n_ranges, bpr, d_widest);
-        if (try_wide)
+        if (try_wide) {
             hipLaunchKernelGGL(stream_range_max_kernel, dim3((w_ranges + 255) / 256), dim3(256), 0, stream, (const uint32_t*)table, buckets,
                                w_ranges, wbpr, d_widest + 1);
+            hipLaunchKernelGGL(stream_range_max_kernel, dim3((w2_ranges + 255) / 256), dim3(256), 0, stream, (const uint32_t*)table, buckets,
+                               w2_ranges, w2bpr, d_widest + 2);
+        }
         if (!no_stream || try_wide) {
-            SMG_TRY(hipMemcpyAsync(&pin.p[1], d_widest, 8, hipMemcpyDeviceToHost, stream));
+            SMG_TRY(hipMemcpyAsync(&pin.p[1], d_widest, 16, hipMemcpyDeviceToHost, stream));
             SMG_TRY(hipStreamSynchronize(stream));
             widest = (unsigned int)(pin.p[1] & 0xffffffffull);
             w_widest = (unsigned int)(pin.p[1] >> 32);
+            w2_widest = (unsigned int)(pin.p[2] & 0xffffffffull);
         }
     }
     hipError_t e = hipSuccess;
     bool wide_done = false;
     if (try_wide) {
-        static int attr_state = 0;
-        if (attr_state == 0) {
-            const hipError_t ea = hipFuncSetAttribute((const void*)overlap_wide_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)OW_LDS);
-            attr_state = ea == hipSuccess ? 1 : -1;
-            if (ea != hipSuccess) (void)hipGetLastError();
-        }
-        if (attr_state > 0 && w_widest <= (unsigned)OW_QCAP) {
-            uint64_t rpw = (ndb + (uint64_t)n_cu_w - 1) / (uint64_t)n_cu_w;
-            if (rpw > (uint64_t)OW_ROWS) {
-                // more rows than one round of workgroups holds: as many rounds as that takes, all of them full (a last round
-                // of a few workgroups would cost a whole pass over the query for a fraction of the rows)
-                const uint64_t per_round = (uint64_t)OW_ROWS * (uint64_t)n_cu_w;
-                const uint64_t slots = ((ndb + per_round - 1) / per_round) * (uint64_t)n_cu_w;
+        // rows a workgroup owns: every workgroup resident at once, in full rounds (a last round of a few workgroups would cost a
+        // whole pass over the query for a fraction of the rows); SMG_OVERLAP_ROWS overrides (tuning / tests)
+        static const uint64_t rpw_env = [] { const char* e = getenv("SMG_OVERLAP_ROWS"); return e ? (uint64_t)atoll(e) : 0ull; }();
+        auto rows_per_wg = [&](uint64_t resident, uint64_t cap) {
+            uint64_t rpw = (ndb + resident - 1) / resident;
+            if (rpw > cap) {
+                const uint64_t per_round = cap * resident;
+                const uint64_t slots = ((ndb + per_round - 1) / per_round) * resident;
                 rpw = (ndb + slots - 1) / slots;
             }
-            static const uint64_t rpw_env = [] { const char* e = getenv("SMG_OVERLAP_ROWS"); return e ? (uint64_t)atoll(e) : 0ull; }();
-            if (rpw_env) rpw = rpw_env;                                        // tuning: rows a workgroup owns
-            if (rpw > (uint64_t)OW_ROWS) rpw = OW_ROWS;
-            if (rpw < 1) rpw = 1;
+            if (rpw_env) rpw = rpw_env;
+            if (rpw > cap) rpw = cap;
+            return rpw < 1 ? (uint64_t)1 : rpw;
+        };
+        static int attr_state = 0;
+        if (attr_state == 0) {
+            const hipError_t ea = hipFuncSetAttribute((const void*)overlap_wide_kernel<OwOne>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)OwOne::LDS);
+            const hipError_t eb = hipFuncSetAttribute((const void*)overlap_wide_kernel<OwTwo>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)OwTwo::LDS);
+            attr_state = ea == hipSuccess && eb == hipSuccess ? 1 : -1;
+            if (attr_state < 0) (void)hipGetLastError();
+        }
+        // SMG_OVERLAP_WIDE=lean|one|two: the lean-visit kernel (default), the round-3 kernel, its two-workgroups-per-CU geometry
+        static const int pick = [] { const char* e = getenv("SMG_OVERLAP_WIDE"); return !e ? 0 : !strcmp(e, "one") ? 1 : !strcmp(e, "two") ? 2 : !strcmp(e, "lean") ? 3 : 0; }();
+        static int lean_attr = 0;
+        constexpr size_t LEAN_LDS = ((size_t)OwOne::QCAP + 2) * 8 + OwOne::T_BYTES;
+        if (lean_attr == 0) {
+            const hipError_t ea = hipFuncSetAttribute((const void*)overlap_lean_kernel<OwOne>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LEAN_LDS);
+            lean_attr = ea == hipSuccess ? 1 : -1;
+            if (lean_attr < 0) (void)hipGetLastError();
+        }
+        // (2^64 - 1 in the query: the lean kernel's filler value would be a hit -- the round-3 kernel handles it)
+        if (lean_attr > 0 && (pick == 0 || pick == 3) && w_widest <= (unsigned)OwOne::QCAP && q_max != ~0ull) {
+            const uint64_t rpw = rows_per_wg((uint64_t)n_cu_w, OwOne::ROWS);
             const uint64_t n_wg = (ndb + rpw - 1) / rpw;
-            hipLaunchKernelGGL(overlap_wide_kernel, dim3((unsigned)n_wg), dim3(OW_THREADS), OW_LDS, stream, Q, (const uint32_t*)table, buckets,
+            hipLaunchKernelGGL(overlap_lean_kernel<OwOne>, dim3((unsigned)n_wg), dim3(OW_THREADS), LEAN_LDS, stream, Q, (const uint32_t*)table, buckets,
+                               shift, hashes, offsets, ndb, (uint32_t)rpw, w_ranges, wbpr, cnt);
+            wide_done = true;
+        } else if (attr_state > 0 && pick != 1 && pick != 0 && w2_widest <= (unsigned)OwTwo::QCAP && w2_widest > 0) {
+            const uint64_t rpw = rows_per_wg((uint64_t)n_cu_w * 2, OwTwo::ROWS);
+            const uint64_t n_wg = (ndb + rpw - 1) / rpw;
+            hipLaunchKernelGGL(overlap_wide_kernel<OwTwo>, dim3((unsigned)n_wg), dim3(OW_THREADS), OwTwo::LDS, stream, Q, (const uint32_t*)table, buckets,
+                               shift, q_max, hashes, offsets, ndb, (uint32_t)rpw, w2_ranges, w2bpr, cnt);
+            wide_done = true;
+        } else if (attr_state > 0 && pick != 2 && w_widest <= (unsigned)OwOne::QCAP) {
+            const uint64_t rpw = rows_per_wg((uint64_t)n_cu_w, OwOne::ROWS);
+            const uint64_t n_wg = (ndb + rpw - 1) / rpw;
+            hipLaunchKernelGGL(overlap_wide_kernel<OwOne>, dim3((unsigned)n_wg), dim3(OW_THREADS), OwOne::LDS, stream, Q, (const uint32_t*)table, buckets,
                                shift, q_max, hashes, offsets, ndb, (uint32_t)rpw, w_ranges, wbpr, cnt);
             wide_done = true;
         } else if (only_wide) {

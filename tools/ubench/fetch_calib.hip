@@ -21,7 +21,7 @@ namespace calib {
 
 // grid-stride streaming read, W bytes per lane and step, consecutive lanes consecutive addresses; the sum keeps the loads alive
 template <typename T>
-__global__ __launch_bounds__(256) void read_kernel(const T* __restrict__ src, uint64_t n, uint32_t* sink) {
+__device__ __forceinline__ void read_body(const T* __restrict__ src, uint64_t n, uint32_t* sink) {
     uint32_t acc = 0;
     for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
         const T v = src[i];
@@ -31,6 +31,9 @@ __global__ __launch_bounds__(256) void read_kernel(const T* __restrict__ src, ui
     }
     if (acc == 0x12345u) *sink = acc;
 }
+__global__ __launch_bounds__(256) void read_b32_kernel(const uint32_t* __restrict__ src, uint64_t n, uint32_t* sink) { read_body(src, n, sink); }
+__global__ __launch_bounds__(256) void read_b64_kernel(const uint2* __restrict__ src, uint64_t n, uint32_t* sink) { read_body(src, n, sink); }
+__global__ __launch_bounds__(256) void read_b128_kernel(const uint4* __restrict__ src, uint64_t n, uint32_t* sink) { read_body(src, n, sink); }
 
 // the same stream through `global_load_dword ... lds` (one dword per lane straight into LDS, 256 B per wave-instruction)
 __global__ __launch_bounds__(256) void read_lds_b32_kernel(const uint32_t* __restrict__ src, uint64_t n, uint32_t* sink) {
@@ -67,8 +70,20 @@ __global__ __launch_bounds__(256) void read_rowvisit_b64_kernel(const uint64_t* 
     if (acc == 0x12345u) *sink = (uint32_t)acc;
 }
 
+// the overlap pass's visits as they are: a wave loads 512 B at a row's cursor and the cursor then moves on by `advance` bytes
+// (what the visit consumed, ~45 hashes of the 64 loaded): the unconsumed tail is loaded again by the next visit
+__global__ __launch_bounds__(256) void read_cursor_b64_kernel(const uint64_t* __restrict__ src, uint64_t n_rows, uint64_t row_words,
+                                                             uint32_t visits, uint32_t advance_words, uint32_t* sink) {
+    uint64_t acc = 0;
+    const uint32_t lane = threadIdx.x & 63;
+    const uint64_t wave = ((uint64_t)blockIdx.x * 256 + threadIdx.x) >> 6, n_waves = (uint64_t)gridDim.x * 4;
+    for (uint32_t v = 0; v < visits; ++v)
+        for (uint64_t r = wave; r < n_rows; r += n_waves) acc ^= src[r * row_words + (uint64_t)v * advance_words + lane];
+    if (acc == 0x12345u) *sink = (uint32_t)acc;
+}
+
 template <typename T>
-__global__ __launch_bounds__(256) void write_kernel(T* __restrict__ dst, uint64_t n, uint32_t seed) {
+__device__ __forceinline__ void write_body(T* __restrict__ dst, uint64_t n, uint32_t seed) {
     for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
         T v;
         uint32_t* w = reinterpret_cast<uint32_t*>(&v);
@@ -77,6 +92,9 @@ __global__ __launch_bounds__(256) void write_kernel(T* __restrict__ dst, uint64_
         dst[i] = v;
     }
 }
+__global__ __launch_bounds__(256) void write_b32_kernel(uint32_t* __restrict__ dst, uint64_t n, uint32_t seed) { write_body(dst, n, seed); }
+__global__ __launch_bounds__(256) void write_b64_kernel(uint2* __restrict__ dst, uint64_t n, uint32_t seed) { write_body(dst, n, seed); }
+__global__ __launch_bounds__(256) void write_b128_kernel(uint4* __restrict__ dst, uint64_t n, uint32_t seed) { write_body(dst, n, seed); }
 
 // 4-byte scatter: lane i writes element perm(i) (every store its own line): posting lists filled one entry at a time
 __global__ __launch_bounds__(256) void write_scatter_b32_kernel(uint32_t* __restrict__ dst, uint64_t n_stores, uint64_t n_words, uint32_t seed) {
@@ -98,36 +116,40 @@ int main(int argc, char** argv) {
     const int grid = 256 * 8;
     using namespace calib;
     for (int rep = 0; rep < 2; ++rep) {
-        hipLaunchKernelGGL((read_kernel<uint32_t>), dim3(grid), dim3(256), 0, 0, (const uint32_t*)a, bytes / 4, sink);
-        hipLaunchKernelGGL((read_kernel<uint2>), dim3(grid), dim3(256), 0, 0, (const uint2*)b, bytes / 8, sink);
-        hipLaunchKernelGGL((read_kernel<uint4>), dim3(grid), dim3(256), 0, 0, (const uint4*)a, bytes / 16, sink);
+        hipLaunchKernelGGL(read_b32_kernel, dim3(grid), dim3(256), 0, 0, (const uint32_t*)a, bytes / 4, sink);
+        hipLaunchKernelGGL(read_b64_kernel, dim3(grid), dim3(256), 0, 0, (const uint2*)b, bytes / 8, sink);
+        hipLaunchKernelGGL(read_b128_kernel, dim3(grid), dim3(256), 0, 0, (const uint4*)a, bytes / 16, sink);
         hipLaunchKernelGGL(read_lds_b32_kernel, dim3(grid), dim3(256), 0, 0, (const uint32_t*)b, bytes / 4, sink);
         // strided: bytes / 128 loads of 8 B, 128 B apart -> every load its own 128-byte line: 8 useful bytes of every line
         hipLaunchKernelGGL(read_strided_b64_kernel, dim3(grid), dim3(256), 0, 0, (const uint64_t*)a, bytes / 128, (uint64_t)16, sink);
         // row visits: rows of 40,000 bytes (5,000 u64), 4 visits of 512 B at the row's head
         hipLaunchKernelGGL(read_rowvisit_b64_kernel, dim3(grid), dim3(256), 0, 0, (const uint64_t*)b, bytes / 40000, (uint64_t)5000, 4u, sink);
-        hipLaunchKernelGGL((write_kernel<uint32_t>), dim3(grid), dim3(256), 0, 0, (uint32_t*)a, bytes / 4, 7u);
-        hipLaunchKernelGGL((write_kernel<uint2>), dim3(grid), dim3(256), 0, 0, (uint2*)b, bytes / 8, 7u);
-        hipLaunchKernelGGL((write_kernel<uint4>), dim3(grid), dim3(256), 0, 0, (uint4*)a, bytes / 16, 7u);
+        // 100 visits per 40 KB row, each 512 B wide, the cursor advancing 45 hashes: every row is walked end to end once
+        hipLaunchKernelGGL(read_cursor_b64_kernel, dim3(grid), dim3(256), 0, 0, (const uint64_t*)a, bytes / 40000, (uint64_t)5000, 100u, 45u, sink);
+        hipLaunchKernelGGL(write_b32_kernel, dim3(grid), dim3(256), 0, 0, (uint32_t*)a, bytes / 4, 7u);
+        hipLaunchKernelGGL(write_b64_kernel, dim3(grid), dim3(256), 0, 0, (uint2*)b, bytes / 8, 7u);
+        hipLaunchKernelGGL(write_b128_kernel, dim3(grid), dim3(256), 0, 0, (uint4*)a, bytes / 16, 7u);
         hipLaunchKernelGGL(write_scatter_b32_kernel, dim3(grid), dim3(256), 0, 0, (uint32_t*)b, bytes / 64, bytes / 4, 7u);
     }
     CHECK(hipDeviceSynchronize());
     // what each kernel moved, for tools/calib_table.py
     printf("{\"buffer_bytes\": %llu, \"kernels\": {"
-           "\"read_kernel<unsigned int>\": {\"read\": %llu, \"shape\": \"4 B/lane coalesced stream\"}, "
-           "\"read_kernel<HIP_vector_type<unsigned int, 2u>>\": {\"read\": %llu, \"shape\": \"8 B/lane coalesced stream\"}, "
-           "\"read_kernel<HIP_vector_type<unsigned int, 4u>>\": {\"read\": %llu, \"shape\": \"16 B/lane coalesced stream\"}, "
+           "\"read_b32_kernel\": {\"read\": %llu, \"shape\": \"4 B/lane coalesced stream\"}, "
+           "\"read_b64_kernel\": {\"read\": %llu, \"shape\": \"8 B/lane coalesced stream\"}, "
+           "\"read_b128_kernel\": {\"read\": %llu, \"shape\": \"16 B/lane coalesced stream\"}, "
            "\"read_lds_b32_kernel\": {\"read\": %llu, \"shape\": \"global_load_dword ... lds, 256 B per wave-instruction\"}, "
            "\"read_strided_b64_kernel\": {\"read\": %llu, \"lines\": %llu, \"shape\": \"8 B/lane, lanes 128 B apart (one line per lane)\"}, "
            "\"read_rowvisit_b64_kernel\": {\"read\": %llu, \"shape\": \"a wave reads 512 B of one row per step (8 B/lane), rows 40 KB apart, 4 steps per row\"}, "
-           "\"write_kernel<unsigned int>\": {\"write\": %llu, \"shape\": \"4 B/lane coalesced stream\"}, "
-           "\"write_kernel<HIP_vector_type<unsigned int, 2u>>\": {\"write\": %llu, \"shape\": \"8 B/lane coalesced stream\"}, "
-           "\"write_kernel<HIP_vector_type<unsigned int, 4u>>\": {\"write\": %llu, \"shape\": \"16 B/lane coalesced stream\"}, "
+           "\"read_cursor_b64_kernel\": {\"read\": %llu, \"shape\": \"the overlap pass's row visits: 512 B loaded at the row's cursor, cursor advances 45 hashes (360 B) per visit; known bytes = the part of the rows walked once\"}, "
+           "\"write_b32_kernel\": {\"write\": %llu, \"shape\": \"4 B/lane coalesced stream\"}, "
+           "\"write_b64_kernel\": {\"write\": %llu, \"shape\": \"8 B/lane coalesced stream\"}, "
+           "\"write_b128_kernel\": {\"write\": %llu, \"shape\": \"16 B/lane coalesced stream\"}, "
            "\"write_scatter_b32_kernel\": {\"write\": %llu, \"lines\": %llu, \"shape\": \"4 B/lane scattered (one line per lane)\"}}}\n",
            (unsigned long long)bytes, (unsigned long long)bytes, (unsigned long long)bytes, (unsigned long long)bytes,
            (unsigned long long)(bytes / 4 / 256 / grid * 256 * grid * 4),
            (unsigned long long)(bytes / 128 * 8), (unsigned long long)(bytes / 128),
            (unsigned long long)(bytes / 40000 * 4 * 512),
+           (unsigned long long)(bytes / 40000 * (99 * 45 + 64) * 8),
            (unsigned long long)bytes, (unsigned long long)bytes, (unsigned long long)bytes,
            (unsigned long long)(bytes / 64 * 4), (unsigned long long)(bytes / 64));
     return 0;
