@@ -42,9 +42,21 @@ LDS_PEAK_GBS = 150_000.0   # same guide, LDS: ~150 TB/s aggregate for ds_read_b6
 # profiles/pmcfile.py, which also refuses them (null + note) when the kernel's source files have changed since the
 # profile was taken -- bench.py itself cannot run counters (they need their own rocprofv3 passes, tools/prof_r03.sh).
 sys.path.insert(0, os.path.join(ROOT, "profiles"))
-from pmcfile import PmcFile  # noqa: E402
-PMC_FILE = "profiles/r03_pmc.txt"
-PMC_GATHER_FILE = "profiles/r03_gather_pmc.txt"
+from pmcfile import Calibration, PmcFile, ValuMix  # noqa: E402
+
+
+def _newest(*names):
+    "the first of these summaries that exists (a round re-profiles what it changed; untouched kernels keep their older summary)"
+    for n in names:
+        if os.path.exists(os.path.join(ROOT, n)):
+            return n
+    return names[-1]
+
+
+PMC_FILE = _newest("profiles/r04_pmc.txt", "profiles/r03_pmc.txt")
+PMC_GATHER_FILE = _newest("profiles/r04_gather_pmc.txt", "profiles/r03_gather_pmc.txt")
+PMC_COMPARE_FILE = _newest("profiles/r04_compare_pmc.txt", "profiles/r03_compare_pmc.txt")
+COMPARE_BITS_SOURCES = ["bitindex.hip"]
 SKETCH_SOURCES = ["sketch.hip", "kmer_core.hpp", "murmur3.hpp"]
 GATHER_SOURCES = ["gather.hip", "qindex.hpp"]
 PMC_C2_INPUT_BYTES = 9_990_000_999                        # the launch the sketch counters were taken on (default C2 batch)
@@ -63,6 +75,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-compare", action="store_true", help="skip every secondary metric (compare / gather)")
     ap.add_argument("--no-xl", action="store_true", help="skip the XL multi-GPU configurations (compare_xl_dist, gather_xl_dist)")
+    ap.add_argument("--no-io", action="store_true", help="skip the file ingest / signature loading metrics (they write ~1.8 GB to a temp directory)")
     ap.add_argument("--cpu-sample", type=float, default=0.0, help="bases for the N-thread CPU sketch leg (0 = auto)")
     return ap.parse_args()
 
@@ -241,6 +254,13 @@ def main():
         except Exception as e:
             extra["error"] = repr(e)
 
+    # ---- the steps either side of the kernels, on this box (N = 1): file ingest and bulk signature loading ----
+    if rank == 0 and world == 1 and not args.no_compare and not args.no_io:
+        try:
+            io_extras(extra, torch, np, dev, smd)
+        except Exception as e:
+            extra["io_error"] = repr(e)
+
     if rank == 0:
         extra["arena"] = {**smd.arena_stats(), "what": "the library's device arena (csrc/arena.hpp) over the whole run: driver "
                           "allocator calls, nanoseconds inside them, allocations served from cached blocks"}
@@ -288,20 +308,28 @@ def sketch_counters(n_bytes, ksize, bases_per_step):
     fetch, write = (pmc.get(K, "FETCH_SIZE"), pmc.get(K, "WRITE_SIZE")) if not why else (None, None)
     if why or fetch is None or write is None:
         return {"traffic": None, "traffic_note": why or f"{PMC_FILE} has no FETCH_SIZE / WRITE_SIZE rows for {K}", "valu": None}
-    out = {"traffic": int((2 * fetch + write) * 1024),
-           "traffic_from": PMC_FILE + ": 2 x FETCH_SIZE (gfx950 counts half of a 16 B/lane coalesced read, MI355X_MICROARCH.md) + "
-                           "WRITE_SIZE, KiB per dispatch, separate --pmc passes of `bench.py --steps 1 --warmup 0 --no-cpu-baseline "
-                           "--no-compare`; source hashes of " + ", ".join(SKETCH_SOURCES) + " match the present tree"}
+    cal = Calibration()
+    if not cal.ok:
+        return {"traffic": None, "traffic_note": f"{cal.path} is absent or its access widths disagree: the counters cannot be turned into bytes", "valu": None}
+    out = {"traffic": int(cal.bytes_read(fetch) + cal.bytes_written(write)),
+           "traffic_from": PMC_FILE + ": FETCH_SIZE / WRITE_SIZE (KiB per dispatch, separate --pmc passes of `bench.py --steps 1 --warmup 0 "
+                           "--no-cpu-baseline --no-compare`), turned into bytes with " + cal.describe() + "; source hashes of " +
+                           ", ".join(SKETCH_SOURCES) + " match the present tree"}
     g = {c: pmc.get(K, c) for c in ("SQ_INSTS_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "GRBM_GUI_ACTIVE")}
     if all(v for v in g.values()):
         gui = g["GRBM_GUI_ACTIVE"] / 8                     # summed over the 8 XCDs
+        mix = ValuMix()
+        mix_why = mix.stale()
+        cost = None if mix_why else mix.doc["mix_cycles_per_valu_inst"]
         out["valu"] = {"insts_per_kmer": round(g["SQ_INSTS_VALU"] * 64 / bases_per_step, 1),
-                       # VALU wave-instructions per SIMD and shader cycle (the ubenchmarked cost of this kernel's mix is 2.4
-                       # cycles for and/or/xor/add/shift, 4.3 for multiplies, v_add3, permutes, selects: r01_ubench_valu.txt)
                        "valu_insts_per_simd_cycle": round(g["SQ_INSTS_VALU"] / N_SIMDS / gui, 4),
                        "cycles_per_valu_inst_per_simd": round(N_SIMDS * gui / g["SQ_INSTS_VALU"], 2),
-                       "mix_cycles_per_valu_inst": 3.76,
-                       "valu_issue_busy_frac": round(3.76 * g["SQ_INSTS_VALU"] / N_SIMDS / gui, 3),
+                       # average issue cost of THIS kernel's instruction mix, from its disassembly and the per-opcode costs of
+                       # profiles/r01_ubench_valu.txt (tools/valu_mix.py; refused when the kernel's sources changed since)
+                       "mix_cycles_per_valu_inst": cost,
+                       "mix_from": mix_why or (mix.path + ": static histogram of the main loop, hot path + wave-conditional blocks weighted by their "
+                                               "probability; predicts %.1f VALU instructions per k-mer" % mix.doc["expected_valu_insts_per_kmer"]),
+                       "valu_issue_busy_frac": None if cost is None else round(cost * g["SQ_INSTS_VALU"] / N_SIMDS / gui, 3),
                        "wave_cycles_issuing_frac": round(g["SQ_ACTIVE_INST_ANY"] / g["SQ_WAVE_CYCLES"], 3),
                        "wave_cycles_waiting_to_issue_frac": round(g["SQ_WAIT_INST_ANY"] / g["SQ_WAVE_CYCLES"], 3),
                        "from": PMC_FILE + " (SQ_INSTS_VALU, SQ_WAVE_CYCLES, SQ_WAIT_INST_ANY, SQ_ACTIVE_INST_ANY, GRBM_GUI_ACTIVE)"}
@@ -311,9 +339,12 @@ def sketch_counters(n_bytes, ksize, bases_per_step):
 
 
 def gather_counters(db_bytes):
-    "(build traffic, overlap traffic, note): FETCH_SIZE + WRITE_SIZE per build / per overlap pass from the committed C5 PMC summary"
+    "(build traffic, overlap traffic, note): bytes per build / per overlap pass from the committed C5 PMC summary, calibrated"
     pmc = PmcFile(PMC_GATHER_FILE)
     why = pmc.stale(GATHER_SOURCES) if db_bytes == 3997497344 else "counters were taken on config C5 only"
+    cal = Calibration()
+    if not why and not cal.ok:
+        why = f"{cal.path} is absent or its access widths disagree"
     if why:
         return None, None, why
     build = 0.0
@@ -322,13 +353,52 @@ def gather_counters(db_bytes):
         f, w = pmc.get(k, "FETCH_SIZE"), pmc.get(k, "WRITE_SIZE")
         if f is None or w is None:
             return None, None, f"{PMC_GATHER_FILE} has no rows for {k}"
-        build += f + w
-    ok = "overlap_wide_kernel" if pmc.get("overlap_wide_kernel", "FETCH_SIZE") is not None else "stream_lookup_kernel<3>"
-    fo, wo = pmc.get(ok, "FETCH_SIZE"), pmc.get(ok, "WRITE_SIZE")
-    over = None if fo is None or wo is None else int((fo + wo) * 1024)
-    return int(build * 1024), over, (PMC_GATHER_FILE + ": FETCH_SIZE + WRITE_SIZE as counted (KiB per dispatch, tools/bench_gather.py under separate "
-                                     "--pmc passes); FETCH_SIZE counts half of the bytes of wide coalesced reads on gfx950, so reads of the "
-                                     "database proper are under-counted by up to 2x")
+        build += cal.bytes_read(f) + cal.bytes_written(w)
+    ok = next((k for k in ("overlap_lean_kernel", "overlap_wide_kernel", "stream_lookup_kernel<3>") if pmc.get(k, "FETCH_SIZE") is not None), None)
+    fo, wo = (pmc.get(ok, "FETCH_SIZE"), pmc.get(ok, "WRITE_SIZE")) if ok else (None, None)
+    over = None if fo is None else int(cal.bytes_read(fo) + (cal.bytes_written(wo) if wo is not None else 0))
+    return int(build), over, (PMC_GATHER_FILE + ": FETCH_SIZE / WRITE_SIZE (KiB per dispatch, tools/bench_gather.py under separate --pmc passes) turned "
+                              "into bytes with " + cal.describe())
+
+
+def bitmatrix_roofline(n, universe, matrix_ms):
+    """VALU-issue roofline of the dense compare path (bitmatrix_kernel): the work is one AND + one population count per 32-bit word
+    of every pair of the tiles on or above the diagonal; the floor is those two instructions at their measured issue costs
+    (v_and_b32 2.43, v_bcnt_u32_b32 4.26 cycles per wave-instruction per SIMD: profiles/r01_ubench_valu.txt) on 1,024 SIMDs."""
+    words = (universe + 31) // 32
+    nt = (n + 63) // 64
+    pair_words = nt * (nt + 1) // 2 * 4096 * words
+    clock = 2.4e9
+    peak = N_SIMDS * clock / (2.43 + 4.26) * 64
+    achieved = pair_words / (matrix_ms * 1e-3)
+    out = {"bound": "valu", "kernel": "bitmatrix_kernel", "achieved": round(achieved / 1e12, 3), "peak": round(peak / 1e12, 3),
+           "unit": "T(pair x 32-bit word)/s", "frac": round(achieved / peak, 4), "pair_words": int(pair_words), "ms": round(matrix_ms, 3),
+           "what": "AND + popcount of one 32-bit word of one pair = 2 VALU instructions at 2.43 + 4.26 cycles per wave-instruction per "
+                   "SIMD (profiles/r01_ubench_valu.txt) x 1,024 SIMDs x 2.4 GHz; tiles on or above the diagonal (64 x 64 pairs each); "
+                   "the time includes the mirror pass"}
+    pmc = PmcFile(PMC_COMPARE_FILE)
+    why = pmc.stale(COMPARE_BITS_SOURCES)
+    insts = None if why else pmc.get("bitmatrix_kernel", "SQ_INSTS_VALU")
+    if insts:
+        out["valu_insts_per_word_step"] = round(insts / (pair_words / 64), 3)
+        out["counters_from"] = PMC_COMPARE_FILE + " (SQ_INSTS_VALU per triangle launch at C4)"
+    else:
+        out["counters_note"] = why or f"{PMC_COMPARE_FILE} has no SQ_INSTS_VALU row for bitmatrix_kernel"
+    return out
+
+
+def loop_roofline(rounds, loop_ms):
+    """Latency roofline of the resident gather loop: a round is a chain of dependent trips -- the winner's positions, the run
+    bounds of the newly covered hashes, their posting entries (three trips to HBM, ~900 cycles each: MI355X_MICROARCH.md) -- and
+    one all-gather of 32-byte records among 256 workgroups through device-scope memory (two L2 round trips of ~200 cycles);
+    nothing in a round can start before the round in front has finished (the next winner depends on every decrement)."""
+    clock = 2.4e9
+    floor_us = (3 * 900 + 2 * 200) / clock * 1e6
+    achieved = rounds / (loop_ms * 1e-3)
+    peak = 1e6 / floor_us
+    return {"bound": "latency", "kernel": "gather_loop_kernel", "achieved": round(achieved, 1), "peak": round(peak, 1), "unit": "rounds/s",
+            "frac": round(achieved / peak, 4), "us_per_round": round(loop_ms * 1e3 / max(rounds, 1), 2), "floor_us_per_round": round(floor_us, 2),
+            "what": "dependent chain per round: 3 HBM-miss latencies (~900 cycles) + 2 L2 round trips (~200 cycles) at 2.4 GHz"}
 
 
 def cpu_baseline(args, seq, n_bytes, sk, np):
@@ -583,6 +653,10 @@ def single_gpu_extras(extra, torch, np, dev, be, smd, synth_sketches, synth_gath
                                     "loop_ms": round((t2 - t1) * 1e3, 2),
                                     "us_per_round": round((t2 - t1) * 1e6 / max(len(res), 1), 1)}
     del state, gh, goff, gq
+    try:
+        compare_ext_extras(extra, torch, np, dev, be, smd, synth_sketches, timed)
+    except Exception as e:
+        extra["compare_ext_error"] = repr(e)
     # ---- the kernels behind C4 and C5 one by one, each against its roof ----
     big = synth_sketches(10_000, seed=1234)
     bh, boff = smd.pack_csr(big, device=dev)
@@ -598,7 +672,7 @@ def single_gpu_extras(extra, torch, np, dev, be, smd, synth_sketches, synth_gath
         ca, ja = smd.compare_rows(bh, boff, method="auto")
         torch.cuda.synchronize()
         auto_big = (time.perf_counter() - t0) * 1e3
-    big_build_ms = big_matrix_ms = None
+    big_build_ms = big_matrix_ms = big_universe = None
     for _ in range(2):                                  # the two parts of the auto path on their own (second pass)
         idx_big = None
         torch.cuda.synchronize()
@@ -608,6 +682,7 @@ def single_gpu_extras(extra, torch, np, dev, be, smd, synth_sketches, synth_gath
         big_build_ms = (time.perf_counter() - t0) * 1e3
         if idx_big is None:
             break
+        big_universe = idx_big.universe
         t0 = time.perf_counter()
         smd.compare_rows(bh, boff, common=ca, index=idx_big, want_jaccard=False)
         torch.cuda.synchronize()
@@ -619,11 +694,10 @@ def single_gpu_extras(extra, torch, np, dev, be, smd, synth_sketches, synth_gath
         "pairs": bpairs, "merge_ms": round(ms_big, 2), "merge_pairs_per_s": round(bpairs / (ms_big * 1e-3), 1),
         "merge_roofline": merge_roofline(balg, ms_big),
         "auto_ms": round(auto_big, 2), "auto_pairs_per_s": round(bpairs / (auto_big * 1e-3), 1),
+        "auto_roofline": None if big_matrix_ms is None or big_universe is None else bitmatrix_roofline(bn, big_universe, big_matrix_ms),
         "identical": bool((ca == bc).all().item() and (ja == bj).all().item()),
-        "note": "config C4 (pool-drawn sketches: the cost model picks bit columns); auto includes the index build; "
-                "bitmatrix_kernel is VALU-bound: 2.55 instructions per 32-bit AND+popcount against a floor of 2, ~87 % "
-                "issue-busy at the measured instruction costs (profiles/r03_compare_pmc.txt), upper triangle + mirror; the "
-                "index is built without a sort (csrc/dictindex.hip)"}
+        "note": "config C4 (pool-drawn sketches: the cost model picks bit columns); auto includes the index build (built without a "
+                "sort, csrc/dictindex.hip); auto_roofline prices the matrix part (triangle + mirror) against the VALU issue floor"}
     del bc, bj, ca, ja, bh, boff
     torch.cuda.empty_cache()
     gq5, gh5, goff5 = synth_gather_device(1_000_000, 100_000, 5000, dev)
@@ -658,6 +732,8 @@ def single_gpu_extras(extra, torch, np, dev, be, smd, synth_sketches, synth_gath
         "index_build_roofline": hbm_roofline(build_alg, (t1 - t0) * 1e3,
                                              "8 B per database hash + 4 B per posting + 2 x 4 B query position per element; wall clock of smgpu_gather_new_raw",
                                              traffic=pmc_build, traffic_note=pmc_note, kernels_ms=st5_stats["build_kernels_ms"]),
+        "loop_roofline": loop_roofline(len(res5), st5_stats["loop_gpu_ms"] or (t2 - t1) * 1e3),
+        "loop_fallbacks": st5_stats.get("loop_fallbacks"),
         "loop_floor_ms": round(postings / 23.0e9 * 1e3, 2),
         "loop_note": "a dependent chain of small kernels (latency, not bandwidth): %d rounds touch %.1f MB of postings in all; "
                      "one 64-bit counter decrement per posting, and the device does 23 G such atomics/s on 100,000 counters "
@@ -668,8 +744,154 @@ def single_gpu_extras(extra, torch, np, dev, be, smd, synth_sketches, synth_gath
     ms_ov = timed(lambda: be.overlaps(gq5, gq5.numel(), gh5, goff5, 100_000, cnt, 0), reps=3)
     extra["overlaps_1M_vs_100000"] = {"ms": round(ms_ov, 3), "sketches_per_s": round(100_000 / (ms_ov * 1e-3), 1),
                                       "roofline": hbm_roofline(db_bytes + 8 * int(gq5.numel()), ms_ov,
-                                                               "8 B per database hash + the query once; overlap_wide_kernel (one workgroup per CU, ranges of ~10,000 query hashes in LDS, a wave per row visit)",
+                                                               "8 B per database hash + the query once; overlap_lean_kernel (one workgroup per CU, ranges of ~10,000 query hashes in LDS, a wave per row visit)",
                                                                traffic=pmc_overlap, traffic_note=pmc_note)}
+
+
+def compare_ext_extras(extra, torch, np, dev, be, smd, synth_sketches, timed):
+    """The batched launches of csrc/compare_ext.hip on resident collections (kernel time, HIP events): bottom-k sketches
+    (num = 500, the reference's golden compare shape: tests/test_compare.py:48-63) and abundance-weighted similarity on a
+    config-C3-shaped collection (compare.py:14-64 with track_abundance sketches; minhash.rs:593-680)."""
+    import ctypes as C
+    lib, p, st = be.lib, be._p, be._s
+    n = 1000
+    pairs = n * (n - 1) // 2
+    rng = np.random.default_rng(3)
+    pool = np.unique(rng.integers(1, 2**62, 20_000, dtype=np.int64).astype(np.uint64))
+    rows = [np.sort(rng.choice(pool, size=2000, replace=False))[:500] for _ in range(n)]
+    h, off = smd.pack_csr(rows, device=dev)
+    nums = torch.full((n,), 500, dtype=torch.int32, device=dev)
+    common = torch.zeros((n, n), dtype=torch.int32, device=dev)
+    union = torch.zeros((n, n), dtype=torch.int32, device=dev)
+    jac = torch.zeros((n, n), dtype=torch.float64, device=dev)
+    ms = timed(lambda: be.rustcall(lib.smgpu_compare_num_raw, p(h), p(off), p(nums), n, p(common), p(union), p(jac), st()))
+    alg = 8 * 2 * 500 * pairs
+    extra["compare_num_1000x500"] = {"pairs": pairs, "ms": round(ms, 3), "pairs_per_s": round(pairs / (ms * 1e-3), 1),
+                                     "roofline": merge_roofline(alg, ms),
+                                     "kernel": "compare_ext_kernel<num>: 16 x 16 tiles, one lane per pair, the merge walk stopped after num steps "
+                                               "(minhash.rs:593-621); parity: tests/test_gpu_compare.py::test_num_all_pairs_batched_vs_oracle"}
+    sk = synth_sketches(n, seed=1234)
+    h, off = smd.pack_csr(sk, device=dev)
+    ab = (h % 7 + 1) * ((h >> 3) % 11 + 1)
+    prod = torch.zeros((n, n), dtype=torch.int64, device=dev)
+    sq = torch.zeros((n,), dtype=torch.int64, device=dev)
+    sizes = (off[1:] - off[:-1]).cpu().numpy().astype(np.int64)
+    alg = 2 * 8 * int(sizes.sum() * (n - 1))                 # hashes and abundances of both sketches of every pair
+    ms = timed(lambda: be.rustcall(lib.smgpu_compare_abund_raw, p(h), p(ab), p(off), n, True, p(common), p(prod), p(sq), st()))
+    extra["compare_abund_1000x1000"] = {"pairs": pairs, "ms": round(ms, 3), "pairs_per_s": round(pairs / (ms * 1e-3), 1),
+                                        "roofline": merge_roofline(alg, ms),
+                                        "kernel": "compare_ext_kernel<abund32>: the same tiles accumulating abundance products (minhash.rs:635-680), "
+                                                  "tiles with a long sketch cut into hash-range slices; parity: "
+                                                  "tests/test_gpu_compare.py::test_angular_all_pairs_batched_vs_oracle"}
+
+
+def io_extras(extra, torch, np, dev, smd):
+    """SURVEY.md 8(f) ranks 1-2 measured on THIS box inside the driver's run: a FASTA file -> sketch through the native ingest
+    (command_sketch.py:697,746-768: the reference reads through screed, record by record), the same file as ONE gzip member
+    (many-thread inflate, csrc/pargz.hpp), and a zip of 10,000 signatures -> CSR in HBM (signature.rs:569-659 per file in the
+    reference).  Each against the bound it sits under.  Files go to a temporary directory and are removed."""
+    import gzip
+    import hashlib
+    import io
+    import shutil
+    import tempfile
+    import zipfile
+    import zlib
+    from sourmash_amd import index
+    from sourmash_amd.sketch import sketch_file
+    from sourmash_amd.synth import splitmix64, MAX_HASH_1000
+    tmp = tempfile.mkdtemp(prefix="smg_bench_")
+    try:
+        # ---- 1 GB FASTA (100 records of 1e7 bases, 80-column lines) ----
+        n, rec = 1_000_000_000, 10_000_000
+        seq = smd.synth_dna(n + n // rec, seed=42, record_len=rec, device=dev).cpu().numpy()
+        path = os.path.join(tmp, "synth.fa")
+        bases = 0
+        with open(path, "wb") as fh:
+            for i, r in enumerate(bytes(seq).split(b"\n")):
+                a = np.frombuffer(r, dtype=np.uint8)
+                bases += len(a)
+                fh.write(b">synth_%d\n" % i)
+                full = (len(a) // 80) * 80
+                if full:
+                    fh.write(np.concatenate([a[:full].reshape(-1, 80), np.full((full // 80, 1), 10, dtype=np.uint8)], axis=1).tobytes())
+                if len(a) > full:
+                    fh.write(a[full:].tobytes() + b"\n")
+        del seq
+        file_bytes = os.path.getsize(path)
+        sketch_file(path, "k=31,scaled=1000")                 # warm: page cache, pinned ring, code objects
+        t0 = time.perf_counter()
+        sig, = sketch_file(path, "k=31,scaled=1000")
+        dt = time.perf_counter() - t0
+        plain_md5 = sig.md5sum()
+        extra["ingest_fasta"] = {
+            "file_bytes": file_bytes, "bases": bases, "seconds": round(dt, 3), "Gbase_per_s": round(bases / dt / 1e9, 2),
+            "hashes": len(sig.minhash), "bound": "PCIe H2D of the raw file (~57 GB/s measured on this class of box, tests/probe_host.py) "
+                                                  "and the page-cache read; the record structure is resolved on the GPU",
+            "frac_of_h2d_57GBps": round(file_bytes / dt / 57e9, 3),
+            "what": "smgpu_signature_add_file on a 1 GB FASTA in the page cache -> k=31 scaled=1000 sketch, end to end"}
+        # ---- the same bases as ONE gzip member (level 1), first 400 MB of the file: many-thread inflate vs one zlib stream ----
+        gz = os.path.join(tmp, "synth_part.fa.gz")
+        part_bytes = 0
+        co = zlib.compressobj(1, zlib.DEFLATED, 31)
+        part = os.path.join(tmp, "synth_part.fa")
+        with open(path, "rb") as fi, open(gz, "wb") as fo, open(part, "wb") as fp:
+            while part_bytes < 400_000_000:
+                block = fi.read(16 << 20)
+                if not block:
+                    break
+                # cut at a line end so that the part is a well-formed FASTA
+                block = block[:block.rfind(b"\n") + 1] if part_bytes + len(block) >= 400_000_000 else block
+                fo.write(co.compress(block))
+                fp.write(block)
+                part_bytes += len(block)
+            fo.write(co.flush())
+        sig_part, = sketch_file(part, "k=31,scaled=1000")
+        raw = np.fromfile(part, dtype=np.uint8)
+        nl = np.flatnonzero(raw == 10)
+        heads = np.flatnonzero(raw == ord(">"))
+        part_bases = int(raw.size - nl.size - (nl[np.searchsorted(nl, heads)] - heads).sum())     # minus newlines, minus the header lines' text
+        del raw
+        sketch_file(gz, "k=31,scaled=1000")
+        t0 = time.perf_counter()
+        sig_gz, = sketch_file(gz, "k=31,scaled=1000")
+        dt = time.perf_counter() - t0
+        extra["ingest_gz"] = {
+            "gz_bytes": os.path.getsize(gz), "inflated_bytes": part_bytes, "bases": part_bases, "seconds": round(dt, 3),
+            "Gbase_per_s": round(part_bases / dt / 1e9, 2), "same_sketch_as_the_plain_file": bool(sig_gz.md5sum() == sig_part.md5sum()),
+            "host_threads": os.cpu_count(), "bound": "zlib inflate on the host's cores: one stream does ~0.25 GB/s; csrc/pargz.hpp cuts one "
+                                                     "member into spans inflated on all usable threads",
+            "what": "one gzip member (level 1) of 400 MB of the same FASTA -> sketch, end to end"}
+        # ---- 10,000 signatures of ~5,000 hashes as a sourmash-style zip -> CSR in HBM ----
+        zpath = os.path.join(tmp, "coll.zip")
+        nsig = 10_000
+        with zipfile.ZipFile(zpath, "w", zipfile.ZIP_STORED) as zf:
+            man = io.StringIO()
+            man.write("# SOURMASH-MANIFEST-VERSION: 1.0\n")
+            man.write("internal_location,md5,md5short,ksize,moltype,num,scaled,n_hashes,with_abundance,name,filename\r\n")
+            for i in range(nsig):
+                mins = np.unique(splitmix64((np.uint64(i) << np.uint64(32)) + np.arange(5000, dtype=np.uint64)) % np.uint64(MAX_HASH_1000))
+                text_mins = ",".join(map(str, mins.tolist()))
+                md5 = hashlib.md5(("31" + text_mins.replace(",", "")).encode()).hexdigest()
+                doc = ('[{"class":"sourmash_signature","email":"","hash_function":"0.murmur64","filename":"g%d.fa","name":"genome %d",'
+                       '"license":"CC0","signatures":[{"num":0,"ksize":31,"seed":42,"max_hash":%d,"mins":[%s],"md5sum":"%s",'
+                       '"molecule":"dna"}],"version":0.4}]' % (i, i, MAX_HASH_1000, text_mins, md5))
+                loc = f"signatures/{md5}.sig.gz"
+                zf.writestr(loc, gzip.compress(doc.encode(), compresslevel=1))
+                man.write(f"{loc},{md5},{md5[:8]},31,DNA,0,1000,{len(mins)},0,genome {i},g{i}.fa\r\n")
+            zf.writestr("SOURMASH-MANIFEST.csv", man.getvalue(), compress_type=zipfile.ZIP_DEFLATED)
+        zbytes = os.path.getsize(zpath)
+        index.SketchSet.load(zpath, ksize=31, moltype="DNA")   # warm
+        t0 = time.perf_counter()
+        db = index.SketchSet.load(zpath, ksize=31, moltype="DNA")
+        dt = time.perf_counter() - t0
+        extra["sigload_10k"] = {
+            "signatures": len(db), "zip_bytes": zbytes, "seconds": round(dt, 3), "signatures_per_s": round(len(db) / dt, 1),
+            "zip_MB_per_s": round(zbytes / dt / 1e6, 1), "host_threads": os.cpu_count(),
+            "bound": "gzip inflate + JSON number parsing on the host's cores (the H2D copy of the 400 MB CSR is ~7 ms)",
+            "what": "SketchSet.load of a 10,000-member zip (stored .sig.gz members + manifest) -> one CSR in HBM, no per-sketch object"}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 def hbm_roofline(alg_bytes, ms, what, traffic=None, traffic_note=None, kernels_ms=None):

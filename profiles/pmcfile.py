@@ -85,6 +85,64 @@ class PmcFile:
         return None if any(v is None for v in vals) else sum(vals)
 
 
+class Calibration:
+    """FETCH_SIZE / WRITE_SIZE -> bytes, with the ratios measured on kernels that move a known number of bytes
+    (profiles/r04_fetch_calib.txt, written by tools/prof_calib.sh from tools/ubench/fetch_calib.hip): on gfx950 under this
+    rocprofv3 FETCH_SIZE reports 0.500 of the bytes of EVERY coalesced read that was measured -- 4, 8 and 16 B per lane,
+    `global_load ... lds` alike -- and WRITE_SIZE 1.000 of coalesced writes; a lone 8-byte read counts 64 B, a lone 4-byte
+    write 32 B.  `bytes_read(kib)` / `bytes_written(kib)` apply the coalesced ratios; `describe()` says which were used."""
+    FILE = "profiles/r04_fetch_calib.txt"
+    READ_ROWS = ("read_b32_kernel", "read_b64_kernel", "read_b128_kernel", "read_lds_b32_kernel")
+    WRITE_ROWS = ("write_b32_kernel", "write_b64_kernel", "write_b128_kernel")
+
+    def __init__(self, path=None):
+        self.path = path or self.FILE
+        self.ratios = {}
+        full = self.path if os.path.isabs(self.path) else os.path.join(ROOT, self.path)
+        if os.path.exists(full):
+            with open(full) as f:
+                for line in f:
+                    if line.startswith("calib "):
+                        parts = line.split("|")[0].split()
+                        self.ratios[(parts[1], parts[2])] = float(parts[5])
+        r = [self.ratios.get((k, "FETCH_SIZE")) for k in self.READ_ROWS]
+        w = [self.ratios.get((k, "WRITE_SIZE")) for k in self.WRITE_ROWS]
+        # one ratio per direction only if every measured width agrees (else nothing is quoted)
+        self.read_ratio = r[0] if all(v is not None and abs(v - r[0]) < 0.01 for v in r) else None
+        self.write_ratio = w[0] if all(v is not None and abs(v - w[0]) < 0.01 for v in w) else None
+
+    @property
+    def ok(self):
+        return self.read_ratio is not None and self.write_ratio is not None
+
+    def bytes_read(self, fetch_kib):
+        return fetch_kib * 1024.0 / self.read_ratio
+
+    def bytes_written(self, write_kib):
+        return write_kib * 1024.0 / self.write_ratio
+
+    def describe(self):
+        return (f"{self.path}: FETCH_SIZE = {self.read_ratio:.3f} x bytes for coalesced reads of 4 / 8 / 16 B per lane and global_load-to-LDS, "
+                f"WRITE_SIZE = {self.write_ratio:.3f} x bytes for coalesced writes (kernels moving a known 2 GiB); bytes = KiB x 1024 / ratio")
+
+
+class ValuMix:
+    """profiles/valu_mix_sketch.json (tools/valu_mix.py): average issue cost of the sketch kernel's VALU instruction mix, derived
+    from its disassembly; stale() like PmcFile's."""
+    def __init__(self, path="profiles/valu_mix_sketch.json"):
+        import json
+        self.path = path
+        full = path if os.path.isabs(path) else os.path.join(ROOT, path)
+        self.doc = json.load(open(full)) if os.path.exists(full) else None
+
+    def stale(self):
+        if self.doc is None:
+            return f"{self.path} is absent (python tools/valu_mix.py)"
+        now = source_hashes()
+        changed = [f for f, h in self.doc.get("sources", {}).items() if now.get(f) != h]
+        return f"{', '.join(changed)} changed since {self.path} was made (python tools/valu_mix.py)" if changed else None
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "header":
         print(header_line())

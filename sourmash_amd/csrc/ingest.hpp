@@ -201,6 +201,22 @@ struct IngestScratch {
     size_t temp_bytes = 0;
     static constexpr size_t HALO = 256;             // bytes reserved in front of every compacted chunk
 
+    // The device blocks go back to the arena while the stream their work ran on still exists (its owner calls this before it
+    // destroys the stream: a DevBuf released later would record its release event on a destroyed stream).  The stream is
+    // drained first, so the blocks carry no pending work and are handed back untied to any stream.
+    void release(hipStream_t stream) {
+        if (stream) (void)hipStreamSynchronize(stream);
+        if (copy_stream) (void)hipStreamSynchronize(copy_stream);
+        for (DevBuf* b : {&raw[0], &raw[1], &comp[0], &comp[1], &state, &temp, &small}) { b->st = nullptr; b->release(); }
+        for (int i = 0; i < 2; ++i) {
+            if (copied[i]) (void)hipEventDestroy(copied[i]);
+            if (consumed[i]) (void)hipEventDestroy(consumed[i]);
+            copied[i] = consumed[i] = nullptr;
+        }
+        if (copy_stream) (void)hipStreamDestroy(copy_stream);
+        copy_stream = nullptr;
+        chunk = 0;
+    }
     void prepare(size_t chunk_bytes, hipStream_t stream) {
         if (!copy_stream) {
             hip_check(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking), "hipStreamCreate");
@@ -238,7 +254,12 @@ struct IngestWorker {
     void init_own_stream() {
         if (!stream) { hip_check(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking), "hipStreamCreate"); own_stream = true; }
     }
-    ~IngestWorker() { if (own_stream && stream) (void)hipStreamDestroy(stream); }
+    ~IngestWorker() {
+        if (own_stream && stream) {
+            scratch.release(stream);
+            (void)hipStreamDestroy(stream);
+        }
+    }
 };
 
 // Sketch a sequence file into every (DNA) sketch of `mhs` on the worker's pipeline.  force == true semantics.

@@ -35,3 +35,22 @@ def test_staleness_rule(tmp_path):
     assert why and "gather.hip changed" in why
     assert "no source hashes" in pmcfile.PmcFile("profiles/r02_pmc.txt").stale(["sketch.hip"])
     assert "absent" in pmcfile.PmcFile("profiles/nope.txt").stale(["sketch.hip"])
+
+
+def test_valu_mix_file_is_current_and_calibration_is_usable():
+    """bench.py prices SQ_INSTS_VALU with the instruction mix of profiles/valu_mix_sketch.json (tools/valu_mix.py) and turns
+    FETCH_SIZE / WRITE_SIZE into bytes with the ratios of profiles/r04_fetch_calib.txt.  The mix file must belong to the
+    present sources of the sketch kernel (bench.py refuses a stale one: regenerate with `python tools/valu_mix.py`), its
+    prediction of the instruction count must stay near the counter's, and the calibration must give one ratio per direction."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "profiles"))
+    from pmcfile import Calibration, ValuMix
+    mix = ValuMix()
+    assert mix.stale() is None, mix.stale()
+    assert 3.0 < mix.doc["mix_cycles_per_valu_inst"] < 4.4
+    assert abs(mix.doc["expected_valu_insts_per_kmer"] - 116.5) / 116.5 < 0.08        # profiles/r03_pmc.txt: 116.5 per k-mer
+    assert not [op for op in mix.doc["unmeasured_opcodes"] if not op.startswith(("v_min", "v_mbcnt", "v_max"))]
+    cal = Calibration()
+    assert cal.ok and cal.read_ratio == 0.5 and cal.write_ratio == 1.0
+    assert cal.bytes_read(1024) == 2 * 1024 * 1024 and cal.bytes_written(1024) == 1024 * 1024
+    assert cal.ratios[("read_cursor_b64_kernel", "FETCH_SIZE")] > 0.6            # the overlap pass's access shape over-fetches
