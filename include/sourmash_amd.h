@@ -470,6 +470,15 @@ bool smgpu_gather_loop_eligible(const SmgpuGather *ptr, uint32_t n_wg);
 /* (one process driving several ranks: reserve every rank's loop memory BEFORE the first launch -- an allocation may synchronise
  *  the device while a loop that already runs waits for its peers) */
 void smgpu_gather_loop_reserve(SmgpuGather *ptr, uint32_t n_wg, uint64_t rowcap, void *stream);
+/* The exchange in DEVICE memory instead (BASELINE north_star: the gather exchange "over xGMI"): rank `rank` allocates ITS area
+ * (fine-grained device memory), exports it (handle_out: smgpu_gather_xchg_ipc_handle_size() bytes, a hipIpcMemHandle_t), the
+ * handles travel by one all-gather, and every rank opens its peers' (world <= 16, the ranks of one node).  A rank's loop kernel
+ * writes its own area and polls the others'.  smgpu_gather_launch_shared takes either kind. */
+SmgpuGatherXchg *smgpu_gather_xchg_new_device(uint32_t world, uint32_t rank, uint64_t rowcap);
+uintptr_t smgpu_gather_xchg_ipc_handle_size(void);
+void smgpu_gather_xchg_ipc_export(const SmgpuGatherXchg *xchg, uint8_t *handle_out);
+void smgpu_gather_xchg_ipc_open(SmgpuGatherXchg *xchg, uint32_t peer_rank, const uint8_t *handle);
+bool smgpu_gather_xchg_is_device(const SmgpuGatherXchg *xchg);
 bool smgpu_gather_launch_shared(SmgpuGather *ptr, SmgpuGatherXchg *xchg, uint32_t rank, uint32_t run_id, uint32_t n_wg, void *stream);
 /* Test support: `n_wg` workgroups that keep `lds_bytes` of LDS each and spin for `micros` microseconds on `stream` -- "somebody
  * else's kernel holds CUs of this device" (the resident gather loop must step aside for the two-kernel rounds, not fail). */

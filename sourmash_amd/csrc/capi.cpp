@@ -1736,7 +1736,18 @@ struct GatherXchg {
     uint64_t rowcap = 0;
     std::string shm_name;                    // "" : private pinned memory (one process drives every rank)
     bool creator = false, registered = false;
+    // device kind: this rank's area lives in its own device memory, the peers' areas are mapped in through hipIpc handles
+    bool device = false;
+    uint32_t rank = 0;
+    unsigned long long* own = nullptr;
+    std::vector<unsigned long long*> peers;  // [world] device-visible address of every rank's area (own included)
+    std::vector<void*> opened;               // mappings to close
     ~GatherXchg() {
+        if (device) {
+            for (void* p : opened) (void)hipIpcCloseMemHandle(p);
+            if (own) (void)hipFree(own);     // (not an arena block: IPC handles are per allocation; freed once per process lifetime)
+            return;
+        }
         if (!host) return;
         if (shm_name.empty()) (void)hipHostFree(host);
         else {
@@ -1777,6 +1788,53 @@ SmgpuGatherXchg* smgpu_gather_xchg_new(const char* shm_name, uint32_t world, uin
         return reinterpret_cast<SmgpuGatherXchg*>(x.release());
     });
 }
+// The exchange in DEVICE memory (north_star: "over xGMI"): every rank owns one area -- [2][4] record granules + [2][rowcap] row
+// granules -- in its own HBM, fine-grained so that a peer's system-scope loads see the owner's write-through stores, exports it as
+// an IPC handle, and maps its peers' areas.  A rank writes only its own area (local stores) and polls the others' (reads over
+// xGMI between the GPUs of a node; plain device memory between two processes on one GPU).  The tags of the granules tell runs
+// apart, so the area is zeroed once, here.
+SmgpuGatherXchg* smgpu_gather_xchg_new_device(uint32_t world, uint32_t rank, uint64_t rowcap) {
+    return landing<SmgpuGatherXchg*>([&]() -> SmgpuGatherXchg* {
+        if (world == 0 || world > GATHER_PEERS_MAX || rank >= world || rowcap == 0) throw err_internal("gather exchange (device): bad geometry");
+        std::unique_ptr<GatherXchg> x(new GatherXchg());
+        x->device = true;
+        x->world = world; x->rank = rank; x->rowcap = rowcap;
+        x->bytes = (((size_t)8 + (size_t)2 * rowcap) * 8 + 4095) & ~(size_t)4095;
+        void* p = nullptr;
+        hipError_t e = hipExtMallocWithFlags(&p, x->bytes, hipDeviceMallocFinegrained);
+        if (e != hipSuccess) { (void)hipGetLastError(); throw err_internal(std::string("gather exchange (device): fine-grained allocation failed: ") + hipGetErrorString(e)); }
+        x->own = (unsigned long long*)p;
+        hip_check(hipMemset(x->own, 0, x->bytes), "memset");
+        hip_check(hipDeviceSynchronize(), "sync");
+        x->peers.assign(world, nullptr);
+        x->peers[rank] = x->own;
+        return reinterpret_cast<SmgpuGatherXchg*>(x.release());
+    });
+}
+uintptr_t smgpu_gather_xchg_ipc_handle_size(void) { return sizeof(hipIpcMemHandle_t); }
+void smgpu_gather_xchg_ipc_export(const SmgpuGatherXchg* xp, uint8_t* handle_out) {
+    landing_void([&] {
+        const GatherXchg* x = reinterpret_cast<const GatherXchg*>(xp);
+        if (!x->device) throw err_internal("gather exchange: not a device-memory exchange");
+        hipIpcMemHandle_t h;
+        hip_check(hipIpcGetMemHandle(&h, x->own), "hipIpcGetMemHandle");
+        memcpy(handle_out, &h, sizeof(h));
+    });
+}
+void smgpu_gather_xchg_ipc_open(SmgpuGatherXchg* xp, uint32_t peer_rank, const uint8_t* handle) {
+    landing_void([&] {
+        GatherXchg* x = reinterpret_cast<GatherXchg*>(xp);
+        if (!x->device || peer_rank >= x->world) throw err_internal("gather exchange: bad peer");
+        if (peer_rank == x->rank) return;
+        hipIpcMemHandle_t h;
+        memcpy(&h, handle, sizeof(h));
+        void* p = nullptr;
+        hip_check(hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess), "hipIpcOpenMemHandle");
+        x->opened.push_back(p);
+        x->peers[peer_rank] = (unsigned long long*)p;
+    });
+}
+bool smgpu_gather_xchg_is_device(const SmgpuGatherXchg* xp) { return reinterpret_cast<const GatherXchg*>(xp)->device; }
 void smgpu_gather_xchg_free(SmgpuGatherXchg* p) { delete reinterpret_cast<GatherXchg*>(p); }
 bool smgpu_gather_loop_eligible(const SmgpuGather* p, uint32_t n_wg) {
     return gather_loop_eligible(reinterpret_cast<const GatherRaw*>(p)->g, n_wg);
@@ -1791,8 +1849,14 @@ bool smgpu_gather_launch_shared(SmgpuGather* p, SmgpuGatherXchg* xp, uint32_t ra
         GatherXchg* x = reinterpret_cast<GatherXchg*>(xp);
         GatherShared sh;
         sh.rec = x->dev;
-        sh.rows = x->dev + (size_t)2 * x->world * 4;
+        sh.rows = x->dev ? x->dev + (size_t)2 * x->world * 4 : nullptr;
         sh.W = x->world; sh.rank = rank; sh.rowcap = x->rowcap; sh.run_id = run_id;
+        if (x->device) {
+            if (rank != x->rank) throw err_internal("gather exchange (device): this area belongs to another rank");
+            for (uint32_t r = 0; r < x->world; ++r)
+                if (!x->peers[r]) throw err_internal("gather exchange (device): the area of rank " + std::to_string(r) + " was never opened");
+            sh.peers = x->peers.data();
+        }
         if (g.longest_row > x->rowcap) throw err_internal("gather exchange: a row of this shard is longer than the exchange's slots");
         bool ran = false;
         hip_check(gather_launch_loop(g, (hipStream_t)stream, n_wg, &sh, &ran), "gather loop (shared)");

@@ -58,8 +58,14 @@ __global__ __launch_bounds__(XT * XT) void compare_ext_kernel(
     //       minhash.rs:596-604: self.num); common / prod: full n x n, diagonal left to the caller
     constexpr bool ABUND = MODE != X_NUM;
     using AbT = typename std::conditional<MODE == X_ABUND32, uint32_t, uint64_t>::type;
-    __shared__ uint64_t s_seg[2 * XT][XSTRIDE];
-    __shared__ AbT s_ab[ABUND ? 2 * XT : 1][ABUND ? XSTRIDE : 1];
+    // 64-bit abundances: a staged element is {hash, abundance} side by side, 16 bytes -- the walk's step reads each side's head with
+    // ONE ds_read_b128 (measured at C3: 7.83 -> 6.86 ms).  32-bit abundances keep two arrays: the 16-byte elements cost two of the six
+    // workgroups a CU's LDS holds, and with this latency-bound walk occupancy is worth more (5.86 ms against 6.49 interleaved).
+    constexpr bool PACKED = MODE == X_ABUND64;
+    struct alignas(16) Elem { uint64_t h; uint64_t a; };
+    __shared__ uint64_t s_seg[PACKED ? 1 : 2 * XT][PACKED ? 1 : XSTRIDE];
+    __shared__ uint32_t s_ab[MODE == X_ABUND32 ? 2 * XT : 1][MODE == X_ABUND32 ? XSTRIDE : 1];
+    __shared__ Elem s_el[PACKED ? 2 * XT : 1][PACKED ? XSEG + 1 : 1];
     __shared__ uint64_t s_pos[2 * XT], s_end[2 * XT];
     __shared__ uint32_t s_take[2 * XT];
     __shared__ unsigned long long s_hi;
@@ -140,8 +146,9 @@ __global__ __launch_bounds__(XT * XT) void compare_ext_kernel(
             have[i] = len;
             const uint64_t v = (uint32_t)lane < len ? hashes[pos + lane] : ~0ull;
             e[i] = v;
-            s_seg[s][lane] = v;
-            if (ABUND) s_ab[s][lane] = (uint32_t)lane < len ? (AbT)abunds[pos + lane] : (AbT)0;
+            if (PACKED) s_el[s][lane] = Elem{v, (uint32_t)lane < len ? abunds[pos + lane] : 0ull};
+            else s_seg[s][lane] = v;
+            if (MODE == X_ABUND32) s_ab[s][lane] = (uint32_t)lane < len ? (uint32_t)abunds[pos + lane] : 0u;
             if (lane == 0) {
                 if (left > (uint64_t)XSEG) atomicMin(&s_hi, (unsigned long long)hashes[pos + XSEG - 1]);
                 if (len) atomicOr(&s_live[s < XT ? 0 : 1], 1u);
@@ -161,8 +168,8 @@ __global__ __launch_bounds__(XT * XT) void compare_ext_kernel(
         __syncthreads();
         if (mine) {
             const uint32_t na = s_take[r], nb = s_take[XT + c];
-            const uint64_t* A = s_seg[r];
-            const uint64_t* B = s_seg[XT + c];
+            const uint64_t* A = s_seg[PACKED ? 0 : r];
+            const uint64_t* B = s_seg[PACKED ? 0 : XT + c];
             uint32_t ia = 0, ib = 0;
             if (MODE == X_NUM) {
                 while (ia < na && ib < nb && steps < cap) {
@@ -175,11 +182,19 @@ __global__ __launch_bounds__(XT * XT) void compare_ext_kernel(
                 }
                 steps += (na - ia) + (nb - ib);                // what one side has left below the bound: union elements, none common
             } else {
-                const AbT* WA = s_ab[r];
-                const AbT* WB = s_ab[XT + c];
+                const Elem* EA = s_el[PACKED ? r : 0];
+                const Elem* EB = s_el[PACKED ? XT + c : 0];
+                const uint32_t* WA = s_ab[PACKED ? 0 : r];
+                const uint32_t* WB = s_ab[PACKED ? 0 : XT + c];
                 while (ia < na && ib < nb) {
-                    const uint64_t a = A[ia], b = B[ib];
-                    const AbT wa = WA[ia], wb = WB[ib];
+                    uint64_t a, b;
+                    AbT wa, wb;
+                    if (PACKED) {
+                        const Elem ea = EA[ia], eb = EB[ib];
+                        a = ea.h; b = eb.h; wa = (AbT)ea.a; wb = (AbT)eb.a;
+                    } else {
+                        a = A[ia]; b = B[ib]; wa = (AbT)WA[ia]; wb = (AbT)WB[ib];
+                    }
                     const bool lt = a < b, gt = b < a, eq = !(lt | gt);
                     // no branch: with 64 walks per wave some lane meets a common hash at almost every step anyway
                     cnt += eq;

@@ -1053,6 +1053,11 @@ struct LoopArgs {
     uint32_t W, rank, epoch_base, rowcap;   // ranks, this rank, tag offset of this run, granules per row slot
     unsigned long long* x_rec;          // shared: [2][W][4] record granules {key hi, key lo, row length, -}
     unsigned long long* x_rows;         // shared: [2][W][rowcap] {tag, query position} granules: every rank's local best row
+    // ... or (peers != 0) one area PER RANK in that rank's own device memory, mapped into every peer (hipIpc: over xGMI between the
+    // GPUs of a node): a rank WRITES only its own area -- local, write-through -- and READS the others'.  Area of rank r:
+    // [2][4] record granules, then [2][rowcap] row granules.
+    uint32_t peers;
+    unsigned long long* peer[GATHER_PEERS_MAX];
     unsigned long long* gwin;           // local:  [2][4] the global winner {key hi, key lo, length, owner rank}
     unsigned long long* gate;           // local:  [0] workgroups that have started, bit 63: somebody gave up waiting for the rest
     unsigned long long gate_ticks;      // how long a workgroup waits at the gate for the others to start (wall_clock64 ticks, 10 ns)
@@ -1073,6 +1078,13 @@ __device__ __forceinline__ void sys_store(unsigned long long* p, unsigned long l
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 constexpr uint32_t PL_STAGERS = 8;             // workgroups that copy a remote winner's row into local memory
+// where rank r's record / row granules of parity `par` live: in the one shared area, or in r's own area
+__device__ __forceinline__ unsigned long long* xchg_rec(const LoopArgs& a, uint32_t par, uint32_t r) {
+    return a.peers ? a.peer[r] + (uint64_t)par * 4 : a.x_rec + ((uint64_t)par * a.W + r) * 4;
+}
+__device__ __forceinline__ unsigned long long* xchg_row(const LoopArgs& a, uint32_t par, uint32_t r) {
+    return a.peers ? a.peer[r] + 8 + (uint64_t)par * a.rowcap : a.x_rows + ((uint64_t)par * a.W + r) * a.rowcap;
+}
 
 __global__ __launch_bounds__(PL_THREADS) void gather_loop_kernel(LoopArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t pl_lds[];
@@ -1114,7 +1126,7 @@ __global__ __launch_bounds__(PL_THREADS) void gather_loop_kernel(LoopArgs a) {
                         a.state[13] = 0; a.state[14] = wg;
                         if (a.W > 0) {                                // (their workgroup 0 polls this record in epoch 1)
                             const unsigned long long gtag = (unsigned long long)(a.epoch_base + 1u) << 32;
-                            unsigned long long* rec = a.x_rec + ((uint64_t)1u * a.W + a.rank) * 4;
+                            unsigned long long* rec = xchg_rec(a, 1u, a.rank);
                             sys_store(rec + 0, gtag); sys_store(rec + 1, gtag); sys_store(rec + 2, gtag | 0xffffffffull);
                         }
                     } else v = seen;
@@ -1237,13 +1249,13 @@ __global__ __launch_bounds__(PL_THREADS) void gather_loop_kernel(LoopArgs a) {
             if (llen > a.rowcap) { if (tid == 0) a.state[GS_ERR] = 4; failed = true; break; }   // (the host sized the slots from the longest row)
             __syncthreads();                                        // (s_wstart / s_wlen are about to be reused)
             // every rank pushes its own best row (query positions, tagged): whoever wins, its row is already on its way
-            unsigned long long* my_row = a.x_rows + ((uint64_t)par * a.W + a.rank) * a.rowcap;
+            unsigned long long* my_row = xchg_row(a, par, a.rank);
             for (uint32_t i = wg * PL_THREADS + (uint32_t)tid; i < llen; i += n_wg * PL_THREADS)
                 sys_store(my_row + i, gtag | a.qpos[(uint64_t)lstart + i]);
             unsigned long long* gw = a.gwin + (uint64_t)par * 4;
             if (wg == 0) {
                 if (tid == 0) {
-                    unsigned long long* rec = a.x_rec + ((uint64_t)par * a.W + a.rank) * 4;
+                    unsigned long long* rec = xchg_rec(a, par, a.rank);
                     sys_store(rec + 0, gtag | (top >> 32));
                     sys_store(rec + 1, gtag | (top & 0xffffffffull));
                     sys_store(rec + 2, gtag | llen);
@@ -1254,7 +1266,7 @@ __global__ __launch_bounds__(PL_THREADS) void gather_loop_kernel(LoopArgs a) {
                 for (uint32_t spins = 0;; ++spins) {
                     bool ok = true;
                     if ((uint32_t)tid < a.W) {
-                        const unsigned long long* rec = a.x_rec + ((uint64_t)par * a.W + (uint32_t)tid) * 4;
+                        const unsigned long long* rec = xchg_rec(a, par, (uint32_t)tid);
                         const unsigned long long x0 = sys_load(rec + 0), x1 = sys_load(rec + 1), x2 = sys_load(rec + 2);
                         ok = (x0 >> 32) == (gtag >> 32) && (x1 >> 32) == (gtag >> 32) && (x2 >> 32) == (gtag >> 32);
                         rk = ((x0 & 0xffffffffull) << 32) | (x1 & 0xffffffffull);
@@ -1307,7 +1319,7 @@ __global__ __launch_bounds__(PL_THREADS) void gather_loop_kernel(LoopArgs a) {
             if (top != 0 && owner != a.rank) {
                 // the winner's positions: copied out of shared memory ONCE per rank by a few workgroups, read locally by all
                 unsigned long long* st = a.stage + (uint64_t)par * a.rowcap;
-                const unsigned long long* src = a.x_rows + ((uint64_t)par * a.W + owner) * a.rowcap;
+                const unsigned long long* src = xchg_row(a, par, owner);
                 if (wg < PL_STAGERS)
                     for (uint32_t i = wg * PL_THREADS + (uint32_t)tid; i < glen; i += PL_STAGERS * PL_THREADS) {
                         unsigned long long x = sys_load(src + i);
@@ -1918,6 +1930,13 @@ hipError_t gather_launch_loop(GatherDev& g, hipStream_t stream, uint32_t n_wg, c
     a.W = sh ? sh->W : 0; a.rank = sh ? sh->rank : 0; a.rowcap = (uint32_t)rowcap;
     a.epoch_base = sh ? (sh->run_id & 0xfffu) << 20 : 0;                    // tags of the shared slots: unique per run, no zeroing between runs
     a.x_rec = sh ? sh->rec : nullptr; a.x_rows = sh ? sh->rows : nullptr;
+    a.peers = 0;
+    for (uint32_t r = 0; r < GATHER_PEERS_MAX; ++r) a.peer[r] = nullptr;
+    if (sh && sh->peers) {
+        if (sh->W > GATHER_PEERS_MAX) return hipErrorInvalidValue;
+        a.peers = 1;
+        for (uint32_t r = 0; r < sh->W; ++r) a.peer[r] = sh->peers[r];
+    }
     SMG_TRY(hipMemsetAsync(g.loop_xchg, 0, ((size_t)2 * n_wg * 4 + 16 + 8 + 8) * 8, stream));   // local epochs count from 1 within a launch
     if (rowcap) SMG_TRY(hipMemsetAsync(a.stage, 0, (size_t)2 * rowcap * 8, stream));
     // One workgroup per CU: all of them must be resident at once (the sweeps wait for every workgroup).  A plain launch has

@@ -134,9 +134,12 @@ hipError_t gather_run_persistent(GatherDev& g, hipStream_t stream, bool* ran);
 // shared by all ranks (pinned; POSIX shared memory registered with HIP when the ranks are processes), the best of them is
 // the round's winner everywhere, and its query positions reach the other ranks through the same memory -- no host
 // collective inside the loop.  rec: [2][W][4] granules, rows: [2][W][rowcap] granules (device-visible addresses).
+constexpr uint32_t GATHER_PEERS_MAX = 16;    // ranks of one node that can exchange through per-rank device areas
 struct GatherShared {
     unsigned long long* rec;
     unsigned long long* rows;
+    unsigned long long* const* peers = nullptr;   // non-null: W device-visible addresses, area r = rank r's own device memory
+                                                  // ([2][4] record granules + [2][rowcap] row granules); rec / rows unused
     uint32_t W, rank;
     uint64_t rowcap;              // >= the longest row of any rank's shard
     uint32_t run_id;              // the same on every rank, different from the previous run on this memory

@@ -254,6 +254,8 @@ class GatherExchange:
     POSIX shared memory registered with HIP when the ranks are processes of one node, private pinned memory when one process
     drives every rank (tests)."""
 
+    transport = "shared host memory"
+
     def __init__(self, lib, rustcall, world, rowcap, shm_name=None, create=True):
         self.lib, self.world, self.rowcap, self.shm_name = lib, int(world), int(rowcap), shm_name
         self._ptr = rustcall(lib.smgpu_gather_xchg_new, shm_name.encode() if shm_name else None, int(world), int(rowcap), bool(create))
@@ -262,6 +264,60 @@ class GatherExchange:
         if getattr(self, "_ptr", None) and self.lib is not None:
             self.lib.smgpu_gather_xchg_free(self._ptr)
             self._ptr = None
+
+
+class DeviceGatherExchange(GatherExchange):
+    """The exchange in DEVICE memory: this rank's area in its own HBM (fine-grained), the peers' areas mapped in through hipIpc
+    handles -- between the GPUs of a node the loop kernels then poll each other over xGMI (smgpu_gather_xchg_new_device)."""
+    transport = "per-rank device memory mapped through hipIpc (xGMI between the GPUs of a node)"
+
+    def __init__(self, lib, rustcall, world, rank, rowcap):
+        self.lib, self.rustcall, self.world, self.rank, self.rowcap, self.shm_name = lib, rustcall, int(world), int(rank), int(rowcap), None
+        self._ptr = rustcall(lib.smgpu_gather_xchg_new_device, int(world), int(rank), int(rowcap))
+
+    def export(self):
+        buf = (C.c_uint8 * int(self.lib.smgpu_gather_xchg_ipc_handle_size()))()
+        self.rustcall(self.lib.smgpu_gather_xchg_ipc_export, self._ptr, buf)
+        return bytes(buf)
+
+    def open_peer(self, peer_rank, handle):
+        buf = (C.c_uint8 * len(handle)).from_buffer_copy(handle)
+        self.rustcall(self.lib.smgpu_gather_xchg_ipc_open, self._ptr, int(peer_rank), buf)
+
+
+def open_device_exchange(owner, lib, rustcall, world, rank, rowcap, group=None):
+    """The device-memory exchange of this job's ranks, made once and reused while it is large enough: every rank allocates its
+    area, the IPC handles travel by one all-gather, every rank maps its peers' areas.  Like open_shared_exchange every step is
+    agreed before anybody goes on (all ranks end with the exchange, or all raise).  -> (exchange, run id)."""
+    dist = _dist()
+    cur = getattr(owner, "_xchg_dev", None)
+    grouped = world > 1 or (dist.is_available() and dist.is_initialized())
+    if cur is None or cur.world != world or cur.rowcap < rowcap or getattr(owner, "_xchg_dev_runs", 0) >= EXCHANGE_RUNS_MAX:
+        owner._xchg_dev = None
+        made, err = None, None
+        try:
+            made = DeviceGatherExchange(lib, rustcall, world, rank, rowcap)
+        except Exception as e:                                           # noqa: BLE001 -- the peers must learn of it
+            err = e
+        if grouped and not agree(err is None, group):
+            raise err or RuntimeError("the device-memory gather exchange could not be allocated on some rank")
+        if err is not None:
+            raise err
+        if grouped and world > 1:
+            handles = [None] * world
+            dist.all_gather_object(handles, made.export(), group=group)
+            try:
+                for r, h in enumerate(handles):
+                    if r != rank:
+                        made.open_peer(r, h)
+            except Exception as e:                                       # noqa: BLE001
+                err = e
+            if not agree(err is None, group):
+                raise err or RuntimeError("a peer's device-memory exchange area could not be mapped on some rank")
+        owner._xchg_dev = made
+        owner._xchg_dev_runs = 0
+    owner._xchg_dev_runs += 1
+    return owner._xchg_dev, owner._xchg_dev_runs
 
 
 class DeviceBackend:
@@ -325,8 +381,18 @@ class DeviceBackend:
 
     # -- gather --
     def open_exchange(self, world, rank, rowcap, group=None):
-        """the shared exchange of this job's ranks (one node): POSIX shared memory every rank maps and registers with HIP
-        (open_shared_exchange has the choreography); run ids count up per use."""
+        """the exchange through which this job's loop kernels agree on every round (one node).  SMG_GATHER_EXCHANGE:
+        `device` -- per-rank device memory mapped through hipIpc (xGMI between GPUs); `shared` -- POSIX shared host memory every
+        rank maps and registers with HIP; unset -- the device form, the host form where it cannot be set up (the ranks agree)."""
+        import os
+        kind = os.environ.get("SMG_GATHER_EXCHANGE", "auto")
+        if kind in ("auto", "device") and world <= 16:
+            try:
+                return open_device_exchange(self, self.lib, self.rustcall, world, rank, rowcap, group)
+            except Exception:
+                if kind == "device":
+                    raise
+
         def make(name, create):
             return GatherExchange(self.lib, self.rustcall, world, rowcap, name, create=create)
         return open_shared_exchange(self, make, world, rank, rowcap, group)
@@ -481,7 +547,7 @@ def gather_distributed(query, nq, shard_hashes, shard_offsets, n_shard, index_ba
     import os
     # (stepwise=True asks for the record protocol explicitly: tests, and the single-rank comparison of the two)
     if (collect and not stepwise and hasattr(backend, "open_exchange") and hasattr(state, "launch_shared")
-            and os.environ.get("SMG_GATHER_EXCHANGE", "shared") != "records"):
+            and os.environ.get("SMG_GATHER_EXCHANGE", "auto") != "records"):
         # workgroups per rank's loop kernel: one per CU (0) on a GPU of its own; ranks that SHARE a GPU (tests) must fit side by side
         n_wg = int(os.environ.get("SMG_GATHER_LOOP_WGS", "0"))
         grouped = collect and dist.is_available() and dist.is_initialized()
@@ -507,7 +573,7 @@ def gather_distributed(query, nq, shard_hashes, shard_offsets, n_shard, index_ba
                 if all_ok(good):
                     if stats is not None:
                         stats.update(exchanges=0, rounds_per_exchange=None, records_per_rank=None, record_words=None, rounds=len(res),
-                                     protocol="resident loop kernels, winners agreed through shared host memory every round")
+                                     protocol="resident loop kernels, winners agreed every round through " + getattr(xchg, "transport", "shared host memory"))
                         stats.update(state.stats())
                     return res
             # the shared exchange did not work out on some rank: start over with a fresh index and the record protocol

@@ -263,9 +263,12 @@ def test_gather_distributed_falls_back_when_the_shared_exchange_is_unavailable(b
     dist.init_process_group("nccl", rank=0, world_size=1, init_method="tcp://127.0.0.1:%d" % (29600 + os.getpid() % 300),
                             device_id=torch.device("cuda", torch.cuda.current_device()))
     try:
-        stats = {}
-        assert parallel.gather_distributed(q, len(qh), h, off, len(dbh), 0, 20_000, 1000, be, force_collectives=True, stats=stats) == want
-        assert "shared host memory" in stats.get("protocol", ""), stats
+        for kind, word in (("device", "hipIpc"), ("shared", "shared host memory")):
+            monkeypatch.setenv("SMG_GATHER_EXCHANGE", kind)
+            stats = {}
+            assert parallel.gather_distributed(q, len(qh), h, off, len(dbh), 0, 20_000, 1000, be, force_collectives=True, stats=stats) == want
+            assert word in stats.get("protocol", ""), (kind, stats)
+        monkeypatch.delenv("SMG_GATHER_EXCHANGE")
         def broken(*a, **k):
             raise OSError("no shared memory here")
         monkeypatch.setattr(be, "open_exchange", broken)

@@ -45,13 +45,15 @@ def test_two_processes_drive_every_distributed_entry_point():
         assert "error" not in r, r["error"]
         assert r["compare"] and r["overlaps"] and r["sketch_union"], r
         for thr in (0, 30_000):
-            for mode in ("shared", "records"):
+            for mode in ("device", "shared", "records"):
                 g = r["gather_%s_thr%d" % (mode, thr)]
                 assert g["ok"] and g["rounds"] > 20, (mode, thr, g)       # whichever protocol ran: the oracle's ordered picks
             assert r["gather_records_thr%d" % thr]["protocol"] == "candidate records"
-    # the default path -- resident loops of both processes agreeing through the shared segment -- must have been the one that
+    # the resident loops of both processes agreeing every round -- through per-rank device memory mapped with hipIpc (the
+    # default: what ranks on the GPUs of one node use over xGMI) and through the shared host segment -- must have been what
     # answered (a run in which the two grids were not resident together falls back, correctly, and is repeated up to 4 times)
     for r in res:
+        assert any("hipIpc" in r["gather_device_thr%d" % thr]["protocol"] for thr in (0, 30_000)), r
         assert any("shared host memory" in r["gather_shared_thr%d" % thr]["protocol"] for thr in (0, 30_000)), r
 
 
@@ -63,5 +65,5 @@ def test_two_full_size_grids_on_one_gpu_fall_back_instead_of_failing():
     for r in res:
         assert "error" not in r, r["error"]
         for thr in (0, 30_000):
-            for mode in ("shared", "records"):
+            for mode in ("device", "shared", "records"):
                 assert r["gather_%s_thr%d" % (mode, thr)]["ok"], r

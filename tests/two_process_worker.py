@@ -38,17 +38,17 @@ def main():
         fh, foff = oracle.make_csr(dbh)
         for thr in (0, 30_000):
             want = oracle.gather(qh, fh, foff, threshold_bp=thr, scaled=1000, nthreads=4)
-            for mode in ("shared", "records"):
+            for mode in ("device", "shared", "records"):
                 os.environ["SMG_GATHER_EXCHANGE"] = mode
                 tries, proto, ok, fallbacks = 0, "", True, 0
-                while tries < (4 if mode == "shared" else 1):
+                while tries < (4 if mode != "records" else 1):
                     tries += 1
                     stats = {}
                     got = parallel.gather_distributed(q, len(qh), h, off, hi - lo, lo, thr, 1000, be, stats=stats)
                     ok = ok and got == want
                     proto = stats.get("protocol") or stats.get("shared_exchange") or "candidate records"
                     fallbacks += 1 if "shared_exchange" in stats else 0
-                    if mode == "records" or "shared host memory" in proto:
+                    if mode == "records" or "resident loop kernels" in proto:
                         break
                 out["gather_%s_thr%d" % (mode, thr)] = {"ok": bool(ok), "rounds": len(want), "protocol": proto, "tries": tries,
                                                         "fell_back": fallbacks}
