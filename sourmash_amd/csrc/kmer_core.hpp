@@ -233,8 +233,8 @@ SMG_HD void process_lane_impl(const uint32_t* raw, uint64_t seed, uint64_t thr, 
             bad &= (1u << (8 * (G::NBYTES % 4))) - 1u;
         anybad |= bad;
     }
-    // bit b of (badlo, badhi) = window byte b is invalid.  Rare: built only if needed.
-    uint64_t badlo = 0, badhi = 0;
+    // bit b of (badlo, badhi, badtop) = window byte b is invalid (192 bits: k <= 128 at P = 16 ... 64).  Rare: built only if needed.
+    uint64_t badlo = 0, badhi = 0, badtop = 0;
     if (anybad != 0) {
 #pragma unroll
         for (int i = 0; i < G::NW; ++i) {
@@ -244,10 +244,11 @@ SMG_HD void process_lane_impl(const uint32_t* raw, uint64_t seed, uint64_t thr, 
             if (i == G::NW - 1 && (G::NBYTES % 4) != 0) bad &= (1u << (8 * (G::NBYTES % 4))) - 1u;
             const uint64_t nib = nonzero_bytes4(bad);
             if (4 * i < 64) badlo |= nib << (4 * i);
-            else badhi |= nib << (4 * i - 64);
+            else if (4 * i < 128) badhi |= nib << (4 * i - 64);
+            else badtop |= nib << (4 * i - 128);
         }
     }
-    static_assert(G::NBYTES <= 128, "window too long for the 128-bit validity mask");
+    static_assert(G::NBYTES <= 192 && K <= 128 && P <= 64, "window too long for the 192-bit validity mask");
     (
         [&] {
             const Mmh3Open open = PosOps<K, P, O>::hash_open(U, C, seed);
@@ -259,12 +260,11 @@ SMG_HD void process_lane_impl(const uint32_t* raw, uint64_t seed, uint64_t thr, 
             bool ok = (h - 1) < thr;                          // h != 0 (signature.rs:50) and h <= thr (minhash.rs:319)
             if (anybad != 0) {
                 // any invalid byte in [O, O+K) kills the k-mer (signature.rs:271-286, force=true)
-                uint64_t lo, hi;                              // bits [O, O+128) of the mask
+                uint64_t lo, hi;                              // bits [O, O+128) of the mask (O < 64: P <= 64)
                 if constexpr (O == 0) { lo = badlo; hi = badhi; }
-                else if constexpr (O < 64) { lo = (badlo >> O) | (badhi << (64 - O)); hi = badhi >> O; }
-                else { lo = badhi >> (O - 64); hi = 0; }
+                else { lo = (badlo >> O) | (badhi << (64 - O)); hi = (badhi >> O) | (badtop << (64 - O)); }
                 const uint64_t mlo = K >= 64 ? ~0ull : ((1ull << K) - 1);
-                const uint64_t mhi = K > 64 ? ((1ull << (K - 64)) - 1) : 0;
+                const uint64_t mhi = K >= 128 ? ~0ull : K > 64 ? ((1ull << (K - 64)) - 1) : 0;
                 if ((lo & mlo) | (hi & mhi)) ok = false;
             }
             if (ok) emit(O, h);

@@ -25,7 +25,7 @@ static uint64_t run(const uint8_t* seq, uint64_t len, uint64_t seed, uint64_t th
     return n;
 }
 
-// every ksize the GPU dispatch instantiates (sketch.hip: K = 1 .. 64 at P = 16) plus a few other lane widths
+// every ksize the GPU dispatch instantiates (sketch.hip / sketch_long.hip: K = 1 .. 128 at P = 16) plus a few other lane widths
 typedef uint64_t (*run_fn)(const uint8_t*, uint64_t, uint64_t, uint64_t, uint64_t*, uint64_t);
 template <int... KS>
 static run_fn pick16(uint32_t k, std::integer_sequence<int, KS...>) {
@@ -36,7 +36,7 @@ static run_fn pick16(uint32_t k, std::integer_sequence<int, KS...>) {
 extern "C" uint64_t emul_sketch(const uint8_t* seq, uint64_t len, uint32_t k, uint32_t p, uint64_t seed,
                                 uint64_t thr, uint64_t* out, uint64_t cap) {
     if (p == 16) {
-        const run_fn f = pick16(k, std::make_integer_sequence<int, 64>());
+        const run_fn f = pick16(k, std::make_integer_sequence<int, 128>());
         return f ? f(seq, len, seed, thr, out, cap) : ~0ull;
     }
 #define CASE(KK, PP) if (k == KK && p == PP) return run<KK, PP>(seq, len, seed, thr, out, cap);

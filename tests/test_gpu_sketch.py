@@ -111,13 +111,13 @@ def test_random_vs_oracle(sm, k):
 
 
 def test_every_ksize_on_the_gpu(sm):
-    "k = 1 .. 64 dispatch to instantiations of the register-window kernel, longer k-mers to the byte-wise one: all vs the oracle"
+    "k = 1 .. 128 dispatch to instantiations of the register-window kernel, longer k-mers to the byte-wise one: all vs the oracle"
     rng = np.random.default_rng(77)
     s = bytearray(_rand_dna(rng, 40_000, b"ACGTacgt"))
     for i in range(11, len(s), 1013):
         s[i] = ord("N")
     s = bytes(s)
-    for k in list(range(1, 66)) + [80, 127]:
+    for k in list(range(1, 66)) + [79, 80, 81, 96, 97, 112, 113, 127, 128, 129, 200]:
         mh = sm.MinHash(0, k, scaled=4)
         mh.add_sequence_buffer(s)
         assert np.array_equal(mh._mins_array(), oracle.sketch_dna_bulk(s, k, scaled=4, nthreads=4)), k

@@ -46,9 +46,9 @@ def _rand_dna(rng, n, alphabet=b"ACGT"):
 
 
 def test_every_dispatched_ksize_matches_oracle(emul):
-    "sketch.hip instantiates the register-window kernel for every k = 1 .. 64 (P = 16): each one against the oracle"
+    "sketch.hip / sketch_long.hip instantiate the register-window kernel for every k = 1 .. 128 (P = 16): each one against the oracle"
     rng = np.random.default_rng(2024)
-    for k in range(1, 65):
+    for k in range(1, 129):
         for n in (k - 1, k, k + 17, 700):
             s = _rand_dna(rng, n, alphabet=b"ACGTacgtN" if n == 700 else b"ACGT")
             assert np.array_equal(emul(s, k, 16), _oracle_all(s, k)), (k, n)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Sketch throughput by ksize on resident synthetic DNA (kernel + sort + unique, scaled = 1000): every k from 1 to 64 runs
+"""Sketch throughput by ksize on resident synthetic DNA (kernel + sort + unique, scaled = 1000): every k from 1 to 128 runs
 an instantiation of the register-window kernel; SMG_SKETCH_GENERIC=1 forces the byte-wise kernel that used to serve
 every k outside {21, 31, 51} (run in a subprocess, the switch is read once).   python tools/bench_sketch_k.py"""
 import json
@@ -34,8 +34,8 @@ if __name__ == "__main__":
         print(json.dumps(run([int(x) for x in sys.argv[3:]], int(sys.argv[2]))))
         sys.exit(0)
     n = 2_000_000_000
-    fast = run([15, 21, 25, 27, 31, 33, 41, 51, 63, 64], n)
-    child = subprocess.run([sys.executable, __file__, "child", str(n // 10), "25", "33"], capture_output=True, text=True,
+    fast = run([15, 21, 25, 27, 31, 33, 41, 51, 63, 64, 65, 80, 96, 112, 127, 128], n)
+    child = subprocess.run([sys.executable, __file__, "child", str(n // 10), "25", "33", "65", "127"], capture_output=True, text=True,
                            env=dict(os.environ, SMG_SKETCH_GENERIC="1"))
     generic = json.loads(child.stdout.strip().splitlines()[-1]) if child.returncode == 0 else {"error": child.stderr[-500:]}
     print(json.dumps({"bases": n, "register_window_kernel": fast, "byte_wise_kernel_forced": generic,
