@@ -29,6 +29,8 @@ import ctypes as C
 import math
 
 TILE = 16   # rows per compare tile (csrc/compare.hip CT)
+COMPARE_BANDS = 4   # pieces the compare exchange is cut into so that it overlaps the tiles (compare_all_pairs_distributed)
+COMPARE_BAND_MIN_SLOTS = 8   # ... when every piece holds at least this many 16-row tiles per rank
 TOPK_MAX = 16    # candidates a rank can export per exchange (csrc/gather_api.hpp GATHER_TOPK_MAX)
 CAND_MAX = 64    # candidates of all ranks together (GATHER_CAND_MAX: one mask bit each)
 CAND_HEAD = 3    # record header: key, bound, len
@@ -65,8 +67,8 @@ def _all_reduce(t, op, group=None):
         dist.all_reduce(t, op=op, group=group)
 
 
-def _all_gather(outs, t, group=None):
-    "outs[r] <- rank r's t (same shape and dtype everywhere)"
+def _all_gather(outs, t, group=None, async_op=False):
+    "outs[r] <- rank r's t (same shape and dtype everywhere); async_op: -> a work handle to wait() on (None when done already)"
     dist = _dist()
     if _staged(t, group):
         c = t.cpu().contiguous()
@@ -74,8 +76,11 @@ def _all_gather(outs, t, group=None):
         dist.all_gather(parts, c, group=group)
         for o, part in zip(outs, parts):
             o.copy_(part)
-    else:
-        dist.all_gather(outs, t, group=group)
+        return None
+    if async_op:
+        return dist.all_gather(outs, t, group=group, async_op=True)
+    dist.all_gather(outs, t, group=group)
+    return None
 
 
 def agree(flag, group=None):
@@ -438,30 +443,54 @@ def compare_all_pairs_distributed(hashes, offsets, n, backend, group=None, want_
 
     mark()
     first, stride, count = tiles_for_rank(n, world, rank)
-    local = backend.compare_tiles(hashes, offsets, n, first, stride, count)
-    mark()
     n_tiles = (n + TILE - 1) // TILE
     if world == 1 and not force_collectives:
+        local = backend.compare_tiles(hashes, offsets, n, first, stride, count)
+        mark()
         full = local[:n]
     else:
-        max_count = (n_tiles + world - 1) // world
-        if local.shape[0] != max_count * TILE:                    # equal-sized pieces for all_gather
-            pad = backend.zeros((max_count * TILE, n), local.dtype)
-            pad[:local.shape[0]] = local
-            local = pad
+        torch = __import__("torch")
+        max_count = (n_tiles + world - 1) // world                # tile slots per rank (the last ranks may own one less)
         # a count is at most the size of the smaller sketch: when no sketch holds 65,536 hashes the shards travel as 16-bit
         # words -- half the bytes on the ring, which is bound per xGMI link (200 MB instead of 400 MB at N = 10,000)
-        torch = __import__("torch")
         narrow = bool(n > 0 and int((offsets[1:] - offsets[:-1]).max().item()) < 65536)
-        # (as bytes: neither RCCL nor gloo moves 16-bit integers; truncation keeps the low 16 bits)
-        send = local.to(torch.int16).view(torch.uint8) if narrow else local
-        pieces = [backend.empty(tuple(send.shape), send.dtype) for _ in range(world)]
-        _all_gather(pieces, send, group)                          # the ONE collective of the compare path
-        if narrow:
-            pieces = [p.view(torch.int16).to(torch.int32).bitwise_and_(0xFFFF) for p in pieces]
-        full = assemble_tiles(pieces, n, world, backend)
+        # The exchange is cut into BANDS of tile slots: the all-gather of a band travels (RCCL's own stream) while the next
+        # band's tiles are computed -- on 8 ranks the 200 MB exchange, not the tiles, would otherwise bound C4.
+        # Still ONE logical exchange of every count, in a few pieces; small problems and host-staged groups keep one piece.
+        bands = COMPARE_BANDS if (max_count >= COMPARE_BAND_MIN_SLOTS * COMPARE_BANDS and not _staged(hashes, group)) else 1
+        per = (max_count + bands - 1) // bands
+        full = backend.empty((n_tiles * TILE, n), torch.int32)
+        view = full.view(n_tiles, TILE, n)
+        in_flight = []
+        for b in range(bands):
+            s0, s1 = b * per, min(max_count, (b + 1) * per)
+            if s1 <= s0:
+                break
+            mine = min(count, s1) - min(count, s0)                 # this rank's tiles of the band
+            local = backend.compare_tiles(hashes, offsets, n, first + s0 * stride, stride, mine)
+            if local.shape[0] != (s1 - s0) * TILE:                 # equal-sized pieces for all_gather
+                pad = backend.zeros(((s1 - s0) * TILE, n), local.dtype)
+                pad[:local.shape[0]] = local
+                local = pad
+            # (as bytes: neither RCCL nor gloo moves 16-bit integers; truncation keeps the low 16 bits)
+            send = local.to(torch.int16).view(torch.uint8) if narrow else local
+            pieces = [backend.empty(tuple(send.shape), send.dtype) for _ in range(world)]
+            work = _all_gather(pieces, send, group, async_op=bands > 1)
+            in_flight.append((s0, s1, pieces, work, send))
+        mark()
+        for s0, s1, pieces, work, _send in in_flight:
+            if work is not None:
+                work.wait()                                        # (orders the current stream behind the collective)
+            if narrow:
+                pieces = [p.view(torch.int16).to(torch.int32).bitwise_and_(0xFFFF) for p in pieces]
+            for r in range(world):                                 # un-deal: slot s of rank r is tile r + world * s
+                cnt = max(0, min((n_tiles - r + world - 1) // world if n_tiles > r else 0, s1) - s0)
+                if cnt:
+                    view[r + world * s0: r + world * (s0 + cnt): world] = pieces[r].view(-1, TILE, n)[:cnt]
+        full = full[:n].contiguous() if full.shape[0] != n else full
         if timing is not None:
             timing["exchange_bytes_per_entry"] = 2 if narrow else 4
+            timing["exchange_pieces"] = len(in_flight)
     mark()
     backend.symmetrize(full, n)
     jac = backend.jaccard(full, offsets, n) if want_jaccard else None

@@ -217,6 +217,13 @@ def _worker(rank, world, port, ret):
         wc, wj = oracle.compare_all_pairs(*oracle.make_csr(sk))
         ok_cmp = np.array_equal(common.numpy().view(np.uint32), wc) and \
             np.array_equal(jac.numpy().view(np.uint64), wj.view(np.uint64))
+        # the same exchange cut into bands that travel while the next band's tiles are computed (asynchronous all-gathers)
+        parallel.COMPARE_BAND_MIN_SLOTS = 0
+        t_banded = {}
+        common_b, jac_b = parallel.compare_all_pairs_distributed(h, off, len(sk), be, timing=t_banded)
+        parallel.COMPARE_BAND_MIN_SLOTS = 8
+        ok_cmp = ok_cmp and np.array_equal(common_b.numpy().view(np.uint32), wc) and np.array_equal(jac_b.numpy().view(np.uint64), wj.view(np.uint64))
+        ok_cmp = ok_cmp and t_banded.get("exchange_pieces") == 2
         # counts travel as 16-bit words unless a sketch could share 65,536 hashes or more: two sketches of 70,000 that share
         # 66,000 take the 32-bit form (and a wrapped count would show)
         wide = [np.arange(1, 70_001, dtype=np.uint64) * np.uint64(977), np.arange(4001, 74_001, dtype=np.uint64) * np.uint64(977)]
