@@ -111,8 +111,43 @@ def jaccard_to_distance_vectors():
         json.dump(doc, fh)
 
 
+def containment_to_distance_vectors():
+    """tests/golden/containment_to_distance.json: outputs of the REFERENCE's containment_to_distance (distance_utils.py:258-346,
+    point estimate + confidence interval), get_exp_probability_nothing_common (:233-255), set_size_exact_prob (:198-231) and
+    set_size_chernoff (:181-196) on seeded inputs, floats as hex -- pins the host float layer of this package
+    (sourmash_amd/distance_utils.py) to the reference module itself, beyond the handful of values its tests print."""
+    import random
+    m = reference_distance_utils()
+    random.seed(11)
+    cases = []
+    for i in range(150):
+        c = random.random() ** random.choice([1, 3])
+        if i % 25 == 0:
+            c = [0.0, 1.0][(i // 25) % 2]
+        k = random.choice([21, 31, 51, 7, 10])
+        scaled = random.choice([1, 100, 1000, 10000])
+        n = random.choice([1000, 50000, 5_000_000])
+        try:
+            r = m.containment_to_distance(c, k, scaled, n_unique_kmers=n, estimate_ci=True)
+            out = [r.dist.hex(), None if r.dist_low is None else float(r.dist_low).hex(), None if r.dist_high is None else float(r.dist_high).hex(),
+                   float(r.p_nothing_in_common).hex(), bool(r.p_exceeds_threshold)]
+        except ValueError:
+            out = None
+        cases.append(["c2d", c.hex(), k, scaled, n, out])
+    for i in range(60):
+        n = random.choice([100, 5000, 123456, 5_000_000])
+        scaled = random.choice([1, 10, 100, 1000])
+        cases.append(["size", n, scaled, float(m.set_size_exact_prob(n, scaled, relative_error=0.2)).hex(), float(m.set_size_chernoff(n, scaled, relative_error=0.2)).hex()])
+    doc = {"source": "src/sourmash/distance_utils.py: containment_to_distance(c, ksize, scaled, n_unique_kmers=n, estimate_ci=True) -> "
+                     "[dist, dist_low, dist_high, p_nothing_in_common (hex), p_exceeds_threshold] or null where it raises; "
+                     "set_size_exact_prob / set_size_chernoff(n, scaled, relative_error=0.2)", "cases": cases}
+    with open(os.path.join(HERE, "containment_to_distance.json"), "w") as fh:
+        json.dump(doc, fh)
+
+
 def main():
     jaccard_to_distance_vectors()
+    containment_to_distance_vectors()
     manifest = []
     for src, dst, why in FILES:
         s = os.path.join(REF, src)
