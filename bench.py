@@ -57,7 +57,7 @@ PMC_FILE = _newest("profiles/r04_pmc.txt", "profiles/r03_pmc.txt")
 PMC_GATHER_FILE = _newest("profiles/r04_gather_pmc.txt", "profiles/r03_gather_pmc.txt")
 PMC_COMPARE_FILE = _newest("profiles/r04_compare_pmc.txt", "profiles/r03_compare_pmc.txt")
 COMPARE_BITS_SOURCES = ["bitindex.hip"]
-SKETCH_SOURCES = ["sketch.hip", "kmer_core.hpp", "murmur3.hpp"]
+SKETCH_SOURCES = ["sketch.hip", "sketch_kernel.hpp", "kmer_core.hpp", "murmur3.hpp"]
 GATHER_SOURCES = ["gather.hip", "qindex.hpp"]
 PMC_C2_INPUT_BYTES = 9_990_000_999                        # the launch the sketch counters were taken on (default C2 batch)
 N_SIMDS = 1024

@@ -31,7 +31,7 @@ from pmcfile import source_hashes  # noqa: E402
 
 CSRC = os.path.join(ROOT, "sourmash_amd", "csrc")
 KERNEL = "sketch_dna_kernelILi31ELi16ELb0E"
-SOURCES = ["sketch.hip", "kmer_core.hpp", "murmur3.hpp"]
+SOURCES = ["sketch.hip", "sketch_kernel.hpp", "kmer_core.hpp", "murmur3.hpp"]
 FINISH_PROB = 1.0 / 16.0      # wave-steps whose hash is finished at scaled = 1000 (early reject on the top dword)
 KEEP_PROB = 1.0 - (1.0 - 1.0 / 1000.0) ** 64   # wave-steps in which some lane keeps a hash at scaled = 1000 (the LDS append)
 
