@@ -25,6 +25,7 @@
 // Only tiles on or above the diagonal run; a lane writes its pair's entry and the mirrored one.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <type_traits>
 #include "device_api.hpp"
 
@@ -39,6 +40,7 @@ constexpr int XSTRIDE = XSEG + XPAD;
 
 constexpr int XZMAX = 16;              // hash-range slices a tile of abundance sketches can be cut into (grid.z)
 constexpr uint32_t XSLICE = 6144;      // hashes of the tile's longest sketch per slice: ordinary sketches (~5,000) are never cut
+constexpr uint32_t XSLICE_SMALL = 1700;   // ... for small grids (see compare_abund_launch)
 
 enum { X_NUM = 0, X_ABUND32 = 1, X_ABUND64 = 2 };
 
@@ -53,7 +55,8 @@ __device__ __forceinline__ uint64_t lower_bound_u64(const uint64_t* __restrict__
 template <int MODE>
 __global__ __launch_bounds__(XT * XT) void compare_ext_kernel(
     const uint64_t* __restrict__ hashes, const uint64_t* __restrict__ abunds, const uint64_t* __restrict__ offsets,
-    const uint32_t* __restrict__ nums, uint32_t n, uint32_t* __restrict__ common, unsigned long long* __restrict__ prod) {
+    const uint32_t* __restrict__ nums, uint32_t n, uint32_t* __restrict__ common, unsigned long long* __restrict__ prod,
+    uint32_t slice_len) {
     // nums: per sketch, the `num` of the pair (i, j), i < j, is nums[i] (compare.py:39: siglist[i].similarity(siglist[j]);
     //       minhash.rs:596-604: self.num); common / prod: full n x n, diagonal left to the caller
     constexpr bool ABUND = MODE != X_NUM;
@@ -101,7 +104,7 @@ __global__ __launch_bounds__(XT * XT) void compare_ext_kernel(
             const unsigned long long holders = __ballot(len == best_len);
             const uint64_t best_pos = __shfl(pos, (int)__builtin_ctzll(holders));
             if (lane == 0) {
-                uint32_t zt = (uint32_t)((best_len + XSLICE - 1) / XSLICE);
+                uint32_t zt = (uint32_t)((best_len + slice_len - 1) / slice_len);
                 zt = zt < 1 ? 1 : (zt > (uint32_t)XZMAX ? (uint32_t)XZMAX : zt);
                 s_zt = zt;
                 const uint32_t z = blockIdx.z;
@@ -268,7 +271,7 @@ hipError_t compare_num_launch(const uint64_t* d_hashes, const uint64_t* d_offset
     if (n == 0) return hipSuccess;
     const uint32_t nt = (n + XT - 1) / XT;
     hipLaunchKernelGGL((compare_ext_kernel<X_NUM>), dim3(nt, nt), dim3(XT * XT), 0, stream, d_hashes, (const uint64_t*)nullptr, d_offsets,
-                       d_nums, n, d_common, (unsigned long long*)nullptr);
+                       d_nums, n, d_common, (unsigned long long*)nullptr, XSLICE);
     hipLaunchKernelGGL(ext_rows_kernel, dim3((n * 64u + 255u) / 256u), dim3(256), 0, stream, (const uint64_t*)nullptr, d_offsets, n, d_common,
                        (unsigned long long*)nullptr, (unsigned long long*)nullptr);
     if (d_union || d_jaccard)
@@ -287,12 +290,18 @@ hipError_t compare_abund_launch(const uint64_t* d_hashes, const uint64_t* d_abun
     if (e != hipSuccess) return e;
     e = hipMemsetAsync(d_prod, 0, (size_t)n * n * 8, stream);
     if (e != hipSuccess) return e;
+    // slice length: tiles of ordinary sketches are cut as well when the grid is small -- a 1,000-sketch collection is 2,016 tiles
+    // on 1,536 resident workgroups (two rounds, the second a third full); three slices per tile fill the rounds (5.83 -> 5.47 ms at C3)
+    static const uint32_t slice_env = [] { const char* e = getenv("SMG_COMPARE_ABUND_SLICE"); return e ? (uint32_t)atoi(e) : 0u; }();
+    const uint32_t tiles = nt * (nt + 1) / 2;
+    uint32_t slice_len = tiles >= 16384 ? XSLICE : XSLICE_SMALL;
+    if (slice_env) slice_len = slice_env;
     if (narrow)
         hipLaunchKernelGGL((compare_ext_kernel<X_ABUND32>), dim3(nt, nt, XZMAX), dim3(XT * XT), 0, stream, d_hashes, d_abunds, d_offsets,
-                           (const uint32_t*)nullptr, n, d_common, d_prod);
+                           (const uint32_t*)nullptr, n, d_common, d_prod, slice_len);
     else
         hipLaunchKernelGGL((compare_ext_kernel<X_ABUND64>), dim3(nt, nt, XZMAX), dim3(XT * XT), 0, stream, d_hashes, d_abunds, d_offsets,
-                           (const uint32_t*)nullptr, n, d_common, d_prod);
+                           (const uint32_t*)nullptr, n, d_common, d_prod, slice_len);
     hipLaunchKernelGGL(ext_rows_kernel, dim3((n * 64u + 255u) / 256u), dim3(256), 0, stream, d_abunds, d_offsets, n, d_common, d_prod, d_sumsq);
     return hipGetLastError();
 }
