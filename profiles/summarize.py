@@ -13,6 +13,8 @@ def short(name):
     if "rocprim" in name and m:
         return "rocprim::" + m.group(1)
     name = name.replace("(anonymous namespace)::", "")
+    name = re.sub(r"^void ", "", name)
+    name = re.sub(r"<smg::OwGeom<(\d+), [^>]*> >", r"<OwGeom\1>", name)       # overlap_lean_kernel<smg::OwGeom<25, 8192, ...> > -> <OwGeom25>
     name = re.sub(r"\(.*", "", name)
     return name[:90]
 
