@@ -12,8 +12,9 @@ and Jaccard / containment / ANI are derived from it on whole arrays:
     ani[i][j]          = 1 - (1 - containment^(1/k))             (host libm pow, distance_utils.py:276-283)
 Bottom-k (num) sketches and abundance-weighted (angular) similarity have tile kernels of their own (csrc/compare_ext.hip);
 collections with several scaled values are served one launch per value (every pair at ITS coarser scaled, like
-similarity(downsample=True)); Jaccard-derived ANI is whole-array arithmetic on the Jaccard matrix.  Only the containment
-variants of mixed-scaled collections still walk the pairs.
+similarity(downsample=True)); Jaccard- and containment-derived ANI and the containment matrices of mixed-scaled lists are
+whole-array arithmetic on count matrices.  The per-pair loop remains only as the way a list with an incompatible pair raises
+the reference's error from the reference's pair.
 """
 import ctypes as C
 import itertools
@@ -265,30 +266,75 @@ def _ani_from_containment(cont, ksize):
     return 1 - point
 
 
-def _containment(siglist, downsample, mode, return_ani):
-    n = len(siglist)
-    mhs = [s.minhash for s in siglist]
-    if not all(mh.scaled for mh in mhs):
-        raise TypeError("Error: can only calculate %s for scaled MinHashes" % ("ANI" if return_ani else "containment"))
-    if not _uniform(mhs):
-        return _containment_pairs(siglist, downsample, mode, return_ani)
-    flat = [mh.flatten() for mh in mhs]
+def _containment_block(flat, scaled, mode, return_ani):
+    "containment / max / avg containment (or their ANI point estimates, no trust masking) of flat sketches of ONE scaled value"
+    n = len(flat)
     common, _ = common_matrix(flat, want_jaccard=False)
     sizes = [len(mh) for mh in flat]
-    scaled, ksize = flat[0].scaled, flat[0].ksize
+    ksize = flat[0].ksize
     if not return_ani:
         return _debias_matrix(common, sizes, scaled, mode)
-    # ANI (compare.py:67-187): the containment of every entry -> point estimate; an estimate is withheld (0 in the
-    # matrix) when either sketch is too small for its size to be trusted (minhash.py:869-871)
+    # ANI (compare.py:67-187): the containment of every entry -> point estimate
     if mode == "avg":
         sz = np.asarray(sizes, dtype=np.float64)
         bias = _bias_factors(sizes, scaled)
         cm = np.asarray(common, dtype=np.float64)
         a1 = _ani_from_containment(_debias(cm, sz[None, :], bias[None, :]), ksize).reshape(n, n)
         a2 = _ani_from_containment(_debias(cm, sz[:, None], bias[:, None]), ksize).reshape(n, n)
-        out = (a1 + a2) / 2
-    else:
-        out = _ani_from_containment(_debias_matrix(common, sizes, scaled, mode), ksize).reshape(n, n)
+        return (a1 + a2) / 2
+    return _ani_from_containment(_debias_matrix(common, sizes, scaled, mode), ksize).reshape(n, n)
+
+
+def _containment_mixed(flat, mode):
+    """containment / max / avg containment of a list with SEVERAL scaled values, downsample = True, in the reference's
+    (asymmetric) arithmetic: the count of a pair is taken at the pair's coarser scaled (count_common downsamples the finer
+    sketch, minhash.rs:539-548), but the denominator and its bias factor are those of the sketch AS GIVEN -- len(self) and
+    self.scaled (minhash.py:819-841), min(len(self), len(other)) with self.scaled for max containment (:881-905), self being
+    the sketch with the higher index of the pair (compare.py:111-150).  One launch per scaled value for the counts, then
+    whole-array arithmetic; the bias factors are one libm pow per (sketch, scaled value)."""
+    n = len(flat)
+    cm = _by_scaled(flat, True, lambda sub, s: common_matrix(sub, want_jaccard=False)[0].astype(np.float64))
+    sz = np.array([len(mh) for mh in flat], dtype=np.float64)
+    sc = [mh.scaled for mh in flat]
+    own_bias = np.array([_bias_factors([len(mh)], mh.scaled)[0] for mh in flat], dtype=np.float64)
+    if mode == "containment":            # [i][j] = siglist[j].contained_by(siglist[i]): j's size, j's scaled
+        out = _debias(cm, sz[None, :], own_bias[None, :])
+    elif mode == "avg":                  # (self.contained_by(other) + other.contained_by(self)) / 2
+        out = (_debias(cm, sz[None, :], own_bias[None, :]) + _debias(cm, sz[:, None], own_bias[:, None])) / 2
+    else:                                # max: min of the two sizes, the bias at the scaled of `self` = the higher index
+        values = sorted(set(sc))
+        bias_at = {s: _bias_factors([len(mh) for mh in flat], s) for s in values}       # [scaled][sketch]
+        idx = np.arange(n)
+        hi = np.maximum(idx[:, None], idx[None, :])                 # `self` of the pair
+        lo = np.minimum(idx[:, None], idx[None, :])
+        small = np.where(sz[hi] <= sz[lo], hi, lo)                  # whose size is min(len(self), len(other)) (ties: the value is the same)
+        denom = sz[small]
+        sc_arr = np.array(sc)
+        bias = np.empty((n, n), dtype=np.float64)
+        for s in values:
+            m = sc_arr[hi] == s
+            bias[m] = bias_at[s][small[m]]
+        out = _debias(cm, denom, bias)
+    out[np.arange(n), np.arange(n)] = 1.0
+    return out
+
+
+def _containment(siglist, downsample, mode, return_ani):
+    n = len(siglist)
+    mhs = [s.minhash for s in siglist]
+    if not all(mh.scaled for mh in mhs):
+        raise TypeError("Error: can only calculate %s for scaled MinHashes" % ("ANI" if return_ani else "containment"))
+    if not _batchable(mhs, downsample):
+        return _containment_pairs(siglist, downsample, mode, return_ani)      # some pair raises: from the same pair as the reference's loop
+    flat = [mh.flatten() for mh in mhs]
+    if not return_ani:
+        if len({mh.scaled for mh in flat}) == 1:
+            return _containment_block(flat, flat[0].scaled, mode, False)
+        return _containment_mixed(flat, mode)
+    # ANI: both sketches are downsampled to the pair's coarser scaled first, then everything is computed there
+    # (minhash.py:843-879,907-944): the blocks of _by_scaled are exactly that; an estimate is withheld (0 in the matrix) when
+    # either sketch AS GIVEN is too small for its size to be trusted (minhash.py:869-871)
+    out = _by_scaled(flat, downsample, lambda sub, s: _containment_block(sub, s, mode, True))
     trusted = np.array([mh.size_is_accurate() for mh in mhs], dtype=bool)
     out = np.where(trusted[:, None] & trusted[None, :], out, 0.0)
     out[np.arange(n), np.arange(n)] = 1.0

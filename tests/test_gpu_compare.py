@@ -379,16 +379,26 @@ def test_mixed_scaled_and_mixed_abundance_follow_the_per_pair_rule(sm):
     sigs += [sm.SourmashSignature(mh, name="coarse") for mh in coarse]
     with pytest.raises(ValueError):
         compare_serial(sigs, True, downsample=False)                 # MismatchScaled, like the reference's first mixed pair
+    from sourmash_amd.compare import compare_serial_avg_containment
     j = compare_serial(sigs, True, downsample=True)
     c = compare_serial_containment(sigs, downsample=True)
     m = compare_serial_max_containment(sigs, downsample=True)
+    av = compare_serial_avg_containment(sigs, downsample=True)
+    c_ani = compare_serial_containment(sigs, downsample=True, return_ani=True)
+    m_ani = compare_serial_max_containment(sigs, downsample=True, return_ani=True)
     for a in range(len(sigs)):
         for b in range(len(sigs)):
             if a == b:
                 continue
             assert j[a, b] == sigs[a].similarity(sigs[b], ignore_abundance=True, downsample=True)
             assert c[a, b] == sigs[b].contained_by(sigs[a], downsample=True)
-            assert m[a, b] == sigs[b].max_containment(sigs[a], downsample=True)
+            hi, lo = (a, b) if a > b else (b, a)                     # the reference's loops call the method on the higher index
+            assert m[a, b] == sigs[hi].max_containment(sigs[lo], downsample=True)
+            assert av[a, b] == sigs[hi].avg_containment(sigs[lo], downsample=True)
+            r = sigs[b].containment_ani(sigs[a], downsample=True).ani
+            assert c_ani[a, b] == (0.0 if r is None else r)
+            r = sigs[hi].max_containment_ani(sigs[lo], downsample=True).ani
+            assert m_ani[a, b] == (0.0 if r is None else r)
     # the (0, 1) pair is compared at scaled 1000 although the list holds scaled-2000 sketches
     assert j[0, 1] == sigs[0].jaccard(sigs[1]) != sigs[0].minhash.downsample(scaled=2000).jaccard(sigs[1].minhash.downsample(scaled=2000))
     # abundance: sketches 1 and 3 weighted, the others flat
