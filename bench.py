@@ -97,6 +97,12 @@ def main():
     if not torch.cuda.is_available():
         print("bench.py needs a GPU (the product path has no CPU fallback)", file=sys.stderr)
         sys.exit(2)
+    # SMG_BENCH_SHARE_GPU=1: a rehearsal of the N > 1 launch on a box with ONE GPU -- every rank uses device 0 and the process
+    # group is gloo (RCCL refuses two ranks on one device; sourmash_amd.parallel stages device tensors through the host around
+    # gloo collectives).  Same code path as `--gpus N` otherwise; the numbers it prints mean nothing.
+    share_gpu = os.environ.get("SMG_BENCH_SHARE_GPU") == "1"
+    if share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     # SMG_BENCH_FORCE_COLLECTIVES=1 exercises the RCCL code path even with a single rank (1-GPU test boxes)
@@ -104,7 +110,10 @@ def main():
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if share_gpu:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import sourmash_amd as sm  # noqa: F401
     from sourmash_amd import device as smd, parallel
@@ -276,7 +285,7 @@ def main():
                        "bases_per_gpu": bases_per_step, "bytes_per_gpu": n_bytes, "ksize": args.ksize,
                        "scaled": args.scaled, "unique_hashes_rank0": n_unique_local,
                        "unique_hashes_job": n_unique_total, "allgather_ms": gather_ms,
-                       "collectives": "rccl" if use_dist else "none (single rank)"},
+                       "collectives": ("gloo, ranks sharing one GPU (rehearsal)" if share_gpu else "rccl") if use_dist else "none (single rank)"},
             "roofline": roofline, "cpu_baseline": cpu, "extra": extra,
         }
     if use_dist:
