@@ -2264,6 +2264,10 @@ struct OwGeom {
 };
 using OwOne = OwGeom<25, 8192, 11264, uint32_t, 4, 4>;    // 88 KB + 32 KB + 4.7 KB = 127.7 KB: one workgroup per CU
 using OwTwo = OwGeom<13, 8192, 7680, uint16_t, 8, 2>;     // 60 KB + 16 KB + 2.5 KB = 78.5 KB: two workgroups per CU
+#ifndef SMG_OW_LEAN_BATCH
+#define SMG_OW_LEAN_BATCH 4
+#endif
+using OwLean = OwGeom<25, 8192, 11264, uint32_t, 4, SMG_OW_LEAN_BATCH>;   // the lean kernel's geometry: One's, more visits looked up side by side
 constexpr int OW_BUCKETS = OwOne::BUCKETS;
 
 template <class G>
@@ -2744,7 +2748,7 @@ hipError_t overlap_ranges_launch(const uint64_t* Q, uint64_t nq, const uint64_t*
         static int lean_attr = 0;
         constexpr size_t LEAN_LDS = ((size_t)OwOne::QCAP + 2) * 8 + OwOne::T_BYTES;
         if (lean_attr == 0) {
-            const hipError_t ea = hipFuncSetAttribute((const void*)overlap_lean_kernel<OwOne>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LEAN_LDS);
+            const hipError_t ea = hipFuncSetAttribute((const void*)overlap_lean_kernel<OwLean>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LEAN_LDS);
             lean_attr = ea == hipSuccess ? 1 : -1;
             if (lean_attr < 0) (void)hipGetLastError();
         }
@@ -2752,7 +2756,7 @@ hipError_t overlap_ranges_launch(const uint64_t* Q, uint64_t nq, const uint64_t*
         if (lean_attr > 0 && (pick == 0 || pick == 3) && w_widest <= (unsigned)OwOne::QCAP && q_max != ~0ull) {
             const uint64_t rpw = rows_per_wg((uint64_t)n_cu_w, OwOne::ROWS);
             const uint64_t n_wg = (ndb + rpw - 1) / rpw;
-            hipLaunchKernelGGL(overlap_lean_kernel<OwOne>, dim3((unsigned)n_wg), dim3(OW_THREADS), LEAN_LDS, stream, Q, (const uint32_t*)table, buckets,
+            hipLaunchKernelGGL(overlap_lean_kernel<OwLean>, dim3((unsigned)n_wg), dim3(OW_THREADS), LEAN_LDS, stream, Q, (const uint32_t*)table, buckets,
                                shift, hashes, offsets, ndb, (uint32_t)rpw, w_ranges, wbpr, cnt);
             wide_done = true;
         } else if (attr_state > 0 && pick != 1 && pick != 0 && w2_widest <= (unsigned)OwTwo::QCAP && w2_widest > 0) {
