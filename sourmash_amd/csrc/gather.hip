@@ -2267,7 +2267,7 @@ using OwTwo = OwGeom<13, 8192, 7680, uint16_t, 8, 2>;     // 60 KB + 16 KB + 2.5
 #ifndef SMG_OW_LEAN_BATCH
 #define SMG_OW_LEAN_BATCH 4
 #endif
-using OwLean = OwGeom<25, 8192, 11264, uint32_t, 4, SMG_OW_LEAN_BATCH>;   // the lean kernel's geometry: One's, more visits looked up side by side
+using OwLean = OwGeom<25, 10240, 11264, uint32_t, 4, SMG_OW_LEAN_BATCH>;  // the lean kernel's geometry: ranges cut by query hashes held, not at a power of two of buckets
 constexpr int OW_BUCKETS = OwOne::BUCKETS;
 
 template <class G>
@@ -2544,7 +2544,8 @@ void overlap_lean_kernel(const uint64_t* __restrict__ Q, const uint32_t* __restr
 #pragma unroll
                 for (int u = 0; u < FILL_STEP; ++u) {
                     const uint32_t i = (uint32_t)tid + (uint32_t)(u0 + u) * OW_THREADS;
-                    if (u0 + u < TPER && i < cnt_t) s_t[i] = (TT)(tv[u] - p0);
+                    // every slot of the slice is written, the ones behind the range's buckets with the slice's size
+                    if (u0 + u < TPER && i < (uint32_t)BUCKETS + 4u) s_t[i] = i < cnt_t ? (TT)(tv[u] - p0) : (TT)cnt_q;
                 }
             }
 #pragma unroll
@@ -2565,8 +2566,7 @@ void overlap_lean_kernel(const uint64_t* __restrict__ Q, const uint32_t* __restr
         // padding buckets behind the table slice; two words of 2^64 - 1 behind the query slice: a lookup reads the two query
         // hashes at its bucket's start whatever the bucket holds, and scans on while they are below its hash -- the slice is
         // sorted, so what follows a bucket is larger than any hash that falls into it, and the padding ends every scan
-        if (tid < 2) { s_t[bpr + 1 + tid] = (TT)cnt_q; s_q[cnt_q + tid] = ~0ull; }
-        if (tid >= 64 && tid < 64 + 3 && cnt_t + (uint32_t)(tid - 64) <= bpr) s_t[cnt_t + (uint32_t)(tid - 64)] = (TT)cnt_q;   // a short last range
+        if (tid < 2) s_q[cnt_q + tid] = ~0ull;                            // (the table slice's padding is written by its fill)
         __syncthreads();
         if (!last) {                                                     // the next range's bounds
             const uint32_t nb0 = b1, nb1 = nb0 + bpr < n_buckets ? nb0 + bpr : n_buckets;
@@ -2698,8 +2698,15 @@ hipError_t overlap_ranges_launch(const uint64_t* Q, uint64_t nq, const uint64_t*
     if (w2bpr > (uint32_t)OwTwo::BUCKETS) w2bpr = OwTwo::BUCKETS;
     if (w2bpr < 64) w2bpr = 64;
     const uint32_t w2_ranges = (buckets + w2bpr - 1) / w2bpr;
+    // the lean form: about `lean_q` query hashes per range (a row's part of a range is then ~46 of the 64 hashes a visit loads;
+    // more and one visit in thirty would have to load a second block on the spot)
+    static const double lean_q = [] { const char* e = getenv("SMG_OVERLAP_QPR"); return e ? atof(e) : 9600.0; }();
+    uint32_t lbpr = (uint32_t)(lean_q * (double)buckets / (double)nq);
+    if (lbpr > (uint32_t)OwLean::BUCKETS) lbpr = OwLean::BUCKETS;
+    if (lbpr < 64) lbpr = 64;
+    const uint32_t l_ranges = (buckets + lbpr - 1) / lbpr;
     // the widest range of either partition decides whether its LDS has room: all maxima come back with one synchronisation
-    unsigned int widest = 0, w_widest = 0, w2_widest = 0;
+    unsigned int widest = 0, w_widest = 0, w2_widest = 0, l_widest = 0;
     {
         unsigned int* d_widest = (unsigned int*)(cnt + ndb);                // the 64 spare bytes, zeroed above
         if (!no_stream)
@@ -2710,6 +2717,8 @@ hipError_t overlap_ranges_launch(const uint64_t* Q, uint64_t nq, const uint64_t*
                                w_ranges, wbpr, d_widest + 1);
             hipLaunchKernelGGL(stream_range_max_kernel, dim3((w2_ranges + 255) / 256), dim3(256), 0, stream, (const uint32_t*)table, buckets,
                                w2_ranges, w2bpr, d_widest + 2);
+            hipLaunchKernelGGL(stream_range_max_kernel, dim3((l_ranges + 255) / 256), dim3(256), 0, stream, (const uint32_t*)table, buckets,
+                               l_ranges, lbpr, d_widest + 3);
         }
         if (!no_stream || try_wide) {
             SMG_TRY(hipMemcpyAsync(&pin.p[1], d_widest, 16, hipMemcpyDeviceToHost, stream));
@@ -2717,6 +2726,7 @@ hipError_t overlap_ranges_launch(const uint64_t* Q, uint64_t nq, const uint64_t*
             widest = (unsigned int)(pin.p[1] & 0xffffffffull);
             w_widest = (unsigned int)(pin.p[1] >> 32);
             w2_widest = (unsigned int)(pin.p[2] & 0xffffffffull);
+            l_widest = (unsigned int)(pin.p[2] >> 32);
         }
     }
     hipError_t e = hipSuccess;
@@ -2746,18 +2756,18 @@ hipError_t overlap_ranges_launch(const uint64_t* Q, uint64_t nq, const uint64_t*
         // SMG_OVERLAP_WIDE=lean|one|two: the lean-visit kernel (default), the round-3 kernel, its two-workgroups-per-CU geometry
         static const int pick = [] { const char* e = getenv("SMG_OVERLAP_WIDE"); return !e ? 0 : !strcmp(e, "one") ? 1 : !strcmp(e, "two") ? 2 : !strcmp(e, "lean") ? 3 : 0; }();
         static int lean_attr = 0;
-        constexpr size_t LEAN_LDS = ((size_t)OwOne::QCAP + 2) * 8 + OwOne::T_BYTES;
+        constexpr size_t LEAN_LDS = ((size_t)OwLean::QCAP + 2) * 8 + OwLean::T_BYTES;
         if (lean_attr == 0) {
             const hipError_t ea = hipFuncSetAttribute((const void*)overlap_lean_kernel<OwLean>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LEAN_LDS);
             lean_attr = ea == hipSuccess ? 1 : -1;
             if (lean_attr < 0) (void)hipGetLastError();
         }
         // (2^64 - 1 in the query: the lean kernel's filler value would be a hit -- the round-3 kernel handles it)
-        if (lean_attr > 0 && (pick == 0 || pick == 3) && w_widest <= (unsigned)OwOne::QCAP && q_max != ~0ull) {
-            const uint64_t rpw = rows_per_wg((uint64_t)n_cu_w, OwOne::ROWS);
+        if (lean_attr > 0 && (pick == 0 || pick == 3) && l_widest <= (unsigned)OwLean::QCAP && l_widest > 0 && q_max != ~0ull) {
+            const uint64_t rpw = rows_per_wg((uint64_t)n_cu_w, OwLean::ROWS);
             const uint64_t n_wg = (ndb + rpw - 1) / rpw;
             hipLaunchKernelGGL(overlap_lean_kernel<OwLean>, dim3((unsigned)n_wg), dim3(OW_THREADS), LEAN_LDS, stream, Q, (const uint32_t*)table, buckets,
-                               shift, hashes, offsets, ndb, (uint32_t)rpw, w_ranges, wbpr, cnt);
+                               shift, hashes, offsets, ndb, (uint32_t)rpw, l_ranges, lbpr, cnt);
             wide_done = true;
         } else if (attr_state > 0 && pick != 1 && pick != 0 && w2_widest <= (unsigned)OwTwo::QCAP && w2_widest > 0) {
             const uint64_t rpw = rows_per_wg((uint64_t)n_cu_w * 2, OwTwo::ROWS);
