@@ -589,6 +589,43 @@ __global__ __launch_bounds__(256) void build_merge_counts_kernel(uint32_t* __res
     post_cnt[j] = run;
 }
 
+// The same for pass 1 through the lean kernel (overlap_lean_kernel<.., true>): part16 [n_sub][nq] holds what each of the n_sub
+// workgroups counted, row block b of the builder is the `m` consecutive workgroups b * m ...  A workgroup takes one window of
+// BR_SUB lists: thread t walks list j0 + t through the blocks, writes the block's exclusive prefix to partial[b][j] and leaves
+// the list's total in post_cnt[j]; the window's postings per block (subcnt, what pass 2 lays its intermediate buffer out by)
+// are summed from LDS afterwards.  B <= 64.
+constexpr int MS_BMAX = 64;
+__global__ __launch_bounds__(BR_SUB) void build_merge_sub_kernel(const uint16_t* __restrict__ part16, uint32_t n_sub, uint32_t m, uint32_t B,
+                                                                 uint64_t nq, uint32_t* __restrict__ partial,
+                                                                 unsigned long long* __restrict__ post_cnt, uint32_t* __restrict__ subcnt) {
+    __shared__ uint16_t s_c[MS_BMAX][BR_SUB + 2];                      // (+ 2: rows start on different banks)
+    const uint32_t w = blockIdx.x, t = threadIdx.x;
+    const uint64_t j = (uint64_t)w * BR_SUB + t;
+    const bool have = j < nq;
+    uint32_t run = 0;
+    for (uint32_t b = 0; b < B; ++b) {
+        uint32_t c = 0;
+        if (have) {
+            const uint32_t i0 = b * m, i1 = i0 + m < n_sub ? i0 + m : n_sub;
+            for (uint32_t i = i0; i < i1; ++i) c += part16[(uint64_t)i * nq + j];
+            partial[(uint64_t)b * nq + j] = run;
+        }
+        s_c[b][t] = (uint16_t)c;                                        // a block has < 65,536 rows
+        run += c;
+    }
+    if (j <= nq) post_cnt[j] = run;                                     // (post_cnt[nq] = 0 for the scan)
+    __syncthreads();
+    if ((uint64_t)w * BR_SUB >= nq) return;
+    // 4 threads per block: 64 lists each, then a sum over the 4
+    const uint32_t b = t >> 2, part = t & 3u;
+    uint32_t sum = 0;
+    if (b < B)
+        for (uint32_t x = 0; x < (uint32_t)BR_SUB / 4; ++x) sum += s_c[b][part * (BR_SUB / 4) + x];
+    sum += __shfl_down(sum, 2, 4);
+    sum += __shfl_down(sum, 1, 4);
+    if (part == 0 && b < B) subcnt[(uint64_t)w * B + b] = sum;
+}
+
 __device__ __forceinline__ unsigned long long wave_max(unsigned long long k) {
     for (int off = 32; off > 0; off >>= 1) {
         const unsigned long long o = __shfl_down(k, off);
@@ -1578,6 +1615,21 @@ hipError_t gather_build_kernel_ms(GatherDev& g, float* ms) {
 }
 
 static hipError_t gather_build_body(GatherDev& g, hipStream_t stream);
+// pass 1 through the lean streaming kernel (defined with it, further down)
+hipError_t build_lean_launch(const uint64_t* Q, uint64_t nq, const uint32_t* T, uint32_t n_buckets, uint32_t shift, const uint64_t* hashes,
+                             const uint64_t* offsets, uint64_t ndb, uint32_t rows_per_wg, uint32_t n_ranges, uint32_t bpr,
+                             unsigned long long* counters, uint32_t* qpos, uint16_t* part16, hipStream_t stream);
+struct LeanPlan { uint32_t bpr, n_ranges, qcap, rows_cap; };
+LeanPlan build_lean_plan(uint64_t nq, uint32_t buckets);
+// largest number of query hashes in any range (the caller checks it against the LDS room of the kernel that walks the ranges)
+__global__ __launch_bounds__(256) void stream_range_max_kernel(const uint32_t* __restrict__ T, uint32_t n_buckets, uint32_t n_ranges,
+                                                              uint32_t bpr, unsigned int* out) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_ranges) return;
+    const uint32_t b0 = r * bpr, b1 = b0 + bpr < n_buckets ? b0 + bpr : n_buckets;
+    atomicMax(out, T[b1] - T[b0]);
+}
+
 
 hipError_t gather_build(GatherDev& g, hipStream_t stream) {
     g.stream = stream;
@@ -1645,7 +1697,7 @@ static hipError_t gather_build_body(GatherDev& g, hipStream_t stream) {
         return hipSuccess;
     }
     const QIndex qi = qindex_of(g);
-    ArenaBuf post_cnt_b, scan_tmp_b, bounds_b, partial_b, subcnt_b, inter_off_b, lay_tmp_b, inter_b;
+    ArenaBuf post_cnt_b, scan_tmp_b, bounds_b, partial_b, subcnt_b, inter_off_b, lay_tmp_b, inter_b, part16_b;
     SMG_TRY(post_cnt_b.get(nq1 * 8, stream));
     unsigned long long* post_cnt = post_cnt_b.as<unsigned long long>();
     size_t scan_bytes = 0;
@@ -1688,17 +1740,56 @@ static hipError_t gather_build_body(GatherDev& g, hipStream_t stream) {
         if (B > (g.ndb + 127) / 128) B = (g.ndb + 127) / 128;       // at least one full step (8 waves x 16 rows) per block
         if (B < B_min) B = B_min;
         if (B < 1) B = 1;
-        const uint64_t rows_per_block = (g.ndb + B - 1) / B;
+        uint64_t rows_per_block = (g.ndb + B - 1) / B;
+        // two-level fill unless forced off or its packing does not apply (entries hold the row in 24 bits, offsets in 32)
+        const char* fill_env = getenv("SMG_GATHER_FILL");
+        bool staged = !(fill_env && !strcmp(fill_env, "direct")) && g.ndb < (1ull << BR_ROWBITS);
+        // Pass 1 through the lean streaming kernel (SMG_GATHER_PASS1=lean|ranges forces / forbids it): the query flows through LDS
+        // in ranges and every workgroup walks its own rows once -- no lookups in L2.  It wants a few hundred rows per CU, a query
+        // without the hash 2^64 - 1, ranges that fit its LDS (one more synchronisation: the widest range's size comes back first),
+        // and it counts per WORKGROUP: a row block of the builder becomes `m_sub` consecutive workgroups of `rpw` rows.
+        const char* pass1_s = getenv("SMG_GATHER_PASS1");
+        const int pass1_env = !pass1_s ? 0 : !strcmp(pass1_s, "ranges") ? 1 : !strcmp(pass1_s, "lean") ? 2 : 0;
+        bool lean1 = false;
+        LeanPlan lp{};
+        uint64_t m_sub = 1, rpw = 0, n_sub = 0;
+        {
+            int n_cu = 256;
+            { int dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev); }
+            if (pass1_env != 1 && staged && B <= (uint64_t)MS_BMAX && g.q_max != ~0ull && (pass1_env == 2 || g.ndb >= (uint64_t)n_cu * 64)) {
+                lp = build_lean_plan(g.nq, g.q_buckets);
+                unsigned int* d_widest = (unsigned int*)&g.state[GS_KEY];       // scratch again: zero since the first synchronisation
+                hipLaunchKernelGGL(stream_range_max_kernel, dim3((lp.n_ranges + 255) / 256), dim3(256), 0, stream, (const uint32_t*)g.q_table,
+                                   g.q_buckets, lp.n_ranges, lp.bpr, d_widest);
+                SMG_TRY(hipGetLastError());
+                g.pinned[9] = 0;
+                SMG_TRY(hipMemcpyAsync(&g.pinned[9], d_widest, 8, hipMemcpyDeviceToHost, stream));
+                SMG_TRY(hipMemsetAsync(&g.state[GS_KEY], 0, 8, stream));
+                SMG_TRY(timed_sync(g, stream));                           // synchronisation 2 of 3
+                const unsigned int widest = (unsigned int)(g.pinned[9] & 0xffffffffull);
+                if (widest > 0 && widest <= lp.qcap) {
+                    const uint64_t m_min = (rows_per_block + lp.rows_cap - 1) / lp.rows_cap;
+                    const uint64_t rounds = (B * m_min + (uint64_t)n_cu - 1) / (uint64_t)n_cu;
+                    m_sub = rounds * (uint64_t)n_cu / B;                    // full rounds of resident workgroups, no tail of a few
+                    if (m_sub < m_min) m_sub = m_min;
+                    rpw = (rows_per_block + m_sub - 1) / m_sub;
+                    n_sub = (g.ndb + rpw - 1) / rpw;
+                    lean1 = n_sub * g.nq * 2 <= (3ull << 30);
+                }
+                if (!lean1 && pass1_env == 2) return hipErrorInvalidValue;
+                if (lean1) {
+                    rows_per_block = rpw * m_sub;
+                    B = (g.ndb + rows_per_block - 1) / rows_per_block;
+                }
+            }
+        }
         SMG_TRY(bounds_b.get(((uint64_t)R + 1) * g.ndb * 4, stream));
         SMG_TRY(partial_b.get(B * g.nq * 4, stream));
         uint32_t *bounds = bounds_b.as<uint32_t>(), *partial = partial_b.as<uint32_t>();
         hipLaunchKernelGGL(build_bounds_kernel, dim3(blocks_for_rows(g.ndb)), dim3(256), 0, stream, g.Q, R, g.hashes,
                            g.offsets, g.ndb, bounds);
         SMG_TRY(hipGetLastError());
-        // two-level fill unless forced off or its packing does not apply (entries hold the row in 24 bits, offsets in 32)
-        const char* fill_env = getenv("SMG_GATHER_FILL");
         const uint32_t n_windows = R * BR_NSUB;
-        bool staged = !(fill_env && !strcmp(fill_env, "direct")) && g.ndb < (1ull << BR_ROWBITS);
         uint32_t *subcnt = nullptr, *inter_off = nullptr, *inter = nullptr;
         if (staged) {
             SMG_TRY(subcnt_b.get((uint64_t)n_windows * B * 4, stream));
@@ -1708,13 +1799,22 @@ static hipError_t gather_build_body(GatherDev& g, hipStream_t stream) {
             SMG_TRY(hipMemsetAsync(subcnt, 0, (uint64_t)n_windows * B * 4, stream));   // ranges past R launch nothing
         }
         const unsigned range_grid = (unsigned)(((R + 7) / 8) * 8 * B);
-        hipLaunchKernelGGL(build_range_kernel<0>, dim3(range_grid), dim3(BR_THREADS), 0, stream, qi, g.hashes, g.offsets,
-                           g.ndb, bounds, R, (uint32_t)B, rows_per_block, partial, (const uint64_t*)nullptr, (uint32_t*)nullptr,
-                           g.counters, g.qpos, subcnt, (const uint32_t*)nullptr, (uint32_t*)nullptr);
-        SMG_TRY(hipGetLastError());
-        hipLaunchKernelGGL(build_merge_counts_kernel, dim3((unsigned)((nq1 + 255) / 256)), dim3(256), 0, stream, partial,
-                           (uint32_t)B, g.nq, post_cnt);
-        SMG_TRY(hipGetLastError());
+        if (lean1) {
+            SMG_TRY(part16_b.get(n_sub * g.nq * 2 + 64, stream));
+            SMG_TRY(build_lean_launch(g.Q, g.nq, g.q_table, g.q_buckets, g.q_shift, g.hashes, g.offsets, g.ndb, (uint32_t)rpw, lp.n_ranges,
+                                      lp.bpr, g.counters, g.qpos, part16_b.as<uint16_t>(), stream));
+            hipLaunchKernelGGL(build_merge_sub_kernel, dim3((unsigned)((nq1 + BR_SUB - 1) / BR_SUB)), dim3(BR_SUB), 0, stream,
+                               (const uint16_t*)part16_b.as<uint16_t>(), (uint32_t)n_sub, (uint32_t)m_sub, (uint32_t)B, g.nq, partial, post_cnt, subcnt);
+            SMG_TRY(hipGetLastError());
+        } else {
+            hipLaunchKernelGGL(build_range_kernel<0>, dim3(range_grid), dim3(BR_THREADS), 0, stream, qi, g.hashes, g.offsets,
+                               g.ndb, bounds, R, (uint32_t)B, rows_per_block, partial, (const uint64_t*)nullptr, (uint32_t*)nullptr,
+                               g.counters, g.qpos, subcnt, (const uint32_t*)nullptr, (uint32_t*)nullptr);
+            SMG_TRY(hipGetLastError());
+            hipLaunchKernelGGL(build_merge_counts_kernel, dim3((unsigned)((nq1 + 255) / 256)), dim3(256), 0, stream, partial,
+                               (uint32_t)B, g.nq, post_cnt);
+            SMG_TRY(hipGetLastError());
+        }
         SMG_TRY(rocprim::exclusive_scan(scan_tmp, scan_bytes, (uint64_t*)post_cnt, g.post_off, (uint64_t)0, (size_t)nq1,
                                         rocprim::plus<uint64_t>(), stream));
         SMG_TRY(hipMemcpyAsync(&g.pinned[8], g.post_off + g.nq, 8, hipMemcpyDeviceToHost, stream));
@@ -1725,7 +1825,7 @@ static hipError_t gather_build_body(GatherDev& g, hipStream_t stream) {
             SMG_TRY(lay_tmp_b.get(lay_bytes + 256, stream));
             SMG_TRY(rocprim::exclusive_scan(lay_tmp_b.p, lay_bytes, subcnt, inter_off, 0u, (size_t)n_windows * B, rocprim::plus<uint32_t>(), stream));
         }
-        SMG_TRY(timed_sync(g, stream));                           // synchronisation 2 of 2
+        SMG_TRY(timed_sync(g, stream));                           // the last synchronisation (2 of 2, or 3 of 3 with the lean pass 1)
         g.npairs = g.pinned[8];
         SMG_TRY(own_alloc(g, &g.post_rows, (g.npairs + 4) * 4));
         const uint64_t inter_words = g.npairs + 4;
@@ -2127,15 +2227,6 @@ constexpr int SL_GROUPS = SL_THREADS / SL_GROUP;
 constexpr int SL_AHEAD = 4;               // row visits a group has in flight: a visit is one ~1 us load from HBM, and 51 million of
                                           // them (rows x ranges at C5) must overlap
 
-// largest number of query hashes in any range (the caller checks it against SL_QCAP)
-__global__ __launch_bounds__(256) void stream_range_max_kernel(const uint32_t* __restrict__ T, uint32_t n_buckets, uint32_t n_ranges,
-                                                              uint32_t bpr, unsigned int* out) {
-    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n_ranges) return;
-    const uint32_t b0 = r * bpr, b1 = b0 + bpr < n_buckets ? b0 + bpr : n_buckets;
-    atomicMax(out, T[b1] - T[b0]);
-}
-
 template <int MODE>    // 3: overlaps only (counters[d] += |Q ∩ row d|)
 __global__ __launch_bounds__(SL_THREADS) void stream_lookup_kernel(const uint64_t* __restrict__ Q, const uint32_t* __restrict__ T,
                                                                    uint32_t n_buckets, uint32_t shift, uint64_t qmax,
@@ -2269,6 +2360,16 @@ using OwTwo = OwGeom<13, 8192, 7680, uint16_t, 8, 2>;     // 60 KB + 16 KB + 2.5
 #endif
 using OwLean = OwGeom<25, 10240, 11264, uint32_t, 4, SMG_OW_LEAN_BATCH>;  // the lean kernel's geometry: ranges cut by query hashes held, not at a power of two of buckets
 constexpr int OW_BUCKETS = OwOne::BUCKETS;
+
+// ranges of the lean kernel: about `lean_q` query hashes each (a row's part of a range is then ~48 of the 64 hashes a visit loads;
+// more and one visit in sixteen would have to load a second block on the spot), at most as many buckets as the table slice holds
+LeanPlan build_lean_plan(uint64_t nq, uint32_t buckets) {
+    static const double lean_q = [] { const char* e = getenv("SMG_OVERLAP_QPR"); return e ? atof(e) : 9600.0; }();
+    uint32_t bpr = (uint32_t)(lean_q * (double)buckets / (double)nq);
+    if (bpr > (uint32_t)OwLean::BUCKETS) bpr = OwLean::BUCKETS;
+    if (bpr < 64) bpr = 64;
+    return LeanPlan{bpr, (buckets + bpr - 1) / bpr, (uint32_t)OwLean::QCAP, (uint32_t)OwLean::ROWS};
+}
 
 template <class G>
 __global__ __launch_bounds__(OW_THREADS) __attribute__((amdgpu_waves_per_eu(G::WAVES_PER_EU, G::WAVES_PER_EU)))
@@ -2488,22 +2589,32 @@ void overlap_wide_kernel(const uint64_t* __restrict__ Q, const uint32_t* __restr
 //     belong to later buckets and cannot equal a hash that falls into this one;
 //   * no clamp on the way to the query slice (two spare words behind it), no test against the largest query hash (hashes above
 //     it fall into padding buckets); a query that holds 2^64 - 1 itself takes the kernel above.
-template <class G>
+// BUILD: the same walk as pass 1 of the gather index build (build_range_kernel<0>'s outputs): every database hash's position in
+// the query (or NONE32) goes to `qpos` -- a visit stores the positions of the hashes it consumes, consecutive lanes -- and the
+// postings this workgroup's rows add to every query hash are counted in LDS (16-bit counters: a workgroup has < 65,536 rows)
+// and written to part16[workgroup][query position] when the range is through.  counts[] then is the builder's 64-bit overlap.
+template <class G, bool BUILD>
 __global__ __launch_bounds__(OW_THREADS) __attribute__((amdgpu_waves_per_eu(G::WAVES_PER_EU, G::WAVES_PER_EU)))
 void overlap_lean_kernel(const uint64_t* __restrict__ Q, const uint32_t* __restrict__ T, uint32_t n_buckets, uint32_t shift,
                          const uint64_t* __restrict__ hashes, const uint64_t* __restrict__ offsets, uint64_t ndb,
-                         uint32_t rows_per_wg, uint32_t n_ranges, uint32_t bpr, unsigned long long* __restrict__ counts) {
+                         uint32_t rows_per_wg, uint32_t n_ranges, uint32_t bpr, unsigned long long* __restrict__ counts,
+                         uint32_t* __restrict__ qpos, uint16_t* __restrict__ part16, uint64_t nq) {
     constexpr int SLOTS = G::SLOTS, BUCKETS = G::BUCKETS, QCAP = G::QCAP, BATCH = G::BATCH;
     using TT = typename G::TT;
     extern __shared__ __attribute__((aligned(16))) uint64_t ow_lds[];
     uint64_t* s_q = ow_lds;                                              // [QCAP + 2]
     TT* s_t = reinterpret_cast<TT*>(s_q + QCAP + 2);                     // [BUCKETS + 4]
+    uint32_t* s_h = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(s_t) + G::T_BYTES);   // BUILD: [QCAP / 2] pairs of 16-bit counters
     const uint64_t d_lo = (uint64_t)blockIdx.x * rows_per_wg;
     if (d_lo >= ndb) return;
     const uint32_t n_rows = (uint32_t)(ndb - d_lo < (uint64_t)rows_per_wg ? ndb - d_lo : (uint64_t)rows_per_wg);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint64_t block_base = offsets[d_lo];
     const uint64_t* rows = hashes + block_base;
+    uint32_t* const qrows = BUILD ? qpos + block_base : nullptr;
+    uint16_t* const part_row = BUILD ? part16 + (uint64_t)blockIdx.x * nq : nullptr;
+    if (BUILD)
+        for (uint32_t i = tid; i < (uint32_t)QCAP / 2; i += OW_THREADS) s_h[i] = 0;     // (ordered before the first add by the range's barriers)
     uint32_t pos[SLOTS], end[SLOTS], hv[SLOTS];
     uint64_t e[SLOTS];
 #pragma unroll
@@ -2525,12 +2636,25 @@ void overlap_lean_kernel(const uint64_t* __restrict__ Q, const uint32_t* __restr
     for (int k = 0; k < SLOTS; ++k) ask(k);
     constexpr int QPER = (QCAP + OW_THREADS - 1) / OW_THREADS, TPER = (BUCKETS + 1 + OW_THREADS - 1) / OW_THREADS;
     uint32_t n_p0 = T[0], n_p1 = T[bpr < n_buckets ? bpr : n_buckets];
+    uint32_t done_p0 = 0, done_cnt = 0;                                   // BUILD: the slice whose counters are still in LDS
+    auto flush_counts = [&]() {                                            // ... go to this workgroup's row of part16, and back to zero
+        uint16_t* const h16 = reinterpret_cast<uint16_t*>(s_h);
+        for (uint32_t i = tid; i < done_cnt; i += OW_THREADS) {
+            part_row[done_p0 + i] = h16[i];
+            h16[i] = 0;
+        }
+    };
     for (uint32_t r = 0; r < n_ranges; ++r) {
         const uint32_t b0 = r * bpr, b1 = b0 + bpr < n_buckets ? b0 + bpr : n_buckets;
         const bool last = r + 1 == n_ranges;
         const uint64_t upper = last ? ~0ull : ((uint64_t)b1 << shift);
         const uint32_t p0 = uniform32(n_p0), cnt_q = uniform32(n_p1) - p0, cnt_t = b1 - b0 + 1;
         __syncthreads();                                                  // the previous range's readers are done
+        if (BUILD) {
+            flush_counts();
+            done_p0 = p0;
+            done_cnt = cnt_q;
+        }
         {
             constexpr int FILL_STEP = 4;                                  // (registers: 25 slots x (2 + 1) stay live across the fill)
 #pragma unroll
@@ -2599,7 +2723,10 @@ void overlap_lean_kernel(const uint64_t* __restrict__ Q, const uint32_t* __restr
             for (int w = 0; w < BATCH; ++w) {
                 const int k = v0 + w;
                 if (k >= SLOTS) continue;
-                uint64_t found = in[w] & (mask_of(qa[w] == e[k]) | mask_of(qb[w] == e[k]));
+                const uint64_t second = mask_of(qb[w] == e[k]);
+                uint64_t found = in[w] & (mask_of(qa[w] == e[k]) | second);
+                uint32_t jr = 0;                                             // BUILD: position within the slice of the hash found
+                if (BUILD) jr = t0[w] + (lanes_of(second) ? 1u : 0u);
                 // a bucket of three or more whose second hash is still below the lane's hash (rare: ~1 visit in 3 has such a
                 // lane, and a scan is a divergent loop over LDS): scan on.  (Without the size test every hash ABOVE both hashes of
                 // a bucket of two came here too -- 3 % of the lookups, three visits in four: 2.46 -> 3.44 ms.)
@@ -2609,9 +2736,13 @@ void overlap_lean_kernel(const uint64_t* __restrict__ Q, const uint32_t* __restr
                     if (lanes_of(deep))
                         for (uint32_t t = t0[w] + 2;; ++t) {
                             const uint64_t qv = s_q[t];
-                            if (qv >= e[k]) { hit = qv == e[k]; break; }
+                            if (qv >= e[k]) { hit = qv == e[k]; if (BUILD && hit) jr = t; break; }
                         }
                     found |= in[w] & mask_of(hit);
+                }
+                if (BUILD) {
+                    if (lanes_of(in[w])) (qrows + pos[k])[lane] = lanes_of(found) ? p0 + jr : NONE32;
+                    if (lanes_of(found)) atomicAdd(&s_h[jr >> 1], 1u << ((jr & 1u) << 4));
                 }
                 hv[k] += (uint32_t)__popcll(found);
                 uint32_t taken = (uint32_t)__popcll(in[w]);
@@ -2624,9 +2755,14 @@ void overlap_lean_kernel(const uint64_t* __restrict__ Q, const uint32_t* __restr
                     if (more) {
                         uint32_t k2 = (uint32_t)(ev >> shift) - b0;
                         k2 = k2 < bpr ? k2 : bpr;
-                        for (uint32_t t = (uint32_t)s_t[k2];; ++t) {
+                        uint32_t t = (uint32_t)s_t[k2];
+                        for (;; ++t) {
                             const uint64_t qv = s_q[t];
                             if (qv >= ev) { h2 = qv == ev; break; }
+                        }
+                        if (BUILD) {
+                            (qrows + pos[k])[lane] = h2 ? p0 + t : NONE32;
+                            if (h2) atomicAdd(&s_h[t >> 1], 1u << ((t & 1u) << 4));
                         }
                     }
                     hv[k] += (uint32_t)__popcll(mask_of(h2));
@@ -2637,11 +2773,37 @@ void overlap_lean_kernel(const uint64_t* __restrict__ Q, const uint32_t* __restr
             }
         }
     }
+    if (BUILD) {
+        __syncthreads();                                                  // the last range's adds are in
+        flush_counts();
+        // what the walk never consumed (a row's hash 2^64 - 1, which reads like the filler of lanes past a row's end): not in the query
+#pragma unroll
+        for (int k = 0; k < SLOTS; ++k)
+            for (uint32_t i = pos[k] + (uint32_t)lane; i < end[k]; i += 64) qrows[i] = NONE32;
+    }
 #pragma unroll
     for (int k = 0; k < SLOTS; ++k) {
         const uint32_t i = (uint32_t)wave + (uint32_t)k * OW_WAVES;
         if (lane == 0 && i < n_rows) counts[d_lo + i] = hv[k];
     }
+}
+
+// The builder's pass 1 through the kernel above: n_sub workgroups of rows_per_wg rows, part16 [n_sub][nq].
+constexpr size_t LEAN_BUILD_LDS = ((size_t)OwLean::QCAP + 2) * 8 + OwLean::T_BYTES + (size_t)OwLean::QCAP * 2;
+hipError_t build_lean_launch(const uint64_t* Q, uint64_t nq, const uint32_t* T, uint32_t n_buckets, uint32_t shift, const uint64_t* hashes,
+                             const uint64_t* offsets, uint64_t ndb, uint32_t rows_per_wg, uint32_t n_ranges, uint32_t bpr,
+                             unsigned long long* counters, uint32_t* qpos, uint16_t* part16, hipStream_t stream) {
+    static int attr = 0;
+    if (attr == 0) {
+        const hipError_t ea = hipFuncSetAttribute((const void*)overlap_lean_kernel<OwLean, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LEAN_BUILD_LDS);
+        attr = ea == hipSuccess ? 1 : -1;
+        if (attr < 0) (void)hipGetLastError();
+    }
+    if (attr < 0) return hipErrorInvalidValue;
+    const uint64_t n_sub = (ndb + rows_per_wg - 1) / rows_per_wg;
+    hipLaunchKernelGGL((overlap_lean_kernel<OwLean, true>), dim3((unsigned)n_sub), dim3(OW_THREADS), LEAN_BUILD_LDS, stream, Q, T, n_buckets, shift,
+                       hashes, offsets, ndb, rows_per_wg, n_ranges, bpr, counters, qpos, part16, nq);
+    return hipGetLastError();
 }
 
 // op 0: overlap[d] = cnt[d]; op 1: overlap[d] -= cnt[d], saturating (rows at 0 stay dropped, index/__init__.py:908-909)
@@ -2698,13 +2860,8 @@ hipError_t overlap_ranges_launch(const uint64_t* Q, uint64_t nq, const uint64_t*
     if (w2bpr > (uint32_t)OwTwo::BUCKETS) w2bpr = OwTwo::BUCKETS;
     if (w2bpr < 64) w2bpr = 64;
     const uint32_t w2_ranges = (buckets + w2bpr - 1) / w2bpr;
-    // the lean form: about `lean_q` query hashes per range (a row's part of a range is then ~46 of the 64 hashes a visit loads;
-    // more and one visit in thirty would have to load a second block on the spot)
-    static const double lean_q = [] { const char* e = getenv("SMG_OVERLAP_QPR"); return e ? atof(e) : 9600.0; }();
-    uint32_t lbpr = (uint32_t)(lean_q * (double)buckets / (double)nq);
-    if (lbpr > (uint32_t)OwLean::BUCKETS) lbpr = OwLean::BUCKETS;
-    if (lbpr < 64) lbpr = 64;
-    const uint32_t l_ranges = (buckets + lbpr - 1) / lbpr;
+    const LeanPlan lean = build_lean_plan(nq, buckets);                     // the lean form: ranges cut by query hashes held
+    const uint32_t lbpr = lean.bpr, l_ranges = lean.n_ranges;
     // the widest range of either partition decides whether its LDS has room: all maxima come back with one synchronisation
     unsigned int widest = 0, w_widest = 0, w2_widest = 0, l_widest = 0;
     {
@@ -2758,7 +2915,7 @@ hipError_t overlap_ranges_launch(const uint64_t* Q, uint64_t nq, const uint64_t*
         static int lean_attr = 0;
         constexpr size_t LEAN_LDS = ((size_t)OwLean::QCAP + 2) * 8 + OwLean::T_BYTES;
         if (lean_attr == 0) {
-            const hipError_t ea = hipFuncSetAttribute((const void*)overlap_lean_kernel<OwLean>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LEAN_LDS);
+            const hipError_t ea = hipFuncSetAttribute((const void*)overlap_lean_kernel<OwLean, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LEAN_LDS);
             lean_attr = ea == hipSuccess ? 1 : -1;
             if (lean_attr < 0) (void)hipGetLastError();
         }
@@ -2766,8 +2923,8 @@ hipError_t overlap_ranges_launch(const uint64_t* Q, uint64_t nq, const uint64_t*
         if (lean_attr > 0 && (pick == 0 || pick == 3) && l_widest <= (unsigned)OwLean::QCAP && l_widest > 0 && q_max != ~0ull) {
             const uint64_t rpw = rows_per_wg((uint64_t)n_cu_w, OwLean::ROWS);
             const uint64_t n_wg = (ndb + rpw - 1) / rpw;
-            hipLaunchKernelGGL(overlap_lean_kernel<OwLean>, dim3((unsigned)n_wg), dim3(OW_THREADS), LEAN_LDS, stream, Q, (const uint32_t*)table, buckets,
-                               shift, hashes, offsets, ndb, (uint32_t)rpw, l_ranges, lbpr, cnt);
+            hipLaunchKernelGGL((overlap_lean_kernel<OwLean, false>), dim3((unsigned)n_wg), dim3(OW_THREADS), LEAN_LDS, stream, Q, (const uint32_t*)table, buckets,
+                               shift, hashes, offsets, ndb, (uint32_t)rpw, l_ranges, lbpr, cnt, (uint32_t*)nullptr, (uint16_t*)nullptr, (uint64_t)0);
             wide_done = true;
         } else if (attr_state > 0 && pick != 1 && pick != 0 && w2_widest <= (unsigned)OwTwo::QCAP && w2_widest > 0) {
             const uint64_t rpw = rows_per_wg((uint64_t)n_cu_w * 2, OwTwo::ROWS);

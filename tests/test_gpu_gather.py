@@ -166,8 +166,9 @@ def test_synthetic_gather_vs_oracle(sm, build, monkeypatch):
         assert len(want) > 10 or thr_bp == 200_000
 
 
-@pytest.mark.parametrize("fill", ["staged", "streams", "direct"])
-def test_range_builder_postings_are_exact(fill, monkeypatch):
+@pytest.mark.parametrize("fill,pass1", [("staged", "ranges"), ("staged", "lean"), ("streams", "lean"), ("streams", "ranges"),
+                                        ("direct", "ranges")])
+def test_range_builder_postings_are_exact(fill, pass1, monkeypatch):
     """The postings themselves (not only the gather they drive): after the range-partitioned build every counter equals
     |Q ∩ row|, and consuming the whole query through the postings brings every counter to exactly zero -- which holds
     iff every (query hash, row) pair sits in exactly one posting.  Ragged rows, an empty row, rows outside the query,
@@ -177,11 +178,14 @@ def test_range_builder_postings_are_exact(fill, monkeypatch):
     from sourmash_amd.synth import synth_gather
     monkeypatch.setenv("SMG_GATHER_BUILD", "ranges")
     monkeypatch.setenv("SMG_GATHER_FILL", fill)
+    monkeypatch.setenv("SMG_GATHER_PASS1", pass1)                 # pass 1 by lookups in L2 / by the lean streaming kernel (a fallback is an error)
     qh, dbh = synth_gather(n_query=3 * 32768 + 77, n_db=700, db_size=900)
     dbh[3] = np.zeros(0, dtype=np.uint64)
     dbh[4] = np.array([1, 2, 3], dtype=np.uint64)
     dbh[5] = qh[::7].copy()                                       # a long row made of query hashes only
     dbh[6] = qh[-40:].copy()                                      # only the last (short) range
+    dbh[7] = np.concatenate([qh[5:50], np.array([2**64 - 1], dtype=np.uint64)])   # the hash the walk's filler value looks like
+    dbh[8] = qh[2000:2300].copy()                                 # 300 consecutive query hashes: a row's part of one range > a visit
     be = parallel.DeviceBackend()
     h, off = smd.pack_csr(dbh)
     q = torch.from_numpy(qh.view(np.int64).copy()).cuda()
@@ -194,6 +198,33 @@ def test_range_builder_postings_are_exact(fill, monkeypatch):
     got = st.run()
     assert got == oracle.gather(qh, *oracle.make_csr(dbh), threshold_bp=0, scaled=1000, nthreads=8)
     assert not st.counters().any()
+
+
+def test_index_build_of_many_rows_takes_the_lean_pass(monkeypatch):
+    """From 64 rows per CU up the builder's pass 1 is the lean streaming kernel by default (gather.hip: gather_build_body): 17,000
+    ragged rows, the result the oracle's, every counter zero at the end (every posting in exactly one list), and the same
+    again with pass 1 by lookups."""
+    import torch
+    from sourmash_amd import device as smd, parallel
+    from sourmash_amd.synth import synth_gather
+    qh, dbh = synth_gather(n_query=150_000, n_db=17_000, db_size=70)
+    dbh[0] = np.zeros(0, dtype=np.uint64)
+    dbh[1] = qh[::5].copy()                                       # 30,000 hashes, all in the query
+    dbh[16_999] = np.concatenate([qh[-3:], np.array([2**64 - 1], dtype=np.uint64)])
+    be = parallel.DeviceBackend()
+    h, off = smd.pack_csr(dbh)
+    q = torch.from_numpy(qh.view(np.int64).copy()).cuda()
+    want = np.array([oracle.intersection_size(qh, d)[0] for d in dbh], dtype=np.uint64)
+    ref = oracle.gather(qh, *oracle.make_csr(dbh), threshold_bp=0, scaled=1000, nthreads=8)
+    for pass1 in (None, "ranges"):
+        if pass1:
+            monkeypatch.setenv("SMG_GATHER_PASS1", pass1)
+        st = be.gather_state(q, len(qh), h, off, len(dbh), 0)
+        assert np.array_equal(st.counters(), want), pass1
+        assert int(be.lib.smgpu_gather_postings(st._ptr)) == int(want.sum())
+        st.begin(0, len(dbh))
+        assert st.run() == ref, pass1
+        assert not st.counters().any()
 
 
 @pytest.mark.parametrize("form", ["wide", "stream", "ranges"])
