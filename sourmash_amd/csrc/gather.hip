@@ -437,13 +437,17 @@ __global__ __launch_bounds__(BR_THREADS) void build_partition_kernel(uint64_t nq
 // [post_off[j] + partial[b][j], post_off[j] + partial[b + 1][j]), which is what lets a workgroup of the persistent gather
 // loop read only ITS rows' part of a list.
 constexpr int BR_ORD_NB = 8;
+// A window's postings arrive as `n_sub` runs, run i holding those of row block i / m (m = 1: one run per block, laid out by
+// pass 2a; m > 1: one run per workgroup of the lean pass 1, m consecutive workgroups to a block), (start, length) in
+// inter_off / subcnt [window][n_sub].
 template <bool ORDERED>
 __global__ __launch_bounds__(512) void build_scatter_kernel(uint64_t nq, uint32_t n_windows, uint32_t B,
                                                             const uint32_t* __restrict__ partial,
                                                             const uint64_t* __restrict__ post_off,
                                                             const uint32_t* __restrict__ subcnt,
                                                             const uint32_t* __restrict__ inter_off,
-                                                            const uint32_t* __restrict__ inter, uint32_t* __restrict__ post_rows) {
+                                                            const uint32_t* __restrict__ inter, uint32_t* __restrict__ post_rows,
+                                                            uint32_t n_sub, uint32_t m) {
     constexpr int NK = ORDERED ? BR_SUB * BR_ORD_NB : BR_SUB;        // sort keys
     __shared__ uint32_t s_sorted[BR_SORT_CAP];
     __shared__ uint32_t s_cnt[NK], s_start[NK + 1], s_fill[NK], s_cur[BR_SUB];
@@ -458,7 +462,8 @@ __global__ __launch_bounds__(512) void build_scatter_kernel(uint64_t nq, uint32_
     const uint32_t per = (B + BR_GROUPS - 1) / BR_GROUPS;
     const uint32_t b_lo = g * per, b_hi = b_lo + per < B ? b_lo + per : B;
     if (b_lo >= B) return;
-    const uint32_t nb = b_hi - b_lo;                                 // <= 64 (B <= 512 is enforced by the host)
+    const uint32_t i_lo = b_lo * m, i_hi = b_hi * m < n_sub ? b_hi * m : n_sub;
+    const uint32_t nb = i_hi > i_lo ? i_hi - i_lo : 0u;               // runs of this group: <= 64 (enforced by the host)
     const uint64_t wbase = post_off[j0];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (uint32_t k = tid; k < (uint32_t)BR_SUB; k += blockDim.x)
@@ -467,8 +472,8 @@ __global__ __launch_bounds__(512) void build_scatter_kernel(uint64_t nq, uint32_
         uint32_t run = 0;
         for (uint32_t i = 0; i < nb; ++i) {
             s_pre[i] = run;
-            s_src[i] = inter_off[(uint64_t)w * B + b_lo + i];
-            run += subcnt[(uint64_t)w * B + b_lo + i];
+            s_src[i] = inter_off[(uint64_t)w * n_sub + i_lo + i];
+            run += subcnt[(uint64_t)w * n_sub + i_lo + i];
         }
         s_pre[nb] = run;
     }
@@ -502,7 +507,7 @@ __global__ __launch_bounds__(512) void build_scatter_kernel(uint64_t nq, uint32_
 #pragma unroll
         for (int i = 0; i < PER; ++i)
             if (f0 + (uint32_t)tid + (uint32_t)i * 512u < f1) {
-                key[i] = ORDERED ? (ent[i] & (BR_SUB - 1)) * BR_ORD_NB + key[i] : (ent[i] & (BR_SUB - 1));
+                key[i] = ORDERED ? (ent[i] & (BR_SUB - 1)) * BR_ORD_NB + key[i] / m : (ent[i] & (BR_SUB - 1));
                 atomicAdd(&s_cnt[key[i]], 1u);
             }
         __syncthreads();
@@ -561,6 +566,38 @@ __global__ __launch_bounds__(512) void build_scatter_kernel(uint64_t nq, uint32_
         for (uint32_t k = tid; k < (uint32_t)BR_SUB; k += blockDim.x)
             if (k < nl) s_cur[k] += s_start[(k + 1) * KPL] - s_start[k * KPL];
         __syncthreads();
+    }
+}
+
+// What pass 1 leaves undone when it stages the postings itself (lean kernel, MODE 2): partial[b][j], the postings row block b adds
+// to list j, counted from the runs.  Workgroup (window, group) as in the scatter kernel: its runs' entries are counted by
+// (list, block of the group) in LDS and written out, 8 blocks x 256 lists.
+__global__ __launch_bounds__(512) void build_count_runs_kernel(uint64_t nq, uint32_t n_windows, uint32_t B, uint32_t n_sub, uint32_t m,
+                                                               const uint32_t* __restrict__ dir_start, const uint32_t* __restrict__ dir_len,
+                                                               const uint32_t* __restrict__ inter, uint32_t* __restrict__ partial) {
+    __shared__ uint32_t s_cnt[BR_SUB * BR_ORD_NB];
+    const uint32_t q = blockIdx.x >> 3, x = blockIdx.x & 7u;
+    const uint32_t w = (q / BR_GROUPS) * 8u + x, g = q % BR_GROUPS;
+    if (w >= n_windows) return;
+    const uint64_t j0 = (uint64_t)w * BR_SUB;
+    if (j0 >= nq) return;
+    const uint32_t nl = (uint32_t)(nq - j0 < (uint64_t)BR_SUB ? nq - j0 : (uint64_t)BR_SUB);
+    const uint32_t per = (B + BR_GROUPS - 1) / BR_GROUPS;              // <= BR_ORD_NB (the host checks)
+    const uint32_t b_lo = g * per, b_hi = b_lo + per < B ? b_lo + per : B;
+    if (b_lo >= B) return;
+    const uint32_t i_lo = b_lo * m, i_hi = b_hi * m < n_sub ? b_hi * m : n_sub;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (uint32_t k = tid; k < (uint32_t)(BR_SUB * BR_ORD_NB); k += blockDim.x) s_cnt[k] = 0;
+    __syncthreads();
+    for (uint32_t i = i_lo + (uint32_t)wave; i < i_hi; i += blockDim.x >> 6) {       // a wave per run
+        const uint32_t from = dir_start[(uint64_t)w * n_sub + i], n = dir_len[(uint64_t)w * n_sub + i];
+        const uint32_t bl = i / m - b_lo;
+        for (uint32_t f = lane; f < n; f += 64) atomicAdd(&s_cnt[(inter[from + f] & (uint32_t)(BR_SUB - 1)) * BR_ORD_NB + bl], 1u);
+    }
+    __syncthreads();
+    for (uint32_t k = tid; k < (uint32_t)BR_SUB * (b_hi - b_lo); k += blockDim.x) {
+        const uint32_t bl = k / (uint32_t)BR_SUB, jl = k % (uint32_t)BR_SUB;
+        if (jl < nl) partial[(uint64_t)(b_lo + bl) * nq + j0 + jl] = s_cnt[jl * BR_ORD_NB + bl];
     }
 }
 
@@ -1619,6 +1656,16 @@ static hipError_t gather_build_body(GatherDev& g, hipStream_t stream);
 hipError_t build_lean_launch(const uint64_t* Q, uint64_t nq, const uint32_t* T, uint32_t n_buckets, uint32_t shift, const uint64_t* hashes,
                              const uint64_t* offsets, uint64_t ndb, uint32_t rows_per_wg, uint32_t n_ranges, uint32_t bpr,
                              unsigned long long* counters, uint32_t* qpos, uint16_t* part16, hipStream_t stream);
+uint32_t build_stage_positions(uint64_t nq, uint32_t buckets);
+uint32_t build_stage_buckets_max();
+uint32_t build_stage_rows_max();
+size_t build_stage_desc_bytes(uint32_t n_ranges);
+hipError_t build_stage_plan(const uint64_t* Q, uint64_t nq, uint32_t shift, uint32_t n_buckets, uint32_t W, uint32_t n_ranges, void* desc,
+                            unsigned int* max_nb, hipStream_t stream);
+hipError_t build_stage_launch(const uint64_t* Q, uint64_t nq, const uint32_t* T, uint32_t n_buckets, uint32_t shift, const uint64_t* hashes,
+                              const uint64_t* offsets, uint64_t ndb, uint32_t rows_per_wg, uint32_t n_ranges, const void* desc,
+                              unsigned long long* counters, uint32_t* qpos, uint32_t* inter, uint32_t* dir_start, uint32_t* dir_len,
+                              unsigned int* misc, hipStream_t stream);
 struct LeanPlan { uint32_t bpr, n_ranges, qcap, rows_cap; };
 LeanPlan build_lean_plan(uint64_t nq, uint32_t buckets);
 // largest number of query hashes in any range (the caller checks it against the LDS room of the kernel that walks the ranges)
@@ -1697,7 +1744,7 @@ static hipError_t gather_build_body(GatherDev& g, hipStream_t stream) {
         return hipSuccess;
     }
     const QIndex qi = qindex_of(g);
-    ArenaBuf post_cnt_b, scan_tmp_b, bounds_b, partial_b, subcnt_b, inter_off_b, lay_tmp_b, inter_b, part16_b;
+    ArenaBuf post_cnt_b, scan_tmp_b, bounds_b, partial_b, subcnt_b, inter_off_b, lay_tmp_b, inter_b, part16_b, desc_b, misc_b;
     SMG_TRY(post_cnt_b.get(nq1 * 8, stream));
     unsigned long long* post_cnt = post_cnt_b.as<unsigned long long>();
     size_t scan_bytes = 0;
@@ -1748,39 +1795,97 @@ static hipError_t gather_build_body(GatherDev& g, hipStream_t stream) {
         // in ranges and every workgroup walks its own rows once -- no lookups in L2.  It wants a few hundred rows per CU, a query
         // without the hash 2^64 - 1, ranges that fit its LDS (one more synchronisation: the widest range's size comes back first),
         // and it counts per WORKGROUP: a row block of the builder becomes `m_sub` consecutive workgroups of `rpw` rows.
+        // SMG_GATHER_PASS1 = stage | lean | ranges: the staging form below (the default when it applies), the lean kernel with counts
+        // only, lookups in L2; a forced form that cannot run is an error.
         const char* pass1_s = getenv("SMG_GATHER_PASS1");
-        const int pass1_env = !pass1_s ? 0 : !strcmp(pass1_s, "ranges") ? 1 : !strcmp(pass1_s, "lean") ? 2 : 0;
-        bool lean1 = false;
+        const int pass1_env = !pass1_s ? 0 : !strcmp(pass1_s, "ranges") ? 1 : !strcmp(pass1_s, "lean") ? 2 : !strcmp(pass1_s, "stage") ? 3 : 0;
+        bool lean1 = false, stage1 = false;
         LeanPlan lp{};
         uint64_t m_sub = 1, rpw = 0, n_sub = 0;
+        uint32_t stage_W = 0, stage_ranges = 0;
+        const uint32_t n_windows = R * BR_NSUB;
         {
             int n_cu = 256;
             { int dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev); }
-            if (pass1_env != 1 && staged && B <= (uint64_t)MS_BMAX && g.q_max != ~0ull && (pass1_env == 2 || g.ndb >= (uint64_t)n_cu * 64)) {
+            if (pass1_env != 1 && staged && B <= (uint64_t)MS_BMAX && g.q_max != ~0ull && (pass1_env >= 2 || g.ndb >= (uint64_t)n_cu * 64)) {
                 lp = build_lean_plan(g.nq, g.q_buckets);
+                stage_W = build_stage_positions(g.nq, g.q_buckets);
+                stage_ranges = (uint32_t)((g.nq + stage_W - 1) / stage_W);
+                SMG_TRY(desc_b.get(build_stage_desc_bytes(stage_ranges) + 64, stream));
                 unsigned int* d_widest = (unsigned int*)&g.state[GS_KEY];       // scratch again: zero since the first synchronisation
                 hipLaunchKernelGGL(stream_range_max_kernel, dim3((lp.n_ranges + 255) / 256), dim3(256), 0, stream, (const uint32_t*)g.q_table,
                                    g.q_buckets, lp.n_ranges, lp.bpr, d_widest);
                 SMG_TRY(hipGetLastError());
+                SMG_TRY(build_stage_plan(g.Q, g.nq, g.q_shift, g.q_buckets, stage_W, stage_ranges, desc_b.p, d_widest + 1, stream));
                 g.pinned[9] = 0;
                 SMG_TRY(hipMemcpyAsync(&g.pinned[9], d_widest, 8, hipMemcpyDeviceToHost, stream));
                 SMG_TRY(hipMemsetAsync(&g.state[GS_KEY], 0, 8, stream));
                 SMG_TRY(timed_sync(g, stream));                           // synchronisation 2 of 3
-                const unsigned int widest = (unsigned int)(g.pinned[9] & 0xffffffffull);
-                if (widest > 0 && widest <= lp.qcap) {
-                    const uint64_t m_min = (rows_per_block + lp.rows_cap - 1) / lp.rows_cap;
-                    const uint64_t rounds = (B * m_min + (uint64_t)n_cu - 1) / (uint64_t)n_cu;
-                    m_sub = rounds * (uint64_t)n_cu / B;                    // full rounds of resident workgroups, no tail of a few
-                    if (m_sub < m_min) m_sub = m_min;
-                    rpw = (rows_per_block + m_sub - 1) / m_sub;
-                    n_sub = (g.ndb + rpw - 1) / rpw;
-                    lean1 = n_sub * g.nq * 2 <= (3ull << 30);
-                }
-                if (!lean1 && pass1_env == 2) return hipErrorInvalidValue;
-                if (lean1) {
+                const unsigned int widest = (unsigned int)(g.pinned[9] & 0xffffffffull), most_buckets = (unsigned int)(g.pinned[9] >> 32);
+                const uint64_t rows_cap = lp.rows_cap < build_stage_rows_max() ? lp.rows_cap : build_stage_rows_max();
+                const uint64_t m_min = (rows_per_block + rows_cap - 1) / rows_cap;
+                const uint64_t rounds = (B * m_min + (uint64_t)n_cu - 1) / (uint64_t)n_cu;
+                m_sub = rounds * (uint64_t)n_cu / B;                        // full rounds of resident workgroups, no tail of a few
+                if (m_sub < m_min) m_sub = m_min;
+                rpw = (rows_per_block + m_sub - 1) / m_sub;
+                n_sub = (g.ndb + rpw - 1) / rpw;
+                const uint64_t per = (B + BR_GROUPS - 1) / BR_GROUPS;
+                stage1 = pass1_env != 2 && most_buckets > 0 && most_buckets <= build_stage_buckets_max() && total + 4 < 0xffffffffull &&
+                         per <= (uint64_t)BR_ORD_NB && per * m_sub <= 64 && n_sub * (uint64_t)((g.nq + BR_SUB - 1) / BR_SUB) * 8 <= (1ull << 30);
+                lean1 = !stage1 && pass1_env != 3 && widest > 0 && widest <= lp.qcap && n_sub * g.nq * 2 <= (3ull << 30);
+                if (!lean1 && !stage1 && pass1_env >= 2) return hipErrorInvalidValue;
+                if (lean1 || stage1) {
                     rows_per_block = rpw * m_sub;
                     B = (g.ndb + rows_per_block - 1) / rows_per_block;
                 }
+            }
+        }
+        if (stage1) {
+            // pass 1 + 2a in one kernel: query positions, postings staged by window and written as runs; then the runs are counted
+            const uint64_t win_used = (g.nq + BR_SUB - 1) / BR_SUB;
+            SMG_TRY(partial_b.get(B * g.nq * 4, stream));
+            SMG_TRY(inter_b.get((total + 4) * 4, stream));
+            SMG_TRY(subcnt_b.get(win_used * n_sub * 4 + 64, stream));         // the directory: a run's length ...
+            SMG_TRY(inter_off_b.get(win_used * n_sub * 4 + 64, stream));      // ... and start
+            SMG_TRY(misc_b.get(64, stream));
+            SMG_TRY(hipMemsetAsync(misc_b.p, 0, 64, stream));
+            uint32_t* partial = partial_b.as<uint32_t>();
+            SMG_TRY(build_stage_launch(g.Q, g.nq, g.q_table, g.q_buckets, g.q_shift, g.hashes, g.offsets, g.ndb, (uint32_t)rpw, stage_ranges,
+                                       desc_b.p, g.counters, g.qpos, inter_b.as<uint32_t>(), inter_off_b.as<uint32_t>(), subcnt_b.as<uint32_t>(),
+                                       misc_b.as<unsigned int>(), stream));
+            const unsigned win_grid = (unsigned)((n_windows + 7) / 8 * 8 * BR_GROUPS);
+            hipLaunchKernelGGL(build_count_runs_kernel, dim3(win_grid), dim3(512), 0, stream, g.nq, n_windows, (uint32_t)B, (uint32_t)n_sub,
+                               (uint32_t)m_sub, (const uint32_t*)inter_off_b.as<uint32_t>(), (const uint32_t*)subcnt_b.as<uint32_t>(),
+                               (const uint32_t*)inter_b.as<uint32_t>(), partial);
+            SMG_TRY(hipGetLastError());
+            hipLaunchKernelGGL(build_merge_counts_kernel, dim3((unsigned)((nq1 + 255) / 256)), dim3(256), 0, stream, partial, (uint32_t)B, g.nq, post_cnt);
+            SMG_TRY(hipGetLastError());
+            SMG_TRY(rocprim::exclusive_scan(scan_tmp, scan_bytes, (uint64_t*)post_cnt, g.post_off, (uint64_t)0, (size_t)nq1,
+                                            rocprim::plus<uint64_t>(), stream));
+            SMG_TRY(hipMemcpyAsync(&g.pinned[8], g.post_off + g.nq, 8, hipMemcpyDeviceToHost, stream));
+            g.pinned[10] = 0;
+            SMG_TRY(hipMemcpyAsync(&g.pinned[10], misc_b.p, 8, hipMemcpyDeviceToHost, stream));
+            SMG_TRY(timed_sync(g, stream));                               // synchronisation 3 of 3
+            if ((g.pinned[10] >> 32) != 0) {
+                // a window's part of the staging area overflowed (many rows meeting in a few lists): build by the lookup form instead
+                if (pass1_env == 3) return hipErrorInvalidValue;
+                stage1 = false;
+                SMG_TRY(hipMemsetAsync(g.counters, 0, (g.ndb + 1) * 8, stream));
+            } else {
+                g.npairs = g.pinned[8];
+                SMG_TRY(own_alloc(g, &g.post_rows, (g.npairs + 4) * 4));
+                hipLaunchKernelGGL(build_scatter_kernel<true>, dim3(win_grid), dim3(512), 0, stream, g.nq, n_windows, (uint32_t)B,
+                                   (const uint32_t*)partial, (const uint64_t*)g.post_off, (const uint32_t*)subcnt_b.as<uint32_t>(),
+                                   (const uint32_t*)inter_off_b.as<uint32_t>(), (const uint32_t*)inter_b.as<uint32_t>(), g.post_rows, (uint32_t)n_sub,
+                                   (uint32_t)m_sub);
+                SMG_TRY(hipGetLastError());
+                SMG_TRY(own_alloc(g, &g.block_pre, (g.nq * (B + 1) + 4) * 4));
+                hipLaunchKernelGGL(build_bounds_table_kernel, dim3((unsigned)((g.nq + 63) / 64)), dim3(256), 0, stream, (const uint32_t*)partial,
+                                   g.nq, (uint32_t)B, (const uint64_t*)g.post_off, g.block_pre);
+                SMG_TRY(hipGetLastError());
+                g.block_B = (uint32_t)B;
+                g.block_rows = (uint32_t)rows_per_block;
+                return hipSuccess;
             }
         }
         SMG_TRY(bounds_b.get(((uint64_t)R + 1) * g.ndb * 4, stream));
@@ -1789,7 +1894,6 @@ static hipError_t gather_build_body(GatherDev& g, hipStream_t stream) {
         hipLaunchKernelGGL(build_bounds_kernel, dim3(blocks_for_rows(g.ndb)), dim3(256), 0, stream, g.Q, R, g.hashes,
                            g.offsets, g.ndb, bounds);
         SMG_TRY(hipGetLastError());
-        const uint32_t n_windows = R * BR_NSUB;
         uint32_t *subcnt = nullptr, *inter_off = nullptr, *inter = nullptr;
         if (staged) {
             SMG_TRY(subcnt_b.get((uint64_t)n_windows * B * 4, stream));
@@ -1847,11 +1951,11 @@ static hipError_t gather_build_body(GatherDev& g, hipStream_t stream) {
             if (ordered)
                 hipLaunchKernelGGL(build_scatter_kernel<true>, dim3((unsigned)((n_windows + 7) / 8 * 8 * BR_GROUPS)), dim3(512), 0, stream, g.nq,
                                    n_windows, (uint32_t)B, (const uint32_t*)partial, (const uint64_t*)g.post_off, (const uint32_t*)subcnt,
-                                   (const uint32_t*)inter_off, (const uint32_t*)inter, g.post_rows);
+                                   (const uint32_t*)inter_off, (const uint32_t*)inter, g.post_rows, (uint32_t)B, 1u);
             else
                 hipLaunchKernelGGL(build_scatter_kernel<false>, dim3((unsigned)((n_windows + 7) / 8 * 8 * BR_GROUPS)), dim3(512), 0, stream, g.nq,
                                    n_windows, (uint32_t)B, (const uint32_t*)partial, (const uint64_t*)g.post_off, (const uint32_t*)subcnt,
-                                   (const uint32_t*)inter_off, (const uint32_t*)inter, g.post_rows);
+                                   (const uint32_t*)inter_off, (const uint32_t*)inter, g.post_rows, (uint32_t)B, 1u);
             SMG_TRY(hipGetLastError());
             if (ordered && g.npairs < 0xffffffffull) {
                 // where every row block's run begins and ends inside every list, for the resident loop: [nq][B + 1]
@@ -2572,6 +2676,19 @@ void overlap_wide_kernel(const uint64_t* __restrict__ Q, const uint32_t* __restr
     for (uint32_t i = tid; i < n_rows; i += OW_THREADS) counts[d_lo + i] = s_hits[i];
 }
 
+// what the lean kernel's staging form (MODE 2) needs besides the walk's arguments
+struct RangeDesc { uint32_t b0, nb, p0, cnt; uint64_t upper; };   // first bucket, buckets, first query position, positions, first hash of the next range
+struct StageArgs {
+    const RangeDesc* desc = nullptr;      // [n_ranges]
+    uint32_t* inter = nullptr;            // the postings, window by window and workgroup by workgroup, wherever their runs were placed
+    uint32_t* dir_start = nullptr;        // [windows][n_sub] a run's start in inter ...
+    uint32_t* dir_len = nullptr;          //                  ... and length
+    uint32_t n_sub = 0;
+    unsigned int* misc = nullptr;         // [0] words of inter given out, [1] != 0: a window's part of the staging area overflowed
+};
+constexpr int LEAN_NW = 32;               // windows per range at most (W <= 8,192 query positions)
+constexpr int LEAN_CAPW = 352;            // postings a window's part of the staging area holds
+
 // ---- the wide form, lean visits (round 4) -----------------------------------------------------------------------------
 // Counters of the kernel above at C5 (profiles/r03_overlap_pmc.txt): 0.65e9 vector + 0.72e9 scalar + 0.13e9 LDS wave-instructions
 // per pass for 13 million visits -- ~115 instructions a visit, of which the lookup proper needs ~35 -- and its waves spend 57 % of
@@ -2593,28 +2710,42 @@ void overlap_wide_kernel(const uint64_t* __restrict__ Q, const uint32_t* __restr
 // the query (or NONE32) goes to `qpos` -- a visit stores the positions of the hashes it consumes, consecutive lanes -- and the
 // postings this workgroup's rows add to every query hash are counted in LDS (16-bit counters: a workgroup has < 65,536 rows)
 // and written to part16[workgroup][query position] when the range is through.  counts[] then is the builder's 64-bit overlap.
-template <class G, bool BUILD>
+// MODE 2 (STAGE): pass 1 AND pass 2a of the builder.  The ranges are cut by query POSITION (sa.desc: `W` positions each, a
+// multiple of BR_SUB, so that the windows of BR_SUB lists the final scatter works by nest in them), the table slice of a range is
+// clipped to the range's positions, and every posting found -- (row << BR_SUB_BITS) | list within its window -- waits in LDS in
+// its window's part of a staging area until the range is through; then the workgroup reserves room for all of them in `inter`
+// with ONE atomic, writes every window's run with consecutive lanes and leaves (start, length) in the directory
+// dir[window][workgroup] the counting and scatter kernels read the runs by.  A window's part of the staging area holds
+// LEAN_CAPW postings (six standard deviations above the ~250 a window gets from 400 rows of a C5-like database); more than that
+// in any window raises sa.misc[1] and the host builds by the slower path instead.
+template <class G, int MODE>
 __global__ __launch_bounds__(OW_THREADS) __attribute__((amdgpu_waves_per_eu(G::WAVES_PER_EU, G::WAVES_PER_EU)))
 void overlap_lean_kernel(const uint64_t* __restrict__ Q, const uint32_t* __restrict__ T, uint32_t n_buckets, uint32_t shift,
                          const uint64_t* __restrict__ hashes, const uint64_t* __restrict__ offsets, uint64_t ndb,
                          uint32_t rows_per_wg, uint32_t n_ranges, uint32_t bpr, unsigned long long* __restrict__ counts,
-                         uint32_t* __restrict__ qpos, uint16_t* __restrict__ part16, uint64_t nq) {
+                         uint32_t* __restrict__ qpos, uint16_t* __restrict__ part16, uint64_t nq, StageArgs sa) {
     constexpr int SLOTS = G::SLOTS, BUCKETS = G::BUCKETS, QCAP = G::QCAP, BATCH = G::BATCH;
+    constexpr bool BUILD = MODE == 1, STAGE = MODE == 2, QPOS = MODE != 0;
     using TT = typename G::TT;
     extern __shared__ __attribute__((aligned(16))) uint64_t ow_lds[];
     uint64_t* s_q = ow_lds;                                              // [QCAP + 2]
     TT* s_t = reinterpret_cast<TT*>(s_q + QCAP + 2);                     // [BUCKETS + 4]
     uint32_t* s_h = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(s_t) + G::T_BYTES);   // BUILD: [QCAP / 2] pairs of 16-bit counters
+    uint32_t* s_stage = s_h;                                             // STAGE: [LEAN_NW][LEAN_CAPW] postings waiting, by window
+    uint32_t* s_wcur = s_stage + LEAN_NW * LEAN_CAPW;                    //        [LEAN_NW] postings staged per window
+    uint32_t* s_wbase = s_wcur + LEAN_NW;                                //        [LEAN_NW] where the window's run starts in `inter`
+    uint32_t* s_wn = s_wbase + LEAN_NW;                                  //        [LEAN_NW] its length
     const uint64_t d_lo = (uint64_t)blockIdx.x * rows_per_wg;
     if (d_lo >= ndb) return;
     const uint32_t n_rows = (uint32_t)(ndb - d_lo < (uint64_t)rows_per_wg ? ndb - d_lo : (uint64_t)rows_per_wg);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const uint64_t block_base = offsets[d_lo];
     const uint64_t* rows = hashes + block_base;
-    uint32_t* const qrows = BUILD ? qpos + block_base : nullptr;
+    uint32_t* const qrows = QPOS ? qpos + block_base : nullptr;
     uint16_t* const part_row = BUILD ? part16 + (uint64_t)blockIdx.x * nq : nullptr;
     if (BUILD)
         for (uint32_t i = tid; i < (uint32_t)QCAP / 2; i += OW_THREADS) s_h[i] = 0;     // (ordered before the first add by the range's barriers)
+    if (STAGE && tid < LEAN_NW) s_wcur[tid] = 0;
     uint32_t pos[SLOTS], end[SLOTS], hv[SLOTS];
     uint64_t e[SLOTS];
 #pragma unroll
@@ -2635,8 +2766,51 @@ void overlap_lean_kernel(const uint64_t* __restrict__ Q, const uint32_t* __restr
 #pragma unroll
     for (int k = 0; k < SLOTS; ++k) ask(k);
     constexpr int QPER = (QCAP + OW_THREADS - 1) / OW_THREADS, TPER = (BUCKETS + 1 + OW_THREADS - 1) / OW_THREADS;
-    uint32_t n_p0 = T[0], n_p1 = T[bpr < n_buckets ? bpr : n_buckets];
-    uint32_t done_p0 = 0, done_cnt = 0;                                   // BUILD: the slice whose counters are still in LDS
+    uint32_t n_p0 = 0, n_p1 = 0;
+    RangeDesc n_rd{};
+    if (STAGE) n_rd = sa.desc[0];
+    else { n_p0 = T[0]; n_p1 = T[bpr < n_buckets ? bpr : n_buckets]; }
+    uint32_t done_p0 = 0, done_cnt = 0;                                   // BUILD / STAGE: the slice whose counters / postings are still in LDS
+    // STAGE, after a barrier: every window's run gets its place in `inter` (one atomic for the workgroup) and its directory entry
+    auto stage_place = [&]() {
+        if (tid < 64) {
+            const uint32_t nw = (done_cnt + (uint32_t)BR_SUB - 1) >> BR_SUB_BITS;        // windows of the range (<= LEAN_NW)
+            uint32_t have = (uint32_t)lane < nw ? s_wcur[lane] : 0u;
+            if (have > (uint32_t)LEAN_CAPW) { atomicOr(&sa.misc[1], 1u); have = LEAN_CAPW; }
+            uint32_t incl = have;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t o = __shfl_up(incl, d);
+                if (lane >= d) incl += o;
+            }
+            const uint32_t total = __shfl(incl, 63);
+            uint32_t base = 0;
+            if (lane == 0 && total) base = atomicAdd(&sa.misc[0], total);
+            base = __shfl(base, 0);
+            if (lane < LEAN_NW) {
+                s_wbase[lane] = base + incl - have;
+                s_wn[lane] = have;
+                s_wcur[lane] = 0;
+            }
+            if ((uint32_t)lane < nw) {
+                const uint64_t di = (uint64_t)((done_p0 >> BR_SUB_BITS) + (uint32_t)lane) * sa.n_sub + blockIdx.x;
+                sa.dir_start[di] = base + incl - have;
+                sa.dir_len[di] = have;
+            }
+        }
+    };
+    auto stage_write = [&]() {                                             // after another barrier: the runs go out, consecutive lanes
+        for (uint32_t i = tid; i < (uint32_t)(LEAN_NW * LEAN_CAPW); i += OW_THREADS) {
+            const uint32_t wdw = i / (uint32_t)LEAN_CAPW, x = i - wdw * (uint32_t)LEAN_CAPW;
+            if (x < s_wn[wdw]) sa.inter[s_wbase[wdw] + x] = s_stage[i];
+        }
+    };
+    // a posting found: position jr of the range's slice, row `rowid`
+    auto stage_put = [&](uint32_t jr, uint32_t rowid) {
+        const uint32_t wdw = jr >> BR_SUB_BITS;
+        const uint32_t slot = atomicAdd(&s_wcur[wdw], 1u);
+        if (slot < (uint32_t)LEAN_CAPW) s_stage[wdw * (uint32_t)LEAN_CAPW + slot] = (rowid << BR_SUB_BITS) | (jr & (uint32_t)(BR_SUB - 1));
+    };
     auto flush_counts = [&]() {                                            // ... go to this workgroup's row of part16, and back to zero
         uint16_t* const h16 = reinterpret_cast<uint16_t*>(s_h);
         for (uint32_t i = tid; i < done_cnt; i += OW_THREADS) {
@@ -2645,13 +2819,29 @@ void overlap_lean_kernel(const uint64_t* __restrict__ Q, const uint32_t* __restr
         }
     };
     for (uint32_t r = 0; r < n_ranges; ++r) {
-        const uint32_t b0 = r * bpr, b1 = b0 + bpr < n_buckets ? b0 + bpr : n_buckets;
         const bool last = r + 1 == n_ranges;
-        const uint64_t upper = last ? ~0ull : ((uint64_t)b1 << shift);
-        const uint32_t p0 = uniform32(n_p0), cnt_q = uniform32(n_p1) - p0, cnt_t = b1 - b0 + 1;
+        // b0: the slice's first bucket; kcap: buckets in the slice (a lane's bucket index is clamped to it: the padding behind)
+        uint32_t b0, b1 = 0, kcap, p0, cnt_q, cnt_t;
+        uint64_t upper;
+        if (STAGE) {
+            b0 = uniform32(n_rd.b0); kcap = uniform32(n_rd.nb); p0 = uniform32(n_rd.p0); cnt_q = uniform32(n_rd.cnt);
+            upper = uniform64(n_rd.upper);
+            cnt_t = kcap + 1;
+        } else {
+            b0 = r * bpr;
+            b1 = b0 + bpr < n_buckets ? b0 + bpr : n_buckets;
+            upper = last ? ~0ull : ((uint64_t)b1 << shift);
+            p0 = uniform32(n_p0); cnt_q = uniform32(n_p1) - p0; cnt_t = b1 - b0 + 1;
+            kcap = bpr;
+        }
         __syncthreads();                                                  // the previous range's readers are done
-        if (BUILD) {
-            flush_counts();
+        if (BUILD) flush_counts();
+        if (STAGE && r > 0) {
+            stage_place();
+            __syncthreads();
+            stage_write();
+        }
+        if (QPOS) {
             done_p0 = p0;
             done_cnt = cnt_q;
         }
@@ -2669,7 +2859,9 @@ void overlap_lean_kernel(const uint64_t* __restrict__ Q, const uint32_t* __restr
                 for (int u = 0; u < FILL_STEP; ++u) {
                     const uint32_t i = (uint32_t)tid + (uint32_t)(u0 + u) * OW_THREADS;
                     // every slot of the slice is written, the ones behind the range's buckets with the slice's size
-                    if (u0 + u < TPER && i < (uint32_t)BUCKETS + 4u) s_t[i] = i < cnt_t ? (TT)(tv[u] - p0) : (TT)cnt_q;
+                    uint32_t v = tv[u] - p0;
+                    if (STAGE) v = tv[u] < p0 ? 0u : (v < cnt_q ? v : cnt_q);  // clipped to the range's positions: buckets at its ends reach past them
+                    if (u0 + u < TPER && i < (uint32_t)BUCKETS + 4u) s_t[i] = i < cnt_t ? (TT)v : (TT)cnt_q;
                 }
             }
 #pragma unroll
@@ -2693,9 +2885,13 @@ void overlap_lean_kernel(const uint64_t* __restrict__ Q, const uint32_t* __restr
         if (tid < 2) s_q[cnt_q + tid] = ~0ull;                            // (the table slice's padding is written by its fill)
         __syncthreads();
         if (!last) {                                                     // the next range's bounds
-            const uint32_t nb0 = b1, nb1 = nb0 + bpr < n_buckets ? nb0 + bpr : n_buckets;
-            n_p0 = T[nb0];
-            n_p1 = T[nb1];
+            if (STAGE) {
+                n_rd = sa.desc[r + 1];
+            } else {
+                const uint32_t nb0 = b1, nb1 = nb0 + bpr < n_buckets ? nb0 + bpr : n_buckets;
+                n_p0 = T[nb0];
+                n_p1 = T[nb1];
+            }
         }
 #pragma unroll
         for (int v0 = 0; v0 < SLOTS; v0 += BATCH) {
@@ -2707,8 +2903,8 @@ void overlap_lean_kernel(const uint64_t* __restrict__ Q, const uint32_t* __restr
                 const int k = v0 + w;
                 if (k >= SLOTS) continue;
                 in[w] = mask_of(e[k] < upper);                               // lanes past the row's end hold 2^64 - 1
-                uint32_t kk = (uint32_t)(e[k] >> shift) - b0;                // < bpr for the lanes of `in`
-                kk = kk < bpr ? kk : bpr;                                    // the others: the padding buckets behind the slice
+                uint32_t kk = (uint32_t)(e[k] >> shift) - b0;                // < kcap for the lanes of `in`
+                kk = kk < kcap ? kk : kcap;                                  // the others: the padding buckets behind the slice
                 t0[w] = (uint32_t)s_t[kk];
                 t1[w] = (uint32_t)s_t[kk + 1];
             }
@@ -2725,8 +2921,8 @@ void overlap_lean_kernel(const uint64_t* __restrict__ Q, const uint32_t* __restr
                 if (k >= SLOTS) continue;
                 const uint64_t second = mask_of(qb[w] == e[k]);
                 uint64_t found = in[w] & (mask_of(qa[w] == e[k]) | second);
-                uint32_t jr = 0;                                             // BUILD: position within the slice of the hash found
-                if (BUILD) jr = t0[w] + (lanes_of(second) ? 1u : 0u);
+                uint32_t jr = 0;                                             // BUILD / STAGE: position within the slice of the hash found
+                if (QPOS) jr = t0[w] + (lanes_of(second) ? 1u : 0u);
                 // a bucket of three or more whose second hash is still below the lane's hash (rare: ~1 visit in 3 has such a
                 // lane, and a scan is a divergent loop over LDS): scan on.  (Without the size test every hash ABOVE both hashes of
                 // a bucket of two came here too -- 3 % of the lookups, three visits in four: 2.46 -> 3.44 ms.)
@@ -2736,13 +2932,14 @@ void overlap_lean_kernel(const uint64_t* __restrict__ Q, const uint32_t* __restr
                     if (lanes_of(deep))
                         for (uint32_t t = t0[w] + 2;; ++t) {
                             const uint64_t qv = s_q[t];
-                            if (qv >= e[k]) { hit = qv == e[k]; if (BUILD && hit) jr = t; break; }
+                            if (qv >= e[k]) { hit = qv == e[k]; if (QPOS && hit) jr = t; break; }
                         }
                     found |= in[w] & mask_of(hit);
                 }
-                if (BUILD) {
+                if (QPOS) {
                     if (lanes_of(in[w])) (qrows + pos[k])[lane] = lanes_of(found) ? p0 + jr : NONE32;
-                    if (lanes_of(found)) atomicAdd(&s_h[jr >> 1], 1u << ((jr & 1u) << 4));
+                    if (BUILD && lanes_of(found)) atomicAdd(&s_h[jr >> 1], 1u << ((jr & 1u) << 4));
+                    if (STAGE && lanes_of(found)) stage_put(jr, (uint32_t)d_lo + (uint32_t)wave + (uint32_t)k * OW_WAVES);
                 }
                 hv[k] += (uint32_t)__popcll(found);
                 uint32_t taken = (uint32_t)__popcll(in[w]);
@@ -2754,15 +2951,16 @@ void overlap_lean_kernel(const uint64_t* __restrict__ Q, const uint32_t* __restr
                     bool h2 = false;
                     if (more) {
                         uint32_t k2 = (uint32_t)(ev >> shift) - b0;
-                        k2 = k2 < bpr ? k2 : bpr;
+                        k2 = k2 < kcap ? k2 : kcap;
                         uint32_t t = (uint32_t)s_t[k2];
                         for (;; ++t) {
                             const uint64_t qv = s_q[t];
                             if (qv >= ev) { h2 = qv == ev; break; }
                         }
-                        if (BUILD) {
+                        if (QPOS) {
                             (qrows + pos[k])[lane] = h2 ? p0 + t : NONE32;
-                            if (h2) atomicAdd(&s_h[t >> 1], 1u << ((t & 1u) << 4));
+                            if (BUILD && h2) atomicAdd(&s_h[t >> 1], 1u << ((t & 1u) << 4));
+                            if (STAGE && h2) stage_put(t, (uint32_t)d_lo + (uint32_t)wave + (uint32_t)k * OW_WAVES);
                         }
                     }
                     hv[k] += (uint32_t)__popcll(mask_of(h2));
@@ -2773,9 +2971,14 @@ void overlap_lean_kernel(const uint64_t* __restrict__ Q, const uint32_t* __restr
             }
         }
     }
-    if (BUILD) {
+    if (QPOS) {
         __syncthreads();                                                  // the last range's adds are in
-        flush_counts();
+        if (BUILD) flush_counts();
+        if (STAGE) {
+            stage_place();
+            __syncthreads();
+            stage_write();
+        }
         // what the walk never consumed (a row's hash 2^64 - 1, which reads like the filler of lanes past a row's end): not in the query
 #pragma unroll
         for (int k = 0; k < SLOTS; ++k)
@@ -2795,14 +2998,78 @@ hipError_t build_lean_launch(const uint64_t* Q, uint64_t nq, const uint32_t* T, 
                              unsigned long long* counters, uint32_t* qpos, uint16_t* part16, hipStream_t stream) {
     static int attr = 0;
     if (attr == 0) {
-        const hipError_t ea = hipFuncSetAttribute((const void*)overlap_lean_kernel<OwLean, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LEAN_BUILD_LDS);
+        const hipError_t ea = hipFuncSetAttribute((const void*)overlap_lean_kernel<OwLean, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LEAN_BUILD_LDS);
         attr = ea == hipSuccess ? 1 : -1;
         if (attr < 0) (void)hipGetLastError();
     }
     if (attr < 0) return hipErrorInvalidValue;
     const uint64_t n_sub = (ndb + rows_per_wg - 1) / rows_per_wg;
-    hipLaunchKernelGGL((overlap_lean_kernel<OwLean, true>), dim3((unsigned)n_sub), dim3(OW_THREADS), LEAN_BUILD_LDS, stream, Q, T, n_buckets, shift,
-                       hashes, offsets, ndb, rows_per_wg, n_ranges, bpr, counters, qpos, part16, nq);
+    hipLaunchKernelGGL((overlap_lean_kernel<OwLean, 1>), dim3((unsigned)n_sub), dim3(OW_THREADS), LEAN_BUILD_LDS, stream, Q, T, n_buckets, shift,
+                       hashes, offsets, ndb, rows_per_wg, n_ranges, bpr, counters, qpos, part16, nq, StageArgs{});
+    return hipGetLastError();
+}
+
+// ... and its staging form (MODE 2): ranges of `W` query positions described by range_plan_kernel
+using OwStage = OwGeom<25, 9216, 8192, uint32_t, 4, 4>;
+constexpr size_t LEAN_STAGE_LDS = ((size_t)OwStage::QCAP + 2) * 8 + OwStage::T_BYTES + ((size_t)LEAN_NW * LEAN_CAPW + 3 * LEAN_NW) * 4;
+static_assert(LEAN_STAGE_LDS <= 160 * 1024, "");
+static_assert(LEAN_NW * BR_SUB >= OwStage::QCAP, "a range's windows all have a part of the staging area");
+
+__global__ __launch_bounds__(256) void range_plan_kernel(const uint64_t* __restrict__ Q, uint64_t nq, uint32_t shift, uint32_t n_buckets,
+                                                         uint32_t W, uint32_t n_ranges, RangeDesc* __restrict__ desc, unsigned int* max_nb) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_ranges) return;
+    const uint64_t p0 = (uint64_t)r * W;
+    const bool last = r + 1 == n_ranges;
+    RangeDesc d;
+    d.p0 = (uint32_t)p0;
+    d.cnt = (uint32_t)(nq - p0 < (uint64_t)W ? nq - p0 : (uint64_t)W);
+    d.upper = last ? ~0ull : Q[p0 + W];                                  // hashes below it belong to this range or an earlier one
+    d.b0 = r == 0 ? 0u : (uint32_t)(Q[p0] >> shift);                      // (what lies below the query's first hash is range 0's, and misses)
+    const uint32_t b1 = last ? n_buckets - 1 : (uint32_t)(d.upper >> shift);
+    d.nb = b1 - d.b0 + 1;
+    desc[r] = d;
+    atomicMax(max_nb, d.nb);
+}
+
+uint32_t build_stage_positions(uint64_t nq, uint32_t buckets) {          // W: query positions per range
+    double w = 8900.0 * (double)nq / (double)buckets;                     // ~8,900 buckets per range, the slice has room for 9,216
+    if (w > (double)OwStage::QCAP) w = (double)OwStage::QCAP;
+    const uint32_t W = ((uint32_t)w / (uint32_t)BR_SUB) * (uint32_t)BR_SUB;
+    return W < (uint32_t)BR_SUB ? (uint32_t)BR_SUB : W;
+}
+uint32_t build_stage_buckets_max() { return (uint32_t)OwStage::BUCKETS; }
+uint32_t build_stage_rows_max() { return (uint32_t)OwStage::ROWS; }
+size_t build_stage_desc_bytes(uint32_t n_ranges) { return (size_t)n_ranges * sizeof(RangeDesc); }
+
+hipError_t build_stage_plan(const uint64_t* Q, uint64_t nq, uint32_t shift, uint32_t n_buckets, uint32_t W, uint32_t n_ranges, void* desc,
+                            unsigned int* max_nb, hipStream_t stream) {
+    hipLaunchKernelGGL(range_plan_kernel, dim3((n_ranges + 255) / 256), dim3(256), 0, stream, Q, nq, shift, n_buckets, W, n_ranges,
+                       (RangeDesc*)desc, max_nb);
+    return hipGetLastError();
+}
+
+hipError_t build_stage_launch(const uint64_t* Q, uint64_t nq, const uint32_t* T, uint32_t n_buckets, uint32_t shift, const uint64_t* hashes,
+                              const uint64_t* offsets, uint64_t ndb, uint32_t rows_per_wg, uint32_t n_ranges, const void* desc,
+                              unsigned long long* counters, uint32_t* qpos, uint32_t* inter, uint32_t* dir_start, uint32_t* dir_len,
+                              unsigned int* misc, hipStream_t stream) {
+    static int attr = 0;
+    if (attr == 0) {
+        const hipError_t ea = hipFuncSetAttribute((const void*)overlap_lean_kernel<OwStage, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LEAN_STAGE_LDS);
+        attr = ea == hipSuccess ? 1 : -1;
+        if (attr < 0) (void)hipGetLastError();
+    }
+    if (attr < 0) return hipErrorInvalidValue;
+    const uint64_t n_sub = (ndb + rows_per_wg - 1) / rows_per_wg;
+    StageArgs sa;
+    sa.desc = (const RangeDesc*)desc;
+    sa.inter = inter;
+    sa.dir_start = dir_start;
+    sa.dir_len = dir_len;
+    sa.n_sub = (uint32_t)n_sub;
+    sa.misc = misc;
+    hipLaunchKernelGGL((overlap_lean_kernel<OwStage, 2>), dim3((unsigned)n_sub), dim3(OW_THREADS), LEAN_STAGE_LDS, stream, Q, T, n_buckets, shift,
+                       hashes, offsets, ndb, rows_per_wg, n_ranges, 0u, counters, qpos, (uint16_t*)nullptr, nq, sa);
     return hipGetLastError();
 }
 
@@ -2915,7 +3182,7 @@ hipError_t overlap_ranges_launch(const uint64_t* Q, uint64_t nq, const uint64_t*
         static int lean_attr = 0;
         constexpr size_t LEAN_LDS = ((size_t)OwLean::QCAP + 2) * 8 + OwLean::T_BYTES;
         if (lean_attr == 0) {
-            const hipError_t ea = hipFuncSetAttribute((const void*)overlap_lean_kernel<OwLean, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LEAN_LDS);
+            const hipError_t ea = hipFuncSetAttribute((const void*)overlap_lean_kernel<OwLean, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LEAN_LDS);
             lean_attr = ea == hipSuccess ? 1 : -1;
             if (lean_attr < 0) (void)hipGetLastError();
         }
@@ -2923,8 +3190,8 @@ hipError_t overlap_ranges_launch(const uint64_t* Q, uint64_t nq, const uint64_t*
         if (lean_attr > 0 && (pick == 0 || pick == 3) && l_widest <= (unsigned)OwLean::QCAP && l_widest > 0 && q_max != ~0ull) {
             const uint64_t rpw = rows_per_wg((uint64_t)n_cu_w, OwLean::ROWS);
             const uint64_t n_wg = (ndb + rpw - 1) / rpw;
-            hipLaunchKernelGGL((overlap_lean_kernel<OwLean, false>), dim3((unsigned)n_wg), dim3(OW_THREADS), LEAN_LDS, stream, Q, (const uint32_t*)table, buckets,
-                               shift, hashes, offsets, ndb, (uint32_t)rpw, l_ranges, lbpr, cnt, (uint32_t*)nullptr, (uint16_t*)nullptr, (uint64_t)0);
+            hipLaunchKernelGGL((overlap_lean_kernel<OwLean, 0>), dim3((unsigned)n_wg), dim3(OW_THREADS), LEAN_LDS, stream, Q, (const uint32_t*)table, buckets,
+                               shift, hashes, offsets, ndb, (uint32_t)rpw, l_ranges, lbpr, cnt, (uint32_t*)nullptr, (uint16_t*)nullptr, (uint64_t)0, StageArgs{});
             wide_done = true;
         } else if (attr_state > 0 && pick != 1 && pick != 0 && w2_widest <= (unsigned)OwTwo::QCAP && w2_widest > 0) {
             const uint64_t rpw = rows_per_wg((uint64_t)n_cu_w * 2, OwTwo::ROWS);

@@ -166,8 +166,8 @@ def test_synthetic_gather_vs_oracle(sm, build, monkeypatch):
         assert len(want) > 10 or thr_bp == 200_000
 
 
-@pytest.mark.parametrize("fill,pass1", [("staged", "ranges"), ("staged", "lean"), ("streams", "lean"), ("streams", "ranges"),
-                                        ("direct", "ranges")])
+@pytest.mark.parametrize("fill,pass1", [("staged", "ranges"), ("staged", "lean"), ("staged", "stage"), ("streams", "lean"),
+                                        ("streams", "ranges"), ("direct", "ranges")])
 def test_range_builder_postings_are_exact(fill, pass1, monkeypatch):
     """The postings themselves (not only the gather they drive): after the range-partitioned build every counter equals
     |Q ∩ row|, and consuming the whole query through the postings brings every counter to exactly zero -- which holds
@@ -178,7 +178,8 @@ def test_range_builder_postings_are_exact(fill, pass1, monkeypatch):
     from sourmash_amd.synth import synth_gather
     monkeypatch.setenv("SMG_GATHER_BUILD", "ranges")
     monkeypatch.setenv("SMG_GATHER_FILL", fill)
-    monkeypatch.setenv("SMG_GATHER_PASS1", pass1)                 # pass 1 by lookups in L2 / by the lean streaming kernel (a fallback is an error)
+    monkeypatch.setenv("SMG_GATHER_PASS1", pass1)                 # pass 1 by lookups in L2 / by the lean streaming kernel (counting, or
+                                                                  # staging the postings itself); a fallback is an error
     qh, dbh = synth_gather(n_query=3 * 32768 + 77, n_db=700, db_size=900)
     dbh[3] = np.zeros(0, dtype=np.uint64)
     dbh[4] = np.array([1, 2, 3], dtype=np.uint64)
@@ -216,7 +217,7 @@ def test_index_build_of_many_rows_takes_the_lean_pass(monkeypatch):
     q = torch.from_numpy(qh.view(np.int64).copy()).cuda()
     want = np.array([oracle.intersection_size(qh, d)[0] for d in dbh], dtype=np.uint64)
     ref = oracle.gather(qh, *oracle.make_csr(dbh), threshold_bp=0, scaled=1000, nthreads=8)
-    for pass1 in (None, "ranges"):
+    for pass1 in (None, "stage", "lean", "ranges"):                # the default must be one of the lean forms: both are forced as well
         if pass1:
             monkeypatch.setenv("SMG_GATHER_PASS1", pass1)
         st = be.gather_state(q, len(qh), h, off, len(dbh), 0)
@@ -225,6 +226,22 @@ def test_index_build_of_many_rows_takes_the_lean_pass(monkeypatch):
         st.begin(0, len(dbh))
         assert st.run() == ref, pass1
         assert not st.counters().any()
+    # eighty neighbouring rows that all hold the same 256 consecutive query hashes: more postings in one window than the staging
+    # form has room for in LDS -- it must notice and the builder fall back (forced, it refuses)
+    monkeypatch.delenv("SMG_GATHER_PASS1")
+    for d in range(4000, 4080):
+        dbh[d] = np.unique(np.concatenate([dbh[d], qh[70_000:70_256]]))
+    h, off = smd.pack_csr(dbh)
+    want = np.array([oracle.intersection_size(qh, d)[0] for d in dbh], dtype=np.uint64)
+    st = be.gather_state(q, len(qh), h, off, len(dbh), 0)
+    assert np.array_equal(st.counters(), want)
+    assert int(be.lib.smgpu_gather_postings(st._ptr)) == int(want.sum())
+    st.begin(0, len(dbh))
+    assert st.run() == oracle.gather(qh, *oracle.make_csr(dbh), threshold_bp=0, scaled=1000, nthreads=8)
+    assert not st.counters().any()
+    monkeypatch.setenv("SMG_GATHER_PASS1", "stage")
+    with pytest.raises(Exception):
+        be.gather_state(q, len(qh), h, off, len(dbh), 0)
 
 
 @pytest.mark.parametrize("form", ["wide", "stream", "ranges"])
