@@ -15,6 +15,8 @@ def short(name):
     name = name.replace("(anonymous namespace)::", "")
     name = re.sub(r"^void ", "", name)
     name = re.sub(r"<smg::OwGeom<(\d+), [^>]*> >", r"<OwGeom\1>", name)       # overlap_lean_kernel<smg::OwGeom<25, 8192, ...> > -> <OwGeom25>
+    # overlap_lean_kernel<smg::OwGeom<25, 10240, ...>, 2> -> overlap_lean_kernel<2> (0: overlaps, 1: builder's pass 1 counting, 2: staging)
+    name = re.sub(r"<smg::OwGeom<(\d+), [^>]*>, (\d+)>", r"<\2>", name)
     name = re.sub(r"\(.*", "", name)
     return name[:90]
 

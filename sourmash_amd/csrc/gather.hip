@@ -468,14 +468,20 @@ __global__ __launch_bounds__(512) void build_scatter_kernel(uint64_t nq, uint32_
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (uint32_t k = tid; k < (uint32_t)BR_SUB; k += blockDim.x)
         s_cur[k] = k < nl ? (uint32_t)(post_off[j0 + k] - wbase) + partial[(uint64_t)b_lo * nq + j0 + k] : 0u;
-    if (tid == 0) {
-        uint32_t run = 0;
-        for (uint32_t i = 0; i < nb; ++i) {
-            s_pre[i] = run;
-            s_src[i] = inter_off[(uint64_t)w * n_sub + i_lo + i];
-            run += subcnt[(uint64_t)w * n_sub + i_lo + i];
+    if (tid < 64) {                                                  // the runs' lengths, all loads at once, and their prefix
+        const bool ok = (uint32_t)tid < nb;
+        const uint32_t len = ok ? subcnt[(uint64_t)w * n_sub + i_lo + tid] : 0u;
+        uint32_t incl = len;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = __shfl_up(incl, d);
+            if (lane >= d) incl += o;
         }
-        s_pre[nb] = run;
+        if (ok) {
+            s_pre[tid] = incl - len;
+            s_src[tid] = inter_off[(uint64_t)w * n_sub + i_lo + tid];
+        }
+        if (tid == 63) s_pre[nb] = incl;
     }
     __syncthreads();
     const uint32_t total = s_pre[nb];
@@ -586,13 +592,45 @@ __global__ __launch_bounds__(512) void build_count_runs_kernel(uint64_t nq, uint
     const uint32_t b_lo = g * per, b_hi = b_lo + per < B ? b_lo + per : B;
     if (b_lo >= B) return;
     const uint32_t i_lo = b_lo * m, i_hi = b_hi * m < n_sub ? b_hi * m : n_sub;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t nreg = i_hi > i_lo ? i_hi - i_lo : 0u;              // <= 64
+    const int tid = threadIdx.x, lane = tid & 63;
+    __shared__ uint32_t s_pre[BR_GROUPS * 8 + 1], s_src[BR_GROUPS * 8];
     for (uint32_t k = tid; k < (uint32_t)(BR_SUB * BR_ORD_NB); k += blockDim.x) s_cnt[k] = 0;
+    if (tid < 64) {
+        const bool ok = (uint32_t)tid < nreg;
+        const uint32_t len = ok ? dir_len[(uint64_t)w * n_sub + i_lo + tid] : 0u;
+        uint32_t incl = len;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t o = __shfl_up(incl, d);
+            if (lane >= d) incl += o;
+        }
+        if (ok) {
+            s_pre[tid] = incl - len;
+            s_src[tid] = dir_start[(uint64_t)w * n_sub + i_lo + tid];
+        }
+        if (tid == 63) s_pre[nreg] = incl;
+    }
     __syncthreads();
-    for (uint32_t i = i_lo + (uint32_t)wave; i < i_hi; i += blockDim.x >> 6) {       // a wave per run
-        const uint32_t from = dir_start[(uint64_t)w * n_sub + i], n = dir_len[(uint64_t)w * n_sub + i];
-        const uint32_t bl = i / m - b_lo;
-        for (uint32_t f = lane; f < n; f += 64) atomicAdd(&s_cnt[(inter[from + f] & (uint32_t)(BR_SUB - 1)) * BR_ORD_NB + bl], 1u);
+    const uint32_t total = s_pre[nreg];
+    constexpr int PER = 8;                                              // entries a thread has in flight
+    for (uint32_t f0 = 0; f0 < total; f0 += 512u * PER) {
+        uint32_t ent[PER], blk[PER];
+        uint32_t reg = 0;
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            const uint32_t f = f0 + (uint32_t)tid + (uint32_t)i * 512u;
+            ent[i] = 0;
+            blk[i] = ~0u;
+            if (f < total) {
+                while (f >= s_pre[reg + 1]) ++reg;
+                ent[i] = __builtin_nontemporal_load(&inter[(uint64_t)s_src[reg] + (f - s_pre[reg])]);
+                blk[i] = (i_lo + reg) / m - b_lo;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < PER; ++i)
+            if (blk[i] != ~0u) atomicAdd(&s_cnt[(ent[i] & (uint32_t)(BR_SUB - 1)) * BR_ORD_NB + blk[i]], 1u);
     }
     __syncthreads();
     for (uint32_t k = tid; k < (uint32_t)BR_SUB * (b_hi - b_lo); k += blockDim.x) {
