@@ -469,6 +469,25 @@ def cpu_baseline(args, seq, n_bytes, sk, np):
     return cpu
 
 
+def root_only_compare(torch, parallel, be, bh, boff, n, use_dist, barrier, max_over_ranks, want_checksum):
+    """The same compare with the matrices wanted on rank 0 only (result_on="root": the shards are gathered to rank 0, mirror +
+    Jaccard run there alone) -- SURVEY.md 8(d)'s "matrix assembled on rank 0".  None without an exchange."""
+    if not use_dist:
+        return None
+    be._index, be._index_key = None, None
+    timing = {}
+    barrier()
+    t0 = time.perf_counter()
+    full, jac = parallel.compare_all_pairs_distributed(bh, boff, n, be, force_collectives=True, timing=timing, result_on="root")
+    barrier()
+    dt = max_over_ranks(time.perf_counter() - t0)
+    same = None if full is None else bool(int(full.to(torch.int64).sum().item()) == want_checksum)
+    del full, jac
+    return {"ms": round(dt * 1e3, 2), "pairs_per_s": round(n * (n - 1) // 2 / dt, 1), "collective": "gather to rank 0 (rccl)",
+            "gather_ms_rank0": round(timing.get("allgather_ms", 0.0), 2), "mirror_and_jaccard_ms_rank0": round(timing.get("finish_ms", 0.0), 2),
+            "same_counts_as_on_every_rank": same}
+
+
 def bench_compare_dist(torch, dist, np, dev, be, parallel, smd, synth_sketches, world, rank, use_dist, barrier, max_over_ranks):
     "config C4 through parallel.compare_all_pairs_distributed: CSR replicated, 16-row tiles dealt to the ranks, ONE all-gather"
     n = 10_000
@@ -495,7 +514,8 @@ def bench_compare_dist(torch, dist, np, dev, be, parallel, smd, synth_sketches, 
     barrier()
     dt = max_over_ranks(time.perf_counter() - t0)
     checksum = int(full.to(torch.int64).sum().item())
-    out = {"ranks": world, "pairs": pairs, "ms": round(dt * 1e3, 2), "pairs_per_s": round(pairs / dt, 1),
+    root = root_only_compare(torch, parallel, be, bh, boff, n, use_dist, barrier, max_over_ranks, checksum if rank == 0 else None)
+    out = {"ranks": world, "pairs": pairs, "ms": round(dt * 1e3, 2), "pairs_per_s": round(pairs / dt, 1), "result_on_rank0_only": root,
            "tiles_ms_rank0": round(timing.get("tiles_ms", 0.0), 2), "allgather_ms": round(timing.get("allgather_ms", 0.0), 2),
            "mirror_and_jaccard_ms": round(timing.get("finish_ms", 0.0), 2), "collective": "all-gather (rccl)" if use_dist else "none",
            "exchange_bytes": int(((n + 15) // 16 + world - 1) // world * world * 16 * n * timing.get("exchange_bytes_per_entry", 4))
@@ -563,7 +583,10 @@ def bench_compare_xl_dist(torch, dev, be, parallel, synth_sketches_device, world
               "symmetric_on_4096_samples": bool((full[idx, jdx] == full[jdx, idx]).all().item()),
               "counts_at_most_smaller_sketch": bool((full[idx, jdx].to(torch.int64) <= torch.minimum(sizes[idx], sizes[jdx])).all().item()),
               "jaccard_diagonal_is_one": bool((jac.diagonal() == 1.0).all().item())}
+    root = root_only_compare(torch, parallel, be, bh, boff, n, use_dist, barrier, max_over_ranks,
+                             int(full.to(torch.int64).sum().item()) if rank == 0 else None)
     out = {"ranks": world, "sketches": n, "hashes": int(boff[-1].item()), "pairs": pairs, "ms": round(dt * 1e3, 2),
+           "result_on_rank0_only": root,
            "pairs_per_s": round(pairs / dt, 1), "tiles_ms_rank0": round(timing.get("tiles_ms", 0.0), 2),
            "allgather_ms": round(timing.get("allgather_ms", 0.0), 2), "mirror_and_jaccard_ms": round(timing.get("finish_ms", 0.0), 2),
            "collective": "all-gather (rccl)" if use_dist else "none", "scaling": "strong", "checks": checks,

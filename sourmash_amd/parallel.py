@@ -83,6 +83,25 @@ def _all_gather(outs, t, group=None, async_op=False):
     return None
 
 
+def _gather_to_root(outs, t, group=None, async_op=False):
+    """rank 0's outs[r] <- rank r's t (outs is None elsewhere): what the all-gather moves, to ONE receiver -- every rank sends its
+    shard over its own link to rank 0 instead of every shard travelling round the ring"""
+    dist = _dist()
+    root = dist.get_global_rank(group, 0) if group is not None else 0
+    if _staged(t, group):
+        c = t.cpu().contiguous()
+        parts = [c.new_empty(c.shape) for _ in outs] if outs is not None else None
+        dist.gather(c, parts, dst=root, group=group)
+        if outs is not None:
+            for o, part in zip(outs, parts):
+                o.copy_(part)
+        return None
+    if async_op:
+        return dist.gather(t, outs, dst=root, group=group, async_op=True)
+    dist.gather(t, outs, dst=root, group=group)
+    return None
+
+
 def agree(flag, group=None):
     "True iff `flag` holds on every rank (one MIN all-reduce; a plain bool without a process group)"
     dist = _dist()
@@ -427,10 +446,16 @@ class DeviceBackend:
 
 # ---------------------------------------------------------------------------------------------------
 def compare_all_pairs_distributed(hashes, offsets, n, backend, group=None, want_jaccard=True, force_collectives=False,
-                                  timing=None):
+                                  timing=None, result_on="all"):
     """N x N common-hash matrix (int32 bit patterns of u32) and f64 Jaccard on every rank.
     hashes / offsets: the full CSR, replicated on every rank.
-    timing (dict, optional; CUDA tensors only): receives tiles_ms / allgather_ms / finish_ms from stream events."""
+    timing (dict, optional; CUDA tensors only): receives tiles_ms / allgather_ms / finish_ms from stream events.
+    result_on: "all" -- every rank ends up with both matrices (one all-gather of the counts); "root" -- only rank 0 does, as
+    the caller of the reference's compare does (compare.py:14-64 returns ONE matrix): the shards travel to rank 0 alone (a
+    gather: each over its own link, an eighth of the all-gather's bytes on the fabric) and the mirror + Jaccard passes run
+    there only; the other ranks return (None, None)."""
+    if result_on not in ("all", "root"):
+        raise ValueError("result_on must be 'all' or 'root'")
     dist = _dist()
     rank, world = world_info(group)
     marks = []
@@ -459,8 +484,8 @@ def compare_all_pairs_distributed(hashes, offsets, n, backend, group=None, want_
         # Still ONE logical exchange of every count, in a few pieces; small problems and host-staged groups keep one piece.
         bands = COMPARE_BANDS if (max_count >= COMPARE_BAND_MIN_SLOTS * COMPARE_BANDS and not _staged(hashes, group)) else 1
         per = (max_count + bands - 1) // bands
-        full = backend.empty((n_tiles * TILE, n), torch.int32)
-        view = full.view(n_tiles, TILE, n)
+        full = backend.empty((n_tiles * TILE, n), torch.int32) if (result_on == "all" or rank == 0) else None
+        view = full.view(n_tiles, TILE, n) if full is not None else None
         in_flight = []
         for b in range(bands):
             s0, s1 = b * per, min(max_count, (b + 1) * per)
@@ -474,26 +499,36 @@ def compare_all_pairs_distributed(hashes, offsets, n, backend, group=None, want_
                 local = pad
             # (as bytes: neither RCCL nor gloo moves 16-bit integers; truncation keeps the low 16 bits)
             send = local.to(torch.int16).view(torch.uint8) if narrow else local
-            pieces = [backend.empty(tuple(send.shape), send.dtype) for _ in range(world)]
-            work = _all_gather(pieces, send, group, async_op=bands > 1)
+            if result_on == "root":
+                pieces = [backend.empty(tuple(send.shape), send.dtype) for _ in range(world)] if rank == 0 else None
+                work = _gather_to_root(pieces, send, group, async_op=bands > 1)
+            else:
+                pieces = [backend.empty(tuple(send.shape), send.dtype) for _ in range(world)]
+                work = _all_gather(pieces, send, group, async_op=bands > 1)
             in_flight.append((s0, s1, pieces, work, send))
         mark()
         for s0, s1, pieces, work, _send in in_flight:
             if work is not None:
                 work.wait()                                        # (orders the current stream behind the collective)
+            if pieces is None:
+                continue                                           # not the root: its shard is sent, nothing to assemble
             if narrow:
                 pieces = [p.view(torch.int16).to(torch.int32).bitwise_and_(0xFFFF) for p in pieces]
             for r in range(world):                                 # un-deal: slot s of rank r is tile r + world * s
                 cnt = max(0, min((n_tiles - r + world - 1) // world if n_tiles > r else 0, s1) - s0)
                 if cnt:
                     view[r + world * s0: r + world * (s0 + cnt): world] = pieces[r].view(-1, TILE, n)[:cnt]
-        full = full[:n].contiguous() if full.shape[0] != n else full
+        if full is not None:
+            full = full[:n].contiguous() if full.shape[0] != n else full
         if timing is not None:
             timing["exchange_bytes_per_entry"] = 2 if narrow else 4
             timing["exchange_pieces"] = len(in_flight)
     mark()
-    backend.symmetrize(full, n)
-    jac = backend.jaccard(full, offsets, n) if want_jaccard else None
+    if result_on == "root" and rank != 0:
+        full, jac = None, None
+    else:
+        backend.symmetrize(full, n)
+        jac = backend.jaccard(full, offsets, n) if want_jaccard else None
     mark()
     if marks:
         backend.torch.cuda.synchronize()

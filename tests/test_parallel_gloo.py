@@ -224,6 +224,16 @@ def _worker(rank, world, port, ret):
         parallel.COMPARE_BAND_MIN_SLOTS = 8
         ok_cmp = ok_cmp and np.array_equal(common_b.numpy().view(np.uint32), wc) and np.array_equal(jac_b.numpy().view(np.uint64), wj.view(np.uint64))
         ok_cmp = ok_cmp and t_banded.get("exchange_pieces") == 2
+        # the matrices on rank 0 only (what the reference's caller gets): a gather instead of the all-gather, mirror + Jaccard
+        # on the root alone, None elsewhere -- plain and in bands
+        for min_slots in (8, 0):
+            parallel.COMPARE_BAND_MIN_SLOTS = min_slots
+            common_r, jac_r = parallel.compare_all_pairs_distributed(h, off, len(sk), be, result_on="root")
+            parallel.COMPARE_BAND_MIN_SLOTS = 8
+            if rank == 0:
+                ok_cmp = ok_cmp and np.array_equal(common_r.numpy().view(np.uint32), wc) and np.array_equal(jac_r.numpy().view(np.uint64), wj.view(np.uint64))
+            else:
+                ok_cmp = ok_cmp and common_r is None and jac_r is None
         # counts travel as 16-bit words unless a sketch could share 65,536 hashes or more: two sketches of 70,000 that share
         # 66,000 take the 32-bit form (and a wrapped count would show)
         wide = [np.arange(1, 70_001, dtype=np.uint64) * np.uint64(977), np.arange(4001, 74_001, dtype=np.uint64) * np.uint64(977)]
