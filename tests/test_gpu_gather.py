@@ -244,6 +244,31 @@ def test_index_build_of_many_rows_takes_the_lean_pass(monkeypatch):
         be.gather_state(q, len(qh), h, off, len(dbh), 0)
 
 
+@pytest.mark.parametrize("n_query", [700, 8193, 8450, 16_384 + 255])
+def test_lean_index_build_with_short_and_awkward_queries(n_query, monkeypatch):
+    """The staging form of pass 1 cuts the query into ranges of W positions (a multiple of 256, at most 8,192): a query of one
+    partial window, one of a full range plus a single position, one whose last window is a few lists, one that ends one list
+    short of a window -- 17,000 short rows each; forced, so a fallback would be an error."""
+    import torch
+    from sourmash_amd import device as smd, parallel
+    from sourmash_amd.synth import synth_gather
+    monkeypatch.setenv("SMG_GATHER_PASS1", "stage")
+    qh, dbh = synth_gather(n_query=n_query, n_db=17_000, db_size=24)
+    dbh[5] = qh.copy()                                            # the whole query as a row
+    dbh[6] = qh[-1:].copy()
+    dbh[7] = qh[:1].copy()
+    be = parallel.DeviceBackend()
+    h, off = smd.pack_csr(dbh)
+    q = torch.from_numpy(qh.view(np.int64).copy()).cuda()
+    want = np.array([oracle.intersection_size(qh, d)[0] for d in dbh], dtype=np.uint64)
+    st = be.gather_state(q, len(qh), h, off, len(dbh), 0)
+    assert np.array_equal(st.counters(), want)
+    assert int(be.lib.smgpu_gather_postings(st._ptr)) == int(want.sum())
+    st.begin(0, len(dbh))
+    assert st.run() == oracle.gather(qh, *oracle.make_csr(dbh), threshold_bp=0, scaled=1000, nthreads=8)
+    assert not st.counters().any()
+
+
 @pytest.mark.parametrize("form", ["wide", "stream", "ranges"])
 def test_overlaps_of_a_large_query_take_the_range_partitioned_pass(form):
     """smgpu_overlap_raw with a large query over >= 4096 rows (gather.hip: overlap_ranges_launch), both ops, vs the oracle:
