@@ -1694,7 +1694,7 @@ static hipError_t gather_build_body(GatherDev& g, hipStream_t stream);
 hipError_t build_lean_launch(const uint64_t* Q, uint64_t nq, const uint32_t* T, uint32_t n_buckets, uint32_t shift, const uint64_t* hashes,
                              const uint64_t* offsets, uint64_t ndb, uint32_t rows_per_wg, uint32_t n_ranges, uint32_t bpr,
                              unsigned long long* counters, uint32_t* qpos, uint16_t* part16, hipStream_t stream);
-uint32_t build_stage_positions(uint64_t nq, uint32_t buckets);
+uint32_t build_stage_positions(uint64_t nq, uint32_t buckets, double mean_row);
 uint32_t build_stage_buckets_max();
 uint32_t build_stage_rows_max();
 size_t build_stage_desc_bytes(uint32_t n_ranges);
@@ -1704,8 +1704,9 @@ hipError_t build_stage_launch(const uint64_t* Q, uint64_t nq, const uint32_t* T,
                               const uint64_t* offsets, uint64_t ndb, uint32_t rows_per_wg, uint32_t n_ranges, const void* desc,
                               unsigned long long* counters, uint32_t* qpos, uint32_t* inter, uint32_t* dir_start, uint32_t* dir_len,
                               unsigned int* misc, hipStream_t stream);
+void lean_table_geometry(uint64_t nq, uint64_t q_max, double mean_row, uint32_t* shift, uint32_t* buckets);
 struct LeanPlan { uint32_t bpr, n_ranges, qcap, rows_cap; };
-LeanPlan build_lean_plan(uint64_t nq, uint32_t buckets);
+LeanPlan build_lean_plan(uint64_t nq, uint32_t buckets, double mean_row);
 // largest number of query hashes in any range (the caller checks it against the LDS room of the kernel that walks the ranges)
 __global__ __launch_bounds__(256) void stream_range_max_kernel(const uint32_t* __restrict__ T, uint32_t n_buckets, uint32_t n_ranges,
                                                               uint32_t bpr, unsigned int* out) {
@@ -1782,7 +1783,7 @@ static hipError_t gather_build_body(GatherDev& g, hipStream_t stream) {
         return hipSuccess;
     }
     const QIndex qi = qindex_of(g);
-    ArenaBuf post_cnt_b, scan_tmp_b, bounds_b, partial_b, subcnt_b, inter_off_b, lay_tmp_b, inter_b, part16_b, desc_b, misc_b;
+    ArenaBuf post_cnt_b, scan_tmp_b, bounds_b, partial_b, subcnt_b, inter_off_b, lay_tmp_b, inter_b, part16_b, desc_b, misc_b, lean_table_b;
     SMG_TRY(post_cnt_b.get(nq1 * 8, stream));
     unsigned long long* post_cnt = post_cnt_b.as<unsigned long long>();
     size_t scan_bytes = 0;
@@ -1841,20 +1842,31 @@ static hipError_t gather_build_body(GatherDev& g, hipStream_t stream) {
         LeanPlan lp{};
         uint64_t m_sub = 1, rpw = 0, n_sub = 0;
         uint32_t stage_W = 0, stage_ranges = 0;
+        uint32_t lean_shift = g.q_shift, lean_buckets = g.q_buckets;
+        uint32_t* lean_T = g.q_table;
         const uint32_t n_windows = R * BR_NSUB;
         {
             int n_cu = 256;
             { int dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev); }
             if (pass1_env != 1 && staged && B <= (uint64_t)MS_BMAX && g.q_max != ~0ull && (pass1_env >= 2 || g.ndb >= (uint64_t)n_cu * 64)) {
-                lp = build_lean_plan(g.nq, g.q_buckets);
-                stage_W = build_stage_positions(g.nq, g.q_buckets);
+                // (the streaming kernels take a coarser table of their own when the shared one has close to two buckets per hash)
+                const double mean_row = (double)total / (double)g.ndb;
+                lean_table_geometry(g.nq, g.q_max, mean_row, &lean_shift, &lean_buckets);
+                if (lean_buckets != g.q_buckets) {
+                    SMG_TRY(lean_table_b.get(((uint64_t)lean_buckets + 1) * 4 + 64, stream));
+                    lean_T = lean_table_b.as<uint32_t>();
+                    hipLaunchKernelGGL(qtable_kernel, dim3((lean_buckets + 256) / 256), dim3(256), 0, stream, g.Q, g.nq, lean_shift, lean_buckets, lean_T);
+                    SMG_TRY(hipGetLastError());
+                }
+                lp = build_lean_plan(g.nq, lean_buckets, mean_row);
+                stage_W = build_stage_positions(g.nq, lean_buckets, mean_row);
                 stage_ranges = (uint32_t)((g.nq + stage_W - 1) / stage_W);
                 SMG_TRY(desc_b.get(build_stage_desc_bytes(stage_ranges) + 64, stream));
                 unsigned int* d_widest = (unsigned int*)&g.state[GS_KEY];       // scratch again: zero since the first synchronisation
-                hipLaunchKernelGGL(stream_range_max_kernel, dim3((lp.n_ranges + 255) / 256), dim3(256), 0, stream, (const uint32_t*)g.q_table,
-                                   g.q_buckets, lp.n_ranges, lp.bpr, d_widest);
+                hipLaunchKernelGGL(stream_range_max_kernel, dim3((lp.n_ranges + 255) / 256), dim3(256), 0, stream, (const uint32_t*)lean_T,
+                                   lean_buckets, lp.n_ranges, lp.bpr, d_widest);
                 SMG_TRY(hipGetLastError());
-                SMG_TRY(build_stage_plan(g.Q, g.nq, g.q_shift, g.q_buckets, stage_W, stage_ranges, desc_b.p, d_widest + 1, stream));
+                SMG_TRY(build_stage_plan(g.Q, g.nq, lean_shift, lean_buckets, stage_W, stage_ranges, desc_b.p, d_widest + 1, stream));
                 g.pinned[9] = 0;
                 SMG_TRY(hipMemcpyAsync(&g.pinned[9], d_widest, 8, hipMemcpyDeviceToHost, stream));
                 SMG_TRY(hipMemsetAsync(&g.state[GS_KEY], 0, 8, stream));
@@ -1888,7 +1900,7 @@ static hipError_t gather_build_body(GatherDev& g, hipStream_t stream) {
             SMG_TRY(misc_b.get(64, stream));
             SMG_TRY(hipMemsetAsync(misc_b.p, 0, 64, stream));
             uint32_t* partial = partial_b.as<uint32_t>();
-            SMG_TRY(build_stage_launch(g.Q, g.nq, g.q_table, g.q_buckets, g.q_shift, g.hashes, g.offsets, g.ndb, (uint32_t)rpw, stage_ranges,
+            SMG_TRY(build_stage_launch(g.Q, g.nq, lean_T, lean_buckets, lean_shift, g.hashes, g.offsets, g.ndb, (uint32_t)rpw, stage_ranges,
                                        desc_b.p, g.counters, g.qpos, inter_b.as<uint32_t>(), inter_off_b.as<uint32_t>(), subcnt_b.as<uint32_t>(),
                                        misc_b.as<unsigned int>(), stream));
             const unsigned win_grid = (unsigned)((n_windows + 7) / 8 * 8 * BR_GROUPS);
@@ -1943,7 +1955,7 @@ static hipError_t gather_build_body(GatherDev& g, hipStream_t stream) {
         const unsigned range_grid = (unsigned)(((R + 7) / 8) * 8 * B);
         if (lean1) {
             SMG_TRY(part16_b.get(n_sub * g.nq * 2 + 64, stream));
-            SMG_TRY(build_lean_launch(g.Q, g.nq, g.q_table, g.q_buckets, g.q_shift, g.hashes, g.offsets, g.ndb, (uint32_t)rpw, lp.n_ranges,
+            SMG_TRY(build_lean_launch(g.Q, g.nq, lean_T, lean_buckets, lean_shift, g.hashes, g.offsets, g.ndb, (uint32_t)rpw, lp.n_ranges,
                                       lp.bpr, g.counters, g.qpos, part16_b.as<uint16_t>(), stream));
             hipLaunchKernelGGL(build_merge_sub_kernel, dim3((unsigned)((nq1 + BR_SUB - 1) / BR_SUB)), dim3(BR_SUB), 0, stream,
                                (const uint16_t*)part16_b.as<uint16_t>(), (uint32_t)n_sub, (uint32_t)m_sub, (uint32_t)B, g.nq, partial, post_cnt, subcnt);
@@ -2503,11 +2515,34 @@ using OwTwo = OwGeom<13, 8192, 7680, uint16_t, 8, 2>;     // 60 KB + 16 KB + 2.5
 using OwLean = OwGeom<25, 10240, 11264, uint32_t, 4, SMG_OW_LEAN_BATCH>;  // the lean kernel's geometry: ranges cut by query hashes held, not at a power of two of buckets
 constexpr int OW_BUCKETS = OwOne::BUCKETS;
 
-// ranges of the lean kernel: about `lean_q` query hashes each (a row's part of a range is then ~48 of the 64 hashes a visit loads;
-// more and one visit in sixteen would have to load a second block on the spot), at most as many buckets as the table slice holds
-LeanPlan build_lean_plan(uint64_t nq, uint32_t buckets) {
-    static const double lean_q = [] { const char* e = getenv("SMG_OVERLAP_QPR"); return e ? atof(e) : 9600.0; }();
-    uint32_t bpr = (uint32_t)(lean_q * (double)buckets / (double)nq);
+// Query hashes per range of the streaming kernels.  A visit loads the next 64 hashes of its row and uses the ones below the
+// range's upper bound: a range should hold so many query hashes that a row's part of it is ~48 hashes (more, and one visit in
+// sixteen has to fetch a second block on the spot; fewer, and the visits multiply) -- 48 x nq / (mean row length), at most what
+// the LDS slice holds.  C5: 48 x 1e6 / 5,000 = 9,600.  SMG_OVERLAP_QPR overrides.
+double lean_hashes_per_range(uint64_t nq, double mean_row) {
+    static const double env = [] { const char* e = getenv("SMG_OVERLAP_QPR"); return e ? atof(e) : 0.0; }();
+    if (env > 0.0) return env;
+    double q = 48.0 * (double)nq / (mean_row < 1.0 ? 1.0 : mean_row);
+    if (q > 9600.0) q = 9600.0;
+    if (q < 512.0) q = 512.0;
+    return q;
+}
+
+// The streaming kernels hold a range's slice of the table in LDS as well, so the BUCKETS per query hash decide how many hashes
+// a range can hold.  qindex_geometry gives between one and two (its callers look single hashes up in L2 and want short buckets):
+// at 1.95 -- a 1.1e6-hash query -- a 10,240-bucket slice held 5,250 hashes instead of the 9,600 wanted and the overlap pass took
+// 2.44 ms where the 1.0e6-hash query (1.07) takes 1.54.  When the wanted range does not fit the slice, the streaming kernels use a
+// table of their own with buckets twice as wide.
+void lean_table_geometry(uint64_t nq, uint64_t q_max, double mean_row, uint32_t* shift, uint32_t* buckets) {
+    const double want = lean_hashes_per_range(nq, mean_row) * (double)*buckets / (double)nq;     // buckets a range would need
+    if (want > 1.05 * (double)OwLean::BUCKETS && *shift < 63 && *buckets > 2) {
+        ++*shift;
+        *buckets = (uint32_t)(q_max >> *shift) + 1;
+    }
+}
+
+LeanPlan build_lean_plan(uint64_t nq, uint32_t buckets, double mean_row) {
+    uint32_t bpr = (uint32_t)(lean_hashes_per_range(nq, mean_row) * (double)buckets / (double)nq);
     if (bpr > (uint32_t)OwLean::BUCKETS) bpr = OwLean::BUCKETS;
     if (bpr < 64) bpr = 64;
     return LeanPlan{bpr, (buckets + bpr - 1) / bpr, (uint32_t)OwLean::QCAP, (uint32_t)OwLean::ROWS};
@@ -3070,8 +3105,10 @@ __global__ __launch_bounds__(256) void range_plan_kernel(const uint64_t* __restr
     atomicMax(max_nb, d.nb);
 }
 
-uint32_t build_stage_positions(uint64_t nq, uint32_t buckets) {          // W: query positions per range
+uint32_t build_stage_positions(uint64_t nq, uint32_t buckets, double mean_row) {   // W: query positions per range
     double w = 8900.0 * (double)nq / (double)buckets;                     // ~8,900 buckets per range, the slice has room for 9,216
+    const double q = lean_hashes_per_range(nq, mean_row);                 // ... and a row's part of a range ~48 hashes
+    if (w > q) w = q;
     if (w > (double)OwStage::QCAP) w = (double)OwStage::QCAP;
     const uint32_t W = ((uint32_t)w / (uint32_t)BR_SUB) * (uint32_t)BR_SUB;
     return W < (uint32_t)BR_SUB ? (uint32_t)BR_SUB : W;
@@ -3134,10 +3171,13 @@ hipError_t overlap_ranges_launch(const uint64_t* Q, uint64_t nq, const uint64_t*
     } pin;
     SMG_TRY(arena_pinned_alloc((void**)&pin.p, 64));
     SMG_TRY(hipMemcpyAsync(&pin.p[0], Q + nq - 1, 8, hipMemcpyDeviceToHost, stream));
+    SMG_TRY(hipMemcpyAsync(&pin.p[3], offsets + ndb, 8, hipMemcpyDeviceToHost, stream));
     SMG_TRY(hipStreamSynchronize(stream));
     const uint64_t q_max = pin.p[0];
+    const double mean_row = (double)pin.p[3] / (double)ndb;
     uint32_t shift = 0, buckets = 1;
     qindex_geometry(nq, q_max, &shift, &buckets);
+    lean_table_geometry(nq, q_max, mean_row, &shift, &buckets);
     ArenaBuf table_b, cnt_b, q_padded_b, bounds_b, rec_b;
     SMG_TRY(table_b.get(((uint64_t)buckets + 1) * 4 + 64, stream));
     SMG_TRY(cnt_b.get(ndb * 8 + 64, stream));
@@ -3165,7 +3205,7 @@ hipError_t overlap_ranges_launch(const uint64_t* Q, uint64_t nq, const uint64_t*
     if (w2bpr > (uint32_t)OwTwo::BUCKETS) w2bpr = OwTwo::BUCKETS;
     if (w2bpr < 64) w2bpr = 64;
     const uint32_t w2_ranges = (buckets + w2bpr - 1) / w2bpr;
-    const LeanPlan lean = build_lean_plan(nq, buckets);                     // the lean form: ranges cut by query hashes held
+    const LeanPlan lean = build_lean_plan(nq, buckets, mean_row);                     // the lean form: ranges cut by query hashes held
     const uint32_t lbpr = lean.bpr, l_ranges = lean.n_ranges;
     // the widest range of either partition decides whether its LDS has room: all maxima come back with one synchronisation
     unsigned int widest = 0, w_widest = 0, w2_widest = 0, l_widest = 0;
