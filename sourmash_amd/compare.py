@@ -332,11 +332,19 @@ def _containment(siglist, downsample, mode, return_ani):
             return _containment_block(flat, flat[0].scaled, mode, False)
         return _containment_mixed(flat, mode)
     # ANI: both sketches are downsampled to the pair's coarser scaled first, then everything is computed there
-    # (minhash.py:843-879,907-944): the blocks of _by_scaled are exactly that; an estimate is withheld (0 in the matrix) when
-    # either sketch AS GIVEN is too small for its size to be trusted (minhash.py:869-871)
-    out = _by_scaled(flat, downsample, lambda sub, s: _containment_block(sub, s, mode, True))
-    trusted = np.array([mh.size_is_accurate() for mh in mhs], dtype=bool)
-    out = np.where(trusted[:, None] & trusted[None, :], out, 0.0)
+    # (minhash.py:843-879,907-944): the blocks of _by_scaled are exactly that.  An estimate is withheld (0 in the matrix) when
+    # a sketch is too small for its size to be trusted -- and WHICH sketch is asked differs by mode, as in the reference:
+    # containment / max go through MinHash.{containment,max_containment}_ani, which ask the sketches AS GIVEN
+    # (minhash.py:877-878,938-939); avg goes through FracMinHashComparison (compare.py:166-168), whose mh1_cmp / mh2_cmp are the
+    # sketches already downsampled to the pair's scaled (sketchcomparison.py:53-70,143-170) -- a sketch trusted at its own
+    # scaled but not after downsampling gives 0.0 there.
+    def trust_mask(m, sketches):
+        ok = np.array([mh.size_is_accurate() for mh in sketches], dtype=bool)
+        return np.where(ok[:, None] & ok[None, :], m, 0.0)
+    if mode == "avg":
+        out = _by_scaled(flat, downsample, lambda sub, s: trust_mask(_containment_block(sub, s, mode, True), sub))
+    else:
+        out = trust_mask(_by_scaled(flat, downsample, lambda sub, s: _containment_block(sub, s, mode, True)), mhs)
     out[np.arange(n), np.arange(n)] = 1.0
     return out
 

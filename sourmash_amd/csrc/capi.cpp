@@ -1256,8 +1256,14 @@ static bool gather_use_replay() {
     }();
     return mode == 1;
 }
-// persistent-loop exit codes after which the state is that of a whole number of rounds (gather.hip: the gate, the sweeps)
-static bool gather_loop_gave_up_cleanly(unsigned long long code) { return code >= 10 && code <= 14; }
+// Persistent-loop exit codes that mean "gave up waiting" rather than "broken" (gather.hip: the gate 10, the sweeps 11-13, a peer
+// rank's gate 14).  Only the GATE codes are a decision of the grid as a whole: one word decides, nothing has been touched, and
+// the rounds can carry on in place from the same state.  11-13 are per-workgroup spin limits inside a round: workgroup X can
+// leave at epoch e while workgroup Z, whose sweep began later, still sees the late record and applies round e -- the written-back
+// counters and uncovered set then belong to different round counts.  After those the state is void: single-rank callers get the
+// error, gather_distributed builds a fresh index and runs the record protocol (parallel.py).
+static bool gather_loop_gave_up(unsigned long long code) { return code >= 10 && code <= 14; }
+static bool gather_loop_state_untouched(unsigned long long code) { return code == 10 || code == 14; }
 static uint64_t gather_drain(GatherDev& g, uint64_t* out_idx, uint64_t* out_isect, uint64_t cap, hipStream_t st) {
     unsigned long long head[GS_SLOTS];
     const bool replay = gather_use_replay() && g.ndb > 0 && g.nq > 0;
@@ -1284,11 +1290,12 @@ static uint64_t gather_drain(GatherDev& g, uint64_t* out_idx, uint64_t* out_isec
         memcpy(head, g.pinned + 16, sizeof(head));
         if (head[GS_ERR]) {
             // The grid did not become resident as a whole (another kernel or another process holds CUs): the kernel gave up at
-            // its gate with nothing touched (code 10), or between two rounds with the state of `GS_ROUNDS` whole rounds (11).
-            // Either way the two-kernel rounds below carry on from exactly that state -- a library inside somebody's process
-            // cannot ask for an idle device.  Anything else (a staged row that never arrived: 2-4) is an error.
-            if (!gather_loop_gave_up_cleanly(head[GS_ERR]))
-                throw err_internal("gather loop failed (code " + std::to_string(head[GS_ERR]) + ", epoch " + std::to_string(head[13]) + ")");
+            // its gate with nothing touched (code 10) and the two-kernel rounds below carry on from exactly that state -- a
+            // library inside somebody's process cannot ask for an idle device.  Anything else -- a spin limit inside a round
+            // (11-13: not a grid-wide decision, see above), a staged row that never arrived (2-4) -- is an error.
+            if (!gather_loop_state_untouched(head[GS_ERR]))
+                throw err_internal("gather loop failed (code " + std::to_string(head[GS_ERR]) + ", epoch " + std::to_string(head[13]) +
+                                   ", workgroup " + std::to_string(head[14]) + "): the index's counters are void, build it again");
             if (trace)
                 fprintf(stderr, "[gather] persistent loop gave up (code %llu, workgroup %llu) after %llu rounds, %.1f us: two-kernel rounds take over\n",
                         head[GS_ERR], head[14], head[GS_ROUNDS], std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_all).count());
@@ -1904,7 +1911,7 @@ uint64_t smgpu_gather_results(SmgpuGather* p, uint64_t* out_index, uint64_t* out
             // codes 10-14: the loop gave up between two rounds (at its gate, or waiting for a workgroup or a rank) and the index is
             // intact -- the caller agrees with its peers on what to do next (parallel.gather_distributed: the record protocol)
             const unsigned long long code = head[GS_ERR];
-            if (gather_loop_gave_up_cleanly(code)) { hip_check(hipMemsetAsync(g.state + GS_ERR, 0, 8, st), "memset"); g.loop_fallbacks++; }
+            if (gather_loop_gave_up(code)) { hip_check(hipMemsetAsync(g.state + GS_ERR, 0, 8, st), "memset"); g.loop_fallbacks++; }
             throw err_internal("gather loop: a workgroup or rank waited too long for its peers (code " + std::to_string(code) + ", epoch " +
                                std::to_string(head[13]) + ", workgroup " + std::to_string(head[14]) + ")");
         }

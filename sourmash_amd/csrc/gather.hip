@@ -1593,8 +1593,8 @@ __global__ __launch_bounds__(PL_THREADS) void gather_loop_kernel(LoopArgs a) {
         a.state[GS_QLEN] = qlen;
         a.state[GS_ACC] = 0;
         a.state[GS_PENDING] = 0;
-        a.state[GS_DONE] = failed ? 0 : 1;        // given up between two rounds: the state is that of `rounds` whole rounds, and whoever
-    }                                             // carries on (the two-kernel rounds, the record protocol) starts from it
+        a.state[GS_DONE] = failed ? 0 : 1;        // given up inside a round (spin limits 11-13: each workgroup's own decision, so the
+    }                                             // written-back state may mix round counts): the host treats the index as void
     if (failed && tid == 0 && a.state[GS_ERR] == 0) { a.state[GS_ERR] = fail_code; a.state[13] = fail_epoch; a.state[14] = wg; }
 }
 
@@ -3196,7 +3196,11 @@ hipError_t overlap_ranges_launch(const uint64_t* Q, uint64_t nq, const uint64_t*
     static const bool only_wide = [] { const char* e = getenv("SMG_OVERLAP"); return e && !strcmp(e, "wide"); }();
     int n_cu_w = 256;
     { int dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n_cu_w, hipDeviceAttributeMultiprocessorCount, dev); }
-    const bool try_wide = !no_wide && (only_wide || ndb >= (uint64_t)n_cu_w * 64);
+    // The streaming kernels keep row cursors as 32-bit element offsets from their workgroup's first row: a collection of 2^32
+    // hashes or more (32 GB) could put more than that under one workgroup -- it takes the range-partitioned form, whose
+    // offsets are per row (the index build makes the same check on pinned[0]).
+    const bool spans32 = pin.p[3] < 0xffffffffull;
+    const bool try_wide = spans32 && !no_wide && (only_wide || ndb >= (uint64_t)n_cu_w * 64);
     uint32_t wbpr = OW_BUCKETS;                                            // buckets per range of the wide form: about 10,000 query hashes
     while (wbpr > 64 && (double)wbpr * (double)nq / (double)buckets > 10000.0) wbpr >>= 1;
     const uint32_t w_ranges = (buckets + wbpr - 1) / wbpr;
@@ -3288,7 +3292,9 @@ hipError_t overlap_ranges_launch(const uint64_t* Q, uint64_t nq, const uint64_t*
         }
     }
     if (wide_done) {
-    } else if (!no_stream && widest <= (unsigned)SL_QCAP) {
+    } else if (only_wide) {
+        return hipErrorInvalidValue;
+    } else if (spans32 && !no_stream && widest <= (unsigned)SL_QCAP) {
         const uint32_t n_blocks = (uint32_t)((ndb + SL_ROWS - 1) / SL_ROWS);
         // every workgroup resident at once (4 per CU by LDS and waves): with even a few more than fit, the kernel takes two
         // rounds -- 784 workgroups on 768 slots ran 4.2 ms with the CUs idle 42 % of the wave-time (profiles/r02_gather_sq.txt)

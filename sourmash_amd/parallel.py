@@ -410,12 +410,18 @@ class DeviceBackend:
         rank maps and registers with HIP; unset -- the device form, the host form where it cannot be set up (the ranks agree)."""
         import os
         kind = os.environ.get("SMG_GATHER_EXCHANGE", "auto")
-        if kind in ("auto", "device") and world <= 16:
+        # (a device form that could not be set up once is not tried again by this backend: every attempt costs an allocation, an
+        #  IPC export / open and several collectives, and the outcome is agreed among the ranks, so all of them remember alike)
+        if kind in ("auto", "device") and world <= 16 and not (kind == "auto" and getattr(self, "_xchg_dev_failed", None)):
             try:
                 return open_device_exchange(self, self.lib, self.rustcall, world, rank, rowcap, group)
-            except Exception:
+            except Exception as e:                                           # noqa: BLE001
                 if kind == "device":
                     raise
+                self._xchg_dev_failed = repr(e)
+                import sys
+                print(f"[sourmash_amd] rank {rank}: device-memory gather exchange unavailable ({e!r}); using shared host memory",
+                      file=sys.stderr)
 
         def make(name, create):
             return GatherExchange(self.lib, self.rustcall, world, rowcap, name, create=create)
@@ -486,7 +492,25 @@ def compare_all_pairs_distributed(hashes, offsets, n, backend, group=None, want_
         per = (max_count + bands - 1) // bands
         full = backend.empty((n_tiles * TILE, n), torch.int32) if (result_on == "all" or rank == 0) else None
         view = full.view(n_tiles, TILE, n) if full is not None else None
-        in_flight = []
+        pieces_sent = 0
+
+        def undeal(s0, s1, pieces, work, _send):
+            # wait for the band's collective (orders the current stream behind it), then scatter its pieces into `full`
+            if work is not None:
+                work.wait()
+            if pieces is None:
+                return                                             # not the root: its shard is sent, nothing to assemble
+            if narrow:
+                pieces = [p.view(torch.int16).to(torch.int32).bitwise_and_(0xFFFF) for p in pieces]
+            for r in range(world):                                 # un-deal: slot s of rank r is tile r + world * s
+                cnt = max(0, min((n_tiles - r + world - 1) // world if n_tiles > r else 0, s1) - s0)
+                if cnt:
+                    view[r + world * s0: r + world * (s0 + cnt): world] = pieces[r].view(-1, TILE, n)[:cnt]
+
+        # Band b - 1 is un-dealt right after band b's tiles and collective are enqueued: its exchange has had the whole of band
+        # b's tiles to travel, and only ONE band's receive pieces and send buffer are alive next to `full` (keeping every band's
+        # until the end held about 2 x N x N x 4 bytes per rank, 1.5 x when narrow -- ADVICE r04).
+        pending = None
         for b in range(bands):
             s0, s1 = b * per, min(max_count, (b + 1) * per)
             if s1 <= s0:
@@ -505,24 +529,19 @@ def compare_all_pairs_distributed(hashes, offsets, n, backend, group=None, want_
             else:
                 pieces = [backend.empty(tuple(send.shape), send.dtype) for _ in range(world)]
                 work = _all_gather(pieces, send, group, async_op=bands > 1)
-            in_flight.append((s0, s1, pieces, work, send))
+            pieces_sent += 1
+            if pending is not None:
+                undeal(*pending)
+            pending = (s0, s1, pieces, work, send)
         mark()
-        for s0, s1, pieces, work, _send in in_flight:
-            if work is not None:
-                work.wait()                                        # (orders the current stream behind the collective)
-            if pieces is None:
-                continue                                           # not the root: its shard is sent, nothing to assemble
-            if narrow:
-                pieces = [p.view(torch.int16).to(torch.int32).bitwise_and_(0xFFFF) for p in pieces]
-            for r in range(world):                                 # un-deal: slot s of rank r is tile r + world * s
-                cnt = max(0, min((n_tiles - r + world - 1) // world if n_tiles > r else 0, s1) - s0)
-                if cnt:
-                    view[r + world * s0: r + world * (s0 + cnt): world] = pieces[r].view(-1, TILE, n)[:cnt]
+        if pending is not None:
+            undeal(*pending)
+        pending = None
         if full is not None:
             full = full[:n].contiguous() if full.shape[0] != n else full
         if timing is not None:
             timing["exchange_bytes_per_entry"] = 2 if narrow else 4
-            timing["exchange_pieces"] = len(in_flight)
+            timing["exchange_pieces"] = pieces_sent
     mark()
     if result_on == "root" and rank != 0:
         full, jac = None, None

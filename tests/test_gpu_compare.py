@@ -790,3 +790,44 @@ def test_mixed_scaled_and_jaccard_ani_batched_vs_oracle(sm):
     for i, j in ((0, 1), (5, 30), (38, 39)):
         r = same[i].jaccard_ani(same[j]).ani
         assert a1[i, j] == (0.0 if r is None else r)
+
+
+def test_avg_containment_ani_mixed_scaled_asks_the_downsampled_sketches(sm):
+    """compare.py:141-176 with return_ani: the avg form goes through FracMinHashComparison, whose containment_ani calls ask
+    size_is_accurate() of the sketches ALREADY downsampled to the pair's scaled (sketchcomparison.py:53-70,143-170) -- a sketch
+    of ~450 hashes at scaled 1000 is trusted as given and not at scaled 4000 (~110 hashes); the containment / max forms ask
+    the sketches as given (minhash.py:877-878,938-939).  Batched matrices == the per-pair object API, entry by entry."""
+    from sourmash_amd.compare import compare_serial_avg_containment, compare_serial_containment, compare_serial_max_containment
+    from sourmash_amd.sketchcomparison import FracMinHashComparison
+    from sourmash_amd.synth import synth_sketches
+    big = synth_sketches(12, seed=9, pool_size=40_000, keep_one_in=4, planted=False)       # ~10,000 hashes at scaled 1000
+    sigs = []
+    for i, a in enumerate(big):
+        mh = sm.MinHash(0, 31, scaled=1000)
+        mh.add_many(a if i % 2 == 0 else a[::22])                  # odd: ~450 hashes, trusted at 1000 only
+        if i % 3 == 2:
+            mh = mh.downsample(scaled=4000)
+        sigs.append(sm.SourmashSignature(mh, name=str(i)))
+    as_given = [s.minhash.size_is_accurate() for s in sigs]
+    at_4000 = [s.minhash.downsample(scaled=4000).size_is_accurate() for s in sigs]
+    assert any(g and not d for g, d in zip(as_given, at_4000))       # the case the test is about
+    avg = compare_serial_avg_containment(sigs, downsample=True, return_ani=True)
+    n_masked_by_downsampling = 0
+    for i in range(len(sigs)):
+        for j in range(i + 1, len(sigs)):
+            cmp = FracMinHashComparison(sigs[j].minhash, sigs[i].minhash)
+            r = cmp.avg_containment_ani
+            assert avg[i, j] == avg[j, i] == (0.0 if r is None else r), (i, j)
+            if r is None and as_given[i] and as_given[j]:
+                n_masked_by_downsampling += 1
+    assert n_masked_by_downsampling > 0
+    con = compare_serial_containment(sigs, downsample=True, return_ani=True)
+    mx = compare_serial_max_containment(sigs, downsample=True, return_ani=True)
+    for i in range(len(sigs)):
+        for j in range(len(sigs)):
+            if i == j:
+                continue
+            r = sigs[j].containment_ani(sigs[i], downsample=True).ani
+            assert con[i, j] == (0.0 if r is None else r), (i, j)
+            r = sigs[j].max_containment_ani(sigs[i], downsample=True).ani
+            assert mx[i, j] == (0.0 if r is None else r), (i, j)
