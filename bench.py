@@ -97,6 +97,15 @@ def main():
     if not torch.cuda.is_available():
         print("bench.py needs a GPU (the product path has no CPU fallback)", file=sys.stderr)
         sys.exit(2)
+    if args.gpus != world:
+        print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE is {world}: launch N > 1 through torch.distributed.run "
+              f"(python -m torch.distributed.run --nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 bench.py --gpus {args.gpus})",
+              file=sys.stderr)
+        sys.exit(2)
+    if os.environ.get("SMG_BENCH_SHARE_GPU") != "1" and torch.cuda.device_count() < world:
+        print(f"bench.py: {world} ranks asked for, {torch.cuda.device_count()} GPU(s) visible on this node: one rank per GPU is the "
+              f"contract (SMG_BENCH_SHARE_GPU=1 rehearses the launch with all ranks on device 0)", file=sys.stderr)
+        sys.exit(2)
     # SMG_BENCH_SHARE_GPU=1: a rehearsal of the N > 1 launch on a box with ONE GPU -- every rank uses device 0 and the process
     # group is gloo (RCCL refuses two ranks on one device; sourmash_amd.parallel stages device tensors through the host around
     # gloo collectives).  Same code path as `--gpus N` otherwise; the numbers it prints mean nothing.
@@ -114,6 +123,9 @@ def main():
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    # what the process group REALLY is: every `collective` string below is built from these, nothing is assumed
+    comm = comm_info(torch, dist, use_dist, dev, share_gpu)
 
     import sourmash_amd as sm  # noqa: F401
     from sourmash_amd import device as smd, parallel
@@ -229,13 +241,13 @@ def main():
     if not args.no_compare:
         try:
             extra["compare_c4_dist"] = bench_compare_dist(torch, dist, np, dev, be, parallel, smd, synth_sketches, world, rank,
-                                                          use_dist, barrier, max_over_ranks)
+                                                          use_dist, barrier, max_over_ranks, comm)
         except Exception as e:   # the headline metric must still print
             extra["compare_c4_dist"] = {"error": repr(e)}
         torch.cuda.empty_cache()
         try:
             extra["gather_c5_dist"] = bench_gather_dist(torch, np, dev, be, parallel, synth_gather_device, world, rank,
-                                                        use_dist, barrier, max_over_ranks)
+                                                        use_dist, barrier, max_over_ranks, comm)
         except Exception as e:
             extra["gather_c5_dist"] = {"error": repr(e)}
         torch.cuda.empty_cache()
@@ -245,13 +257,13 @@ def main():
         from sourmash_amd.synth import synth_sketches_device
         try:
             extra["compare_xl_dist"] = bench_compare_xl_dist(torch, dev, be, parallel, synth_sketches_device, world, rank, use_dist,
-                                                             barrier, max_over_ranks)
+                                                             barrier, max_over_ranks, comm)
         except Exception as e:
             extra["compare_xl_dist"] = {"error": repr(e)}
         torch.cuda.empty_cache()
         try:
             extra["gather_xl_dist"] = bench_gather_xl_dist(torch, dev, be, parallel, synth_gather_device, world, rank, use_dist,
-                                                           barrier, max_over_ranks)
+                                                           barrier, max_over_ranks, comm)
         except Exception as e:
             extra["gather_xl_dist"] = {"error": repr(e)}
         torch.cuda.empty_cache()
@@ -280,12 +292,14 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-            "config": {"workload": "C2: sketch 10 GB synthetic random-DNA per GPU (1,000 records x 1e7 bases, "
-                                   "ASCII resident in HBM), k=31 scaled=1000 seed=42; kernel + radix sort + unique",
+            "config": {"workload": "C2: sketch 10 GB synthetic random-DNA per GPU (%d whole records of %d bases = %d bytes with their "
+                                   "separators: what fits 10^10 bytes; ASCII resident in HBM), k=%d scaled=%d seed=42; kernel + radix sort + unique"
+                                   % (n_bytes // stride if n_bytes >= stride else 1, rec, n_bytes, args.ksize, args.scaled),
                        "bases_per_gpu": bases_per_step, "bytes_per_gpu": n_bytes, "ksize": args.ksize,
                        "scaled": args.scaled, "unique_hashes_rank0": n_unique_local,
                        "unique_hashes_job": n_unique_total, "allgather_ms": gather_ms,
-                       "collectives": ("gloo, ranks sharing one GPU (rehearsal)" if share_gpu else "rccl") if use_dist else "none (single rank)"},
+                       "collectives": coll(comm, "all-gather of the hash vectors (union)") + (" -- REHEARSAL: ranks share one GPU" if share_gpu else ""),
+                       "comm": comm},
             "roofline": roofline, "cpu_baseline": cpu, "extra": extra,
         }
     if use_dist:
@@ -302,6 +316,35 @@ def main():
     os.close(real_stdout)
     if out is not None:
         print(json.dumps(out), flush=True)
+
+
+def comm_info(torch, dist, use_dist, dev, share_gpu):
+    """backend / world size / library version / device of every rank, as the running process group reports them (gathered once;
+    the bench line's `collective` strings say `comm["backend"]`, never a literal)"""
+    if not use_dist:
+        return {"backend": None, "world_size_observed": 1, "devices": [torch.cuda.get_device_name(dev) + " #" + str(dev.index)],
+                "ranks_share_one_gpu": False, "library": None}
+    backend = dist.get_backend()
+    lib = None
+    if backend == "nccl":
+        try:
+            lib = "RCCL " + ".".join(str(v) for v in torch.cuda.nccl.version())      # (nccl == RCCL on ROCm)
+        except Exception as e:                                                   # noqa: BLE001
+            lib = "RCCL (version unavailable: %r)" % (e,)
+    mine = {"rank": dist.get_rank(), "device_index": dev.index, "device": torch.cuda.get_device_name(dev),
+            "uuid": str(getattr(torch.cuda.get_device_properties(dev), "uuid", "")), "pid": os.getpid()}
+    everyone = [None] * dist.get_world_size()
+    dist.all_gather_object(everyone, mine)
+    return {"backend": backend, "world_size_observed": dist.get_world_size(), "library": lib, "ranks": everyone,
+            "devices": ["%s #%s" % (r["device"], r["device_index"]) for r in everyone], "ranks_share_one_gpu": bool(share_gpu),
+            "distinct_devices": len({(r["uuid"] or r["device_index"]) for r in everyone})}
+
+
+def coll(comm, what):
+    "a `collective` string: what travels, and the backend that moved it as the process group reports it"
+    if comm["backend"] is None:
+        return "none (single rank)"
+    return "%s (%s, %d rank%s)" % (what, comm["library"] or comm["backend"], comm["world_size_observed"], "" if comm["world_size_observed"] == 1 else "s")
 
 
 def sketch_counters(n_bytes, ksize, bases_per_step):
@@ -371,7 +414,7 @@ def gather_counters(db_bytes):
                               "into bytes with " + cal.describe())
 
 
-def bitmatrix_roofline(n, universe, matrix_ms):
+def bitmatrix_roofline(n, universe, matrix_ms, counters=True):
     """VALU-issue roofline of the dense compare path (bitmatrix_kernel): the work is one AND + one population count per 32-bit word
     of every pair of the tiles on or above the diagonal; the floor is those two instructions at their measured issue costs
     (v_and_b32 2.43, v_bcnt_u32_b32 4.26 cycles per wave-instruction per SIMD: profiles/r01_ubench_valu.txt) on 1,024 SIMDs."""
@@ -386,6 +429,8 @@ def bitmatrix_roofline(n, universe, matrix_ms):
            "what": "AND + popcount of one 32-bit word of one pair = 2 VALU instructions at 2.43 + 4.26 cycles per wave-instruction per "
                    "SIMD (profiles/r01_ubench_valu.txt) x 1,024 SIMDs x 2.4 GHz; tiles on or above the diagonal (64 x 64 pairs each); "
                    "the time includes the mirror pass"}
+    if not counters:                                        # (the committed counters were taken at C4's shape)
+        return out
     pmc = PmcFile(PMC_COMPARE_FILE)
     why = pmc.stale(COMPARE_BITS_SOURCES)
     insts = None if why else pmc.get("bitmatrix_kernel", "SQ_INSTS_VALU")
@@ -398,17 +443,22 @@ def bitmatrix_roofline(n, universe, matrix_ms):
 
 
 def loop_roofline(rounds, loop_ms):
-    """Latency roofline of the resident gather loop: a round is a chain of dependent trips -- the winner's positions, the run
-    bounds of the newly covered hashes, their posting entries (three trips to HBM, ~900 cycles each: MI355X_MICROARCH.md) -- and
-    one all-gather of 32-byte records among 256 workgroups through device-scope memory (two L2 round trips of ~200 cycles);
-    nothing in a round can start before the round in front has finished (the next winner depends on every decrement)."""
+    """Latency roofline of the resident gather loop.  A round cannot start before the round in front has finished (the next
+    winner depends on every decrement), and it cannot avoid (i) ONE agreement of the whole grid on the winner -- every workgroup's
+    record to every workgroup: MI355X_MICROARCH.md prices a 256-workgroup grid agreement at 4.1-4.7 us (barrier-xcd) and an
+    8 KB all-gather of tagged granules at 2.4-3.0 us (allgather row); the lower figure is taken -- and (ii) the dependent trips
+    behind it: the winner's positions, then the postings of the newly covered hashes (two trips to memory of ~900 cycles each
+    once the run bounds sit with the postings; three with a separate bounds table).  Round 4's floor (1.29 us) left the
+    agreement out."""
     clock = 2.4e9
-    floor_us = (3 * 900 + 2 * 200) / clock * 1e6
+    agree_us, trips = 2.4, 2
+    floor_us = agree_us + trips * 900 / clock * 1e6
     achieved = rounds / (loop_ms * 1e-3)
     peak = 1e6 / floor_us
     return {"bound": "latency", "kernel": "gather_loop_kernel", "achieved": round(achieved, 1), "peak": round(peak, 1), "unit": "rounds/s",
             "frac": round(achieved / peak, 4), "us_per_round": round(loop_ms * 1e3 / max(rounds, 1), 2), "floor_us_per_round": round(floor_us, 2),
-            "what": "dependent chain per round: 3 HBM-miss latencies (~900 cycles) + 2 L2 round trips (~200 cycles) at 2.4 GHz"}
+            "what": "per round: one grid-wide agreement among 256 workgroups (2.4 us: the guide's 8 KB granule all-gather, parked) + "
+                    "%d dependent trips to memory (~900 cycles each at 2.4 GHz)" % trips}
 
 
 def cpu_baseline(args, seq, n_bytes, sk, np):
@@ -469,7 +519,7 @@ def cpu_baseline(args, seq, n_bytes, sk, np):
     return cpu
 
 
-def root_only_compare(torch, parallel, be, bh, boff, n, use_dist, barrier, max_over_ranks, want_checksum):
+def root_only_compare(torch, parallel, be, bh, boff, n, use_dist, barrier, max_over_ranks, want_checksum, comm):
     """The same compare with the matrices wanted on rank 0 only (result_on="root": the shards are gathered to rank 0, mirror +
     Jaccard run there alone) -- SURVEY.md 8(d)'s "matrix assembled on rank 0".  None without an exchange."""
     if not use_dist:
@@ -487,12 +537,12 @@ def root_only_compare(torch, parallel, be, bh, boff, n, use_dist, barrier, max_o
     dt = max_over_ranks(time.perf_counter() - t0)
     same = None if full is None else bool(int(full.to(torch.int64).sum().item()) == want_checksum)
     del full, jac
-    return {"ms": round(dt * 1e3, 2), "pairs_per_s": round(n * (n - 1) // 2 / dt, 1), "collective": "gather to rank 0 (rccl)",
+    return {"ms": round(dt * 1e3, 2), "pairs_per_s": round(n * (n - 1) // 2 / dt, 1), "collective": coll(comm, "gather of the count shards to rank 0"),
             "gather_ms_rank0": round(timing.get("allgather_ms", 0.0), 2), "mirror_and_jaccard_ms_rank0": round(timing.get("finish_ms", 0.0), 2),
             "same_counts_as_on_every_rank": same}
 
 
-def bench_compare_dist(torch, dist, np, dev, be, parallel, smd, synth_sketches, world, rank, use_dist, barrier, max_over_ranks):
+def bench_compare_dist(torch, dist, np, dev, be, parallel, smd, synth_sketches, world, rank, use_dist, barrier, max_over_ranks, comm):
     "config C4 through parallel.compare_all_pairs_distributed: CSR replicated, 16-row tiles dealt to the ranks, ONE all-gather"
     n = 10_000
     if rank == 0:
@@ -518,10 +568,10 @@ def bench_compare_dist(torch, dist, np, dev, be, parallel, smd, synth_sketches, 
     barrier()
     dt = max_over_ranks(time.perf_counter() - t0)
     checksum = int(full.to(torch.int64).sum().item())
-    root = root_only_compare(torch, parallel, be, bh, boff, n, use_dist, barrier, max_over_ranks, checksum if rank == 0 else None)
+    root = root_only_compare(torch, parallel, be, bh, boff, n, use_dist, barrier, max_over_ranks, checksum if rank == 0 else None, comm)
     out = {"ranks": world, "pairs": pairs, "ms": round(dt * 1e3, 2), "pairs_per_s": round(pairs / dt, 1), "result_on_rank0_only": root,
            "tiles_ms_rank0": round(timing.get("tiles_ms", 0.0), 2), "allgather_ms": round(timing.get("allgather_ms", 0.0), 2),
-           "mirror_and_jaccard_ms": round(timing.get("finish_ms", 0.0), 2), "collective": "all-gather (rccl)" if use_dist else "none",
+           "mirror_and_jaccard_ms": round(timing.get("finish_ms", 0.0), 2), "collective": coll(comm, "ONE all-gather of the count shards"),
            "exchange_bytes": int(((n + 15) // 16 + world - 1) // world * world * 16 * n * timing.get("exchange_bytes_per_entry", 4))
            if use_dist else 0,
            "counts_checksum": checksum,
@@ -531,7 +581,7 @@ def bench_compare_dist(torch, dist, np, dev, be, parallel, smd, synth_sketches, 
     return out
 
 
-def bench_gather_dist(torch, np, dev, be, parallel, synth_gather_device, world, rank, use_dist, barrier, max_over_ranks):
+def bench_gather_dist(torch, np, dev, be, parallel, synth_gather_device, world, rank, use_dist, barrier, max_over_ranks, comm):
     "config C5 through parallel.gather_distributed: the database sharded by dataset, candidate exchange per batch of rounds"
     nq, ndb, dbsize, thr_bp = 1_000_000, 100_000, 5000, 50_000
     lo, hi = ndb * rank // world, ndb * (rank + 1) // world
@@ -556,7 +606,7 @@ def bench_gather_dist(torch, np, dev, be, parallel, synth_gather_device, world, 
            "exchanges": stats.get("exchanges"), "rounds_per_exchange": stats.get("rounds_per_exchange"),
            "records_per_rank": stats.get("records_per_rank"),
            "exchange_bytes_per_rank": (stats["records_per_rank"] * stats["record_words"] * 8) if stats.get("records_per_rank") else None,
-           "collective": (stats.get("protocol") or "all-gather of candidate rows (rccl)") if use_dist else "none (native single-shard loop)",
+           **gather_transport(stats, use_dist, comm),
            "overlaps_non_increasing": bool(all(a >= b for a, b in zip(iso, iso[1:]))),
            "first": res[:2], "last": res[-1:] if res else None,
            "note": "wall clock of index build + every round, threshold_bp 50,000; exact parity at this size: "
@@ -564,7 +614,19 @@ def bench_gather_dist(torch, np, dev, be, parallel, synth_gather_device, world, 
     return out
 
 
-def bench_compare_xl_dist(torch, dev, be, parallel, synth_sketches_device, world, rank, use_dist, barrier, max_over_ranks):
+def gather_transport(stats, use_dist, comm):
+    """how the ranks' gather loops agreed: `protocol` is what parallel.gather_distributed reports having USED (resident loop kernels
+    through hipIpc-mapped device memory / shared host memory, or the candidate-record protocol over the process group's
+    all-gather); fell_back says that the resident form was tried and given up (3x slower at C5, still correct)"""
+    if not use_dist:
+        return {"collective": "none (native single-shard loop)", "protocol": None, "fell_back": False}
+    proto = stats.get("protocol")
+    fell = bool(stats.get("shared_exchange")) or bool(stats.get("loop_fallbacks"))
+    return {"collective": proto or coll(comm, "all-gather of candidate rows per batch of rounds"), "protocol": proto or "candidate records",
+            "fell_back": fell, "fell_back_note": stats.get("shared_exchange")}
+
+
+def bench_compare_xl_dist(torch, dev, be, parallel, synth_sketches_device, world, rank, use_dist, barrier, max_over_ranks, comm):
     """40,000 x 40,000 compare (8e8 pairs; 16 x C4) through the same distributed driver: the collection is generated in HBM,
     identically on every rank; strong scaling (the matrix is fixed).  Checked through size-independent properties."""
     n = 40_000
@@ -588,12 +650,12 @@ def bench_compare_xl_dist(torch, dev, be, parallel, synth_sketches_device, world
               "counts_at_most_smaller_sketch": bool((full[idx, jdx].to(torch.int64) <= torch.minimum(sizes[idx], sizes[jdx])).all().item()),
               "jaccard_diagonal_is_one": bool((jac.diagonal() == 1.0).all().item())}
     root = root_only_compare(torch, parallel, be, bh, boff, n, use_dist, barrier, max_over_ranks,
-                             int(full.to(torch.int64).sum().item()) if rank == 0 else None)
+                             int(full.to(torch.int64).sum().item()) if rank == 0 else None, comm)
     out = {"ranks": world, "sketches": n, "hashes": int(boff[-1].item()), "pairs": pairs, "ms": round(dt * 1e3, 2),
            "result_on_rank0_only": root,
            "pairs_per_s": round(pairs / dt, 1), "tiles_ms_rank0": round(timing.get("tiles_ms", 0.0), 2),
            "allgather_ms": round(timing.get("allgather_ms", 0.0), 2), "mirror_and_jaccard_ms": round(timing.get("finish_ms", 0.0), 2),
-           "collective": "all-gather (rccl)" if use_dist else "none", "scaling": "strong", "checks": checks,
+           "collective": coll(comm, "ONE all-gather of the count shards"), "scaling": "strong", "checks": checks,
            "counts_checksum": int(full.to(torch.int64).sum().item()),
            "note": "cost model + compare-index build (replicated) + owned 16-row tiles + ONE all-gather of 16-bit counts (3.2 GB in all) "
                    "+ mirror + Jaccard on every rank; what does not shard: the index build and the N x N finish"}
@@ -601,7 +663,7 @@ def bench_compare_xl_dist(torch, dev, be, parallel, synth_sketches_device, world
     return out
 
 
-def bench_gather_xl_dist(torch, dev, be, parallel, synth_gather_device, world, rank, use_dist, barrier, max_over_ranks):
+def bench_gather_xl_dist(torch, dev, be, parallel, synth_gather_device, world, rank, use_dist, barrier, max_over_ranks, comm):
     """Weak scaling of the gather: every rank holds 125,000 datasets (5 GB; 10^6 datasets = 40 GB on 8 ranks), the 10^6-hash
     query is replicated.  What shards is the index build and the memory; the loop is a chain of dependent rounds."""
     nq, per_rank, dbsize, thr_bp = 1_000_000, 125_000, 5000, 50_000
@@ -623,7 +685,7 @@ def bench_gather_xl_dist(torch, dev, be, parallel, synth_gather_device, world, r
             "total_ms": round(best * 1e3, 2), "datasets_per_s": round(ndb / best, 1), "scaling": "weak",
             "index_build_kernels_ms": stats.get("build_kernels_ms"), "loop_kernels_ms": stats.get("loop_gpu_ms"),
             "exchanges": stats.get("exchanges"), "rounds_per_exchange": stats.get("rounds_per_exchange"),
-            "collective": (stats.get("protocol") or "all-gather of candidate rows (rccl)") if use_dist else "none (native single-shard loop)",
+            **gather_transport(stats, use_dist, comm),
             "overlaps_non_increasing": bool(all(a >= b for a, b in zip(iso, iso[1:]))),
             "winners_distinct": bool(len({r[0] for r in res}) == len(res)),
             "first": res[:2], "last": res[-1:] if res else None}
@@ -658,6 +720,7 @@ def single_gpu_extras(extra, torch, np, dev, be, smd, synth_sketches, synth_gath
             "pairs_per_s_incl_index_build": round(pairs / ((ms_bits + build_ms) * 1e-3), 1),
             "matrix_ms": round(ms_bits, 3), "index_build_ms": round(build_ms, 3), "universe": idx.universe,
             "identical_to_merge": bool((c2 == common).all().item() and (j2 == jac).all().item()),
+            "roofline": bitmatrix_roofline(n, idx.universe, ms_bits, counters=False),
             "kernel": "bitmatrix_kernel (hashes held by many sketches as bit columns + popcount, triangle + mirror; "
                       "auto-selected); index built without a sort (csrc/dictindex.hip)"}
         auto_ms = 0.0
@@ -668,6 +731,10 @@ def single_gpu_extras(extra, torch, np, dev, be, smd, synth_sketches, synth_gath
             torch.cuda.synchronize()
             auto_ms = (time.perf_counter() - t0) * 1e3
         extra["compare_1000x1000_auto"] = {"ms": round(auto_ms, 3), "pairs_per_s": round(pairs / (auto_ms * 1e-3), 1),
+                                           "roofline": dict(bitmatrix_roofline(n, idx.universe, auto_ms, counters=False),
+                                                            note="BASELINE config 3 end to end: the WHOLE one-shot call (cost model + index build + "
+                                                                 "matrix + Jaccard, host wall clock) priced against the matrix kernel's VALU floor -- "
+                                                                 "at this size launches and the index build, not the matrix, are most of the time"),
                                            "identical_to_merge": bool((ca == common).all().item() and (ja == jac).all().item()),
                                            "note": "one-shot: cost model + index build + matrix + Jaccard, data resident in HBM"}
     del idx
