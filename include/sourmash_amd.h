@@ -321,9 +321,22 @@ void smgpu_host_pow_f64(const double *x, const double *y, uintptr_t ny, double *
  * invalid: src/core/src/encodings.rs:370-377 after the upper-casing of src/core/src/signature.rs:214), or UINTPTR_MAX
  * when there is none.  No device involved; exported so that the CPU test suite can pin the vectorised scan. */
 uintptr_t smgpu_first_invalid_dna_byte(const char *seq, uintptr_t len);
-/* Host convenience: n sketch handles -> n x n matrices on the host (either may be NULL). */
+/* n sketch handles -> n x n matrices on the host (either may be NULL): what src/sourmash/compare.py:326-358 walks pair by pair
+ * through kmerminhash_similarity / kmerminhash_count_common (src/core/src/ffi/minhash.rs:409-457).  The sketches are packed into
+ * pinned chunks by worker threads and travel as one H2D copy per chunk; the matrices come back through the same ring. */
 void smgpu_compare_all_pairs(const SourmashKmerMinHash *const *mhs, uintptr_t n, uint32_t *common_out,
                              double *jaccard_out);
+/* The same for a list with SEVERAL scaled values and downsample = true (compare.py:14-64; src/core/src/sketch/minhash.rs:682-702):
+ * common_out[i][j] = |A ∩ B| with both sketches downsampled to the pair's coarser scaled -- a prefix of the finer row
+ * (minhash.rs:777-798) -- and the row's own size on the diagonal.  class_of[i] = index of sketch i's scaled value in the ascending
+ * list of the list's distinct values, class_max_hash[c] = max_hash of value c; sizes_out [n_classes][n] receives the size of
+ * sketch i downsampled to value c (0 where c is finer than the sketch).  One upload, no downsampled host objects.  Errors: the
+ * ksize / molecule / seed mismatch of the first sketch that does not match sketch 0. */
+void smgpu_compare_all_pairs_mixed(const SourmashKmerMinHash *const *mhs, uintptr_t n, const uint32_t *class_of,
+                                   const uint64_t *class_max_hash, uintptr_t n_classes, uint32_t *common_out, uint64_t *sizes_out);
+/* Bytes and nanoseconds the host-pointer entry points spent moving large pageable buffers (csrc/hostxfer.hpp) since the last reset:
+ * out5 = {H2D bytes, D2H bytes, H2D ns, D2H ns, calls}.  Diagnostics for bench.py's API-level lines. */
+void smgpu_xfer_stats(uint64_t *out5, bool reset);
 /* All pairs of BOTTOM-K (num) sketches in one launch (csrc/compare_ext.hip) -- what src/sourmash/compare.py:36-54 asks
  * kmerminhash_similarity for pair by pair: common_out[i][j] = |A ∩ B ∩ merged|, union_out[i][j] = |merged| with merged = the
  * num smallest hashes of A ∪ B, num taken from the sketch with the lower index (src/core/src/sketch/minhash.rs:593-621: the

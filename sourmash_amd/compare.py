@@ -139,10 +139,65 @@ def _by_scaled(mhs, downsample, block):
     return out
 
 
-def _jaccard_block(flat, scaled):
-    if scaled == 0:                                    # bottom-k sketches
+def _mixed_common(flat):
+    """A list of flat scaled sketches with SEVERAL scaled values, every pair at its coarser scaled, in ONE call
+    (smgpu_compare_all_pairs_mixed): the sketches travel once as they are, downsampling is a prefix cut on the device
+    (minhash.rs:777-798), no downsampled host objects.  -> (common u32 [n][n], the distinct scaled values ascending,
+    sizes_at int64 [value][sketch] = len(sketch downsampled to that value), class_of = index of every sketch's own value)."""
+    from .minhash import _get_max_hash_for_scaled
+    n = len(flat)
+    scaleds = sorted({mh.scaled for mh in flat})
+    where = {s: c for c, s in enumerate(scaleds)}
+    class_of = np.array([where[mh.scaled] for mh in flat], dtype=np.uint32)
+    max_hashes = np.array([_get_max_hash_for_scaled(s) for s in scaleds], dtype=np.uint64)
+    common = np.empty((n, n), dtype=np.uint32)
+    sizes = np.zeros((len(scaleds), n), dtype=np.uint64)
+    ptrs = (C.c_void_p * n)(*[mh._get_objptr() for mh in flat])
+    rustcall(lib.smgpu_compare_all_pairs_mixed, ptrs, n, class_of.ctypes.data_as(C.c_void_p), max_hashes.ctypes.data_as(C.c_void_p),
+             len(scaleds), common.ctypes.data_as(C.c_void_p), sizes.ctypes.data_as(C.c_void_p))
+    return common, scaleds, sizes.astype(np.int64), class_of.astype(np.int64)
+
+
+def _by_scaled_counts(flat, block):
+    """_by_scaled for quantities that are arithmetic on counts and sizes: block(common u32 [m][m], sizes int64 [m], scaled)
+    -> f64 [m][m] is called once per scaled value of the list with the sketches that are as fine or finer, their sizes AT
+    that value, and the counts of the pairs whose coarser scaled it is (0 elsewhere); the entries of those pairs are kept."""
+    n = len(flat)
+    if len({mh.scaled for mh in flat}) == 1:
+        return block(common_matrix(flat, want_jaccard=False)[0], np.array([len(mh) for mh in flat], dtype=np.int64), flat[0].scaled)
+    common, scaleds, sizes_at, class_of = _mixed_common(flat)
+    out = np.ones((n, n), dtype=np.float64)
+    for c, s in enumerate(scaleds):
+        idx = np.flatnonzero(class_of <= c)
+        if len(idx) < 2 or not (class_of[idx] == c).any():
+            continue
+        here = np.maximum(class_of[idx][:, None], class_of[idx][None, :]) == c
+        m = block(np.where(here, common[np.ix_(idx, idx)], 0).astype(np.uint32), sizes_at[c][idx], int(s))
+        view = out[np.ix_(idx, idx)]
+        view[here] = m[here]
+        out[np.ix_(idx, idx)] = view
+    out[np.arange(n), np.arange(n)] = 1.0
+    return out
+
+
+def _jaccard_from_counts(common, sizes):
+    "common / max(1, n_i + n_j - common): ONE IEEE divide per entry like csrc/compare.hip: jaccard_from_counts_kernel (minhash.rs:624-631)"
+    cm = common.astype(np.int64)
+    uni = sizes[:, None] + sizes[None, :] - cm
+    jac = cm.astype(np.float64) / np.maximum(uni, 1).astype(np.float64)
+    jac[np.arange(len(sizes)), np.arange(len(sizes))] = 1.0
+    return jac
+
+
+def _jaccard_matrix(flat, downsample):
+    "Jaccard of every pair of flat sketches: bottom-k -> one launch; one scaled value -> one launch incl. the f64 matrix; several -> counts"
+    scaleds = {mh.scaled for mh in flat}
+    if scaleds == {0}:
         return num_matrix(flat)
-    return common_matrix(flat, want_jaccard=True)[1]
+    if len(scaleds) == 1:
+        return common_matrix(flat, want_jaccard=True)[1]
+    assert downsample
+    return _by_scaled_counts(flat, lambda cm, sz, s: _jaccard_from_counts(cm, sz))
 
 
 def _raise_like_the_loop(siglist, call):
@@ -184,13 +239,13 @@ def jaccard_ani_values(jaccard, ksize, n_unique_kmers, err_threshold=1e-4):
     return (1 - dist).reshape(shape), withheld.reshape(shape)
 
 
-def _jaccard_ani_block(flat, scaled):
-    "jaccard_ani of every pair of flat scaled sketches of ONE scaled value (minhash.py:749-785) -> f64 matrix, 0.0 = withheld"
-    n = len(flat)
-    jac = common_matrix(flat, want_jaccard=True)[1]
-    sizes = np.array([len(mh) for mh in flat], dtype=np.float64)
+def _jaccard_ani_block(common, sizes, scaled, ksize):
+    "jaccard_ani of every pair of sketches of ONE scaled value from their counts and sizes (minhash.py:749-785) -> f64 matrix, 0.0 = withheld"
+    n = len(sizes)
+    jac = _jaccard_from_counts(common, sizes)
+    sizes = sizes.astype(np.float64)
     n_kmers = np.rint((sizes[:, None] + sizes[None, :]) / 2 * scaled)       # round(avg_sketch_kmers * scaled): half to even, both
-    ani, withheld = jaccard_ani_values(jac, flat[0].ksize, n_kmers)
+    ani, withheld = jaccard_ani_values(jac, ksize, n_kmers)
     out = np.where(withheld, 0.0, ani)
     out[np.arange(n), np.arange(n)] = 1.0
     return out
@@ -209,7 +264,8 @@ def compare_serial(siglist, ignore_abundance, *, downsample=False, return_ani=Fa
     if return_ani:
         if not all(mh.scaled for mh in mhs) or not _batchable(mhs, downsample):
             _raise_like_the_loop(siglist, lambda a, b: a.jaccard_ani(b, downsample=downsample))
-        out = _by_scaled([mh.flatten() for mh in mhs], downsample, _jaccard_ani_block)
+        ksize = mhs[0].ksize
+        out = _by_scaled_counts([mh.flatten() for mh in mhs], lambda cm, sz, s: _jaccard_ani_block(cm, sz, s, ksize))
         trusted = np.array([mh.size_is_accurate() for mh in mhs], dtype=bool)   # of the sketches as given (minhash.py:783)
         out = np.where(trusted[:, None] & trusted[None, :], out, 0.0)
         out[np.arange(n), np.arange(n)] = 1.0
@@ -219,7 +275,7 @@ def compare_serial(siglist, ignore_abundance, *, downsample=False, return_ani=Fa
     weighted = [] if ignore_abundance else [i for i, mh in enumerate(mhs) if mh.track_abundance]
     if len(weighted) == n:
         return _by_scaled(mhs, downsample, lambda sub, s: angular_matrix(sub))
-    sims = _by_scaled([mh.flatten() for mh in mhs], downsample, _jaccard_block)
+    sims = _jaccard_matrix([mh.flatten() for mh in mhs], downsample)
     if len(weighted) > 1:                                         # minhash.rs:697-701 decides per pair: both track abundance
         w = np.array(weighted)
         sims[np.ix_(w, w)] = _by_scaled([mhs[i] for i in weighted], downsample, lambda sub, s: angular_matrix(sub))
@@ -266,12 +322,10 @@ def _ani_from_containment(cont, ksize):
     return 1 - point
 
 
-def _containment_block(flat, scaled, mode, return_ani):
-    "containment / max / avg containment (or their ANI point estimates, no trust masking) of flat sketches of ONE scaled value"
-    n = len(flat)
-    common, _ = common_matrix(flat, want_jaccard=False)
-    sizes = [len(mh) for mh in flat]
-    ksize = flat[0].ksize
+def _containment_block(common, sizes, scaled, ksize, mode, return_ani):
+    "containment / max / avg containment (or their ANI point estimates, no trust masking) of sketches of ONE scaled value from their counts"
+    n = len(sizes)
+    sizes = [int(v) for v in sizes]
     if not return_ani:
         return _debias_matrix(common, sizes, scaled, mode)
     # ANI (compare.py:67-187): the containment of every entry -> point estimate
@@ -285,6 +339,12 @@ def _containment_block(flat, scaled, mode, return_ani):
     return _ani_from_containment(_debias_matrix(common, sizes, scaled, mode), ksize).reshape(n, n)
 
 
+def _sizes_trusted(sizes, scaled, relative_error=0.20, confidence=0.95):
+    "size_is_accurate() of sketches known by their sizes at `scaled` (minhash.py:1099-1120: set_size_exact_prob of len * scaled)"
+    from .distance_utils import set_size_exact_prob
+    return [set_size_exact_prob(int(n) * scaled, scaled, relative_error=relative_error) >= confidence for n in sizes]
+
+
 def _containment_mixed(flat, mode):
     """containment / max / avg containment of a list with SEVERAL scaled values, downsample = True, in the reference's
     (asymmetric) arithmetic: the count of a pair is taken at the pair's coarser scaled (count_common downsamples the finer
@@ -293,7 +353,7 @@ def _containment_mixed(flat, mode):
     the sketch with the higher index of the pair (compare.py:111-150).  One launch per scaled value for the counts, then
     whole-array arithmetic; the bias factors are one libm pow per (sketch, scaled value)."""
     n = len(flat)
-    cm = _by_scaled(flat, True, lambda sub, s: common_matrix(sub, want_jaccard=False)[0].astype(np.float64))
+    cm = _mixed_common(flat)[0].astype(np.float64)                # every pair at its coarser scaled, one call
     sz = np.array([len(mh) for mh in flat], dtype=np.float64)
     sc = [mh.scaled for mh in flat]
     own_bias = np.array([_bias_factors([len(mh)], mh.scaled)[0] for mh in flat], dtype=np.float64)
@@ -327,9 +387,10 @@ def _containment(siglist, downsample, mode, return_ani):
     if not _batchable(mhs, downsample):
         return _containment_pairs(siglist, downsample, mode, return_ani)      # some pair raises: from the same pair as the reference's loop
     flat = [mh.flatten() for mh in mhs]
+    ksize = flat[0].ksize
     if not return_ani:
         if len({mh.scaled for mh in flat}) == 1:
-            return _containment_block(flat, flat[0].scaled, mode, False)
+            return _by_scaled_counts(flat, lambda cm, sz, s: _containment_block(cm, sz, s, ksize, mode, False))
         return _containment_mixed(flat, mode)
     # ANI: both sketches are downsampled to the pair's coarser scaled first, then everything is computed there
     # (minhash.py:843-879,907-944): the blocks of _by_scaled are exactly that.  An estimate is withheld (0 in the matrix) when
@@ -338,13 +399,14 @@ def _containment(siglist, downsample, mode, return_ani):
     # (minhash.py:877-878,938-939); avg goes through FracMinHashComparison (compare.py:166-168), whose mh1_cmp / mh2_cmp are the
     # sketches already downsampled to the pair's scaled (sketchcomparison.py:53-70,143-170) -- a sketch trusted at its own
     # scaled but not after downsampling gives 0.0 there.
-    def trust_mask(m, sketches):
-        ok = np.array([mh.size_is_accurate() for mh in sketches], dtype=bool)
+    def trust_mask(m, ok):
+        ok = np.asarray(ok, dtype=bool)
         return np.where(ok[:, None] & ok[None, :], m, 0.0)
     if mode == "avg":
-        out = _by_scaled(flat, downsample, lambda sub, s: trust_mask(_containment_block(sub, s, mode, True), sub))
+        out = _by_scaled_counts(flat, lambda cm, sz, s: trust_mask(_containment_block(cm, sz, s, ksize, mode, True), _sizes_trusted(sz, s)))
     else:
-        out = trust_mask(_by_scaled(flat, downsample, lambda sub, s: _containment_block(sub, s, mode, True)), mhs)
+        out = trust_mask(_by_scaled_counts(flat, lambda cm, sz, s: _containment_block(cm, sz, s, ksize, mode, True)),
+                         [mh.size_is_accurate() for mh in mhs])
     out[np.arange(n), np.arange(n)] = 1.0
     return out
 

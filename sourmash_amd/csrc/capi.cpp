@@ -21,6 +21,7 @@
 #include <sys/stat.h>
 #include <unistd.h>
 #include "device_ctx.hpp"
+#include "hostxfer.hpp"
 #include "pargz.hpp"
 #include "ingest.hpp"
 #include "murmur3.hpp"
@@ -1041,26 +1042,46 @@ void smgpu_bitindex_compare_upper_raw(const SmgpuBitIndex* p, uint32_t rb_first,
     });
 }
 
-// n x n counts (+ Jaccard) of a device-resident CSR into host matrices; dense collections take the bit-row path
-static void compare_device_csr(const uint64_t* d_hashes, const uint64_t* d_offsets, uint64_t n, uint64_t total,
-                               uint32_t* common_out, double* jaccard_out, hipStream_t st) {
-    // result matrices from the stream-ordered pool (kept between calls): hipMalloc / hipFree of a gigabyte per call cost
-    // more than the comparison on hosts with a slow driver path
-    AsyncBuf dc((size_t)((n + 15) / 16 * 16) * n * 4, st);
+// n x n counts of a device-resident CSR into dc (device; ceil(n / 16) * 16 rows): dense collections take the bit-row path
+static void compare_counts_device(const uint64_t* d_hashes, const uint64_t* d_offsets, uint64_t n, uint64_t total, AsyncBuf& dc,
+                                  hipStream_t st) {
+    // result matrices from the arena (kept between calls): hipMalloc / hipFree of a gigabyte per call cost more than the
+    // comparison on hosts with a slow driver path
+    dc.reset((size_t)((n + 15) / 16 * 16) * n * 4, st);
     std::unique_ptr<BitIndex> bi(bitindex_build(d_hashes, d_offsets, (uint32_t)n, st, 0, true, total));
     if (bi) { // bit rows for the frequent hashes + inverted lists for the rare ones: the triangle, then its mirror image
         bitindex_compare(bi.get(), 0, 1, (uint32_t)((n + 15) / 16), dc.as<uint32_t>(), st, true);
         hip_check(symmetrize_launch(dc.as<uint32_t>(), (uint32_t)n, st), "symmetrize");
     } else    // LDS-tiled merge walk
         hip_check(compare_counts_launch(d_hashes, d_offsets, (uint32_t)n, 0, (uint32_t)n, dc.as<uint32_t>(), st), "compare");
+}
+
+// ... (+ Jaccard) into host matrices.  The matrices leave through the pinned ring (hostxfer.hpp): the f64 matrix of config C4
+// is 800 MB, and a pageable hipMemcpy of that size was most of the call.
+static void compare_device_csr(const uint64_t* d_hashes, const uint64_t* d_offsets, uint64_t n, uint64_t total,
+                               uint32_t* common_out, double* jaccard_out, hipStream_t st) {
+    AsyncBuf dc;
+    compare_counts_device(d_hashes, d_offsets, n, total, dc, st);
     std::unique_ptr<AsyncBuf> dj;
     if (jaccard_out) {
         dj.reset(new AsyncBuf((size_t)n * n * 8, st));
         hip_check(jaccard_from_counts_launch(dc.as<uint32_t>(), d_offsets, (uint32_t)n, 0, (uint32_t)n, dj->as<double>(), st), "jaccard");
-        hip_check(hipMemcpyAsync(jaccard_out, dj->p, (size_t)n * n * 8, hipMemcpyDeviceToHost, st), "D2H");
     }
-    if (common_out) hip_check(hipMemcpyAsync(common_out, dc.p, (size_t)n * n * 4, hipMemcpyDeviceToHost, st), "D2H");
+    if (common_out) HostXfer::get().device_to_host(common_out, dc.p, (size_t)n * n * 4, st);     // (travels while the Jaccard kernel runs)
+    if (jaccard_out) HostXfer::get().device_to_host(jaccard_out, dj->p, (size_t)n * n * 8, st);
     hip_check(hipStreamSynchronize(st), "sync");
+}
+
+// the hash vectors (or abundance vectors) of n sketches back to back into d_dst: worker threads pack pinned chunks, ONE H2D copy
+// per 32 MiB chunk (round 4: one pageable copy per sketch)
+static void upload_rows(const SourmashKmerMinHash* const* mhs, uintptr_t n, const std::vector<uint64_t>& offsets, bool abunds,
+                        void* d_dst, hipStream_t st) {
+    std::vector<HostPiece> pieces(n);
+    for (uintptr_t i = 0; i < n; ++i) {
+        const KmerMinHash* m = MH(mhs[i]);
+        pieces[i] = HostPiece{abunds ? (const void*)m->abunds.data() : (const void*)m->mins.data(), (size_t)offsets[i] * 8, m->size() * 8};
+    }
+    HostXfer::get().gather_to_device(d_dst, pieces, (size_t)offsets[n] * 8, st);
 }
 
 void smgpu_compare_all_pairs(const SourmashKmerMinHash* const* mhs, uintptr_t n, uint32_t* common_out, double* jaccard_out) {
@@ -1077,13 +1098,85 @@ void smgpu_compare_all_pairs(const SourmashKmerMinHash* const* mhs, uintptr_t n,
         std::lock_guard<std::recursive_mutex> g(ctx.mutex());
         hipStream_t st = ctx.stream();
         AsyncBuf dh(total * 8 + 16, st), doff((n + 1) * 8, st);
-        for (uintptr_t i = 0; i < n; ++i)
-            if (MH(mhs[i])->size())
-                hip_check(hipMemcpyAsync(dh.as<uint64_t>() + offsets[i], MH(mhs[i])->mins.data(), MH(mhs[i])->size() * 8,
-                                         hipMemcpyHostToDevice, st), "H2D");
+        upload_rows(mhs, n, offsets, false, dh.p, st);
         hip_check(hipMemcpyAsync(doff.p, offsets.data(), (n + 1) * 8, hipMemcpyHostToDevice, st), "H2D");
         compare_device_csr(dh.as<uint64_t>(), doff.as<uint64_t>(), n, total, common_out, jaccard_out, st);
     });
+}
+
+// A list with SEVERAL scaled values, downsample = True: common_out[i][j] = |A ∩ B| with both sketches downsampled to the pair's
+// coarser scaled (compare.py:14-64 -> minhash.rs:682-702, 777-798), the diagonal = the row's size as given.  class_of[i]: index of
+// sketch i's own scaled value in the ascending list of distinct values; class_max_hash[c]: max_hash of value c.  sizes_out
+// [n_classes][n]: the size of sketch i downsampled to value c (0 where c is finer than the sketch).  One upload of the
+// sketches as given, the prefixes of every class gathered on the device; the host builds no downsampled sketch objects.
+void smgpu_compare_all_pairs_mixed(const SourmashKmerMinHash* const* mhs, uintptr_t n, const uint32_t* class_of,
+                                   const uint64_t* class_max_hash, uintptr_t n_classes, uint32_t* common_out, uint64_t* sizes_out) {
+    landing_void([&] {
+        if (n == 0 || n_classes == 0) return;
+        if (n > 0xffffffffu) throw err_internal("too many sketches");
+        if (!class_of || !class_max_hash || !common_out || !sizes_out) throw err_internal("null pointer");
+        for (uintptr_t i = 1; i < n; ++i) {                          // as check_compatible with downsample = true: everything but the threshold
+            const KmerMinHash *a = MH(mhs[0]), *b = MH(mhs[i]);
+            if (a->ksize != b->ksize) throw Error(E_MISMATCH_KSIZES, "different ksizes cannot be compared");
+            if (a->hash_function != b->hash_function) throw Error(E_MISMATCH_DNA_PROT, "DNA/prot minhashes cannot be compared");
+            if (a->seed != b->seed) throw Error(E_MISMATCH_SEED, "mismatch in seed; comparison fail");
+        }
+        for (uintptr_t i = 0; i < n; ++i) {
+            if (MH(mhs[i])->num != 0 || MH(mhs[i])->max_hash == 0) throw err_internal("smgpu_compare_all_pairs_mixed takes scaled sketches");
+            if (class_of[i] >= n_classes) throw err_internal("class index out of range");
+        }
+        std::vector<uint64_t> offsets(n + 1, 0);
+        for (uintptr_t i = 0; i < n; ++i) offsets[i + 1] = offsets[i] + MH(mhs[i])->size();
+        const uint64_t total = offsets[n];
+        // prefix lengths: hashes <= max_hash of every class at least as coarse as the sketch's own (minhash.rs:777-798)
+        for (uintptr_t c = 0; c < n_classes; ++c)
+            for (uintptr_t i = 0; i < n; ++i) {
+                const KmerMinHash* m = MH(mhs[i]);
+                uint64_t len = 0;
+                if (class_of[i] == c) len = m->size();
+                else if (class_of[i] < c) len = (uint64_t)(std::upper_bound(m->mins.begin(), m->mins.end(), class_max_hash[c]) - m->mins.begin());
+                sizes_out[c * n + i] = len;
+            }
+        DeviceCtx& ctx = DeviceCtx::get();
+        std::lock_guard<std::recursive_mutex> g(ctx.mutex());
+        hipStream_t st = ctx.stream();
+        AsyncBuf dh(total * 8 + 16, st), dcls(n * 4 + 16, st), dout((size_t)n * n * 4 + 16, st);
+        upload_rows(mhs, n, offsets, false, dh.p, st);
+        hip_check(hipMemcpyAsync(dcls.p, class_of, n * 4, hipMemcpyHostToDevice, st), "H2D");
+        hip_check(hipMemsetAsync(dout.p, 0, (size_t)n * n * 4, st), "memset");
+        std::vector<uint64_t> src, noff;
+        std::vector<uint32_t> rows;
+        for (uintptr_t c = 0; c < n_classes; ++c) {
+            rows.clear(); src.clear(); noff.assign(1, 0);
+            bool any_own = false;
+            for (uintptr_t i = 0; i < n; ++i)
+                if (class_of[i] <= c) {
+                    rows.push_back((uint32_t)i);
+                    src.push_back(offsets[i]);
+                    noff.push_back(noff.back() + sizes_out[c * n + i]);
+                    any_own = any_own || class_of[i] == c;
+                }
+            const uint32_t m = (uint32_t)rows.size();
+            if (!any_own || m == 0) continue;
+            AsyncBuf dsrc(m * 8 + 16, st), dnoff((m + 1) * 8 + 16, st), drows(m * 4 + 16, st), dsub_h(noff.back() * 8 + 16, st), dsub;
+            hip_check(hipMemcpyAsync(dsrc.p, src.data(), m * 8, hipMemcpyHostToDevice, st), "H2D");
+            hip_check(hipMemcpyAsync(dnoff.p, noff.data(), (m + 1) * 8, hipMemcpyHostToDevice, st), "H2D");
+            hip_check(hipMemcpyAsync(drows.p, rows.data(), m * 4, hipMemcpyHostToDevice, st), "H2D");
+            hip_check(csr_prefix_gather_launch(dh.as<uint64_t>(), dsrc.as<uint64_t>(), dnoff.as<uint64_t>(), m, dsub_h.as<uint64_t>(), st), "gather rows");
+            compare_counts_device(dsub_h.as<uint64_t>(), dnoff.as<uint64_t>(), m, noff.back(), dsub, st);
+            hip_check(class_scatter_launch(dsub.as<uint32_t>(), m, drows.as<uint32_t>(), dcls.as<uint32_t>(), (uint32_t)c, (uint32_t)n,
+                                           dout.as<uint32_t>(), st), "scatter class");
+            hip_check(hipStreamSynchronize(st), "sync");             // (the host vectors above are reused by the next class)
+        }
+        HostXfer::get().device_to_host(common_out, dout.p, (size_t)n * n * 4, st);
+        hip_check(hipStreamSynchronize(st), "sync");
+    });
+}
+
+void smgpu_xfer_stats(uint64_t* out5, bool reset) {
+    const HostXfer::Stats x = HostXfer::get().stats();
+    if (out5) { out5[0] = x.h2d_bytes; out5[1] = x.d2h_bytes; out5[2] = x.h2d_ns; out5[3] = x.d2h_ns; out5[4] = x.calls; }
+    if (reset) HostXfer::get().reset_stats();
 }
 
 // ---- all pairs of bottom-k / abundance-tracking sketches (compare_ext.hip) ------------------------------------------
@@ -1098,14 +1191,11 @@ static void pack_collection(const SourmashKmerMinHash* const* mhs, uintptr_t n, 
     doff.reset((n + 1) * 8, st);
     if (with_abund) da.reset(total * 8 + 16, st);
     bool small = true;
-    for (uintptr_t i = 0; i < n; ++i) {
-        const KmerMinHash* m = MH(mhs[i]);
-        if (!m->size()) continue;
-        hip_check(hipMemcpyAsync(dh.as<uint64_t>() + offsets[i], m->mins.data(), m->size() * 8, hipMemcpyHostToDevice, st), "H2D");
-        if (with_abund) {
-            hip_check(hipMemcpyAsync(da.as<uint64_t>() + offsets[i], m->abunds.data(), m->size() * 8, hipMemcpyHostToDevice, st), "H2D");
-            for (uint64_t a : m->abunds) small = small && a <= 0xffffffffull;
-        }
+    upload_rows(mhs, n, offsets, false, dh.p, st);
+    if (with_abund) {
+        upload_rows(mhs, n, offsets, true, da.p, st);
+        for (uintptr_t i = 0; i < n && small; ++i)
+            for (uint64_t a : MH(mhs[i])->abunds) small = small && a <= 0xffffffffull;
     }
     hip_check(hipMemcpyAsync(doff.p, offsets.data(), (n + 1) * 8, hipMemcpyHostToDevice, st), "H2D");
     if (narrow) *narrow = small;
@@ -1133,9 +1223,9 @@ void smgpu_compare_num_all_pairs(const SourmashKmerMinHash* const* mhs, uintptr_
         hip_check(hipMemsetAsync(dc.p, 0, (size_t)n * n * 4, st), "memset");
         hip_check(compare_num_launch(dh.as<uint64_t>(), doff.as<uint64_t>(), dn.as<uint32_t>(), (uint32_t)n, dc.as<uint32_t>(),
                                      du.as<uint32_t>(), dj.as<double>(), st), "compare (num)");
-        if (common_out) hip_check(hipMemcpyAsync(common_out, dc.p, (size_t)n * n * 4, hipMemcpyDeviceToHost, st), "D2H");
-        if (union_out) hip_check(hipMemcpyAsync(union_out, du.p, (size_t)n * n * 4, hipMemcpyDeviceToHost, st), "D2H");
-        if (jaccard_out) hip_check(hipMemcpyAsync(jaccard_out, dj.p, (size_t)n * n * 8, hipMemcpyDeviceToHost, st), "D2H");
+        if (common_out) HostXfer::get().device_to_host(common_out, dc.p, (size_t)n * n * 4, st);
+        if (union_out) HostXfer::get().device_to_host(union_out, du.p, (size_t)n * n * 4, st);
+        if (jaccard_out) HostXfer::get().device_to_host(jaccard_out, dj.p, (size_t)n * n * 8, st);
         hip_check(hipStreamSynchronize(st), "sync");
     });
 }
@@ -1196,7 +1286,7 @@ void smgpu_compare_angular_all_pairs(const SourmashKmerMinHash* const* mhs, uint
             hip_check(hipMemsetAsync(dp.p, 0, (size_t)n * n * 8, st), "memset");
             hip_check(compare_abund_launch(dh.as<uint64_t>(), da.as<uint64_t>(), doff.as<uint64_t>(), (uint32_t)n, narrow,
                                            dc.as<uint32_t>(), dp.as<unsigned long long>(), ds.as<unsigned long long>(), st), "compare (abundance)");
-            hip_check(hipMemcpyAsync(prod.data(), dp.p, (size_t)n * n * 8, hipMemcpyDeviceToHost, st), "D2H");
+            HostXfer::get().device_to_host(prod.data(), dp.p, (size_t)n * n * 8, st);
             hip_check(hipMemcpyAsync(sq.data(), ds.p, n * 8, hipMemcpyDeviceToHost, st), "D2H");
             hip_check(hipStreamSynchronize(st), "sync");
         }
@@ -1359,11 +1449,7 @@ SmgpuSketchSet* smgpu_sketchset_new(const SourmashKmerMinHash* const* mhs, uintp
         hipStream_t st = ctx.stream();
         s->hashes.reserve(s->total * 8 + 16, st);
         s->offsets.reserve((n + 1) * 8, st);
-        // stage through one host vector: one large H2D copy instead of n small ones
-        std::vector<uint64_t> flat(s->total);
-        for (uintptr_t i = 0; i < n; ++i)
-            if (MH(mhs[i])->size()) memcpy(flat.data() + off[i], MH(mhs[i])->mins.data(), MH(mhs[i])->size() * 8);
-        if (s->total) hip_check(hipMemcpyAsync(s->hashes.p, flat.data(), s->total * 8, hipMemcpyHostToDevice, st), "H2D");
+        upload_rows(mhs, n, off, false, s->hashes.p, st);               // pinned chunks packed by worker threads, one H2D copy each
         hip_check(hipMemcpyAsync(s->offsets.p, off.data(), (n + 1) * 8, hipMemcpyHostToDevice, st), "H2D");
         hip_check(hipStreamSynchronize(st), "sync");
         return reinterpret_cast<SmgpuSketchSet*>(s.release());

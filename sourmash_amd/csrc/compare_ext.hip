@@ -306,4 +306,44 @@ hipError_t compare_abund_launch(const uint64_t* d_hashes, const uint64_t* d_abun
     return hipGetLastError();
 }
 
+// ---- lists with several scaled values: every pair at ITS coarser scaled (minhash.rs:688-696, 777-798) --------------------------
+// Downsampling a FracMinHash sketch to a coarser scaled keeps the hashes <= max_hash(scaled): a PREFIX of the sorted row.  The
+// host works out, per scaled value of the list, how long that prefix is in every row that is as fine or finer (binary
+// searches in the host copies), the rows' prefixes are gathered into a CSR of their own on the device (no host sketch objects,
+// no second upload), the ordinary compare runs on it, and the entries of the pairs whose coarser scaled is this value go
+// to their places in the one n x n matrix.
+__global__ __launch_bounds__(256) void csr_prefix_gather_kernel(const uint64_t* __restrict__ hashes, const uint64_t* __restrict__ src_start,
+                                                                const uint64_t* __restrict__ new_off, uint32_t m, uint64_t* __restrict__ out) {
+    const uint32_t r = blockIdx.x;
+    if (r >= m) return;
+    const uint64_t s = src_start[r], d = new_off[r], len = new_off[r + 1] - d;
+    for (uint64_t i = threadIdx.x; i < len; i += 256) out[d + i] = hashes[s + i];
+}
+
+__global__ __launch_bounds__(256) void class_scatter_kernel(const uint32_t* __restrict__ sub, uint32_t m, const uint32_t* __restrict__ rows,
+                                                            const uint32_t* __restrict__ class_of, uint32_t cls, uint32_t n,
+                                                            uint32_t* __restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (uint64_t)m * m) return;
+    const uint32_t a = (uint32_t)(i / m), b = (uint32_t)(i % m);
+    const uint32_t ra = rows[a], rb = rows[b];
+    const uint32_t ca = class_of[ra], cb = class_of[rb];
+    if ((ca > cb ? ca : cb) == cls) out[(uint64_t)ra * n + rb] = sub[i];
+}
+
+hipError_t csr_prefix_gather_launch(const uint64_t* d_hashes, const uint64_t* d_src_start, const uint64_t* d_new_off, uint32_t m,
+                                    uint64_t* d_out, hipStream_t stream) {
+    if (m == 0) return hipSuccess;
+    hipLaunchKernelGGL(csr_prefix_gather_kernel, dim3(m), dim3(256), 0, stream, d_hashes, d_src_start, d_new_off, m, d_out);
+    return hipGetLastError();
+}
+
+hipError_t class_scatter_launch(const uint32_t* d_sub, uint32_t m, const uint32_t* d_rows, const uint32_t* d_class_of, uint32_t cls,
+                                uint32_t n, uint32_t* d_out, hipStream_t stream) {
+    if (m == 0) return hipSuccess;
+    hipLaunchKernelGGL(class_scatter_kernel, dim3((unsigned)(((uint64_t)m * m + 255) / 256)), dim3(256), 0, stream, d_sub, m, d_rows,
+                       d_class_of, cls, n, d_out);
+    return hipGetLastError();
+}
+
 }  // namespace smg

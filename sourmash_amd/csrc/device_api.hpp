@@ -71,6 +71,14 @@ hipError_t compare_abund_launch(const uint64_t* d_hashes, const uint64_t* d_abun
                                 bool narrow, uint32_t* d_common, unsigned long long* d_prod, unsigned long long* d_sumsq,
                                 hipStream_t stream);
 
+// Lists with several scaled values: gather the first new_off[r + 1] - new_off[r] hashes of the rows starting at src_start[r] into
+// a CSR of their own; then move the entries sub[a][b] of an m x m matrix over rows[] whose pair class max(class_of[rows[a]],
+// class_of[rows[b]]) equals `cls` to out[rows[a]][rows[b]] of the n x n matrix.
+hipError_t csr_prefix_gather_launch(const uint64_t* d_hashes, const uint64_t* d_src_start, const uint64_t* d_new_off, uint32_t m,
+                                    uint64_t* d_out, hipStream_t stream);
+hipError_t class_scatter_launch(const uint32_t* d_sub, uint32_t m, const uint32_t* d_rows, const uint32_t* d_class_of, uint32_t cls,
+                                uint32_t n, uint32_t* d_out, hipStream_t stream);
+
 // ---- bitindex.hip (dense compare path) ---------------------------------------------------------
 hipError_t bitmap_build_launch(const uint64_t* d_hashes, const uint64_t* d_offsets, uint32_t n, const uint64_t* d_dict,
                                uint64_t U, uint32_t* d_bits, uint32_t words_per_row, hipStream_t stream);
