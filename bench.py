@@ -275,6 +275,19 @@ def main():
         except Exception as e:
             extra["error"] = repr(e)
 
+    # ---- the reference-shaped entry points (lists of signature objects in, numpy matrices / result lists out) and the protein
+    #      sketch kernels, N = 1 ----
+    if rank == 0 and world == 1 and not args.no_compare:
+        try:
+            api_extras(extra, torch, np, dev, smd, synth_sketches, synth_gather_device)
+        except Exception as e:
+            extra["api_error"] = repr(e)
+        try:
+            protein_extras(extra, torch, np, dev, smd, args)
+        except Exception as e:
+            extra["protein_error"] = repr(e)
+        torch.cuda.empty_cache()
+
     # ---- the steps either side of the kernels, on this box (N = 1): file ingest and bulk signature loading ----
     if rank == 0 and world == 1 and not args.no_compare and not args.no_io:
         try:
@@ -891,6 +904,161 @@ def compare_ext_extras(extra, torch, np, dev, be, smd, synth_sketches, timed):
                                         "kernel": "compare_ext_kernel<abund32>: the same tiles accumulating abundance products (minhash.rs:635-680), "
                                                   "tiles with a long sketch cut into hash-range slices; parity: "
                                                   "tests/test_gpu_compare.py::test_angular_all_pairs_batched_vs_oracle"}
+
+
+PCIE_GBS = 57.0            # H2D rate measured on this class of box (tests/probe_host.py); the bound of every host-pointer entry point
+
+
+def _xfer(lib, reset=False):
+    import ctypes as C
+    out = (C.c_uint64 * 5)()
+    lib.smgpu_xfer_stats(out, reset)
+    return {"h2d_bytes": int(out[0]), "d2h_bytes": int(out[1]), "h2d_ms": round(out[2] / 1e6, 2), "d2h_ms": round(out[3] / 1e6, 2)}
+
+
+def api_extras(extra, torch, np, dev, smd, synth_sketches, synth_gather_device):
+    """The entry points the reference's callers use, wall clock: compare_all_pairs over a LIST OF SourmashSignature objects -> numpy
+    matrix (compare.py:326-358), and a gather over a collection built from sketch objects (SketchSet -> CounterGather's device
+    counter, index/__init__.py:783-909).  Beside each: the bytes that crossed PCIe and the time that alone costs at the measured
+    H2D rate, and the device-resident kernel time of the same work from the lines above -- the API wall clock should be about
+    kernel + transfer."""
+    import sourmash_amd as sm
+    from sourmash_amd._lowlevel import lib
+    from sourmash_amd.compare import compare_all_pairs
+    from sourmash_amd.index import SketchSet
+    for n, resident in ((1000, "compare_1000x1000_auto"), (10_000, "compare_10000x10000")):
+        sk = synth_sketches(n, seed=1234)
+        sigs = []
+        for i, a in enumerate(sk):
+            mh = sm.MinHash(0, 31, scaled=1000)
+            mh.add_many(a)
+            sigs.append(sm.SourmashSignature(mh, name="s%d" % i))
+        h, off = smd.pack_csr(sk, device=dev)
+        want = smd.compare_rows(h, off, method="auto")[1]
+        best, stats = None, None
+        for _ in range(3):
+            _xfer(lib, reset=True)
+            t0 = time.perf_counter()
+            m = compare_all_pairs(sigs, True)
+            dt = time.perf_counter() - t0
+            if best is None or dt < best:
+                best, stats = dt, _xfer(lib)
+        same = bool(np.array_equal(m.view(np.uint64), want.cpu().numpy().view(np.uint64)))
+        r = extra.get(resident, {})
+        kernel_ms = r.get("auto_ms", r.get("ms"))
+        moved = stats["h2d_bytes"] + stats["d2h_bytes"]
+        pcie_ms = moved / (PCIE_GBS * 1e9) * 1e3
+        pairs = n * (n - 1) // 2
+        extra["compare_api_%d" % n] = {
+            "what": "sourmash_amd.compare.compare_all_pairs(list of %d SourmashSignature objects, ignore_abundance=True) -> f64 numpy matrix, "
+                    "wall clock of the call (best of 3)" % n,
+            "ms": round(best * 1e3, 2), "pairs_per_s": round(pairs / best, 1), **stats,
+            "pcie_bound_ms": round(pcie_ms, 2), "resident_kernel_ms": kernel_ms,
+            "kernel_plus_transfer_ms": None if kernel_ms is None else round(kernel_ms + pcie_ms, 2),
+            "wall_over_kernel_plus_transfer": None if kernel_ms is None else round(best * 1e3 / (kernel_ms + pcie_ms), 3),
+            "bit_identical_to_the_resident_path": same}
+        del sigs, sk, m, want, h, off
+    # gather: 100,000 sketch objects -> collection in HBM -> every round of the min-set-cover
+    nq, ndb, dbsize, thr_bp = 1_000_000, 100_000, 5000, 50_000
+    q, gh, goff = synth_gather_device(nq, ndb, dbsize, dev)
+    hh, oo = gh.cpu().numpy().view(np.uint64), goff.cpu().numpy()
+    del gh, goff
+    torch.cuda.empty_cache()
+    t0 = time.perf_counter()
+    mhs = []
+    for d in range(ndb):
+        mh = sm.MinHash(0, 31, scaled=1000)
+        mh.add_many(hh[oo[d]:oo[d + 1]])
+        mhs.append(mh)
+    qmh = sm.MinHash(0, 31, scaled=1000)
+    qmh.add_many(q.cpu().numpy().view(np.uint64))
+    objects_s = time.perf_counter() - t0
+    db_bytes = int(hh.nbytes)
+    del hh
+    best = None
+    for _ in range(2):
+        _xfer(lib, reset=True)
+        t0 = time.perf_counter()
+        ss = SketchSet(mhs)
+        t1 = time.perf_counter()
+        res = ss.gather(qmh, threshold_bp=thr_bp)
+        t2 = time.perf_counter()
+        if best is None or t2 - t0 < best[0]:
+            best = (t2 - t0, t1 - t0, t2 - t1, _xfer(lib))
+        del ss
+    r = extra.get("gather_1M_vs_100000", {})
+    kernel_ms = None if "total_ms" not in r else r["total_ms"]
+    pcie_ms = db_bytes / (PCIE_GBS * 1e9) * 1e3
+    extra["gather_api_c5"] = {
+        "what": "SketchSet(list of 100,000 MinHash objects) -> .gather(query MinHash of 1e6 hashes, threshold_bp=50,000): wall clock of "
+                "packing + upload, then counter + index build + every round + the result list (best of 2); the objects themselves "
+                "took objects_s to create and are not timed",
+        "total_ms": round(best[0] * 1e3, 2), "pack_and_upload_ms": round(best[1] * 1e3, 2), "gather_ms": round(best[2] * 1e3, 2),
+        "rounds": len(res), **best[3], "db_bytes": db_bytes, "pcie_bound_ms": round(pcie_ms, 2), "resident_kernel_ms": kernel_ms,
+        "kernel_plus_transfer_ms": None if kernel_ms is None else round(kernel_ms + pcie_ms, 2),
+        "wall_over_kernel_plus_transfer": None if kernel_ms is None else round(best[0] * 1e3 / (kernel_ms + pcie_ms), 3),
+        "same_rounds_as_the_resident_path": None if "rounds" not in r else bool(r["rounds"] == len(res)), "objects_s": round(objects_s, 1)}
+
+
+def protein_extras(extra, torch, np, dev, smd, args):
+    """Protein / dayhoff / hp sketches (signature.rs:307-393, encodings.rs:103-368): the kernels on resident
+    input -- residues of a protein sequence, and DNA translated in six frames -- in residue windows hashed per second, with the
+    CPU restatement timed beside them on a bounded sample."""
+    import ctypes as C
+    import oracle
+    from sourmash_amd._lowlevel import lib
+    from sourmash_amd.utils import rustcall
+    from sourmash_amd.minhash import _get_max_hash_for_scaled
+    p = lambda t: C.c_void_p(t.data_ptr())
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    out = {}
+    n = 1_000_000_000
+    aas = torch.tensor(list(b"ACDEFGHIKLMNPQRSTVWY"), dtype=torch.uint8, device=dev)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(7)
+    prot = aas[torch.randint(0, 20, (n,), device=dev, generator=gen)]
+    dna = smd.synth_dna(n, seed=43, record_len=n + 1, device=dev)
+    aa = torch.empty(2 * n + 16, dtype=torch.uint8, device=dev)
+    mh200 = _get_max_hash_for_scaled(200)
+    cap = int(2 * n / 200 * 1.3) + 65536
+    hashes = torch.empty(cap, dtype=torch.int64, device=dev)
+    cnt = torch.zeros(2, dtype=torch.int64, device=dev)
+    for name, src, hf, k_aa, translate in (("protein_k10", prot, 2, 10, False), ("dayhoff_k16", prot, 3, 16, False), ("hp_k42", prot, 4, 42, False),
+                                           ("translate_protein_k10", dna, 2, 10, True)):
+        def run():
+            cnt.zero_()
+            return rustcall(lib.smgpu_sketch_residues_kernels_raw, p(src), n, k_aa, hf, 42, mh200, translate, p(aa), aa.numel(), p(hashes), cap, p(cnt), st)
+        n_aa = run()
+        torch.cuda.synchronize()
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(3)]
+        for a, b in evs:
+            a.record()
+            run()
+            b.record()
+        torch.cuda.synchronize()
+        ms = float(np.median([a.elapsed_time(b) for a, b in evs]))
+        kept = int(cnt[0].item())
+        # CPU restatement on a bounded sample of the same input, and parity of the kept hashes on it
+        sample = 2_000_000 if not translate else 1_000_000
+        host = bytes(src[:sample].cpu().numpy())
+        moltype = {2: "protein", 3: "dayhoff", 4: "hp"}[hf]
+        t0 = time.perf_counter()
+        ref = oracle.seq_to_hashes_protein(host, k_aa, moltype, is_protein=not translate)      # (the oracle's function calls itself twice: count, then fill)
+        cpu_s = (time.perf_counter() - t0) / 2
+        want = np.sort(ref[(ref >= 1) & (ref <= np.uint64(mh200))])
+        cnt.zero_()
+        rustcall(lib.smgpu_sketch_residues_kernels_raw, p(src), sample, k_aa, hf, 42, mh200, translate, p(aa), aa.numel(), p(hashes), cap, p(cnt), st)
+        torch.cuda.synchronize()
+        got = np.sort(hashes[:int(cnt[0].item())].cpu().numpy().view(np.uint64))
+        windows = int(n_aa) - (6 if translate else 0)
+        out[name] = {"input_bytes": n, "residues": int(n_aa), "ms": round(ms, 3), "G_windows_per_s": round(windows / (ms * 1e-3) / 1e9, 2),
+                     "input_Gbytes_per_s": round(n / (ms * 1e-3) / 1e9, 2), "kept_at_scaled_200": kept,
+                     "roofline": hbm_roofline(n + int(n_aa) * 2 + 8 * kept, ms,
+                                              "input once + residues written and read once (1 B each) + 8 B per kept hash; residues / translate kernel + window kernel"),
+                     "cpu_port": {"sample_bytes": sample, "seconds": round(cpu_s, 2), "threads": 1, "M_windows_per_s": round(len(ref) / cpu_s / 1e6, 2),
+                                  "gpu_matches_oracle_on_sample": bool(np.array_equal(got, want))}}
+    extra["sketch_protein"] = {k: v for k, v in out.items() if not k.startswith("translate")}
+    extra["sketch_translate"] = {k: v for k, v in out.items() if k.startswith("translate")}
 
 
 def io_extras(extra, torch, np, dev, smd):

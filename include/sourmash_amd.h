@@ -265,6 +265,14 @@ uint64_t smgpu_sketch_dna_raw(const uint8_t *d_seq, uint64_t len, uint32_t ksize
  * count to *d_count (device u64, caller zeroes).  Fully asynchronous. */
 void smgpu_sketch_dna_kernel_raw(const uint8_t *d_seq, uint64_t len, uint32_t ksize, uint64_t seed, uint64_t max_hash,
                                  uint64_t *d_out, uint64_t out_capacity, uint64_t *d_count, void *stream);
+/* The kernels of protein / dayhoff / hp sketches on device-resident input (src/core/src/signature.rs:307-393,
+ * src/core/src/encodings.rs:103-368): the residues of a protein sequence -- or, translate = true, the six-frame translation of
+ * DNA -- go to d_aa (capacity aa_capacity bytes; translated DNA needs 2 * len + 6), every window of k_aa residues is hashed and
+ * the hashes 1 <= h <= max_hash are appended unordered to d_out, their count added to *d_count (device u64, caller zeroes).
+ * -> residues written to d_aa.  Fully asynchronous.  hash_function: 2 protein, 3 dayhoff, 4 hp. */
+uint64_t smgpu_sketch_residues_kernels_raw(const uint8_t *d_seq, uint64_t len, uint32_t k_aa, uint32_t hash_function, uint64_t seed,
+                                           uint64_t max_hash, bool translate, uint8_t *d_aa, uint64_t aa_capacity, uint64_t *d_out,
+                                           uint64_t out_capacity, uint64_t *d_count, void *stream);
 /* Synthetic random DNA written straight into HBM (BASELINE config C2 generator). */
 void smgpu_synth_dna_raw(uint8_t *d_out, uint64_t start, uint64_t n, uint64_t seed, uint64_t record_len, void *stream);
 
@@ -334,6 +342,14 @@ void smgpu_compare_all_pairs(const SourmashKmerMinHash *const *mhs, uintptr_t n,
  * ksize / molecule / seed mismatch of the first sketch that does not match sketch 0. */
 void smgpu_compare_all_pairs_mixed(const SourmashKmerMinHash *const *mhs, uintptr_t n, const uint32_t *class_of,
                                    const uint64_t *class_max_hash, uintptr_t n_classes, uint32_t *common_out, uint64_t *sizes_out);
+/* Views for batched callers (src/sourmash/compare.py:326-358 reads `sig.minhash` per pair, and signature_first_mh
+ * (src/core/src/ffi/signature.rs:167-182) CLONES the sketch every time): out_mhs[i] = the first sketch of sigs[i] as a BORROWED
+ * handle -- valid while the signature lives and is not modified, never to be freed -- and params[i][8] = {ksize as stored,
+ * hash_function, seed, max_hash, num, track_abundance, number of hashes, 0} in one call.  smgpu_minhashes_params: the same
+ * parameter rows for sketch handles. */
+void smgpu_signatures_sketch_views(const SourmashSignature *const *sigs, uintptr_t n, const SourmashKmerMinHash **out_mhs,
+                                   uint64_t *params);
+void smgpu_minhashes_params(const SourmashKmerMinHash *const *mhs, uintptr_t n, uint64_t *params);
 /* Bytes and nanoseconds the host-pointer entry points spent moving large pageable buffers (csrc/hostxfer.hpp) since the last reset:
  * out5 = {H2D bytes, D2H bytes, H2D ns, D2H ns, calls}.  Diagnostics for bench.py's API-level lines. */
 void smgpu_xfer_stats(uint64_t *out5, bool reset);

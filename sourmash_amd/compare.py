@@ -29,23 +29,73 @@ __all__ = ["compare_all_pairs", "compare_serial", "compare_parallel", "compare_s
            "jaccard_ani_values"]
 
 
-def _uniform(mhs):
-    "every sketch scaled, none bottom-k, one scaled value: the batched kernels apply as they are"
-    return bool(mhs) and not any(mh.num for mh in mhs) and all(mh.scaled for mh in mhs) and len({mh.scaled for mh in mhs}) == 1
+class _Views:
+    """The first sketches of a list of signatures as BORROWED handles plus their parameters as arrays, from ONE C call
+    (smgpu_signatures_sketch_views).  The reference's loop reads `sig.minhash` per pair, and that property clones the sketch
+    through the FFI (signature.rs:167-182): for 10,000 signatures 400 MB of copies and a dozen FFI calls per sketch before any
+    comparing starts.  The views keep the signature objects alive; nothing here is freed or modified."""
+
+    def __init__(self, siglist=None, *, _from=None, _idx=None):
+        from .minhash import _get_scaled_for_max_hash
+        if _from is not None:                                      # a subset of another view (shares the signatures)
+            idx = np.asarray(_idx, dtype=np.int64)
+            self.sigs = [_from.sigs[i] for i in idx]
+            self.n = len(idx)
+            self.ptrs = (C.c_void_p * max(self.n, 1))(*[_from.ptrs[i] for i in idx])
+            self.params = _from.params[idx].copy()
+        else:
+            self.sigs = list(siglist)
+            self.n = n = len(self.sigs)
+            self.ptrs = (C.c_void_p * max(n, 1))()
+            self.params = np.zeros((max(n, 1), 8), dtype=np.uint64)
+            if n:
+                sp = (C.c_void_p * n)(*[s._get_objptr() for s in self.sigs])
+                rustcall(lib.smgpu_signatures_sketch_views, sp, n, self.ptrs, self.params.ctypes.data_as(C.c_void_p))
+            self.params = self.params[:n]
+        p = self.params
+        self.ksize_raw, self.hf, self.seed, self.max_hash, self.num = p[:, 0], p[:, 1], p[:, 2], p[:, 3], p[:, 4]
+        self.abund = p[:, 5] != 0
+        self.size = p[:, 6].astype(np.int64)
+        per = {int(m): (_get_scaled_for_max_hash(int(m)) if m else 0) for m in np.unique(self.max_hash)}
+        self.scaled = np.array([per[int(m)] for m in self.max_hash], dtype=np.int64)
+
+    @property
+    def ksize(self):
+        "MinHash.ksize of the first sketch (residues for protein / dayhoff / hp)"
+        k = int(self.ksize_raw[0])
+        return k if int(self.hf[0]) == 1 else k // 3
+
+    def subset(self, idx):
+        return _Views(_from=self, _idx=idx)
+
+    def minhashes(self):
+        "sketch OBJECTS (the cloning path): only for the corners that need host-side set operations"
+        return [s.minhash for s in self.sigs]
+
+
+class _Handles:
+    "the same for a list of MinHash objects (common_matrix / num_matrix / angular_matrix as public helpers)"
+
+    def __init__(self, mhs):
+        self.keep = list(mhs)
+        self.n = len(self.keep)
+        self.ptrs = (C.c_void_p * max(self.n, 1))(*[mh._get_objptr() for mh in self.keep])
+
+
+def _common_ptrs(ptrs, n, want_jaccard=True):
+    common = np.empty((n, n), dtype=np.uint32)
+    jac = np.empty((n, n), dtype=np.float64) if want_jaccard else None
+    if n:
+        rustcall(lib.smgpu_compare_all_pairs, ptrs, n, common.ctypes.data_as(C.POINTER(C.c_uint32)),
+                 jac.ctypes.data_as(C.POINTER(C.c_double)) if want_jaccard else None)
+    return common, jac
 
 
 def common_matrix(mhs, want_jaccard=True):
     """u32 common[n][n] (+ f64 jaccard[n][n]) of flat scaled sketches: one GPU call
     (smgpu_compare_all_pairs).  Raises the compatibility error of the first mismatch."""
-    n = len(mhs)
-    common = np.zeros((n, n), dtype=np.uint32)
-    jac = np.zeros((n, n), dtype=np.float64) if want_jaccard else None
-    if n == 0:
-        return common, jac
-    ptrs = (C.c_void_p * n)(*[mh._get_objptr() for mh in mhs])
-    rustcall(lib.smgpu_compare_all_pairs, ptrs, n, common.ctypes.data_as(C.POINTER(C.c_uint32)),
-             jac.ctypes.data_as(C.POINTER(C.c_double)) if want_jaccard else None)
-    return common, jac
+    h = _Handles(mhs)
+    return _common_ptrs(h.ptrs, h.n, want_jaccard)
 
 
 def _pow(x, y):
@@ -65,16 +115,11 @@ def _pow(x, y):
     return out
 
 
-def num_matrix(mhs, want_counts=False):
-    """Jaccard of every pair of flat BOTTOM-K sketches in one launch (smgpu_compare_num_all_pairs, csrc/compare_ext.hip): the
-    intersection is taken against the merged sketch truncated to `num` (minhash.rs:593-621), num being that of the sketch
-    with the lower index, as in compare.py:39 `siglist[i].similarity(siglist[j])`.  -> f64 [n][n] (and u32 common, union)."""
-    n = len(mhs)
+def _num_ptrs(ptrs, n, want_counts=False):
     jac = np.ones((n, n), dtype=np.float64)
     common = np.zeros((n, n), dtype=np.uint32) if want_counts else None
     union = np.zeros((n, n), dtype=np.uint32) if want_counts else None
     if n:
-        ptrs = (C.c_void_p * n)(*[mh._get_objptr() for mh in mhs])
         rustcall(lib.smgpu_compare_num_all_pairs, ptrs, n,
                  common.ctypes.data_as(C.POINTER(C.c_uint32)) if want_counts else None,
                  union.ctypes.data_as(C.POINTER(C.c_uint32)) if want_counts else None,
@@ -82,42 +127,53 @@ def num_matrix(mhs, want_counts=False):
     return (jac, common, union) if want_counts else jac
 
 
-def angular_matrix(mhs):
-    """Angular similarity of every pair of abundance-tracking sketches (minhash.rs:635-680): the integer sums -- sum over
-    the common hashes of abund x abund, per sketch the sum of squares -- from one launch (csrc/compare_ext.hip), sqrt / acos
-    from the host's libm in the reference's operation order (smgpu_compare_angular_all_pairs).  -> f64 [n][n], diagonal 1.0."""
-    n = len(mhs)
+def num_matrix(mhs, want_counts=False):
+    """Jaccard of every pair of flat BOTTOM-K sketches in one launch (smgpu_compare_num_all_pairs, csrc/compare_ext.hip): the
+    intersection is taken against the merged sketch truncated to `num` (minhash.rs:593-621), num being that of the sketch
+    with the lower index, as in compare.py:39 `siglist[i].similarity(siglist[j])`.  -> f64 [n][n] (and u32 common, union)."""
+    h = _Handles(mhs)
+    return _num_ptrs(h.ptrs, h.n, want_counts)
+
+
+def _angular_ptrs(ptrs, n):
     sims = np.ones((n, n), dtype=np.float64)
     if n:
-        ptrs = (C.c_void_p * n)(*[mh._get_objptr() for mh in mhs])
         rustcall(lib.smgpu_compare_angular_all_pairs, ptrs, n, sims.ctypes.data_as(C.POINTER(C.c_double)), None, None)
     return sims
 
 
-def _compat_key(mh):
-    "what check_compatible looks at besides the threshold (minhash.rs:886-912): ksize, hash function, seed"
-    return (mh.ksize, mh.moltype, mh.seed)
+def angular_matrix(mhs):
+    """Angular similarity of every pair of abundance-tracking sketches (minhash.rs:635-680): the integer sums -- sum over
+    the common hashes of abund x abund, per sketch the sum of squares -- from one launch (csrc/compare_ext.hip), sqrt / acos
+    from the host's libm in the reference's operation order (smgpu_compare_angular_all_pairs).  -> f64 [n][n], diagonal 1.0."""
+    h = _Handles(mhs)
+    return _angular_ptrs(h.ptrs, h.n)
 
 
-def _batchable(mhs, downsample):
+def _batchable(v, downsample):
     """Can the pairs of this list be served by batched launches with the per-pair semantics intact?  Yes when every sketch
-    is mutually compatible with every other: one (ksize, molecule, seed), and either all bottom-k, or all scaled with one
-    scaled value -- or several, if the caller asked for downsampling (every pair is then compared at ITS coarser scaled,
-    minhash.rs:688-696).  Otherwise some pair raises in the reference's loop, and the caller lets that very pair raise."""
-    if len({_compat_key(mh) for mh in mhs}) > 1:
-        return False
-    if all(mh.num for mh in mhs):
+    is mutually compatible with every other: one (ksize, molecule, seed) (what check_compatible looks at besides the
+    threshold, minhash.rs:886-912), and either all bottom-k, or all scaled with one scaled value -- or several, if the caller
+    asked for downsampling (every pair is then compared at ITS coarser scaled, minhash.rs:688-696).  Otherwise some pair raises
+    in the reference's loop, and the caller lets that very pair raise."""
+    if v.n == 0:
         return True
-    if any(mh.num for mh in mhs) or not all(mh.scaled for mh in mhs):
+    if len(np.unique(v.params[:, :3], axis=0)) > 1:
         return False
-    return downsample or len({mh.scaled for mh in mhs}) == 1
+    if (v.num != 0).all():
+        return True
+    if (v.num != 0).any() or (v.max_hash == 0).any():
+        return False
+    return downsample or len(np.unique(v.max_hash)) == 1
 
 
 def _by_scaled(mhs, downsample, block):
     """f64 [n][n], diagonal 1.0, assembled from one `block(sketches, scaled) -> matrix` call per distinct scaled value s of the
     list: the sketches with scaled <= s, downsampled to s (a prefix of their hashes, minhash.rs:777-798), give the entries of
     the pairs whose coarser scaled is s -- what similarity(downsample=True) does pair by pair (minhash.rs:688-696).  One
-    value (or bottom-k sketches: scaled 0): one call on the sketches as they are."""
+    value (or bottom-k sketches: scaled 0): one call on the sketches as they are.  (Host sketch OBJECTS: only the abundance-
+    weighted similarity of a list with several scaled values still comes here; everything count-based goes through
+    _by_scaled_counts.)"""
     n = len(mhs)
     scaleds = sorted({mh.scaled for mh in mhs})
     if len(scaleds) == 1:
@@ -139,33 +195,32 @@ def _by_scaled(mhs, downsample, block):
     return out
 
 
-def _mixed_common(flat):
-    """A list of flat scaled sketches with SEVERAL scaled values, every pair at its coarser scaled, in ONE call
+def _mixed_common(v):
+    """A list of scaled sketches with SEVERAL scaled values, every pair at its coarser scaled, in ONE call
     (smgpu_compare_all_pairs_mixed): the sketches travel once as they are, downsampling is a prefix cut on the device
     (minhash.rs:777-798), no downsampled host objects.  -> (common u32 [n][n], the distinct scaled values ascending,
     sizes_at int64 [value][sketch] = len(sketch downsampled to that value), class_of = index of every sketch's own value)."""
-    from .minhash import _get_max_hash_for_scaled
-    n = len(flat)
-    scaleds = sorted({mh.scaled for mh in flat})
-    where = {s: c for c, s in enumerate(scaleds)}
-    class_of = np.array([where[mh.scaled] for mh in flat], dtype=np.uint32)
-    max_hashes = np.array([_get_max_hash_for_scaled(s) for s in scaleds], dtype=np.uint64)
+    n = v.n
+    max_hashes = np.unique(v.max_hash)[::-1].copy()               # ascending SCALED = descending max_hash
+    lookup = {int(m): c for c, m in enumerate(max_hashes)}
+    class_of = np.array([lookup[int(m)] for m in v.max_hash], dtype=np.uint32)
+    scaleds = [int(v.scaled[np.flatnonzero(class_of == c)[0]]) for c in range(len(max_hashes))]
     common = np.empty((n, n), dtype=np.uint32)
-    sizes = np.zeros((len(scaleds), n), dtype=np.uint64)
-    ptrs = (C.c_void_p * n)(*[mh._get_objptr() for mh in flat])
-    rustcall(lib.smgpu_compare_all_pairs_mixed, ptrs, n, class_of.ctypes.data_as(C.c_void_p), max_hashes.ctypes.data_as(C.c_void_p),
-             len(scaleds), common.ctypes.data_as(C.c_void_p), sizes.ctypes.data_as(C.c_void_p))
+    sizes = np.zeros((len(max_hashes), n), dtype=np.uint64)
+    mh_arr = np.ascontiguousarray(max_hashes, dtype=np.uint64)
+    rustcall(lib.smgpu_compare_all_pairs_mixed, v.ptrs, n, class_of.ctypes.data_as(C.c_void_p), mh_arr.ctypes.data_as(C.c_void_p),
+             len(max_hashes), common.ctypes.data_as(C.c_void_p), sizes.ctypes.data_as(C.c_void_p))
     return common, scaleds, sizes.astype(np.int64), class_of.astype(np.int64)
 
 
-def _by_scaled_counts(flat, block):
+def _by_scaled_counts(v, block):
     """_by_scaled for quantities that are arithmetic on counts and sizes: block(common u32 [m][m], sizes int64 [m], scaled)
     -> f64 [m][m] is called once per scaled value of the list with the sketches that are as fine or finer, their sizes AT
     that value, and the counts of the pairs whose coarser scaled it is (0 elsewhere); the entries of those pairs are kept."""
-    n = len(flat)
-    if len({mh.scaled for mh in flat}) == 1:
-        return block(common_matrix(flat, want_jaccard=False)[0], np.array([len(mh) for mh in flat], dtype=np.int64), flat[0].scaled)
-    common, scaleds, sizes_at, class_of = _mixed_common(flat)
+    n = v.n
+    if len(np.unique(v.max_hash)) == 1:
+        return block(_common_ptrs(v.ptrs, n, want_jaccard=False)[0], v.size, int(v.scaled[0]))
+    common, scaleds, sizes_at, class_of = _mixed_common(v)
     out = np.ones((n, n), dtype=np.float64)
     for c, s in enumerate(scaleds):
         idx = np.flatnonzero(class_of <= c)
@@ -189,15 +244,21 @@ def _jaccard_from_counts(common, sizes):
     return jac
 
 
-def _jaccard_matrix(flat, downsample):
-    "Jaccard of every pair of flat sketches: bottom-k -> one launch; one scaled value -> one launch incl. the f64 matrix; several -> counts"
-    scaleds = {mh.scaled for mh in flat}
-    if scaleds == {0}:
-        return num_matrix(flat)
-    if len(scaleds) == 1:
-        return common_matrix(flat, want_jaccard=True)[1]
+def _jaccard_matrix(v, downsample):
+    "Jaccard of every pair: bottom-k -> one launch; one scaled value -> one launch incl. the f64 matrix; several -> counts + arithmetic"
+    if (v.num != 0).all():
+        return _num_ptrs(v.ptrs, v.n)
+    if len(np.unique(v.max_hash)) == 1:
+        return _common_ptrs(v.ptrs, v.n, want_jaccard=True)[1]
     assert downsample
-    return _by_scaled_counts(flat, lambda cm, sz, s: _jaccard_from_counts(cm, sz))
+    return _by_scaled_counts(v, lambda cm, sz, s: _jaccard_from_counts(cm, sz))
+
+
+def _angular(v, downsample):
+    "abundance-weighted similarity of every pair (all sketches track abundance)"
+    if (v.num != 0).all() or len(np.unique(v.max_hash)) == 1:
+        return _angular_ptrs(v.ptrs, v.n)
+    return _by_scaled(v.minhashes(), downsample, lambda sub, s: angular_matrix(sub))     # several scaled values: host objects
 
 
 def _raise_like_the_loop(siglist, call):
@@ -251,34 +312,44 @@ def _jaccard_ani_block(common, sizes, scaled, ksize):
     return out
 
 
+def _sizes_trusted(sizes, scaled, relative_error=0.20, confidence=0.95):
+    """size_is_accurate() of sketches known by their sizes (minhash.py:1099-1120: set_size_exact_prob of len * scaled); scaled: one
+    value or one per sketch"""
+    from .distance_utils import set_size_exact_prob
+    sc = np.broadcast_to(np.asarray(scaled, dtype=np.int64), (len(sizes),))
+    return np.array([set_size_exact_prob(int(n) * int(s), int(s), relative_error=relative_error) >= confidence for n, s in zip(sizes, sc)],
+                    dtype=bool)
+
+
 def compare_serial(siglist, ignore_abundance, *, downsample=False, return_ani=False):
     """Similarity matrix (compare.py:14-64).  Per pair the reference computes: Jaccard-derived ANI (return_ani); else the
     angular similarity when both sketches track abundance and it is not ignored, else Jaccard -- with the bottom-k rule for
     num sketches, and at the pair's coarser scaled when downsampling (minhash.rs:682-702).  Here every one of these is a
     batched launch over the whole list (or over the sketches sharing a scaled value); lists in which some pair is
-    incompatible raise what the reference's loop raises, from the same pair."""
+    incompatible raise what the reference's loop raises, from the same pair.  The sketches are read through borrowed views
+    (_Views): no clone per signature, one parameter call for the list."""
+    siglist = list(siglist)
     n = len(siglist)
-    mhs = [s.minhash for s in siglist]
     if n < 2:
         return np.ones((n, n))
+    v = _Views(siglist)
     if return_ani:
-        if not all(mh.scaled for mh in mhs) or not _batchable(mhs, downsample):
+        if (v.max_hash == 0).any() or not _batchable(v, downsample):
             _raise_like_the_loop(siglist, lambda a, b: a.jaccard_ani(b, downsample=downsample))
-        ksize = mhs[0].ksize
-        out = _by_scaled_counts([mh.flatten() for mh in mhs], lambda cm, sz, s: _jaccard_ani_block(cm, sz, s, ksize))
-        trusted = np.array([mh.size_is_accurate() for mh in mhs], dtype=bool)   # of the sketches as given (minhash.py:783)
+        ksize = v.ksize
+        out = _by_scaled_counts(v, lambda cm, sz, s: _jaccard_ani_block(cm, sz, s, ksize))
+        trusted = _sizes_trusted(v.size, v.scaled)                  # of the sketches as given (minhash.py:783)
         out = np.where(trusted[:, None] & trusted[None, :], out, 0.0)
         out[np.arange(n), np.arange(n)] = 1.0
         return out
-    if not _batchable(mhs, downsample):
+    if not _batchable(v, downsample):
         _raise_like_the_loop(siglist, lambda a, b: a.similarity(b, ignore_abundance=ignore_abundance, downsample=downsample))
-    weighted = [] if ignore_abundance else [i for i, mh in enumerate(mhs) if mh.track_abundance]
+    weighted = np.zeros(0, dtype=np.int64) if ignore_abundance else np.flatnonzero(v.abund)
     if len(weighted) == n:
-        return _by_scaled(mhs, downsample, lambda sub, s: angular_matrix(sub))
-    sims = _jaccard_matrix([mh.flatten() for mh in mhs], downsample)
+        return _angular(v, downsample)
+    sims = _jaccard_matrix(v, downsample)                            # (the count kernels read the hashes only: no flatten() copies)
     if len(weighted) > 1:                                         # minhash.rs:697-701 decides per pair: both track abundance
-        w = np.array(weighted)
-        sims[np.ix_(w, w)] = _by_scaled([mhs[i] for i in weighted], downsample, lambda sub, s: angular_matrix(sub))
+        sims[np.ix_(weighted, weighted)] = _angular(v.subset(weighted), downsample)
     return sims
 
 
@@ -339,31 +410,26 @@ def _containment_block(common, sizes, scaled, ksize, mode, return_ani):
     return _ani_from_containment(_debias_matrix(common, sizes, scaled, mode), ksize).reshape(n, n)
 
 
-def _sizes_trusted(sizes, scaled, relative_error=0.20, confidence=0.95):
-    "size_is_accurate() of sketches known by their sizes at `scaled` (minhash.py:1099-1120: set_size_exact_prob of len * scaled)"
-    from .distance_utils import set_size_exact_prob
-    return [set_size_exact_prob(int(n) * scaled, scaled, relative_error=relative_error) >= confidence for n in sizes]
-
-
-def _containment_mixed(flat, mode):
+def _containment_mixed(v, mode):
     """containment / max / avg containment of a list with SEVERAL scaled values, downsample = True, in the reference's
     (asymmetric) arithmetic: the count of a pair is taken at the pair's coarser scaled (count_common downsamples the finer
     sketch, minhash.rs:539-548), but the denominator and its bias factor are those of the sketch AS GIVEN -- len(self) and
     self.scaled (minhash.py:819-841), min(len(self), len(other)) with self.scaled for max containment (:881-905), self being
-    the sketch with the higher index of the pair (compare.py:111-150).  One launch per scaled value for the counts, then
+    the sketch with the higher index of the pair (compare.py:111-150).  ONE call for the counts (prefix cut on the device), then
     whole-array arithmetic; the bias factors are one libm pow per (sketch, scaled value)."""
-    n = len(flat)
-    cm = _mixed_common(flat)[0].astype(np.float64)                # every pair at its coarser scaled, one call
-    sz = np.array([len(mh) for mh in flat], dtype=np.float64)
-    sc = [mh.scaled for mh in flat]
-    own_bias = np.array([_bias_factors([len(mh)], mh.scaled)[0] for mh in flat], dtype=np.float64)
+    n = v.n
+    cm = _mixed_common(v)[0].astype(np.float64)                   # every pair at its coarser scaled, one call
+    sizes = [int(x) for x in v.size]
+    sz = v.size.astype(np.float64)
+    sc = [int(x) for x in v.scaled]
+    own_bias = np.array([_bias_factors([sizes[i]], sc[i])[0] for i in range(n)], dtype=np.float64)
     if mode == "containment":            # [i][j] = siglist[j].contained_by(siglist[i]): j's size, j's scaled
         out = _debias(cm, sz[None, :], own_bias[None, :])
     elif mode == "avg":                  # (self.contained_by(other) + other.contained_by(self)) / 2
         out = (_debias(cm, sz[None, :], own_bias[None, :]) + _debias(cm, sz[:, None], own_bias[:, None])) / 2
     else:                                # max: min of the two sizes, the bias at the scaled of `self` = the higher index
         values = sorted(set(sc))
-        bias_at = {s: _bias_factors([len(mh) for mh in flat], s) for s in values}       # [scaled][sketch]
+        bias_at = {s: _bias_factors(sizes, s) for s in values}       # [scaled][sketch]
         idx = np.arange(n)
         hi = np.maximum(idx[:, None], idx[None, :])                 # `self` of the pair
         lo = np.minimum(idx[:, None], idx[None, :])
@@ -380,21 +446,23 @@ def _containment_mixed(flat, mode):
 
 
 def _containment(siglist, downsample, mode, return_ani):
+    siglist = list(siglist)
     n = len(siglist)
-    mhs = [s.minhash for s in siglist]
-    if not all(mh.scaled for mh in mhs):
+    v = _Views(siglist)
+    if (v.max_hash == 0).any():
         raise TypeError("Error: can only calculate %s for scaled MinHashes" % ("ANI" if return_ani else "containment"))
-    if not _batchable(mhs, downsample):
+    if n < 2:
+        return np.ones((n, n))
+    if not _batchable(v, downsample):
         return _containment_pairs(siglist, downsample, mode, return_ani)      # some pair raises: from the same pair as the reference's loop
-    flat = [mh.flatten() for mh in mhs]
-    ksize = flat[0].ksize
+    ksize = v.ksize
     if not return_ani:
-        if len({mh.scaled for mh in flat}) == 1:
-            return _by_scaled_counts(flat, lambda cm, sz, s: _containment_block(cm, sz, s, ksize, mode, False))
-        return _containment_mixed(flat, mode)
+        if len(np.unique(v.max_hash)) == 1:
+            return _by_scaled_counts(v, lambda cm, sz, s: _containment_block(cm, sz, s, ksize, mode, False))
+        return _containment_mixed(v, mode)
     # ANI: both sketches are downsampled to the pair's coarser scaled first, then everything is computed there
-    # (minhash.py:843-879,907-944): the blocks of _by_scaled are exactly that.  An estimate is withheld (0 in the matrix) when
-    # a sketch is too small for its size to be trusted -- and WHICH sketch is asked differs by mode, as in the reference:
+    # (minhash.py:843-879,907-944): the blocks of _by_scaled_counts are exactly that.  An estimate is withheld (0 in the matrix)
+    # when a sketch is too small for its size to be trusted -- and WHICH sketch is asked differs by mode, as in the reference:
     # containment / max go through MinHash.{containment,max_containment}_ani, which ask the sketches AS GIVEN
     # (minhash.py:877-878,938-939); avg goes through FracMinHashComparison (compare.py:166-168), whose mh1_cmp / mh2_cmp are the
     # sketches already downsampled to the pair's scaled (sketchcomparison.py:53-70,143-170) -- a sketch trusted at its own
@@ -403,10 +471,10 @@ def _containment(siglist, downsample, mode, return_ani):
         ok = np.asarray(ok, dtype=bool)
         return np.where(ok[:, None] & ok[None, :], m, 0.0)
     if mode == "avg":
-        out = _by_scaled_counts(flat, lambda cm, sz, s: trust_mask(_containment_block(cm, sz, s, ksize, mode, True), _sizes_trusted(sz, s)))
+        out = _by_scaled_counts(v, lambda cm, sz, s: trust_mask(_containment_block(cm, sz, s, ksize, mode, True), _sizes_trusted(sz, s)))
     else:
-        out = trust_mask(_by_scaled_counts(flat, lambda cm, sz, s: _containment_block(cm, sz, s, ksize, mode, True)),
-                         [mh.size_is_accurate() for mh in mhs])
+        out = trust_mask(_by_scaled_counts(v, lambda cm, sz, s: _containment_block(cm, sz, s, ksize, mode, True)),
+                         _sizes_trusted(v.size, v.scaled))
     out[np.arange(n), np.arange(n)] = 1.0
     return out
 

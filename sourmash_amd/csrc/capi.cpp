@@ -831,6 +831,25 @@ void smgpu_sketch_dna_kernel_raw(const uint8_t* d_seq, uint64_t len, uint32_t ks
     });
 }
 
+// The kernels behind protein / dayhoff / hp sketches on device-resident input (benchmarks; the object API goes through
+// DeviceCtx::protein_sketch_host): residues of a protein sequence, or the six-frame translation of DNA (signature.rs:307-393), into
+// d_aa, then every window of k_aa residues hashed and the hashes 1 <= h <= max_hash appended to d_out.  -> residues written.
+uint64_t smgpu_sketch_residues_kernels_raw(const uint8_t* d_seq, uint64_t len, uint32_t k_aa, uint32_t hash_function, uint64_t seed,
+                                           uint64_t max_hash, bool translate, uint8_t* d_aa, uint64_t aa_capacity, uint64_t* d_out,
+                                           uint64_t cap, uint64_t* d_count, void* stream) {
+    return landing<uint64_t>([&]() -> uint64_t {
+        if (hash_function < HF_PROTEIN || hash_function > HF_HP) throw err_internal("hash_function must be protein, dayhoff or hp");
+        const uint64_t n_aa = translate ? translated_bytes(len) : len;
+        if (n_aa > aa_capacity) throw err_internal("d_aa is too small: " + std::to_string(n_aa) + " residues");
+        hipStream_t st = (hipStream_t)stream;
+        if (translate) hip_check(translate_launch(d_seq, len, hash_function, d_aa, st), "translate");
+        else hip_check(residues_launch(d_seq, len, hash_function, d_aa, st), "residues");
+        hip_check(residue_windows_launch(d_aa, n_aa, k_aa, seed, max_hash ? max_hash : ~0ull, d_out, (unsigned long long*)d_count, cap,
+                                         false, st), "residue windows");
+        return n_aa;
+    });
+}
+
 void smgpu_synth_dna_raw(uint8_t* d_out, uint64_t start, uint64_t n, uint64_t seed, uint64_t record_len, void* stream) {
     landing_void([&] { hip_check(synth_dna_launch(d_out, start, n, seed, record_len, (hipStream_t)stream), "synth_dna"); });
 }
@@ -1073,7 +1092,7 @@ static void compare_device_csr(const uint64_t* d_hashes, const uint64_t* d_offse
 }
 
 // the hash vectors (or abundance vectors) of n sketches back to back into d_dst: worker threads pack pinned chunks, ONE H2D copy
-// per 32 MiB chunk (round 4: one pageable copy per sketch)
+// per 64 MiB chunk (round 4: one pageable copy per sketch)
 static void upload_rows(const SourmashKmerMinHash* const* mhs, uintptr_t n, const std::vector<uint64_t>& offsets, bool abunds,
                         void* d_dst, hipStream_t st) {
     std::vector<HostPiece> pieces(n);
@@ -1171,6 +1190,28 @@ void smgpu_compare_all_pairs_mixed(const SourmashKmerMinHash* const* mhs, uintpt
         HostXfer::get().device_to_host(common_out, dout.p, (size_t)n * n * 4, st);
         hip_check(hipStreamSynchronize(st), "sync");
     });
+}
+
+// The first sketch of each signature WITHOUT the clone signature_first_mh makes (ffi/signature.rs:167-182 clones; a 10,000-signature
+// compare cloned 400 MB before it started), and every sketch's parameters in one call instead of a dozen FFI calls per sketch:
+// params[i] = {ksize as stored, hash_function, seed, max_hash, num, track_abundance, size, 0}.  The handles are BORROWED: valid while
+// the signature lives and is not modified, never to be freed.
+static void sketch_params(const KmerMinHash* m, uint64_t* out) {
+    out[0] = m->ksize; out[1] = m->hash_function; out[2] = m->seed; out[3] = m->max_hash; out[4] = m->num;
+    out[5] = m->track_abundance ? 1 : 0; out[6] = m->size(); out[7] = 0;
+}
+void smgpu_signatures_sketch_views(const SourmashSignature* const* sigs, uintptr_t n, const SourmashKmerMinHash** out_mhs, uint64_t* params) {
+    landing_void([&] {
+        for (uintptr_t i = 0; i < n; ++i) {
+            if (SIG(sigs[i])->sketches.empty()) throw err_internal("found unsupported sketch type");
+            const KmerMinHash* m = &SIG(sigs[i])->sketches[0];
+            out_mhs[i] = reinterpret_cast<const SourmashKmerMinHash*>(m);
+            sketch_params(MH(out_mhs[i]), params + 8 * i);             // (MH: queued records are hashed first, like every reader)
+        }
+    });
+}
+void smgpu_minhashes_params(const SourmashKmerMinHash* const* mhs, uintptr_t n, uint64_t* params) {
+    landing_void([&] { for (uintptr_t i = 0; i < n; ++i) sketch_params(MH(mhs[i]), params + 8 * i); });
 }
 
 void smgpu_xfer_stats(uint64_t* out5, bool reset) {

@@ -1282,6 +1282,7 @@ __global__ __launch_bounds__(PL_THREADS) void gather_loop_kernel(LoopArgs a) {
 #define PL_WAITLAP(slot) do { if (a.dbg != nullptr && wg == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); PL_LAP(slot); } } while (0)
 #define PL_LAP(slot) do { if (timing) { const unsigned long long t_ = wall_clock64(); t_acc[slot] += t_ - t_mark; t_mark = t_; } } while (0)
     if (timing) a.dbg[6] = t_mark;
+    uint32_t pf_sink = 0, pf_ahead = 0;                           // what prefetch touches returned: folded in late, never meaningful
     for (uint32_t epoch = 1;; ++epoch) {
         fail_epoch = epoch;
         // ---- local best of the owned rows -> this workgroup's record of the epoch ----
@@ -1296,8 +1297,11 @@ __global__ __launch_bounds__(PL_THREADS) void gather_loop_kernel(LoopArgs a) {
         k = wave_max(k);
         if (lane == 0) s_red[wave] = k;
         __syncthreads();
+        if (wave == 0) {                                             // the 16 wave maxima: one LDS read per lane + a wave reduction (was: 16 dependent reads by thread 0)
+            k = lane < PL_THREADS / 64 ? s_red[lane] : 0ull;
+            k = wave_max(k);
+        }
         if (tid == 0) {
-            for (int w = 1; w < PL_THREADS / 64; ++w) k = s_red[w] > k ? s_red[w] : k;
             uint32_t start = 0, len = 0;
             if (k) {
                 const uint32_t i = (uint32_t)((0xffffffffull & ~k) - a.index_base - r0);
@@ -1316,10 +1320,17 @@ __global__ __launch_bounds__(PL_THREADS) void gather_loop_kernel(LoopArgs a) {
         __syncthreads();
         // While the records travel: touch the positions of this workgroup's own best row, one lane per 64-byte line.  The
         // round's winner is one of these rows, so its slice is in the memory-side cache (and one XCD's L2) when everybody asks.
-        if (a.prefetch) {
+        // (Round 4 spelled the touch as a volatile load: the compiler follows every volatile access with s_waitcnt vmcnt(0), so
+        //  each thread sat out a trip to HBM right here, in front of the sweep.  Now the touches are plain loads issued by the
+        //  waves that take no part in the sweep -- loads return in order, a sweep behind a touch would wait for it -- and what
+        //  they return is folded into a sink only after the round's positions have arrived, a wait that covers them anyway.)
+        uint32_t pf_own = 0;
+        constexpr int SWEEP_WAVES = 4;                               // the sweep reads with threads 0 .. n_wg - 1
+        if (a.prefetch && (wave >= SWEEP_WAVES || n_wg > SWEEP_WAVES * 64u)) {
             const uint32_t ps = s_wstart, pl = s_wlen;
-            for (uint32_t i = (uint32_t)tid * 16u; i < pl; i += PL_THREADS * 16u)
-                (void)*reinterpret_cast<const volatile uint32_t*>(a.qpos + (uint64_t)ps + i);   // volatile: issued, its value unused
+            const uint32_t t0 = n_wg > SWEEP_WAVES * 64u ? (uint32_t)tid : (uint32_t)tid - SWEEP_WAVES * 64u;
+            const uint32_t nt = n_wg > SWEEP_WAVES * 64u ? (uint32_t)PL_THREADS : (uint32_t)PL_THREADS - SWEEP_WAVES * 64u;
+            for (uint32_t i = t0 * 16u; i < pl; i += nt * 16u) pf_own += a.qpos[(uint64_t)ps + i];
         }
         PL_LAP(0);                                                   // local arg-max + publish
         // ---- sweep everyone's records until all of them carry this epoch: the winner of the round ----
@@ -1469,24 +1480,81 @@ __global__ __launch_bounds__(PL_THREADS) void gather_loop_kernel(LoopArgs a) {
             const uint32_t i = (uint32_t)u * PL_THREADS + (uint32_t)tid;
             pos[u] = i < wlen && i < a.chunk ? row_pos(i) : NONE32;
         }
+        // ---- look-ahead (a.prefetch >= 2; one workgroup per XCD, its last wave): the next round's winner is very likely one of the
+        //      best few records of THIS round that lost.  The wave reads the records again behind its own position loads (one wait
+        //      covers both), picks the best a.prefetch - 1 of them while the others scan the row, and touches their rows' positions
+        //      at the END of the apply phase -- its next load after that is the next round's positions, so nothing waits for the
+        //      touches, and they have a whole agreement to arrive in this XCD's L2.  The keys are those from before this round's
+        //      decrements: a guess, which is all a prefetch needs.
+        const bool looker = a.prefetch >= 2 && wg < 8u && wave == PL_THREADS / 64 - 1 && n_wg <= 256u;
+        unsigned long long lk_key[4] = {0, 0, 0, 0};
+        uint32_t lk_st[4] = {0, 0, 0, 0}, lk_ln[4] = {0, 0, 0, 0};
+        if (looker) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t sidx = (uint32_t)lane + 64u * (uint32_t)u;
+                if (sidx < n_wg) {
+                    const unsigned long long x0 = gran_load(all + (uint64_t)sidx * 4 + 0), x1 = gran_load(all + (uint64_t)sidx * 4 + 1),
+                                             x2 = gran_load(all + (uint64_t)sidx * 4 + 2), x3 = gran_load(all + (uint64_t)sidx * 4 + 3);
+                    lk_key[u] = ((x0 & 0xffffffffull) << 32) | (x1 & 0xffffffffull);
+                    lk_st[u] = (uint32_t)x2; lk_ln[u] = (uint32_t)x3;
+                }
+            }
+        }
+        uint32_t la_ps[2] = {0, 0}, la_pl[2] = {0, 0};
         const uint32_t grp = (uint32_t)tid / PL_LANES, gl = (uint32_t)tid % PL_LANES;
         constexpr uint32_t GROUPS = PL_THREADS / PL_LANES;
         for (uint32_t c0 = 0; c0 < wlen; c0 += a.chunk) {
             if (tid == 0) s_nI = 0;
             __syncthreads();
             PL_WAITLAP(6);                                           // (trace) waiting for the row's positions
+            if (c0 == 0) {
+                pf_sink += pf_own + pf_ahead;                            // what the touches of the last phases returned (arrived before the positions did)
+                pf_ahead = 0;
+                if (looker) {
 #pragma unroll
-            for (int u = 0; u < PL_ROW_PER; ++u) {
-                bool fresh = false;
-                if (pos[u] != NONE32) {
-                    const uint32_t bit = 1u << (pos[u] & 31u);
-                    fresh = (atomicAnd(&s_bits[pos[u] >> 5], ~bit) & bit) != 0;      // row hashes are distinct: no two lanes share a bit
+                    for (int u = 0; u < 4; ++u)
+                        if (lk_key[u] == top) lk_key[u] = 0;
+                    for (int rank_ = 0; rank_ < 2 && rank_ < (int)a.prefetch - 1; ++rank_) {   // the best, second best of the records that lost
+                        unsigned long long mine_k = 0;
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) mine_k = lk_key[u] > mine_k ? lk_key[u] : mine_k;
+                        const unsigned long long best_k = __shfl(wave_max(mine_k), 0);
+                        uint32_t ps = 0, pl = 0;
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                            if (best_k != 0 && lk_key[u] == best_k) { ps = lk_st[u]; pl = lk_ln[u]; lk_key[u] = 0; }
+                        const unsigned long long who = __ballot(pl != 0);
+                        const int src = who ? __ffsll((long long)who) - 1 : 0;
+                        la_ps[rank_] = __shfl(ps, src); la_pl[rank_] = __shfl(pl, src);
+                    }
                 }
-                const unsigned long long m = __ballot(fresh);
+            }
+            {
+                // all of a thread's test-and-clears are issued before the first result is used (the loop this replaces made
+                // PL_ROW_PER rounds of: returning LDS atomic -> ballot -> returning LDS atomic on the counter -> store), and a
+                // wave reserves room for ALL its hits of the chunk with one atomic
+                uint32_t old_w[PL_ROW_PER];
+#pragma unroll
+                for (int u = 0; u < PL_ROW_PER; ++u) {
+                    old_w[u] = 0;
+                    if (pos[u] != NONE32) old_w[u] = atomicAnd(&s_bits[pos[u] >> 5], ~(1u << (pos[u] & 31u)));   // row hashes are distinct: no two lanes share a bit
+                }
+                unsigned long long m[PL_ROW_PER];
+                uint32_t total = 0;
+#pragma unroll
+                for (int u = 0; u < PL_ROW_PER; ++u) {
+                    m[u] = __ballot(pos[u] != NONE32 && ((old_w[u] >> (pos[u] & 31u)) & 1u) != 0);
+                    total += (uint32_t)__popcll(m[u]);
+                }
                 uint32_t base = 0;
-                if (lane == 0 && m) base = atomicAdd(&s_nI, (uint32_t)__popcll(m));  // one LDS atomic per wave, not per hit
+                if (lane == 0 && total) base = atomicAdd(&s_nI, total);
                 base = __shfl(base, 0);
-                if (fresh) s_I[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = pos[u];
+#pragma unroll
+                for (int u = 0; u < PL_ROW_PER; ++u) {
+                    if ((m[u] >> lane) & 1ull) s_I[base + (uint32_t)__popcll(m[u] & ((1ull << lane) - 1ull))] = pos[u];
+                    base += (uint32_t)__popcll(m[u]);
+                }
             }
             {
                 const uint32_t n0 = c0 + a.chunk, n1 = n0 + a.chunk < wlen ? n0 + a.chunk : wlen;
@@ -1565,6 +1633,12 @@ __global__ __launch_bounds__(PL_THREADS) void gather_loop_kernel(LoopArgs a) {
             __syncthreads();
             PL_LAP(3);                                               // run bounds + postings + LDS decrements
         }
+        if (looker) {
+#pragma unroll
+            for (int rank_ = 0; rank_ < 2; ++rank_)
+                for (uint32_t i = (uint32_t)lane * 32u; i < la_pl[rank_]; i += 64u * 32u)      // one lane per 128-byte line
+                    pf_ahead += a.qpos[(uint64_t)la_ps[rank_] + i];
+        }
         // ---- bookkeeping (pick_kernel's record_pending) ----
         if (wg == 0 && tid == 0) {
             a.out_idx[rounds] = 0xffffffffull & ~top;
@@ -1575,6 +1649,7 @@ __global__ __launch_bounds__(PL_THREADS) void gather_loop_kernel(LoopArgs a) {
         if (rounds >= maxr) break;
     }
     // ---- hand the state back ----
+    if (pf_sink + pf_ahead == 0xdeadbeefu && a.dbg) a.dbg[15] = pf_sink;    // (keeps the touches' loads alive; never true in any way that matters)
     __syncthreads();
     if (timing) {
         a.dbg[7] = wall_clock64() - a.dbg[6];
@@ -2170,8 +2245,10 @@ hipError_t gather_launch_loop(GatherDev& g, hipStream_t stream, uint32_t n_wg, c
     if (sh && (sh->W == 0 || sh->W > (uint32_t)PL_THREADS || sh->rank >= sh->W || rowcap == 0)) return hipErrorInvalidValue;
     SMG_TRY(gather_loop_reserve(g, stream, n_wg, rowcap));
     a.xchg = g.loop_xchg;
-    static const bool prefetch = [] { const char* e = getenv("SMG_GATHER_PREFETCH"); return !e || atoi(e) != 0; }();
-    a.prefetch = prefetch ? 1u : 0u;
+    // 0: none; 1: every workgroup touches its own best row while the records travel; n >= 2: also, once the winner is known, one
+    // workgroup per XCD touches the rows of the n - 1 best records that lost (default 3: two rows ahead)
+    static const uint32_t ahead = [] { const char* e = getenv("SMG_GATHER_PREFETCH"); return e ? (uint32_t)atoi(e) : 3u; }();
+    a.prefetch = ahead;
     static const bool trace = getenv("SMG_GATHER_TRACE") != nullptr;
     a.dbg = trace ? g.loop_xchg + (size_t)2 * n_wg * 4 : nullptr;           // 16 words behind the granules
     a.gwin = g.loop_xchg + (size_t)2 * n_wg * 4 + 16;

@@ -795,7 +795,7 @@ def test_mixed_scaled_and_jaccard_ani_batched_vs_oracle(sm):
 def test_avg_containment_ani_mixed_scaled_asks_the_downsampled_sketches(sm):
     """compare.py:141-176 with return_ani: the avg form goes through FracMinHashComparison, whose containment_ani calls ask
     size_is_accurate() of the sketches ALREADY downsampled to the pair's scaled (sketchcomparison.py:53-70,143-170) -- a sketch
-    of ~450 hashes at scaled 1000 is trusted as given and not at scaled 4000 (~110 hashes); the containment / max forms ask
+    of ~250 hashes at scaled 1000 is trusted as given and not at scaled 4000 (~62 hashes); the containment / max forms ask
     the sketches as given (minhash.py:877-878,938-939).  Batched matrices == the per-pair object API, entry by entry."""
     from sourmash_amd.compare import compare_serial_avg_containment, compare_serial_containment, compare_serial_max_containment
     from sourmash_amd.sketchcomparison import FracMinHashComparison
@@ -804,7 +804,7 @@ def test_avg_containment_ani_mixed_scaled_asks_the_downsampled_sketches(sm):
     sigs = []
     for i, a in enumerate(big):
         mh = sm.MinHash(0, 31, scaled=1000)
-        mh.add_many(a if i % 2 == 0 else a[::22])                  # odd: ~450 hashes, trusted at 1000 only
+        mh.add_many(a if i % 2 == 0 else a[::40])                  # odd: ~250 hashes: trusted at scaled 1000 (p = 0.9986), not as ~62 at 4000 (0.89)
         if i % 3 == 2:
             mh = mh.downsample(scaled=4000)
         sigs.append(sm.SourmashSignature(mh, name=str(i)))
