@@ -987,7 +987,7 @@ def api_extras(extra, torch, np, dev, smd, synth_sketches, synth_gather_device):
             best = (t2 - t0, t1 - t0, t2 - t1, _xfer(lib))
         del ss
     r = extra.get("gather_1M_vs_100000", {})
-    kernel_ms = None if "total_ms" not in r else r["total_ms"]
+    kernel_ms = None if "total_ms" not in r else r["total_ms"]     # index build + every round on resident inputs (the line above)
     pcie_ms = db_bytes / (PCIE_GBS * 1e9) * 1e3
     extra["gather_api_c5"] = {
         "what": "SketchSet(list of 100,000 MinHash objects) -> .gather(query MinHash of 1e6 hashes, threshold_bp=50,000): wall clock of "

@@ -82,11 +82,12 @@ class _Handles:
         self.ptrs = (C.c_void_p * max(self.n, 1))(*[mh._get_objptr() for mh in self.keep])
 
 
-def _common_ptrs(ptrs, n, want_jaccard=True):
-    common = np.empty((n, n), dtype=np.uint32)
+def _common_ptrs(ptrs, n, want_jaccard=True, want_common=True):
+    "only the matrices asked for cross PCIe (the u32 matrix of 10,000 sketches is 400 MB, the f64 one 800 MB)"
+    common = np.empty((n, n), dtype=np.uint32) if want_common else None
     jac = np.empty((n, n), dtype=np.float64) if want_jaccard else None
     if n:
-        rustcall(lib.smgpu_compare_all_pairs, ptrs, n, common.ctypes.data_as(C.POINTER(C.c_uint32)),
+        rustcall(lib.smgpu_compare_all_pairs, ptrs, n, common.ctypes.data_as(C.POINTER(C.c_uint32)) if want_common else None,
                  jac.ctypes.data_as(C.POINTER(C.c_double)) if want_jaccard else None)
     return common, jac
 
@@ -249,7 +250,7 @@ def _jaccard_matrix(v, downsample):
     if (v.num != 0).all():
         return _num_ptrs(v.ptrs, v.n)
     if len(np.unique(v.max_hash)) == 1:
-        return _common_ptrs(v.ptrs, v.n, want_jaccard=True)[1]
+        return _common_ptrs(v.ptrs, v.n, want_jaccard=True, want_common=False)[1]
     assert downsample
     return _by_scaled_counts(v, lambda cm, sz, s: _jaccard_from_counts(cm, sz))
 

@@ -1092,7 +1092,7 @@ static void compare_device_csr(const uint64_t* d_hashes, const uint64_t* d_offse
 }
 
 // the hash vectors (or abundance vectors) of n sketches back to back into d_dst: worker threads pack pinned chunks, ONE H2D copy
-// per 64 MiB chunk (round 4: one pageable copy per sketch)
+// per 32 MiB chunk (round 4: one pageable copy per sketch)
 static void upload_rows(const SourmashKmerMinHash* const* mhs, uintptr_t n, const std::vector<uint64_t>& offsets, bool abunds,
                         void* d_dst, hipStream_t st) {
     std::vector<HostPiece> pieces(n);

@@ -1282,7 +1282,7 @@ __global__ __launch_bounds__(PL_THREADS) void gather_loop_kernel(LoopArgs a) {
 #define PL_WAITLAP(slot) do { if (a.dbg != nullptr && wg == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); PL_LAP(slot); } } while (0)
 #define PL_LAP(slot) do { if (timing) { const unsigned long long t_ = wall_clock64(); t_acc[slot] += t_ - t_mark; t_mark = t_; } } while (0)
     if (timing) a.dbg[6] = t_mark;
-    uint32_t pf_sink = 0, pf_ahead = 0;                           // what prefetch touches returned: folded in late, never meaningful
+    uint32_t pf_sink = 0;                                         // what prefetch touches returned: folded in late, never meaningful
     for (uint32_t epoch = 1;; ++epoch) {
         fail_epoch = epoch;
         // ---- local best of the owned rows -> this workgroup's record of the epoch ----
@@ -1326,7 +1326,11 @@ __global__ __launch_bounds__(PL_THREADS) void gather_loop_kernel(LoopArgs a) {
         //  they return is folded into a sink only after the round's positions have arrived, a wait that covers them anyway.)
         uint32_t pf_own = 0;
         constexpr int SWEEP_WAVES = 4;                               // the sweep reads with threads 0 .. n_wg - 1
-        if (a.prefetch && (wave >= SWEEP_WAVES || n_wg > SWEEP_WAVES * 64u)) {
+        if (a.prefetch == 2) {                                       // round 4's form, kept for the A/B (SMG_GATHER_PREFETCH=2)
+            const uint32_t ps = s_wstart, pl = s_wlen;
+            for (uint32_t i = (uint32_t)tid * 16u; i < pl; i += PL_THREADS * 16u)
+                (void)*reinterpret_cast<const volatile uint32_t*>(a.qpos + (uint64_t)ps + i);
+        } else if (a.prefetch && (wave >= SWEEP_WAVES || n_wg > SWEEP_WAVES * 64u)) {
             const uint32_t ps = s_wstart, pl = s_wlen;
             const uint32_t t0 = n_wg > SWEEP_WAVES * 64u ? (uint32_t)tid : (uint32_t)tid - SWEEP_WAVES * 64u;
             const uint32_t nt = n_wg > SWEEP_WAVES * 64u ? (uint32_t)PL_THREADS : (uint32_t)PL_THREADS - SWEEP_WAVES * 64u;
@@ -1480,56 +1484,13 @@ __global__ __launch_bounds__(PL_THREADS) void gather_loop_kernel(LoopArgs a) {
             const uint32_t i = (uint32_t)u * PL_THREADS + (uint32_t)tid;
             pos[u] = i < wlen && i < a.chunk ? row_pos(i) : NONE32;
         }
-        // ---- look-ahead (a.prefetch >= 2; one workgroup per XCD, its last wave): the next round's winner is very likely one of the
-        //      best few records of THIS round that lost.  The wave reads the records again behind its own position loads (one wait
-        //      covers both), picks the best a.prefetch - 1 of them while the others scan the row, and touches their rows' positions
-        //      at the END of the apply phase -- its next load after that is the next round's positions, so nothing waits for the
-        //      touches, and they have a whole agreement to arrive in this XCD's L2.  The keys are those from before this round's
-        //      decrements: a guess, which is all a prefetch needs.
-        const bool looker = a.prefetch >= 2 && wg < 8u && wave == PL_THREADS / 64 - 1 && n_wg <= 256u;
-        unsigned long long lk_key[4] = {0, 0, 0, 0};
-        uint32_t lk_st[4] = {0, 0, 0, 0}, lk_ln[4] = {0, 0, 0, 0};
-        if (looker) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const uint32_t sidx = (uint32_t)lane + 64u * (uint32_t)u;
-                if (sidx < n_wg) {
-                    const unsigned long long x0 = gran_load(all + (uint64_t)sidx * 4 + 0), x1 = gran_load(all + (uint64_t)sidx * 4 + 1),
-                                             x2 = gran_load(all + (uint64_t)sidx * 4 + 2), x3 = gran_load(all + (uint64_t)sidx * 4 + 3);
-                    lk_key[u] = ((x0 & 0xffffffffull) << 32) | (x1 & 0xffffffffull);
-                    lk_st[u] = (uint32_t)x2; lk_ln[u] = (uint32_t)x3;
-                }
-            }
-        }
-        uint32_t la_ps[2] = {0, 0}, la_pl[2] = {0, 0};
         const uint32_t grp = (uint32_t)tid / PL_LANES, gl = (uint32_t)tid % PL_LANES;
         constexpr uint32_t GROUPS = PL_THREADS / PL_LANES;
         for (uint32_t c0 = 0; c0 < wlen; c0 += a.chunk) {
             if (tid == 0) s_nI = 0;
             __syncthreads();
             PL_WAITLAP(6);                                           // (trace) waiting for the row's positions
-            if (c0 == 0) {
-                pf_sink += pf_own + pf_ahead;                            // what the touches of the last phases returned (arrived before the positions did)
-                pf_ahead = 0;
-                if (looker) {
-#pragma unroll
-                    for (int u = 0; u < 4; ++u)
-                        if (lk_key[u] == top) lk_key[u] = 0;
-                    for (int rank_ = 0; rank_ < 2 && rank_ < (int)a.prefetch - 1; ++rank_) {   // the best, second best of the records that lost
-                        unsigned long long mine_k = 0;
-#pragma unroll
-                        for (int u = 0; u < 4; ++u) mine_k = lk_key[u] > mine_k ? lk_key[u] : mine_k;
-                        const unsigned long long best_k = __shfl(wave_max(mine_k), 0);
-                        uint32_t ps = 0, pl = 0;
-#pragma unroll
-                        for (int u = 0; u < 4; ++u)
-                            if (best_k != 0 && lk_key[u] == best_k) { ps = lk_st[u]; pl = lk_ln[u]; lk_key[u] = 0; }
-                        const unsigned long long who = __ballot(pl != 0);
-                        const int src = who ? __ffsll((long long)who) - 1 : 0;
-                        la_ps[rank_] = __shfl(ps, src); la_pl[rank_] = __shfl(pl, src);
-                    }
-                }
-            }
+            if (c0 == 0) pf_sink += pf_own;                          // what the touches returned (they arrived before the positions did)
             {
                 // all of a thread's test-and-clears are issued before the first result is used (the loop this replaces made
                 // PL_ROW_PER rounds of: returning LDS atomic -> ballot -> returning LDS atomic on the counter -> store), and a
@@ -1633,12 +1594,6 @@ __global__ __launch_bounds__(PL_THREADS) void gather_loop_kernel(LoopArgs a) {
             __syncthreads();
             PL_LAP(3);                                               // run bounds + postings + LDS decrements
         }
-        if (looker) {
-#pragma unroll
-            for (int rank_ = 0; rank_ < 2; ++rank_)
-                for (uint32_t i = (uint32_t)lane * 32u; i < la_pl[rank_]; i += 64u * 32u)      // one lane per 128-byte line
-                    pf_ahead += a.qpos[(uint64_t)la_ps[rank_] + i];
-        }
         // ---- bookkeeping (pick_kernel's record_pending) ----
         if (wg == 0 && tid == 0) {
             a.out_idx[rounds] = 0xffffffffull & ~top;
@@ -1649,7 +1604,7 @@ __global__ __launch_bounds__(PL_THREADS) void gather_loop_kernel(LoopArgs a) {
         if (rounds >= maxr) break;
     }
     // ---- hand the state back ----
-    if (pf_sink + pf_ahead == 0xdeadbeefu && a.dbg) a.dbg[15] = pf_sink;    // (keeps the touches' loads alive; never true in any way that matters)
+    if (pf_sink == 0xdeadbeefu && a.dbg) a.dbg[15] = pf_sink;    // (keeps the touches' loads alive; never true in any way that matters)
     __syncthreads();
     if (timing) {
         a.dbg[7] = wall_clock64() - a.dbg[6];
@@ -2245,10 +2200,12 @@ hipError_t gather_launch_loop(GatherDev& g, hipStream_t stream, uint32_t n_wg, c
     if (sh && (sh->W == 0 || sh->W > (uint32_t)PL_THREADS || sh->rank >= sh->W || rowcap == 0)) return hipErrorInvalidValue;
     SMG_TRY(gather_loop_reserve(g, stream, n_wg, rowcap));
     a.xchg = g.loop_xchg;
-    // 0: none; 1: every workgroup touches its own best row while the records travel; n >= 2: also, once the winner is known, one
-    // workgroup per XCD touches the rows of the n - 1 best records that lost (default 3: two rows ahead)
-    static const uint32_t ahead = [] { const char* e = getenv("SMG_GATHER_PREFETCH"); return e ? (uint32_t)atoi(e) : 3u; }();
-    a.prefetch = ahead;
+    // 0: none; 1 (default): every workgroup touches its own best row while the records travel, with plain loads whose values are
+    // folded into a sink a phase later; 2: the same with round 4's volatile loads (each followed by s_waitcnt vmcnt(0)).
+    // (Round 5 also tried touching the rows of the best records that LOST, for the next round: the state it carries across the
+    //  phases of a round pushed this kernel from 36 to 136 bytes of scratch per lane and the round from 12 to 17-20 us.)
+    static const uint32_t pf = [] { const char* e = getenv("SMG_GATHER_PREFETCH"); return e ? (uint32_t)atoi(e) : 1u; }();
+    a.prefetch = pf;
     static const bool trace = getenv("SMG_GATHER_TRACE") != nullptr;
     a.dbg = trace ? g.loop_xchg + (size_t)2 * n_wg * 4 : nullptr;           // 16 words behind the granules
     a.gwin = g.loop_xchg + (size_t)2 * n_wg * 4 + 16;

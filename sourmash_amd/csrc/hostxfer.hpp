@@ -35,7 +35,7 @@ struct HostPiece {            // `bytes` bytes at `src` belong at byte offset `d
 
 class HostXfer {
   public:
-    static constexpr size_t CHUNK = (size_t)64 << 20;      // per ring slot: large enough that starting the worker threads is noise
+    static constexpr size_t CHUNK = (size_t)32 << 20;      // per ring slot (64 MiB slots and 16 workers measured slower: 107 vs 93 ms for 4 GB)
     static HostXfer& get() { static HostXfer* x = new HostXfer(); return *x; }      // (leaked like the context: HIP may be gone at exit)
 
     struct Stats { uint64_t h2d_bytes = 0, d2h_bytes = 0, h2d_ns = 0, d2h_ns = 0, calls = 0; };
@@ -48,7 +48,7 @@ class HostXfer {
             cpu_set_t set;
             if (sched_getaffinity(0, sizeof(set), &set) == 0) c = std::min<unsigned>(c, (unsigned)CPU_COUNT(&set));
             if (const char* e = getenv("SMG_XFER_THREADS")) c = (unsigned)std::max(1, atoi(e));
-            return std::min(c, 16u);
+            return std::min(c, 8u);
         }();
         return n;
     }

@@ -8,13 +8,19 @@
 //   residues_kernel   protein input: upper-case + alphabet mapping, one lane per byte
 //   translate_kernel  DNA input: one lane per residue of the six translations, written as six segments separated
 //                     by a 0xFF byte (no residue maps to it), so that one window kernel serves both inputs
-//   window_kernel     one lane per window start: skip windows touching a separator, MurmurHash3 of the k bytes,
-//                     keep 1 <= h <= thr (append) or write per position (dense)
-// Residue k-mers are short keys of arbitrary length (7 ... 60 bytes); the byte-wise hash of murmur3.hpp is used.
+//   window_fast_kernel<NB>  (round 5; k <= 79 residues) a lane owns the 8 window starts of one aligned word of the residue
+//                     buffer and hashes its windows from registers (residue_core.hpp); kept hashes are staged in LDS and leave
+//                     in batches (one global atomic per batch -- one per HIT, as the kernel below does it, is 5 million
+//                     returning atomics on one word per 10^9 windows at scaled = 200: that alone was most of its 53 ms)
+//   window_kernel     longer windows: one lane per window start, the k bytes copied out and hashed byte by byte
+// both: skip windows touching a separator; keep 1 <= h <= thr (append) or write per position (dense).
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
+#include <string.h>
 #include "device_api.hpp"
 #include "murmur3.hpp"
 #include "residues.hpp"
+#include "residue_core.hpp"
 
 namespace smg {
 
@@ -78,6 +84,72 @@ __global__ __launch_bounds__(256) void window_kernel(const uint8_t* __restrict__
     }
 }
 
+constexpr int RW_BLOCK = 256;
+constexpr int RW_OUT_CAP = 2048;     // LDS staging entries for kept hashes (16 KiB)
+
+template <int NB, bool DENSE>
+__global__ __launch_bounds__(RW_BLOCK) void window_fast_kernel(const uint64_t* __restrict__ aa64, uint64_t n, ResidueTail t, uint64_t seed,
+                                                               uint64_t thr, uint64_t* __restrict__ out,
+                                                               unsigned long long* __restrict__ out_count, uint64_t cap, uint64_t n_lanes) {
+    __shared__ uint64_t s_out[RW_OUT_CAP];
+    __shared__ unsigned int s_cnt;
+    __shared__ unsigned long long s_base;
+    const int tid = threadIdx.x;
+    if (tid == 0) s_cnt = 0;
+    __syncthreads();
+    auto flush = [&](unsigned int at_least) {                            // (called by every thread of the block)
+        __syncthreads();
+        const unsigned int cnt = s_cnt;
+        if (cnt >= at_least && cnt) {
+            const unsigned int m = cnt < (unsigned)RW_OUT_CAP ? cnt : (unsigned)RW_OUT_CAP;
+            if (tid == 0) s_base = atomicAdd(out_count, (unsigned long long)m);
+            __syncthreads();
+            const unsigned long long b = s_base;
+            for (unsigned int i = tid; i < m; i += RW_BLOCK)
+                if (b + i < cap) out[b + i] = s_out[i];
+            __syncthreads();
+            if (tid == 0) s_cnt = 0;
+        }
+        __syncthreads();
+    };
+    const uint64_t rounds = (n_lanes + (uint64_t)gridDim.x * RW_BLOCK - 1) / ((uint64_t)gridDim.x * RW_BLOCK);
+    for (uint64_t r = 0; r < rounds; ++r) {                              // (uniform trip count: the flush has barriers)
+        const uint64_t g = (r * gridDim.x + blockIdx.x) * RW_BLOCK + tid;
+        if (g < n_lanes)
+            residue_windows_lane<NB>(aa64, n, g, t, seed, [&](uint64_t start, uint64_t h) {
+                if constexpr (DENSE) {
+                    if (start < cap) out[start] = h;
+                } else if ((h - 1) < thr) {
+                    const unsigned int idx = atomicAdd(&s_cnt, 1u);
+                    if (idx < (unsigned)RW_OUT_CAP) {
+                        s_out[idx] = h;
+                    } else {                                             // pathological density: straight to HBM
+                        const unsigned long long gi = atomicAdd(out_count, 1ull);
+                        if (gi < cap) out[gi] = h;
+                    }
+                }
+            });
+        if constexpr (!DENSE) flush(RW_OUT_CAP / 2);
+    }
+    if constexpr (!DENSE) flush(1);
+}
+
+template <int NB>
+hipError_t window_fast_launch(const uint8_t* d_aa, uint64_t n, uint32_t k, uint64_t seed, uint64_t thr, uint64_t* d_out,
+                              unsigned long long* d_count, uint64_t cap, bool dense, hipStream_t stream) {
+    const uint64_t n_lanes = (n - k + 1 + RW_P - 1) / RW_P;              // lanes that own at least one window start
+    const uint64_t blocks = (n_lanes + RW_BLOCK - 1) / RW_BLOCK;
+    const unsigned grid = (unsigned)(blocks < 1 ? 1 : (blocks > 256 * 8 ? 256 * 8 : blocks));
+    const ResidueTail t = residue_tail(k);
+    if (dense)
+        hipLaunchKernelGGL((window_fast_kernel<NB, true>), dim3(grid), dim3(RW_BLOCK), 0, stream, (const uint64_t*)d_aa, n, t, seed, thr, d_out,
+                           d_count, cap, n_lanes);
+    else
+        hipLaunchKernelGGL((window_fast_kernel<NB, false>), dim3(grid), dim3(RW_BLOCK), 0, stream, (const uint64_t*)d_aa, n, t, seed, thr, d_out,
+                           d_count, cap, n_lanes);
+    return hipGetLastError();
+}
+
 unsigned grid_for(uint64_t n) {
     const uint64_t b = (n + 255) / 256;
     return (unsigned)(b < 1 ? 1 : (b > 8192 ? 8192 : b));
@@ -108,6 +180,18 @@ hipError_t residue_windows_launch(const uint8_t* d_aa, uint64_t n, uint32_t k, u
                                   unsigned long long* d_count, uint64_t cap, bool dense, hipStream_t stream) {
     if (k == 0 || k > (uint32_t)MAX_RESIDUES) return hipErrorInvalidValue;
     if (n < k) return hipSuccess;
+    // the register-window form: windows of up to 79 residues over an 8-byte aligned buffer (every buffer the library makes is);
+    // SMG_RESIDUE_KERNEL=bytes keeps the byte-wise kernel (tests: both against the oracle)
+    static const bool bytes_only = [] { const char* e = getenv("SMG_RESIDUE_KERNEL"); return e && !strcmp(e, "bytes"); }();
+    if (!bytes_only && k / 16 <= (uint32_t)RW_MAX_NB && ((uintptr_t)d_aa & 7) == 0) {
+        switch (k / 16) {
+        case 0: return window_fast_launch<0>(d_aa, n, k, seed, thr, d_out, d_count, cap, dense, stream);
+        case 1: return window_fast_launch<1>(d_aa, n, k, seed, thr, d_out, d_count, cap, dense, stream);
+        case 2: return window_fast_launch<2>(d_aa, n, k, seed, thr, d_out, d_count, cap, dense, stream);
+        case 3: return window_fast_launch<3>(d_aa, n, k, seed, thr, d_out, d_count, cap, dense, stream);
+        default: return window_fast_launch<4>(d_aa, n, k, seed, thr, d_out, d_count, cap, dense, stream);
+        }
+    }
     hipLaunchKernelGGL(window_kernel, dim3(grid_for(n - k + 1)), dim3(256), 0, stream, d_aa, n, k, seed, thr, d_out, d_count,
                        cap, dense ? 1 : 0);
     return hipGetLastError();

@@ -127,7 +127,9 @@ def test_golden_translated_genome_and_gene_benchmarks(sm):
     assert round(aa["NP_414544.1"].similarity(tr["gi|556503834:337-2799"]), 3) == 0.0
 
 
-@pytest.mark.parametrize("moltype,k,scaled", [("protein", 10, 20), ("dayhoff", 16, 20), ("hp", 42, 20)])
+# (windows of up to 79 residues take the register-window kernel, residue_core.hpp; longer ones the byte-wise kernel: both here)
+@pytest.mark.parametrize("moltype,k,scaled", [("protein", 10, 20), ("dayhoff", 16, 20), ("hp", 42, 20), ("protein", 7, 5), ("dayhoff", 33, 20),
+                                              ("hp", 79, 20), ("hp", 85, 20)])
 def test_scaled_sketches_vs_oracle(sm, moltype, k, scaled, track_abundance):
     rng = np.random.default_rng(5)
     dna = "".join(rng.choice(list("ACGTacgtN"), size=30_000))
