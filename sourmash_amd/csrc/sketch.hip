@@ -86,29 +86,10 @@ __global__ __launch_bounds__(SK_BLOCK) void first_invalid_kernel(const uint8_t* 
     if (best != ~0ull) atomicMin(first, best);
 }
 
-template <int K, int P>
-static hipError_t launch_k(const uint8_t* d_seq, uint64_t len, uint64_t seed, uint64_t thr, uint64_t* d_out,
-                           unsigned long long* d_count, uint64_t cap, bool dense, hipStream_t stream) {
-    constexpr uint64_t TILE = (uint64_t)SK_BLOCK * P;
-    const uint32_t skip = (uint32_t)((uintptr_t)d_seq & 15);     // realign: 16-byte loads need an aligned base
-    d_seq -= skip;
-    len += skip;
-    const uint64_t n_tiles = (len + TILE - 1) / TILE;
-    if (n_tiles == 0) return hipSuccess;
-    const uint64_t max_blocks = 256ull * 8;   // 256 CUs x 8 resident workgroups
-    const unsigned grid = (unsigned)(n_tiles < max_blocks ? n_tiles : max_blocks);
-    if (dense)
-        hipLaunchKernelGGL((sketch_dna_kernel<K, P, true>), dim3(grid), dim3(SK_BLOCK), 0, stream, d_seq, len, seed,
-                           thr, d_out, d_count, cap, n_tiles, skip);
-    else
-        hipLaunchKernelGGL((sketch_dna_kernel<K, P, false>), dim3(grid), dim3(SK_BLOCK), 0, stream, d_seq, len, seed,
-                           thr, d_out, d_count, cap, n_tiles, skip);
-    return hipGetLastError();
-}
-
 // The register-window kernel is instantiated for EVERY ksize 1 .. 128 (the reference treats all k alike,
 // signature.rs:246-306; tests/test_kmer_core_cpu.py checks each instantiation against the oracle on the host): k = 1 .. 64 in
-// this unit, 65 .. 128 in sketch_long.hip.  Longer k-mers still take the byte-wise generic kernel.
+// this unit, 65 .. 128 in sketch_long.hip, the per-position form of all of them in sketch_dense.hip.  Longer k-mers still take the
+// byte-wise generic kernel.
 constexpr int FAST_MAX_K = 128;
 constexpr int FAST_HERE_K = 64;
 
@@ -122,12 +103,8 @@ static hipError_t sketch_any(const uint8_t* d_seq, uint64_t len, uint32_t k, uin
                                                              : sparse_launcher_long(k);
         return f(d_seq, len, seed, thr, d_out, d_count, cap, false, stream);
     }
-    if (!generic_only) switch (k) {                                    // per-position output (seq_to_hashes): the usual ksizes
-    case 21: return launch_k<21, 16>(d_seq, len, seed, thr, d_out, d_count, cap, dense, stream);
-    case 31: return launch_k<31, 16>(d_seq, len, seed, thr, d_out, d_count, cap, dense, stream);
-    case 51: return launch_k<51, 16>(d_seq, len, seed, thr, d_out, d_count, cap, dense, stream);
-    default: break;
-    }
+    if (dense && k <= (uint32_t)FAST_MAX_K && !generic_only)          // per-position output (seq_to_hashes): every k <= 128 (sketch_dense.hip)
+        return dense_launcher(k)(d_seq, len, seed, thr, d_out, d_count, cap, true, stream);
     if (k > (uint32_t)GENERIC_MAX_K) return hipErrorInvalidValue;
     const uint64_t n_tiles = (len + GENERIC_TILE - 1) / GENERIC_TILE;
     const uint64_t max_blocks = 256ull * 8;

@@ -140,6 +140,48 @@ static sketch_launch_fn sparse_launcher_from(uint32_t k, std::integer_sequence<i
     static const sketch_launch_fn table[] = {&launch_sparse_k<K0 + KS + 1>...};
     return table[k - K0 - 1];
 }
+// the per-position form (kmerminhash_seq_to_hashes: one hash per k-mer start, 0 for bad k-mers) at P = 16 for one ksize
+template <int K>
+static hipError_t launch_dense_k(const uint8_t* d_seq, uint64_t len, uint64_t seed, uint64_t thr, uint64_t* d_out,
+                                 unsigned long long* d_count, uint64_t cap, bool, hipStream_t stream) {
+    constexpr uint64_t TILE = (uint64_t)SK_BLOCK * 16;
+    const uint32_t skip = (uint32_t)((uintptr_t)d_seq & 15);
+    d_seq -= skip;
+    len += skip;
+    const uint64_t n_tiles = (len + TILE - 1) / TILE;
+    if (n_tiles == 0) return hipSuccess;
+    const uint64_t max_blocks = 256ull * 8;
+    const unsigned grid = (unsigned)(n_tiles < max_blocks ? n_tiles : max_blocks);
+    hipLaunchKernelGGL((sketch_dna_kernel<K, 16, true>), dim3(grid), dim3(SK_BLOCK), 0, stream, d_seq, len, seed, thr, d_out,
+                       d_count, cap, n_tiles, skip);
+    return hipGetLastError();
+}
+template <int K0, int... KS>
+static sketch_launch_fn dense_launcher_from(uint32_t k, std::integer_sequence<int, KS...>) {
+    static const sketch_launch_fn table[] = {&launch_dense_k<K0 + KS + 1>...};
+    return table[k - K0 - 1];
+}
+// sketch_dense.hip, compiled as eight parts of 16 ksizes each: k = 1 .. 16, ..., 113 .. 128
+sketch_launch_fn dense_launcher_0(uint32_t k);
+sketch_launch_fn dense_launcher_1(uint32_t k);
+sketch_launch_fn dense_launcher_2(uint32_t k);
+sketch_launch_fn dense_launcher_3(uint32_t k);
+sketch_launch_fn dense_launcher_4(uint32_t k);
+sketch_launch_fn dense_launcher_5(uint32_t k);
+sketch_launch_fn dense_launcher_6(uint32_t k);
+sketch_launch_fn dense_launcher_7(uint32_t k);
+inline sketch_launch_fn dense_launcher(uint32_t k) {
+    switch ((k - 1u) / 16u) {
+    case 0: return dense_launcher_0(k);
+    case 1: return dense_launcher_1(k);
+    case 2: return dense_launcher_2(k);
+    case 3: return dense_launcher_3(k);
+    case 4: return dense_launcher_4(k);
+    case 5: return dense_launcher_5(k);
+    case 6: return dense_launcher_6(k);
+    default: return dense_launcher_7(k);
+    }
+}
 // sketch_long.hip, compiled as four parts: k = 65 .. 80, 81 .. 96, 97 .. 112, 113 .. 128
 sketch_launch_fn sparse_launcher_long_0(uint32_t k);
 sketch_launch_fn sparse_launcher_long_1(uint32_t k);

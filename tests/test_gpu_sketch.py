@@ -111,18 +111,19 @@ def test_random_vs_oracle(sm, k):
 
 
 def test_every_ksize_on_the_gpu(sm):
-    "k = 1 .. 128 dispatch to instantiations of the register-window kernel, longer k-mers to the byte-wise one: all vs the oracle"
+    """k = 1 .. 128 dispatch to instantiations of the register-window kernel -- the appending form (sketch.hip, sketch_long.hip) and
+    the per-position form (sketch_dense.hip: kmerminhash_seq_to_hashes) alike -- longer k-mers to the byte-wise one: all vs the oracle"""
     rng = np.random.default_rng(77)
     s = bytearray(_rand_dna(rng, 40_000, b"ACGTacgt"))
     for i in range(11, len(s), 1013):
         s[i] = ord("N")
     s = bytes(s)
-    for k in list(range(1, 66)) + [79, 80, 81, 96, 97, 112, 113, 127, 128, 129, 200]:
+    for k in list(range(1, 129)) + [129, 200]:
         mh = sm.MinHash(0, k, scaled=4)
         mh.add_sequence_buffer(s)
         assert np.array_equal(mh._mins_array(), oracle.sketch_dna_bulk(s, k, scaled=4, nthreads=4)), k
-        ordered = mh.seq_to_hashes(s[:300].decode(), force=True, bad_kmers_as_zeroes=True)      # per-position output
-        assert ordered == [h or 0 for h in oracle.seq_to_hashes(s[:300], k, force=True, bad_kmers_as_zeroes=True)], k
+        ordered = mh.seq_to_hashes(s[:4200].decode(), force=True, bad_kmers_as_zeroes=True)     # per-position output (two tiles of the kernel)
+        assert ordered == [h or 0 for h in oracle.seq_to_hashes(s[:4200], k, force=True, bad_kmers_as_zeroes=True)], k
 
 
 def test_abundance_and_num(sm):
