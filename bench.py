@@ -58,7 +58,7 @@ PMC_GATHER_FILE = _newest("profiles/r04_gather_pmc.txt", "profiles/r03_gather_pm
 PMC_COMPARE_FILE = _newest("profiles/r04_compare_pmc.txt", "profiles/r03_compare_pmc.txt")
 COMPARE_BITS_SOURCES = ["bitindex.hip"]
 SKETCH_SOURCES = ["sketch.hip", "sketch_kernel.hpp", "kmer_core.hpp", "murmur3.hpp"]
-GATHER_SOURCES = ["gather.hip", "qindex.hpp"]
+GATHER_SOURCES = ["gather.hip", "overlap.hip", "gather_parts.hpp", "qindex.hpp"]
 PMC_C2_INPUT_BYTES = 9_990_000_999                        # the launch the sketch counters were taken on (default C2 batch)
 N_SIMDS = 1024
 
@@ -420,7 +420,7 @@ def gather_counters(db_bytes):
         if f is None or w is None:
             return None, None, f"{PMC_GATHER_FILE} has no rows for {k}"
         build += cal.bytes_read(f) + cal.bytes_written(w)
-    ok = next((k for k in ("overlap_lean_kernel<0>", "overlap_wide_kernel", "stream_lookup_kernel<3>") if pmc.get(k, "FETCH_SIZE") is not None), None)
+    ok = next((k for k in ("overlap_lean_kernel<0>", "stream_lookup_kernel") if pmc.get(k, "FETCH_SIZE") is not None), None)
     fo, wo = (pmc.get(ok, "FETCH_SIZE"), pmc.get(ok, "WRITE_SIZE")) if ok else (None, None)
     over = None if fo is None else int(cal.bytes_read(fo) + (cal.bytes_written(wo) if wo is not None else 0))
     return int(build), over, (PMC_GATHER_FILE + ": FETCH_SIZE / WRITE_SIZE (KiB per dispatch, tools/bench_gather.py under separate --pmc passes) turned "

@@ -32,6 +32,7 @@
 #include "wavemask.hpp"
 #include <chrono>
 #include "qindex.hpp"
+#include "gather_parts.hpp"
 
 namespace smg {
 
@@ -113,13 +114,13 @@ constexpr int BR_THREADS = 512;      // 64 KB of LDS per workgroup (u16 slots, t
 //            streams, i.e. it has that many lines open: the L2 write-combines them (64 resident workgroups x 16 KB).
 //   pass 2b  a window of BR_SUB lists goes to BR_GROUPS workgroups on ONE XCD; each counting-sorts the entries of its
 //            row blocks by list in LDS and writes every list's run (about a line) with consecutive lanes.
-constexpr int BR_SUB = 256;                       // lists per window of the final scatter
-constexpr int BR_SUB_BITS = 8;
+// (BR_SUB = 256 lists per window of the final scatter, BR_SUB_BITS: gather_parts.hpp -- the staging kernel of overlap.hip packs by them)
 constexpr int BR_NSUB = BR_RANGE / BR_SUB;        // sub-ranges per range
 constexpr int BR_ROWBITS = 32 - BR_SUB_BITS;      // entry = (row << 8) | list within the window
 constexpr int BR_GROUPS = 8;                      // workgroups per window in pass 2b (each takes B / 8 row blocks)
 constexpr int BR_SORT_CAP = 12288;                // entries a pass-2b workgroup sorts at a time (48 KB of LDS)
 static_assert((1 << BR_SUB_BITS) == BR_SUB, "");
+constexpr int MS_BMAX = 64;                      // row blocks the staged builder's directory and scatter are laid out for
 
 __global__ __launch_bounds__(256) void build_bounds_kernel(const uint64_t* __restrict__ Q, uint32_t R,
                                                            const uint64_t* __restrict__ hashes,
@@ -147,8 +148,8 @@ __global__ __launch_bounds__(256) void build_bounds_kernel(const uint64_t* __res
 }
 
 // MODE 0: pass 1 (lookups, query positions, histogram, counters)   MODE 1: direct fill (one store per posting into its list)
-// MODE 2: pass 2a of the two-level fill (postings of this workgroup re-partitioned by sub-range into `inter`)
-// MODE 3: overlaps only (search / prefetch over a large query): lookups and counters, nothing else is read or written
+// (Rounds 1-4 also had a MODE 2 -- pass 2a by plain 4-byte stores into 128 open streams -- and a MODE 3 -- the overlap pass by
+//  lookups in L2; build_partition_kernel and the streaming kernels of overlap.hip replaced them and they are gone.)
 template <int MODE>
 __global__ __launch_bounds__(BR_THREADS) void build_range_kernel(QIndex qi, const uint64_t* __restrict__ hashes,
                                                           const uint64_t* __restrict__ offsets, uint64_t ndb,
@@ -156,14 +157,12 @@ __global__ __launch_bounds__(BR_THREADS) void build_range_kernel(QIndex qi, cons
                                                           uint64_t rows_per_block, uint32_t* __restrict__ partial,
                                                           const uint64_t* __restrict__ post_off,
                                                           uint32_t* __restrict__ post_rows, unsigned long long* counters,
-                                                          uint32_t* __restrict__ qpos, uint32_t* __restrict__ subcnt,
-                                                          const uint32_t* __restrict__ inter_off, uint32_t* __restrict__ inter) {
+                                                          uint32_t* __restrict__ qpos, uint32_t* __restrict__ subcnt) {
+    static_assert(MODE == 0 || MODE == 1, "");
     constexpr bool FILL = MODE == 1;
-    constexpr bool PART = MODE == 2;
-    constexpr bool COUNT = MODE == 0 || MODE == 3;
+    constexpr bool COUNT = MODE == 0;
     // pass 1: histogram; direct fill: cursors.  A block holds < 65536 rows and a row adds at most 1 to a slot, so 16 bits do.
-    __shared__ uint32_t s_slot[(MODE == 3 || PART) ? 1 : BR_RANGE / 2];
-    __shared__ uint32_t s_gbase[BR_NSUB], s_gcur[BR_NSUB];    // pass 2a: start and fill of this workgroup's BR_NSUB streams
+    __shared__ uint32_t s_slot[BR_RANGE / 2];
     // Launch order: ranges in groups of 8, range (8g + x) entirely on workgroup ids = x mod 8, i.e. on one XCD (workgroups
     // are dealt to the 8 XCDs round-robin), blocks in ascending order.  The 4-byte stores of pass 2 that fill one posting
     // list then meet in a single L2, whose working set is one open cache line per list of the range.
@@ -172,14 +171,7 @@ __global__ __launch_bounds__(BR_THREADS) void build_range_kernel(QIndex qi, cons
     if (r >= R) return;
     const uint64_t j0 = (uint64_t)r * BR_RANGE;
     const uint32_t nj = (uint32_t)(qi.nq - j0 < (uint64_t)BR_RANGE ? qi.nq - j0 : (uint64_t)BR_RANGE);
-    if (MODE != 3 && !PART)
-        for (int k = threadIdx.x; k < BR_RANGE / 2; k += BR_THREADS) s_slot[k] = 0;
-    if (PART) {
-        for (int k = threadIdx.x; k < BR_NSUB; k += BR_THREADS) {
-            s_gbase[k] = inter_off[((uint64_t)r * BR_NSUB + k) * B + b];
-            s_gcur[k] = 0;
-        }
-    }
+    for (int k = threadIdx.x; k < BR_RANGE / 2; k += BR_THREADS) s_slot[k] = 0;
     __syncthreads();
     const uint64_t d_lo = (uint64_t)b * rows_per_block;
     const uint64_t d_hi = d_lo + rows_per_block < ndb ? d_lo + rows_per_block : ndb;
@@ -265,11 +257,7 @@ __global__ __launch_bounds__(BR_THREADS) void build_range_kernel(QIndex qi, cons
             const uint32_t first = (uint32_t)__shfl((int)excl, h);
             uint32_t j = NONE32;
             if (t < total) {
-                if (PART) {
-                    // read once, never again: a streaming (non-temporal) load, so that the 2 GB of positions flowing through
-                    // do not push the partially written lines of the output streams out of the L2
-                    j = __builtin_nontemporal_load(&qpos[start + (t - first)]);
-                } else if (FILL) {
+                if (FILL) {
                     j = qpos[start + (t - first)];                  // pass 1 left it there
                 } else {
                     j = q_find(qi, hashes[start + (t - first)]);
@@ -277,14 +265,7 @@ __global__ __launch_bounds__(BR_THREADS) void build_range_kernel(QIndex qi, cons
                 }
             }
             const bool hit = j != NONE32;
-            if (PART) {
-                if (hit) {
-                    const uint32_t k = j - (uint32_t)j0;
-                    const uint32_t sub = k >> BR_SUB_BITS;
-                    const uint32_t at = atomicAdd(&s_gcur[sub], 1u);                 // rank within this workgroup's stream
-                    inter[(uint64_t)s_gbase[sub] + at] = ((uint32_t)(dbase + (uint64_t)h) << BR_SUB_BITS) | (k & (BR_SUB - 1));
-                }
-            } else if (hit) {
+            if (hit) {
                 const uint32_t k = j - (uint32_t)j0;                // < nj: the slice lies inside the range
                 const uint32_t sh = 16u * (k & 1u);
                 if (FILL) {
@@ -307,8 +288,7 @@ __global__ __launch_bounds__(BR_THREADS) void build_range_kernel(QIndex qi, cons
         }
         if (COUNT && lane < BR_EPW && row_hits) atomicAdd(&counters[d], (unsigned long long)row_hits);
     }
-    if (FILL || MODE == 3) return;
-    if (PART) return;
+    if (FILL) return;
     __syncthreads();
     uint32_t* out = partial + (uint64_t)b * qi.nq + j0;
     for (uint32_t k = threadIdx.x; k < nj; k += BR_THREADS) out[k] = (s_slot[k >> 1] >> (16u * (k & 1u))) & 0xffffu;
@@ -327,7 +307,7 @@ __global__ __launch_bounds__(BR_THREADS) void build_range_kernel(QIndex qi, cons
     }
 }
 
-// pass 2a with staging (the default): the same walk as build_range_kernel<2>, but the workgroup moves through its rows in
+// pass 2a with staging: the walk of build_range_kernel over the positions pass 1 left, but the workgroup moves through its rows in
 // chunks of 8 waves x 16 rows with all waves in step; an entry's final slot in its stream is reserved at once (an LDS
 // counter per stream), the entry itself waits in LDS -- stream k's entries of the chunk at s_stage[k][slot - chunk start]
 // -- and after the chunk every stream's part goes out with consecutive lanes (~80 entries = 330 bytes at C5).  An entry
@@ -662,43 +642,6 @@ __global__ __launch_bounds__(256) void build_merge_counts_kernel(uint32_t* __res
         }
     }
     post_cnt[j] = run;
-}
-
-// The same for pass 1 through the lean kernel (overlap_lean_kernel<.., true>): part16 [n_sub][nq] holds what each of the n_sub
-// workgroups counted, row block b of the builder is the `m` consecutive workgroups b * m ...  A workgroup takes one window of
-// BR_SUB lists: thread t walks list j0 + t through the blocks, writes the block's exclusive prefix to partial[b][j] and leaves
-// the list's total in post_cnt[j]; the window's postings per block (subcnt, what pass 2 lays its intermediate buffer out by)
-// are summed from LDS afterwards.  B <= 64.
-constexpr int MS_BMAX = 64;
-__global__ __launch_bounds__(BR_SUB) void build_merge_sub_kernel(const uint16_t* __restrict__ part16, uint32_t n_sub, uint32_t m, uint32_t B,
-                                                                 uint64_t nq, uint32_t* __restrict__ partial,
-                                                                 unsigned long long* __restrict__ post_cnt, uint32_t* __restrict__ subcnt) {
-    __shared__ uint16_t s_c[MS_BMAX][BR_SUB + 2];                      // (+ 2: rows start on different banks)
-    const uint32_t w = blockIdx.x, t = threadIdx.x;
-    const uint64_t j = (uint64_t)w * BR_SUB + t;
-    const bool have = j < nq;
-    uint32_t run = 0;
-    for (uint32_t b = 0; b < B; ++b) {
-        uint32_t c = 0;
-        if (have) {
-            const uint32_t i0 = b * m, i1 = i0 + m < n_sub ? i0 + m : n_sub;
-            for (uint32_t i = i0; i < i1; ++i) c += part16[(uint64_t)i * nq + j];
-            partial[(uint64_t)b * nq + j] = run;
-        }
-        s_c[b][t] = (uint16_t)c;                                        // a block has < 65,536 rows
-        run += c;
-    }
-    if (j <= nq) post_cnt[j] = run;                                     // (post_cnt[nq] = 0 for the scan)
-    __syncthreads();
-    if ((uint64_t)w * BR_SUB >= nq) return;
-    // 4 threads per block: 64 lists each, then a sum over the 4
-    const uint32_t b = t >> 2, part = t & 3u;
-    uint32_t sum = 0;
-    if (b < B)
-        for (uint32_t x = 0; x < (uint32_t)BR_SUB / 4; ++x) sum += s_c[b][part * (BR_SUB / 4) + x];
-    sum += __shfl_down(sum, 2, 4);
-    sum += __shfl_down(sum, 1, 4);
-    if (part == 0 && b < B) subcnt[(uint64_t)w * B + b] = sum;
 }
 
 __device__ __forceinline__ unsigned long long wave_max(unsigned long long k) {
@@ -1282,7 +1225,6 @@ __global__ __launch_bounds__(PL_THREADS) void gather_loop_kernel(LoopArgs a) {
 #define PL_WAITLAP(slot) do { if (a.dbg != nullptr && wg == 0) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); PL_LAP(slot); } } while (0)
 #define PL_LAP(slot) do { if (timing) { const unsigned long long t_ = wall_clock64(); t_acc[slot] += t_ - t_mark; t_mark = t_; } } while (0)
     if (timing) a.dbg[6] = t_mark;
-    uint32_t pf_sink = 0;                                         // what prefetch touches returned: folded in late, never meaningful
     for (uint32_t epoch = 1;; ++epoch) {
         fail_epoch = epoch;
         // ---- local best of the owned rows -> this workgroup's record of the epoch ----
@@ -1320,21 +1262,15 @@ __global__ __launch_bounds__(PL_THREADS) void gather_loop_kernel(LoopArgs a) {
         __syncthreads();
         // While the records travel: touch the positions of this workgroup's own best row, one lane per 64-byte line.  The
         // round's winner is one of these rows, so its slice is in the memory-side cache (and one XCD's L2) when everybody asks.
-        // (Round 4 spelled the touch as a volatile load: the compiler follows every volatile access with s_waitcnt vmcnt(0), so
-        //  each thread sat out a trip to HBM right here, in front of the sweep.  Now the touches are plain loads issued by the
-        //  waves that take no part in the sweep -- loads return in order, a sweep behind a touch would wait for it -- and what
-        //  they return is folded into a sink only after the round's positions have arrived, a wait that covers them anyway.)
-        uint32_t pf_own = 0;
-        constexpr int SWEEP_WAVES = 4;                               // the sweep reads with threads 0 .. n_wg - 1
-        if (a.prefetch == 2) {                                       // round 4's form, kept for the A/B (SMG_GATHER_PREFETCH=2)
+        // (Round 5 tried the touches as plain loads issued by the waves that do not sweep, their values folded into a sink a phase
+        //  later, so that nobody waits for a touch: 12.75 us per round against 11.8 with the volatile loads below, whose
+        //  s_waitcnt vmcnt(0) sits in the shadow of the records' travel -- profiles/r05_gather_prefetch_ab.txt.  Also tried and
+        //  dropped: touching the rows of the best records that LOST for the next round (17-20 us: the state carried across the
+        //  round's phases cost 100 bytes of scratch per lane).)
+        if (a.prefetch) {
             const uint32_t ps = s_wstart, pl = s_wlen;
             for (uint32_t i = (uint32_t)tid * 16u; i < pl; i += PL_THREADS * 16u)
-                (void)*reinterpret_cast<const volatile uint32_t*>(a.qpos + (uint64_t)ps + i);
-        } else if (a.prefetch && (wave >= SWEEP_WAVES || n_wg > SWEEP_WAVES * 64u)) {
-            const uint32_t ps = s_wstart, pl = s_wlen;
-            const uint32_t t0 = n_wg > SWEEP_WAVES * 64u ? (uint32_t)tid : (uint32_t)tid - SWEEP_WAVES * 64u;
-            const uint32_t nt = n_wg > SWEEP_WAVES * 64u ? (uint32_t)PL_THREADS : (uint32_t)PL_THREADS - SWEEP_WAVES * 64u;
-            for (uint32_t i = t0 * 16u; i < pl; i += nt * 16u) pf_own += a.qpos[(uint64_t)ps + i];
+                (void)*reinterpret_cast<const volatile uint32_t*>(a.qpos + (uint64_t)ps + i);   // volatile: issued, its value unused
         }
         PL_LAP(0);                                                   // local arg-max + publish
         // ---- sweep everyone's records until all of them carry this epoch: the winner of the round ----
@@ -1490,7 +1426,6 @@ __global__ __launch_bounds__(PL_THREADS) void gather_loop_kernel(LoopArgs a) {
             if (tid == 0) s_nI = 0;
             __syncthreads();
             PL_WAITLAP(6);                                           // (trace) waiting for the row's positions
-            if (c0 == 0) pf_sink += pf_own;                          // what the touches returned (they arrived before the positions did)
             {
                 // all of a thread's test-and-clears are issued before the first result is used (the loop this replaces made
                 // PL_ROW_PER rounds of: returning LDS atomic -> ballot -> returning LDS atomic on the counter -> store), and a
@@ -1604,7 +1539,6 @@ __global__ __launch_bounds__(PL_THREADS) void gather_loop_kernel(LoopArgs a) {
         if (rounds >= maxr) break;
     }
     // ---- hand the state back ----
-    if (pf_sink == 0xdeadbeefu && a.dbg) a.dbg[15] = pf_sink;    // (keeps the touches' loads alive; never true in any way that matters)
     __syncthreads();
     if (timing) {
         a.dbg[7] = wall_clock64() - a.dbg[6];
@@ -1673,11 +1607,7 @@ unsigned blocks_for_rows(uint64_t ndb) {
 
 static QIndex qindex_of(const GatherDev& g) { return QIndex{g.q_padded, g.nq, g.q_table, g.q_shift, g.q_max, g.q_rec}; }
 
-#define SMG_TRY(expr)                      \
-    do {                                   \
-        hipError_t e_ = (expr);            \
-        if (e_ != hipSuccess) return e_;   \
-    } while (0)
+
 
 // Owned buffers and build scratch come from the arena (arena.hpp): blocks the library keeps between builds, so that a
 // rebuild of the same shape makes no driver call.  (Round 2 used hipMallocAsync with a raised release threshold; on the
@@ -1720,32 +1650,10 @@ hipError_t gather_build_kernel_ms(GatherDev& g, float* ms) {
 }
 
 static hipError_t gather_build_body(GatherDev& g, hipStream_t stream);
-// pass 1 through the lean streaming kernel (defined with it, further down)
-hipError_t build_lean_launch(const uint64_t* Q, uint64_t nq, const uint32_t* T, uint32_t n_buckets, uint32_t shift, const uint64_t* hashes,
-                             const uint64_t* offsets, uint64_t ndb, uint32_t rows_per_wg, uint32_t n_ranges, uint32_t bpr,
-                             unsigned long long* counters, uint32_t* qpos, uint16_t* part16, hipStream_t stream);
-uint32_t build_stage_positions(uint64_t nq, uint32_t buckets, double mean_row);
-uint32_t build_stage_buckets_max();
-uint32_t build_stage_rows_max();
-size_t build_stage_desc_bytes(uint32_t n_ranges);
-hipError_t build_stage_plan(const uint64_t* Q, uint64_t nq, uint32_t shift, uint32_t n_buckets, uint32_t W, uint32_t n_ranges, void* desc,
-                            unsigned int* max_nb, hipStream_t stream);
-hipError_t build_stage_launch(const uint64_t* Q, uint64_t nq, const uint32_t* T, uint32_t n_buckets, uint32_t shift, const uint64_t* hashes,
-                              const uint64_t* offsets, uint64_t ndb, uint32_t rows_per_wg, uint32_t n_ranges, const void* desc,
-                              unsigned long long* counters, uint32_t* qpos, uint32_t* inter, uint32_t* dir_start, uint32_t* dir_len,
-                              unsigned int* misc, hipStream_t stream);
-void lean_table_geometry(uint64_t nq, uint64_t q_max, double mean_row, uint32_t* shift, uint32_t* buckets);
-struct LeanPlan { uint32_t bpr, n_ranges, qcap, rows_cap; };
-LeanPlan build_lean_plan(uint64_t nq, uint32_t buckets, double mean_row);
-// largest number of query hashes in any range (the caller checks it against the LDS room of the kernel that walks the ranges)
-__global__ __launch_bounds__(256) void stream_range_max_kernel(const uint32_t* __restrict__ T, uint32_t n_buckets, uint32_t n_ranges,
-                                                              uint32_t bpr, unsigned int* out) {
-    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n_ranges) return;
-    const uint32_t b0 = r * bpr, b1 = b0 + bpr < n_buckets ? b0 + bpr : n_buckets;
-    atomicMax(out, T[b1] - T[b0]);
+hipError_t qtable_launch(const uint64_t* Q, uint64_t nq, uint32_t shift, uint32_t buckets, uint32_t* table, hipStream_t stream) {
+    hipLaunchKernelGGL(qtable_kernel, dim3((buckets + 256) / 256), dim3(256), 0, stream, Q, nq, shift, buckets, table);
+    return hipGetLastError();
 }
-
 
 hipError_t gather_build(GatherDev& g, hipStream_t stream) {
     g.stream = stream;
@@ -1813,7 +1721,7 @@ static hipError_t gather_build_body(GatherDev& g, hipStream_t stream) {
         return hipSuccess;
     }
     const QIndex qi = qindex_of(g);
-    ArenaBuf post_cnt_b, scan_tmp_b, bounds_b, partial_b, subcnt_b, inter_off_b, lay_tmp_b, inter_b, part16_b, desc_b, misc_b, lean_table_b;
+    ArenaBuf post_cnt_b, scan_tmp_b, bounds_b, partial_b, subcnt_b, inter_off_b, lay_tmp_b, inter_b, desc_b, misc_b, lean_table_b;
     SMG_TRY(post_cnt_b.get(nq1 * 8, stream));
     unsigned long long* post_cnt = post_cnt_b.as<unsigned long long>();
     size_t scan_bytes = 0;
@@ -1860,15 +1768,16 @@ static hipError_t gather_build_body(GatherDev& g, hipStream_t stream) {
         // two-level fill unless forced off or its packing does not apply (entries hold the row in 24 bits, offsets in 32)
         const char* fill_env = getenv("SMG_GATHER_FILL");
         bool staged = !(fill_env && !strcmp(fill_env, "direct")) && g.ndb < (1ull << BR_ROWBITS);
-        // Pass 1 through the lean streaming kernel (SMG_GATHER_PASS1=lean|ranges forces / forbids it): the query flows through LDS
-        // in ranges and every workgroup walks its own rows once -- no lookups in L2.  It wants a few hundred rows per CU, a query
-        // without the hash 2^64 - 1, ranges that fit its LDS (one more synchronisation: the widest range's size comes back first),
-        // and it counts per WORKGROUP: a row block of the builder becomes `m_sub` consecutive workgroups of `rpw` rows.
-        // SMG_GATHER_PASS1 = stage | lean | ranges: the staging form below (the default when it applies), the lean kernel with counts
-        // only, lookups in L2; a forced form that cannot run is an error.
+        // Pass 1 (+ 2a) through the lean streaming kernel's staging form (SMG_GATHER_PASS1=stage|ranges forces / forbids it): the query
+        // flows through LDS in ranges and every workgroup walks its own rows once -- no lookups in L2.  It wants a few hundred rows
+        // per CU, a query without the hash 2^64 - 1, ranges that fit its LDS (one more synchronisation: the widest range's size
+        // comes back first), and it works per WORKGROUP: a row block of the builder becomes `m_sub` consecutive workgroups of `rpw`
+        // rows.  Anything it cannot take goes to pass 1 by lookups in L2 (build_range_kernel<0>); a forced form that cannot run is
+        // an error.  (Round 4 kept a third form between the two -- the lean kernel counting only, SMG_GATHER_PASS1=lean -- as the
+        // fallback for queries whose ranges do not fit the staging form's table slice; the lookups take those now.)
         const char* pass1_s = getenv("SMG_GATHER_PASS1");
-        const int pass1_env = !pass1_s ? 0 : !strcmp(pass1_s, "ranges") ? 1 : !strcmp(pass1_s, "lean") ? 2 : !strcmp(pass1_s, "stage") ? 3 : 0;
-        bool lean1 = false, stage1 = false;
+        const int pass1_env = !pass1_s ? 0 : !strcmp(pass1_s, "ranges") ? 1 : !strcmp(pass1_s, "stage") ? 3 : 0;
+        bool stage1 = false;
         LeanPlan lp{};
         uint64_t m_sub = 1, rpw = 0, n_sub = 0;
         uint32_t stage_W = 0, stage_ranges = 0;
@@ -1878,7 +1787,7 @@ static hipError_t gather_build_body(GatherDev& g, hipStream_t stream) {
         {
             int n_cu = 256;
             { int dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev); }
-            if (pass1_env != 1 && staged && B <= (uint64_t)MS_BMAX && g.q_max != ~0ull && (pass1_env >= 2 || g.ndb >= (uint64_t)n_cu * 64)) {
+            if (pass1_env != 1 && staged && B <= (uint64_t)MS_BMAX && g.q_max != ~0ull && (pass1_env == 3 || g.ndb >= (uint64_t)n_cu * 64)) {
                 // (the streaming kernels take a coarser table of their own when the shared one has close to two buckets per hash)
                 const double mean_row = (double)total / (double)g.ndb;
                 lean_table_geometry(g.nq, g.q_max, mean_row, &lean_shift, &lean_buckets);
@@ -1893,15 +1802,12 @@ static hipError_t gather_build_body(GatherDev& g, hipStream_t stream) {
                 stage_ranges = (uint32_t)((g.nq + stage_W - 1) / stage_W);
                 SMG_TRY(desc_b.get(build_stage_desc_bytes(stage_ranges) + 64, stream));
                 unsigned int* d_widest = (unsigned int*)&g.state[GS_KEY];       // scratch again: zero since the first synchronisation
-                hipLaunchKernelGGL(stream_range_max_kernel, dim3((lp.n_ranges + 255) / 256), dim3(256), 0, stream, (const uint32_t*)lean_T,
-                                   lean_buckets, lp.n_ranges, lp.bpr, d_widest);
-                SMG_TRY(hipGetLastError());
                 SMG_TRY(build_stage_plan(g.Q, g.nq, lean_shift, lean_buckets, stage_W, stage_ranges, desc_b.p, d_widest + 1, stream));
                 g.pinned[9] = 0;
                 SMG_TRY(hipMemcpyAsync(&g.pinned[9], d_widest, 8, hipMemcpyDeviceToHost, stream));
                 SMG_TRY(hipMemsetAsync(&g.state[GS_KEY], 0, 8, stream));
                 SMG_TRY(timed_sync(g, stream));                           // synchronisation 2 of 3
-                const unsigned int widest = (unsigned int)(g.pinned[9] & 0xffffffffull), most_buckets = (unsigned int)(g.pinned[9] >> 32);
+                const unsigned int most_buckets = (unsigned int)(g.pinned[9] >> 32);
                 const uint64_t rows_cap = lp.rows_cap < build_stage_rows_max() ? lp.rows_cap : build_stage_rows_max();
                 const uint64_t m_min = (rows_per_block + rows_cap - 1) / rows_cap;
                 const uint64_t rounds = (B * m_min + (uint64_t)n_cu - 1) / (uint64_t)n_cu;
@@ -1910,11 +1816,10 @@ static hipError_t gather_build_body(GatherDev& g, hipStream_t stream) {
                 rpw = (rows_per_block + m_sub - 1) / m_sub;
                 n_sub = (g.ndb + rpw - 1) / rpw;
                 const uint64_t per = (B + BR_GROUPS - 1) / BR_GROUPS;
-                stage1 = pass1_env != 2 && most_buckets > 0 && most_buckets <= build_stage_buckets_max() && total + 4 < 0xffffffffull &&
+                stage1 = most_buckets > 0 && most_buckets <= build_stage_buckets_max() && total + 4 < 0xffffffffull &&
                          per <= (uint64_t)BR_ORD_NB && per * m_sub <= 64 && n_sub * (uint64_t)((g.nq + BR_SUB - 1) / BR_SUB) * 8 <= (1ull << 30);
-                lean1 = !stage1 && pass1_env != 3 && widest > 0 && widest <= lp.qcap && n_sub * g.nq * 2 <= (3ull << 30);
-                if (!lean1 && !stage1 && pass1_env >= 2) return hipErrorInvalidValue;
-                if (lean1 || stage1) {
+                if (!stage1 && pass1_env == 3) return hipErrorInvalidValue;
+                if (stage1) {
                     rows_per_block = rpw * m_sub;
                     B = (g.ndb + rows_per_block - 1) / rows_per_block;
                 }
@@ -1983,22 +1888,13 @@ static hipError_t gather_build_body(GatherDev& g, hipStream_t stream) {
             SMG_TRY(hipMemsetAsync(subcnt, 0, (uint64_t)n_windows * B * 4, stream));   // ranges past R launch nothing
         }
         const unsigned range_grid = (unsigned)(((R + 7) / 8) * 8 * B);
-        if (lean1) {
-            SMG_TRY(part16_b.get(n_sub * g.nq * 2 + 64, stream));
-            SMG_TRY(build_lean_launch(g.Q, g.nq, lean_T, lean_buckets, lean_shift, g.hashes, g.offsets, g.ndb, (uint32_t)rpw, lp.n_ranges,
-                                      lp.bpr, g.counters, g.qpos, part16_b.as<uint16_t>(), stream));
-            hipLaunchKernelGGL(build_merge_sub_kernel, dim3((unsigned)((nq1 + BR_SUB - 1) / BR_SUB)), dim3(BR_SUB), 0, stream,
-                               (const uint16_t*)part16_b.as<uint16_t>(), (uint32_t)n_sub, (uint32_t)m_sub, (uint32_t)B, g.nq, partial, post_cnt, subcnt);
-            SMG_TRY(hipGetLastError());
-        } else {
-            hipLaunchKernelGGL(build_range_kernel<0>, dim3(range_grid), dim3(BR_THREADS), 0, stream, qi, g.hashes, g.offsets,
-                               g.ndb, bounds, R, (uint32_t)B, rows_per_block, partial, (const uint64_t*)nullptr, (uint32_t*)nullptr,
-                               g.counters, g.qpos, subcnt, (const uint32_t*)nullptr, (uint32_t*)nullptr);
-            SMG_TRY(hipGetLastError());
-            hipLaunchKernelGGL(build_merge_counts_kernel, dim3((unsigned)((nq1 + 255) / 256)), dim3(256), 0, stream, partial,
-                               (uint32_t)B, g.nq, post_cnt);
-            SMG_TRY(hipGetLastError());
-        }
+        hipLaunchKernelGGL(build_range_kernel<0>, dim3(range_grid), dim3(BR_THREADS), 0, stream, qi, g.hashes, g.offsets,
+                           g.ndb, bounds, R, (uint32_t)B, rows_per_block, partial, (const uint64_t*)nullptr, (uint32_t*)nullptr,
+                           g.counters, g.qpos, subcnt);
+        SMG_TRY(hipGetLastError());
+        hipLaunchKernelGGL(build_merge_counts_kernel, dim3((unsigned)((nq1 + 255) / 256)), dim3(256), 0, stream, partial,
+                           (uint32_t)B, g.nq, post_cnt);
+        SMG_TRY(hipGetLastError());
         SMG_TRY(rocprim::exclusive_scan(scan_tmp, scan_bytes, (uint64_t*)post_cnt, g.post_off, (uint64_t)0, (size_t)nq1,
                                         rocprim::plus<uint64_t>(), stream));
         SMG_TRY(hipMemcpyAsync(&g.pinned[8], g.post_off + g.nq, 8, hipMemcpyDeviceToHost, stream));
@@ -2017,14 +1913,9 @@ static hipError_t gather_build_body(GatherDev& g, hipStream_t stream) {
         if (staged) {
             SMG_TRY(inter_b.get(inter_words * 4, stream));
             inter = inter_b.as<uint32_t>();
-            if (fill_env && !strcmp(fill_env, "streams"))       // pass 2a without staging: 4-byte stores into 128 open streams
-                hipLaunchKernelGGL(build_range_kernel<2>, dim3(range_grid), dim3(BR_THREADS), 0, stream, qi, g.hashes, g.offsets,
-                                   g.ndb, bounds, R, (uint32_t)B, rows_per_block, partial, (const uint64_t*)nullptr, (uint32_t*)nullptr,
-                                   g.counters, g.qpos, (uint32_t*)nullptr, (const uint32_t*)inter_off, inter);
-            else
-                hipLaunchKernelGGL(build_partition_kernel, dim3(range_grid), dim3(BR_THREADS), 0, stream, g.nq, g.offsets, g.ndb,
-                                   (const uint32_t*)bounds, R, (uint32_t)B, rows_per_block, (const uint32_t*)g.qpos,
-                                   (const uint32_t*)inter_off, inter);
+            hipLaunchKernelGGL(build_partition_kernel, dim3(range_grid), dim3(BR_THREADS), 0, stream, g.nq, g.offsets, g.ndb,
+                               (const uint32_t*)bounds, R, (uint32_t)B, rows_per_block, (const uint32_t*)g.qpos,
+                               (const uint32_t*)inter_off, inter);
             SMG_TRY(hipGetLastError());
             const uint32_t per = (uint32_t)((B + BR_GROUPS - 1) / BR_GROUPS);
             const bool ordered = per <= (uint32_t)BR_ORD_NB;            // row-block runs inside every list (persistent loop)
@@ -2056,7 +1947,7 @@ static hipError_t gather_build_body(GatherDev& g, hipStream_t stream) {
             hipLaunchKernelGGL(build_range_kernel<1>, dim3(range_grid), dim3(BR_THREADS), 0, stream, qi, g.hashes, g.offsets,
                                g.ndb, bounds, R, (uint32_t)B, rows_per_block, partial,
                                absolute ? (const uint64_t*)nullptr : (const uint64_t*)g.post_off, g.post_rows, g.counters, g.qpos,
-                               (uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr);
+                               (uint32_t*)nullptr);
             SMG_TRY(hipGetLastError());
         }
     }
@@ -2200,11 +2091,7 @@ hipError_t gather_launch_loop(GatherDev& g, hipStream_t stream, uint32_t n_wg, c
     if (sh && (sh->W == 0 || sh->W > (uint32_t)PL_THREADS || sh->rank >= sh->W || rowcap == 0)) return hipErrorInvalidValue;
     SMG_TRY(gather_loop_reserve(g, stream, n_wg, rowcap));
     a.xchg = g.loop_xchg;
-    // 0: none; 1 (default): every workgroup touches its own best row while the records travel, with plain loads whose values are
-    // folded into a sink a phase later; 2: the same with round 4's volatile loads (each followed by s_waitcnt vmcnt(0)).
-    // (Round 5 also tried touching the rows of the best records that LOST, for the next round: the state it carries across the
-    //  phases of a round pushed this kernel from 36 to 136 bytes of scratch per lane and the round from 12 to 17-20 us.)
-    static const uint32_t pf = [] { const char* e = getenv("SMG_GATHER_PREFETCH"); return e ? (uint32_t)atoi(e) : 1u; }();
+    static const uint32_t pf = [] { const char* e = getenv("SMG_GATHER_PREFETCH"); return e ? (uint32_t)atoi(e) : 1u; }();   // 0: no touches
     a.prefetch = pf;
     static const bool trace = getenv("SMG_GATHER_TRACE") != nullptr;
     a.dbg = trace ? g.loop_xchg + (size_t)2 * n_wg * 4 : nullptr;           // 16 words behind the granules
@@ -2392,982 +2279,6 @@ hipError_t gather_enqueue_replay(GatherDev& g, unsigned exchanges, hipStream_t s
         SMG_TRY(gather_replay_rounds(g, K, stream));
     }
     return hipSuccess;
-}
-
-// ---- streaming lookups: the query flows through LDS, the database is read once -----------------------------------
-// The range kernels above look every database hash up in structures that live in L2 (two dependent 16-byte loads per
-// element from lines nobody else in the wave touches): 5e8 lookups cost 5-6 ms at C5 whatever else the pass does.
-// Here a workgroup owns a block of rows and walks the QUERY in order: the hash space is cut at multiples of
-// SL_BUCKETS buckets of the first-level table (about SL_BUCKETS query hashes each, because there is about one hash per
-// bucket); for each such range the workgroup loads that slice of the table and of the query into LDS (32 KB), then
-// visits each of its rows once: a group of 16 lanes reads the row's next 16 hashes at the row's cursor, the ones below
-// the range's upper bound are looked up in LDS (table entry -> at most a few query hashes, compared in registers) and
-// consumed, the cursor moves on.  Rows are sorted, so a row's hashes inside a range are contiguous and every database
-// hash is read from HBM once, by consecutive lanes.  No per-(row, range) bounds are precomputed: the cursors carry over.
-// Workgroup (block b, group g) covers ranges [g * per, (g + 1) * per); its first cursors come from a binary search.
-constexpr int SL_BUCKETS = 2048;          // table buckets per range
-constexpr int SL_QCAP = 2432;             // query hashes a range may hold (at most ~2,048 by construction, +- 45); else the caller falls back.
-                                          // 39.9 KB of LDS in all: four workgroups (32 waves) per CU
-constexpr int SL_ROWS = 1024;             // rows per block (row starts, cursors and per-row hit counts live in LDS)
-constexpr int SL_THREADS = 512;
-constexpr int SL_GROUP = 16;              // lanes per row visit
-constexpr int SL_GROUPS = SL_THREADS / SL_GROUP;
-constexpr int SL_AHEAD = 4;               // row visits a group has in flight: a visit is one ~1 us load from HBM, and 51 million of
-                                          // them (rows x ranges at C5) must overlap
-
-template <int MODE>    // 3: overlaps only (counters[d] += |Q ∩ row d|)
-__global__ __launch_bounds__(SL_THREADS) void stream_lookup_kernel(const uint64_t* __restrict__ Q, const uint32_t* __restrict__ T,
-                                                                   uint32_t n_buckets, uint32_t shift, uint64_t qmax,
-                                                                   const uint64_t* __restrict__ hashes,
-                                                                   const uint64_t* __restrict__ offsets, uint64_t ndb,
-                                                                   uint32_t n_blocks, uint32_t n_ranges, uint32_t ranges_per_group,
-                                                                   uint32_t bpr, unsigned long long* __restrict__ counters) {
-    // bpr: buckets per range (<= SL_BUCKETS): the table holds between one and two query hashes per bucket, the caller picks
-    // the power of two that puts about 2,000 of them into a range
-    __shared__ __attribute__((aligned(16))) uint64_t s_q[SL_QCAP];
-    __shared__ __attribute__((aligned(16))) uint32_t s_t[SL_BUCKETS + 4];
-    __shared__ uint32_t s_base[SL_ROWS + 1];                             // row starts relative to the block's first hash
-    __shared__ uint32_t s_cur[SL_ROWS], s_hits[SL_ROWS];
-    const uint32_t b = blockIdx.x % n_blocks, g = blockIdx.x / n_blocks;
-    const uint64_t d_lo = (uint64_t)b * SL_ROWS;
-    const uint32_t n_rows = (uint32_t)(ndb - d_lo < (uint64_t)SL_ROWS ? ndb - d_lo : (uint64_t)SL_ROWS);
-    const uint32_t r_lo = g * ranges_per_group;
-    const uint32_t r_hi = r_lo + ranges_per_group < n_ranges ? r_lo + ranges_per_group : n_ranges;
-    if (r_lo >= r_hi) return;
-    const int tid = threadIdx.x;
-    const uint64_t block_base = offsets[d_lo];
-    const uint64_t* rows = hashes + block_base;
-    // first cursors: where the group's first range starts in every row
-    const uint64_t first_hash = ((uint64_t)r_lo * bpr) << shift;
-    for (uint32_t i = tid; i <= n_rows; i += SL_THREADS) s_base[i] = (uint32_t)(offsets[d_lo + i] - block_base);
-    __syncthreads();
-    for (uint32_t i = tid; i < n_rows; i += SL_THREADS) {
-        uint32_t lo = 0, hi = s_base[i + 1] - s_base[i];
-        const uint64_t* row = rows + s_base[i];
-        if (r_lo != 0) {
-            while (lo < hi) {
-                const uint32_t mid = (lo + hi) >> 1;
-                if (row[mid] < first_hash) lo = mid + 1; else hi = mid;
-            }
-        } else {
-            lo = 0;
-        }
-        s_cur[i] = lo;
-        s_hits[i] = 0;
-    }
-    const int grp = tid / SL_GROUP, gl = tid % SL_GROUP;
-    const int sh16 = (tid & 63) / SL_GROUP * SL_GROUP;                   // this group's bit offset inside the wave's ballot
-    for (uint32_t r = r_lo; r < r_hi; ++r) {
-        const uint32_t b0 = r * bpr, b1 = b0 + bpr < n_buckets ? b0 + bpr : n_buckets;
-        const uint32_t p0 = T[b0], p1 = T[b1];
-        const bool last = r + 1 == n_ranges;
-        // hashes below `upper` belong to this range or an earlier one (earlier ones are consumed already)
-        const uint64_t upper = last ? ~0ull : ((uint64_t)b1 << shift);
-        __syncthreads();                                                  // the previous range's readers are done
-        for (uint32_t i = tid; i < b1 - b0 + 1; i += SL_THREADS) s_t[i] = T[b0 + i] - p0;
-        for (uint32_t i = tid; i < p1 - p0; i += SL_THREADS) s_q[i] = Q[p0 + i];
-        __syncthreads();
-        // one group of 16 lanes per row; SL_AHEAD rows' loads are issued before the first of them is looked at
-        for (uint32_t i0 = grp; i0 < n_rows; i0 += SL_GROUPS * SL_AHEAD) {
-            uint64_t e[SL_AHEAD];
-            uint32_t c[SL_AHEAD], len[SL_AHEAD], rb[SL_AHEAD];
-#pragma unroll
-            for (int u = 0; u < SL_AHEAD; ++u) {
-                const uint32_t i = i0 + u * SL_GROUPS;
-                const bool row_ok = i < n_rows;
-                rb[u] = row_ok ? s_base[i] : 0u;
-                len[u] = row_ok ? s_base[i + 1] - rb[u] : 0u;
-                c[u] = row_ok ? s_cur[i] : 0u;
-                e[u] = c[u] + gl < len[u] ? rows[(uint64_t)rb[u] + c[u] + gl] : ~0ull;
-            }
-#pragma unroll
-            for (int u = 0; u < SL_AHEAD; ++u) {
-                const uint32_t i = i0 + u * SL_GROUPS;
-                uint32_t cur = c[u], hits = 0;
-                uint64_t ev = e[u];
-                for (;;) {
-                    const bool have = cur + gl < len[u];
-                    const bool in = have && (last || ev < upper);
-                    const uint32_t taken = (uint32_t)__popc((uint32_t)((__ballot(in) >> sh16) & 0xffffu));
-                    bool hit = false;
-                    if (in && ev <= qmax) {
-                        const uint32_t k = (uint32_t)(ev >> shift) - b0;         // < SL_BUCKETS: the hash lies in this range
-                        const uint32_t t0 = s_t[k], t1 = s_t[k + 1];
-                        for (uint32_t t = t0; t < t1; ++t) {
-                            const uint64_t qv = s_q[t];
-                            if (qv == ev) { hit = true; break; }
-                            if (qv > ev) break;
-                        }
-                    }
-                    hits += (uint32_t)__popc((uint32_t)((__ballot(hit) >> sh16) & 0xffffu));
-                    cur += taken;
-                    if (taken < (uint32_t)SL_GROUP) break;                // the row's part of this range is through
-                    ev = cur + gl < len[u] ? rows[(uint64_t)rb[u] + cur + gl] : ~0ull;   // a longer slice: keep reading
-                }
-                if (gl == 0 && i < n_rows) { s_cur[i] = cur; if (hits) s_hits[i] += hits; }
-            }
-        }
-    }
-    __syncthreads();
-    for (uint32_t i = tid; i < n_rows; i += SL_THREADS)
-        if (s_hits[i]) atomicAdd(&counters[d_lo + i], (unsigned long long)s_hits[i]);   // one add per (row, group of ranges)
-}
-
-// ---- the wide form: one workgroup per CU, a wave per row visit ------------------------------------------------------
-// stream_lookup_kernel above spends 118 lane-instructions per database hash (profiles/r02_gather_sq.txt: VALU issue 55 % busy
-// for 5e8 lookups): with ~2,000 query hashes per range a row's part of a range is ~10 hashes, so 51 million visits each pay
-// cursor / ballot / bounds bookkeeping for ten useful lanes of sixteen, and every visit's 128-byte read overlaps the next
-// one's (FETCH_SIZE 1.84 x the database).  Here a workgroup takes the whole LDS of a CU: ranges of ~10,000 query hashes
-// (88 KB) and 8,192 table buckets (32 KB), so that a row's part of a range is ~50 hashes and ONE wave reads it as one
-// 512-byte load: six times fewer visits, most lanes busy, and a row's boundary line is re-read by 1 visit in 5 lines
-// instead of 1 in 1.  A workgroup owns a contiguous block of rows and walks every range over them (cursors in LDS), so
-// every row is counted by exactly one workgroup: plain stores, no atomics.
-constexpr int OW_THREADS = 1024;
-constexpr int OW_WAVES = OW_THREADS / 64;
-// Two geometries of the same kernel (round 4).  `One`: a workgroup takes the whole LDS of a CU -- the round-3 form, 4 waves per
-// SIMD.  `Two`: TWO workgroups share a CU (8 waves per SIMD; the kernel needs 60 VGPRs, 64 are to be had): the table slice as
-// 16-bit offsets (a range holds < 65,536 query hashes by construction), ~6,800 query hashes per range instead of ~10,000,
-// half the rows per workgroup.  The round-3 phase trace said what the One form waits for: with one 1,024-thread workgroup
-// per CU nothing runs while its 16 waves stand at a range's two barriers or wait out a lookup's two dependent LDS trips.
-template <int SLOTS_, int BUCKETS_, int QCAP_, typename TT_, int WAVES_PER_EU_, int BATCH_>
-struct OwGeom {
-    static constexpr int BATCH = BATCH_;          // visits looked up side by side
-    static constexpr int SLOTS = SLOTS_;          // rows a wave owns, each with its next 64 hashes in (or on the way to) registers
-    static constexpr int BUCKETS = BUCKETS_;      // table buckets per range (at most)
-    static constexpr int QCAP = QCAP_;            // query hashes a range may hold; the caller checks the widest range
-    using TT = TT_;                               // a table entry in LDS: offset of the bucket's first query hash within the slice
-    static constexpr int ROWS = OW_WAVES * SLOTS_; // rows per workgroup (at most)
-    static constexpr size_t T_BYTES = (((size_t)BUCKETS_ + 4) * sizeof(TT_) + 7) & ~(size_t)7;
-    static constexpr size_t LDS = (size_t)QCAP_ * 8 + T_BYTES + ((size_t)3 * ROWS + 8) * 4;
-    static constexpr int WAVES_PER_EU = WAVES_PER_EU_;
-};
-using OwOne = OwGeom<25, 8192, 11264, uint32_t, 4, 4>;    // 88 KB + 32 KB + 4.7 KB = 127.7 KB: one workgroup per CU
-using OwTwo = OwGeom<13, 8192, 7680, uint16_t, 8, 2>;     // 60 KB + 16 KB + 2.5 KB = 78.5 KB: two workgroups per CU
-#ifndef SMG_OW_LEAN_BATCH
-#define SMG_OW_LEAN_BATCH 4
-#endif
-using OwLean = OwGeom<25, 10240, 11264, uint32_t, 4, SMG_OW_LEAN_BATCH>;  // the lean kernel's geometry: ranges cut by query hashes held, not at a power of two of buckets
-constexpr int OW_BUCKETS = OwOne::BUCKETS;
-
-// Query hashes per range of the streaming kernels.  A visit loads the next 64 hashes of its row and uses the ones below the
-// range's upper bound: a range should hold so many query hashes that a row's part of it is ~48 hashes (more, and one visit in
-// sixteen has to fetch a second block on the spot; fewer, and the visits multiply) -- 48 x nq / (mean row length), at most what
-// the LDS slice holds.  C5: 48 x 1e6 / 5,000 = 9,600.  SMG_OVERLAP_QPR overrides.
-double lean_hashes_per_range(uint64_t nq, double mean_row) {
-    static const double env = [] { const char* e = getenv("SMG_OVERLAP_QPR"); return e ? atof(e) : 0.0; }();
-    if (env > 0.0) return env;
-    double q = 48.0 * (double)nq / (mean_row < 1.0 ? 1.0 : mean_row);
-    if (q > 9600.0) q = 9600.0;
-    if (q < 512.0) q = 512.0;
-    return q;
-}
-
-// The streaming kernels hold a range's slice of the table in LDS as well, so the BUCKETS per query hash decide how many hashes
-// a range can hold.  qindex_geometry gives between one and two (its callers look single hashes up in L2 and want short buckets):
-// at 1.95 -- a 1.1e6-hash query -- a 10,240-bucket slice held 5,250 hashes instead of the 9,600 wanted and the overlap pass took
-// 2.44 ms where the 1.0e6-hash query (1.07) takes 1.54.  When the wanted range does not fit the slice, the streaming kernels use a
-// table of their own with buckets twice as wide.
-void lean_table_geometry(uint64_t nq, uint64_t q_max, double mean_row, uint32_t* shift, uint32_t* buckets) {
-    const double want = lean_hashes_per_range(nq, mean_row) * (double)*buckets / (double)nq;     // buckets a range would need
-    if (want > 1.05 * (double)OwLean::BUCKETS && *shift < 63 && *buckets > 2) {
-        ++*shift;
-        *buckets = (uint32_t)(q_max >> *shift) + 1;
-    }
-}
-
-LeanPlan build_lean_plan(uint64_t nq, uint32_t buckets, double mean_row) {
-    uint32_t bpr = (uint32_t)(lean_hashes_per_range(nq, mean_row) * (double)buckets / (double)nq);
-    if (bpr > (uint32_t)OwLean::BUCKETS) bpr = OwLean::BUCKETS;
-    if (bpr < 64) bpr = 64;
-    return LeanPlan{bpr, (buckets + bpr - 1) / bpr, (uint32_t)OwLean::QCAP, (uint32_t)OwLean::ROWS};
-}
-
-template <class G>
-__global__ __launch_bounds__(OW_THREADS) __attribute__((amdgpu_waves_per_eu(G::WAVES_PER_EU, G::WAVES_PER_EU)))
-void overlap_wide_kernel(const uint64_t* __restrict__ Q, const uint32_t* __restrict__ T,
-                                                                  uint32_t n_buckets, uint32_t shift, uint64_t qmax,
-                                                                  const uint64_t* __restrict__ hashes,
-                                                                  const uint64_t* __restrict__ offsets, uint64_t ndb,
-                                                                  uint32_t rows_per_wg, uint32_t n_ranges, uint32_t bpr,
-                                                                  unsigned long long* __restrict__ counts) {
-    constexpr int OW_SLOTS = G::SLOTS, OW_BUCKETS = G::BUCKETS, OW_QCAP = G::QCAP, OW_ROWS = G::ROWS, OW_BATCH = G::BATCH;
-    using TT = typename G::TT;
-    extern __shared__ __attribute__((aligned(16))) uint64_t ow_lds[];
-    uint64_t* s_q = ow_lds;
-    TT* s_t = reinterpret_cast<TT*>(s_q + OW_QCAP);
-    uint32_t* s_base = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(s_t) + G::T_BYTES);   // row starts relative to the block's first hash
-    uint32_t* s_cur = s_base + OW_ROWS + 2;
-    uint32_t* s_hits = s_cur + OW_ROWS + 1;
-    const uint64_t d_lo = (uint64_t)blockIdx.x * rows_per_wg;
-    if (d_lo >= ndb) return;
-    const uint32_t n_rows = (uint32_t)(ndb - d_lo < (uint64_t)rows_per_wg ? ndb - d_lo : (uint64_t)rows_per_wg);
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const uint64_t block_base = offsets[d_lo];
-    const uint64_t* rows = hashes + block_base;
-    for (uint32_t i = tid; i <= n_rows + 1; i += OW_THREADS)          // entry n_rows + 1 closes an empty row behind the last one
-        s_base[i] = (uint32_t)(offsets[d_lo + (i <= n_rows ? i : n_rows)] - block_base);
-    for (uint32_t i = tid; i <= n_rows; i += OW_THREADS) { s_cur[i] = 0; s_hits[i] = 0; }
-    // A range's slice of the table and of the query goes from L2 straight to LDS between the range's two barriers (20 loads
-    // per thread, one trip): staging it in registers a range ahead, as this kernel first did, costs 31 registers that the
-    // rows' data needs more.  Only the slice's bounds (two table entries the loads' addresses depend on) are asked for a
-    // range ahead.
-    constexpr int QPER = (OW_QCAP + OW_THREADS - 1) / OW_THREADS, TPER = (OW_BUCKETS + 1 + OW_THREADS - 1) / OW_THREADS;
-    uint32_t n_p0 = T[0], n_p1 = T[bpr < n_buckets ? bpr : n_buckets];   // range 0's; every lane holds the same two values
-    // A wave owns the rows wave, wave + 16, ... of the block: OW_SLOTS of them at most, each with a register pair that holds
-    // the row's next 64 hashes.  A row is visited once per range, and the load for its NEXT visit is issued right after the
-    // present one (the cursor is known then), a whole range ahead: when a range starts, all of its data is in registers or
-    // on its way, and nothing in a range waits for a trip to memory that began in the same range.  (2.62 -> 2.44 ms against the
-    // two-stage pipeline this replaces.  What is left is each wave's own instruction stream -- ~200 instructions of all kinds
-    // per visit with four waves on a SIMD: DESIGN.md 4.4, profiles/r03_overlap_stages.txt.)
-    // A visit's row is the same for all lanes: its start, length and cursor are read from LDS into SCALAR registers (one
-    // broadcast read, v_readfirstlane) and the address of the 512-byte load is a scalar base plus lane * 8.
-    uint64_t e[OW_SLOTS];
-    auto ask = [&](int k) {                                                // the next 64 hashes of slot k's row
-        const uint32_t i = (uint32_t)wave + (uint32_t)k * OW_WAVES;          // wave-uniform
-        e[k] = ~0ull;
-        if (i < n_rows) {
-            const uint32_t rb = uniform32(s_base[i]), cur = uniform32(s_cur[i]);
-            const uint32_t left = uniform32(s_base[i + 1]) - rb - cur;       // the cursor never passes the row's end
-            if ((uint32_t)lane < left) e[k] = (rows + rb + cur)[lane];
-        }
-    };
-    __syncthreads();                                                      // row starts and cursors are in LDS
-#pragma unroll
-    for (int k = 0; k < OW_SLOTS; ++k) ask(k);
-#ifdef SMG_OW_TRACE
-    unsigned long long tr_b1 = 0, tr_fill = 0, tr_b2 = 0, tr_proc = 0, tr_t = __builtin_readcyclecounter();
-#define OW_MARK(acc) { const unsigned long long now_ = __builtin_readcyclecounter(); acc += now_ - tr_t; tr_t = now_; }
-#else
-#define OW_MARK(acc)
-#endif
-    for (uint32_t r = 0; r < n_ranges; ++r) {
-        const uint32_t b0 = r * bpr, b1 = b0 + bpr < n_buckets ? b0 + bpr : n_buckets;
-        const bool last = r + 1 == n_ranges;
-        const uint64_t upper = last ? ~0ull : ((uint64_t)b1 << shift);    // hashes below it belong to this range (earlier ones are consumed)
-        const uint32_t p0 = uniform32(n_p0), cnt_q = uniform32(n_p1) - p0, cnt_t = b1 - b0 + 1;
-        __syncthreads();                                                  // the previous range's readers are done
-        OW_MARK(tr_b1)
-        {   // (in pieces of FILL_STEP loads per thread: all of a piece's loads are in flight together; the Two form has 64 registers)
-            constexpr int FILL_STEP = G::WAVES_PER_EU > 4 ? 4 : 16;
-#pragma unroll
-            for (int u0 = 0; u0 < TPER; u0 += FILL_STEP) {
-                uint32_t tv[FILL_STEP];
-#pragma unroll
-                for (int u = 0; u < FILL_STEP; ++u) {
-                    const uint32_t i = (uint32_t)tid + (uint32_t)(u0 + u) * OW_THREADS;
-                    tv[u] = (u0 + u < TPER && i < cnt_t) ? T[b0 + i] : 0u;
-                }
-#pragma unroll
-                for (int u = 0; u < FILL_STEP; ++u) {
-                    const uint32_t i = (uint32_t)tid + (uint32_t)(u0 + u) * OW_THREADS;
-                    if (u0 + u < TPER && i < cnt_t) s_t[i] = (TT)(tv[u] - p0);
-                }
-            }
-#pragma unroll
-            for (int u0 = 0; u0 < QPER; u0 += FILL_STEP) {
-                uint64_t qv[FILL_STEP];
-#pragma unroll
-                for (int u = 0; u < FILL_STEP; ++u) {
-                    const uint32_t i = (uint32_t)tid + (uint32_t)(u0 + u) * OW_THREADS;
-                    qv[u] = (u0 + u < QPER && i < cnt_q) ? Q[p0 + i] : 0ull;
-                }
-#pragma unroll
-                for (int u = 0; u < FILL_STEP; ++u) {
-                    const uint32_t i = (uint32_t)tid + (uint32_t)(u0 + u) * OW_THREADS;
-                    if (u0 + u < QPER && i < cnt_q) s_q[i] = qv[u];
-                }
-            }
-        }
-        if (tid < 2) s_t[bpr + 1 + tid] = (TT)cnt_q;                     // padding: lanes without a hash of the range read an empty bucket
-        if (tid >= 64 && tid < 64 + 3 && cnt_t + (uint32_t)(tid - 64) <= bpr) s_t[cnt_t + (uint32_t)(tid - 64)] = (TT)cnt_q;   // a short last range
-        OW_MARK(tr_fill)
-        __syncthreads();
-        OW_MARK(tr_b2)
-        if (!last) {                                                     // the next range's bounds
-            const uint32_t nb0 = b1, nb1 = nb0 + bpr < n_buckets ? nb0 + bpr : n_buckets;
-            n_p0 = T[nb0];
-            n_p1 = T[nb1];
-        }
-        // The visits' lookups run OW_BATCH side by side and branch-free: every lane reads its bucket's two table entries and
-        // the bucket's first two query hashes whether or not it holds a hash of this range (indices clamped into the arrays;
-        // the compares decide).  Buckets of more than two hashes and slices of more than 64 hashes (both rare) take the slow
-        // paths, one visit at a time.  Which lanes hold a hash of this range / one that can be in the query / one that was
-        // found are wave masks in scalar registers, combined from the masks of plain compares (wavemask.hpp).
-#pragma unroll
-        for (int v0 = 0; v0 < OW_SLOTS; v0 += OW_BATCH) {
-            if ((uint32_t)wave + (uint32_t)v0 * OW_WAVES >= n_rows) break;  // no rows in this batch or behind it (wave-uniform)
-            uint64_t in[OW_BATCH], lk[OW_BATCH];
-            uint32_t t0[OW_BATCH], nb[OW_BATCH];
-#pragma unroll
-            for (int w = 0; w < OW_BATCH; ++w) {
-                const int k = v0 + w;
-                if (k >= OW_SLOTS) continue;
-                if (last) {                                                  // 2^64 - 1 can be a hash here: count the lanes instead
-                    const uint32_t i = (uint32_t)wave + (uint32_t)k * OW_WAVES;
-                    uint32_t left = 0;
-                    if (i < n_rows) left = uniform32(s_base[i + 1]) - uniform32(s_base[i]) - uniform32(s_cur[i]);
-                    in[w] = mask_of((uint32_t)lane < left);
-                } else {
-                    in[w] = mask_of(e[k] < upper);                           // lanes past the row's end hold 2^64 - 1
-                }
-                lk[w] = in[w] & mask_of(e[k] <= qmax);
-                uint32_t kk = (uint32_t)(e[k] >> shift) - b0;                // < bpr when lk: the hash lies in this range
-                kk = kk < bpr ? kk : bpr;                                    // other lanes: the padding entries behind the slice
-                t0[w] = (uint32_t)s_t[kk];
-                nb[w] = (uint32_t)s_t[kk + 1] - t0[w];
-            }
-            uint64_t qa[OW_BATCH], qb[OW_BATCH];
-#pragma unroll
-            for (int w = 0; w < OW_BATCH; ++w) {
-                if (v0 + w >= OW_SLOTS) continue;
-                const uint32_t ta = t0[w] < (uint32_t)(OW_QCAP - 2) ? t0[w] : (uint32_t)(OW_QCAP - 2);
-                qa[w] = s_q[ta];
-                qb[w] = s_q[ta + 1];
-            }
-#pragma unroll
-            for (int w = 0; w < OW_BATCH; ++w) {
-                const int k = v0 + w;
-                if (k >= OW_SLOTS) continue;
-                const uint32_t i = (uint32_t)wave + (uint32_t)k * OW_WAVES;
-                const uint64_t eq = (mask_of(nb[w] >= 1u) & mask_of(qa[w] == e[k])) | (mask_of(nb[w] >= 2u) & mask_of(qb[w] == e[k]));
-                uint64_t found = lk[w] & eq;
-                // the bucket goes on and has not passed the hash yet
-                const uint64_t deep = lk[w] & ~eq & mask_of(nb[w] > 2u) & mask_of(qb[w] < e[k]);
-                if (__builtin_expect(deep != 0ull, 0)) {
-                    bool hit = false;
-                    if (lanes_of(deep))
-                        for (uint32_t t = t0[w] + 2; t < t0[w] + nb[w]; ++t) {
-                            const uint64_t qv = s_q[t];
-                            if (qv == e[k]) { hit = true; break; }
-                            if (qv > e[k]) break;
-                        }
-                    found |= mask_of(hit);
-                }
-                uint32_t taken = (uint32_t)__popcll(in[w]);
-                uint32_t hits = (uint32_t)__popcll(found);
-                if (__builtin_expect(taken == 64u, 0)) {                     // a longer slice (rare): keep reading, one load at a time
-                    const uint32_t rb = uniform32(s_base[i]), len = uniform32(s_base[i + 1]) - rb;
-                    uint32_t cur = uniform32(s_cur[i]) + 64u, more_n = 64u;
-                    while (more_n == 64u) {
-                        const bool have = (uint32_t)lane < len - cur;
-                        const uint64_t ev = have ? (rows + rb + cur)[lane] : ~0ull;
-                        const bool more = have && (last || ev < upper);
-                        bool h2 = false;
-                        if (more && ev <= qmax) {
-                            const uint32_t k2 = (uint32_t)(ev >> shift) - b0;
-                            for (uint32_t t = (uint32_t)s_t[k2], te = (uint32_t)s_t[k2 + 1]; t < te; ++t) {
-                                const uint64_t qv = s_q[t];
-                                if (qv == ev) { h2 = true; break; }
-                                if (qv > ev) break;
-                            }
-                        }
-                        more_n = (uint32_t)__popcll(mask_of(more));
-                        hits += (uint32_t)__popcll(mask_of(h2));
-                        cur += more_n;
-                        taken += more_n;
-                    }
-                }
-                if (i < n_rows) {
-                    if (lane == 0) { s_cur[i] += taken; s_hits[i] += hits; }
-                    if (!last) ask(k);                                       // the row's part of the next range, a range ahead
-                }
-            }
-        }
-        OW_MARK(tr_proc)
-    }
-#ifdef SMG_OW_TRACE
-    if (blockIdx.x < 2 && lane == 0)
-        printf("wg %u wave %d: barrier1 %llu fill %llu barrier2 %llu rows %llu (cycles of s_memtime, %u ranges, %u rows)\n", blockIdx.x, wave, tr_b1, tr_fill, tr_b2, tr_proc, n_ranges, n_rows);
-#endif
-    __syncthreads();
-    for (uint32_t i = tid; i < n_rows; i += OW_THREADS) counts[d_lo + i] = s_hits[i];
-}
-
-// what the lean kernel's staging form (MODE 2) needs besides the walk's arguments
-struct RangeDesc { uint32_t b0, nb, p0, cnt; uint64_t upper; };   // first bucket, buckets, first query position, positions, first hash of the next range
-struct StageArgs {
-    const RangeDesc* desc = nullptr;      // [n_ranges]
-    uint32_t* inter = nullptr;            // the postings, window by window and workgroup by workgroup, wherever their runs were placed
-    uint32_t* dir_start = nullptr;        // [windows][n_sub] a run's start in inter ...
-    uint32_t* dir_len = nullptr;          //                  ... and length
-    uint32_t n_sub = 0;
-    unsigned int* misc = nullptr;         // [0] words of inter given out, [1] != 0: a window's part of the staging area overflowed
-};
-constexpr int LEAN_NW = 32;               // windows per range at most (W <= 8,192 query positions)
-constexpr int LEAN_CAPW = 352;            // postings a window's part of the staging area holds
-
-// ---- the wide form, lean visits (round 4) -----------------------------------------------------------------------------
-// Counters of the kernel above at C5 (profiles/r03_overlap_pmc.txt): 0.65e9 vector + 0.72e9 scalar + 0.13e9 LDS wave-instructions
-// per pass for 13 million visits -- ~115 instructions a visit, of which the lookup proper needs ~35 -- and its waves spend 57 % of
-// their cycles in s_waitcnt.  Twice the waves per SIMD (OwTwo) bought 3 %: it is the length of a visit's own dependent chain.
-// Where the instructions and the waits went: a row's start, end and cursor lived in LDS and were read back through
-// v_readfirstlane three to five times per visit (each a trip to LDS in FRONT of the load or the compare that needs it), hits
-// went to LDS counters, the last range's special cases (2^64 - 1 as a hash, hashes above the query) were tested in every range.
-// Here
-//   * a slot's row state is two scalars that never leave registers: pos[k] / end[k], element offsets of the row's next
-//     unconsumed hash and of its end -- the next load's address is scalar arithmetic on them;
-//   * hits are a scalar per slot as well (population count of the found mask); the compiler parks scalars it has no
-//     register for in lanes of a vector register (one v_readlane / v_writelane), which is far cheaper than an LDS counter;
-//   * "which lanes hold a hash of this range" is ONE compare (e < upper; lanes past the row's end hold 2^64 - 1), "found" is
-//     two compares: a bucket's first two query hashes are read whatever its size -- for a bucket of fewer the words behind it
-//     belong to later buckets and cannot equal a hash that falls into this one;
-//   * no clamp on the way to the query slice (two spare words behind it), no test against the largest query hash (hashes above
-//     it fall into padding buckets); a query that holds 2^64 - 1 itself takes the kernel above.
-// BUILD: the same walk as pass 1 of the gather index build (build_range_kernel<0>'s outputs): every database hash's position in
-// the query (or NONE32) goes to `qpos` -- a visit stores the positions of the hashes it consumes, consecutive lanes -- and the
-// postings this workgroup's rows add to every query hash are counted in LDS (16-bit counters: a workgroup has < 65,536 rows)
-// and written to part16[workgroup][query position] when the range is through.  counts[] then is the builder's 64-bit overlap.
-// MODE 2 (STAGE): pass 1 AND pass 2a of the builder.  The ranges are cut by query POSITION (sa.desc: `W` positions each, a
-// multiple of BR_SUB, so that the windows of BR_SUB lists the final scatter works by nest in them), the table slice of a range is
-// clipped to the range's positions, and every posting found -- (row << BR_SUB_BITS) | list within its window -- waits in LDS in
-// its window's part of a staging area until the range is through; then the workgroup reserves room for all of them in `inter`
-// with ONE atomic, writes every window's run with consecutive lanes and leaves (start, length) in the directory
-// dir[window][workgroup] the counting and scatter kernels read the runs by.  A window's part of the staging area holds
-// LEAN_CAPW postings (six standard deviations above the ~250 a window gets from 400 rows of a C5-like database); more than that
-// in any window raises sa.misc[1] and the host builds by the slower path instead.
-template <class G, int MODE>
-__global__ __launch_bounds__(OW_THREADS) __attribute__((amdgpu_waves_per_eu(G::WAVES_PER_EU, G::WAVES_PER_EU)))
-void overlap_lean_kernel(const uint64_t* __restrict__ Q, const uint32_t* __restrict__ T, uint32_t n_buckets, uint32_t shift,
-                         const uint64_t* __restrict__ hashes, const uint64_t* __restrict__ offsets, uint64_t ndb,
-                         uint32_t rows_per_wg, uint32_t n_ranges, uint32_t bpr, unsigned long long* __restrict__ counts,
-                         uint32_t* __restrict__ qpos, uint16_t* __restrict__ part16, uint64_t nq, StageArgs sa) {
-    constexpr int SLOTS = G::SLOTS, BUCKETS = G::BUCKETS, QCAP = G::QCAP, BATCH = G::BATCH;
-    constexpr bool BUILD = MODE == 1, STAGE = MODE == 2, QPOS = MODE != 0;
-    using TT = typename G::TT;
-    extern __shared__ __attribute__((aligned(16))) uint64_t ow_lds[];
-    uint64_t* s_q = ow_lds;                                              // [QCAP + 2]
-    TT* s_t = reinterpret_cast<TT*>(s_q + QCAP + 2);                     // [BUCKETS + 4]
-    uint32_t* s_h = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(s_t) + G::T_BYTES);   // BUILD: [QCAP / 2] pairs of 16-bit counters
-    uint32_t* s_stage = s_h;                                             // STAGE: [LEAN_NW][LEAN_CAPW] postings waiting, by window
-    uint32_t* s_wcur = s_stage + LEAN_NW * LEAN_CAPW;                    //        [LEAN_NW] postings staged per window
-    uint32_t* s_wbase = s_wcur + LEAN_NW;                                //        [LEAN_NW] where the window's run starts in `inter`
-    uint32_t* s_wn = s_wbase + LEAN_NW;                                  //        [LEAN_NW] its length
-    const uint64_t d_lo = (uint64_t)blockIdx.x * rows_per_wg;
-    if (d_lo >= ndb) return;
-    const uint32_t n_rows = (uint32_t)(ndb - d_lo < (uint64_t)rows_per_wg ? ndb - d_lo : (uint64_t)rows_per_wg);
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const uint64_t block_base = offsets[d_lo];
-    const uint64_t* rows = hashes + block_base;
-    uint32_t* const qrows = QPOS ? qpos + block_base : nullptr;
-    uint16_t* const part_row = BUILD ? part16 + (uint64_t)blockIdx.x * nq : nullptr;
-    if (BUILD)
-        for (uint32_t i = tid; i < (uint32_t)QCAP / 2; i += OW_THREADS) s_h[i] = 0;     // (ordered before the first add by the range's barriers)
-    if (STAGE && tid < LEAN_NW) s_wcur[tid] = 0;
-    uint32_t pos[SLOTS], end[SLOTS], hv[SLOTS];
-    uint64_t e[SLOTS];
-#pragma unroll
-    for (int k = 0; k < SLOTS; ++k) {
-        const uint32_t i = (uint32_t)wave + (uint32_t)k * OW_WAVES;          // wave-uniform: the loads below are scalar
-        pos[k] = end[k] = 0;
-        hv[k] = 0;
-        if (i < n_rows) {
-            pos[k] = uniform32((uint32_t)(offsets[d_lo + i] - block_base));
-            end[k] = uniform32((uint32_t)(offsets[d_lo + i + 1] - block_base));
-        }
-    }
-    auto ask = [&](int k) {                                                // the next 64 hashes of slot k's row
-        const uint32_t left = end[k] - pos[k];
-        e[k] = ~0ull;
-        if ((uint32_t)lane < left) e[k] = (rows + pos[k])[lane];
-    };
-#pragma unroll
-    for (int k = 0; k < SLOTS; ++k) ask(k);
-    constexpr int QPER = (QCAP + OW_THREADS - 1) / OW_THREADS, TPER = (BUCKETS + 1 + OW_THREADS - 1) / OW_THREADS;
-    uint32_t n_p0 = 0, n_p1 = 0;
-    RangeDesc n_rd{};
-    if (STAGE) n_rd = sa.desc[0];
-    else { n_p0 = T[0]; n_p1 = T[bpr < n_buckets ? bpr : n_buckets]; }
-    uint32_t done_p0 = 0, done_cnt = 0;                                   // BUILD / STAGE: the slice whose counters / postings are still in LDS
-    // STAGE, after a barrier: every window's run gets its place in `inter` (one atomic for the workgroup) and its directory entry
-    auto stage_place = [&]() {
-        if (tid < 64) {
-            const uint32_t nw = (done_cnt + (uint32_t)BR_SUB - 1) >> BR_SUB_BITS;        // windows of the range (<= LEAN_NW)
-            uint32_t have = (uint32_t)lane < nw ? s_wcur[lane] : 0u;
-            if (have > (uint32_t)LEAN_CAPW) { atomicOr(&sa.misc[1], 1u); have = LEAN_CAPW; }
-            uint32_t incl = have;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const uint32_t o = __shfl_up(incl, d);
-                if (lane >= d) incl += o;
-            }
-            const uint32_t total = __shfl(incl, 63);
-            uint32_t base = 0;
-            if (lane == 0 && total) base = atomicAdd(&sa.misc[0], total);
-            base = __shfl(base, 0);
-            if (lane < LEAN_NW) {
-                s_wbase[lane] = base + incl - have;
-                s_wn[lane] = have;
-                s_wcur[lane] = 0;
-            }
-            if ((uint32_t)lane < nw) {
-                const uint64_t di = (uint64_t)((done_p0 >> BR_SUB_BITS) + (uint32_t)lane) * sa.n_sub + blockIdx.x;
-                sa.dir_start[di] = base + incl - have;
-                sa.dir_len[di] = have;
-            }
-        }
-    };
-    auto stage_write = [&]() {                                             // after another barrier: the runs go out, consecutive lanes
-        for (uint32_t i = tid; i < (uint32_t)(LEAN_NW * LEAN_CAPW); i += OW_THREADS) {
-            const uint32_t wdw = i / (uint32_t)LEAN_CAPW, x = i - wdw * (uint32_t)LEAN_CAPW;
-            if (x < s_wn[wdw]) sa.inter[s_wbase[wdw] + x] = s_stage[i];
-        }
-    };
-    // a posting found: position jr of the range's slice, row `rowid`
-    auto stage_put = [&](uint32_t jr, uint32_t rowid) {
-        const uint32_t wdw = jr >> BR_SUB_BITS;
-        const uint32_t slot = atomicAdd(&s_wcur[wdw], 1u);
-        if (slot < (uint32_t)LEAN_CAPW) s_stage[wdw * (uint32_t)LEAN_CAPW + slot] = (rowid << BR_SUB_BITS) | (jr & (uint32_t)(BR_SUB - 1));
-    };
-    auto flush_counts = [&]() {                                            // ... go to this workgroup's row of part16, and back to zero
-        uint16_t* const h16 = reinterpret_cast<uint16_t*>(s_h);
-        for (uint32_t i = tid; i < done_cnt; i += OW_THREADS) {
-            part_row[done_p0 + i] = h16[i];
-            h16[i] = 0;
-        }
-    };
-    for (uint32_t r = 0; r < n_ranges; ++r) {
-        const bool last = r + 1 == n_ranges;
-        // b0: the slice's first bucket; kcap: buckets in the slice (a lane's bucket index is clamped to it: the padding behind)
-        uint32_t b0, b1 = 0, kcap, p0, cnt_q, cnt_t;
-        uint64_t upper;
-        if (STAGE) {
-            b0 = uniform32(n_rd.b0); kcap = uniform32(n_rd.nb); p0 = uniform32(n_rd.p0); cnt_q = uniform32(n_rd.cnt);
-            upper = uniform64(n_rd.upper);
-            cnt_t = kcap + 1;
-        } else {
-            b0 = r * bpr;
-            b1 = b0 + bpr < n_buckets ? b0 + bpr : n_buckets;
-            upper = last ? ~0ull : ((uint64_t)b1 << shift);
-            p0 = uniform32(n_p0); cnt_q = uniform32(n_p1) - p0; cnt_t = b1 - b0 + 1;
-            kcap = bpr;
-        }
-        __syncthreads();                                                  // the previous range's readers are done
-        if (BUILD) flush_counts();
-        if (STAGE && r > 0) {
-            stage_place();
-            __syncthreads();
-            stage_write();
-        }
-        if (QPOS) {
-            done_p0 = p0;
-            done_cnt = cnt_q;
-        }
-        {
-            constexpr int FILL_STEP = 4;                                  // (registers: 25 slots x (2 + 1) stay live across the fill)
-#pragma unroll
-            for (int u0 = 0; u0 < TPER; u0 += FILL_STEP) {
-                uint32_t tv[FILL_STEP];
-#pragma unroll
-                for (int u = 0; u < FILL_STEP; ++u) {
-                    const uint32_t i = (uint32_t)tid + (uint32_t)(u0 + u) * OW_THREADS;
-                    tv[u] = (u0 + u < TPER && i < cnt_t) ? T[b0 + i] : 0u;
-                }
-#pragma unroll
-                for (int u = 0; u < FILL_STEP; ++u) {
-                    const uint32_t i = (uint32_t)tid + (uint32_t)(u0 + u) * OW_THREADS;
-                    // every slot of the slice is written, the ones behind the range's buckets with the slice's size
-                    uint32_t v = tv[u] - p0;
-                    if (STAGE) v = tv[u] < p0 ? 0u : (v < cnt_q ? v : cnt_q);  // clipped to the range's positions: buckets at its ends reach past them
-                    if (u0 + u < TPER && i < (uint32_t)BUCKETS + 4u) s_t[i] = i < cnt_t ? (TT)v : (TT)cnt_q;
-                }
-            }
-#pragma unroll
-            for (int u0 = 0; u0 < QPER; u0 += FILL_STEP) {
-                uint64_t qv[FILL_STEP];
-#pragma unroll
-                for (int u = 0; u < FILL_STEP; ++u) {
-                    const uint32_t i = (uint32_t)tid + (uint32_t)(u0 + u) * OW_THREADS;
-                    qv[u] = (u0 + u < QPER && i < cnt_q) ? Q[p0 + i] : 0ull;
-                }
-#pragma unroll
-                for (int u = 0; u < FILL_STEP; ++u) {
-                    const uint32_t i = (uint32_t)tid + (uint32_t)(u0 + u) * OW_THREADS;
-                    if (u0 + u < QPER && i < cnt_q) s_q[i] = qv[u];
-                }
-            }
-        }
-        // padding buckets behind the table slice; two words of 2^64 - 1 behind the query slice: a lookup reads the two query
-        // hashes at its bucket's start whatever the bucket holds, and scans on while they are below its hash -- the slice is
-        // sorted, so what follows a bucket is larger than any hash that falls into it, and the padding ends every scan
-        if (tid < 2) s_q[cnt_q + tid] = ~0ull;                            // (the table slice's padding is written by its fill)
-        __syncthreads();
-        if (!last) {                                                     // the next range's bounds
-            if (STAGE) {
-                n_rd = sa.desc[r + 1];
-            } else {
-                const uint32_t nb0 = b1, nb1 = nb0 + bpr < n_buckets ? nb0 + bpr : n_buckets;
-                n_p0 = T[nb0];
-                n_p1 = T[nb1];
-            }
-        }
-#pragma unroll
-        for (int v0 = 0; v0 < SLOTS; v0 += BATCH) {
-            if ((uint32_t)wave + (uint32_t)v0 * OW_WAVES >= n_rows) break;  // no rows in this batch or behind it (wave-uniform)
-            uint64_t in[BATCH];
-            uint32_t t0[BATCH], t1[BATCH];
-#pragma unroll
-            for (int w = 0; w < BATCH; ++w) {
-                const int k = v0 + w;
-                if (k >= SLOTS) continue;
-                in[w] = mask_of(e[k] < upper);                               // lanes past the row's end hold 2^64 - 1
-                uint32_t kk = (uint32_t)(e[k] >> shift) - b0;                // < kcap for the lanes of `in`
-                kk = kk < kcap ? kk : kcap;                                  // the others: the padding buckets behind the slice
-                t0[w] = (uint32_t)s_t[kk];
-                t1[w] = (uint32_t)s_t[kk + 1];
-            }
-            uint64_t qa[BATCH], qb[BATCH];
-#pragma unroll
-            for (int w = 0; w < BATCH; ++w) {
-                if (v0 + w >= SLOTS) continue;
-                qa[w] = s_q[t0[w]];
-                qb[w] = s_q[t0[w] + 1];
-            }
-#pragma unroll
-            for (int w = 0; w < BATCH; ++w) {
-                const int k = v0 + w;
-                if (k >= SLOTS) continue;
-                const uint64_t second = mask_of(qb[w] == e[k]);
-                uint64_t found = in[w] & (mask_of(qa[w] == e[k]) | second);
-                uint32_t jr = 0;                                             // BUILD / STAGE: position within the slice of the hash found
-                if (QPOS) jr = t0[w] + (lanes_of(second) ? 1u : 0u);
-                // a bucket of three or more whose second hash is still below the lane's hash (rare: ~1 visit in 3 has such a
-                // lane, and a scan is a divergent loop over LDS): scan on.  (Without the size test every hash ABOVE both hashes of
-                // a bucket of two came here too -- 3 % of the lookups, three visits in four: 2.46 -> 3.44 ms.)
-                const uint64_t deep = mask_of(t1[w] > t0[w] + 2u) & mask_of(qb[w] < e[k]);
-                if (__builtin_expect(deep != 0ull, 0)) {
-                    bool hit = false;
-                    if (lanes_of(deep))
-                        for (uint32_t t = t0[w] + 2;; ++t) {
-                            const uint64_t qv = s_q[t];
-                            if (qv >= e[k]) { hit = qv == e[k]; if (QPOS && hit) jr = t; break; }
-                        }
-                    found |= in[w] & mask_of(hit);
-                }
-                if (QPOS) {
-                    if (lanes_of(in[w])) (qrows + pos[k])[lane] = lanes_of(found) ? p0 + jr : NONE32;
-                    if (BUILD && lanes_of(found)) atomicAdd(&s_h[jr >> 1], 1u << ((jr & 1u) << 4));
-                    if (STAGE && lanes_of(found)) stage_put(jr, (uint32_t)d_lo + (uint32_t)wave + (uint32_t)k * OW_WAVES);
-                }
-                hv[k] += (uint32_t)__popcll(found);
-                uint32_t taken = (uint32_t)__popcll(in[w]);
-                pos[k] += taken;
-                while (__builtin_expect(taken == 64u, 0)) {                  // the row's part of this range goes on (rare): block by block
-                    const uint32_t left = end[k] - pos[k];
-                    const uint64_t ev = (uint32_t)lane < left ? (rows + pos[k])[lane] : ~0ull;
-                    const bool more = ev < upper;
-                    bool h2 = false;
-                    if (more) {
-                        uint32_t k2 = (uint32_t)(ev >> shift) - b0;
-                        k2 = k2 < kcap ? k2 : kcap;
-                        uint32_t t = (uint32_t)s_t[k2];
-                        for (;; ++t) {
-                            const uint64_t qv = s_q[t];
-                            if (qv >= ev) { h2 = qv == ev; break; }
-                        }
-                        if (QPOS) {
-                            (qrows + pos[k])[lane] = h2 ? p0 + t : NONE32;
-                            if (BUILD && h2) atomicAdd(&s_h[t >> 1], 1u << ((t & 1u) << 4));
-                            if (STAGE && h2) stage_put(t, (uint32_t)d_lo + (uint32_t)wave + (uint32_t)k * OW_WAVES);
-                        }
-                    }
-                    hv[k] += (uint32_t)__popcll(mask_of(h2));
-                    taken = (uint32_t)__popcll(mask_of(more));
-                    pos[k] += taken;
-                }
-                if (!last) ask(k);                                           // the row's part of the next range, a range ahead
-            }
-        }
-    }
-    if (QPOS) {
-        __syncthreads();                                                  // the last range's adds are in
-        if (BUILD) flush_counts();
-        if (STAGE) {
-            stage_place();
-            __syncthreads();
-            stage_write();
-        }
-        // what the walk never consumed (a row's hash 2^64 - 1, which reads like the filler of lanes past a row's end): not in the query
-#pragma unroll
-        for (int k = 0; k < SLOTS; ++k)
-            for (uint32_t i = pos[k] + (uint32_t)lane; i < end[k]; i += 64) qrows[i] = NONE32;
-    }
-#pragma unroll
-    for (int k = 0; k < SLOTS; ++k) {
-        const uint32_t i = (uint32_t)wave + (uint32_t)k * OW_WAVES;
-        if (lane == 0 && i < n_rows) counts[d_lo + i] = hv[k];
-    }
-}
-
-// The builder's pass 1 through the kernel above: n_sub workgroups of rows_per_wg rows, part16 [n_sub][nq].
-constexpr size_t LEAN_BUILD_LDS = ((size_t)OwLean::QCAP + 2) * 8 + OwLean::T_BYTES + (size_t)OwLean::QCAP * 2;
-hipError_t build_lean_launch(const uint64_t* Q, uint64_t nq, const uint32_t* T, uint32_t n_buckets, uint32_t shift, const uint64_t* hashes,
-                             const uint64_t* offsets, uint64_t ndb, uint32_t rows_per_wg, uint32_t n_ranges, uint32_t bpr,
-                             unsigned long long* counters, uint32_t* qpos, uint16_t* part16, hipStream_t stream) {
-    static int attr = 0;
-    if (attr == 0) {
-        const hipError_t ea = hipFuncSetAttribute((const void*)overlap_lean_kernel<OwLean, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LEAN_BUILD_LDS);
-        attr = ea == hipSuccess ? 1 : -1;
-        if (attr < 0) (void)hipGetLastError();
-    }
-    if (attr < 0) return hipErrorInvalidValue;
-    const uint64_t n_sub = (ndb + rows_per_wg - 1) / rows_per_wg;
-    hipLaunchKernelGGL((overlap_lean_kernel<OwLean, 1>), dim3((unsigned)n_sub), dim3(OW_THREADS), LEAN_BUILD_LDS, stream, Q, T, n_buckets, shift,
-                       hashes, offsets, ndb, rows_per_wg, n_ranges, bpr, counters, qpos, part16, nq, StageArgs{});
-    return hipGetLastError();
-}
-
-// ... and its staging form (MODE 2): ranges of `W` query positions described by range_plan_kernel
-using OwStage = OwGeom<25, 9216, 8192, uint32_t, 4, 4>;
-constexpr size_t LEAN_STAGE_LDS = ((size_t)OwStage::QCAP + 2) * 8 + OwStage::T_BYTES + ((size_t)LEAN_NW * LEAN_CAPW + 3 * LEAN_NW) * 4;
-static_assert(LEAN_STAGE_LDS <= 160 * 1024, "");
-static_assert(LEAN_NW * BR_SUB >= OwStage::QCAP, "a range's windows all have a part of the staging area");
-
-__global__ __launch_bounds__(256) void range_plan_kernel(const uint64_t* __restrict__ Q, uint64_t nq, uint32_t shift, uint32_t n_buckets,
-                                                         uint32_t W, uint32_t n_ranges, RangeDesc* __restrict__ desc, unsigned int* max_nb) {
-    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n_ranges) return;
-    const uint64_t p0 = (uint64_t)r * W;
-    const bool last = r + 1 == n_ranges;
-    RangeDesc d;
-    d.p0 = (uint32_t)p0;
-    d.cnt = (uint32_t)(nq - p0 < (uint64_t)W ? nq - p0 : (uint64_t)W);
-    d.upper = last ? ~0ull : Q[p0 + W];                                  // hashes below it belong to this range or an earlier one
-    d.b0 = r == 0 ? 0u : (uint32_t)(Q[p0] >> shift);                      // (what lies below the query's first hash is range 0's, and misses)
-    const uint32_t b1 = last ? n_buckets - 1 : (uint32_t)(d.upper >> shift);
-    d.nb = b1 - d.b0 + 1;
-    desc[r] = d;
-    atomicMax(max_nb, d.nb);
-}
-
-uint32_t build_stage_positions(uint64_t nq, uint32_t buckets, double mean_row) {   // W: query positions per range
-    double w = 8900.0 * (double)nq / (double)buckets;                     // ~8,900 buckets per range, the slice has room for 9,216
-    const double q = lean_hashes_per_range(nq, mean_row);                 // ... and a row's part of a range ~48 hashes
-    if (w > q) w = q;
-    if (w > (double)OwStage::QCAP) w = (double)OwStage::QCAP;
-    const uint32_t W = ((uint32_t)w / (uint32_t)BR_SUB) * (uint32_t)BR_SUB;
-    return W < (uint32_t)BR_SUB ? (uint32_t)BR_SUB : W;
-}
-uint32_t build_stage_buckets_max() { return (uint32_t)OwStage::BUCKETS; }
-uint32_t build_stage_rows_max() { return (uint32_t)OwStage::ROWS; }
-size_t build_stage_desc_bytes(uint32_t n_ranges) { return (size_t)n_ranges * sizeof(RangeDesc); }
-
-hipError_t build_stage_plan(const uint64_t* Q, uint64_t nq, uint32_t shift, uint32_t n_buckets, uint32_t W, uint32_t n_ranges, void* desc,
-                            unsigned int* max_nb, hipStream_t stream) {
-    hipLaunchKernelGGL(range_plan_kernel, dim3((n_ranges + 255) / 256), dim3(256), 0, stream, Q, nq, shift, n_buckets, W, n_ranges,
-                       (RangeDesc*)desc, max_nb);
-    return hipGetLastError();
-}
-
-hipError_t build_stage_launch(const uint64_t* Q, uint64_t nq, const uint32_t* T, uint32_t n_buckets, uint32_t shift, const uint64_t* hashes,
-                              const uint64_t* offsets, uint64_t ndb, uint32_t rows_per_wg, uint32_t n_ranges, const void* desc,
-                              unsigned long long* counters, uint32_t* qpos, uint32_t* inter, uint32_t* dir_start, uint32_t* dir_len,
-                              unsigned int* misc, hipStream_t stream) {
-    static int attr = 0;
-    if (attr == 0) {
-        const hipError_t ea = hipFuncSetAttribute((const void*)overlap_lean_kernel<OwStage, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LEAN_STAGE_LDS);
-        attr = ea == hipSuccess ? 1 : -1;
-        if (attr < 0) (void)hipGetLastError();
-    }
-    if (attr < 0) return hipErrorInvalidValue;
-    const uint64_t n_sub = (ndb + rows_per_wg - 1) / rows_per_wg;
-    StageArgs sa;
-    sa.desc = (const RangeDesc*)desc;
-    sa.inter = inter;
-    sa.dir_start = dir_start;
-    sa.dir_len = dir_len;
-    sa.n_sub = (uint32_t)n_sub;
-    sa.misc = misc;
-    hipLaunchKernelGGL((overlap_lean_kernel<OwStage, 2>), dim3((unsigned)n_sub), dim3(OW_THREADS), LEAN_STAGE_LDS, stream, Q, T, n_buckets, shift,
-                       hashes, offsets, ndb, rows_per_wg, n_ranges, 0u, counters, qpos, (uint16_t*)nullptr, nq, sa);
-    return hipGetLastError();
-}
-
-// op 0: overlap[d] = cnt[d]; op 1: overlap[d] -= cnt[d], saturating (rows at 0 stay dropped, index/__init__.py:908-909)
-__global__ __launch_bounds__(256) void overlap_finish_kernel(const unsigned long long* __restrict__ cnt, uint64_t ndb,
-                                                             unsigned long long* __restrict__ overlap, int op) {
-    const uint64_t d = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (d >= ndb) return;
-    const unsigned long long c = cnt[d];
-    if (op == 0) overlap[d] = c;
-    else overlap[d] = c >= overlap[d] ? 0 : overlap[d] - c;
-}
-
-// |Q ∩ row| for every row with the lookups partitioned by query range (the builder's pass 1 without its outputs): the
-// slice of the query and of its first-level table a workgroup looks into stays in its XCD's L2, where the one-wave-per-row
-// kernel of pair_ops.hip re-fetched 14 GB for a 4 GB database with a 10^6-hash query.  One stream synchronisation (the
-// table geometry needs the largest query hash on the host).
-hipError_t overlap_ranges_launch(const uint64_t* Q, uint64_t nq, const uint64_t* hashes, const uint64_t* offsets, uint64_t ndb,
-                                 unsigned long long* overlap, int op, hipStream_t stream) {
-    if (nq == 0 || ndb == 0 || nq >= NONE32 || ndb >= NONE32) return hipErrorInvalidValue;
-    struct Pinned {
-        unsigned long long* p = nullptr;
-        ~Pinned() { if (p) arena_pinned_free(p); }
-    } pin;
-    SMG_TRY(arena_pinned_alloc((void**)&pin.p, 64));
-    SMG_TRY(hipMemcpyAsync(&pin.p[0], Q + nq - 1, 8, hipMemcpyDeviceToHost, stream));
-    SMG_TRY(hipMemcpyAsync(&pin.p[3], offsets + ndb, 8, hipMemcpyDeviceToHost, stream));
-    SMG_TRY(hipStreamSynchronize(stream));
-    const uint64_t q_max = pin.p[0];
-    const double mean_row = (double)pin.p[3] / (double)ndb;
-    uint32_t shift = 0, buckets = 1;
-    qindex_geometry(nq, q_max, &shift, &buckets);
-    lean_table_geometry(nq, q_max, mean_row, &shift, &buckets);
-    ArenaBuf table_b, cnt_b, q_padded_b, bounds_b, rec_b;
-    SMG_TRY(table_b.get(((uint64_t)buckets + 1) * 4 + 64, stream));
-    SMG_TRY(cnt_b.get(ndb * 8 + 64, stream));
-    uint32_t* table = table_b.as<uint32_t>();
-    unsigned long long* cnt = cnt_b.as<unsigned long long>();
-    SMG_TRY(hipMemsetAsync(cnt, 0, ndb * 8 + 64, stream));
-    hipLaunchKernelGGL(qtable_kernel, dim3((buckets + 256) / 256), dim3(256), 0, stream, Q, nq, shift, buckets, table);
-    // streaming form (the query through LDS) unless a range of the table holds more query hashes than LDS has room for
-    static const bool no_stream = [] { const char* e = getenv("SMG_OVERLAP"); return e && !strcmp(e, "ranges"); }();
-    static const bool only_stream = [] { const char* e = getenv("SMG_OVERLAP"); return e && !strcmp(e, "stream"); }();   // tests: no fallback
-    uint32_t bpr = SL_BUCKETS;                                             // buckets per range: about 2,000 query hashes
-    while (bpr > 64 && (double)bpr * (double)nq / (double)buckets > 2200.0) bpr >>= 1;
-    const uint32_t n_ranges = (buckets + bpr - 1) / bpr;
-    // the wide form for databases large enough to give every CU a few hundred rows; SMG_OVERLAP=wide makes a fallback an error
-    static const bool no_wide = [] { const char* e = getenv("SMG_OVERLAP"); return e && strcmp(e, "wide") != 0; }();
-    static const bool only_wide = [] { const char* e = getenv("SMG_OVERLAP"); return e && !strcmp(e, "wide"); }();
-    int n_cu_w = 256;
-    { int dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n_cu_w, hipDeviceAttributeMultiprocessorCount, dev); }
-    // The streaming kernels keep row cursors as 32-bit element offsets from their workgroup's first row: a collection of 2^32
-    // hashes or more (32 GB) could put more than that under one workgroup -- it takes the range-partitioned form, whose
-    // offsets are per row (the index build makes the same check on pinned[0]).
-    const bool spans32 = pin.p[3] < 0xffffffffull;
-    const bool try_wide = spans32 && !no_wide && (only_wide || ndb >= (uint64_t)n_cu_w * 64);
-    uint32_t wbpr = OW_BUCKETS;                                            // buckets per range of the wide form: about 10,000 query hashes
-    while (wbpr > 64 && (double)wbpr * (double)nq / (double)buckets > 10000.0) wbpr >>= 1;
-    const uint32_t w_ranges = (buckets + wbpr - 1) / wbpr;
-    // the Two form: about 6,800 query hashes per range, any number of buckets up to its table's room (not a power of two)
-    uint32_t w2bpr = (uint32_t)(6800.0 * (double)buckets / (double)nq);
-    if (w2bpr > (uint32_t)OwTwo::BUCKETS) w2bpr = OwTwo::BUCKETS;
-    if (w2bpr < 64) w2bpr = 64;
-    const uint32_t w2_ranges = (buckets + w2bpr - 1) / w2bpr;
-    const LeanPlan lean = build_lean_plan(nq, buckets, mean_row);                     // the lean form: ranges cut by query hashes held
-    const uint32_t lbpr = lean.bpr, l_ranges = lean.n_ranges;
-    // the widest range of either partition decides whether its LDS has room: all maxima come back with one synchronisation
-    unsigned int widest = 0, w_widest = 0, w2_widest = 0, l_widest = 0;
-    {
-        unsigned int* d_widest = (unsigned int*)(cnt + ndb);                // the 64 spare bytes, zeroed above
-        if (!no_stream)
-            hipLaunchKernelGGL(stream_range_max_kernel, dim3((n_ranges + 255) / 256), dim3(256), 0, stream, (const uint32_t*)table, buckets,
-                               n_ranges, bpr, d_widest);
-        if (try_wide) {
-            hipLaunchKernelGGL(stream_range_max_kernel, dim3((w_ranges + 255) / 256), dim3(256), 0, stream, (const uint32_t*)table, buckets,
-                               w_ranges, wbpr, d_widest + 1);
-            hipLaunchKernelGGL(stream_range_max_kernel, dim3((w2_ranges + 255) / 256), dim3(256), 0, stream, (const uint32_t*)table, buckets,
-                               w2_ranges, w2bpr, d_widest + 2);
-            hipLaunchKernelGGL(stream_range_max_kernel, dim3((l_ranges + 255) / 256), dim3(256), 0, stream, (const uint32_t*)table, buckets,
-                               l_ranges, lbpr, d_widest + 3);
-        }
-        if (!no_stream || try_wide) {
-            SMG_TRY(hipMemcpyAsync(&pin.p[1], d_widest, 16, hipMemcpyDeviceToHost, stream));
-            SMG_TRY(hipStreamSynchronize(stream));
-            widest = (unsigned int)(pin.p[1] & 0xffffffffull);
-            w_widest = (unsigned int)(pin.p[1] >> 32);
-            w2_widest = (unsigned int)(pin.p[2] & 0xffffffffull);
-            l_widest = (unsigned int)(pin.p[2] >> 32);
-        }
-    }
-    hipError_t e = hipSuccess;
-    bool wide_done = false;
-    if (try_wide) {
-        // rows a workgroup owns: every workgroup resident at once, in full rounds (a last round of a few workgroups would cost a
-        // whole pass over the query for a fraction of the rows); SMG_OVERLAP_ROWS overrides (tuning / tests)
-        static const uint64_t rpw_env = [] { const char* e = getenv("SMG_OVERLAP_ROWS"); return e ? (uint64_t)atoll(e) : 0ull; }();
-        auto rows_per_wg = [&](uint64_t resident, uint64_t cap) {
-            uint64_t rpw = (ndb + resident - 1) / resident;
-            if (rpw > cap) {
-                const uint64_t per_round = cap * resident;
-                const uint64_t slots = ((ndb + per_round - 1) / per_round) * resident;
-                rpw = (ndb + slots - 1) / slots;
-            }
-            if (rpw_env) rpw = rpw_env;
-            if (rpw > cap) rpw = cap;
-            return rpw < 1 ? (uint64_t)1 : rpw;
-        };
-        static int attr_state = 0;
-        if (attr_state == 0) {
-            const hipError_t ea = hipFuncSetAttribute((const void*)overlap_wide_kernel<OwOne>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)OwOne::LDS);
-            const hipError_t eb = hipFuncSetAttribute((const void*)overlap_wide_kernel<OwTwo>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)OwTwo::LDS);
-            attr_state = ea == hipSuccess && eb == hipSuccess ? 1 : -1;
-            if (attr_state < 0) (void)hipGetLastError();
-        }
-        // SMG_OVERLAP_WIDE=lean|one|two: the lean-visit kernel (default), the round-3 kernel, its two-workgroups-per-CU geometry
-        static const int pick = [] { const char* e = getenv("SMG_OVERLAP_WIDE"); return !e ? 0 : !strcmp(e, "one") ? 1 : !strcmp(e, "two") ? 2 : !strcmp(e, "lean") ? 3 : 0; }();
-        static int lean_attr = 0;
-        constexpr size_t LEAN_LDS = ((size_t)OwLean::QCAP + 2) * 8 + OwLean::T_BYTES;
-        if (lean_attr == 0) {
-            const hipError_t ea = hipFuncSetAttribute((const void*)overlap_lean_kernel<OwLean, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LEAN_LDS);
-            lean_attr = ea == hipSuccess ? 1 : -1;
-            if (lean_attr < 0) (void)hipGetLastError();
-        }
-        // (2^64 - 1 in the query: the lean kernel's filler value would be a hit -- the round-3 kernel handles it)
-        if (lean_attr > 0 && (pick == 0 || pick == 3) && l_widest <= (unsigned)OwLean::QCAP && l_widest > 0 && q_max != ~0ull) {
-            const uint64_t rpw = rows_per_wg((uint64_t)n_cu_w, OwLean::ROWS);
-            const uint64_t n_wg = (ndb + rpw - 1) / rpw;
-            hipLaunchKernelGGL((overlap_lean_kernel<OwLean, 0>), dim3((unsigned)n_wg), dim3(OW_THREADS), LEAN_LDS, stream, Q, (const uint32_t*)table, buckets,
-                               shift, hashes, offsets, ndb, (uint32_t)rpw, l_ranges, lbpr, cnt, (uint32_t*)nullptr, (uint16_t*)nullptr, (uint64_t)0, StageArgs{});
-            wide_done = true;
-        } else if (attr_state > 0 && pick != 1 && pick != 0 && w2_widest <= (unsigned)OwTwo::QCAP && w2_widest > 0) {
-            const uint64_t rpw = rows_per_wg((uint64_t)n_cu_w * 2, OwTwo::ROWS);
-            const uint64_t n_wg = (ndb + rpw - 1) / rpw;
-            hipLaunchKernelGGL(overlap_wide_kernel<OwTwo>, dim3((unsigned)n_wg), dim3(OW_THREADS), OwTwo::LDS, stream, Q, (const uint32_t*)table, buckets,
-                               shift, q_max, hashes, offsets, ndb, (uint32_t)rpw, w2_ranges, w2bpr, cnt);
-            wide_done = true;
-        } else if (attr_state > 0 && pick != 2 && w_widest <= (unsigned)OwOne::QCAP) {
-            const uint64_t rpw = rows_per_wg((uint64_t)n_cu_w, OwOne::ROWS);
-            const uint64_t n_wg = (ndb + rpw - 1) / rpw;
-            hipLaunchKernelGGL(overlap_wide_kernel<OwOne>, dim3((unsigned)n_wg), dim3(OW_THREADS), OwOne::LDS, stream, Q, (const uint32_t*)table, buckets,
-                               shift, q_max, hashes, offsets, ndb, (uint32_t)rpw, w_ranges, wbpr, cnt);
-            wide_done = true;
-        } else if (only_wide) {
-            return hipErrorInvalidValue;
-        }
-    }
-    if (wide_done) {
-    } else if (only_wide) {
-        return hipErrorInvalidValue;
-    } else if (spans32 && !no_stream && widest <= (unsigned)SL_QCAP) {
-        const uint32_t n_blocks = (uint32_t)((ndb + SL_ROWS - 1) / SL_ROWS);
-        // every workgroup resident at once (4 per CU by LDS and waves): with even a few more than fit, the kernel takes two
-        // rounds -- 784 workgroups on 768 slots ran 4.2 ms with the CUs idle 42 % of the wave-time (profiles/r02_gather_sq.txt)
-        int n_cu = 256;
-        { int dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev); }
-        const uint32_t slots = (uint32_t)n_cu * 4u;
-        uint32_t n_groups = slots / n_blocks;                                // floor: never one workgroup more than fits
-        if (n_groups > n_ranges) n_groups = n_ranges;
-        if (n_groups < 1) n_groups = 1;
-        const uint32_t per = (n_ranges + n_groups - 1) / n_groups;
-        n_groups = (n_ranges + per - 1) / per;
-        hipLaunchKernelGGL(stream_lookup_kernel<3>, dim3(n_blocks * n_groups), dim3(SL_THREADS), 0, stream, Q, (const uint32_t*)table, buckets,
-                           shift, q_max, hashes, offsets, ndb, n_blocks, n_ranges, per, bpr, cnt);
-    } else if (only_stream) {
-        return hipErrorInvalidValue;
-    } else {
-        const uint32_t R = (uint32_t)((nq + BR_RANGE - 1) / BR_RANGE);
-        uint64_t B = 64;
-        if (B > (ndb + 127) / 128) B = (ndb + 127) / 128;
-        if (B < 1) B = 1;
-        const uint64_t rows_per_block = (ndb + B - 1) / B;
-        SMG_TRY(q_padded_b.get((nq + 4) * 8, stream));
-        SMG_TRY(bounds_b.get(((uint64_t)R + 1) * ndb * 4, stream));
-        SMG_TRY(rec_b.get((uint64_t)buckets * sizeof(QRec), stream));
-        uint64_t* q_padded = q_padded_b.as<uint64_t>();
-        uint32_t* bounds = bounds_b.as<uint32_t>();
-        QRec* rec = rec_b.as<QRec>();
-        SMG_TRY(hipMemcpyAsync(q_padded, Q, nq * 8, hipMemcpyDeviceToDevice, stream));
-        for (int i = 0; i < 4; ++i) SMG_TRY(hipMemcpyAsync(q_padded + nq + i, Q + nq - 1, 8, hipMemcpyDeviceToDevice, stream));
-        hipLaunchKernelGGL(qrec_kernel, dim3((buckets + 255) / 256), dim3(256), 0, stream, Q, (const uint32_t*)table, buckets, rec);
-        hipLaunchKernelGGL(build_bounds_kernel, dim3(blocks_for_rows(ndb)), dim3(256), 0, stream, Q, R, hashes, offsets, ndb, bounds);
-        const QIndex qi{q_padded, nq, table, shift, q_max, rec};
-        hipLaunchKernelGGL(build_range_kernel<3>, dim3((unsigned)(((R + 7) / 8) * 8 * B)), dim3(BR_THREADS), 0, stream, qi, hashes, offsets,
-                           ndb, (const uint32_t*)bounds, R, (uint32_t)B, rows_per_block, (uint32_t*)nullptr, (const uint64_t*)nullptr,
-                           (uint32_t*)nullptr, cnt, (uint32_t*)nullptr, (uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr);
-    }
-    hipLaunchKernelGGL(overlap_finish_kernel, dim3((unsigned)((ndb + 255) / 256)), dim3(256), 0, stream, cnt, ndb, overlap, op);
-    e = hipGetLastError();
-    return e;
 }
 
 }  // namespace smg

@@ -157,8 +157,9 @@ hipError_t gather_enqueue_rounds(GatherDev& g, unsigned rounds, hipStream_t stre
 // queue ahead of the kernels (profiles/r02_gather_host_variance.txt); the caller decides.
 hipError_t gather_enqueue_rounds_graph(GatherDev& g, unsigned rounds, hipStream_t* used);
 
-// overlap[d] = |Q ∩ D_d| (op 0) or overlap[d] -= |Q ∩ D_d| saturating (op 1) with range-partitioned lookups: the form of
-// pair_api.hpp's overlap_vector_launch for queries of many ranges (synchronises the stream once)
+// overlap[d] = |Q ∩ D_d| (op 0) or overlap[d] -= |Q ∩ D_d| saturating (op 1) by the streaming walks of overlap.hip: the form of
+// pair_api.hpp's overlap_vector_launch for large queries over many rows (synchronises the stream twice); hipErrorNotSupported when
+// the query's ranges fit neither streaming form
 hipError_t overlap_ranges_launch(const uint64_t* Q, uint64_t nq, const uint64_t* hashes, const uint64_t* offsets, uint64_t ndb,
                                  unsigned long long* overlap, int op, hipStream_t stream);
 constexpr uint64_t OVERLAP_RANGES_MIN_NQ = 4 * 32768;   // below this the one-wave-per-row kernel's table already sits in L2

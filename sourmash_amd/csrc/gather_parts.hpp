@@ -1,0 +1,39 @@
+// gather_parts.hpp -- what gather.hip (index build, rounds, resident loop) and overlap.hip (the streaming walks over a
+// collection: the overlap pass of search / prefetch, and pass 1 + 2a of the index build) share.  Internal to the two units.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+namespace smg {
+
+#define SMG_TRY(expr)                      \
+    do {                                   \
+        hipError_t e_ = (expr);            \
+        if (e_ != hipSuccess) return e_;   \
+    } while (0)
+
+// the final scatter of the index build works by windows of BR_SUB posting lists; a staged posting is (row << BR_SUB_BITS) | list
+// within its window
+constexpr int BR_SUB = 256;
+constexpr int BR_SUB_BITS = 8;
+
+// gather.hip: T[b] = first position of the sorted query with Q >= b << shift, b = 0 .. buckets (qindex.hpp: qindex_geometry)
+hipError_t qtable_launch(const uint64_t* Q, uint64_t nq, uint32_t shift, uint32_t buckets, uint32_t* table, hipStream_t stream);
+
+// overlap.hip: the builder's pass 1 + 2a through the lean streaming kernel's staging form
+uint32_t build_stage_positions(uint64_t nq, uint32_t buckets, double mean_row);
+uint32_t build_stage_buckets_max();
+uint32_t build_stage_rows_max();
+size_t build_stage_desc_bytes(uint32_t n_ranges);
+hipError_t build_stage_plan(const uint64_t* Q, uint64_t nq, uint32_t shift, uint32_t n_buckets, uint32_t W, uint32_t n_ranges, void* desc,
+                            unsigned int* max_nb, hipStream_t stream);
+hipError_t build_stage_launch(const uint64_t* Q, uint64_t nq, const uint32_t* T, uint32_t n_buckets, uint32_t shift, const uint64_t* hashes,
+                              const uint64_t* offsets, uint64_t ndb, uint32_t rows_per_wg, uint32_t n_ranges, const void* desc,
+                              unsigned long long* counters, uint32_t* qpos, uint32_t* inter, uint32_t* dir_start, uint32_t* dir_len,
+                              unsigned int* misc, hipStream_t stream);
+void lean_table_geometry(uint64_t nq, uint64_t q_max, double mean_row, uint32_t* shift, uint32_t* buckets);
+struct LeanPlan { uint32_t bpr, n_ranges, qcap, rows_cap; };
+LeanPlan build_lean_plan(uint64_t nq, uint32_t buckets, double mean_row);
+
+}  // namespace smg

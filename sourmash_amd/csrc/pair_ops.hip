@@ -253,8 +253,12 @@ hipError_t overlap_vector_launch(const uint64_t* Q, uint64_t nq, const uint64_t*
     }
     if (nq >= NONE32) return hipErrorInvalidValue;
     static const bool no_ranges = [] { const char* e = getenv("SMG_OVERLAP"); return e && !strcmp(e, "rows"); }();
-    if (!no_ranges && nq >= OVERLAP_RANGES_MIN_NQ && ndb >= OVERLAP_RANGES_MIN_ROWS && ndb < NONE32)
-        return overlap_ranges_launch(Q, nq, hashes, offsets, ndb, overlap, op, stream);   // gather.hip: lookups stay in L2
+    if (!no_ranges && nq >= OVERLAP_RANGES_MIN_NQ && ndb >= OVERLAP_RANGES_MIN_ROWS && ndb < NONE32) {
+        // overlap.hip: the query streams through LDS in ranges.  hipErrorNotSupported: neither streaming form has room for this
+        // query's ranges (or the collection holds 2^32 hashes or more) -- the one-wave-per-row kernel below takes anything
+        const hipError_t es = overlap_ranges_launch(Q, nq, hashes, offsets, ndb, overlap, op, stream);
+        if (es != hipErrorNotSupported) return es;
+    }
     // scratch: header, padded query, table of at most 2 * nq + 2 entries; allocated and released in stream order
     uint8_t* scratch = nullptr;
     const size_t bytes = QIH_BYTES + (nq + 4) * 8 + (2 * nq + 4) * 4;

@@ -143,7 +143,7 @@ def test_search_and_prefetch_vs_oracle(sm):
     assert db.best_containment(q).signature.name in ("s5", "s116")          # itself or its planted duplicate
 
 
-@pytest.mark.parametrize("build", ["atomic", "ranges", "ranges-direct", "ranges-streams"])
+@pytest.mark.parametrize("build", ["atomic", "ranges", "ranges-direct"])
 def test_synthetic_gather_vs_oracle(sm, build, monkeypatch):
     # the builders of the inverted index (csrc/gather.hip: one atomic per element / range-partitioned with the
     # histogram in LDS, postings filled through the two-level partition or by direct stores) -- the size heuristic
@@ -166,8 +166,7 @@ def test_synthetic_gather_vs_oracle(sm, build, monkeypatch):
         assert len(want) > 10 or thr_bp == 200_000
 
 
-@pytest.mark.parametrize("fill,pass1", [("staged", "ranges"), ("staged", "lean"), ("staged", "stage"), ("streams", "lean"),
-                                        ("streams", "ranges"), ("direct", "ranges")])
+@pytest.mark.parametrize("fill,pass1", [("staged", "ranges"), ("staged", "stage"), ("direct", "ranges")])
 def test_range_builder_postings_are_exact(fill, pass1, monkeypatch):
     """The postings themselves (not only the gather they drive): after the range-partitioned build every counter equals
     |Q ∩ row|, and consuming the whole query through the postings brings every counter to exactly zero -- which holds
@@ -178,8 +177,8 @@ def test_range_builder_postings_are_exact(fill, pass1, monkeypatch):
     from sourmash_amd.synth import synth_gather
     monkeypatch.setenv("SMG_GATHER_BUILD", "ranges")
     monkeypatch.setenv("SMG_GATHER_FILL", fill)
-    monkeypatch.setenv("SMG_GATHER_PASS1", pass1)                 # pass 1 by lookups in L2 / by the lean streaming kernel (counting, or
-                                                                  # staging the postings itself); a fallback is an error
+    monkeypatch.setenv("SMG_GATHER_PASS1", pass1)                 # pass 1 by lookups in L2 / by the lean streaming kernel staging the
+                                                                  # postings itself; a fallback is an error
     qh, dbh = synth_gather(n_query=3 * 32768 + 77, n_db=700, db_size=900)
     dbh[3] = np.zeros(0, dtype=np.uint64)
     dbh[4] = np.array([1, 2, 3], dtype=np.uint64)
@@ -217,7 +216,7 @@ def test_index_build_of_many_rows_takes_the_lean_pass(monkeypatch):
     q = torch.from_numpy(qh.view(np.int64).copy()).cuda()
     want = np.array([oracle.intersection_size(qh, d)[0] for d in dbh], dtype=np.uint64)
     ref = oracle.gather(qh, *oracle.make_csr(dbh), threshold_bp=0, scaled=1000, nthreads=8)
-    for pass1 in (None, "stage", "lean", "ranges"):                # the default must be one of the lean forms: both are forced as well
+    for pass1 in (None, "stage", "ranges"):                        # the default must be the staging form: it is forced as well, and the lookups
         if pass1:
             monkeypatch.setenv("SMG_GATHER_PASS1", pass1)
         st = be.gather_state(q, len(qh), h, off, len(dbh), 0)
@@ -269,11 +268,11 @@ def test_lean_index_build_with_short_and_awkward_queries(n_query, monkeypatch):
     assert not st.counters().any()
 
 
-@pytest.mark.parametrize("form", ["wide", "stream", "ranges"])
+@pytest.mark.parametrize("form", ["wide", "stream", "rows"])
 def test_overlaps_of_a_large_query_take_the_range_partitioned_pass(form):
-    """smgpu_overlap_raw with a large query over >= 4096 rows (gather.hip: overlap_ranges_launch), both ops, vs the oracle:
-    the streaming form (the query through LDS; SMG_OVERLAP=stream makes a fallback an error) and the range-partitioned
-    form it falls back to.  The switch is read once per process, so each form runs in its own interpreter."""
+    """smgpu_overlap_raw with a large query over >= 4096 rows (overlap.hip: overlap_ranges_launch), both ops, vs the oracle: the
+    lean walk (SMG_OVERLAP=wide: a fallback is an error), the 16-lane streaming form (stream: likewise) and the one-wave-per-row
+    kernel that takes whatever fits neither (rows).  The switch is read once per process, so each form runs in its own interpreter."""
     import os, subprocess, sys
     from conftest import ROOT
     code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
@@ -305,6 +304,33 @@ def _overlaps_large_query():
     sub = np.array([oracle.intersection_size(part, d)[0] for d in dbh], dtype=np.int64)
     want[7] = 1
     assert np.array_equal(cnt.cpu().numpy(), np.maximum(want - sub, 0))
+
+
+def test_overlaps_of_a_crowded_query_fall_back_to_the_row_kernel():
+    """A query crowded into a sliver of the hash space: 100,000 of its 140,000 hashes are consecutive integers, so one bucket of the
+    first-level table -- one range of either streaming form -- holds far more query hashes than their LDS slices have room for.
+    overlap_ranges_launch reports that, and the one-wave-per-row kernel answers (pair_ops.hip: overlap_vector_launch): the counts of
+    numpy's |Q ∩ row|, no error, default settings."""
+    import torch
+    from sourmash_amd import device as smd, parallel
+    rng = np.random.default_rng(12)
+    dense = np.arange(100_000, dtype=np.uint64) + np.uint64(1 << 40)
+    spread = np.unique(rng.integers(0, 1 << 54, size=40_000, dtype=np.uint64))
+    qh = np.unique(np.concatenate([dense, spread]))
+    dbh = []
+    for d in range(4300):
+        own = rng.integers(0, 1 << 54, size=40, dtype=np.uint64)
+        take = rng.choice(qh, size=int(rng.integers(0, 60)), replace=False)
+        dbh.append(np.unique(np.concatenate([own, take])))
+    dbh[7] = dense[500:900].copy()
+    dbh[8] = np.zeros(0, dtype=np.uint64)
+    be = parallel.DeviceBackend()
+    h, off = smd.pack_csr(dbh)
+    q = torch.from_numpy(qh.view(np.int64).copy()).cuda()
+    cnt = be.zeros((len(dbh),), torch.int64)
+    be.overlaps(q, len(qh), h, off, len(dbh), cnt, 0)
+    want = np.array([np.isin(d, qh).sum() for d in dbh], dtype=np.int64)
+    assert np.array_equal(cnt.cpu().numpy(), want) and want[7] == 400
 
 
 def test_overlaps_wide_form_with_more_rows_than_one_round_of_workgroups():
@@ -374,7 +400,7 @@ def test_gather_random_shapes_every_builder(monkeypatch):
         assert np.array_equal(cnt.cpu().numpy().view(np.uint64), want_cnt), ("overlaps", case)
         thr_bp = int(rng.choice([0, 3000, 60_000]))
         want = oracle.gather(qh, fh, foff, threshold_bp=thr_bp, scaled=1000)
-        for build, fill in (("atomic", "staged"), ("ranges", "staged"), ("ranges", "streams"), ("ranges", "direct")):
+        for build, fill in (("atomic", "staged"), ("ranges", "staged"), ("ranges", "direct")):
             monkeypatch.setenv("SMG_GATHER_BUILD", build)
             monkeypatch.setenv("SMG_GATHER_FILL", fill)
             st = be.gather_state(q, len(qh), h, off, ndb, 0)

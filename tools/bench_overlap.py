@@ -1,5 +1,5 @@
 """The overlap pass (search / prefetch: |Q ∩ row| for every row) at config-C5 size on one GPU:
-python tools/bench_overlap.py [--ndb 100000] [--reps 5]   (SMG_OVERLAP / SMG_OVERLAP_WIDE / SMG_OVERLAP_ROWS select the form)
+python tools/bench_overlap.py [--ndb 100000] [--reps 5]   (SMG_OVERLAP / SMG_OVERLAP_ROWS select the form)
 -> one JSON line: ms per pass (HIP events), algorithmic GB/s, and two checksums of the counts (equal across forms)."""
 import argparse
 import json
@@ -35,7 +35,7 @@ def main():
     ms = sorted(e0.elapsed_time(e1) for e0, e1 in evs)
     db_bytes = int(h.numel()) * 8
     w = torch.arange(1, a.ndb + 1, device=dev, dtype=torch.int64)
-    print(json.dumps({"form": os.environ.get("SMG_OVERLAP", "auto") + "/" + os.environ.get("SMG_OVERLAP_WIDE", "auto"),
+    print(json.dumps({"form": os.environ.get("SMG_OVERLAP", "auto"),
                       "rows_env": os.environ.get("SMG_OVERLAP_ROWS"), "ndb": a.ndb, "db_bytes": db_bytes,
                       "ms_min": round(ms[0], 3), "ms_median": round(ms[len(ms) // 2], 3),
                       "GBps_algorithmic": round((db_bytes + 8 * int(q.numel())) / (ms[len(ms) // 2] * 1e-3) / 1e9, 1),
