@@ -1,0 +1,274 @@
+// abund_pairs.hip -- all pairs of abundance-tracking sketches through lists sorted by hash (round 5).
+//
+// What is computed: prod[i][j] = sum over the hashes common to sketches i and j of abund_i * abund_j (u64, wrapping like the
+// reference's release build), common[i][j] = the number of those hashes -- the integer part of angular_similarity,
+// src/core/src/sketch/minhash.rs:635-680, for every pair of a collection (src/sourmash/compare.py:14-64 walks the pairs).
+//
+// Rounds 3-4 ran the reference's two-pointer walk for every pair (compare_ext.hip, one lane per pair over LDS-staged segments):
+// 5 x 10^5 pairs x 10^4 steps at config C3's shape, 5.5 ms, a dependent LDS chain per step.  The work that has to be done is the
+// MATCHES: 2.5 x 10^8 products at C3 (10 % of every pair's hashes are shared), a twentieth of the walk's steps.  Here the
+// collection is turned once into per-block lists -- the elements of 64 consecutive sketches sorted by hash, each with its row within
+// the block and its abundance (two stable device radix sorts: by hash, then by block) -- and an output tile (block bi x block bj)
+// is the merge-join of two such lists: equal hashes meet, and every (row of bi, row of bj) pair of a met hash adds one product to
+// the tile's 64 x 64 accumulators in LDS.  A tile's join is cut into Z hash slices when there are few tiles (C3: 136 tiles on
+// 256 CUs), the slices' sums meeting in the zeroed matrices through atomics.
+//
+// The join, per workgroup: the next <= 2,048 entries of list B go to LDS (whole runs of equal hashes only); every entry of list A up
+// to B's last staged hash is taken by one thread, which finds its hash in the staged B entries by binary search (11 LDS reads,
+// independent of its neighbours': 16 waves per CU overlap them) and walks the run of equal hashes there.  Work grows with
+// |A| + |B| + matches per tile, not with pairs x lengths.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <rocprim/device/device_radix_sort.hpp>
+#include "arena.hpp"
+#include "device_api.hpp"
+
+namespace smg {
+
+namespace {
+
+constexpr int AP_T = 64;                 // sketches per block = tile edge
+constexpr int AP_THREADS = 1024;
+constexpr int AP_CHUNK = 2048;           // entries of list B staged per round
+constexpr int AP_ZMAX = 16;              // hash slices per tile at most
+
+#define AP_TRY(expr)                       \
+    do {                                   \
+        hipError_t e_ = (expr);            \
+        if (e_ != hipSuccess) return e_;   \
+    } while (0)
+
+// pos[p] = p, blk[p] = block of the sketch that element p belongs to
+__global__ __launch_bounds__(256) void ap_rows_kernel(const uint64_t* __restrict__ offsets, uint32_t n, uint32_t* __restrict__ pos,
+                                                      uint32_t* __restrict__ rowid) {
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    for (uint64_t r = wave; r < n; r += n_waves)
+        for (uint64_t i = offsets[r] + lane; i < offsets[r + 1]; i += 64) { pos[i] = (uint32_t)i; rowid[i] = (uint32_t)r; }
+}
+
+__global__ __launch_bounds__(256) void ap_block_keys_kernel(const uint32_t* __restrict__ pos_sorted, const uint32_t* __restrict__ rowid,
+                                                            uint64_t total, uint32_t* __restrict__ key) {
+    for (uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (uint64_t)gridDim.x * blockDim.x)
+        key[q] = rowid[pos_sorted[q]] / (uint32_t)AP_T;
+}
+
+// the lists: element q of the block-major, hash-sorted order -> its hash, its row within the block and its abundance
+template <bool NARROW>
+__global__ __launch_bounds__(256) void ap_gather_kernel(const uint32_t* __restrict__ pos_sorted, const uint32_t* __restrict__ rowid,
+                                                        const uint64_t* __restrict__ hashes, const uint64_t* __restrict__ abunds,
+                                                        uint64_t total, uint64_t* __restrict__ l_hash, uint64_t* __restrict__ l_pay,
+                                                        uint8_t* __restrict__ l_row) {
+    for (uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t p = pos_sorted[q];
+        const uint32_t r = rowid[p] % (uint32_t)AP_T;
+        l_hash[q] = hashes[p];
+        if (NARROW) l_pay[q] = ((uint64_t)r << 32) | (uint32_t)abunds[p];     // row and 32-bit abundance in one word
+        else { l_pay[q] = abunds[p]; l_row[q] = (uint8_t)r; }
+    }
+}
+
+__device__ __forceinline__ uint64_t ap_lower_bound(const uint64_t* __restrict__ a, uint64_t lo, uint64_t hi, uint64_t x) {
+    while (lo < hi) {
+        const uint64_t mid = (lo + hi) >> 1;
+        if (a[mid] < x) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+}
+
+// one workgroup per (tile, slice): tile t = (bi, bj), bi <= bj, enumerated row by row of the upper triangle
+template <bool NARROW>
+__global__ __launch_bounds__(AP_THREADS) void ap_join_kernel(const uint64_t* __restrict__ l_hash, const uint64_t* __restrict__ l_pay,
+                                                             const uint8_t* __restrict__ l_row, const uint64_t* __restrict__ offsets,
+                                                             uint32_t n, uint32_t nb, uint32_t Z, uint32_t* __restrict__ common,
+                                                             unsigned long long* __restrict__ prod) {
+    extern __shared__ __attribute__((aligned(16))) uint64_t ap_lds[];      // AP_LDS bytes (more than the 64 KB a static array may take)
+    uint64_t* s_bh = ap_lds;                                         // [AP_CHUNK] staged hashes of list B
+    uint64_t* s_bp = s_bh + AP_CHUNK;                                // [AP_CHUNK] their payloads
+    unsigned long long* s_prod = reinterpret_cast<unsigned long long*>(s_bp + AP_CHUNK);   // [AP_T * AP_T]
+    uint32_t* s_cnt = reinterpret_cast<uint32_t*>(s_prod + AP_T * AP_T);                   // [AP_T * AP_T]
+    uint8_t* s_br = reinterpret_cast<uint8_t*>(s_cnt + AP_T * AP_T);                       // [AP_CHUNK] rows of the staged entries (wide abundances)
+    __shared__ uint64_t s_bound[4];                                  // this slice's ranges in the two lists
+    const int tid = threadIdx.x;
+    const uint32_t z = blockIdx.x % Z;
+    uint32_t t = blockIdx.x / Z, bi = 0;
+    while (t >= nb - bi) { t -= nb - bi; ++bi; }                     // (nb is small: at most a few hundred steps)
+    const uint32_t bj = bi + t;
+    const bool diag = bi == bj;
+    const uint32_t row0 = bi * AP_T, col0 = bj * AP_T;
+    const uint32_t ra_end = row0 + AP_T < n ? row0 + AP_T : n, rb_end = col0 + AP_T < n ? col0 + AP_T : n;
+    const uint64_t A0 = offsets[row0], A1 = offsets[ra_end], B0 = offsets[col0], B1 = offsets[rb_end];
+    for (int i = tid; i < AP_T * AP_T; i += AP_THREADS) { s_prod[i] = 0; s_cnt[i] = 0; }
+    if (tid == 0) {
+        // slice z of the tile: an equal share of list A's entries, moved to the start of a run of equal hashes; list B between the
+        // same two hash values
+        uint64_t a0 = A0 + (A1 - A0) * z / Z, a1 = z + 1 == Z ? A1 : A0 + (A1 - A0) * (z + 1) / Z;
+        if (a0 > A0 && a0 < A1) a0 = ap_lower_bound(l_hash, A0, a0, l_hash[a0]);
+        if (a1 > A0 && a1 < A1) a1 = ap_lower_bound(l_hash, A0, a1, l_hash[a1]);
+        uint64_t b0 = B0, b1 = B1;
+        if (a0 < a1) {
+            if (a0 > A0) b0 = ap_lower_bound(l_hash, B0, B1, l_hash[a0]);
+            if (a1 < A1) b1 = ap_lower_bound(l_hash, b0, B1, l_hash[a1]);
+        } else b1 = b0;
+        s_bound[0] = a0; s_bound[1] = a1; s_bound[2] = b0; s_bound[3] = b1;
+    }
+    __syncthreads();
+    uint64_t a_cur = s_bound[0];
+    const uint64_t a_end = s_bound[1];
+    uint64_t b_cur = s_bound[2];
+    const uint64_t b_end = s_bound[3];
+    while (a_cur < a_end && b_cur < b_end) {
+        // ---- stage the next entries of B: whole runs of equal hashes only (a run holds at most AP_T entries) ----
+        uint64_t nb_stage = b_end - b_cur < (uint64_t)AP_CHUNK ? b_end - b_cur : (uint64_t)AP_CHUNK;
+        for (uint32_t i = tid; i < (uint32_t)nb_stage; i += AP_THREADS) {
+            s_bh[i] = l_hash[b_cur + i];
+            s_bp[i] = l_pay[b_cur + i];
+            if (!NARROW) s_br[i] = l_row[b_cur + i];
+        }
+        __syncthreads();
+        if (b_cur + nb_stage < b_end) {                              // the run the chunk ends in may go on: leave it for the next round
+            const uint64_t last = s_bh[nb_stage - 1];
+            uint64_t cut = nb_stage - 1;
+            while (cut > 0 && s_bh[cut - 1] == last) --cut;           // (every thread walks the same <= AP_T broadcast reads)
+            nb_stage = cut;                                           // > 0: a run is shorter than the chunk
+        }
+        const uint64_t hi = s_bh[nb_stage - 1];                       // A's entries up to this hash meet everything they can meet here
+        // ---- A's entries <= hi, a batch of AP_THREADS at a time ----
+        for (;;) {
+            const uint64_t idx = a_cur + (uint64_t)tid;
+            uint64_t h = ~0ull, pay = 0;
+            uint32_t ra = 0;
+            bool mine = false;
+            if (idx < a_end) {
+                h = l_hash[idx];
+                mine = h <= hi;
+                if (mine) {
+                    pay = l_pay[idx];
+                    ra = NARROW ? (uint32_t)(pay >> 32) : (uint32_t)l_row[idx];
+                }
+            }
+            if (mine) {
+                uint32_t lo = 0, hi_i = (uint32_t)nb_stage;
+                while (lo < hi_i) {
+                    const uint32_t mid = (lo + hi_i) >> 1;
+                    if (s_bh[mid] < h) lo = mid + 1; else hi_i = mid;
+                }
+                const unsigned long long aa = NARROW ? (unsigned long long)(uint32_t)pay : (unsigned long long)pay;
+                for (uint32_t j = lo; j < (uint32_t)nb_stage && s_bh[j] == h; ++j) {
+                    const uint64_t pb = s_bp[j];
+                    const uint32_t rb = NARROW ? (uint32_t)(pb >> 32) : (uint32_t)s_br[j];
+                    if (diag && rb <= ra) continue;                  // a diagonal tile joins a list with itself: every pair once
+                    const unsigned long long ab = NARROW ? (unsigned long long)(uint32_t)pb : (unsigned long long)pb;
+                    atomicAdd(&s_prod[ra * AP_T + rb], aa * ab);
+                    atomicAdd(&s_cnt[ra * AP_T + rb], 1u);
+                }
+            }
+            const int took = __syncthreads_count(mine ? 1 : 0);       // sorted: the entries taken are a prefix of the batch
+            a_cur += (uint64_t)took;
+            if (took < AP_THREADS) break;
+        }
+        b_cur += nb_stage;
+        __syncthreads();                                             // the staged entries are about to be overwritten
+    }
+    __syncthreads();
+    // ---- the tile's sums go out; the mirrored entries with them (the matrices are symmetric) ----
+    for (int i = tid; i < AP_T * AP_T; i += AP_THREADS) {
+        const uint32_t r = row0 + (uint32_t)i / AP_T, c = col0 + (uint32_t)i % AP_T;
+        if (r >= n || c >= n || (diag && c <= r)) continue;
+        const unsigned long long p = s_prod[i];
+        const uint32_t k = s_cnt[i];
+        if (Z == 1) {
+            prod[(uint64_t)r * n + c] = p; prod[(uint64_t)c * n + r] = p;
+            common[(uint64_t)r * n + c] = k; common[(uint64_t)c * n + r] = k;
+        } else if (k) {
+            atomicAdd(&prod[(uint64_t)r * n + c], p); atomicAdd(&prod[(uint64_t)c * n + r], p);
+            atomicAdd(&common[(uint64_t)r * n + c], k); atomicAdd(&common[(uint64_t)c * n + r], k);
+        }
+    }
+}
+
+constexpr size_t AP_LDS = (size_t)AP_CHUNK * 16 + (size_t)AP_T * AP_T * 12 + AP_CHUNK;
+
+unsigned ap_grid(uint64_t n_items) {
+    const uint64_t b = (n_items + 255) / 256;
+    return (unsigned)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
+}
+
+}  // namespace
+
+// -> hipErrorNotSupported when this formulation does not apply (2^32 elements or more): the caller keeps the walk kernel
+hipError_t abund_pairs_launch(const uint64_t* d_hashes, const uint64_t* d_abunds, const uint64_t* d_offsets, uint32_t n, uint64_t total,
+                              bool narrow, uint32_t* d_common, unsigned long long* d_prod, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    if (total >= 0xffffffffull) return hipErrorNotSupported;
+    const uint32_t nb = (n + AP_T - 1) / AP_T;
+    const uint64_t tiles = (uint64_t)nb * (nb + 1) / 2;
+    if (tiles * AP_ZMAX > 0x7fffffffull) return hipErrorNotSupported;
+    AP_TRY(hipMemsetAsync(d_common, 0, (size_t)n * n * 4, stream));       // (pairs with nothing in common stay zero; slices add up)
+    AP_TRY(hipMemsetAsync(d_prod, 0, (size_t)n * n * 8, stream));
+    if (total == 0) return hipSuccess;
+    ArenaBuf pos_b, pos1_b, pos2_b, rowid_b, key_b, key2_b, h1_b, h2_b, lh_b, lp_b, lr_b, tmp_b;
+    AP_TRY(pos_b.get(total * 4 + 64, stream));
+    AP_TRY(pos1_b.get(total * 4 + 64, stream));
+    AP_TRY(pos2_b.get(total * 4 + 64, stream));
+    AP_TRY(rowid_b.get(total * 4 + 64, stream));
+    AP_TRY(key_b.get(total * 4 + 64, stream));
+    AP_TRY(key2_b.get(total * 4 + 64, stream));
+    AP_TRY(h1_b.get(total * 8 + 64, stream));
+    AP_TRY(h2_b.get(total * 8 + 64, stream));
+    AP_TRY(lh_b.get(total * 8 + 64, stream));
+    AP_TRY(lp_b.get(total * 8 + 64, stream));
+    if (!narrow) AP_TRY(lr_b.get(total + 64, stream));
+    uint32_t *pos = pos_b.as<uint32_t>(), *pos1 = pos1_b.as<uint32_t>(), *pos2 = pos2_b.as<uint32_t>(), *rowid = rowid_b.as<uint32_t>();
+    uint32_t *key = key_b.as<uint32_t>(), *key2 = key2_b.as<uint32_t>();
+    uint64_t *h1 = h1_b.as<uint64_t>(), *h2 = h2_b.as<uint64_t>();
+    size_t t1 = 0, t2 = 0;
+    unsigned bits = 1;
+    while ((1u << bits) < nb) ++bits;
+    AP_TRY(rocprim::radix_sort_pairs(nullptr, t1, h1, h2, pos, pos1, (size_t)total, 0u, 64u, stream));
+    AP_TRY(rocprim::radix_sort_pairs(nullptr, t2, key, key2, pos1, pos2, (size_t)total, 0u, bits, stream));
+    const size_t tbytes = (t1 > t2 ? t1 : t2) + 256;
+    AP_TRY(tmp_b.get(tbytes, stream));
+    // by hash (stable: equal hashes keep the order of their sketches) ...
+    AP_TRY(hipMemcpyAsync(h1, d_hashes, total * 8, hipMemcpyDeviceToDevice, stream));
+    hipLaunchKernelGGL(ap_rows_kernel, dim3(ap_grid(((uint64_t)n + 3) / 4 * 256)), dim3(256), 0, stream, d_offsets, n, pos, rowid);
+    AP_TRY(hipGetLastError());
+    size_t tb = tbytes;
+    AP_TRY(rocprim::radix_sort_pairs(tmp_b.p, tb, h1, h2, pos, pos1, (size_t)total, 0u, 64u, stream));
+    // ... then by block (stable: inside a block the elements stay sorted by hash, equal hashes by row)
+    hipLaunchKernelGGL(ap_block_keys_kernel, dim3(ap_grid(total)), dim3(256), 0, stream, (const uint32_t*)pos1, (const uint32_t*)rowid, total, key);
+    AP_TRY(hipGetLastError());
+    tb = tbytes;
+    AP_TRY(rocprim::radix_sort_pairs(tmp_b.p, tb, key, key2, pos1, pos2, (size_t)total, 0u, bits, stream));
+    if (narrow)
+        hipLaunchKernelGGL((ap_gather_kernel<true>), dim3(ap_grid(total)), dim3(256), 0, stream, (const uint32_t*)pos2, (const uint32_t*)rowid, d_hashes,
+                           d_abunds, total, lh_b.as<uint64_t>(), lp_b.as<uint64_t>(), (uint8_t*)nullptr);
+    else
+        hipLaunchKernelGGL((ap_gather_kernel<false>), dim3(ap_grid(total)), dim3(256), 0, stream, (const uint32_t*)pos2, (const uint32_t*)rowid, d_hashes,
+                           d_abunds, total, lh_b.as<uint64_t>(), lp_b.as<uint64_t>(), lr_b.as<uint8_t>());
+    AP_TRY(hipGetLastError());
+    // hash slices per tile: enough work items to fill the chip twice over when the tiles alone do not (SMG_ABUND_SLICES overrides)
+    static const uint32_t z_env = [] { const char* e = getenv("SMG_ABUND_SLICES"); return e ? (uint32_t)atoi(e) : 0u; }();
+    uint32_t Z = 1;
+    while (Z < (uint32_t)AP_ZMAX && tiles * Z < 512) Z *= 2;
+    if (z_env >= 1 && z_env <= (uint32_t)AP_ZMAX) Z = z_env;
+    static int attr = 0;
+    if (attr == 0) {
+        const hipError_t ea = hipFuncSetAttribute((const void*)ap_join_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)AP_LDS);
+        const hipError_t eb = hipFuncSetAttribute((const void*)ap_join_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)AP_LDS);
+        attr = ea == hipSuccess && eb == hipSuccess ? 1 : -1;
+        if (attr < 0) (void)hipGetLastError();
+    }
+    if (attr < 0) return hipErrorNotSupported;
+    if (narrow)
+        hipLaunchKernelGGL((ap_join_kernel<true>), dim3((unsigned)(tiles * Z)), dim3(AP_THREADS), AP_LDS, stream, (const uint64_t*)lh_b.as<uint64_t>(),
+                           (const uint64_t*)lp_b.as<uint64_t>(), (const uint8_t*)nullptr, d_offsets, n, nb, Z, d_common, d_prod);
+    else
+        hipLaunchKernelGGL((ap_join_kernel<false>), dim3((unsigned)(tiles * Z)), dim3(AP_THREADS), AP_LDS, stream, (const uint64_t*)lh_b.as<uint64_t>(),
+                           (const uint64_t*)lp_b.as<uint64_t>(), (const uint8_t*)lr_b.as<uint8_t>(), d_offsets, n, nb, Z, d_common, d_prod);
+    return hipGetLastError();
+}
+
+}  // namespace smg

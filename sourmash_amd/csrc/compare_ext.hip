@@ -26,6 +26,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <string.h>
 #include <type_traits>
 #include "device_api.hpp"
 
@@ -284,6 +285,22 @@ hipError_t compare_abund_launch(const uint64_t* d_hashes, const uint64_t* d_abun
                                 bool narrow, uint32_t* d_common, unsigned long long* d_prod, unsigned long long* d_sumsq,
                                 hipStream_t stream) {
     if (n == 0) return hipSuccess;
+    // Round 5: the sums come from joins of per-block lists sorted by hash (abund_pairs.hip: work grows with the MATCHES, not with
+    // pairs x lengths).  SMG_COMPARE_ABUND=walk keeps the per-pair walk below (tests run both against the oracle); it also serves
+    // collections of 2^32 elements or more.
+    static const bool walk_only = [] { const char* e = getenv("SMG_COMPARE_ABUND"); return e && !strcmp(e, "walk"); }();
+    if (!walk_only) {
+        uint64_t total = 0;
+        hipError_t et = hipMemcpyAsync(&total, d_offsets + n, 8, hipMemcpyDeviceToHost, stream);
+        if (et == hipSuccess) et = hipStreamSynchronize(stream);
+        if (et != hipSuccess) return et;
+        const hipError_t ej = abund_pairs_launch(d_hashes, d_abunds, d_offsets, n, total, narrow, d_common, d_prod, stream);
+        if (ej == hipSuccess) {
+            hipLaunchKernelGGL(ext_rows_kernel, dim3((n * 64u + 255u) / 256u), dim3(256), 0, stream, d_abunds, d_offsets, n, d_common, d_prod, d_sumsq);
+            return hipGetLastError();
+        }
+        if (ej != hipErrorNotSupported) return ej;
+    }
     const uint32_t nt = (n + XT - 1) / XT;
     // (sliced tiles add their parts up: the matrices start from zero)
     hipError_t e = hipMemsetAsync(d_common, 0, (size_t)n * n * 4, stream);

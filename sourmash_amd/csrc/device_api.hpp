@@ -71,6 +71,10 @@ hipError_t compare_abund_launch(const uint64_t* d_hashes, const uint64_t* d_abun
                                 bool narrow, uint32_t* d_common, unsigned long long* d_prod, unsigned long long* d_sumsq,
                                 hipStream_t stream);
 
+// abund_pairs.hip: the same two matrices (diagonals excluded: the caller's row kernel writes them) from joins of per-block lists
+// sorted by hash; scratch from the library's arena.  hipErrorNotSupported: 2^32 elements or more -- the caller keeps the walk.
+hipError_t abund_pairs_launch(const uint64_t* d_hashes, const uint64_t* d_abunds, const uint64_t* d_offsets, uint32_t n, uint64_t total,
+                              bool narrow, uint32_t* d_common, unsigned long long* d_prod, hipStream_t stream);
 // Lists with several scaled values: gather the first new_off[r + 1] - new_off[r] hashes of the rows starting at src_start[r] into
 // a CSR of their own; then move the entries sub[a][b] of an m x m matrix over rows[] whose pair class max(class_of[rows[a]],
 // class_of[rows[b]]) equals `cls` to out[rows[a]][rows[b]] of the n x n matrix.

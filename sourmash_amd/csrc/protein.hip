@@ -28,15 +28,49 @@ namespace {
 
 constexpr uint8_t SEP = 0xff;
 
+// Both kernels map bytes through small tables in LDS that every block fills from the scalar functions of residues.hpp at its
+// start (the functions ARE the definition: encodings.rs:103-347); round 4 evaluated those functions -- compare chains of a few
+// dozen instructions -- for every byte, which made the dayhoff / hp / translated sketches 2.5 x slower than protein ones.
+//   residues: byte -> residue of the sketch's alphabet, 16 bytes per lane
 __global__ __launch_bounds__(256) void residues_kernel(const uint8_t* __restrict__ seq, uint64_t len, uint32_t hf,
                                                        uint8_t* __restrict__ aa) {
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < len; i += (uint64_t)gridDim.x * blockDim.x)
-        aa[i] = residue_encode(ascii_upper(seq[i]), hf);
+    __shared__ uint8_t lut[256];
+    lut[threadIdx.x] = residue_encode(ascii_upper((uint8_t)threadIdx.x), hf);
+    __syncthreads();
+    const uint64_t n16 = len / 16;
+    const bool aligned = (((uintptr_t)seq | (uintptr_t)aa) & 15) == 0;
+    if (aligned)
+        for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (uint64_t)gridDim.x * blockDim.x) {
+            const uint4 v = reinterpret_cast<const uint4*>(seq)[i];
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+            uint32_t o[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+                o[k] = (uint32_t)lut[w[k] & 0xffu] | ((uint32_t)lut[(w[k] >> 8) & 0xffu] << 8) | ((uint32_t)lut[(w[k] >> 16) & 0xffu] << 16) |
+                       ((uint32_t)lut[w[k] >> 24] << 24);
+            reinterpret_cast<uint4*>(aa)[i] = make_uint4(o[0], o[1], o[2], o[3]);
+        }
+    for (uint64_t i = (aligned ? n16 * 16 : 0) + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < len; i += (uint64_t)gridDim.x * blockDim.x)
+        aa[i] = lut[seq[i]];
 }
 
-// segment s = 2 * frame + strand holds (len - frame) / 3 residues and is followed by one separator
+// segment s = 2 * frame + strand holds (len - frame) / 3 residues and is followed by one separator.
+//   translate: byte -> nucleotide code (A C G T N other = 0 .. 5; on the reverse strand the code of the complement), three codes ->
+//   the residue of the sketch's alphabet through a 6 x 6 x 6 table
 __global__ __launch_bounds__(256) void translate_kernel(const uint8_t* __restrict__ seq, uint64_t len, uint32_t hf,
                                                         uint8_t* __restrict__ aa, uint64_t total) {
+    __shared__ uint8_t code_f[256], code_r[256], codon[216];
+    {
+        const uint8_t c = ascii_upper((uint8_t)threadIdx.x);
+        code_f[threadIdx.x] = (uint8_t)nt_code(c);
+        code_r[threadIdx.x] = (uint8_t)nt_code(dna_complement_or_nul(c));
+        if (threadIdx.x < 216) {
+            const char* letters = "ACGTN?";                            // '?' stands for every byte that is no base
+            const int x = threadIdx.x / 36, y = (threadIdx.x / 6) % 6, z = threadIdx.x % 6;
+            codon[threadIdx.x] = residue_encode(translate_codon((uint8_t)letters[x], (uint8_t)letters[y], (uint8_t)letters[z]), hf);
+        }
+    }
+    __syncthreads();
     uint64_t start[7];
     start[0] = 0;
     for (int s = 0; s < 6; ++s) start[s + 1] = start[s] + (len - (uint64_t)(s >> 1)) / 3 + 1;
@@ -47,15 +81,13 @@ __global__ __launch_bounds__(256) void translate_kernel(const uint8_t* __restric
         const int frame = s >> 1;
         if (i == start[s + 1] - start[s] - 1) { aa[o] = SEP; continue; }
         const uint64_t p = (uint64_t)frame + 3 * i;
-        uint8_t a, b, c;
+        uint32_t x, y, z;
         if (s & 1) {                                  // reverse complement: rc[p] = complement(seq[len - 1 - p])
-            a = dna_complement_or_nul(ascii_upper(seq[len - 1 - p]));
-            b = dna_complement_or_nul(ascii_upper(seq[len - 2 - p]));
-            c = dna_complement_or_nul(ascii_upper(seq[len - 3 - p]));
+            x = code_r[seq[len - 1 - p]]; y = code_r[seq[len - 2 - p]]; z = code_r[seq[len - 3 - p]];
         } else {
-            a = ascii_upper(seq[p]); b = ascii_upper(seq[p + 1]); c = ascii_upper(seq[p + 2]);
+            x = code_f[seq[p]]; y = code_f[seq[p + 1]]; z = code_f[seq[p + 2]];
         }
-        aa[o] = residue_encode(translate_codon(a, b, c), hf);
+        aa[o] = codon[x * 36 + y * 6 + z];
     }
 }
 

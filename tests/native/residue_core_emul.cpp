@@ -46,3 +46,32 @@ extern "C" uint64_t naive_residue_windows(const uint8_t* aa, uint64_t n, uint32_
     }
     return cnt;
 }
+
+// The translate kernel's tables (protein.hip: byte -> nucleotide code, three codes -> residue) against the scalar functions they
+// are filled from, over every triple of bytes and the three alphabets, both strands: -> number of disagreements.
+#include "../../sourmash_amd/csrc/residues.hpp"
+extern "C" uint64_t check_translate_tables() {
+    uint64_t bad = 0;
+    for (uint32_t hf = 2; hf <= 4; ++hf) {
+        uint8_t code_f[256], code_r[256], codon[216];
+        for (int t = 0; t < 256; ++t) {
+            const uint8_t c = smg::ascii_upper((uint8_t)t);
+            code_f[t] = (uint8_t)smg::nt_code(c);
+            code_r[t] = (uint8_t)smg::nt_code(smg::dna_complement_or_nul(c));
+        }
+        const char* letters = "ACGTN?";
+        for (int t = 0; t < 216; ++t)
+            codon[t] = smg::residue_encode(smg::translate_codon((uint8_t)letters[t / 36], (uint8_t)letters[(t / 6) % 6], (uint8_t)letters[t % 6]), hf);
+        for (int a = 0; a < 256; ++a)
+            for (int b = 0; b < 256; ++b)
+                for (int c = 0; c < 256; ++c) {
+                    const uint8_t ua = smg::ascii_upper((uint8_t)a), ub = smg::ascii_upper((uint8_t)b), uc = smg::ascii_upper((uint8_t)c);
+                    const uint8_t fwd = smg::residue_encode(smg::translate_codon(ua, ub, uc), hf);
+                    bad += fwd != codon[code_f[a] * 36 + code_f[b] * 6 + code_f[c]];
+                    const uint8_t rev = smg::residue_encode(smg::translate_codon(smg::dna_complement_or_nul(ua), smg::dna_complement_or_nul(ub),
+                                                                                 smg::dna_complement_or_nul(uc)), hf);
+                    bad += rev != codon[code_r[a] * 36 + code_r[b] * 6 + code_r[c]];
+                }
+    }
+    return bad;
+}

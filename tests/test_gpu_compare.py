@@ -831,3 +831,44 @@ def test_avg_containment_ani_mixed_scaled_asks_the_downsampled_sketches(sm):
             assert con[i, j] == (0.0 if r is None else r), (i, j)
             r = sigs[j].max_containment_ani(sigs[i], downsample=True).ani
             assert mx[i, j] == (0.0 if r is None else r), (i, j)
+
+
+def test_abundance_join_and_walk_agree_on_ragged_collections(sm):
+    """The abundance sums come from joins of per-block hash-sorted lists (csrc/abund_pairs.hip) -- or, for collections of 2^32 elements
+    and with SMG_COMPARE_ABUND=walk, from the per-pair walk (csrc/compare_ext.hip).  Both against the oracle on a collection with
+    empty sketches, one-hash sketches, a sketch holding every hash of the pool, duplicates, more sketches than one 64-sketch block
+    and not a multiple of it; every hash-slice count the join can be cut into (SMG_ABUND_SLICES)."""
+    import os, subprocess, sys
+    from conftest import ROOT
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import test_gpu_compare as t\nt._abundance_ragged()\nprint('ok')\n" % (ROOT, os.path.join(ROOT, "tests")))
+    for extra in ({}, {"SMG_COMPARE_ABUND": "walk"}, {"SMG_ABUND_SLICES": "1"}, {"SMG_ABUND_SLICES": "3"}, {"SMG_ABUND_SLICES": "16"}):
+        p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, **extra))
+        assert p.returncode == 0 and p.stdout.strip().endswith("ok"), (extra, p.stdout[-1500:], p.stderr[-1500:])
+
+
+def _abundance_ragged():
+    import torch  # noqa: F401
+    import sourmash_amd as sm
+    from sourmash_amd.compare import angular_matrix
+    rng = np.random.default_rng(31)
+    pool = np.unique(rng.integers(1, 2**63, size=6000, dtype=np.uint64))
+    rows = []
+    for i in range(150):
+        size = int(rng.choice([0, 1, 2, 40, 700, 3000]))
+        rows.append(np.sort(rng.choice(pool, size=min(size, len(pool)), replace=False)))
+    rows[7] = pool.copy()                                          # holds every hash: meets everybody everywhere
+    rows[8] = rows[9].copy()                                       # duplicates
+    rows[64] = pool[::2].copy()                                    # first sketch of the second block
+    rows[149] = pool[-3:].copy()
+    mhs, omhs = [], []
+    for i, a in enumerate(rows):
+        ab = (a % np.uint64(13)) * (a % np.uint64(5)) + np.uint64(1 + i % 3)
+        mh = sm.MinHash(0, 31, scaled=1, track_abundance=True)
+        if len(a):
+            mh.set_abundances(dict(zip(a.tolist(), ab.tolist())))
+        mhs.append(mh)
+        omhs.append(_oracle_sketch(a, scaled=1, abunds=ab))
+    want = oracle.similarity_matrix(omhs, ignore_abundance=False, nthreads=oracle.usable_cpus())
+    got = angular_matrix(mhs)
+    assert np.array_equal(got.view(np.uint64), want.view(np.uint64))

@@ -12,7 +12,7 @@ import oracle
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "native", "residue_core_emul.cpp")
 SO = os.path.join(HERE, "native", "libresidue_core_emul.so")
-HDRS = [os.path.join(HERE, "..", "sourmash_amd", "csrc", h) for h in ("residue_core.hpp", "murmur3.hpp")]
+HDRS = [os.path.join(HERE, "..", "sourmash_amd", "csrc", h) for h in ("residue_core.hpp", "murmur3.hpp", "residues.hpp")]
 
 
 @pytest.fixture(scope="module")
@@ -81,3 +81,10 @@ def test_seed_and_high_bytes(emul):
     for k in (5, 12, 20, 37):
         for seed in (0, 1, 42, 2**32 - 1):
             assert np.array_equal(emul.fast(s, k, seed)[1], emul.naive(s, k, seed)[1]), (k, seed)
+
+
+def test_translate_tables_equal_the_scalar_functions(emul):
+    "protein.hip's translate kernel reads byte -> code and code triple -> residue tables: every byte triple, three alphabets, both strands"
+    lib = C.CDLL(SO)
+    lib.check_translate_tables.restype = C.c_uint64
+    assert lib.check_translate_tables() == 0
