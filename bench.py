@@ -53,8 +53,8 @@ def _newest(*names):
     return names[-1]
 
 
-PMC_FILE = _newest("profiles/r04_pmc.txt", "profiles/r03_pmc.txt")
-PMC_GATHER_FILE = _newest("profiles/r04_gather_pmc.txt", "profiles/r03_gather_pmc.txt")
+PMC_FILE = _newest("profiles/r05_pmc.txt", "profiles/r04_pmc.txt", "profiles/r03_pmc.txt")
+PMC_GATHER_FILE = _newest("profiles/r05_gather_pmc.txt", "profiles/r04_gather_pmc.txt", "profiles/r03_gather_pmc.txt")
 PMC_COMPARE_FILE = _newest("profiles/r04_compare_pmc.txt", "profiles/r03_compare_pmc.txt")
 COMPARE_BITS_SOURCES = ["bitindex.hip"]
 SKETCH_SOURCES = ["sketch.hip", "sketch_kernel.hpp", "kmer_core.hpp", "murmur3.hpp"]

@@ -350,6 +350,11 @@ void smgpu_compare_all_pairs_mixed(const SourmashKmerMinHash *const *mhs, uintpt
 void smgpu_signatures_sketch_views(const SourmashSignature *const *sigs, uintptr_t n, const SourmashKmerMinHash **out_mhs,
                                    uint64_t *params);
 void smgpu_minhashes_params(const SourmashKmerMinHash *const *mhs, uintptr_t n, uint64_t *params);
+/* Page-locked host memory (hipHostMalloc through the library's arena, which caches released blocks up to SMG_PINNED_CACHE_MAX
+ * bytes): result matrices placed there are filled by ONE device-to-host copy at the link's rate.  smgpu_host_free takes only
+ * pointers smgpu_host_alloc returned (others are ignored). */
+void *smgpu_host_alloc(uintptr_t bytes);
+void smgpu_host_free(void *ptr);
 /* Bytes and nanoseconds the host-pointer entry points spent moving large pageable buffers (csrc/hostxfer.hpp) since the last reset:
  * out5 = {H2D bytes, D2H bytes, H2D ns, D2H ns, calls}.  Diagnostics for bench.py's API-level lines. */
 void smgpu_xfer_stats(uint64_t *out5, bool reset);

@@ -82,10 +82,45 @@ class _Handles:
         self.ptrs = (C.c_void_p * max(self.n, 1))(*[mh._get_objptr() for mh in self.keep])
 
 
+_PINNED_FROM = 32 << 20         # result arrays from this size up live in page-locked memory (SMG_PINNED_RESULTS=0: never)
+
+
+class _PinnedBlock:
+    "owner of one smgpu_host_alloc block: released (back to the library's cache) when the array built on it goes"
+
+    def __init__(self, nbytes):
+        self.ptr = rustcall(lib.smgpu_host_alloc, nbytes)
+        self.buf = (C.c_char * nbytes).from_address(self.ptr)
+
+    def __del__(self):
+        ptr, self.ptr = getattr(self, "ptr", None), None
+        if ptr:
+            lib.smgpu_host_free(ptr)
+
+
+def _result_array(shape, dtype):
+    """np.empty for a result the library is about to fill.  Large ones are placed in page-locked memory: the device-to-host copy of
+    an 800 MB matrix into fresh pageable memory runs at ~38 GB/s on the transfer ring (page faults under the copy-out threads),
+    into page-locked memory at the link's ~55 GB/s with no threads at all; the block returns to the library's cache when the
+    array is collected, so the next call of the same size pays nothing for it."""
+    import os
+    nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+    if nbytes < _PINNED_FROM or os.environ.get("SMG_PINNED_RESULTS") == "0":
+        return np.empty(shape, dtype=dtype)
+    try:
+        block = _PinnedBlock(nbytes)
+    except Exception:                                             # noqa: BLE001 -- no page-locked memory to be had: pageable will do
+        return np.empty(shape, dtype=dtype)
+    arr = np.frombuffer(block.buf, dtype=dtype).reshape(shape)
+    block.buf._owner = block                                      # the array keeps the ctypes buffer alive, the buffer its owner
+    del block.buf                                                 # (no cycle: the owner must not hold the buffer)
+    return arr
+
+
 def _common_ptrs(ptrs, n, want_jaccard=True, want_common=True):
     "only the matrices asked for cross PCIe (the u32 matrix of 10,000 sketches is 400 MB, the f64 one 800 MB)"
-    common = np.empty((n, n), dtype=np.uint32) if want_common else None
-    jac = np.empty((n, n), dtype=np.float64) if want_jaccard else None
+    common = _result_array((n, n), np.uint32) if want_common else None
+    jac = _result_array((n, n), np.float64) if want_jaccard else None
     if n:
         rustcall(lib.smgpu_compare_all_pairs, ptrs, n, common.ctypes.data_as(C.POINTER(C.c_uint32)) if want_common else None,
                  jac.ctypes.data_as(C.POINTER(C.c_double)) if want_jaccard else None)

@@ -1214,6 +1214,17 @@ void smgpu_minhashes_params(const SourmashKmerMinHash* const* mhs, uintptr_t n, 
     landing_void([&] { for (uintptr_t i = 0; i < n; ++i) sketch_params(MH(mhs[i]), params + 8 * i); });
 }
 
+// Page-locked host memory for large results (cached by the library's arena on release): a device-to-host copy into it runs at the
+// link's rate with no staging and no page faults -- sourmash_amd/compare.py puts the n x n matrices of large collections there.
+void* smgpu_host_alloc(uintptr_t bytes) {
+    return landing<void*>([&]() -> void* {
+        void* p = nullptr;
+        hip_check(arena_pinned_alloc(&p, bytes ? bytes : 1), "pinned host allocation");
+        return p;
+    });
+}
+void smgpu_host_free(void* p) { arena_pinned_free(p); }
+
 void smgpu_xfer_stats(uint64_t* out5, bool reset) {
     const HostXfer::Stats x = HostXfer::get().stats();
     if (out5) { out5[0] = x.h2d_bytes; out5[1] = x.d2h_bytes; out5[2] = x.h2d_ns; out5[3] = x.d2h_ns; out5[4] = x.calls; }
