@@ -13,10 +13,11 @@
 // the tile's 64 x 64 accumulators in LDS.  A tile's join is cut into Z hash slices when there are few tiles (C3: 136 tiles on
 // 256 CUs), the slices' sums meeting in the zeroed matrices through atomics.
 //
-// The join, per workgroup: the next <= 2,048 entries of list B go to LDS (whole runs of equal hashes only); every entry of list A up
-// to B's last staged hash is taken by one thread, which finds its hash in the staged B entries by binary search (11 LDS reads,
-// independent of its neighbours': 16 waves per CU overlap them) and walks the run of equal hashes there.  Work grows with
-// |A| + |B| + matches per tile, not with pairs x lengths.
+// The join, per workgroup: the next <= 4,096 entries of list B go to LDS (whole runs of equal hashes only); every entry of list A up
+// to B's last staged hash is taken by one thread, which finds its hash in the staged B entries by binary search (12 LDS reads,
+// independent of its neighbours': 16 waves per CU overlap them) and walks the run of equal hashes there.  The next chunk of B and
+// the next batch of A are loaded into registers while the present ones are matched.  Work grows with |A| + |B| + matches per
+// tile, not with pairs x lengths.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -30,7 +31,7 @@ namespace {
 
 constexpr int AP_T = 64;                 // sketches per block = tile edge
 constexpr int AP_THREADS = 1024;
-constexpr int AP_CHUNK = 2048;           // entries of list B staged per round
+constexpr int AP_CHUNK = 4096;           // entries of list B staged per round (64 KB of hashes + payloads)
 constexpr int AP_ZMAX = 16;              // hash slices per tile at most
 
 #define AP_TRY(expr)                       \
@@ -119,13 +120,34 @@ __global__ __launch_bounds__(AP_THREADS) void ap_join_kernel(const uint64_t* __r
     const uint64_t a_end = s_bound[1];
     uint64_t b_cur = s_bound[2];
     const uint64_t b_end = s_bound[3];
+    // Round structure: chunk r of list B is in LDS; chunk r + 1 is already on its way into registers (its start is known as soon as
+    // chunk r has been trimmed to whole runs); the batch of list A being matched was loaded while the previous batch was searched.
+    // What a round waits for is then one LDS write + barrier and the first A batch -- not a trip to memory per step.
+    constexpr int BPT = AP_CHUNK / AP_THREADS;                       // staged entries per thread
+    uint64_t rh[BPT], rp[BPT];
+    uint8_t rr[BPT];
+    auto fetch_b = [&](uint64_t from) {                              // entries [from, from + AP_CHUNK) of list B -> registers
+#pragma unroll
+        for (int u = 0; u < BPT; ++u) {
+            const uint64_t i = from + (uint64_t)tid + (uint64_t)u * AP_THREADS;
+            rh[u] = ~0ull; rp[u] = 0; rr[u] = 0;
+            if (i < b_end) {
+                rh[u] = l_hash[i];
+                rp[u] = l_pay[i];
+                if (!NARROW) rr[u] = l_row[i];
+            }
+        }
+    };
+    if (a_cur < a_end && b_cur < b_end) fetch_b(b_cur);
     while (a_cur < a_end && b_cur < b_end) {
-        // ---- stage the next entries of B: whole runs of equal hashes only (a run holds at most AP_T entries) ----
+        // ---- stage the fetched entries of B; whole runs of equal hashes only are used (a run holds at most AP_T entries) ----
         uint64_t nb_stage = b_end - b_cur < (uint64_t)AP_CHUNK ? b_end - b_cur : (uint64_t)AP_CHUNK;
-        for (uint32_t i = tid; i < (uint32_t)nb_stage; i += AP_THREADS) {
-            s_bh[i] = l_hash[b_cur + i];
-            s_bp[i] = l_pay[b_cur + i];
-            if (!NARROW) s_br[i] = l_row[b_cur + i];
+#pragma unroll
+        for (int u = 0; u < BPT; ++u) {
+            const uint32_t i = (uint32_t)tid + (uint32_t)u * AP_THREADS;
+            s_bh[i] = rh[u];
+            s_bp[i] = rp[u];
+            if (!NARROW) s_br[i] = rr[u];
         }
         __syncthreads();
         if (b_cur + nb_stage < b_end) {                              // the run the chunk ends in may go on: leave it for the next round
@@ -135,20 +157,25 @@ __global__ __launch_bounds__(AP_THREADS) void ap_join_kernel(const uint64_t* __r
             nb_stage = cut;                                           // > 0: a run is shorter than the chunk
         }
         const uint64_t hi = s_bh[nb_stage - 1];                       // A's entries up to this hash meet everything they can meet here
-        // ---- A's entries <= hi, a batch of AP_THREADS at a time ----
-        for (;;) {
-            const uint64_t idx = a_cur + (uint64_t)tid;
-            uint64_t h = ~0ull, pay = 0;
-            uint32_t ra = 0;
-            bool mine = false;
+        if (b_cur + nb_stage < b_end) fetch_b(b_cur + nb_stage);      // the next round's entries: in flight behind this round's work
+        // ---- A's entries <= hi, a batch of AP_THREADS at a time; the batch behind the one being matched is loaded meanwhile ----
+        uint64_t nh = ~0ull, npay = 0;
+        uint8_t nrow = 0;
+        auto fetch_a = [&](uint64_t from) {
+            const uint64_t idx = from + (uint64_t)tid;
+            nh = ~0ull; npay = 0; nrow = 0;
             if (idx < a_end) {
-                h = l_hash[idx];
-                mine = h <= hi;
-                if (mine) {
-                    pay = l_pay[idx];
-                    ra = NARROW ? (uint32_t)(pay >> 32) : (uint32_t)l_row[idx];
-                }
+                nh = l_hash[idx];
+                npay = l_pay[idx];
+                if (!NARROW) nrow = l_row[idx];
             }
+        };
+        fetch_a(a_cur);
+        for (;;) {
+            const uint64_t h = nh, pay = npay;
+            const uint32_t ra = NARROW ? (uint32_t)(pay >> 32) : (uint32_t)nrow;
+            const bool mine = h <= hi && a_cur + (uint64_t)tid < a_end;
+            fetch_a(a_cur + AP_THREADS);                              // used only if this whole batch is taken
             if (mine) {
                 uint32_t lo = 0, hi_i = (uint32_t)nb_stage;
                 while (lo < hi_i) {

@@ -180,9 +180,6 @@ struct OwGeom {
     static constexpr size_t LDS = (size_t)QCAP_ * 8 + T_BYTES + ((size_t)3 * ROWS + 8) * 4;
     static constexpr int WAVES_PER_EU = WAVES_PER_EU_;
 };
-#ifndef SMG_RING
-#define SMG_RING 0
-#endif
 #ifndef SMG_OW_LEAN_BATCH
 #define SMG_OW_LEAN_BATCH 4
 #endif
@@ -297,20 +294,10 @@ void overlap_lean_kernel(const uint64_t* __restrict__ Q, const uint32_t* __restr
             end[k] = uniform32((uint32_t)(offsets[d_lo + i + 1] - block_base));
         }
     }
-    // SMG_RING = 1 (round 5, the second attempt at a walk that fetches every sector once): slot k's register pair is a ring over
-    // its row -- lane L holds the element pos + ((L - pos) & 63), so the 64 elements from the cursor on are always there, in rotated
-    // lane order (a lookup does not care which lane holds which hash) -- and after a visit ONLY the consumed lanes are loaded
-    // again, with the elements 64 further on (one exec-masked load, issued a whole range before its data is used, like the plain
-    // form's).  Element granule: no consumed-lane mask, no rotation arithmetic -- the refill costs the plain form's instructions.
     auto ask = [&](int k) {                                                // the next 64 hashes of slot k's row
         const uint32_t left = end[k] - pos[k];
         e[k] = ~0ull;
-#if SMG_RING
-        const uint32_t rel = ((uint32_t)lane - pos[k]) & 63u;
-        if (rel < left) e[k] = (rows + pos[k])[rel];
-#else
         if ((uint32_t)lane < left) e[k] = (rows + pos[k])[lane];
-#endif
     };
 #pragma unroll
     for (int k = 0; k < SLOTS; ++k) ask(k);
@@ -478,16 +465,11 @@ void overlap_lean_kernel(const uint64_t* __restrict__ Q, const uint32_t* __restr
                     found |= in[w] & mask_of(hit);
                 }
                 if (QPOS) {
-#if SMG_RING
-                    if (lanes_of(in[w])) (qrows + pos[k])[((uint32_t)lane - pos[k]) & 63u] = lanes_of(found) ? p0 + jr : NONE32;
-#else
                     if (lanes_of(in[w])) (qrows + pos[k])[lane] = lanes_of(found) ? p0 + jr : NONE32;
-#endif
                     if (STAGE && lanes_of(found)) stage_put(jr, (uint32_t)d_lo + (uint32_t)wave + (uint32_t)k * OW_WAVES);
                 }
                 hv[k] += (uint32_t)__popcll(found);
                 uint32_t taken = (uint32_t)__popcll(in[w]);
-                const bool window_out = taken == 64u;
                 pos[k] += taken;
                 while (__builtin_expect(taken == 64u, 0)) {                  // the row's part of this range goes on (rare): block by block
                     const uint32_t left = end[k] - pos[k];
@@ -511,24 +493,7 @@ void overlap_lean_kernel(const uint64_t* __restrict__ Q, const uint32_t* __restr
                     taken = (uint32_t)__popcll(mask_of(more));
                     pos[k] += taken;
                 }
-#if SMG_RING
-                if (!last) {                                                 // the row's part of the next range, a range ahead
-                    if (__builtin_expect(window_out, 0)) {
-                        ask(k);                                              // the block-by-block walk left the ring behind
-                    } else {
-                        const uint32_t rel = ((uint32_t)lane - pos[k]) & 63u;
-                        if (__builtin_expect(pos[k] + 64u <= end[k], 1)) {   // the new window lies inside the row: the consumed lanes take
-                            if (lanes_of(in[w])) e[k] = (rows + pos[k])[rel];   // the elements 64 further on
-                        } else if (lanes_of(in[w])) {                        // the row ends inside the window
-                            e[k] = ~0ull;
-                            if (rel < end[k] - pos[k]) e[k] = (rows + pos[k])[rel];
-                        }
-                    }
-                }
-#else
-                (void)window_out;
                 if (!last) ask(k);                                           // the row's part of the next range, a range ahead
-#endif
             }
         }
     }
