@@ -21,6 +21,7 @@
 #include "murmur3.hpp"
 #include "residues.hpp"
 #include "residue_core.hpp"
+#include "translate_core.hpp"
 
 namespace smg {
 
@@ -88,6 +89,34 @@ __global__ __launch_bounds__(256) void translate_kernel(const uint8_t* __restric
             x = code_f[seq[p]]; y = code_f[seq[p + 1]]; z = code_f[seq[p + 2]];
         }
         aa[o] = codon[x * 36 + y * 6 + z];
+    }
+}
+
+// the same translation, one aligned output WORD (four residues of one segment) per lane: translate_core.hpp.  Needs 4-byte aligned
+// input and output; the kernel above serves anything else.
+__global__ __launch_bounds__(256) void translate_words_kernel(const uint8_t* __restrict__ seq, uint64_t len, uint32_t hf,
+                                                              uint8_t* __restrict__ aa, uint64_t total) {
+    __shared__ uint8_t code_f[256], code_r[256], codon[216];
+    {
+        const uint8_t c = ascii_upper((uint8_t)threadIdx.x);
+        code_f[threadIdx.x] = (uint8_t)nt_code(c);
+        code_r[threadIdx.x] = (uint8_t)nt_code(dna_complement_or_nul(c));
+        if (threadIdx.x < 216) {
+            const char* letters = "ACGTN?";                            // '?' stands for every byte that is no base
+            const int x = threadIdx.x / 36, y = (threadIdx.x / 6) % 6, z = threadIdx.x % 6;
+            codon[threadIdx.x] = residue_encode(translate_codon((uint8_t)letters[x], (uint8_t)letters[y], (uint8_t)letters[z]), hf);
+        }
+    }
+    __syncthreads();
+    const TranslateLayout L = translate_layout(len);
+    const TranslateTables T{code_f, code_r, codon};
+    const uint64_t n_words = (total + 3) / 4;
+    for (uint64_t G = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; G < n_words; G += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t w = translate_word(seq, reinterpret_cast<const uint32_t*>(seq), L, T, G);
+        if (4 * G + 4 <= total) reinterpret_cast<uint32_t*>(aa)[G] = w;
+        else
+            for (int j = 0; j < 4; ++j)
+                if (4 * G + (uint64_t)j < total) aa[4 * G + (uint64_t)j] = (uint8_t)(w >> (8 * j));
     }
 }
 
@@ -204,7 +233,10 @@ hipError_t residues_launch(const uint8_t* d_seq, uint64_t len, uint32_t hash_fun
 hipError_t translate_launch(const uint8_t* d_seq, uint64_t len, uint32_t hash_function, uint8_t* d_aa, hipStream_t stream) {
     if (len < 3) return hipErrorInvalidValue;
     const uint64_t total = translated_bytes(len);
-    hipLaunchKernelGGL(translate_kernel, dim3(grid_for(total)), dim3(256), 0, stream, d_seq, len, hash_function, d_aa, total);
+    if ((((uintptr_t)d_seq | (uintptr_t)d_aa) & 3) == 0)
+        hipLaunchKernelGGL(translate_words_kernel, dim3(grid_for((total + 3) / 4)), dim3(256), 0, stream, d_seq, len, hash_function, d_aa, total);
+    else
+        hipLaunchKernelGGL(translate_kernel, dim3(grid_for(total)), dim3(256), 0, stream, d_seq, len, hash_function, d_aa, total);
     return hipGetLastError();
 }
 

@@ -75,3 +75,31 @@ extern "C" uint64_t check_translate_tables() {
     }
     return bad;
 }
+
+// The translate kernel's lane (translate_core.hpp: one aligned output word per lane) against the per-byte definition.
+#include "../../sourmash_amd/csrc/translate_core.hpp"
+extern "C" uint64_t emul_translate(const uint8_t* seq, uint64_t len, uint32_t hf, uint8_t* out_fast, uint8_t* out_naive) {
+    uint8_t code_f[256], code_r[256], codon[216];
+    for (int t = 0; t < 256; ++t) {
+        const uint8_t c = smg::ascii_upper((uint8_t)t);
+        code_f[t] = (uint8_t)smg::nt_code(c);
+        code_r[t] = (uint8_t)smg::nt_code(smg::dna_complement_or_nul(c));
+    }
+    const char* letters = "ACGTN?";
+    for (int t = 0; t < 216; ++t)
+        codon[t] = smg::residue_encode(smg::translate_codon((uint8_t)letters[t / 36], (uint8_t)letters[(t / 6) % 6], (uint8_t)letters[t % 6]), hf);
+    const smg::TranslateTables T{code_f, code_r, codon};
+    const smg::TranslateLayout L = smg::translate_layout(len);
+    // the kernel reads aligned words: a padded copy, junk in the padding
+    std::vector<uint32_t> words((len + 3) / 4 + 1, 0x51515151u);
+    std::memcpy(words.data(), seq, len);
+    const uint8_t* s8 = reinterpret_cast<const uint8_t*>(words.data());
+    const uint64_t total = L.start[6];
+    for (uint64_t G = 0; G < (total + 3) / 4; ++G) {
+        const uint32_t w = smg::translate_word(s8, words.data(), L, T, G);
+        for (int j = 0; j < 4; ++j)
+            if (4 * G + (uint64_t)j < total) out_fast[4 * G + (uint64_t)j] = (uint8_t)(w >> (8 * j));
+    }
+    for (uint64_t o = 0; o < total; ++o) out_naive[o] = smg::translate_one(s8, L, T, o);
+    return total;
+}

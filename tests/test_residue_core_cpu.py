@@ -12,7 +12,7 @@ import oracle
 HERE = os.path.dirname(os.path.abspath(__file__))
 SRC = os.path.join(HERE, "native", "residue_core_emul.cpp")
 SO = os.path.join(HERE, "native", "libresidue_core_emul.so")
-HDRS = [os.path.join(HERE, "..", "sourmash_amd", "csrc", h) for h in ("residue_core.hpp", "murmur3.hpp", "residues.hpp")]
+HDRS = [os.path.join(HERE, "..", "sourmash_amd", "csrc", h) for h in ("residue_core.hpp", "murmur3.hpp", "residues.hpp", "translate_core.hpp")]
 
 
 @pytest.fixture(scope="module")
@@ -88,3 +88,29 @@ def test_translate_tables_equal_the_scalar_functions(emul):
     lib = C.CDLL(SO)
     lib.check_translate_tables.restype = C.c_uint64
     assert lib.check_translate_tables() == 0
+
+
+def test_translate_words_equal_the_per_byte_definition_and_the_oracle(emul):
+    """protein.hip's translate kernel gives every lane one aligned word of the six-segment output (translate_core.hpp): against the
+    per-byte definition for every length 3 .. 80 and longer ones (segment starts at every alignment, tails, separators), three
+    alphabets, junk bytes; and the hashes of the translated windows against the oracle's walk over the DNA itself."""
+    lib = C.CDLL(SO)
+    lib.emul_translate.restype = C.c_uint64
+    lib.emul_translate.argtypes = [C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p]
+    rng = np.random.default_rng(17)
+    alphabet = np.frombuffer(b"ACGTacgtNnRY\x00\xfe", dtype=np.uint8)
+    for n in list(range(3, 81)) + [255, 256, 257, 1000, 4099]:
+        for hf in (2, 3, 4):
+            s = rng.choice(alphabet[:8] if n % 3 else alphabet, size=n).astype(np.uint8)
+            total = sum((n - f) // 3 + 1 for f in (0, 0, 1, 1, 2, 2))
+            fast, naive = np.zeros(total + 8, dtype=np.uint8), np.zeros(total + 8, dtype=np.uint8)
+            got = lib.emul_translate(s.ctypes.data, n, hf, fast.ctypes.data, naive.ctypes.data)
+            assert got == total and np.array_equal(fast[:total], naive[:total]), (n, hf)
+    # end to end on the host: translated windows hashed by the register-window lane == the oracle on the DNA
+    s = rng.choice(alphabet[:8], size=3000).astype(np.uint8)
+    total = sum((3000 - f) // 3 + 1 for f in (0, 0, 1, 1, 2, 2))
+    fast, naive = np.zeros(total + 8, dtype=np.uint8), np.zeros(total + 8, dtype=np.uint8)
+    lib.emul_translate(s.ctypes.data, 3000, 2, fast.ctypes.data, naive.ctypes.data)
+    hashes = emul.fast(bytes(fast[:total]), 10)[1]
+    want = oracle.seq_to_hashes_protein(bytes(s), 10, "protein", is_protein=False)
+    assert np.array_equal(hashes, want)
