@@ -15,9 +15,10 @@
 //
 // The join, per workgroup: the next <= 4,096 entries of list B go to LDS (whole runs of equal hashes only); every entry of list A up
 // to B's last staged hash is taken by one thread, which finds its hash in the staged B entries by binary search (12 LDS reads,
-// independent of its neighbours': 16 waves per CU overlap them) and walks the run of equal hashes there.  The next chunk of B and
-// the next batch of A are loaded into registers while the present ones are matched.  Work grows with |A| + |B| + matches per
-// tile, not with pairs x lengths.
+// independent of its neighbours': 16 waves per CU overlap them) and the end of the run of equal hashes there; short runs it adds
+// itself, longer ones are shared out over the workgroup through a worklist in LDS (see the kernel).  The next chunk of B and the
+// next batch of A are loaded into registers while the present ones are matched.  Work grows with |A| + |B| + matches per tile,
+// not with pairs x lengths.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -30,9 +31,16 @@ namespace smg {
 namespace {
 
 constexpr int AP_T = 64;                 // sketches per block = tile edge
+constexpr int AP_TS = AP_T + 1;          // row stride of the tile's accumulators in LDS: a hash shared by a whole block puts the 64
+                                         // lanes of a wave on 64 different rows and ONE column -- at a stride of 64 that is one bank
 constexpr int AP_THREADS = 1024;
 constexpr int AP_CHUNK = 4096;           // entries of list B staged per round (64 KB of hashes + payloads)
 constexpr int AP_ZMAX = 16;              // hash slices per tile at most
+#ifndef AP_INLINE_N
+#define AP_INLINE_N 16
+#endif
+constexpr int AP_INLINE = AP_INLINE_N;            // an entry of list A that meets at most this many entries of B adds its products itself
+constexpr int AP_G = 16;                 // lanes that share a longer run
 
 #define AP_TRY(expr)                       \
     do {                                   \
@@ -88,9 +96,12 @@ __global__ __launch_bounds__(AP_THREADS) void ap_join_kernel(const uint64_t* __r
     extern __shared__ __attribute__((aligned(16))) uint64_t ap_lds[];      // AP_LDS bytes (more than the 64 KB a static array may take)
     uint64_t* s_bh = ap_lds;                                         // [AP_CHUNK] staged hashes of list B
     uint64_t* s_bp = s_bh + AP_CHUNK;                                // [AP_CHUNK] their payloads
-    unsigned long long* s_prod = reinterpret_cast<unsigned long long*>(s_bp + AP_CHUNK);   // [AP_T * AP_T]
-    uint32_t* s_cnt = reinterpret_cast<uint32_t*>(s_prod + AP_T * AP_T);                   // [AP_T * AP_T]
-    uint8_t* s_br = reinterpret_cast<uint8_t*>(s_cnt + AP_T * AP_T);                       // [AP_CHUNK] rows of the staged entries (wide abundances)
+    unsigned long long* s_prod = reinterpret_cast<unsigned long long*>(s_bp + AP_CHUNK);   // [AP_T * AP_TS]
+    uint32_t* s_cnt = reinterpret_cast<uint32_t*>(s_prod + AP_T * AP_TS);                  // [AP_T * AP_TS]
+    unsigned long long* s_wpay = reinterpret_cast<unsigned long long*>(s_cnt + AP_T * AP_TS);   // [2][AP_THREADS] worklists: abundance (+ row) of A
+    uint32_t* s_work = reinterpret_cast<uint32_t*>(s_wpay + 2 * AP_THREADS);                // [2][AP_THREADS] run start | length << 12 | row << 19
+    uint8_t* s_br = reinterpret_cast<uint8_t*>(s_work + 2 * AP_THREADS);                    // [AP_CHUNK] rows of the staged entries (wide abundances)
+    __shared__ uint32_t s_wn[2];                                     // entries ever appended to the two worklists (never reset)
     __shared__ uint64_t s_bound[4];                                  // this slice's ranges in the two lists
     const int tid = threadIdx.x;
     const uint32_t z = blockIdx.x % Z;
@@ -101,7 +112,8 @@ __global__ __launch_bounds__(AP_THREADS) void ap_join_kernel(const uint64_t* __r
     const uint32_t row0 = bi * AP_T, col0 = bj * AP_T;
     const uint32_t ra_end = row0 + AP_T < n ? row0 + AP_T : n, rb_end = col0 + AP_T < n ? col0 + AP_T : n;
     const uint64_t A0 = offsets[row0], A1 = offsets[ra_end], B0 = offsets[col0], B1 = offsets[rb_end];
-    for (int i = tid; i < AP_T * AP_T; i += AP_THREADS) { s_prod[i] = 0; s_cnt[i] = 0; }
+    for (int i = tid; i < AP_T * AP_TS; i += AP_THREADS) { s_prod[i] = 0; s_cnt[i] = 0; }
+    if (tid < 2) s_wn[tid] = 0;
     if (tid == 0) {
         // slice z of the tile: an equal share of list A's entries, moved to the start of a run of equal hashes; list B between the
         // same two hash values
@@ -123,7 +135,17 @@ __global__ __launch_bounds__(AP_THREADS) void ap_join_kernel(const uint64_t* __r
     // Round structure: chunk r of list B is in LDS; chunk r + 1 is already on its way into registers (its start is known as soon as
     // chunk r has been trimmed to whole runs); the batch of list A being matched was loaded while the previous batch was searched.
     // What a round waits for is then one LDS write + barrier and the first A batch -- not a trip to memory per step.
+    //
+    // Matching is in two steps.  A hash held by most sketches of both blocks is a run of up to 64 consecutive entries in A -- one
+    // wave's lanes -- each meeting a run of up to 64 in B: walked by the owning lanes, that is 64 dependent steps in one wave while
+    // the other fifteen wait at the batch's barrier.  So a lane only FINDS its run (lower bound over the chunk, upper bound over the
+    // next 64 entries); runs of up to AP_INLINE it adds itself, longer ones go on a worklist in LDS, and after the batch's barrier
+    // the whole workgroup takes the list, 16 lanes to a run.  The lists alternate between two buffers and their counters only grow,
+    // so no barrier is needed between one batch's list walk and the next batch's appends.  (Measured at C3, where a hash sits in 6
+    // of a block's 64 sketches and nothing is long: sending every run of more than two through the list costs 1.17 -> 1.6 ms; the
+    // list is for collections with a core of shared hashes.)
     constexpr int BPT = AP_CHUNK / AP_THREADS;                       // staged entries per thread
+    uint32_t wbase0 = 0, wbase1 = 0, par = 0;                        // list counters at the start of their present use; the batch's parity
     uint64_t rh[BPT], rp[BPT];
     uint8_t rr[BPT];
     auto fetch_b = [&](uint64_t from) {                              // entries [from, from + AP_CHUNK) of list B -> registers
@@ -176,23 +198,54 @@ __global__ __launch_bounds__(AP_THREADS) void ap_join_kernel(const uint64_t* __r
             const uint32_t ra = NARROW ? (uint32_t)(pay >> 32) : (uint32_t)nrow;
             const bool mine = h <= hi && a_cur + (uint64_t)tid < a_end;
             fetch_a(a_cur + AP_THREADS);                              // used only if this whole batch is taken
+            const uint32_t wbase = par ? wbase1 : wbase0;
+            auto add = [&](uint32_t row_a, unsigned long long aa, uint32_t j) {
+                const uint64_t pb = s_bp[j];
+                const uint32_t rb = NARROW ? (uint32_t)(pb >> 32) : (uint32_t)s_br[j];
+                if (diag && rb <= row_a) return;                     // a diagonal tile joins a list with itself: every pair once
+                const unsigned long long ab = NARROW ? (unsigned long long)(uint32_t)pb : (unsigned long long)pb;
+                atomicAdd(&s_prod[row_a * AP_TS + rb], aa * ab);
+                atomicAdd(&s_cnt[row_a * AP_TS + rb], 1u);
+            };
             if (mine) {
                 uint32_t lo = 0, hi_i = (uint32_t)nb_stage;
                 while (lo < hi_i) {
                     const uint32_t mid = (lo + hi_i) >> 1;
                     if (s_bh[mid] < h) lo = mid + 1; else hi_i = mid;
                 }
-                const unsigned long long aa = NARROW ? (unsigned long long)(uint32_t)pay : (unsigned long long)pay;
-                for (uint32_t j = lo; j < (uint32_t)nb_stage && s_bh[j] == h; ++j) {
-                    const uint64_t pb = s_bp[j];
-                    const uint32_t rb = NARROW ? (uint32_t)(pb >> 32) : (uint32_t)s_br[j];
-                    if (diag && rb <= ra) continue;                  // a diagonal tile joins a list with itself: every pair once
-                    const unsigned long long ab = NARROW ? (unsigned long long)(uint32_t)pb : (unsigned long long)pb;
-                    atomicAdd(&s_prod[ra * AP_T + rb], aa * ab);
-                    atomicAdd(&s_cnt[ra * AP_T + rb], 1u);
+                if (lo < (uint32_t)nb_stage && s_bh[lo] == h) {
+                    uint32_t ulo = lo + 1, uhi = lo + AP_T < (uint32_t)nb_stage ? lo + AP_T : (uint32_t)nb_stage;   // the run ends in (lo, lo + 64]
+                    while (ulo < uhi) {
+                        const uint32_t mid = (ulo + uhi) >> 1;
+                        if (s_bh[mid] == h) ulo = mid + 1; else uhi = mid;
+                    }
+                    const uint32_t cnt = ulo - lo;
+                    const unsigned long long aa = NARROW ? (unsigned long long)(uint32_t)pay : (unsigned long long)pay;
+                    if (cnt <= (uint32_t)AP_INLINE) {
+                        for (uint32_t j = lo; j < ulo; ++j) add(ra, aa, j);
+                    } else {
+                        const uint32_t slot = atomicAdd(&s_wn[par], 1u) - wbase;      // < AP_THREADS: one per thread at most
+                        s_work[par * AP_THREADS + slot] = lo | (cnt << 12) | (ra << 19);
+                        s_wpay[par * AP_THREADS + slot] = aa;
+                    }
                 }
             }
             const int took = __syncthreads_count(mine ? 1 : 0);       // sorted: the entries taken are a prefix of the batch
+            {
+                const uint32_t wend = s_wn[par];                      // (nobody appends to this list again before the next barrier)
+                const uint32_t nw = wend - wbase;
+                if (par) wbase1 = wend; else wbase0 = wend;
+                // (a wave's four groups take entries 16 apart: neighbours on the list are neighbouring rows of one hash, whose
+                //  accumulator rows start two banks apart -- four groups on the same 32 banks)
+                const uint32_t q = (uint32_t)tid / AP_G;
+                for (uint32_t w = (q % 4u) * 16u + q / 4u; w < nw; w += AP_THREADS / AP_G) {
+                    const uint32_t e = s_work[par * AP_THREADS + w];
+                    const unsigned long long aa = s_wpay[par * AP_THREADS + w];
+                    const uint32_t lo = e & 4095u, cnt = (e >> 12) & 127u, row_a = e >> 19;
+                    for (uint32_t o = (uint32_t)tid % AP_G; o < cnt; o += AP_G) add(row_a, aa, lo + o);
+                }
+                par ^= 1u;
+            }
             a_cur += (uint64_t)took;
             if (took < AP_THREADS) break;
         }
@@ -204,8 +257,8 @@ __global__ __launch_bounds__(AP_THREADS) void ap_join_kernel(const uint64_t* __r
     for (int i = tid; i < AP_T * AP_T; i += AP_THREADS) {
         const uint32_t r = row0 + (uint32_t)i / AP_T, c = col0 + (uint32_t)i % AP_T;
         if (r >= n || c >= n || (diag && c <= r)) continue;
-        const unsigned long long p = s_prod[i];
-        const uint32_t k = s_cnt[i];
+        const unsigned long long p = s_prod[((uint32_t)i / AP_T) * AP_TS + (uint32_t)i % AP_T];
+        const uint32_t k = s_cnt[((uint32_t)i / AP_T) * AP_TS + (uint32_t)i % AP_T];
         if (Z == 1) {
             prod[(uint64_t)r * n + c] = p; prod[(uint64_t)c * n + r] = p;
             common[(uint64_t)r * n + c] = k; common[(uint64_t)c * n + r] = k;
@@ -216,7 +269,9 @@ __global__ __launch_bounds__(AP_THREADS) void ap_join_kernel(const uint64_t* __r
     }
 }
 
-constexpr size_t AP_LDS = (size_t)AP_CHUNK * 16 + (size_t)AP_T * AP_T * 12 + AP_CHUNK;
+constexpr size_t AP_LDS = (size_t)AP_CHUNK * 16 + (size_t)AP_T * AP_TS * 12 + (size_t)AP_THREADS * 2 * 12 + AP_CHUNK;
+static_assert(AP_CHUNK <= 4096 && AP_T <= 64, "a worklist word holds a 12-bit run start, a 7-bit length and a 6-bit row");
+static_assert(AP_THREADS == 1024 && AP_G == 16, "the list walk deals 64 groups of 16 lanes, four to a wave");
 
 unsigned ap_grid(uint64_t n_items) {
     const uint64_t b = (n_items + 255) / 256;

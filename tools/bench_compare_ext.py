@@ -55,6 +55,15 @@ def main():
         out["abund_c3_%s" % ("u32" if narrow else "u64")] = {"sketches": n, "hashes": int(off[-1].item()), "pairs": pairs, "ms": round(ms, 3),
                                                             "pairs_per_s": round(pairs / (ms * 1e-3), 1),
                                                             "prod_checksum": int(prod.sum().item())}
+    # abundance, related genomes: 2,000 hashes held by every sketch + 3,000 of its own (runs of 64 in every block list)
+    rng = np.random.default_rng(11)
+    core = np.unique(rng.integers(1, 2**54, 2000, dtype=np.int64).astype(np.uint64))
+    sk = [np.unique(np.concatenate([core, rng.integers(1, 2**54, 3000, dtype=np.int64).astype(np.uint64)])) for _ in range(n)]
+    h, off = smd.pack_csr(sk, device=dev)
+    ab = (h % 7 + 1) * ((h >> 3) % 11 + 1)
+    ms = timed(lambda: be.rustcall(lib.smgpu_compare_abund_raw, p(h), p(ab), p(off), n, True, p(common), p(prod), p(sq), s()))
+    out["abund_core_u32"] = {"sketches": n, "hashes": int(off[-1].item()), "pairs": pairs, "ms": round(ms, 3), "pairs_per_s": round(pairs / (ms * 1e-3), 1),
+                             "prod_checksum": int(prod.sum().item()), "min_common": int((common + torch.eye(n, dtype=torch.int32, device=dev) * 10**6).min().item())}
     print(json.dumps(out))
 
 
