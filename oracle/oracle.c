@@ -699,7 +699,7 @@ static void u64vec_push(u64vec *v, uint64_t x) {
 static void sketch_slice(const uint8_t *seq, uint64_t len, uint64_t kmer_lo, uint64_t kmer_hi,
                          uint32_t k, uint64_t seed, uint64_t max_hash, u64vec *out) {
     /* k-mers with start index in [kmer_lo, kmer_hi) */
-    uint8_t fwd[256], rev[256];
+    uint8_t *fwd = (uint8_t *)malloc((size_t)k * 2), *rev = fwd + k;       /* any k: the reference has no limit */
     (void)len;
     for (uint64_t i = kmer_lo; i < kmer_hi; ++i) {
         int bad = 0;
@@ -714,12 +714,13 @@ static void sketch_slice(const uint8_t *seq, uint64_t len, uint64_t kmer_lo, uin
         uint64_t h = orc_hash_murmur(canon, k, seed);
         if (h != 0 && (max_hash == 0 || h <= max_hash)) u64vec_push(out, h);
     }
+    free(fwd);
 }
 
 ORC_API uint64_t orc_sketch_dna_bulk(const uint8_t *seq, uint64_t len, uint32_t k, uint64_t seed,
                                      uint64_t max_hash, int nthreads, uint64_t **out) {
     *out = NULL;
-    if (len < k || k == 0 || k > 256) return 0;
+    if (len < k || k == 0) return 0;
     uint64_t nk = len - k + 1;
     if (nthreads < 1) nthreads = 1;
     u64vec *parts = (u64vec *)calloc((size_t)nthreads, sizeof(u64vec));

@@ -16,6 +16,10 @@ hipError_t sketch_dna_launch(const uint8_t* d_seq, uint64_t len, uint32_t k, uin
                              uint64_t* d_out, unsigned long long* d_count, uint64_t cap, hipStream_t stream);
 // d_out[i] = hash of the canonical k-mer starting at i for i in [0, n_kmers) (0 for k-mers
 // covering a byte outside ACGTacgt).  d_out must be zeroed by the caller.
+// k-mers longer than the register-window kernel holds (sketch_words.hip): k = 129 .. sketch_dna_max_k(), any k >= 16 accepted
+hipError_t sketch_dna_words_launch(const uint8_t* d_seq, uint64_t len, uint32_t k, uint64_t seed, uint64_t thr, uint64_t* d_out,
+                                   unsigned long long* d_count, uint64_t cap, bool dense, hipStream_t stream);
+uint32_t sketch_dna_max_k();
 hipError_t kmer_hashes_launch(const uint8_t* d_seq, uint64_t len, uint32_t k, uint64_t seed, uint64_t* d_out,
                               uint64_t n_kmers, hipStream_t stream);
 // *d_first = min(*d_first, position of the first byte outside ACGTacgt)

@@ -26,7 +26,7 @@
 namespace smg {
 
 // Any k (1..GENERIC_MAX_K): one lane per start position, bytes read from LDS.
-// Slow path for k values without a specialised instantiation.
+// The plain form of the walk: no default path takes it (SMG_SKETCH_GENERIC=1 selects it for the tests that compare the others with it).
 constexpr int GENERIC_MAX_K = 256;
 constexpr int GENERIC_TILE = 4096;
 
@@ -88,8 +88,8 @@ __global__ __launch_bounds__(SK_BLOCK) void first_invalid_kernel(const uint8_t* 
 
 // The register-window kernel is instantiated for EVERY ksize 1 .. 128 (the reference treats all k alike,
 // signature.rs:246-306; tests/test_kmer_core_cpu.py checks each instantiation against the oracle on the host): k = 1 .. 64 in
-// this unit, 65 .. 128 in sketch_long.hip, the per-position form of all of them in sketch_dense.hip.  Longer k-mers still take the
-// byte-wise generic kernel.
+// this unit, 65 .. 128 in sketch_long.hip, the per-position form of all of them in sketch_dense.hip.  Longer k-mers take the
+// run-time-k kernel of sketch_words.hip.
 constexpr int FAST_MAX_K = 128;
 constexpr int FAST_HERE_K = 64;
 
@@ -105,7 +105,9 @@ static hipError_t sketch_any(const uint8_t* d_seq, uint64_t len, uint32_t k, uin
     }
     if (dense && k <= (uint32_t)FAST_MAX_K && !generic_only)          // per-position output (seq_to_hashes): every k <= 128 (sketch_dense.hip)
         return dense_launcher(k)(d_seq, len, seed, thr, d_out, d_count, cap, true, stream);
-    if (k > (uint32_t)GENERIC_MAX_K) return hipErrorInvalidValue;
+    // longer k-mers: 16 key bytes at a time from the staged stretch (sketch_words.hip); the byte loop below stays as the form the
+    // others are tested against (SMG_SKETCH_GENERIC=1, k <= 256)
+    if (!generic_only || k > (uint32_t)GENERIC_MAX_K) return sketch_dna_words_launch(d_seq, len, k, seed, thr, d_out, d_count, cap, dense, stream);
     const uint64_t n_tiles = (len + GENERIC_TILE - 1) / GENERIC_TILE;
     const uint64_t max_blocks = 256ull * 8;
     const unsigned grid = (unsigned)(n_tiles < max_blocks ? n_tiles : max_blocks);

@@ -112,18 +112,37 @@ def test_random_vs_oracle(sm, k):
 
 def test_every_ksize_on_the_gpu(sm):
     """k = 1 .. 128 dispatch to instantiations of the register-window kernel -- the appending form (sketch.hip, sketch_long.hip) and
-    the per-position form (sketch_dense.hip: kmerminhash_seq_to_hashes) alike -- longer k-mers to the byte-wise one: all vs the oracle"""
+    the per-position form (sketch_dense.hip: kmerminhash_seq_to_hashes) alike -- longer k-mers to the run-time-k kernel of
+    sketch_words.hip (any tail length, past the old limit of 256): all vs the oracle"""
     rng = np.random.default_rng(77)
     s = bytearray(_rand_dna(rng, 40_000, b"ACGTacgt"))
     for i in range(11, len(s), 1013):
         s[i] = ord("N")
     s = bytes(s)
-    for k in list(range(1, 129)) + [129, 200]:
+    for k in list(range(1, 129)) + [129, 130, 143, 144, 145, 160, 200, 255, 256, 257, 300]:
         mh = sm.MinHash(0, k, scaled=4)
         mh.add_sequence_buffer(s)
         assert np.array_equal(mh._mins_array(), oracle.sketch_dna_bulk(s, k, scaled=4, nthreads=4)), k
         ordered = mh.seq_to_hashes(s[:4200].decode(), force=True, bad_kmers_as_zeroes=True)     # per-position output (two tiles of the kernel)
         assert ordered == [h or 0 for h in oracle.seq_to_hashes(s[:4200], k, force=True, bad_kmers_as_zeroes=True)], k
+
+
+def test_long_kmers_palindromes_and_seams(sm):
+    """k > 128 (sketch_words.hip): k-mers equal to their reverse complement for many 16-byte blocks, bad bytes next to the seams of
+    the 4,096-position stretches, k of a thousand and more -- vs the oracle"""
+    half = b"ACGGTCATTGCA" * 40
+    pal = half + bytes(half[::-1].translate(bytes.maketrans(b"ACGT", b"TGCA")))
+    rng = np.random.default_rng(78)
+    s = bytearray(_rand_dna(rng, 3000) + pal + b"A" * 300 + b"T" * 300 + _rand_dna(rng, 12_000, b"ACGTacgt") + b"AT" * 200)
+    for i in (4095, 4096, 4097, 8191 + 150, 12_288):
+        s[i] = ord("N")
+    s = bytes(s)
+    for k in (129, 161, 240, 480, 1000, 5000):
+        mh = sm.MinHash(0, k, scaled=3)
+        mh.add_sequence_buffer(s[3:])
+        assert np.array_equal(mh._mins_array(), oracle.sketch_dna_bulk(s[3:], k, scaled=3, nthreads=4)), k
+        ordered = mh.seq_to_hashes(s[:9000].decode(), force=True, bad_kmers_as_zeroes=True)
+        assert ordered == [h or 0 for h in oracle.seq_to_hashes(s[:9000], k, force=True, bad_kmers_as_zeroes=True)], k
 
 
 def test_abundance_and_num(sm):

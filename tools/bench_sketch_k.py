@@ -33,6 +33,15 @@ if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "child":
         print(json.dumps(run([int(x) for x in sys.argv[3:]], int(sys.argv[2]))))
         sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "long":
+        # k above the register-window kernel's 128: the run-time-k kernel of sketch_words.hip, and the byte loop it replaced
+        n = 500_000_000
+        words = run([128, 129, 144, 160, 200, 256, 300, 1000], n)
+        child = subprocess.run([sys.executable, __file__, "child", str(n // 10), "129", "200", "256"], capture_output=True, text=True,
+                               env=dict(os.environ, SMG_SKETCH_GENERIC="1"))
+        generic = json.loads(child.stdout.strip().splitlines()[-1]) if child.returncode == 0 else {"error": child.stderr[-500:]}
+        print(json.dumps({"bases": n, "words_kernel": words, "byte_wise_kernel_forced": generic}))
+        sys.exit(0)
     n = 2_000_000_000
     fast = run([15, 21, 25, 27, 31, 33, 41, 51, 63, 64, 65, 80, 96, 112, 127, 128], n)
     child = subprocess.run([sys.executable, __file__, "child", str(n // 10), "25", "33", "65", "127"], capture_output=True, text=True,
