@@ -86,11 +86,11 @@ __global__ __launch_bounds__(SK_BLOCK) void first_invalid_kernel(const uint8_t* 
     if (best != ~0ull) atomicMin(first, best);
 }
 
-// The register-window kernel is instantiated for EVERY ksize 1 .. 128 (the reference treats all k alike,
+// The register-window kernel is instantiated for EVERY ksize 1 .. SK_FAST_MAX_K = 88 (the reference treats all k alike,
 // signature.rs:246-306; tests/test_kmer_core_cpu.py checks each instantiation against the oracle on the host): k = 1 .. 64 in
-// this unit, 65 .. 128 in sketch_long.hip, the per-position form of all of them in sketch_dense.hip.  Longer k-mers take the
-// run-time-k kernel of sketch_words.hip.
-constexpr int FAST_MAX_K = 128;
+// this unit, 65 .. 88 in sketch_long.hip, the per-position form of all of them in sketch_dense.hip.  Longer k-mers take the
+// run-time-k kernel of sketch_words.hip (sketch_kernel.hpp says why the line is drawn at 88).
+constexpr int FAST_MAX_K = SK_FAST_MAX_K;
 constexpr int FAST_HERE_K = 64;
 
 static hipError_t sketch_any(const uint8_t* d_seq, uint64_t len, uint32_t k, uint64_t seed, uint64_t thr,
@@ -98,12 +98,15 @@ static hipError_t sketch_any(const uint8_t* d_seq, uint64_t len, uint32_t k, uin
                              hipStream_t stream) {
     if (len < k || k == 0) return hipSuccess;
     static const bool generic_only = [] { const char* e = getenv("SMG_SKETCH_GENERIC"); return e && *e == '1'; }();
+    // from which k on the run-time-k kernel is taken (it accepts any k >= 16)
+    static const uint32_t words_from = [] { const char* e = getenv("SMG_SKETCH_WORDS_FROM"); const int v = e ? atoi(e) : 0; return v >= 16 ? (uint32_t)v : (uint32_t)FAST_MAX_K + 1u; }();
+    if (k >= words_from && !generic_only) return sketch_dna_words_launch(d_seq, len, k, seed, thr, d_out, d_count, cap, dense, stream);
     if (!dense && k <= (uint32_t)FAST_MAX_K && !generic_only) {
         const sketch_launch_fn f = k <= (uint32_t)FAST_HERE_K ? sparse_launcher_from<0>(k, std::make_integer_sequence<int, FAST_HERE_K>())
                                                              : sparse_launcher_long(k);
         return f(d_seq, len, seed, thr, d_out, d_count, cap, false, stream);
     }
-    if (dense && k <= (uint32_t)FAST_MAX_K && !generic_only)          // per-position output (seq_to_hashes): every k <= 128 (sketch_dense.hip)
+    if (dense && k <= (uint32_t)FAST_MAX_K && !generic_only)          // per-position output (seq_to_hashes): every k <= 88 (sketch_dense.hip)
         return dense_launcher(k)(d_seq, len, seed, thr, d_out, d_count, cap, true, stream);
     // longer k-mers: 16 key bytes at a time from the staged stretch (sketch_words.hip); the byte loop below stays as the form the
     // others are tested against (SMG_SKETCH_GENERIC=1, k <= 256)

@@ -1,6 +1,7 @@
 // sketch_kernel.hpp -- the register-window DNA sketch kernel (template) and its launcher, shared by the translation units
-// that instantiate it: sketch.hip (k = 1 .. 64 and the per-position forms) and sketch_long.hip (k = 65 .. 128).  Two units so
-// that 128 instantiations of a fully unrolled kernel compile side by side (sketch_long.hip itself in four parts).  See sketch.hip for the design notes.
+// that instantiate it: sketch.hip (k = 1 .. 64), sketch_long.hip (k = 65 .. SK_FAST_MAX_K, two parts) and sketch_dense.hip (the
+// per-position form of all of them, six parts), so that the fully unrolled instantiations compile side by side.  See sketch.hip
+// for the design notes.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -10,6 +11,11 @@
 namespace smg {
 
 constexpr int SK_BLOCK = 256;      // 4 waves, one per SIMD
+// The longest k-mer the unrolled kernel is instantiated for.  Its window lives in registers: from k = 89 on an instantiation needs
+// more than 256 of them and runs one wave per SIMD (k = 88: 131 Gbase/s, k = 96: 93), where the run-time-k kernel of
+// sketch_words.hip -- 67 registers at any k -- is already faster (k = 96: 106, k = 128: 85 against 68; profiles/r05_long_k.json).
+constexpr int SK_FAST_MAX_K = 88;
+constexpr int sk_part_size(int first_k_minus_1) { return SK_FAST_MAX_K - first_k_minus_1 < 16 ? SK_FAST_MAX_K - first_k_minus_1 : 16; }
 constexpr int SK_OUT_CAP = 2048;   // LDS staging entries for kept hashes (16 KiB)
 
 // DENSE == false: append kept hashes (unordered) to out, count in *out_count.
@@ -161,15 +167,13 @@ static sketch_launch_fn dense_launcher_from(uint32_t k, std::integer_sequence<in
     static const sketch_launch_fn table[] = {&launch_dense_k<K0 + KS + 1>...};
     return table[k - K0 - 1];
 }
-// sketch_dense.hip, compiled as eight parts of 16 ksizes each: k = 1 .. 16, ..., 113 .. 128
+// sketch_dense.hip, compiled as six parts of up to 16 ksizes each: k = 1 .. 16, ..., 81 .. 88
 sketch_launch_fn dense_launcher_0(uint32_t k);
 sketch_launch_fn dense_launcher_1(uint32_t k);
 sketch_launch_fn dense_launcher_2(uint32_t k);
 sketch_launch_fn dense_launcher_3(uint32_t k);
 sketch_launch_fn dense_launcher_4(uint32_t k);
 sketch_launch_fn dense_launcher_5(uint32_t k);
-sketch_launch_fn dense_launcher_6(uint32_t k);
-sketch_launch_fn dense_launcher_7(uint32_t k);
 inline sketch_launch_fn dense_launcher(uint32_t k) {
     switch ((k - 1u) / 16u) {
     case 0: return dense_launcher_0(k);
@@ -177,23 +181,13 @@ inline sketch_launch_fn dense_launcher(uint32_t k) {
     case 2: return dense_launcher_2(k);
     case 3: return dense_launcher_3(k);
     case 4: return dense_launcher_4(k);
-    case 5: return dense_launcher_5(k);
-    case 6: return dense_launcher_6(k);
-    default: return dense_launcher_7(k);
+    default: return dense_launcher_5(k);
     }
 }
-// sketch_long.hip, compiled as four parts: k = 65 .. 80, 81 .. 96, 97 .. 112, 113 .. 128
+// sketch_long.hip, compiled as two parts: k = 65 .. 80, 81 .. 88
 sketch_launch_fn sparse_launcher_long_0(uint32_t k);
 sketch_launch_fn sparse_launcher_long_1(uint32_t k);
-sketch_launch_fn sparse_launcher_long_2(uint32_t k);
-sketch_launch_fn sparse_launcher_long_3(uint32_t k);
-inline sketch_launch_fn sparse_launcher_long(uint32_t k) {
-    switch ((k - 65u) / 16u) {
-    case 0: return sparse_launcher_long_0(k);
-    case 1: return sparse_launcher_long_1(k);
-    case 2: return sparse_launcher_long_2(k);
-    default: return sparse_launcher_long_3(k);
-    }
-}
+inline sketch_launch_fn sparse_launcher_long(uint32_t k) { return k <= 80u ? sparse_launcher_long_0(k) : sparse_launcher_long_1(k); }
+static_assert(SK_FAST_MAX_K > 80 && SK_FAST_MAX_K <= 96, "the part tables above");
 
 }  // namespace smg

@@ -49,9 +49,26 @@ __global__ __launch_bounds__(SK_BLOCK) void sketch_dna_words_kernel(
     uint32_t* const s_bits = s_win + g.win_dwords;               // [n_words]
     uint32_t* const s_before = s_bits + g.n_words;               // [n_words]
     __shared__ uint32_t s_wave[SK_BLOCK / 64];
+    __shared__ uint64_t s_out[SK_OUT_CAP];                       // kept hashes wait here: one global atomic per flush, not per wave
+    __shared__ unsigned int s_cnt;
+    __shared__ unsigned long long s_base;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const WwBad bad{s_bits, s_before};
     const WwLayout lay = ww_layout(g.n_chunks);
+    if (tid == 0) s_cnt = 0;
+    auto flush = [&](unsigned int at_least) {                    // (called by every thread, between barriers)
+        __syncthreads();
+        const unsigned int cnt = s_cnt;
+        if (cnt < at_least || cnt == 0) return;
+        const unsigned int n = cnt < (unsigned)SK_OUT_CAP ? cnt : (unsigned)SK_OUT_CAP;
+        if (tid == 0) s_base = atomicAdd(out_count, (unsigned long long)n);
+        __syncthreads();
+        const unsigned long long b = s_base;
+        for (unsigned int i = (unsigned)tid; i < n; i += SK_BLOCK)
+            if (b + i < out_cap) out[b + i] = s_out[i];
+        __syncthreads();
+        if (tid == 0) s_cnt = 0;
+    };
 
     for (uint64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         const uint64_t base = tile * (uint64_t)WORDS_TILE;
@@ -116,17 +133,19 @@ __global__ __launch_bounds__(SK_BLOCK) void sketch_dna_words_kernel(
                 if (keep && pos < out_cap) out[pos] = h;
                 continue;
             }
-            const uint64_t m = __ballot(keep);
-            if (m == 0ull) continue;
-            unsigned long long g0 = 0;
-            if (lane == 0) g0 = atomicAdd(out_count, (unsigned long long)__popcll(m));
-            g0 = (unsigned long long)__shfl((long long)g0, 0, 64);
             if (keep) {
-                const unsigned long long at = g0 + (unsigned long long)__popcll(m & ((1ull << lane) - 1ull));
-                if (at < out_cap) out[at] = h;
+                const unsigned int idx = atomicAdd(&s_cnt, 1u);
+                if (idx < (unsigned)SK_OUT_CAP) {
+                    s_out[idx] = h;
+                } else {                                         // pathological density (scaled == 1): straight to HBM
+                    const unsigned long long at = atomicAdd(out_count, 1ull);
+                    if (at < out_cap) out[at] = h;
+                }
             }
         }
+        if (!dense) flush((unsigned)SK_OUT_CAP / 2);             // (the next stretch's first barrier orders the reset of s_cnt)
     }
+    if (!dense) flush(1u);
 }
 
 }  // namespace

@@ -111,7 +111,7 @@ def test_random_vs_oracle(sm, k):
 
 
 def test_every_ksize_on_the_gpu(sm):
-    """k = 1 .. 128 dispatch to instantiations of the register-window kernel -- the appending form (sketch.hip, sketch_long.hip) and
+    """k = 1 .. 88 dispatch to instantiations of the register-window kernel -- the appending form (sketch.hip, sketch_long.hip) and
     the per-position form (sketch_dense.hip: kmerminhash_seq_to_hashes) alike -- longer k-mers to the run-time-k kernel of
     sketch_words.hip (any tail length, past the old limit of 256): all vs the oracle"""
     rng = np.random.default_rng(77)
