@@ -21,7 +21,7 @@ namespace smg {
 namespace {
 
 constexpr int WORDS_TILE = 4096;             // start positions per stretch (16 per lane)
-constexpr uint32_t WORDS_MAX_K = 65536;      // LDS: two copies of the stretch + masks = 2.0625 (TILE + k) + slack <= 160 KB
+constexpr uint32_t WORDS_MAX_K = 60000;      // LDS: two copies of the stretch + masks = 2.25 (TILE + k) + the 16 KB of kept hashes <= 160 KB
 
 struct WordsGeom {
     uint32_t n_chunks;       // 16-byte chunks of the stretch (TILE + k - 1 bytes, rounded up)
@@ -160,6 +160,7 @@ hipError_t sketch_dna_words_launch(const uint8_t* d_seq, uint64_t len, uint32_t 
     const uint64_t n_tiles = (len + WORDS_TILE - 1) / WORDS_TILE;
     if (n_tiles == 0) return hipSuccess;
     const WordsGeom g = words_geometry(k);
+    if (g.lds + sizeof(uint64_t) * SK_OUT_CAP + 64 > 160u * 1024u) return hipErrorInvalidValue;   // (WORDS_MAX_K is chosen so that this holds)
     static size_t allowed = 0;
     if (g.lds > 48 * 1024 && g.lds > allowed) {
         const hipError_t e = hipFuncSetAttribute((const void*)sketch_dna_words_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds);

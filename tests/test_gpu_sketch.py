@@ -145,6 +145,19 @@ def test_long_kmers_palindromes_and_seams(sm):
         assert ordered == [h or 0 for h in oracle.seq_to_hashes(s[:9000], k, force=True, bad_kmers_as_zeroes=True)], k
 
 
+def test_the_longest_kmer_the_lds_holds(sm):
+    "k = 60,000 (sketch_words.hip: 2.25 x (4,096 + k) bytes of LDS + the kept-hash buffer = 160 KB) vs the oracle; one more is refused"
+    rng = np.random.default_rng(79)
+    s = _rand_dna(rng, 70_000)
+    mh = sm.MinHash(0, 60_000, scaled=2)
+    mh.add_sequence_buffer(s)
+    want = oracle.sketch_dna_bulk(s, 60_000, scaled=2, nthreads=8)
+    assert len(want) > 3000 and np.array_equal(mh._mins_array(), want)
+    mh = sm.MinHash(0, 60_001, scaled=2)
+    with pytest.raises(Exception):
+        mh.add_sequence_buffer(s)
+
+
 def test_abundance_and_num(sm):
     rng = np.random.default_rng(9)
     s = _rand_dna(rng, 2000) * 3 + _rand_dna(rng, 5000)

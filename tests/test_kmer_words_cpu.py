@@ -87,3 +87,13 @@ def test_seeds(emul):
     s = _rand_dna(rng, 1000)
     for seed in (0, 1, 43, 2**32 - 1):
         assert np.array_equal(emul(s, 150, seed=seed), _oracle_dense(s, 150, seed=seed)), seed
+
+
+def test_very_long_kmers(emul):
+    "k in the thousands, up to the kernel's limit: many blocks, a stretch dominated by its halo"
+    rng = np.random.default_rng(10)
+    s = bytearray(_rand_dna(rng, 61_500))
+    for k in (4999, 60_000):
+        assert np.array_equal(emul(bytes(s), k), _oracle_dense(bytes(s), k)), k
+    s[30_000] = ord("N")
+    assert np.array_equal(emul(bytes(s), 20_000), _oracle_dense(bytes(s), 20_000))
