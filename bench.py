@@ -286,6 +286,10 @@ def main():
             protein_extras(extra, torch, np, dev, smd, args)
         except Exception as e:
             extra["protein_error"] = repr(e)
+        try:
+            ksize_extras(extra, torch, np, dev, smd)
+        except Exception as e:
+            extra["ksize_error"] = repr(e)
         torch.cuda.empty_cache()
 
     # ---- the steps either side of the kernels, on this box (N = 1): file ingest and bulk signature loading ----
@@ -998,6 +1002,35 @@ def api_extras(extra, torch, np, dev, smd, synth_sketches, synth_gather_device):
         "kernel_plus_transfer_ms": None if kernel_ms is None else round(kernel_ms + pcie_ms, 2),
         "wall_over_kernel_plus_transfer": None if kernel_ms is None else round(best[0] * 1e3 / (kernel_ms + pcie_ms), 3),
         "same_rounds_as_the_resident_path": None if "rounds" not in r else bool(r["rounds"] == len(res)), "objects_s": round(objects_s, 1)}
+
+
+def ksize_extras(extra, torch, np, dev, smd):
+    """The sketch step at other ksizes (signature.rs:246-306 treats every k alike): kernel + sort + unique on 10^9 resident bases,
+    scaled = 1000 -- the unrolled register-window kernel to k = 88, the run-time-k kernel of sketch_words.hip beyond -- each checked
+    against the oracle on a sample of the same input."""
+    import oracle
+    n = 1_000_000_000
+    seq = smd.synth_dna(n, seed=44, record_len=10_000_000, device=dev)
+    sample = 400_000
+    host = bytes(seq[:sample].cpu().numpy())
+    out = {}
+    for k in (21, 51, 88, 89, 128, 200, 256, 1000):
+        sk = smd.DeviceSketcher(k, 1000)
+        got = np.sort(sk.sketch(seq[:sample]).cpu().numpy().view(np.uint64))
+        want = oracle.sketch_dna_bulk(host, k, scaled=1000, nthreads=4)
+        sk.sketch(seq)
+        torch.cuda.synchronize()
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(3)]
+        for a, b in evs:
+            a.record()
+            h = sk.sketch(seq)
+            b.record()
+        torch.cuda.synchronize()
+        ms = float(np.median([a.elapsed_time(b) for a, b in evs]))
+        out["k%d" % k] = {"ms": round(ms, 3), "Gbase_per_s": round(n / (ms * 1e-3) / 1e9, 1), "hashes": int(h.numel()),
+                          "kernel": "register window (unrolled)" if k <= 88 else "run-time k (sketch_words.hip)",
+                          "gpu_matches_oracle_on_sample": bool(np.array_equal(got, want))}
+    extra["sketch_by_k"] = {"bases": n, "scaled": 1000, **out}
 
 
 def protein_extras(extra, torch, np, dev, smd, args):
