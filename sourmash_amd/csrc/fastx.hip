@@ -176,8 +176,8 @@ __global__ __launch_bounds__(FX_THREADS) void scatter_kernel(const uint8_t* __re
 // dst[j] = last H bytes of (old halo ++ the n new bytes at src); src[-H .. -1] is the old halo
 __global__ void halo_kernel(const uint8_t* __restrict__ src, const unsigned long long* __restrict__ n_new, int H,
                             uint8_t* __restrict__ dst) {
-    const int j = threadIdx.x;
-    if (j < H) dst[j] = src[(long long)*n_new + j - H];
+    const long long n = (long long)*n_new;
+    for (int j = threadIdx.x; j < H; j += blockDim.x) dst[j] = src[n + j - H];
 }
 
 size_t align256(size_t x) { return (x + 255) / 256 * 256; }
@@ -225,7 +225,6 @@ hipError_t fastx_compact_launch(const uint8_t* d_raw, uint64_t n, int fastq, uin
 hipError_t fastx_halo_launch(const uint8_t* d_src, const unsigned long long* d_n_new, int halo, uint8_t* d_dst,
                              hipStream_t stream) {
     if (halo <= 0) return hipSuccess;
-    if (halo > 256) return hipErrorInvalidValue;
     hipLaunchKernelGGL(halo_kernel, dim3(1), dim3(256), 0, stream, d_src, d_n_new, halo, d_dst);
     return hipGetLastError();
 }

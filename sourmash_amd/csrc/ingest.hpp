@@ -199,7 +199,7 @@ struct IngestScratch {
     hipStream_t copy_stream = nullptr;
     hipEvent_t copied[2] = {nullptr, nullptr}, consumed[2] = {nullptr, nullptr};
     size_t temp_bytes = 0;
-    static constexpr size_t HALO = 256;             // bytes reserved in front of every compacted chunk
+    size_t halo = 256;                              // bytes reserved in front of every compacted chunk: >= the longest ksize, a multiple of 256
 
     // The device blocks go back to the arena while the stream their work ran on still exists (its owner calls this before it
     // destroys the stream: a DevBuf released later would record its release event on a destroyed stream).  The stream is
@@ -217,7 +217,7 @@ struct IngestScratch {
         copy_stream = nullptr;
         chunk = 0;
     }
-    void prepare(size_t chunk_bytes, hipStream_t stream) {
+    void prepare(size_t chunk_bytes, uint32_t kmax, hipStream_t stream) {
         if (!copy_stream) {
             hip_check(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking), "hipStreamCreate");
             for (int i = 0; i < 2; ++i) {
@@ -226,12 +226,14 @@ struct IngestScratch {
             }
             small.reserve(256, stream);
         }
-        if (chunk_bytes <= chunk) return;
-        chunk = chunk_bytes;
+        const size_t need_halo = ((size_t)(kmax > 256u ? kmax : 256u) + 255) / 256 * 256;
+        if (chunk_bytes <= chunk && need_halo <= halo) return;
+        chunk = chunk_bytes > chunk ? chunk_bytes : chunk;
+        halo = need_halo > halo ? need_halo : halo;
         for (auto& r : ring) r.reserve(chunk + 64);
         for (int i = 0; i < 2; ++i) {
             raw[i].reserve(chunk + 64, stream);
-            comp[i].reserve(HALO + chunk + 64, stream);
+            comp[i].reserve(halo + chunk + 64, stream);
         }
         state.reserve(chunk + 64, stream);
         temp_bytes = fastx_temp_bytes(chunk);
@@ -270,10 +272,9 @@ inline void sketch_file_with(IngestWorker& w, std::vector<KmerMinHash*>& mhs, co
     uint32_t kmax = 0;
     for (auto* mh : mhs) kmax = std::max(kmax, mh->ksize);
     if (mhs.empty() || kmax == 0) return;
-    if (kmax > IngestScratch::HALO) throw err_internal("ksize too large for the streaming ingest");
     hipStream_t st = w.stream;
     IngestScratch& scratch = w.scratch;
-    scratch.prepare(CHUNK, st);
+    scratch.prepare(CHUNK, kmax, st);
     const int halo = (int)kmax - 1;
 
     struct Acc {                       // per sketch: unordered kept hashes since the last flush
@@ -332,7 +333,7 @@ inline void sketch_file_with(IngestWorker& w, std::vector<KmerMinHash*>& mhs, co
     unsigned long long* d_records = d_n + 1;
     hip_check(hipMemsetAsync(scratch.small.p, 0, 64, st), "memset");
     for (int b = 0; b < 2; ++b)                      // nothing precedes the first chunk: a halo of separators
-        hip_check(hipMemsetAsync(scratch.comp[b].p, '\n', IngestScratch::HALO, st), "memset");
+        hip_check(hipMemsetAsync(scratch.comp[b].p, '\n', scratch.halo, st), "memset");
     hip_check(hipStreamSynchronize(st), "sync");     // the copy stream must not race these
 
     const bool trace = getenv("SMG_INGEST_TRACE") != nullptr;
@@ -370,7 +371,7 @@ inline void sketch_file_with(IngestWorker& w, std::vector<KmerMinHash*>& mhs, co
         }
         // compute stream: parse + compact behind the halo that the previous chunk left in comp[b]
         hip_check(hipStreamWaitEvent(st, scratch.copied[b], 0), "wait");
-        uint8_t* comp = scratch.comp[b].as<uint8_t>() + IngestScratch::HALO;
+        uint8_t* comp = scratch.comp[b].as<uint8_t>() + scratch.halo;
         hip_check(fastx_compact_launch(scratch.raw[b].as<uint8_t>(), len, fastq, d_carry, scratch.state.as<uint8_t>(), comp,
                                        d_n, d_records, scratch.temp.p, scratch.temp_bytes, st), "fastx");
         hip_check(hipEventRecord(scratch.consumed[b], st), "record");
@@ -414,7 +415,7 @@ inline void sketch_file_with(IngestWorker& w, std::vector<KmerMinHash*>& mhs, co
                                         a.cnt.as<unsigned long long>(), a.cap, st), "sketch_dna");
         }
         // the next chunk's halo: the last kmax-1 bytes of the stream so far
-        hip_check(fastx_halo_launch(comp, d_n, halo, scratch.comp[b ^ 1].as<uint8_t>() + IngestScratch::HALO - halo, st), "halo");
+        hip_check(fastx_halo_launch(comp, d_n, halo, scratch.comp[b ^ 1].as<uint8_t>() + scratch.halo - halo, st), "halo");
         cur = next;
     }
     unsigned long long recs = 0;

@@ -107,6 +107,35 @@ for path in ({fq!r}, {fa!r}):
         assert np.array_equal(np.load(path + ".num.npy"), _oracle_sig(recs, 31, num=300).mins)
 
 
+def test_long_kmers_across_chunk_boundaries(sm, tmp_path):
+    """k = 300 and 1,500 through the streaming ingest with chunks of 1,000 bytes: the halo between chunks is k - 1 bytes -- longer
+    than a chunk for the second (rounds 1-4 kept a fixed 256-byte halo and refused k > 256)"""
+    rng = np.random.default_rng(6)
+    recs = []
+    for i, L in enumerate((9_000, 1_499, 1_500, 23_456, 2_000)):
+        s = bytearray(rng.choice(np.frombuffer(b"ACGTacgt", dtype=np.uint8), size=L).tobytes())
+        for j in range(4_000, L, 7_001):
+            s[j] = ord("N")
+        recs.append((f"rec{i}", s.decode()))
+    fa = str(tmp_path / "long.fa")
+    _write_fasta(fa, recs, width=80)
+    code = f"""
+import sys, numpy as np
+sys.path.insert(0, {ROOT!r})
+import torch
+from sourmash_amd.sketch import sketch_file
+sig, = sketch_file({fa!r}, "k=21,k=300,k=1500,scaled=5,abund")
+for mh in sig.minhashes():
+    np.save({fa!r} + f".k{{mh.ksize}}.npy", np.array([list(mh.hashes.keys()), list(mh.hashes.values())], dtype=np.uint64))
+"""
+    subprocess.check_call([sys.executable, "-c", code], env=dict(os.environ, SMG_INGEST_CHUNK="1000"))
+    for k in (21, 300, 1500):
+        got = np.load(fa + f".k{k}.npy")
+        want = _oracle_sig(recs, k, scaled=5, abund=True)
+        assert len(want.mins) > 0 and np.array_equal(got[0], want.mins), k
+        assert np.array_equal(got[1], want.abunds), k                      # no k-mer hashed twice at a boundary
+
+
 def test_missing_file_raises(sm):
     from sourmash_amd.sketch import sketch_file
     with pytest.raises(sm.exceptions.SourmashError):
