@@ -1027,9 +1027,13 @@ def ksize_extras(extra, torch, np, dev, smd):
             b.record()
         torch.cuda.synchronize()
         ms = float(np.median([a.elapsed_time(b) for a, b in evs]))
+        blocks = k // 16 + (1 if k % 16 else 0)
         out["k%d" % k] = {"ms": round(ms, 3), "Gbase_per_s": round(n / (ms * 1e-3) / 1e9, 1), "hashes": int(h.numel()),
                           "kernel": "register window (unrolled)" if k <= 88 else "run-time k (sketch_words.hip)",
-                          "gpu_matches_oracle_on_sample": bool(np.array_equal(got, want))}
+                          "gpu_matches_oracle_on_sample": bool(np.array_equal(got, want)),
+                          "roofline": hbm_roofline(n + 8 * int(h.numel()), ms, "1 B per base + 8 B per kept hash; whole step (kernel + sort + unique); "
+                                                   "the kernels are bound by instruction issue: MurmurHash3 is 4 64-bit multiplies per 16-byte "
+                                                   "block of the key, %d blocks at this k" % blocks)}
     extra["sketch_by_k"] = {"bases": n, "scaled": 1000, **out}
 
 

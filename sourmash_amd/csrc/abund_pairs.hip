@@ -207,19 +207,23 @@ __global__ __launch_bounds__(AP_THREADS) void ap_join_kernel(const uint64_t* __r
                 atomicAdd(&s_prod[row_a * AP_TS + rb], aa * ab);
                 atomicAdd(&s_cnt[row_a * AP_TS + rb], 1u);
             };
+            // Both searches are written without loops over lane-dependent bounds: twelve and six fixed steps, every lane of the wave
+            // in every step (a `while (lo < hi)` costs its exec-mask bookkeeping in each of its ~18 steps: the kernel is bound by
+            // instruction issue and by these dependent LDS reads, profiles/r05_abund_join_experiments.txt).  The whole staging area is
+            // searched, not just its first nb_stage entries: what lies behind them is the cut-off run of the largest staged hash and
+            // 2^64 - 1 fillers, and no entry of A taken in this round (h <= hi) can equal either.
+            uint32_t lo = 0;
+#pragma unroll
+            for (uint32_t len = AP_CHUNK / 2; len; len >>= 1) lo += s_bh[lo + len - 1] < h ? len : 0u;
             if (mine) {
-                uint32_t lo = 0, hi_i = (uint32_t)nb_stage;
-                while (lo < hi_i) {
-                    const uint32_t mid = (lo + hi_i) >> 1;
-                    if (s_bh[mid] < h) lo = mid + 1; else hi_i = mid;
-                }
                 if (lo < (uint32_t)nb_stage && s_bh[lo] == h) {
-                    uint32_t ulo = lo + 1, uhi = lo + AP_T < (uint32_t)nb_stage ? lo + AP_T : (uint32_t)nb_stage;   // the run ends in (lo, lo + 64]
-                    while (ulo < uhi) {
-                        const uint32_t mid = (ulo + uhi) >> 1;
-                        if (s_bh[mid] == h) ulo = mid + 1; else uhi = mid;
+                    uint32_t cnt = 1;                                 // the run of h: entries lo .. lo + cnt - 1, cnt <= 64
+#pragma unroll
+                    for (uint32_t len = AP_T / 2; len; len >>= 1) {
+                        const uint32_t at = lo + cnt + len - 1;
+                        if (at < (uint32_t)nb_stage && s_bh[at] == h) cnt += len;
                     }
-                    const uint32_t cnt = ulo - lo;
+                    const uint32_t ulo = lo + cnt;
                     const unsigned long long aa = NARROW ? (unsigned long long)(uint32_t)pay : (unsigned long long)pay;
                     if (cnt <= (uint32_t)AP_INLINE) {
                         for (uint32_t j = lo; j < ulo; ++j) add(ra, aa, j);
@@ -271,6 +275,7 @@ __global__ __launch_bounds__(AP_THREADS) void ap_join_kernel(const uint64_t* __r
 
 constexpr size_t AP_LDS = (size_t)AP_CHUNK * 16 + (size_t)AP_T * AP_TS * 12 + (size_t)AP_THREADS * 2 * 12 + AP_CHUNK;
 static_assert(AP_CHUNK <= 4096 && AP_T <= 64, "a worklist word holds a 12-bit run start, a 7-bit length and a 6-bit row");
+static_assert((AP_CHUNK & (AP_CHUNK - 1)) == 0 && AP_T == 64, "the searches halve a power of two");
 static_assert(AP_THREADS == 1024 && AP_G == 16, "the list walk deals 64 groups of 16 lanes, four to a wave");
 
 unsigned ap_grid(uint64_t n_items) {
