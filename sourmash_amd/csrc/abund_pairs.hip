@@ -14,11 +14,12 @@
 // 256 CUs), the slices' sums meeting in the zeroed matrices through atomics.
 //
 // The join, per workgroup: the next <= 4,096 entries of list B go to LDS (whole runs of equal hashes only); every entry of list A up
-// to B's last staged hash is taken by one thread, which finds its hash in the staged B entries by binary search (12 LDS reads,
-// independent of its neighbours': 16 waves per CU overlap them) and the end of the run of equal hashes there; short runs it adds
-// itself, longer ones are shared out over the workgroup through a worklist in LDS (see the kernel).  The next chunk of B and the
-// next batch of A are loaded into registers while the present ones are matched.  Work grows with |A| + |B| + matches per tile,
-// not with pairs x lengths.
+// to B's last staged hash is taken by one thread, which finds its hash in the staged B entries by a fixed-step search (12 LDS reads,
+// independent of its neighbours': 16 waves per CU overlap them) and the end of the run of equal hashes there (6 more); short runs
+// it adds itself, longer ones are shared out over the workgroup through a worklist in LDS (see the kernel).  The next chunk of B
+// and the next batch of A are loaded into registers while the present ones are matched.  Work grows with |A| + |B| + matches per
+// tile, not with pairs x lengths.  What bounds it is instruction issue and the dependent LDS reads of the searches, not the LDS
+// atomics (measured: profiles/r05_abund_join_experiments.txt, tools/ubench/lds_atomic.hip).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
