@@ -145,6 +145,20 @@ def test_long_kmers_palindromes_and_seams(sm):
         assert ordered == [h or 0 for h in oracle.seq_to_hashes(s[:9000], k, force=True, bad_kmers_as_zeroes=True)], k
 
 
+def test_long_kmers_every_hash_kept(sm):
+    "scaled = 1 and bottom-k sketches at k > 88: a stretch keeps more hashes than the kernel's LDS buffer holds (the spill path)"
+    rng = np.random.default_rng(80)
+    s = _rand_dna(rng, 30_000)
+    for k in (89, 130, 300):
+        mh = sm.MinHash(0, k, scaled=1)
+        mh.add_sequence_buffer(s)
+        assert np.array_equal(mh._mins_array(), oracle.sketch_dna_bulk(s, k, scaled=1, nthreads=4)), k
+        mh = sm.MinHash(500, k)
+        om = oracle.OracleMinHash(500, k)
+        mh.add_sequence(s.decode()); om.add_sequence(s)
+        assert np.array_equal(mh._mins_array(), om.mins), k
+
+
 def test_the_longest_kmer_the_lds_holds(sm):
     "k = 60,000 (sketch_words.hip: 2.25 x (4,096 + k) bytes of LDS + the kept-hash buffer = 160 KB) vs the oracle; one more is refused"
     rng = np.random.default_rng(79)
