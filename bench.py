@@ -319,6 +319,7 @@ def main():
                        "comm": comm},
             "roofline": roofline, "cpu_baseline": cpu, "extra": extra,
         }
+        out["summary"] = extras_summary(extra)      # LAST: whoever keeps only the tail of this line still sees the secondary figures
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
@@ -333,6 +334,47 @@ def main():
     os.close(real_stdout)
     if out is not None:
         print(json.dumps(out), flush=True)
+
+
+def extras_summary(extra):
+    """The secondary figures of `extra` once more, in a few hundred bytes at the END of the line (the extras themselves are ~25 KB;
+    a log that keeps the last 8 KB of stdout would otherwise lose the C3 / C4 / C5 numbers).  Names say the unit; None = not run."""
+    def get(*path):
+        v = extra
+        for k in path:
+            if not isinstance(v, dict) or k not in v:
+                return None
+            v = v[k]
+        return v
+    def r(v, nd=3):
+        return round(v, nd) if isinstance(v, (int, float)) else v
+    bk = get("sketch_by_k") or {}
+    return {
+        "c3_compare_1000_auto_ms": r(get("compare_1000x1000_auto", "ms")),
+        "c4_compare_10000_auto_ms": r(get("compare_10000x10000", "auto_ms")), "c4_auto_pairs_per_s": r(get("compare_10000x10000", "auto_pairs_per_s"), 0),
+        "c4_bitmatrix_valu_frac": r(get("compare_10000x10000", "auto_roofline", "frac")),
+        "c4_general_kernel_pairs_per_s": r(get("compare_10000x10000", "merge_pairs_per_s"), 0),
+        "compare_num_1000_ms": r(get("compare_num_1000x500", "ms")), "compare_abund_1000_ms": r(get("compare_abund_1000x1000", "ms")),
+        "compare_abund_pairs_per_s": r(get("compare_abund_1000x1000", "pairs_per_s"), 0),
+        "compare_api_10000_objects_ms": r(get("compare_api_10000", "ms")), "compare_api_1000_objects_ms": r(get("compare_api_1000", "ms")),
+        "c5_overlap_pass_ms": r(get("overlaps_1M_vs_100000", "ms")), "c5_overlap_hbm_frac": r(get("overlaps_1M_vs_100000", "roofline", "frac")),
+        "c5_overlap_traffic_bytes": get("overlaps_1M_vs_100000", "roofline", "traffic"),
+        "c5_gather_total_ms": r(get("gather_1M_vs_100000", "total_ms")), "c5_index_build_ms": r(get("gather_1M_vs_100000", "index_build_ms")),
+        "c5_index_build_hbm_frac": r(get("gather_1M_vs_100000", "index_build_roofline", "frac")),
+        "c5_gather_us_per_round": r(get("gather_1M_vs_100000", "us_per_round")), "c5_gather_rounds": get("gather_1M_vs_100000", "rounds"),
+        "c5_loop_frac_of_floor": r(get("gather_1M_vs_100000", "loop_roofline", "frac")),
+        "gather_api_c5_objects_ms": r(get("gather_api_c5", "total_ms")),
+        "dist_compare_c4_pairs_per_s": r(get("compare_c4_dist", "pairs_per_s"), 0), "dist_compare_c4_collective": get("compare_c4_dist", "collective"),
+        "dist_compare_xl_pairs_per_s": r(get("compare_xl_dist", "pairs_per_s"), 0),
+        "dist_gather_c5_total_ms": r(get("gather_c5_dist", "total_ms")), "dist_gather_c5_collective": get("gather_c5_dist", "collective"),
+        "dist_gather_c5_protocol": get("gather_c5_dist", "protocol"), "dist_gather_c5_fell_back": get("gather_c5_dist", "fell_back"),
+        "dist_gather_xl_datasets_per_s": r(get("gather_xl_dist", "datasets_per_s"), 0),
+        "protein_k10_G_windows_per_s": r(get("sketch_protein", "protein_k10", "G_windows_per_s")),
+        "translate_k10_G_windows_per_s": r(get("sketch_translate", "translate_protein_k10", "G_windows_per_s")),
+        "sketch_Gbase_per_s_by_k": {k[1:]: v.get("Gbase_per_s") for k, v in bk.items() if k.startswith("k") and isinstance(v, dict)},
+        "ingest_fasta_Gbase_per_s": r(get("ingest_fasta", "Gbase_per_s")), "ingest_gz_Gbase_per_s": r(get("ingest_gz", "Gbase_per_s")),
+        "errors": [k for k in extra if k.endswith("error")],
+    }
 
 
 def comm_info(torch, dist, use_dist, dev, share_gpu):
