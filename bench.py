@@ -30,6 +30,7 @@ import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -77,6 +78,9 @@ def parse():
     ap.add_argument("--no-xl", action="store_true", help="skip the XL multi-GPU configurations (compare_xl_dist, gather_xl_dist)")
     ap.add_argument("--no-io", action="store_true", help="skip the file ingest / signature loading metrics (they write ~1.8 GB to a temp directory)")
     ap.add_argument("--cpu-sample", type=float, default=0.0, help="bases for the N-thread CPU sketch leg (0 = auto)")
+    ap.add_argument("--extras-timeout", type=float, default=900.0,
+                    help="seconds the secondary metrics may take before the line is printed without the unfinished ones and every rank "
+                         "leaves (a rank stuck in a collective cannot be interrupted any other way); 0 = no limit")
     return ap.parse_args()
 
 
@@ -222,6 +226,45 @@ def main():
         cpu = cpu_baseline(args, seq, n_bytes, sk, np)
 
     extra = {}
+
+    def build_line():
+        return {
+            "metric": "Gbase/s sketched (k=31, scaled=1000)", "value": round(value, 3), "unit": "Gbase/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "config": {"workload": "C2: sketch 10 GB synthetic random-DNA per GPU (%d whole records of %d bases = %d bytes with their "
+                                   "separators: what fits 10^10 bytes; ASCII resident in HBM), k=%d scaled=%d seed=42; kernel + radix sort + unique"
+                                   % (n_bytes // stride if n_bytes >= stride else 1, rec, n_bytes, args.ksize, args.scaled),
+                       "bases_per_gpu": bases_per_step, "bytes_per_gpu": n_bytes, "ksize": args.ksize,
+                       "scaled": args.scaled, "unique_hashes_rank0": n_unique_local,
+                       "unique_hashes_job": n_unique_total, "allgather_ms": gather_ms,
+                       "collectives": coll(comm, "all-gather of the hash vectors (union)") + (" -- REHEARSAL: ranks share one GPU" if share_gpu else ""),
+                       "comm": comm},
+            "roofline": roofline, "cpu_baseline": cpu, "extra": extra,
+            # LAST: whoever keeps only the tail of this line still sees the secondary figures
+            "summary": extras_summary(extra),
+        }
+
+    # The headline metric is measured; what follows are secondary metrics, some of them collectives among the ranks.  A rank stuck in
+    # one cannot be interrupted from Python, and a job killed from outside prints nothing: after --extras-timeout seconds a timer
+    # thread prints the line with whatever is finished (rank 0) and every rank leaves.
+    def give_up():
+        GIVING_UP.set()
+        try:
+            if rank == 0:
+                extra["timed_out"] = ("the secondary metrics were still running after %.0f s: printed without the unfinished ones, "
+                                      "every rank left through os._exit" % args.extras_timeout)
+                os.write(real_stdout, (json.dumps(build_line()) + "\n").encode())
+                time.sleep(3.0)                              # the other ranks leave first: none of them sees a peer vanish
+        finally:
+            os._exit(0)
+    watchdog = None
+    if args.extras_timeout > 0 and not args.no_compare:
+        watchdog = threading.Timer(args.extras_timeout, give_up)
+        watchdog.daemon = True
+        watchdog.start()
+
     del seq, hashes                                          # 10 GB back before the matrices
     torch.cuda.empty_cache()
     be = parallel.DeviceBackend(dev)
@@ -302,27 +345,12 @@ def main():
     if rank == 0:
         extra["arena"] = {**smd.arena_stats(), "what": "the library's device arena (csrc/arena.hpp) over the whole run: driver "
                           "allocator calls, nanoseconds inside them, allocations served from cached blocks"}
-    out = None
-    if rank == 0:
-        out = {
-            "metric": "Gbase/s sketched (k=31, scaled=1000)", "value": round(value, 3), "unit": "Gbase/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-            "config": {"workload": "C2: sketch 10 GB synthetic random-DNA per GPU (%d whole records of %d bases = %d bytes with their "
-                                   "separators: what fits 10^10 bytes; ASCII resident in HBM), k=%d scaled=%d seed=42; kernel + radix sort + unique"
-                                   % (n_bytes // stride if n_bytes >= stride else 1, rec, n_bytes, args.ksize, args.scaled),
-                       "bases_per_gpu": bases_per_step, "bytes_per_gpu": n_bytes, "ksize": args.ksize,
-                       "scaled": args.scaled, "unique_hashes_rank0": n_unique_local,
-                       "unique_hashes_job": n_unique_total, "allgather_ms": gather_ms,
-                       "collectives": coll(comm, "all-gather of the hash vectors (union)") + (" -- REHEARSAL: ranks share one GPU" if share_gpu else ""),
-                       "comm": comm},
-            "roofline": roofline, "cpu_baseline": cpu, "extra": extra,
-        }
-        out["summary"] = extras_summary(extra)      # LAST: whoever keeps only the tail of this line still sees the secondary figures
+    out = build_line() if rank == 0 else None
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
+    if watchdog is not None:
+        watchdog.cancel()
     # whatever sits in libc's or Python's buffers for descriptor 1 leaves (towards stderr) before stdout comes back
     try:
         import ctypes
@@ -334,6 +362,9 @@ def main():
     os.close(real_stdout)
     if out is not None:
         print(json.dumps(out), flush=True)
+
+
+GIVING_UP = threading.Event()      # set by the watchdog of main(): from then on an exception means a peer has left, not a failure
 
 
 def extras_summary(extra):
@@ -1278,4 +1309,9 @@ def merge_roofline(alg_bytes, ms):
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    except BaseException:
+        if GIVING_UP.is_set():       # a peer left through the watchdog while this rank was inside a collective: the line is out
+            os._exit(0)
+        raise
