@@ -47,7 +47,7 @@ class HostXfer {
             unsigned c = std::max(1u, std::thread::hardware_concurrency());
             cpu_set_t set;
             if (sched_getaffinity(0, sizeof(set), &set) == 0) c = std::min<unsigned>(c, (unsigned)CPU_COUNT(&set));
-            if (const char* e = getenv("SMG_XFER_THREADS")) c = (unsigned)std::max(1, atoi(e));
+            if (const char* e = getenv("SMG_XFER_THREADS")) return (unsigned)std::min(64, std::max(1, atoi(e)));
             return std::min(c, 8u);
         }();
         return n;
