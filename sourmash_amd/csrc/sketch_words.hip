@@ -12,7 +12,7 @@
 // kernels by what the run-time addressing costs, not by an order of magnitude (profiles/r05_long_k.json).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
-#include <atomic>
+#include <mutex>
 #include "kmer_words.hpp"
 #include "sketch_kernel.hpp"
 #include "device_api.hpp"
@@ -162,12 +162,14 @@ hipError_t sketch_dna_words_launch(const uint8_t* d_seq, uint64_t len, uint32_t 
     if (n_tiles == 0) return hipSuccess;
     const WordsGeom g = words_geometry(k);
     if (g.lds + sizeof(uint64_t) * SK_OUT_CAP + 64 > 160u * 1024u) return hipErrorInvalidValue;   // (WORDS_MAX_K is chosen so that this holds)
-    static std::atomic<size_t> allowed{0};                       // (several host threads may sketch at once: ingest workers)
-    if (g.lds > 48 * 1024 && g.lds > allowed.load(std::memory_order_relaxed)) {
-        const hipError_t e = hipFuncSetAttribute((const void*)sketch_dna_words_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)g.lds);
-        if (e != hipSuccess) return e;
-        size_t seen = allowed.load(std::memory_order_relaxed);
-        while (seen < g.lds && !allowed.compare_exchange_weak(seen, g.lds, std::memory_order_relaxed)) { }
+    if (g.lds > 48 * 1024) {                                     // more dynamic LDS than a kernel gets unasked: allow the most any k may need, once
+        static std::once_flag once;
+        static hipError_t allowed = hipSuccess;
+        std::call_once(once, [] {
+            allowed = hipFuncSetAttribute((const void*)sketch_dna_words_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)words_geometry(WORDS_MAX_K).lds);
+        });
+        if (allowed != hipSuccess) return allowed;
     }
     const uint64_t max_blocks = 256ull * 8;
     const unsigned grid = (unsigned)(n_tiles < max_blocks ? n_tiles : max_blocks);
