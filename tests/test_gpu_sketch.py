@@ -145,6 +145,28 @@ def test_long_kmers_palindromes_and_seams(sm):
         assert ordered == [h or 0 for h in oracle.seq_to_hashes(s[:9000], k, force=True, bad_kmers_as_zeroes=True)], k
 
 
+def test_long_kmers_random_cases(sm):
+    "forty random (k, length, alphabet, scaled) cases above the unrolled kernel's range: kept hashes and per-position hashes vs the oracle"
+    rng = np.random.default_rng(81)
+    for case in range(40):
+        k = int(rng.integers(89, 420))
+        n = int(rng.integers(k, 12_000))
+        alphabet = (b"ACGT", b"ACGTacgt", b"ACGTN", b"ACGTacgtRY\n")[case % 4]
+        weights = None if case % 4 < 2 else [0.97 / 4] * 4 + [0.03 / (len(alphabet) - 4)] * (len(alphabet) - 4) if len(alphabet) == 5 else None
+        s = bytes(rng.choice(np.frombuffer(alphabet, dtype=np.uint8), size=n, p=weights))
+        if case % 4 == 3:                                        # rare bad bytes instead of the uniform draw
+            b = bytearray(_rand_dna(rng, n, b"ACGTacgt"))
+            for i in rng.integers(0, n, size=max(1, n // 900)):
+                b[int(i)] = alphabet[int(rng.integers(8, len(alphabet)))]
+            s = bytes(b)
+        scaled = int(rng.choice([1, 2, 7, 50]))
+        mh = sm.MinHash(0, k, scaled=scaled)
+        mh.add_sequence_buffer(s)
+        assert np.array_equal(mh._mins_array(), oracle.sketch_dna_bulk(s, k, scaled=scaled, nthreads=2)), (case, k, n, scaled)
+        ordered = mh.seq_to_hashes(s.decode("latin-1"), force=True, bad_kmers_as_zeroes=True)
+        assert ordered == [h or 0 for h in oracle.seq_to_hashes(s, k, force=True, bad_kmers_as_zeroes=True)], (case, k, n)
+
+
 def test_long_kmers_every_hash_kept(sm):
     "scaled = 1 and bottom-k sketches at k > 88: a stretch keeps more hashes than the kernel's LDS buffer holds (the spill path)"
     rng = np.random.default_rng(80)
