@@ -837,11 +837,13 @@ def test_abundance_join_and_walk_agree_on_ragged_collections(sm):
     """The abundance sums come from joins of per-block hash-sorted lists (csrc/abund_pairs.hip) -- or, for collections of 2^32 elements
     and with SMG_COMPARE_ABUND=walk, from the per-pair walk (csrc/compare_ext.hip).  Both against the oracle on a collection with
     empty sketches, one-hash sketches, a sketch holding every hash of the pool, duplicates, more sketches than one 64-sketch block
-    and not a multiple of it; every hash-slice count the join can be cut into (SMG_ABUND_SLICES)."""
+    and not a multiple of it, and on one with a core of hashes held by EVERY sketch (runs of exactly 64 entries per block, cut by
+    the 4,096-entry staging area; 64-bit abundances whose products wrap); every hash-slice count the join can be cut into
+    (SMG_ABUND_SLICES)."""
     import os, subprocess, sys
     from conftest import ROOT
     code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
-            "import test_gpu_compare as t\nt._abundance_ragged()\nprint('ok')\n" % (ROOT, os.path.join(ROOT, "tests")))
+            "import test_gpu_compare as t\nt._abundance_ragged()\nt._abundance_core()\nprint('ok')\n" % (ROOT, os.path.join(ROOT, "tests")))
     for extra in ({}, {"SMG_COMPARE_ABUND": "walk"}, {"SMG_ABUND_SLICES": "1"}, {"SMG_ABUND_SLICES": "3"}, {"SMG_ABUND_SLICES": "16"}):
         p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, **extra))
         assert p.returncode == 0 and p.stdout.strip().endswith("ok"), (extra, p.stdout[-1500:], p.stderr[-1500:])
@@ -867,6 +869,29 @@ def _abundance_ragged():
         mh = sm.MinHash(0, 31, scaled=1, track_abundance=True)
         if len(a):
             mh.set_abundances(dict(zip(a.tolist(), ab.tolist())))
+        mhs.append(mh)
+        omhs.append(_oracle_sketch(a, scaled=1, abunds=ab))
+    want = oracle.similarity_matrix(omhs, ignore_abundance=False, nthreads=oracle.usable_cpus())
+    got = angular_matrix(mhs)
+    assert np.array_equal(got.view(np.uint64), want.view(np.uint64))
+
+
+def _abundance_core():
+    import torch  # noqa: F401
+    import sourmash_amd as sm
+    from sourmash_amd.compare import angular_matrix
+    rng = np.random.default_rng(32)
+    core = np.unique(rng.integers(1, 2**63, size=300, dtype=np.uint64))
+    pool = np.unique(rng.integers(1, 2**63, size=5000, dtype=np.uint64))
+    mhs, omhs = [], []
+    for i in range(130):                                           # two full blocks and one of two sketches
+        a = np.unique(np.concatenate([core, rng.choice(pool, size=500, replace=False)]))
+        if i % 3 == 0:                                             # products and sums that wrap 2^64 (minhash.rs:635-680, release build)
+            ab = (a | np.uint64(1)) * np.uint64(0x9E3779B97F4A7C15) | np.uint64(1)
+        else:
+            ab = (a % np.uint64(1000)) + np.uint64(1)
+        mh = sm.MinHash(0, 31, scaled=1, track_abundance=True)
+        mh.set_abundances(dict(zip(a.tolist(), ab.tolist())))
         mhs.append(mh)
         omhs.append(_oracle_sketch(a, scaled=1, abunds=ab))
     want = oracle.similarity_matrix(omhs, ignore_abundance=False, nthreads=oracle.usable_cpus())
