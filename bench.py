@@ -330,7 +330,7 @@ def main():
         except Exception as e:
             extra["protein_error"] = repr(e)
         try:
-            ksize_extras(extra, torch, np, dev, smd)
+            ksize_extras(extra, torch, np, dev, smd, args)
         except Exception as e:
             extra["ksize_error"] = repr(e)
         torch.cuda.empty_cache()
@@ -1077,11 +1077,12 @@ def api_extras(extra, torch, np, dev, smd, synth_sketches, synth_gather_device):
         "same_rounds_as_the_resident_path": None if "rounds" not in r else bool(r["rounds"] == len(res)), "objects_s": round(objects_s, 1)}
 
 
-def ksize_extras(extra, torch, np, dev, smd):
+def ksize_extras(extra, torch, np, dev, smd, args):
     """The sketch step at other ksizes (signature.rs:246-306 treats every k alike): kernel + sort + unique on 10^9 resident bases,
-    scaled = 1000 -- the unrolled register-window kernel to k = 88, the run-time-k kernel of sketch_words.hip beyond -- each checked
-    against the oracle on a sample of the same input."""
-    import oracle
+    scaled = 1000 -- the unrolled register-window kernel to k = 88, the run-time-k kernel of sketch_words.hip beyond -- with the CPU
+    restatement timed beside each on a bounded sample of the same input (and the GPU's hashes of that sample compared with its)."""
+    if not args.no_cpu_baseline:
+        import oracle
     n = 1_000_000_000
     seq = smd.synth_dna(n, seed=44, record_len=10_000_000, device=dev)
     sample = 400_000
@@ -1089,8 +1090,14 @@ def ksize_extras(extra, torch, np, dev, smd):
     out = {}
     for k in (21, 51, 88, 89, 128, 200, 256, 1000):
         sk = smd.DeviceSketcher(k, 1000)
-        got = np.sort(sk.sketch(seq[:sample]).cpu().numpy().view(np.uint64))
-        want = oracle.sketch_dna_bulk(host, k, scaled=1000, nthreads=4)
+        cpu_port = None
+        if not args.no_cpu_baseline:
+            got = np.sort(sk.sketch(seq[:sample]).cpu().numpy().view(np.uint64))
+            t0 = time.perf_counter()
+            want = oracle.sketch_dna_bulk(host, k, scaled=1000, nthreads=4)  # the CPU restatement on a bounded sample: timed, and the checker
+            cpu_s = time.perf_counter() - t0
+            cpu_port = {"sample_bases": sample, "seconds": round(cpu_s, 3), "threads": 4, "Mbase_per_s": round(sample / cpu_s / 1e6, 1),
+                        "gpu_matches_oracle_on_sample": bool(np.array_equal(got, want))}
         sk.sketch(seq)
         torch.cuda.synchronize()
         evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(3)]
@@ -1103,7 +1110,7 @@ def ksize_extras(extra, torch, np, dev, smd):
         blocks = k // 16 + (1 if k % 16 else 0)
         out["k%d" % k] = {"ms": round(ms, 3), "Gbase_per_s": round(n / (ms * 1e-3) / 1e9, 1), "hashes": int(h.numel()),
                           "kernel": "register window (unrolled)" if k <= 88 else "run-time k (sketch_words.hip)",
-                          "gpu_matches_oracle_on_sample": bool(np.array_equal(got, want)),
+                          "cpu_port": cpu_port,
                           "roofline": hbm_roofline(n + 8 * int(h.numel()), ms, "1 B per base + 8 B per kept hash; whole step (kernel + sort + unique); "
                                                    "the kernels are bound by instruction issue: MurmurHash3 is 4 64-bit multiplies per 16-byte "
                                                    "block of the key, %d blocks at this k" % blocks)}
