@@ -56,8 +56,13 @@ class _Views:
         self.ksize_raw, self.hf, self.seed, self.max_hash, self.num = p[:, 0], p[:, 1], p[:, 2], p[:, 3], p[:, 4]
         self.abund = p[:, 5] != 0
         self.size = p[:, 6].astype(np.int64)
-        per = {int(m): (_get_scaled_for_max_hash(int(m)) if m else 0) for m in np.unique(self.max_hash)}
-        self.scaled = np.array([per[int(m)] for m in self.max_hash], dtype=np.int64)
+        self.one_max_hash = bool(self.n == 0 or (self.max_hash == self.max_hash[0]).all())
+        if self.n and self.one_max_hash:                             # the usual list: one scaled value
+            m0 = int(self.max_hash[0])
+            self.scaled = np.full(self.n, _get_scaled_for_max_hash(m0) if m0 else 0, dtype=np.int64)
+        else:
+            per = {int(m): (_get_scaled_for_max_hash(int(m)) if m else 0) for m in np.unique(self.max_hash)}
+            self.scaled = np.array([per[int(m)] for m in self.max_hash], dtype=np.int64)
 
     @property
     def ksize(self):
@@ -194,13 +199,13 @@ def _batchable(v, downsample):
     in the reference's loop, and the caller lets that very pair raise."""
     if v.n == 0:
         return True
-    if len(np.unique(v.params[:, :3], axis=0)) > 1:
+    if (v.params[:, :3] != v.params[0, :3]).any():                 # (comparisons, not np.unique: a sort of 10,000 rows is milliseconds)
         return False
     if (v.num != 0).all():
         return True
     if (v.num != 0).any() or (v.max_hash == 0).any():
         return False
-    return downsample or len(np.unique(v.max_hash)) == 1
+    return downsample or v.one_max_hash
 
 
 def _by_scaled(mhs, downsample, block):
@@ -254,7 +259,7 @@ def _by_scaled_counts(v, block):
     -> f64 [m][m] is called once per scaled value of the list with the sketches that are as fine or finer, their sizes AT
     that value, and the counts of the pairs whose coarser scaled it is (0 elsewhere); the entries of those pairs are kept."""
     n = v.n
-    if len(np.unique(v.max_hash)) == 1:
+    if v.one_max_hash:
         return block(_common_ptrs(v.ptrs, n, want_jaccard=False)[0], v.size, int(v.scaled[0]))
     common, scaleds, sizes_at, class_of = _mixed_common(v)
     out = np.ones((n, n), dtype=np.float64)
@@ -284,7 +289,7 @@ def _jaccard_matrix(v, downsample):
     "Jaccard of every pair: bottom-k -> one launch; one scaled value -> one launch incl. the f64 matrix; several -> counts + arithmetic"
     if (v.num != 0).all():
         return _num_ptrs(v.ptrs, v.n)
-    if len(np.unique(v.max_hash)) == 1:
+    if v.one_max_hash:
         return _common_ptrs(v.ptrs, v.n, want_jaccard=True, want_common=False)[1]
     assert downsample
     return _by_scaled_counts(v, lambda cm, sz, s: _jaccard_from_counts(cm, sz))
@@ -292,7 +297,7 @@ def _jaccard_matrix(v, downsample):
 
 def _angular(v, downsample):
     "abundance-weighted similarity of every pair (all sketches track abundance)"
-    if (v.num != 0).all() or len(np.unique(v.max_hash)) == 1:
+    if (v.num != 0).all() or v.one_max_hash:
         return _angular_ptrs(v.ptrs, v.n)
     return _by_scaled(v.minhashes(), downsample, lambda sub, s: angular_matrix(sub))     # several scaled values: host objects
 
@@ -493,7 +498,7 @@ def _containment(siglist, downsample, mode, return_ani):
         return _containment_pairs(siglist, downsample, mode, return_ani)      # some pair raises: from the same pair as the reference's loop
     ksize = v.ksize
     if not return_ani:
-        if len(np.unique(v.max_hash)) == 1:
+        if v.one_max_hash:
             return _by_scaled_counts(v, lambda cm, sz, s: _containment_block(cm, sz, s, ksize, mode, False))
         return _containment_mixed(v, mode)
     # ANI: both sketches are downsampled to the pair's coarser scaled first, then everything is computed there
