@@ -12,6 +12,7 @@
 // Callers hold the device context's lock (device_ctx.hpp), which serialises the use of the ring.
 #pragma once
 #include <hip/hip_runtime_api.h>
+#include <emmintrin.h>
 #include <sched.h>
 #include <sys/mman.h>
 #include <stdint.h>
@@ -131,6 +132,21 @@ class HostXfer {
         if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
         return a.type == hipMemoryTypeHost;
     }
+    // memcpy whose stores bypass the caches (SSE2 streaming stores, 16-byte aligned middle): the destination is a pinned slot the copy
+    // engine reads next -- nothing on the host reads it again (SMG_XFER_STREAM=0: plain memcpy)
+    static void copy_streaming(char* dst, const char* src, size_t n) {
+        static const bool on = [] { const char* e = getenv("SMG_XFER_STREAM"); return !(e && *e == '0'); }();
+        if (!on || n < 256) { memcpy(dst, src, n); return; }
+        const size_t head = (16 - ((uintptr_t)dst & 15)) & 15;
+        memcpy(dst, src, head);
+        dst += head; src += head; n -= head;
+        const size_t blocks = n / 16;
+        for (size_t i = 0; i < blocks; ++i) {
+            __m128i v = _mm_loadu_si128(reinterpret_cast<const __m128i*>(src) + i);
+            _mm_stream_si128(reinterpret_cast<__m128i*>(dst) + i, v);
+        }
+        memcpy(dst + blocks * 16, src + blocks * 16, n - blocks * 16);
+    }
     // bytes [off, off + len) of the packed buffer, gathered from the pieces, by the worker threads (each takes a byte range)
     static void fill(char* dst, const std::vector<HostPiece>& pieces, size_t first, size_t off, size_t len) {
         auto part = [&](size_t lo, size_t hi) {                          // chunk-relative byte range
@@ -138,8 +154,9 @@ class HostXfer {
             while (i < pieces.size() && pieces[i].dst_off + pieces[i].bytes <= off + lo) ++i;
             for (; i < pieces.size() && pieces[i].dst_off < off + hi; ++i) {
                 const size_t a = std::max(pieces[i].dst_off, off + lo), b = std::min(pieces[i].dst_off + pieces[i].bytes, off + hi);
-                if (b > a) memcpy(dst + (a - off), static_cast<const char*>(pieces[i].src) + (a - pieces[i].dst_off), b - a);
+                if (b > a) copy_streaming(dst + (a - off), static_cast<const char*>(pieces[i].src) + (a - pieces[i].dst_off), b - a);
             }
+            _mm_sfence();                                               // the streamed lines are on their way before the copy engine is told
         };
         run(len, part);
     }
