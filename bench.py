@@ -2,16 +2,17 @@
 """bench.py -- headline benchmark of the MI355X FracMinHash engine.
 
 Metric (BASELINE.json): Gbase/s sketched, k=31, scaled=1000, DNA, seed 42.
-Workload (BASELINE.json configs[1], "C2"): 10 GB of synthetic random DNA per GPU,
-1,000 records of 10^7 bases, generated directly in HBM; one
+Workload (BASELINE.json configs[1], "C2"): 10^10 bases of synthetic random DNA per GPU,
+exactly 1,000 records of 10^7 bases (10,000,001,000 bytes with their separators),
+generated directly in HBM; one
 "step" = one full pass of the hot path over that resident batch: the k-mer kernel
 (canonicalise + MurmurHash3 + keep h <= max_hash), the device radix sort and the
 unique pass, leaving the sorted unique hash vector (the sketch) in HBM.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--bases B]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--records R] [--record-len L]
 
 N > 1 is launched by the driver with torch.distributed.run.  Every rank sketches
-its own 10 GB slice of the stream (weak scaling); value = (bases sketched by all
+its own 1,000-record slice of the stream (weak scaling); value = (bases sketched by all
 ranks) / (max over ranks of the elapsed time).  After the timed region the ranks
 also run the two multi-GPU configurations of BASELINE.json through
 sourmash_amd.parallel (the same code at every N; N = 1 takes the same functions,
@@ -20,11 +21,13 @@ SMG_BENCH_FORCE_COLLECTIVES=1 makes a single rank issue the collectives too):
     extra.gather_c5_dist    10^6-hash query vs 100,000 sketches sharded 100,000 / N per rank,
                             one all-gather of candidate rows per batch of rounds
 
-Prints ONE JSON line on rank 0 with the contract fields plus
+Prints ONE JSON line of at most 8 KB on rank 0 (finalize_line) with the contract fields plus
   roofline:     HBM roofline of the dominant kernel (algorithmic bytes / measured kernel time)
   cpu_baseline: the oracle (CPU restatement of the reference algorithm) on bounded samples,
                 one thread and as many threads as this container may run (N = 1 only)
-  extra:        secondary metrics, each with its own roofline object
+  summary:      the headline figure of every secondary metric
+The secondary metrics in full (`extra`, each with its own roofline object, ~25 KB) go to
+gpurun_out/bench_extra.json and to stderr as one `BENCH_EXTRA {...}` line (write_extras).
 """
 import argparse
 import json
@@ -54,13 +57,14 @@ def _newest(*names):
     return names[-1]
 
 
-PMC_FILE = _newest("profiles/r05_pmc.txt", "profiles/r04_pmc.txt", "profiles/r03_pmc.txt")
-PMC_GATHER_FILE = _newest("profiles/r05_gather_pmc.txt", "profiles/r04_gather_pmc.txt", "profiles/r03_gather_pmc.txt")
+PMC_FILE = _newest("profiles/r06_pmc.txt", "profiles/r05_pmc.txt", "profiles/r04_pmc.txt", "profiles/r03_pmc.txt")
+PMC_GATHER_FILE = _newest("profiles/r06_gather_pmc.txt", "profiles/r05_gather_pmc.txt", "profiles/r04_gather_pmc.txt", "profiles/r03_gather_pmc.txt")
 PMC_COMPARE_FILE = _newest("profiles/r04_compare_pmc.txt", "profiles/r03_compare_pmc.txt")
 COMPARE_BITS_SOURCES = ["bitindex.hip"]
 SKETCH_SOURCES = ["sketch.hip", "sketch_kernel.hpp", "kmer_core.hpp", "murmur3.hpp"]
 GATHER_SOURCES = ["gather.hip", "overlap.hip", "gather_parts.hpp", "qindex.hpp"]
-PMC_C2_INPUT_BYTES = 9_990_000_999                        # the launch the sketch counters were taken on (default C2 batch)
+# the launch the sketch counters were taken on: the default C2 batch of the round that took them (round 6: the literal 1,000 records)
+PMC_C2_INPUT_BYTES = 10_000_001_000 if "r06" in PMC_FILE else 9_990_000_999
 N_SIMDS = 1024
 
 
@@ -69,8 +73,9 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--bases", type=float, default=1e10, help="bases per GPU (default: the 10 GB of config C2)")
-    ap.add_argument("--record-len", type=int, default=10_000_000)
+    ap.add_argument("--records", type=int, default=1000, help="records per GPU (default: the 1,000 records of config C2, SURVEY.md 8d)")
+    ap.add_argument("--record-len", type=int, default=10_000_000, help="bases per record (default 10^7: 1,000 of them = the 10^10 bases of C2)")
+    ap.add_argument("--bases", type=float, default=0.0, help="bases per GPU when not a whole number of default records (0 = --records x --record-len)")
     ap.add_argument("--ksize", type=int, default=31)
     ap.add_argument("--scaled", type=int, default=1000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -143,11 +148,15 @@ def main():
     gc.freeze()
     gc.disable()
 
-    n_bases = int(args.bases)
     rec = args.record_len
-    # per-rank slice of one global stream, aligned to whole records (record = rec bases + 1 separator)
+    # per-rank slice of one global stream, aligned to whole records (record = rec bases + 1 separator).  Default = the literal C2 of
+    # 1,000 records of 10^7 bases = 10^10 bases = 10,000,001,000 bytes with their separators.
     stride = rec + 1
-    n_bytes = (n_bases // stride) * stride if n_bases >= stride else n_bases
+    if args.bases:
+        n_bases = int(args.bases)
+        n_bytes = (n_bases // stride) * stride if n_bases >= stride else n_bases
+    else:
+        n_bytes = args.records * stride
     start = rank * n_bytes
     seq = smd.synth_dna(n_bytes, seed=42, record_len=rec, start=start, device=dev)
     torch.cuda.synchronize()
@@ -228,22 +237,25 @@ def main():
     extra = {}
 
     def build_line():
+        """the ONE stdout line: contract fields + roofline + cpu_baseline + summary, at most LINE_LIMIT bytes (finalize_line); the
+        secondary metrics themselves (`extra`, ~25 KB) go to a side file and to stderr (write_extras)"""
         return {
             "metric": "Gbase/s sketched (k=31, scaled=1000)", "value": round(value, 3), "unit": "Gbase/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-            "config": {"workload": "C2: sketch 10 GB synthetic random-DNA per GPU (%d whole records of %d bases = %d bytes with their "
-                                   "separators: what fits 10^10 bytes; ASCII resident in HBM), k=%d scaled=%d seed=42; kernel + radix sort + unique"
-                                   % (n_bytes // stride if n_bytes >= stride else 1, rec, n_bytes, args.ksize, args.scaled),
+            "config": {"workload": "C2: sketch synthetic random DNA resident in HBM as ASCII, per GPU %d records of %d bases (%d bases, %d bytes "
+                                   "with their separators), k=%d scaled=%d seed=42; one step = k-mer kernel + radix sort + unique"
+                                   % (n_bytes // stride if n_bytes >= stride else 1, rec, bases_per_step, n_bytes, args.ksize, args.scaled),
+                       "records_per_gpu": n_bytes // stride if n_bytes >= stride else 1, "record_len": rec,
                        "bases_per_gpu": bases_per_step, "bytes_per_gpu": n_bytes, "ksize": args.ksize,
                        "scaled": args.scaled, "unique_hashes_rank0": n_unique_local,
                        "unique_hashes_job": n_unique_total, "allgather_ms": gather_ms,
                        "collectives": coll(comm, "all-gather of the hash vectors (union)") + (" -- REHEARSAL: ranks share one GPU" if share_gpu else ""),
-                       "comm": comm},
-            "roofline": roofline, "cpu_baseline": cpu, "extra": extra,
-            # LAST: whoever keeps only the tail of this line still sees the secondary figures
+                       "comm": {k: v for k, v in comm.items() if k != "ranks"}},
+            "roofline": roofline, "cpu_baseline": cpu,
             "summary": extras_summary(extra),
+            "extra_file": EXTRA_FILE,
         }
 
     # The headline metric is measured; what follows are secondary metrics, some of them collectives among the ranks.  A rank stuck in
@@ -255,7 +267,8 @@ def main():
             if rank == 0:
                 extra["timed_out"] = ("the secondary metrics were still running after %.0f s: printed without the unfinished ones, "
                                       "every rank left through os._exit" % args.extras_timeout)
-                os.write(real_stdout, (json.dumps(build_line()) + "\n").encode())
+                write_extras(extra, comm)
+                os.write(real_stdout, (finalize_line(build_line()) + "\n").encode())
                 time.sleep(3.0)                              # the other ranks leave first: none of them sees a peer vanish
         finally:
             os._exit(0)
@@ -346,6 +359,8 @@ def main():
         extra["arena"] = {**smd.arena_stats(), "what": "the library's device arena (csrc/arena.hpp) over the whole run: driver "
                           "allocator calls, nanoseconds inside them, allocations served from cached blocks"}
     out = build_line() if rank == 0 else None
+    if rank == 0:
+        write_extras(extra, comm)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
@@ -361,7 +376,78 @@ def main():
     os.dup2(real_stdout, 1)
     os.close(real_stdout)
     if out is not None:
-        print(json.dumps(out), flush=True)
+        print(finalize_line(out), flush=True)
+
+
+LINE_LIMIT = 8000          # bytes of the stdout line: logs keep about 8 KB of tail, and a line that does not parse is no measurement
+EXTRA_FILE = "gpurun_out/bench_extra.json"
+
+
+def write_extras(extra, comm):
+    """the secondary metrics, each with its roofline object, in full: to EXTRA_FILE (relative to the repo; gpurun_out/ is what a
+    GPU box sends back) and as one `BENCH_EXTRA {...}` line on stderr -- never on stdout, which carries the one contract line"""
+    doc = {"extra": extra, "comm": comm}
+    try:
+        text = json.dumps(_strict(doc))
+    except Exception as e:                                  # noqa: BLE001
+        text = json.dumps({"error": "extras not serialisable: %r" % (e,)})
+    try:
+        path = os.path.join(ROOT, EXTRA_FILE)
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "w") as f:
+            f.write(text + "\n")
+    except OSError as e:
+        print("bench.py: could not write %s: %r" % (EXTRA_FILE, e), file=sys.stderr)
+    print("BENCH_EXTRA " + text, file=sys.stderr, flush=True)
+
+
+def _strict(v):
+    "the same value with NaN / +-Infinity turned into null (strict JSON) and numpy scalars into Python numbers"
+    if isinstance(v, dict):
+        return {str(k): _strict(x) for k, x in v.items()}
+    if isinstance(v, (list, tuple)):
+        return [_strict(x) for x in v]
+    if isinstance(v, bool) or v is None or isinstance(v, (int, str)):
+        return v
+    if isinstance(v, float):
+        return v if v == v and v not in (float("inf"), float("-inf")) else None
+    if hasattr(v, "item"):
+        return _strict(v.item())
+    return str(v)
+
+
+# what finalize_line drops, in this order, while the line is over the limit: prose first, detail next, never a contract field
+_SHED = [("roofline", "traffic_from"), ("roofline", "valu", "mix_from"), ("roofline", "valu", "from"), ("cpu_baseline", "note"),
+         ("roofline", "note"), ("cpu_baseline", "gather_200k_vs_5000"), ("cpu_baseline", "compare_c3"), ("cpu_baseline", "sketch"),
+         ("config", "comm"), ("summary", "sketch_Gbase_per_s_by_k"), ("summary", "dist_compare_c4_collective"),
+         ("summary", "dist_gather_c5_collective"), ("roofline", "valu"), ("config", "collectives"), ("summary",)]
+REQUIRED_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                 "dtype", "data", "config", "roofline", "cpu_baseline")
+
+
+def finalize_line(out, limit=LINE_LIMIT):
+    """`out` as ONE line of strict JSON of at most `limit` bytes.  Nothing is dropped when it fits (it does: ~5 KB); otherwise the
+    entries of _SHED leave one by one and `shed` names them.  tests/test_bench_line_cpu.py pins the size, the strictness and the keys."""
+    out = _strict(out)
+    missing = [k for k in REQUIRED_KEYS if k not in out]
+    if missing:
+        raise ValueError("bench line lacks %s" % missing)
+    line = json.dumps(out, allow_nan=False, separators=(",", ":"))
+    shed = []
+    for path in _SHED:
+        if len(line.encode()) <= limit:
+            break
+        d = out
+        for k in path[:-1]:
+            d = d.get(k) if isinstance(d, dict) else None
+        if isinstance(d, dict) and path[-1] in d:
+            del d[path[-1]]
+            shed.append(".".join(path))
+            out["shed"] = shed
+            line = json.dumps(out, allow_nan=False, separators=(",", ":"))
+    if len(line.encode()) > limit:
+        raise ValueError("bench line is %d bytes after shedding %s" % (len(line.encode()), shed))
+    return line
 
 
 GIVING_UP = threading.Event()      # set by the watchdog of main(): from then on an exception means a peer has left, not a failure
