@@ -265,6 +265,13 @@ uint64_t smgpu_sketch_dna_raw(const uint8_t *d_seq, uint64_t len, uint32_t ksize
  * count to *d_count (device u64, caller zeroes).  Fully asynchronous. */
 void smgpu_sketch_dna_kernel_raw(const uint8_t *d_seq, uint64_t len, uint32_t ksize, uint64_t seed, uint64_t max_hash,
                                  uint64_t *d_out, uint64_t out_capacity, uint64_t *d_count, void *stream);
+/* Union of hash vectors on the device (the `merge` of flat scaled sketches, src/core/src/sketch/minhash.rs:432-516, for
+ * vectors already in HBM -- e.g. the all-gathered per-rank sketches): d_keys[0, n) in any order, duplicates allowed ->
+ * the sorted distinct values in d_out[0, m) (capacity n); *d_n_out (device u64) = m.  d_keys is used as scratch.  The
+ * workspace is smgpu_sketch_workspace_bytes(n) bytes.  Radix sort + run-length encode (csrc/device_sort.hip).
+ * Synchronises the stream once.  Returns m, or UINT64_MAX with an error set. */
+uint64_t smgpu_sort_unique_raw(uint64_t *d_keys, uint64_t n, uint64_t *d_out, uint64_t *d_n_out, void *d_workspace,
+                               uint64_t workspace_bytes, void *stream);
 /* The kernels of protein / dayhoff / hp sketches on device-resident input (src/core/src/signature.rs:307-393,
  * src/core/src/encodings.rs:103-368): the residues of a protein sequence -- or, translate = true, the six-frame translation of
  * DNA -- go to d_aa (capacity aa_capacity bytes; translated DNA needs 2 * len + 6), every window of k_aa residues is hashed and

@@ -342,13 +342,14 @@ hipError_t abund_pairs_launch(const uint64_t* d_hashes, const uint64_t* d_abunds
     uint32_t Z = 1;
     while (Z < (uint32_t)AP_ZMAX && tiles * Z < 1024) Z *= 2;          // (C3, 136 tiles: 3.16 / 2.94 / 2.60 / 2.45 / 2.55 ms at 1 / 2 / 4 / 8 / 16 slices)
     if (z_env >= 1 && z_env <= (uint32_t)AP_ZMAX) Z = z_env;
-    static int attr = 0;
-    if (attr == 0) {
+    // (initialised once, whichever host thread comes first: a function-local static's initialiser is serialised by the language)
+    static const int attr = [] {
         const hipError_t ea = hipFuncSetAttribute((const void*)ap_join_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)AP_LDS);
         const hipError_t eb = hipFuncSetAttribute((const void*)ap_join_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)AP_LDS);
-        attr = ea == hipSuccess && eb == hipSuccess ? 1 : -1;
-        if (attr < 0) (void)hipGetLastError();
-    }
+        if (ea == hipSuccess && eb == hipSuccess) return 1;
+        (void)hipGetLastError();
+        return -1;
+    }();
     if (attr < 0) return hipErrorNotSupported;
     if (narrow)
         hipLaunchKernelGGL((ap_join_kernel<true>), dim3((unsigned)(tiles * Z)), dim3(AP_THREADS), AP_LDS, stream, (const uint64_t*)lh_b.as<uint64_t>(),

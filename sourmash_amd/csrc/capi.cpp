@@ -823,6 +823,20 @@ uint64_t smgpu_sketch_dna_raw(const uint8_t* d_seq, uint64_t len, uint32_t ksize
     return ret;
 }
 
+uint64_t smgpu_sort_unique_raw(uint64_t* d_keys, uint64_t n, uint64_t* d_out, uint64_t* d_n_out, void* d_ws, uint64_t ws_bytes, void* stream) {
+    uint64_t ret = ~0ull;
+    landing_void([&] {
+        hipStream_t st = (hipStream_t)stream;
+        if (ws_bytes < sort_unique_temp_bytes(n)) throw err_internal("workspace too small (smgpu_sketch_workspace_bytes)");
+        hip_check(sort_unique(d_keys, n, d_out, nullptr, d_n_out, d_ws, (size_t)ws_bytes, 64, st), "sort_unique");
+        unsigned long long nu = 0;
+        hip_check(hipMemcpyAsync(&nu, d_n_out, 8, hipMemcpyDeviceToHost, st), "D2H");
+        hip_check(hipStreamSynchronize(st), "sync");
+        ret = nu;
+    });
+    return ret;
+}
+
 void smgpu_sketch_dna_kernel_raw(const uint8_t* d_seq, uint64_t len, uint32_t ksize, uint64_t seed, uint64_t max_hash,
                                  uint64_t* d_out, uint64_t cap, uint64_t* d_count, void* stream) {
     landing_void([&] {

@@ -2079,12 +2079,13 @@ hipError_t gather_launch_loop(GatherDev& g, hipStream_t stream, uint32_t n_wg, c
     a.offsets = g.offsets; a.qpos = g.qpos; a.post_rows = g.post_rows; a.block_pre = g.block_pre; a.post_off = g.post_off;
     a.counters = g.counters; a.alive = g.alive; a.state = g.state; a.out_idx = g.out_idx; a.out_isect = g.out_isect;
     a.ndb = g.ndb; a.nq = g.nq; a.index_base = g.index_base;
-    static int attr_state = 0;                                     // 1: set, -1: the runtime refused (no persistent loop)
-    if (attr_state == 0) {
+    // 1: set, -1: the runtime refused (no persistent loop); once, thread-safe (function-local static initialiser)
+    static const int attr_state = [&] {
         const hipError_t e = hipFuncSetAttribute((const void*)gather_loop_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)budget);
-        attr_state = e == hipSuccess ? 1 : -1;
-        if (e != hipSuccess) (void)hipGetLastError();
-    }
+        if (e == hipSuccess) return 1;
+        (void)hipGetLastError();
+        return -1;
+    }();
     if (attr_state < 0) return hipSuccess;
     // local exchange memory: [2][n_wg][4] workgroup records, 16 trace words, [2][4] global winner, 8 gate words, [2][rowcap] staged row
     const uint64_t rowcap = sh ? sh->rowcap : 0;

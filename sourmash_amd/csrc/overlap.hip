@@ -562,12 +562,12 @@ hipError_t build_stage_launch(const uint64_t* Q, uint64_t nq, const uint32_t* T,
                               const uint64_t* offsets, uint64_t ndb, uint32_t rows_per_wg, uint32_t n_ranges, const void* desc,
                               unsigned long long* counters, uint32_t* qpos, uint32_t* inter, uint32_t* dir_start, uint32_t* dir_len,
                               unsigned int* misc, hipStream_t stream) {
-    static int attr = 0;
-    if (attr == 0) {
+    static const int attr = [] {                                   // once, thread-safe (function-local static initialiser)
         const hipError_t ea = hipFuncSetAttribute((const void*)overlap_lean_kernel<OwStage, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LEAN_STAGE_LDS);
-        attr = ea == hipSuccess ? 1 : -1;
-        if (attr < 0) (void)hipGetLastError();
-    }
+        if (ea == hipSuccess) return 1;
+        (void)hipGetLastError();
+        return -1;
+    }();
     if (attr < 0) return hipErrorInvalidValue;
     const uint64_t n_sub = (ndb + rows_per_wg - 1) / rows_per_wg;
     StageArgs sa;
@@ -640,13 +640,13 @@ hipError_t overlap_ranges_launch(const uint64_t* Q, uint64_t nq, const uint64_t*
     SMG_TRY(hipMemcpyAsync(&pin.p[1], d_widest, 8, hipMemcpyDeviceToHost, stream));
     SMG_TRY(hipStreamSynchronize(stream));
     const unsigned int widest = (unsigned int)(pin.p[1] & 0xffffffffull), l_widest = (unsigned int)(pin.p[1] >> 32);
-    static int lean_attr = 0;
     constexpr size_t LEAN_LDS = ((size_t)OwLean::QCAP + 2) * 8 + OwLean::T_BYTES;
-    if (lean_attr == 0) {
+    static const int lean_attr = [] {                              // once, thread-safe (function-local static initialiser)
         const hipError_t ea = hipFuncSetAttribute((const void*)overlap_lean_kernel<OwLean, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LEAN_LDS);
-        lean_attr = ea == hipSuccess ? 1 : -1;
-        if (lean_attr < 0) (void)hipGetLastError();
-    }
+        if (ea == hipSuccess) return 1;
+        (void)hipGetLastError();
+        return -1;
+    }();
     if (try_lean && lean_attr > 0 && l_widest > 0 && l_widest <= (unsigned)OwLean::QCAP) {
         // rows a workgroup owns: every workgroup resident at once, in full rounds (a last round of a few workgroups would cost a
         // whole pass over the query for a fraction of the rows); SMG_OVERLAP_ROWS overrides (tuning / tests)

@@ -113,6 +113,21 @@ class DeviceSketcher:
                  _ptr(out), out.numel(), _ptr(count), _stream(torch))
 
 
+def sort_unique(keys):
+    """int64 tensor of u64 bit patterns, any order, duplicates allowed -> the sorted (as unsigned) distinct values, a new
+    tensor: the library's radix sort + run-length encode (smgpu_sort_unique_raw, csrc/device_sort.hip).  `keys` is consumed."""
+    torch = _torch()
+    assert keys.dtype == torch.int64 and keys.is_cuda and keys.is_contiguous()
+    n = keys.numel()
+    out = _u64(torch, max(n, 1), keys.device)
+    if n == 0:
+        return out[:0]
+    ws = torch.empty(int(lib.smgpu_sketch_workspace_bytes(n)), dtype=torch.uint8, device=keys.device)
+    n_out = torch.zeros(1, dtype=torch.int64, device=keys.device)
+    m = rustcall(lib.smgpu_sort_unique_raw, _ptr(keys), n, _ptr(out), _ptr(n_out), _ptr(ws), ws.numel(), _stream(torch))
+    return out[:m]
+
+
 def pack_csr(sketches, device="cuda"):
     "list of sorted u64 numpy arrays -> (hashes int64 tensor, offsets int64 tensor) on device."
     import numpy as np

@@ -157,11 +157,11 @@ def open_shared_exchange(owner, make, world, rank, rowcap, group=None):
     return owner._xchg, owner._xchg_runs
 
 
-def allgather_union(local_hashes, group=None, force=False):
+def allgather_union(local_hashes, group=None, force=False, backend=None):
     """Sketching shards by records: every rank holds the sorted unique kept hashes of ITS records (int64 tensor of u64
     bit patterns); one all-gather later every rank holds the sketch of the whole input -- set union is associative,
     which is all `merge` (minhash.rs:432-516) needs for flat scaled sketches.  Two collectives: the sizes, then the
-    padded hash vectors (~L / scaled / world u64 each)."""
+    padded hash vectors (~L / scaled / world u64 each); the union itself is the library's device sort + unique."""
     dist = _dist()
     rank, world = world_info(group)
     torch = __import__("torch")
@@ -178,8 +178,10 @@ def allgather_union(local_hashes, group=None, force=False):
     parts = [torch.empty(longest, dtype=torch.int64, device=dev) for _ in range(world)]
     _all_gather(parts, pad, group)
     merged = torch.cat([p[:n] for p, n in zip(parts, sizes)])
-    flip = torch.iinfo(torch.int64).min                 # order as unsigned: flip the sign bit around the sort
-    return torch.unique(merged ^ flip) ^ flip
+    if backend is not None:                              # (tests/test_parallel_gloo.py: the protocol over host tensors with its CPU stand-in)
+        return backend.sort_unique(merged)
+    from .device import sort_unique                      # the library's own radix sort + run-length encode (csrc/device_sort.hip)
+    return sort_unique(merged)
 
 
 def tiles_for_rank(n, world, rank):

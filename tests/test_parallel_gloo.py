@@ -36,6 +36,9 @@ class OracleBackend:
         a = t.numpy().view(np.uint64)
         return a if n is None else a[:n]
 
+    def sort_unique(self, keys):
+        return torch.from_numpy(np.unique(keys.numpy().view(np.uint64)).view(np.int64))
+
     def compare_tiles(self, hashes, offsets, n, first, stride, count):
         h, off = self._u64(hashes), self._u64(offsets)
         out = np.zeros((count * parallel.TILE, n), dtype=np.uint32)
@@ -304,11 +307,11 @@ def _worker(rank, world, port, ret):
         seq = oracle.synth_dna(0, 600_000, seed=42, record_len=50_000)           # 11 records + separators
         bounds = [0, 6 * 50_001, len(seq)]                                       # whole records per rank
         mine = oracle.sketch_dna_bulk(seq[bounds[rank]:bounds[rank + 1]], 31, scaled=100)
-        union = parallel.allgather_union(torch.from_numpy(mine.view(np.int64).copy()))
+        union = parallel.allgather_union(torch.from_numpy(mine.view(np.int64).copy()), backend=be)
         whole = oracle.sketch_dna_bulk(seq, 31, scaled=100)
         ok_s = np.array_equal(union.numpy().view(np.uint64), whole)
         big = torch.tensor([5, -3, -1, 7], dtype=torch.int64) if rank == 0 else torch.tensor([-2, 5], dtype=torch.int64)
-        ordered = parallel.allgather_union(big).numpy().view(np.uint64)          # u64 order with the top bit set (scaled = 1)
+        ordered = parallel.allgather_union(big, backend=be).numpy().view(np.uint64)          # u64 order with the top bit set (scaled = 1)
         ok_s = ok_s and list(ordered) == sorted({5, 7, 2**64 - 3, 2**64 - 1, 2**64 - 2})
         ret[rank] = (bool(ok_cmp), bool(ok_g), len(res[0]), bool(ok_s), bool(ok_o))
     finally:
