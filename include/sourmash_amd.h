@@ -249,6 +249,17 @@ uint64_t smgpu_signature_add_file(SourmashSignature *ptr, const char *path, uint
 SourmashSignature **smgpu_sketch_files(const char *const *paths, uintptr_t n, const SourmashComputeParameters *params,
                                        uint32_t n_threads, uint64_t *total_bases);
 uint64_t smgpu_minhash_add_file(SourmashKmerMinHash *ptr, const char *path, uint64_t *n_records);
+/* The inflater behind the .gz ingest by itself (csrc/gunzip.hpp: the members' compressed bytes go to HBM, every deflate block of
+ * a member is decoded at once, CRC-32 and length are checked against the trailer; what niffler / screed do on one host thread,
+ * src/core/benches/compute.rs:35-38, src/sourmash/command_sketch.py:697).  n single-member gzip files, inflated in ONE batch;
+ * their bytes come back to out[0, capacity) one behind the other, lens[i] = bytes of file i or UINT64_MAX when the device refused
+ * it (several members, damaged, not gzip): such a file is the host inflater's.  stats (NULL or 16 doubles): [0] survivors of the
+ * cheap header test, [1] candidates decoded, [2] runs on the chains, [3..8] milliseconds: scan, pass 1, link, pass 2, tails +
+ * resolve + CRC, everything on the device; [9] H2D copy + file reads.  Returns the bytes written. */
+uint64_t smgpu_gunzip_files(const char *const *paths, uintptr_t n, uint8_t *out, uint64_t capacity, uint64_t *lens, double *stats);
+/* out[0]: gzip files the ingest inflated on the device since the library was loaded, out[1]: files it handed to the host inflater
+ * after the device refused them. */
+void smgpu_gunzip_counters(uint64_t *out);
 
 /* Scratch size needed by smgpu_sketch_dna_raw for an output capacity. */
 uint64_t smgpu_sketch_workspace_bytes(uint64_t out_capacity);

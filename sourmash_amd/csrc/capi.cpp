@@ -779,6 +779,66 @@ SourmashSignature** smgpu_sketch_files(const char* const* paths, uintptr_t n, co
         return sigs_out(std::move(sigs), &size);
     });
 }
+uint64_t smgpu_gunzip_files(const char* const* paths, uintptr_t n, uint8_t* out, uint64_t capacity, uint64_t* lens, double* stats) {
+    return landing<uint64_t>([&]() -> uint64_t {
+        if ((!paths || !lens) && n) throw err_internal("null paths");
+        DeviceCtx& ctx = DeviceCtx::get();
+        std::lock_guard<std::recursive_mutex> g(ctx.mutex());
+        hipStream_t st = ctx.stream();
+        const auto t0 = std::chrono::steady_clock::now();
+        std::vector<GunzipMember> ms(n);
+        std::vector<std::vector<uint8_t>> blobs(n);
+        uint64_t total = 0;
+        for (uintptr_t i = 0; i < n; ++i) {
+            FILE* f = fopen(paths[i], "rb");
+            if (!f) throw Error(E_IO, std::string("No such file or directory: ") + paths[i]);
+            fseek(f, 0, SEEK_END);
+            const long sz = ftell(f);
+            fseek(f, 0, SEEK_SET);
+            blobs[i].resize((size_t)std::max(0L, sz));
+            const size_t got = sz > 0 ? fread(blobs[i].data(), 1, (size_t)sz, f) : 0;
+            fclose(f);
+            if (got != (size_t)std::max(0L, sz)) throw Error(E_IO, std::string("short read on ") + paths[i]);
+            ms[i].file_off = total;
+            ms[i].file_len = (uint64_t)sz;
+            total += ((uint64_t)sz + 7) & ~7ull;
+        }
+        PinnedBuf host;
+        host.reserve((size_t)total + GUNZIP_PAD);
+        memset(host.p, 0, (size_t)total + GUNZIP_PAD);
+        for (uintptr_t i = 0; i < n; ++i) memcpy(host.p + ms[i].file_off, blobs[i].data(), blobs[i].size());
+        blobs.clear();
+        AsyncBuf dev((size_t)total + GUNZIP_PAD, st);
+        hip_check(hipMemcpyAsync(dev.p, host.p, (size_t)total + GUNZIP_PAD, hipMemcpyHostToDevice, st), "H2D");
+        hip_check(hipStreamSynchronize(st), "sync");
+        const double io_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        void* d_out = nullptr;
+        GunzipStats gs;
+        gunzip_device(host.p, dev.as<uint8_t>(), total, ms, &d_out, st, &gs);
+        struct FreeOut { void* p; hipStream_t st; ~FreeOut() { if (p) arena_free(p, st); } } free_out{d_out, st};
+        uint64_t at = 0;
+        for (uintptr_t i = 0; i < n; ++i) {
+            if (!ms[i].ok) { lens[i] = ~0ull; continue; }
+            if (at + ms[i].out_len > capacity) throw err_internal("smgpu_gunzip_files: output capacity too small");
+            if (ms[i].out_len)
+                hip_check(hipMemcpyAsync(out + at, (const uint8_t*)d_out + ms[i].out_off, (size_t)ms[i].out_len, hipMemcpyDeviceToHost, st), "D2H");
+            lens[i] = ms[i].out_len;
+            at += ms[i].out_len;
+        }
+        hip_check(hipStreamSynchronize(st), "sync");
+        if (stats) {
+            const double v[10] = {(double)gs.survivors, (double)gs.candidates, (double)gs.runs, gs.scan_ms, gs.pass1_ms, gs.link_ms, gs.pass2_ms,
+                                  gs.finish_ms, gs.total_ms, io_ms};
+            for (int k = 0; k < 16; ++k) stats[k] = k < 10 ? v[k] : 0.0;
+        }
+        return at;
+    });
+}
+void smgpu_gunzip_counters(uint64_t* out) {
+    if (!out) return;
+    out[0] = gunzip_counters().on_device.load();
+    out[1] = gunzip_counters().refused.load();
+}
 uint64_t smgpu_minhash_add_file(SourmashKmerMinHash* p, const char* path, uint64_t* n_records) {
     return landing<uint64_t>([&]() -> uint64_t {
         if (!path) throw err_internal("null path");

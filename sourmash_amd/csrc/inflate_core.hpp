@@ -41,11 +41,32 @@ namespace inf {
 constexpr uint32_t WIN = 32768;
 constexpr int LIT_ROOT = 10, DIST_ROOT = 8;            // direct-lookup bits of the two code tables; longer codes: canonical search
 constexpr uint16_t MARK = 0x8000;                      // symbol = MARK | m: the byte at window offset m
+constexpr uint32_t SYM_SLOW = 0x80, SYM_END = 0x40;    // flags beside a lane's symbol length (decode_run)
+constexpr uint64_t MAX_RUN_BYTES = (1ull << 30) - 1;   // of one run (the sink keeps positions in 30 bits)
+constexpr uint32_t MAX_BATCHES = 1u << 23;             // of one run: far beyond any block a compressor writes; bounds a false start
 
 // status of a decoded run
 enum : uint32_t { RUN_OK = 0, RUN_FINAL = 1, RUN_BAD_CODE = 2, RUN_BAD_BLOCK = 3, RUN_PAST_END = 4, RUN_BAD_DISTANCE = 5, RUN_TOO_LONG = 6 };
 
+// A "lane" is a lane of the wavefront on the device and a loop index on the host (tests/native/inflate_emul.cpp): per-lane
+// values are arrays of SMG_INF_LANES entries, of which a device lane owns the one.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define SMG_INF_LANES 1
+#define SMG_INF_EACH_LANE(lane, slot) const uint32_t lane = (uint32_t)(threadIdx.x & 63u); constexpr int slot = 0;
+#else
+#define SMG_INF_LANES 64
+#define SMG_INF_EACH_LANE(lane, slot) for (uint32_t lane = 0, slot = 0; lane < 64u; ++lane, ++slot)
+#endif
+SMG_HD uint32_t lane_read(const uint32_t (&v)[SMG_INF_LANES], uint32_t lane) {      // lane: the same in every lane
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint32_t)__builtin_amdgcn_readlane((int)v[0], (int)lane);
+#else
+    return v[lane];
+#endif
+}
+
 // ---- bits: aligned 32-bit words, least significant bit first (RFC 1951 3.1.1) ----
+// One lane by itself (the scan's full header test):
 struct BitReader {
     const uint32_t* w;
     uint64_t pos, end;          // next unread bit, first bit behind the member's deflate data (both from the start of w)
@@ -70,6 +91,75 @@ struct BitReader {
     SMG_HD bool past_end() const { return pos > end; }
 };
 
+// The whole wavefront on one stream (the block walk): the lanes hold the next 128 words of the stream between them (cur, nxt:
+// one coalesced load per 64 words, issued 64 words before its first use), a word reaches the scalar side by a lane read, and
+// the next 128 bits sit in (lo, hi), where every lane can look at "the bits from my lane number on" (lane_bits).
+struct WaveBits {
+    const uint32_t* w;
+    uint64_t end;               // first bit behind the member's deflate data
+    uint64_t base_word;         // the word lane 0 of cur holds
+    uint32_t r0[SMG_INF_LANES], r1[SMG_INF_LANES];   // two chunks of 64 words taking turns: one is read, the other on its way
+    uint32_t turn;              // 0: r0 is read (words base_word ..), r1 holds the 64 behind it; 1: the other way round
+    uint64_t lo, hi;
+    uint32_t cnt;               // valid bits in (lo, hi)
+    uint32_t wi;                // next word to append, as a lane of the chunk being read
+    SMG_HD void init(const uint32_t* words, uint64_t bit, uint64_t end_bit) {
+        w = words; end = end_bit;
+        base_word = bit >> 5;
+        { SMG_INF_EACH_LANE(lane, slot) { r0[slot] = w[base_word + lane]; r1[slot] = w[base_word + 64u + lane]; } }
+        lo = hi = 0; cnt = 0; wi = 0; turn = 0;
+        refill();
+        drop((uint32_t)(bit & 31u));
+        refill();
+    }
+    SMG_HD void refill() {      // afterwards 97 .. 128 bits are valid
+        while (cnt <= 96u) {
+            if (wi == 64u) {    // the chunk just read is asked to fetch the 64 words behind the other one, and they trade places
+                base_word += 64u;
+                wi = 0;
+                if (turn == 0u) { SMG_INF_EACH_LANE(lane, slot) { r0[slot] = w[base_word + 64u + lane]; } }
+                else { SMG_INF_EACH_LANE(lane, slot) { r1[slot] = w[base_word + 64u + lane]; } }
+                turn ^= 1u;
+            }
+            uint64_t x;
+            if (turn == 0u) x = lane_read(r0, wi); else x = lane_read(r1, wi);
+            ++wi;
+            if (cnt < 64u) {
+                lo |= x << cnt;
+                if (cnt > 32u) hi |= x >> (64u - cnt);
+            } else hi |= x << (cnt - 64u);
+            cnt += 32u;
+        }
+    }
+    SMG_HD uint64_t pos() const { return (base_word + wi) * 32u - cnt; }
+    SMG_HD uint32_t peek(uint32_t n) const { return (uint32_t)lo & ((1u << n) - 1u); }
+    SMG_HD void drop(uint32_t n) {                                    // n <= 127
+        if (n >= 64u) { lo = hi >> (n - 64u); hi = 0; }
+        else if (n) { lo = (lo >> n) | (hi << (64u - n)); hi >>= n; }
+        cnt -= n;
+    }
+    SMG_HD uint32_t take(uint32_t n) { const uint32_t v = peek(n); drop(n); return v; }
+    SMG_HD void to_byte() { drop((uint32_t)((8u - (pos() & 7u)) & 7u)); }
+    SMG_HD bool past_end() const { return pos() > end; }
+    // n <= 16 bits from bit `at` of the window (at + n <= cnt)
+    SMG_HD uint32_t bits_at(uint32_t at, uint32_t n) const {
+        const uint64_t v = at < 64u ? ((lo >> at) | (at ? hi << (64u - at) : 0ull)) : hi >> (at - 64u);
+        return (uint32_t)v & ((1u << n) - 1u);
+    }
+    // the 32 bits that begin at this lane's number
+    SMG_HD uint32_t lane_bits(uint32_t lane) const { return (uint32_t)((lo >> lane) | (lane ? hi << (64u - lane) : 0ull)); }
+};
+
+SMG_HD uint32_t ctz64(uint64_t m) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint32_t)__builtin_ctzll(m);
+#else
+    uint32_t n = 0;
+    while (!((m >> n) & 1u)) ++n;
+    return n;
+#endif
+}
+
 SMG_HD uint32_t bitrev15(uint32_t v) {
 #if defined(__HIP_DEVICE_COMPILE__)
     return __brev(v) >> 17;
@@ -81,64 +171,86 @@ SMG_HD uint32_t bitrev15(uint32_t v) {
 }
 
 // ---- one prefix code: direct table for codes of at most `root` bits, canonical search beyond ----
+struct CodeStore {             // per code length: how many symbols, the first canonical code, where its symbols begin in `sorted`
+    uint16_t count[16], first[16], offset[16], fill[16];
+};
+// A table entry: bits 0-3 the code's length (0: no code this short), 4-5 the kind (0 literal / plain symbol, 1 length or
+// distance, 2 end of block, 3 not a symbol of the format), 8-11 the number of extra bits, 16-31 the value (the literal, the
+// symbol, or the base of the length / distance) -- everything the block walk needs in one lookup.
+constexpr int CODE_PLAIN = 0, CODE_LITLEN = 1, CODE_DIST = 2;
+SMG_HD uint32_t len_base(uint32_t s);
+SMG_HD uint32_t len_extra(uint32_t s);
+SMG_HD uint32_t dist_base(uint32_t s);
+SMG_HD uint32_t dist_extra(uint32_t s);
+SMG_HD uint32_t symbol_entry(int what, uint32_t s) {
+    if (what == CODE_LITLEN) {
+        if (s < 256u) return s << 16;
+        if (s == 256u) return 2u << 4;
+        if (s > 285u) return 3u << 4;
+        return (len_base(s - 257u) << 16) | (len_extra(s - 257u) << 8) | (1u << 4);
+    }
+    if (what == CODE_DIST) {
+        if (s > 29u) return 3u << 4;
+        return (dist_base(s) << 16) | (dist_extra(s) << 8) | (1u << 4);
+    }
+    return s << 16;
+}
 struct Code {
-    uint16_t* table;            // 1 << root entries: symbol << 4 | length; 0 = no code this short
+    uint32_t* table;            // 1 << root entries
     uint16_t* sorted;           // symbols ordered by (length, symbol)
-    uint16_t count[16], first[16], offset[16];
+    CodeStore* st;              // (everything a decoder indexes at run time lives in the caller's scratch: LDS on the device)
 };
 
 // lens[0, n) -> code.  false: over-subscribed, or incomplete with more than one code / a code longer than one bit (the sets
 // zlib's inflate_table refuses).
-SMG_HD bool build_code(const uint8_t* lens, int n, int root, Code& c) {
-    for (int i = 0; i < 16; ++i) c.count[i] = 0;
-    for (int i = 0; i < n; ++i) c.count[lens[i]]++;
-    c.count[0] = 0;
-    int left = 1, used = 0, maxlen = 0;
+SMG_HD bool build_code(const uint8_t* lens, int n, int root, Code& c, int what) {
+    CodeStore& t = *c.st;
+    for (int i = 0; i < 16; ++i) t.count[i] = 0;
+    for (int i = 0; i < n; ++i) t.count[lens[i]]++;
+    t.count[0] = 0;
+    int left = 1, maxlen = 0;
     for (int l = 1; l <= 15; ++l) {
-        left = (left << 1) - (int)c.count[l];
+        left = (left << 1) - (int)t.count[l];
         if (left < 0) return false;
-        used += c.count[l];
-        if (c.count[l]) maxlen = l;
+        if (t.count[l]) maxlen = l;
     }
     if (left > 0 && maxlen > 1) return false;
     uint32_t code = 0, off = 0;
     for (int l = 1; l <= 15; ++l) {
-        code = (code + (l > 1 ? c.count[l - 1] : 0u)) << 1;
-        c.first[l] = (uint16_t)code;
-        c.offset[l] = (uint16_t)off;
-        off += c.count[l];
+        code = (code + (l > 1 ? t.count[l - 1] : 0u)) << 1;
+        t.first[l] = (uint16_t)code;
+        t.offset[l] = (uint16_t)off;
+        off += t.count[l];
+        t.fill[l] = 0;
     }
-    c.first[0] = c.offset[0] = 0;
+    t.first[0] = t.offset[0] = t.fill[0] = 0;
     for (int i = 0; i < (1 << root); ++i) c.table[i] = 0;
-    uint16_t fill[16];
-    for (int l = 0; l < 16; ++l) fill[l] = 0;
     for (int s = 0; s < n; ++s) {
         const int l = lens[s];
         if (!l) continue;
-        const uint32_t rank = fill[l]++;
-        c.sorted[c.offset[l] + rank] = (uint16_t)s;
+        const uint32_t rank = t.fill[l]++;
+        c.sorted[t.offset[l] + rank] = (uint16_t)s;
         if (l <= root) {
-            const uint32_t cw = c.first[l] + rank;                     // canonical code, first bit = most significant
+            const uint32_t cw = t.first[l] + rank;                     // canonical code, first bit = most significant
             uint32_t r = 0;
             for (int b = 0; b < l; ++b) r |= ((cw >> b) & 1u) << (l - 1 - b);
-            const uint16_t e = (uint16_t)((s << 4) | l);
+            const uint32_t e = symbol_entry(what, (uint32_t)s) | (uint32_t)l;
             for (uint32_t i = r; i < (1u << root); i += 1u << l) c.table[i] = e;
         }
     }
     return true;
 }
 
-// next symbol of the code (at least 15 bits in the reader); -1: no such code
-SMG_HD int decode_sym(BitReader& br, const Code& c, int root) {
-    const uint32_t v = (uint32_t)br.buf;
-    const uint32_t e = c.table[v & ((1u << root) - 1u)];
-    if (e & 15u) { br.drop(e & 15u); return (int)(e >> 4); }
+// The code whose first bits are v (15 of them), for codes longer than the table's root: -> its entry with the length in bits
+// 0-3, or 0 when there is none.
+SMG_HD uint32_t long_code(uint32_t v, const Code& c, int root, int what) {
     const uint32_t r = bitrev15(v & 0x7fffu);
+    const CodeStore& t = *c.st;
     for (int l = root + 1; l <= 15; ++l) {
-        const uint32_t d = (r >> (15 - l)) - c.first[l];
-        if (d < c.count[l]) { br.drop((uint32_t)l); return (int)c.sorted[c.offset[l] + d]; }
+        const uint32_t d = (r >> (15 - l)) - t.first[l];
+        if (d < t.count[l]) return symbol_entry(what, (uint32_t)c.sorted[t.offset[l] + d]) | (uint32_t)l;
     }
-    return -1;
+    return 0;
 }
 
 // length / distance symbol -> base value and extra bits (RFC 1951 3.2.5)
@@ -152,33 +264,45 @@ SMG_HD uint32_t dist_base(uint32_t s) {   // 0 .. 29
 SMG_HD uint32_t dist_extra(uint32_t s) { return s < 4 ? 0 : (s >> 1) - 1; }
 
 // scratch of one decoder: the tables of the two codes and the code lengths of a dynamic block (LDS on the device)
-struct Scratch {
-    uint16_t lit_table[1 << LIT_ROOT], dist_table[1 << DIST_ROOT];
+struct HeaderScratch {         // what reading a dynamic block's header needs (the scan's full test: one lane each)
+    uint32_t cl_table[128];
+    uint16_t cl_sorted[20];
+    CodeStore cl_store;
+    uint8_t lens[288 + 32 + 32];                                      // literal/length + distance code lengths; [320, 339): the code-length code's
+};
+struct Scratch : HeaderScratch {
+    uint32_t lit_table[1 << LIT_ROOT], dist_table[1 << DIST_ROOT];
     uint16_t lit_sorted[288], dist_sorted[32];
-    uint16_t cl_table[128], cl_sorted[20];
-    uint8_t lens[288 + 32 + 8];
+    CodeStore lit_store, dist_store;
 };
 
 // Code lengths of a dynamic block (RFC 1951 3.2.7): the reader stands behind the 3 header bits.  strict: the conditions a
 // SCANNED block start must meet on top of being decodable (end-of-block code present, the distance code complete, a single
 // code, or absent).  -> false: not a dynamic block header.
-SMG_HD bool read_dynamic_lengths(BitReader& br, Scratch& S, int& hlit, int& hdist, bool strict) {
+template <class Bits>
+SMG_HD bool read_dynamic_lengths(Bits& br, HeaderScratch& S, int& hlit, int& hdist, bool strict) {
     br.refill();
     hlit = (int)br.take(5) + 257;
     hdist = (int)br.take(5) + 1;
     const int hclen = (int)br.take(4) + 4;
     if (hlit > 286 || hdist > 30) return false;
-    const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
-    uint8_t cl[19];
+    // entry i of the header is the length of symbol order[i] (RFC 1951 3.2.7): 16 17 18 0 8 7 9 6 10 5 11 4 12 3 13 2 14 1 15
+    uint8_t* cl = S.lens + 320;
     for (int i = 0; i < 19; ++i) cl[i] = 0;
-    for (int i = 0; i < hclen; ++i) { br.refill(); cl[order[i]] = (uint8_t)br.take(3); }
+    for (int i = 0; i < hclen; ++i) {
+        br.refill();
+        // order[i] as arithmetic (no table in memory): i = 0, 1, 2 -> 16, 17, 18; 3 -> 0; then 8, 7, 9, 6, 10, 5, ... alternate around 8
+        const int sym = i < 3 ? 16 + i : i == 3 ? 0 : (i & 1) ? 8 - ((i - 3) >> 1) : 8 + ((i - 4) >> 1);
+        cl[sym] = (uint8_t)br.take(3);
+    }
     Code cc;
     cc.table = S.cl_table;
     cc.sorted = S.cl_sorted;
-    if (!build_code(cl, 19, 7, cc)) return false;
+    cc.st = &S.cl_store;
+    if (!build_code(cl, 19, 7, cc, CODE_PLAIN)) return false;
     if (strict) {                                                     // the code-length code itself: complete
         int left = 1;
-        for (int l = 1; l <= 7; ++l) left = (left << 1) - (int)cc.count[l];
+        for (int l = 1; l <= 7; ++l) left = (left << 1) - (int)S.cl_store.count[l];
         if (left != 0) return false;
     }
     int got = 0, prev = 0;
@@ -189,7 +313,7 @@ SMG_HD bool read_dynamic_lengths(BitReader& br, Scratch& S, int& hlit, int& hdis
         const uint32_t e = cc.table[br.peek(7)];
         if (!(e & 15u)) return false;
         br.drop(e & 15u);
-        const int sym = (int)(e >> 4);
+        const int sym = (int)(e >> 16);
         if (sym < 16) { S.lens[got++] = (uint8_t)sym; prev = sym; continue; }
         int rep, val = 0;
         if (sym == 16) { if (got == 0) return false; rep = 3 + (int)br.take(2); val = prev; }
@@ -219,26 +343,79 @@ SMG_HD bool plausible_prefix(uint64_t lo, uint64_t hi) {
 }
 
 // The full test of a candidate (the scan's second kernel; one lane each): code lengths readable, the literal/length code
-// complete, the distance code complete -- or one code, or none.  words: the whole buffer; end_bit: its last bit.
-SMG_HD bool valid_dynamic_header(const uint32_t* words, uint64_t bit, uint64_t end_bit, Scratch& S) {
+// complete with an end-of-block code, the distance code complete -- or one code, or none.  Written to live in registers: the
+// code-length code's 19 lengths are a packed word, the two big codes are judged by their Kraft sums as their lengths go by,
+// and the only table is the 128-entry decoder of the code-length code, reached through `tab` (Tab: get(i) / set(i, v) on 128
+// bytes -- a plain array on the host, a lane's column of an LDS tile on the device).
+struct PlainTab {
+    uint8_t t[128];
+    SMG_HD uint32_t get(uint32_t i) const { return t[i]; }
+    SMG_HD void set(uint32_t i, uint32_t v) { t[i] = (uint8_t)v; }
+};
+template <class Tab>
+SMG_HD bool valid_dynamic_header(const uint32_t* words, uint64_t bit, uint64_t end_bit, Tab& tab) {
     BitReader br;
     br.init(words, bit, end_bit);
     if (br.take(3) != 4u) return false;
-    int hlit, hdist;
-    if (!read_dynamic_lengths(br, S, hlit, hdist, true)) return false;
-    if (br.past_end()) return false;
-    int left = 1;
-    uint32_t cnt[16];
-    for (int i = 0; i < 16; ++i) cnt[i] = 0;
-    for (int i = 0; i < hlit; ++i) cnt[S.lens[i]]++;
-    for (int l = 1; l <= 15; ++l) { left = (left << 1) - (int)cnt[l]; if (left < 0) return false; }
-    if (left != 0) return false;
-    for (int i = 0; i < 16; ++i) cnt[i] = 0;
-    int used = 0;
-    for (int i = 0; i < hdist; ++i) { cnt[S.lens[hlit + i]]++; used += S.lens[hlit + i] != 0; }
-    left = 1;
-    for (int l = 1; l <= 15; ++l) { left = (left << 1) - (int)cnt[l]; if (left < 0) return false; }
-    if (left != 0 && !(used == 0 || (used == 1 && cnt[1] == 1))) return false;
+    br.refill();
+    const uint32_t hlit = br.take(5) + 257u, hdist = br.take(5) + 1u, hclen = br.take(4) + 4u;
+    if (hlit > 286u || hdist > 30u) return false;
+    uint64_t cl = 0;                                                  // length of code-length symbol s at bits [3 s, 3 s + 3)
+    for (uint32_t i = 0; i < hclen; ++i) {
+        br.refill();
+        const uint32_t sym = i < 3u ? 16u + i : i == 3u ? 0u : (i & 1u) ? 8u - ((i - 3u) >> 1) : 8u + ((i - 4u) >> 1);
+        cl |= (uint64_t)br.take(3) << (3u * sym);
+    }
+    uint64_t count = 0;                                               // symbols per length, 8 bits each
+    uint32_t kraft = 0;
+    for (uint32_t sym = 0; sym < 19u; ++sym) {
+        const uint32_t l = (uint32_t)(cl >> (3u * sym)) & 7u;
+        if (l) { count += 1ull << (8u * l); kraft += 128u >> l; }
+    }
+    if (kraft != 128u) return false;
+    uint64_t next = 0;                                                // first code of every length, 8 bits each
+    for (uint32_t l = 1, code = 0; l <= 7u; ++l) {
+        code = (code + (l > 1u ? (uint32_t)(count >> (8u * (l - 1u))) & 0xffu : 0u)) << 1;
+        next |= (uint64_t)(code & 0xffu) << (8u * l);
+    }
+    for (uint32_t sym = 0; sym < 19u; ++sym) {
+        const uint32_t l = (uint32_t)(cl >> (3u * sym)) & 7u;
+        if (!l) continue;
+        const uint32_t code = (uint32_t)(next >> (8u * l)) & 0xffu;
+        next += 1ull << (8u * l);
+        uint32_t r = 0;
+        for (uint32_t k = 0; k < l; ++k) r |= ((code >> k) & 1u) << (l - 1u - k);
+        for (uint32_t i = r; i < 128u; i += 1u << l) tab.set(i, (sym << 3) | l);
+    }
+    const uint32_t total = hlit + hdist;
+    uint32_t got = 0, prev = 0, k_lit = 0, k_dist = 0, used_dist = 0;
+    bool eob = false;
+    while (got < total) {
+        br.refill();
+        if (br.past_end()) return false;
+        const uint32_t e = tab.get(br.peek(7));                      // (the code is complete: every index holds a symbol)
+        br.drop(e & 7u);
+        const uint32_t sym = e >> 3;
+        uint32_t rep = 1, val = sym;
+        if (sym == 16u) { if (got == 0u) return false; rep = 3u + br.take(2); val = prev; }
+        else if (sym == 17u) { rep = 3u + br.take(3); val = 0; }
+        else if (sym == 18u) { rep = 11u + br.take(7); val = 0; }
+        if (got + rep > total) return false;
+        if (val) {
+            const uint32_t w = 32768u >> val;
+            // the repeat may straddle the two codes
+            const uint32_t in_lit = got >= hlit ? 0u : (hlit - got < rep ? hlit - got : rep);
+            k_lit += w * in_lit;
+            k_dist += w * (rep - in_lit);
+            used_dist += rep - in_lit;
+            if (got <= 256u && got + rep > 256u) eob = true;
+        }
+        got += rep;
+        prev = val;
+    }
+    if (br.past_end() || !eob) return false;                          // (zlib: "invalid code -- missing end-of-block")
+    if (k_lit != 32768u) return false;
+    if (k_dist != 32768u && !(used_dist == 0u || (used_dist == 1u && k_dist == 16384u))) return false;
     return true;
 }
 
@@ -246,12 +423,33 @@ SMG_HD bool valid_dynamic_header(const uint32_t* words, uint64_t bit, uint64_t e
 
 // pass 1: only the number of bytes
 struct CountSink {
-    uint64_t n = 0;
+    uint64_t n = 0;             // what the uniform path counted
+    uint32_t acc[SMG_INF_LANES];// what each lane's real symbols made (batch): two vector instructions a batch, one sum a run
     bool bad = false;
+    SMG_HD CountSink() { SMG_INF_EACH_LANE(lane, slot) { (void)lane; acc[slot] = 0; } }
     SMG_HD void literal(uint32_t) { ++n; }
     SMG_HD void match(uint32_t len, uint32_t) { n += len; }
     SMG_HD void stored(const uint8_t*, uint32_t len) { n += len; }
+    // the real symbols of a batch: bit l of mask <-> the symbol that begins at bit offset l; L: 0x80000000 | literal, or the
+    // length of a match; D: its distance
+    SMG_HD void batch(uint64_t mask, const uint32_t (&L)[SMG_INF_LANES], const uint32_t (&D)[SMG_INF_LANES]) {
+        (void)D;
+        SMG_INF_EACH_LANE(lane, slot) {
+            if ((mask >> lane) & 1u) acc[slot] += L[slot] & 0x80000000u ? 1u : L[slot];
+        }
+    }
     SMG_HD void finish() {}
+    SMG_HD uint64_t total() const {
+        uint64_t t = n;
+#if defined(__HIP_DEVICE_COMPILE__)
+        uint32_t a = acc[0];                                          // (a run is cut off long before 2^32 bytes: decode_run's batch limit)
+        for (int o = 32; o; o >>= 1) a += __shfl_xor(a, o);
+        t += a;
+#else
+        for (int i = 0; i < SMG_INF_LANES; ++i) t += acc[i];
+#endif
+        return t;
+    }
 };
 
 // pass 2: 16-bit symbols at their final place.  The decoder is uniform across the wavefront; the sink gives every symbol's
@@ -259,13 +457,6 @@ struct CountSink {
 // gather their sources (the run's own earlier output, or a marker for what lies in front of the run) and store 64 symbols side
 // by side.  A match whose source is in the unstored group flushes first; then every source of it lies behind stores already
 // issued -- same wavefront, program order -- and an overlapping match (distance < length) reads its period.
-#if defined(__HIP_DEVICE_COMPILE__)
-#define SMG_INF_LANES 1
-#define SMG_INF_EACH_LANE(lane, slot) const uint32_t lane = (uint32_t)(threadIdx.x & 63u); constexpr int slot = 0;
-#else
-#define SMG_INF_LANES 64
-#define SMG_INF_EACH_LANE(lane, slot) for (uint32_t lane = 0, slot = 0; lane < 64u; ++lane, ++slot)
-#endif
 
 struct WaveSink {
     uint16_t* out;              // the run's first symbol
@@ -273,12 +464,73 @@ struct WaveSink {
     bool no_window;             // the member's first run: nothing in front of it
     uint32_t g0 = 0, o = 0;     // output position of lane 0 of the open group; lanes filled
     bool bad = false;
+    uint32_t pend_g0 = 0, pend_n = 0;   // a group whose gather is under way: first position, lanes
+    uint16_t pend[SMG_INF_LANES];
     int32_t src[SMG_INF_LANES]; // per lane: >= 0 literal symbol | 0x40000000; else source position relative to the run start, as (pos - 2^30) ... see below
     // encoding of src: bit 30 set -> literal in bits 0..15; otherwise a signed position (negative: in front of the run)
 
     SMG_HD void literal(uint32_t b) {
         { SMG_INF_EACH_LANE(lane, slot) { if (lane == o) src[slot] = (int32_t)(0x40000000u | b); } }
         if (++o == 64u) flush();
+    }
+    // The real symbols of a batch at once: their bytes go to the next free lanes of the open group (lane <-> output position),
+    // which is stored when it is full.  The uniform loop over the symbols tells every lane whether it lies in the symbol (2
+    // lane reads and ~5 vector instructions a symbol).  A match whose source lies in the unstored group flushes it first; one
+    // whose source reaches into the batch's own bytes sends the batch through the symbol-by-symbol path.
+    SMG_HD void batch(uint64_t mask, const uint32_t (&L)[SMG_INF_LANES], const uint32_t (&D)[SMG_INF_LANES]) {
+        uint32_t total = 0;
+        bool near_group = false, near_self = false;
+        for (uint64_t m = mask; m; m &= m - 1) {
+            const uint32_t l = ctz64(m);
+            const uint32_t x = lane_read(L, l);
+            if (x & 0x80000000u) ++total;
+            else {
+                total += x;
+                const uint32_t d = lane_read(D, l);
+                near_self = near_self || d < total;
+                near_group = near_group || d < o + total;
+            }
+        }
+        if (near_group && o) flush();
+        if (near_self) {
+            for (uint64_t m = mask; m; m &= m - 1) {
+                const uint32_t l = ctz64(m);
+                const uint32_t x = lane_read(L, l);
+                if (x & 0x80000000u) literal(x & 0xffu);
+                else match(x, lane_read(D, l));
+            }
+            return;
+        }
+        const uint32_t base = g0 + o;                                 // position of the batch's first byte
+        uint32_t done = 0;
+        while (done < total) {
+            const uint32_t take = total - done < 64u - o ? total - done : 64u - o;
+            uint32_t at = 0;
+            for (uint64_t m = mask; m; m &= m - 1) {
+                const uint32_t l = ctz64(m);
+                const uint32_t x = lane_read(L, l);
+                if (x & 0x80000000u) {
+                    { SMG_INF_EACH_LANE(lane, slot) {
+                        if (lane - o < take && done + (lane - o) == at) src[slot] = (int32_t)(0x40000000u | (x & 0xffu));
+                    } }
+                    ++at;
+                } else {
+                    const uint32_t d = lane_read(D, l);
+                    { SMG_INF_EACH_LANE(lane, slot) {
+                        const uint32_t j = done + (lane - o);
+                        if (lane - o < take && j - at < x) {
+                            const int64_t p = (int64_t)base + j - (int64_t)d;
+                            src[slot] = (int32_t)(p < -(int64_t)WIN ? -(int32_t)WIN - 1 : p);
+                        }
+                    } }
+                    at += x;
+                }
+                if (at >= done + take) break;
+            }
+            o += take;
+            done += take;
+            if (o == 64u) flush();
+        }
     }
     SMG_HD void match(uint32_t len, uint32_t dist) {
         uint32_t k0 = 0;
@@ -318,29 +570,43 @@ struct WaveSink {
             if (o == 64u) flush();
         }
     }
+    // The group's gather is ISSUED here and its store waits for the next flush: the symbols decoded in between hide the
+    // trip to memory (a wavefront makes thousands of these trips one after the other).  The store of the group in front goes
+    // out first -- same wavefront, program order: the gather below sees it.
     SMG_HD void flush() {
         if ((uint64_t)g0 + o > cap) { bad = true; o = 0; return; }
+        commit();
         bool wrong = false;
         { SMG_INF_EACH_LANE(lane, slot) {
             if (lane < o) {
                 const int32_t s = src[slot];
                 uint16_t sym;
-                if (s & 0x40000000 && s >= 0) sym = (uint16_t)(s & 0xffff);
+                if ((s & 0x40000000) && s >= 0) sym = (uint16_t)(s & 0xffff);
                 else if (s >= 0) sym = out[s];
                 else if (s < -(int32_t)WIN || no_window) { sym = 0; wrong = true; }
                 else sym = (uint16_t)(MARK | (uint32_t)(s + (int32_t)WIN));
-                out[g0 + lane] = sym;
+                pend[slot] = sym;
             }
         } }
 #if defined(__HIP_DEVICE_COMPILE__)
         wrong = __builtin_amdgcn_ballot_w64(wrong) != 0ull;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");       // the stores above are in front of every later load of this wavefront
 #endif
         if (wrong) bad = true;
+        pend_g0 = g0;
+        pend_n = o;
         g0 += o;
         o = 0;
     }
-    SMG_HD void finish() { if (o) flush(); }
+    SMG_HD void commit() {
+        if (!pend_n) return;
+        { SMG_INF_EACH_LANE(lane, slot) { if (lane < pend_n) out[pend_g0 + lane] = pend[slot]; } }
+#if defined(__HIP_DEVICE_COMPILE__)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");       // the stores above are in front of every later load of this wavefront
+#endif
+        pend_n = 0;
+    }
+    SMG_HD void finish() { if (o) flush(); commit(); }
+    SMG_HD uint64_t total() const { return g0; }
 };
 
 struct RunResult {
@@ -351,21 +617,29 @@ struct RunResult {
 
 // Decode from `bit` (a block header) through stored / fixed / final blocks until the next dynamic non-final block header
 // (the next run's start) or the end of the final block.  max_out bounds a false candidate's run.
+//
+// The symbols of a block, a batch at a time: with >= 97 bits in the window every lane decodes the WHOLE symbol that would begin
+// at the bit offset of its lane number -- literal / length entry, its extra bits, the distance entry behind them, its extra
+// bits: two LDS lookups and ~40 vector instructions for 64 offsets at once -- and the uniform walk hops from real symbol to
+// real symbol by lane reads (bits taken, bytes made, distance).  The chip runs one scalar instruction per CU and cycle for
+// ALL of a CU's wavefronts, and every CU holds ~24 of these: what bounds the walk is its instruction count per symbol, not
+// its latency.  A lane that meets a code longer than the table's root flags itself, and that symbol goes through the
+// canonical search.
 template <class Sink>
 SMG_HD RunResult decode_run(const uint32_t* words, uint64_t bit, uint64_t end_bit, Scratch& S, Sink& sink, uint64_t max_out) {
     RunResult r;
     r.out_len = 0;
     r.status = RUN_OK;
-    BitReader br;
+    WaveBits br;
     br.init(words, bit, end_bit);
     Code lit, dist;
-    lit.table = S.lit_table; lit.sorted = S.lit_sorted;
-    dist.table = S.dist_table; dist.sorted = S.dist_sorted;
-    uint64_t produced = 0;
+    lit.table = S.lit_table; lit.sorted = S.lit_sorted; lit.st = &S.lit_store;
+    dist.table = S.dist_table; dist.sorted = S.dist_sorted; dist.st = &S.dist_store;
+    uint32_t batches = 0;
     bool first = true;
     for (;;) {
         br.refill();
-        if (br.pos + 3 > br.end) { r.status = RUN_PAST_END; break; }
+        if (br.pos() + 3 > br.end) { r.status = RUN_PAST_END; break; }
         const uint32_t hdr = br.peek(3);
         if (!first && hdr == 4u) break;                               // the next run begins here
         first = false;
@@ -376,13 +650,12 @@ SMG_HD RunResult decode_run(const uint32_t* words, uint64_t bit, uint64_t end_bi
             br.to_byte();
             br.refill();
             const uint32_t len = br.take(16);
-            br.refill();
             const uint32_t nlen = br.take(16);
             if ((len ^ nlen) != 0xffffu) { r.status = RUN_BAD_BLOCK; break; }
-            if (br.pos + (uint64_t)len * 8 > br.end) { r.status = RUN_PAST_END; break; }
-            sink.stored(reinterpret_cast<const uint8_t*>(words) + (br.pos >> 3), len);
-            produced += len;
-            br.init(words, br.pos + (uint64_t)len * 8, end_bit);
+            const uint64_t at = br.pos();
+            if (at + (uint64_t)len * 8 > br.end) { r.status = RUN_PAST_END; break; }
+            sink.stored(reinterpret_cast<const uint8_t*>(words) + (at >> 3), len);
+            br.init(words, at + (uint64_t)len * 8, end_bit);
         } else if (type == 3) {
             r.status = RUN_BAD_BLOCK;
             break;
@@ -393,36 +666,80 @@ SMG_HD RunResult decode_run(const uint32_t* words, uint64_t bit, uint64_t end_bi
                 for (int i = 144; i < 256; ++i) S.lens[i] = 9;
                 for (int i = 256; i < 280; ++i) S.lens[i] = 7;
                 for (int i = 280; i < 288; ++i) S.lens[i] = 8;
-                for (int i = 0; i < 30; ++i) S.lens[288 + i] = 5;
-                ok = build_code(S.lens, 288, LIT_ROOT, lit) && build_code(S.lens + 288, 30, DIST_ROOT, dist);
+                for (int i = 0; i < 32; ++i) S.lens[288 + i] = 5;    // (codes 30 and 31 exist in the code and are refused as symbols)
+                ok = build_code(S.lens, 288, LIT_ROOT, lit, CODE_LITLEN) && build_code(S.lens + 288, 32, DIST_ROOT, dist, CODE_DIST);
             } else {
                 int hlit, hdist;
                 ok = read_dynamic_lengths(br, S, hlit, hdist, false);
-                ok = ok && build_code(S.lens, hlit, LIT_ROOT, lit) && build_code(S.lens + hlit, hdist, DIST_ROOT, dist);
+                ok = ok && build_code(S.lens, hlit, LIT_ROOT, lit, CODE_LITLEN) && build_code(S.lens + hlit, hdist, DIST_ROOT, dist, CODE_DIST);
             }
             if (!ok) { r.status = RUN_BAD_BLOCK; break; }
-            for (;;) {
+            bool end_of_block = false;
+            while (!end_of_block) {
                 br.refill();
-                int sym = decode_sym(br, lit, LIT_ROOT);
-                if (sym < 256) {
-                    if (sym < 0) { r.status = RUN_BAD_CODE; break; }
-                    sink.literal((uint32_t)sym);
-                    ++produced;
-                } else if (sym == 256) {
-                    break;
-                } else {
-                    const uint32_t ls = (uint32_t)sym - 257u;
-                    if (ls > 28u) { r.status = RUN_BAD_CODE; break; }
-                    const uint32_t len = len_base(ls) + br.take(len_extra(ls));
-                    br.refill();
-                    const int ds = decode_sym(br, dist, DIST_ROOT);
-                    if (ds < 0 || ds > 29) { r.status = RUN_BAD_CODE; break; }
-                    const uint32_t d = dist_base((uint32_t)ds) + br.take(dist_extra((uint32_t)ds));
-                    sink.match(len, d);
-                    produced += len;
+                // every lane: the whole symbol that would begin at its bit offset -- bits it takes, bytes it makes, distance
+                uint32_t A[SMG_INF_LANES], L[SMG_INF_LANES], D[SMG_INF_LANES];
+                { SMG_INF_EACH_LANE(lane, slot) {
+                    const uint64_t v64 = lane ? (br.lo >> lane) | (br.hi << (64u - lane)) : br.lo;
+                    const uint32_t v = (uint32_t)v64;
+                    const uint32_t e = lit.table[v & ((1u << LIT_ROOT) - 1u)];
+                    const uint32_t cl = e & 15u, kind = (e >> 4) & 3u, eb = (e >> 8) & 15u;
+                    const uint32_t o2 = cl + eb;                     // <= 20
+                    const uint32_t len = (e >> 16) + ((v >> cl) & ((1u << eb) - 1u));
+                    const uint32_t v2 = (uint32_t)(v64 >> o2);
+                    const uint32_t d = dist.table[v2 & ((1u << DIST_ROOT) - 1u)];
+                    const uint32_t dl = d & 15u, db = (d >> 8) & 15u;
+                    uint32_t a;
+                    if (cl == 0u || kind == 3u) a = SYM_SLOW;        // a long code, or no symbol: the uniform path looks (and reports)
+                    else if (kind == 0u) a = cl;
+                    else if (kind == 2u) a = cl | SYM_END;
+                    else if (dl == 0u || ((d >> 4) & 3u) == 3u) a = SYM_SLOW;
+                    else a = o2 + dl + db;                           // <= 20 + 28
+                    A[slot] = a;
+                    L[slot] = kind == 0u ? (0x80000000u | (e >> 16)) : len;
+                    D[slot] = (d >> 16) + ((v2 >> dl) & ((1u << db) - 1u));
+                } }
+                // the uniform walk: from symbol to symbol by lane reads, as far as whole symbols lie inside the window; a lane
+                // that flagged itself ends it
+                const uint32_t o_max = br.cnt - 48u < 63u ? br.cnt - 48u : 63u;
+                uint32_t o = 0, a = 0;
+                uint64_t mask = 0;
+                while (o <= o_max) {
+                    a = lane_read(A, o);
+                    if (a & (SYM_SLOW | SYM_END)) break;
+                    mask |= 1ull << o;
+                    o += a;
                 }
+                if (mask) sink.batch(mask, L, D);
+                if (o <= o_max) {
+                    if (a & SYM_END) { o += a & 0x3fu; end_of_block = true; }
+                    else {                                            // this one symbol through the canonical search
+                        uint32_t e = lit.table[br.bits_at(o, LIT_ROOT)];
+                        if (!(e & 15u)) e = long_code(br.bits_at(o, 15), lit, LIT_ROOT, CODE_LITLEN);
+                        const uint32_t kind = (e >> 4) & 3u;
+                        if (!e || kind == 3u) r.status = RUN_BAD_CODE;
+                        else if (kind == 0u) { sink.literal(e >> 16); o += e & 15u; }
+                        else if (kind == 2u) { o += e & 15u; end_of_block = true; }
+                        else {
+                            const uint32_t eb = (e >> 8) & 15u;
+                            const uint32_t o2 = o + (e & 15u) + eb;  // <= 63 + 20: bits_at reaches that far (cnt >= o_max + 48)
+                            const uint32_t len = (e >> 16) + br.bits_at(o + (e & 15u), eb);
+                            uint32_t d = dist.table[br.bits_at(o2, DIST_ROOT)];
+                            if (!(d & 15u)) d = long_code(br.bits_at(o2, 15), dist, DIST_ROOT, CODE_DIST);
+                            if (!d || ((d >> 4) & 3u) == 3u) r.status = RUN_BAD_CODE;
+                            else {
+                                const uint32_t db = (d >> 8) & 15u;
+                                const uint32_t dd = (d >> 16) + br.bits_at(o2 + (d & 15u), db);
+                                o = o2 + (d & 15u) + db;
+                                sink.match(len, dd);
+                            }
+                        }
+                    }
+                }
+                br.drop(o);
+                if (r.status != RUN_OK) break;
                 if (br.past_end()) { r.status = RUN_PAST_END; break; }
-                if (produced > max_out) { r.status = RUN_TOO_LONG; break; }
+                if (++batches > MAX_BATCHES) { r.status = RUN_TOO_LONG; break; }
             }
             if (r.status != RUN_OK) break;
         }
@@ -431,8 +748,9 @@ SMG_HD RunResult decode_run(const uint32_t* words, uint64_t bit, uint64_t end_bi
     }
     sink.finish();
     if (sink.bad && (r.status == RUN_OK || r.status == RUN_FINAL)) r.status = RUN_BAD_DISTANCE;
-    r.end_bit = br.pos;
-    r.out_len = produced;
+    r.end_bit = br.pos();
+    r.out_len = sink.total();
+    if (r.out_len > max_out && (r.status == RUN_OK || r.status == RUN_FINAL)) r.status = RUN_TOO_LONG;
     return r;
 }
 
@@ -457,6 +775,69 @@ inline uint32_t crc_xpow8(uint64_t n_bytes) {
 }
 // crc of A ++ B from crc(A), crc(B) and x^(8 |B|)
 inline uint32_t crc_join(uint32_t crc_a, uint32_t crc_b, uint32_t xpow_b) { return crc_mul(xpow_b, crc_a) ^ crc_b; }
+
+}  // namespace inf
+}  // namespace smg
+
+// ---- host only: gzip framing, the chain of runs ----
+#include <algorithm>
+#include <string>
+#include <vector>
+namespace smg {
+namespace inf {
+
+// one gzip member inside a buffer (RFC 1952): where its deflate data begins, and what the trailer promises
+struct Member {
+    uint64_t deflate_byte = 0;      // first byte of the deflate stream (from the start of the buffer)
+    uint64_t end_byte = 0;          // first byte behind the member's trailer = end of the file for a single member
+    uint32_t want_crc = 0, want_isize = 0;
+};
+
+// header of a gzip file that is ONE member: false if it is not gzip / not deflate / too short
+inline bool parse_single_member(const uint8_t* p, uint64_t size, Member& m) {
+    if (size < 18 + 8 || p[0] != 0x1f || p[1] != 0x8b || p[2] != 8) return false;
+    const uint8_t flg = p[3];
+    if (flg & 0xe0) return false;                                     // reserved bits
+    uint64_t o = 10;
+    if (flg & 4) { if (o + 2 > size) return false; o += 2 + (uint64_t)(p[o] | (p[o + 1] << 8)); }
+    if (flg & 8) { while (o < size && p[o]) ++o; ++o; }
+    if (flg & 16) { while (o < size && p[o]) ++o; ++o; }
+    if (flg & 2) o += 2;
+    if (o + 8 >= size) return false;
+    m.deflate_byte = o;
+    m.end_byte = size;
+    const uint8_t* t = p + size - 8;
+    m.want_crc = (uint32_t)t[0] | ((uint32_t)t[1] << 8) | ((uint32_t)t[2] << 16) | ((uint32_t)t[3] << 24);
+    m.want_isize = (uint32_t)t[4] | ((uint32_t)t[5] << 8) | ((uint32_t)t[6] << 16) | ((uint32_t)t[7] << 24);
+    return true;
+}
+
+// a candidate block start after pass 1
+struct Cand {
+    uint64_t bit = 0, end_bit = 0, out_len = 0;
+    uint32_t status = 0;
+};
+
+// The chain of runs from `first_bit` to the end of the final block.  cands: sorted by bit, holding first_bit itself.
+// trailer_bit: where the member's 8-byte trailer begins (the final block must end in the byte in front of it).
+// -> indices into cands, in stream order; empty + why on any gap.
+inline std::vector<uint32_t> link_chain(const std::vector<Cand>& cands, uint64_t first_bit, uint64_t trailer_bit, std::string& why) {
+    std::vector<uint32_t> chain;
+    uint64_t at = first_bit;
+    for (;;) {
+        auto it = std::lower_bound(cands.begin(), cands.end(), at, [](const Cand& c, uint64_t b) { return c.bit < b; });
+        if (it == cands.end() || it->bit != at) { why = "no block start was found at bit " + std::to_string(at) + " where the run in front ends"; return {}; }
+        const Cand& c = *it;
+        if (c.status != RUN_OK && c.status != RUN_FINAL) { why = "the run at bit " + std::to_string(at) + " does not decode (status " + std::to_string(c.status) + ")"; return {}; }
+        if (c.end_bit <= at) { why = "a run of no bits"; return {}; }
+        chain.push_back((uint32_t)(it - cands.begin()));
+        if (c.status == RUN_FINAL) {
+            if (((c.end_bit + 7) & ~7ull) != trailer_bit) { why = "the deflate stream ends at bit " + std::to_string(c.end_bit) + ", not in front of the trailer (more than one member?)"; return {}; }
+            return chain;
+        }
+        at = c.end_bit;
+    }
+}
 
 }  // namespace inf
 }  // namespace smg

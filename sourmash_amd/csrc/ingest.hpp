@@ -4,7 +4,10 @@
 // (screed, src/sourmash/command_sketch.py:697,746-768) and crosses the FFI once per record.  Here the host does
 // no parsing at all:
 //   reader threads   raw file bytes -> pinned ring buffers (plain files: several threads pread different chunks
-//                    at once; gzip: one zlib inflate stream, which is then the limit)
+//                    at once)
+//   gzip             a single-member .gz goes to HBM COMPRESSED and is inflated there (gunzip.hpp: every block of the
+//                    member decoded at once, checked against the trailer's CRC-32); what the device refuses --
+//                    several members, a damaged stream -- is inflated on the host's threads (pargz.hpp) as before
 //   copy stream      pinned -> HBM, overlapped with everything else
 //   compute stream   fastx.hip resolves the record structure on the device (headers, line breaks, FASTQ quality
 //                    lines) and compacts the sequence bytes, one separator byte per record; sketch.hip hashes the
@@ -19,6 +22,7 @@
 #include <zlib.h>
 #include <memory>
 #include "pargz.hpp"
+#include "gunzip.hpp"
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -195,7 +199,8 @@ class RawChunkSource {
 struct IngestScratch {
     size_t chunk = 0;
     PinnedBuf ring[RawChunkSource::SLOTS];
-    DevBuf raw[2], comp[2], state, temp, small;
+    DevBuf raw[2], comp[2], state, temp, small, gzdev;
+    PinnedBuf gzfile;                               // a whole .gz file on its way to the device
     hipStream_t copy_stream = nullptr;
     hipEvent_t copied[2] = {nullptr, nullptr}, consumed[2] = {nullptr, nullptr};
     size_t temp_bytes = 0;
@@ -207,7 +212,7 @@ struct IngestScratch {
     void release(hipStream_t stream) {
         if (stream) (void)hipStreamSynchronize(stream);
         if (copy_stream) (void)hipStreamSynchronize(copy_stream);
-        for (DevBuf* b : {&raw[0], &raw[1], &comp[0], &comp[1], &state, &temp, &small}) { b->st = nullptr; b->release(); }
+        for (DevBuf* b : {&raw[0], &raw[1], &comp[0], &comp[1], &state, &temp, &small, &gzdev}) { b->st = nullptr; b->release(); }
         for (int i = 0; i < 2; ++i) {
             if (copied[i]) (void)hipEventDestroy(copied[i]);
             if (consumed[i]) (void)hipEventDestroy(consumed[i]);
@@ -264,9 +269,69 @@ struct IngestWorker {
     }
 };
 
+// A single-member gzip file inflated on the device: -> arena block with its bytes (the caller frees it with arena_free(p, st)) and
+// their number, or nullptr when the device path does not apply (not gzip, too large for one pass, SMG_GUNZIP_DEVICE=0) or refused
+// the file (*why says so): the caller then reads the file through the host inflater.
+inline void* gunzip_file_to_device(IngestScratch& scratch, const std::string& path, hipStream_t st, uint64_t* n_out, std::string* why,
+                                   GunzipStats* stats = nullptr) {
+    *n_out = 0;
+    static const bool off = [] { const char* e = getenv("SMG_GUNZIP_DEVICE"); return e && e[0] == '0'; }();
+    if (off) { if (why) *why = "SMG_GUNZIP_DEVICE=0"; return nullptr; }
+    const int fd = ::open(path.c_str(), O_RDONLY);
+    if (fd < 0) return nullptr;                                      // (the host path reports the error)
+    struct Close { int fd; ~Close() { ::close(fd); } } close_fd{fd};
+    struct stat sb;
+    if (fstat(fd, &sb) != 0 || !S_ISREG(sb.st_mode)) return nullptr;
+    const uint64_t size = (uint64_t)sb.st_size;
+    constexpr uint64_t MAX_FILE = (uint64_t)4 << 30;                  // (symbols + bytes of the inflated member are resident at once)
+    if (size < 26 || size > MAX_FILE) { if (why) *why = "file size outside the device inflater's range"; return nullptr; }
+    uint8_t magic[3] = {0, 0, 0};
+    if (::pread(fd, magic, 3, 0) != 3 || magic[0] != 0x1f || magic[1] != 0x8b || magic[2] != 8) return nullptr;
+    scratch.gzfile.reserve((size_t)size + GUNZIP_PAD + 64);
+    scratch.gzdev.reserve((size_t)size + GUNZIP_PAD + 64, st);
+    uint8_t* h = scratch.gzfile.p;
+    {   // page cache -> pinned memory on a few threads (one memcpy stream moves ~6 GB/s)
+        const unsigned nt = (unsigned)std::min<uint64_t>(8, (size >> 23) + 1);
+        std::atomic<bool> bad(false);
+        auto part = [&](unsigned t) {
+            const uint64_t lo = size * t / nt, hi = size * (t + 1) / nt;
+            uint64_t got = lo;
+            while (got < hi) {
+                const ssize_t r = ::pread(fd, h + got, (size_t)(hi - got), (off_t)got);
+                if (r <= 0) { bad = true; return; }
+                got += (uint64_t)r;
+            }
+        };
+        std::vector<std::thread> th;
+        for (unsigned t = 1; t < nt; ++t) th.emplace_back(part, t);
+        part(0);
+        for (auto& t : th) t.join();
+        if (bad) return nullptr;
+    }
+    memset(h + size, 0, GUNZIP_PAD);
+    hip_check(hipMemcpyAsync(scratch.gzdev.p, h, (size_t)size + GUNZIP_PAD, hipMemcpyHostToDevice, st), "H2D");
+    std::vector<GunzipMember> ms(1);
+    ms[0].file_off = 0;
+    ms[0].file_len = size;
+    void* d_out = nullptr;
+    gunzip_device(h, scratch.gzdev.as<uint8_t>(), size, ms, &d_out, st, stats);
+    if (!ms[0].ok) {
+        if (why) *why = ms[0].why;
+        if (d_out) arena_free(d_out, st);
+        gunzip_counters().refused++;
+        return nullptr;
+    }
+    gunzip_counters().on_device++;
+    *n_out = ms[0].out_len;
+    return d_out;
+}
+
 // Sketch a sequence file into every (DNA) sketch of `mhs` on the worker's pipeline.  force == true semantics.
+// inflated: the file's bytes already in HBM (a member of a batch inflated by the caller: sketch_files_parallel), or
+// {nullptr, 0, true} when the device has refused the file already; default: the file is tried on the device here.
+struct InflatedSlice { const void* p = nullptr; uint64_t len = 0; bool refused = false; };
 inline void sketch_file_with(IngestWorker& w, std::vector<KmerMinHash*>& mhs, const std::string& path, size_t CHUNK,
-                             unsigned max_readers, uint64_t* n_records, uint64_t* n_bases) {
+                             unsigned max_readers, uint64_t* n_records, uint64_t* n_bases, const InflatedSlice* inflated = nullptr) {
     for (auto* mh : mhs)
         if (!mh->is_dna()) throw err_internal("the streaming file ingest takes DNA sketches; protein / dayhoff / hp sketches are fed record by record");
     uint32_t kmax = 0;
@@ -340,15 +405,39 @@ inline void sketch_file_with(IngestWorker& w, std::vector<KmerMinHash*>& mhs, co
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_start = now();
     double t_wait = 0, t_sync = 0;
-    RawChunkSource src(path, CHUNK, scratch.ring, max_readers);
+    // a gzip member inflated in HBM: the chunks below are then slices of that block (no reader threads, no copies)
+    uint64_t plain_len = 0;
+    std::string gz_why;
+    void* d_plain = nullptr;
+    bool own_plain = true;
+    if (inflated && inflated->p) { d_plain = const_cast<void*>(inflated->p); plain_len = inflated->len; own_plain = false; }
+    else if (!(inflated && inflated->refused)) d_plain = gunzip_file_to_device(scratch, path, st, &plain_len, &gz_why);
+    struct FreePlain { void*& p; bool& own; hipStream_t st; ~FreePlain() { if (p && own) arena_free(p, st); } } free_plain{d_plain, own_plain, st};
+    if (!d_plain && !gz_why.empty() && trace) fprintf(stderr, "[ingest] %s: inflated on the host (%s)\n", path.c_str(), gz_why.c_str());
+    std::unique_ptr<RawChunkSource> src_host;
+    if (!d_plain) src_host.reset(new RawChunkSource(path, CHUNK, scratch.ring, max_readers));
+    uint8_t first_byte = 0;
+    if (d_plain && plain_len) {
+        hip_check(hipMemcpyAsync(&first_byte, d_plain, 1, hipMemcpyDeviceToHost, st), "D2H");
+        hip_check(hipStreamSynchronize(st), "sync");
+    }
     constexpr size_t FLUSH_AT = (size_t)64 << 20;            // entries; keeps scratch bounded on huge inputs
     int fastq = -1;
     uint64_t total_kept = 0;
     bool used[2] = {false, false};
     // the copy of chunk seq+1 is queued before chunk seq is parsed, so the copy engine never waits for the host
-    struct Staged { const uint8_t* data = nullptr; size_t len = 0; bool ok = false; };
+    struct Staged { const uint8_t* data = nullptr; const uint8_t* dev = nullptr; size_t len = 0; bool ok = false; };
     auto stage = [&](int64_t seq) -> Staged {
         Staged c;
+        if (d_plain) {
+            const uint64_t off = (uint64_t)seq * CHUNK;
+            if (off >= plain_len) return c;
+            c.ok = true;
+            c.len = (size_t)std::min<uint64_t>(CHUNK, plain_len - off);
+            c.dev = static_cast<const uint8_t*>(d_plain) + off;
+            return c;
+        }
+        RawChunkSource& src = *src_host;
         const double t0 = now();
         c.ok = src.wait(seq, &c.data, &c.len);
         t_wait += now() - t0;
@@ -357,6 +446,7 @@ inline void sketch_file_with(IngestWorker& w, std::vector<KmerMinHash*>& mhs, co
         if (used[b]) hip_check(hipStreamWaitEvent(scratch.copy_stream, scratch.consumed[b], 0), "wait");   // parse of seq-2 read raw[b]
         hip_check(hipMemcpyAsync(scratch.raw[b].p, c.data, c.len, hipMemcpyHostToDevice, scratch.copy_stream), "H2D");
         hip_check(hipEventRecord(scratch.copied[b], scratch.copy_stream), "record");
+        c.dev = scratch.raw[b].as<uint8_t>();
         return c;
     };
     Staged cur = stage(0);
@@ -364,15 +454,15 @@ inline void sketch_file_with(IngestWorker& w, std::vector<KmerMinHash*>& mhs, co
         const int b = (int)(seq & 1);
         const size_t len = cur.len;
         if (fastq < 0) {                                      // format by the first byte of the (inflated) file
-            fastq = cur.data[0] == '@' ? 1 : 0;
+            fastq = (d_plain ? first_byte : cur.data[0]) == '@' ? 1 : 0;
             const uint8_t init[4] = {(uint8_t)(fastq ? 3 : 1), 1, 0, 0};
             hip_check(hipMemcpyAsync(d_carry, init, 4, hipMemcpyHostToDevice, st), "H2D");
             hip_check(hipStreamSynchronize(st), "sync");
         }
         // compute stream: parse + compact behind the halo that the previous chunk left in comp[b]
-        hip_check(hipStreamWaitEvent(st, scratch.copied[b], 0), "wait");
+        if (!d_plain) hip_check(hipStreamWaitEvent(st, scratch.copied[b], 0), "wait");
         uint8_t* comp = scratch.comp[b].as<uint8_t>() + scratch.halo;
-        hip_check(fastx_compact_launch(scratch.raw[b].as<uint8_t>(), len, fastq, d_carry, scratch.state.as<uint8_t>(), comp,
+        hip_check(fastx_compact_launch(cur.dev, len, fastq, d_carry, scratch.state.as<uint8_t>(), comp,
                                        d_n, d_records, scratch.temp.p, scratch.temp_bytes, st), "fastx");
         hip_check(hipEventRecord(scratch.consumed[b], st), "record");
         used[b] = true;
@@ -384,7 +474,7 @@ inline void sketch_file_with(IngestWorker& w, std::vector<KmerMinHash*>& mhs, co
         const double t1 = now();
         hip_check(hipStreamSynchronize(st), "sync");          // also: every launch of the previous chunk is done
         t_sync += now() - t1;
-        src.release(seq);                                     // the copy is complete: the pinned slot can be refilled
+        if (src_host) src_host->release(seq);                 // the copy is complete: the pinned slot can be refilled
         total_kept += n_kept;
         for (size_t s = 0; s < mhs.size(); ++s) {
             KmerMinHash& mh = *mhs[s];
@@ -460,22 +550,83 @@ inline void sketch_files_parallel(const std::vector<std::string>& paths, const C
     std::vector<Error> errors;
     int device = 0;
     (void)hipGetDevice(&device);
+    // files are claimed a batch at a time: the gzip members of a batch (single genomes: a few dozen deflate blocks each) are
+    // inflated on the device in ONE pass (gunzip.hpp) -- a member by itself would keep a few dozen wavefronts busy
+    const size_t per_batch = std::max<size_t>(1, std::min<size_t>(64, paths.size() / std::max(1u, threads)));
+    constexpr uint64_t BATCH_FILE_MAX = (uint64_t)64 << 20;          // larger files go by themselves (sketch_file_with inflates them)
+    static const bool device_gunzip = [] { const char* e = getenv("SMG_GUNZIP_DEVICE"); return !(e && e[0] == '0'); }();
     auto run = [&]() {
         (void)hipSetDevice(device);
         IngestWorker w;
         try {
             w.init_own_stream();
             for (;;) {
-                const size_t i = next.fetch_add(1);
-                if (i >= paths.size()) break;
-                Signature sig = Signature::from_params(params);
-                std::vector<KmerMinHash*> mhs;
-                for (auto& mh : sig.sketches) mhs.push_back(&mh);
-                uint64_t recs = 0, b = 0;
-                sketch_file_with(w, mhs, paths[i], (size_t)4 << 20, 1, &recs, &b);
-                sig.filename = paths[i];
-                bases += b;
-                out[i] = std::move(sig);
+                const size_t i0 = next.fetch_add(per_batch);
+                if (i0 >= paths.size()) break;
+                const size_t i1 = std::min(paths.size(), i0 + per_batch);
+                // ---- the batch's gzip files -> pinned memory -> HBM -> inflated ----
+                std::vector<GunzipMember> ms;
+                std::vector<size_t> owner;                            // ms[k] is paths[owner[k]]
+                std::vector<InflatedSlice> slice(i1 - i0);
+                void* d_out = nullptr;
+                struct FreeOut { void*& p; hipStream_t st; ~FreeOut() { if (p) arena_free(p, st); } } free_out{d_out, w.stream};
+                if (device_gunzip && i1 - i0 > 1) {
+                    std::vector<int> fds;
+                    uint64_t total = 0;
+                    for (size_t i = i0; i < i1; ++i) {
+                        const int fd = ::open(paths[i].c_str(), O_RDONLY);
+                        struct stat sb;
+                        uint8_t magic[3] = {0, 0, 0};
+                        if (fd >= 0 && fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode) && (uint64_t)sb.st_size >= 26 && (uint64_t)sb.st_size <= BATCH_FILE_MAX &&
+                            ::pread(fd, magic, 3, 0) == 3 && magic[0] == 0x1f && magic[1] == 0x8b && magic[2] == 8) {
+                            GunzipMember m;
+                            m.file_off = total;
+                            m.file_len = (uint64_t)sb.st_size;
+                            total += (m.file_len + 7) & ~7ull;
+                            ms.push_back(m);
+                            owner.push_back(i);
+                            fds.push_back(fd);
+                        } else if (fd >= 0) ::close(fd);             // (not a gzip file, or one for the single-file path: it opens the file itself)
+                    }
+                    if (!ms.empty()) {
+                        w.scratch.gzfile.reserve((size_t)total + GUNZIP_PAD + 64);
+                        w.scratch.gzdev.reserve((size_t)total + GUNZIP_PAD + 64, w.stream);
+                        uint8_t* h = w.scratch.gzfile.p;
+                        bool read_ok = true;
+                        for (size_t k = 0; k < ms.size(); ++k) {
+                            uint64_t got = 0;
+                            while (got < ms[k].file_len) {
+                                const ssize_t r = ::pread(fds[k], h + ms[k].file_off + got, (size_t)(ms[k].file_len - got), (off_t)got);
+                                if (r <= 0) { read_ok = false; break; }
+                                got += (uint64_t)r;
+                            }
+                            ::close(fds[k]);
+                            const uint64_t end = ms[k].file_off + ms[k].file_len;
+                            memset(h + end, 0, (size_t)((((end + 7) & ~7ull)) - end));
+                        }
+                        if (read_ok) {
+                            memset(h + total, 0, GUNZIP_PAD);
+                            hip_check(hipMemcpyAsync(w.scratch.gzdev.p, h, (size_t)total + GUNZIP_PAD, hipMemcpyHostToDevice, w.stream), "H2D");
+                            gunzip_device(h, w.scratch.gzdev.as<uint8_t>(), total, ms, &d_out, w.stream);
+                            for (size_t k = 0; k < ms.size(); ++k) {
+                                InflatedSlice& sl = slice[owner[k] - i0];
+                                if (ms[k].ok) { sl.p = (const uint8_t*)d_out + ms[k].out_off; sl.len = ms[k].out_len; gunzip_counters().on_device++; }
+                                else { sl.refused = true; gunzip_counters().refused++; }
+                            }
+                        }
+                    }
+                }
+                for (size_t i = i0; i < i1; ++i) {
+                    Signature sig = Signature::from_params(params);
+                    std::vector<KmerMinHash*> mhs;
+                    for (auto& mh : sig.sketches) mhs.push_back(&mh);
+                    uint64_t recs = 0, b = 0;
+                    const InflatedSlice& sl = slice[i - i0];
+                    sketch_file_with(w, mhs, paths[i], (size_t)4 << 20, 1, &recs, &b, (sl.p || sl.refused) ? &sl : nullptr);
+                    sig.filename = paths[i];
+                    bases += b;
+                    out[i] = std::move(sig);
+                }
             }
             hip_check(hipStreamSynchronize(w.stream), "sync");
         } catch (const Error& e) {

@@ -410,3 +410,39 @@ def sketch_files(paths, param_str=DEFAULTS["dna"], *, threads=0):
     sigs = [SourmashSignature._from_objptr(ptr[i]) for i in range(len(paths))]
     lib.nodegraph_buffer_free(C.cast(ptr, C.POINTER(C.c_uint8)), len(paths) * C.sizeof(C.c_void_p))
     return sigs
+
+
+def gunzip_files(paths, capacity=None):
+    """The device inflater behind the .gz ingest by itself (smgpu_gunzip_files): single-member gzip files -> their bytes.
+
+    -> (list of bytes or None per file -- None: the device refused the member, e.g. several members or a damaged stream --,
+    stats dict).  Test / benchmark entry: the ingest keeps the inflated bytes in HBM and never brings them back."""
+    import numpy as np
+    paths = [str(p) for p in paths]
+    if capacity is None:
+        capacity = 64
+        for p in paths:                                           # ISIZE of the last member's trailer (mod 2^32)
+            with open(p, "rb") as fh:
+                fh.seek(-4, 2)
+                capacity += int.from_bytes(fh.read(4), "little") + 64
+    out = np.empty(int(capacity), dtype=np.uint8)
+    lens = (C.c_uint64 * max(len(paths), 1))()
+    stats = (C.c_double * 16)()
+    arr = (C.c_char_p * max(len(paths), 1))(*[p.encode("utf-8") for p in paths])
+    rustcall(lib.smgpu_gunzip_files, arr, len(paths), out.ctypes.data_as(C.POINTER(C.c_uint8)), int(capacity), lens, stats)
+    res, at = [], 0
+    for i in range(len(paths)):
+        if lens[i] == 2**64 - 1:
+            res.append(None)
+        else:
+            res.append(out[at:at + lens[i]].tobytes())
+            at += lens[i]
+    keys = ("survivors", "candidates", "runs", "scan_ms", "pass1_ms", "link_ms", "pass2_ms", "finish_ms", "device_total_ms", "io_ms")
+    return res, dict(zip(keys, (float(v) for v in stats)))
+
+
+def gunzip_counters():
+    "(gzip files the ingest inflated on the device, files it handed to the host inflater after the device refused them)"
+    out = (C.c_uint64 * 2)()
+    lib.smgpu_gunzip_counters(out)
+    return int(out[0]), int(out[1])
