@@ -5,8 +5,8 @@
 // (a third of the inflated size for DNA) and every block of the member is decoded at once:
 //   gz_scan_kernel      a lane per input byte tests its 8 bit positions for a block header       (VALU: ~25 instructions per position)
 //   gz_validate_kernel  a lane per survivor reads the whole header                                (a few thousand lanes)
-//   gz_pass1_kernel     a wavefront per candidate walks the blocks of its run without output      (latency: one symbol after another)
-//   gz_pass2_kernel     a wavefront per run of the chain, symbols out 64 at a time                (the same, plus gathers from its own output)
+//   gz_pass1_kernel     a wavefront per candidate decodes the blocks of its run into 32-bit records (issue-bound: ~40 instructions a symbol, every CU full)
+//   gz_pass2_kernel     a wavefront per run of the chain expands its records, 64 output positions at a time (gathers from its own output)
 //   gz_tails_a/b_kernel the last 32 KB of every run: rewritten per group of runs, then the groups' windows in order (latency: ~2 sqrt(runs) steps)
 //   gz_resolve_kernel   symbols -> bytes against a 32 KB window in LDS                            (HBM: 2 B in, 1 B out per byte)
 //   gz_crc_kernel       CRC-32 of 64 KB chunks, a kilobyte per lane, joined by polynomial shifts  (LDS table lookups)
@@ -94,34 +94,37 @@ __global__ __launch_bounds__(64) void gz_validate_kernel(const uint32_t* __restr
 }
 
 __global__ __launch_bounds__(64, 6) void gz_pass1_kernel(const uint32_t* __restrict__ words, const GzCand* __restrict__ cands, uint32_t n,
-                                                      GzRunResult* __restrict__ res) {
+                                                      uint32_t* __restrict__ rec, GzRunResult* __restrict__ res) {
     __shared__ Scratch S;
     const uint32_t i = blockIdx.x;
     if (i >= n) return;
     const GzCand c = cands[i];
-    CountSink sink;
+    RecordSink sink;
+    sink.rec = rec + c.bit;
+    sink.cap = c.rec_cap;
     const RunResult r = decode_run(words, c.bit, c.limit_bit, S, sink, MAX_RUN_BYTES);
     if (threadIdx.x == 0) {
         GzRunResult o;
-        o.end_bit = r.end_bit; o.out_len = r.out_len; o.status = r.status; o.pad = 0;
+        o.end_bit = r.end_bit; o.out_len = r.out_len; o.status = r.status; o.n_records = r.n_records;
         res[i] = o;
     }
 }
 
-__global__ __launch_bounds__(64, 6) void gz_pass2_kernel(const uint32_t* __restrict__ words, const GzRunDesc* __restrict__ runs, uint32_t n,
-                                                      uint16_t* sym, GzRunResult* __restrict__ res) {
-    __shared__ Scratch S;
+__global__ __launch_bounds__(64) void gz_pass2_kernel(const uint32_t* __restrict__ words, const uint32_t* __restrict__ rec,
+                                                   const GzRunDesc* __restrict__ runs, uint32_t n, uint16_t* sym, GzRunResult* __restrict__ res) {
+    __shared__ ExpandScratch X;
     const uint32_t i = blockIdx.x;
     if (i >= n) return;
     const GzRunDesc d = runs[i];
-    WaveSink sink;
-    sink.out = sym + d.out_off;
-    sink.cap = d.out_len;
-    sink.no_window = d.first_of_member != 0;
-    const RunResult r = decode_run(words, d.bit, d.limit_bit, S, sink, d.out_len);
+    Expander ex;
+    ex.out = sym + d.out_off;
+    ex.cap = d.out_len;
+    ex.bytes = reinterpret_cast<const uint8_t*>(words);
+    ex.no_window = d.first_of_member != 0;
+    ex.run(rec + d.bit, d.n_records, X);
     if (threadIdx.x == 0) {
         GzRunResult o;
-        o.end_bit = r.end_bit; o.out_len = sink.g0; o.status = r.status; o.pad = 0;
+        o.end_bit = 0; o.out_len = ex.g0; o.status = ex.bad ? RUN_BAD_DISTANCE : RUN_OK; o.n_records = d.n_records;
         res[i] = o;
     }
 }
@@ -336,15 +339,16 @@ hipError_t gz_scan_launch(const uint32_t* words, uint64_t n_bytes, uint64_t* d_s
     return hipGetLastError();
 }
 
-hipError_t gz_pass1_launch(const uint32_t* words, const GzCand* d_cands, uint32_t n, GzRunResult* d_res, hipStream_t stream) {
+hipError_t gz_pass1_launch(const uint32_t* words, const GzCand* d_cands, uint32_t n, uint32_t* d_rec, GzRunResult* d_res, hipStream_t stream) {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(gz_pass1_kernel, dim3(n), dim3(64), 0, stream, words, d_cands, n, d_res);
+    hipLaunchKernelGGL(gz_pass1_kernel, dim3(n), dim3(64), 0, stream, words, d_cands, n, d_rec, d_res);
     return hipGetLastError();
 }
 
-hipError_t gz_pass2_launch(const uint32_t* words, const GzRunDesc* d_runs, uint32_t n, uint16_t* d_sym, GzRunResult* d_res, hipStream_t stream) {
+hipError_t gz_pass2_launch(const uint32_t* words, const uint32_t* d_rec, const GzRunDesc* d_runs, uint32_t n, uint16_t* d_sym, GzRunResult* d_res,
+                           hipStream_t stream) {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(gz_pass2_kernel, dim3(n), dim3(64), 0, stream, words, d_runs, n, d_sym, d_res);
+    hipLaunchKernelGGL(gz_pass2_kernel, dim3(n), dim3(64), 0, stream, words, d_rec, d_runs, n, d_sym, d_res);
     return hipGetLastError();
 }
 

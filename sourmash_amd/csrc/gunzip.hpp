@@ -25,6 +25,7 @@ struct GunzipMember {
     std::string why;
     uint64_t out_off = 0, out_len = 0;       // its inflated bytes inside the output block
     uint32_t n_runs = 0;
+    uint8_t first_byte = 0;                  // of the inflated bytes ('>' FASTA, '@' FASTQ: the ingest picks its parser by it)
 };
 
 struct GunzipStats {
@@ -54,7 +55,7 @@ inline void gunzip_device(const uint8_t* h_files, const uint8_t* d_files, uint64
     for (size_t i = 0; i < members.size(); ++i) {
         GunzipMember& m = members[i];
         m.ok = false; m.why.clear(); m.out_off = m.out_len = 0; m.n_runs = 0;
-        if ((m.file_off & 7) || m.file_off + m.file_len > total_bytes) { m.why = "member outside the buffer"; continue; }
+        if ((m.file_off & 7) || m.file_off + m.file_len > total_bytes || total_bytes >= ((uint64_t)1 << 32)) { m.why = "member outside the buffer"; continue; }
         if (!parse_single_member(h_files + m.file_off, m.file_len, hdr[i])) { m.why = "not a gzip member"; continue; }
         m.ok = true;
         ++n_live;
@@ -95,16 +96,19 @@ inline void gunzip_device(const uint8_t* h_files, const uint8_t* d_files, uint64
         r.first_bit = (members[i].file_off + hdr[i].deflate_byte) * 8;
         r.trailer_bit = (members[i].file_off + members[i].file_len - 8) * 8;
         r.c0 = cands.size();
-        cands.push_back(GzCand{r.first_bit, r.trailer_bit});
+        cands.push_back(GzCand{r.first_bit, r.trailer_bit, 0});
         auto it = std::upper_bound(bits.begin(), bits.end(), r.first_bit);
-        for (; it != bits.end() && *it < r.trailer_bit; ++it) cands.push_back(GzCand{*it, r.trailer_bit});
+        for (; it != bits.end() && *it < r.trailer_bit; ++it) cands.push_back(GzCand{*it, r.trailer_bit, 0});
         r.c1 = cands.size();
+        // a candidate's records go to [its bit, the next candidate's bit) of the record buffer: no run can write into another's
+        for (size_t k = r.c0; k < r.c1; ++k) cands[k].rec_cap = (k + 1 < r.c1 ? cands[k + 1].bit : r.trailer_bit) - cands[k].bit;
     }
     st.candidates = cands.size();
     if (cands.size() > 0x7fffffffull) throw err_internal("gunzip: too many candidates");
     AsyncBuf d_cands(cands.size() * sizeof(GzCand), stream), d_res(cands.size() * sizeof(GzRunResult), stream);
+    AsyncBuf d_rec((size_t)total_bytes * 8 * 4 + 256, stream);         // one record slot per bit of the buffer (inflate_core.hpp: RecordSink)
     hip_check(hipMemcpyAsync(d_cands.p, cands.data(), cands.size() * sizeof(GzCand), hipMemcpyHostToDevice, stream), "H2D");
-    hip_check(gz_pass1_launch(words, d_cands.as<GzCand>(), (uint32_t)cands.size(), d_res.as<GzRunResult>(), stream), "gz_pass1");
+    hip_check(gz_pass1_launch(words, d_cands.as<GzCand>(), (uint32_t)cands.size(), d_rec.as<uint32_t>(), d_res.as<GzRunResult>(), stream), "gz_pass1");
     std::vector<GzRunResult> res(cands.size());
     hip_check(hipMemcpyAsync(res.data(), d_res.p, res.size() * sizeof(GzRunResult), hipMemcpyDeviceToHost, stream), "D2H");
     hip_check(hipStreamSynchronize(stream), "sync");
@@ -127,7 +131,7 @@ inline void gunzip_device(const uint8_t* h_files, const uint8_t* d_files, uint64
         std::vector<Cand> cs(r.c1 - r.c0);
         for (size_t k = r.c0; k < r.c1; ++k) {
             Cand& c = cs[k - r.c0];
-            c.bit = cands[k].bit; c.end_bit = res[k].end_bit; c.out_len = res[k].out_len; c.status = res[k].status;
+            c.bit = cands[k].bit; c.end_bit = res[k].end_bit; c.out_len = res[k].out_len; c.status = res[k].status; c.n_records = res[k].n_records;
         }
         const std::vector<uint32_t> chain = link_chain(cs, r.first_bit, r.trailer_bit, m.why);
         if (chain.empty()) { m.ok = false; continue; }
@@ -156,8 +160,8 @@ inline void gunzip_device(const uint8_t* h_files, const uint8_t* d_files, uint64
                 groups.push_back(g);
             }
             GzRunDesc d;
-            d.bit = c.bit; d.limit_bit = r.trailer_bit; d.out_off = total_out + at; d.out_len = c.out_len;
-            d.first_of_member = k == 0; d.member = (uint32_t)mdesc.size();
+            d.bit = c.bit; d.out_off = total_out + at; d.out_len = c.out_len; d.n_records = c.n_records;
+            d.first_of_member = k == 0; d.member = (uint32_t)mdesc.size(); d.pad = 0;
             runs.push_back(d);
             GzPiece p;
             p.base = total_out; p.member = (uint32_t)mdesc.size(); p.pad = 0;
@@ -207,7 +211,7 @@ inline void gunzip_device(const uint8_t* h_files, const uint8_t* d_files, uint64
         hip_check(hipMemcpyAsync(d_groups.p, groups.data(), groups.size() * sizeof(GzGroupDesc), hipMemcpyHostToDevice, stream), "H2D");
         if (!chunks.empty()) hip_check(hipMemcpyAsync(d_chunks.p, chunks.data(), chunks.size() * sizeof(GzChunk), hipMemcpyHostToDevice, stream), "H2D");
         hip_check(hipMemsetAsync(d_err.p, 0, mdesc.size() * 4 + 4, stream), "memset");
-        hip_check(gz_pass2_launch(words, d_runs.as<GzRunDesc>(), (uint32_t)runs.size(), sym.as<uint16_t>(), d_res2.as<GzRunResult>(), stream), "gz_pass2");
+        hip_check(gz_pass2_launch(words, d_rec.as<uint32_t>(), d_runs.as<GzRunDesc>(), (uint32_t)runs.size(), sym.as<uint16_t>(), d_res2.as<GzRunResult>(), stream), "gz_pass2");
         if (stats) { hip_check(hipStreamSynchronize(stream), "sync"); st.pass2_ms = ms_since(t0); t0 = clk::now(); }
         hip_check(gz_tails_launch(sym.as<uint16_t>(), (uint8_t*)out, d_runs.as<GzRunDesc>(), d_groups.as<GzGroupDesc>(), (uint32_t)groups.size(),
                                   d_m.as<GzMemberDesc>(), (uint32_t)mdesc.size(), d_err.as<uint32_t>(), stream), "gz_tails");
@@ -219,6 +223,9 @@ inline void gunzip_device(const uint8_t* h_files, const uint8_t* d_files, uint64
         hip_check(hipMemcpyAsync(res2.data(), d_res2.p, res2.size() * sizeof(GzRunResult), hipMemcpyDeviceToHost, stream), "D2H");
         hip_check(hipMemcpyAsync(err.data(), d_err.p, err.size() * 4, hipMemcpyDeviceToHost, stream), "D2H");
         if (!crc.empty()) hip_check(hipMemcpyAsync(crc.data(), d_crc.p, crc.size() * 4, hipMemcpyDeviceToHost, stream), "D2H");
+        for (size_t j = 0; j < mdesc.size(); ++j)
+            if (members[mindex[j]].out_len)
+                hip_check(hipMemcpyAsync(&members[mindex[j]].first_byte, (const uint8_t*)out + mdesc[j].base, 1, hipMemcpyDeviceToHost, stream), "D2H");
         hip_check(hipStreamSynchronize(stream), "sync");
         // ---- the checks ----
         const uint32_t x64k = crc_xpow8(65536);

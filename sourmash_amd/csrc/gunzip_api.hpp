@@ -11,16 +11,18 @@ constexpr size_t GZ_COUNTS = 8 + 256;
 
 struct GzCand {                 // a block start to decode from (pass 1)
     uint64_t bit, limit_bit;    // limit: where its member's trailer begins
+    uint64_t rec_cap;           // records it may write (at d_rec + bit): up to the next candidate's first bit
 };
 struct GzRunResult {
     uint64_t end_bit, out_len;
-    uint32_t status, pad;       // inf::RUN_*
+    uint32_t status, n_records; // inf::RUN_*
 };
 struct GzRunDesc {              // a run of the chain (pass 2, tails)
-    uint64_t bit, limit_bit;
+    uint64_t bit;               // its records begin at d_rec + bit
     uint64_t out_off;           // first symbol / byte of the run in the symbol and output buffers
     uint64_t out_len;
-    uint32_t first_of_member, member;
+    uint32_t n_records;
+    uint32_t first_of_member, member, pad;
 };
 struct GzMemberDesc {
     uint64_t base;              // first byte of the member in the output buffer
@@ -47,8 +49,11 @@ struct GzChunk {                // up to 64 KB of output (crc)
 // cap) the lists are incomplete.
 hipError_t gz_scan_launch(const uint32_t* words, uint64_t n_bytes, uint64_t* d_surv, uint64_t* d_valid, unsigned long long* d_counts,
                           uint64_t cap, hipStream_t stream);
-hipError_t gz_pass1_launch(const uint32_t* words, const GzCand* d_cands, uint32_t n, GzRunResult* d_res, hipStream_t stream);
-hipError_t gz_pass2_launch(const uint32_t* words, const GzRunDesc* d_runs, uint32_t n, uint16_t* d_sym, GzRunResult* d_res, hipStream_t stream);
+// pass 1: candidate i decodes from its bit and leaves its symbols as records at d_rec + bit (d_rec: one u32 per BIT of the buffer)
+hipError_t gz_pass1_launch(const uint32_t* words, const GzCand* d_cands, uint32_t n, uint32_t* d_rec, GzRunResult* d_res, hipStream_t stream);
+// pass 2: the records of every run of the chain -> 16-bit symbols at the run's place (d_res[i].out_len = symbols written, status)
+hipError_t gz_pass2_launch(const uint32_t* words, const uint32_t* d_rec, const GzRunDesc* d_runs, uint32_t n, uint16_t* d_sym, GzRunResult* d_res,
+                           hipStream_t stream);
 // d_err[member] |= 1: a symbol points in front of its member.  Rewrites the tail symbols of d_sym (see gunzip.hip).
 hipError_t gz_tails_launch(uint16_t* d_sym, uint8_t* d_out, const GzRunDesc* d_runs, const GzGroupDesc* d_groups, uint32_t n_groups,
                            const GzMemberDesc* d_members, uint32_t n_members, uint32_t* d_err, hipStream_t stream);

@@ -419,28 +419,58 @@ SMG_HD bool valid_dynamic_header(const uint32_t* words, uint64_t bit, uint64_t e
     return true;
 }
 
-// ---- sinks: what a decoded run is turned into ----
+// ---- pass 1's sink: the symbols of a run as 32-bit records, and the number of bytes they make ----
+// A record: 0x80000000 | byte (a literal), or (distance - 1) << 9 | length (a match), or -- a stored block -- the pair
+// 0x40000000 | length, byte offset of its bytes in the buffer.  A symbol takes at least one bit of the stream and a stored
+// block at least 32, so the records of the run that begins at bit b fit into [b, end bit of the run) of a record buffer as long
+// as the stream is in bits: no run needs to know how many symbols the runs in front of it hold.  (A FALSE block start inside
+// a real run may write into that run's stretch; gunzip.hpp refuses the member if a candidate's first bit lies inside the
+// records of a run of the chain.)
+constexpr uint32_t REC_LITERAL = 0x80000000u, REC_STORED = 0x40000000u;
 
-// pass 1: only the number of bytes
-struct CountSink {
-    uint64_t n = 0;             // what the uniform path counted
-    uint32_t acc[SMG_INF_LANES];// what each lane's real symbols made (batch): two vector instructions a batch, one sum a run
+SMG_HD uint32_t popc64(uint64_t m) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint32_t)__popcll(m);
+#else
+    uint32_t n = 0;
+    for (; m; m &= m - 1) ++n;
+    return n;
+#endif
+}
+
+struct RecordSink {
+    uint32_t* rec = nullptr;    // the run's stretch of the record buffer (nullptr: count only)
+    uint64_t cap = 0;           // records it may hold
+    uint32_t n = 0;             // records written
+    uint64_t nb = 0;            // bytes made by what the uniform path recorded
+    uint32_t acc[SMG_INF_LANES];// bytes made by each lane's symbols of the batches: two vector instructions a batch, one sum a run
     bool bad = false;
-    SMG_HD CountSink() { SMG_INF_EACH_LANE(lane, slot) { (void)lane; acc[slot] = 0; } }
-    SMG_HD void literal(uint32_t) { ++n; }
-    SMG_HD void match(uint32_t len, uint32_t) { n += len; }
-    SMG_HD void stored(const uint8_t*, uint32_t len) { n += len; }
+    SMG_HD RecordSink() { SMG_INF_EACH_LANE(lane, slot) { (void)lane; acc[slot] = 0; } }
+    SMG_HD void put(uint32_t r) {
+        if (n >= cap) { bad = true; return; }
+        if (rec) { SMG_INF_EACH_LANE(lane, slot) { (void)slot; if (lane == 0u) rec[n] = r; } }
+        ++n;
+    }
+    SMG_HD void literal(uint32_t b) { put(REC_LITERAL | b); ++nb; }
+    SMG_HD void match(uint32_t len, uint32_t dist) { put(((dist - 1u) << 9) | len); nb += len; }
+    SMG_HD void stored(uint64_t byte_off, uint32_t len) { put(REC_STORED | len); put((uint32_t)byte_off); nb += len; }
     // the real symbols of a batch: bit l of mask <-> the symbol that begins at bit offset l; L: 0x80000000 | literal, or the
-    // length of a match; D: its distance
+    // length of a match; D: its distance.  Lane l's record goes to slot n + (real symbols in front of l).
     SMG_HD void batch(uint64_t mask, const uint32_t (&L)[SMG_INF_LANES], const uint32_t (&D)[SMG_INF_LANES]) {
-        (void)D;
+        const uint32_t k = popc64(mask);
+        if ((uint64_t)n + k > cap) { bad = true; return; }
         SMG_INF_EACH_LANE(lane, slot) {
-            if ((mask >> lane) & 1u) acc[slot] += L[slot] & 0x80000000u ? 1u : L[slot];
+            if ((mask >> lane) & 1u) {
+                const uint32_t x = L[slot];
+                acc[slot] += x & 0x80000000u ? 1u : x;
+                if (rec) rec[n + popc64(mask & ((1ull << lane) - 1ull))] = x & 0x80000000u ? x : (((D[slot] - 1u) << 9) | x);
+            }
         }
+        n += k;
     }
     SMG_HD void finish() {}
     SMG_HD uint64_t total() const {
-        uint64_t t = n;
+        uint64_t t = nb;
 #if defined(__HIP_DEVICE_COMPILE__)
         uint32_t a = acc[0];                                          // (a run is cut off long before 2^32 bytes: decode_run's batch limit)
         for (int o = 32; o; o >>= 1) a += __shfl_xor(a, o);
@@ -452,133 +482,39 @@ struct CountSink {
     }
 };
 
-// pass 2: 16-bit symbols at their final place.  The decoder is uniform across the wavefront; the sink gives every symbol's
-// bytes to the next free lanes of a 64-wide group (lane i <-> output position g0 + i), and when the group is full the lanes
-// gather their sources (the run's own earlier output, or a marker for what lies in front of the run) and store 64 symbols side
-// by side.  A match whose source is in the unstored group flushes first; then every source of it lies behind stores already
-// issued -- same wavefront, program order -- and an overlapping match (distance < length) reads its period.
+// ---- pass 2: records -> 16-bit symbols at their final place, 64 output positions at a time ----
+// No code is decoded any more: 64 records are read side by side, a prefix sum of their lengths places them, and every output
+// position finds its record by a binary search over those places (wave-private LDS).  A match whose source lies in the bytes
+// of the same round -- distance < bytes in front of its end, and it is not the round's first record -- ends the round in
+// front of it: everything it reads is then behind stores already issued (same wavefront, program order).  The gather of a
+// tile is ISSUED and its store waits for the next tile (the trip to memory hides behind the next tile's search).
+struct ExpandScratch { uint32_t pos[64], rec[64]; };
 
-struct WaveSink {
+struct Expander {
     uint16_t* out;              // the run's first symbol
     uint64_t cap;               // symbols the run may write (pass 1's count)
+    const uint8_t* bytes;       // the buffer of the files (stored blocks)
     bool no_window;             // the member's first run: nothing in front of it
-    uint32_t g0 = 0, o = 0;     // output position of lane 0 of the open group; lanes filled
     bool bad = false;
-    uint32_t pend_g0 = 0, pend_n = 0;   // a group whose gather is under way: first position, lanes
+    uint32_t g0 = 0;            // symbols written (or under way)
+    uint32_t pend_g0 = 0, pend_n = 0;
     uint16_t pend[SMG_INF_LANES];
-    int32_t src[SMG_INF_LANES]; // per lane: >= 0 literal symbol | 0x40000000; else source position relative to the run start, as (pos - 2^30) ... see below
-    // encoding of src: bit 30 set -> literal in bits 0..15; otherwise a signed position (negative: in front of the run)
 
-    SMG_HD void literal(uint32_t b) {
-        { SMG_INF_EACH_LANE(lane, slot) { if (lane == o) src[slot] = (int32_t)(0x40000000u | b); } }
-        if (++o == 64u) flush();
+    SMG_HD void commit() {
+        if (!pend_n) return;
+        { SMG_INF_EACH_LANE(lane, slot) { if (lane < pend_n) out[pend_g0 + lane] = pend[slot]; } }
+#if defined(__HIP_DEVICE_COMPILE__)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");       // the stores above are in front of every later load of this wavefront
+#endif
+        pend_n = 0;
     }
-    // The real symbols of a batch at once: their bytes go to the next free lanes of the open group (lane <-> output position),
-    // which is stored when it is full.  The uniform loop over the symbols tells every lane whether it lies in the symbol (2
-    // lane reads and ~5 vector instructions a symbol).  A match whose source lies in the unstored group flushes it first; one
-    // whose source reaches into the batch's own bytes sends the batch through the symbol-by-symbol path.
-    SMG_HD void batch(uint64_t mask, const uint32_t (&L)[SMG_INF_LANES], const uint32_t (&D)[SMG_INF_LANES]) {
-        uint32_t total = 0;
-        bool near_group = false, near_self = false;
-        for (uint64_t m = mask; m; m &= m - 1) {
-            const uint32_t l = ctz64(m);
-            const uint32_t x = lane_read(L, l);
-            if (x & 0x80000000u) ++total;
-            else {
-                total += x;
-                const uint32_t d = lane_read(D, l);
-                near_self = near_self || d < total;
-                near_group = near_group || d < o + total;
-            }
-        }
-        if (near_group && o) flush();
-        if (near_self) {
-            for (uint64_t m = mask; m; m &= m - 1) {
-                const uint32_t l = ctz64(m);
-                const uint32_t x = lane_read(L, l);
-                if (x & 0x80000000u) literal(x & 0xffu);
-                else match(x, lane_read(D, l));
-            }
-            return;
-        }
-        const uint32_t base = g0 + o;                                 // position of the batch's first byte
-        uint32_t done = 0;
-        while (done < total) {
-            const uint32_t take = total - done < 64u - o ? total - done : 64u - o;
-            uint32_t at = 0;
-            for (uint64_t m = mask; m; m &= m - 1) {
-                const uint32_t l = ctz64(m);
-                const uint32_t x = lane_read(L, l);
-                if (x & 0x80000000u) {
-                    { SMG_INF_EACH_LANE(lane, slot) {
-                        if (lane - o < take && done + (lane - o) == at) src[slot] = (int32_t)(0x40000000u | (x & 0xffu));
-                    } }
-                    ++at;
-                } else {
-                    const uint32_t d = lane_read(D, l);
-                    { SMG_INF_EACH_LANE(lane, slot) {
-                        const uint32_t j = done + (lane - o);
-                        if (lane - o < take && j - at < x) {
-                            const int64_t p = (int64_t)base + j - (int64_t)d;
-                            src[slot] = (int32_t)(p < -(int64_t)WIN ? -(int32_t)WIN - 1 : p);
-                        }
-                    } }
-                    at += x;
-                }
-                if (at >= done + take) break;
-            }
-            o += take;
-            done += take;
-            if (o == 64u) flush();
-        }
-    }
-    SMG_HD void match(uint32_t len, uint32_t dist) {
-        uint32_t k0 = 0;
-        int64_t mstart = (int64_t)g0 + o;
-        while (k0 < len) {
-            uint32_t n = len - k0 < 64u - o ? len - k0 : 64u - o;
-            if (o > 0 && dist < o + n) {                              // a source in the unstored group: store it first
-                flush();
-                n = len - k0 < 64u ? len - k0 : 64u;
-            }
-            const int64_t base = mstart - (int64_t)dist;
-            const bool periodic = dist < len;
-            { SMG_INF_EACH_LANE(lane, slot) {
-                const uint32_t i = lane - o;
-                if (i < n) {
-                    uint32_t idx = k0 + i;
-                    if (periodic) idx %= dist;
-                    const int64_t p = base + idx;
-                    src[slot] = (int32_t)(p < -(int64_t)WIN ? -(int32_t)WIN - 1 : p);      // (beyond the window: flagged at the flush)
-                }
-            } }
-            o += n;
-            k0 += n;
-            if (o == 64u) flush();
-        }
-    }
-    SMG_HD void stored(const uint8_t* bytes, uint32_t len) {
-        uint32_t k = 0;
-        while (k < len) {
-            const uint32_t n = len - k < 64u - o ? len - k : 64u - o;
-            { SMG_INF_EACH_LANE(lane, slot) {
-                const uint32_t i = lane - o;
-                if (i < n) src[slot] = (int32_t)(0x40000000u | bytes[k + i]);
-            } }
-            o += n;
-            k += n;
-            if (o == 64u) flush();
-        }
-    }
-    // The group's gather is ISSUED here and its store waits for the next flush: the symbols decoded in between hide the
-    // trip to memory (a wavefront makes thousands of these trips one after the other).  The store of the group in front goes
-    // out first -- same wavefront, program order: the gather below sees it.
-    SMG_HD void flush() {
-        if ((uint64_t)g0 + o > cap) { bad = true; o = 0; return; }
+    // a tile: lane j <-> output position g0 + j, src as WaveSink's: 0x40000000 | symbol, or a position relative to the run start
+    SMG_HD void tile(const int32_t (&src)[SMG_INF_LANES], uint32_t n) {
+        if ((uint64_t)g0 + n > cap) { bad = true; return; }
         commit();
         bool wrong = false;
         { SMG_INF_EACH_LANE(lane, slot) {
-            if (lane < o) {
+            if (lane < n) {
                 const int32_t s = src[slot];
                 uint16_t sym;
                 if ((s & 0x40000000) && s >= 0) sym = (uint16_t)(s & 0xffff);
@@ -593,25 +529,95 @@ struct WaveSink {
 #endif
         if (wrong) bad = true;
         pend_g0 = g0;
-        pend_n = o;
-        g0 += o;
-        o = 0;
+        pend_n = n;
+        g0 += n;
     }
-    SMG_HD void commit() {
-        if (!pend_n) return;
-        { SMG_INF_EACH_LANE(lane, slot) { if (lane < pend_n) out[pend_g0 + lane] = pend[slot]; } }
+
+    SMG_HD void run(const uint32_t* rec, uint32_t n_rec, ExpandScratch& X) {
+        uint32_t r0 = 0;
+        while (r0 < n_rec && !bad) {
+            // 64 records side by side
+            uint32_t R[SMG_INF_LANES], LEN[SMG_INF_LANES], POS[SMG_INF_LANES];
+            { SMG_INF_EACH_LANE(lane, slot) {
+                const uint32_t i = r0 + lane;
+                const uint32_t r = i < n_rec ? rec[i] : REC_STORED;     // (behind the end: stops the round like a stored block does)
+                R[slot] = r;
+                LEN[slot] = r & REC_LITERAL ? 1u : r & REC_STORED ? 0u : r & 0x1ffu;
+            } }
+            uint32_t total = 0;
 #if defined(__HIP_DEVICE_COMPILE__)
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");       // the stores above are in front of every later load of this wavefront
+            {
+                uint32_t v = LEN[0];
+                const uint32_t lane = threadIdx.x & 63u;
+                for (int o = 1; o < 64; o <<= 1) { const uint32_t u = __shfl_up(v, o); if (lane >= (uint32_t)o) v += u; }
+                POS[0] = v - LEN[0];
+                total = __shfl(v, 63);
+            }
+#else
+            for (uint32_t l = 0; l < 64u; ++l) { POS[l] = total; total += LEN[l]; }
 #endif
-        pend_n = 0;
+            // the round ends in front of the first record that cannot go with the ones before it
+            uint64_t stop = 0;
+            { SMG_INF_EACH_LANE(lane, slot) {
+                const uint32_t r = R[slot];
+                bool s = (r & (REC_LITERAL | REC_STORED)) == REC_STORED;
+                if (!(r & (REC_LITERAL | REC_STORED))) s = POS[slot] >= 1u && (r >> 9) + 1u < POS[slot] + LEN[slot];
+#if defined(__HIP_DEVICE_COMPILE__)
+                (void)lane;
+                stop = __builtin_amdgcn_ballot_w64(s);
+#else
+                if (s) stop |= 1ull << lane;
+#endif
+            } }
+            const uint32_t h = stop ? ctz64(stop) : 64u;
+            if (h == 0u) {                                            // a stored block (or nothing left): by itself
+                const uint32_t r = lane_read(R, 0);
+                if (r0 + 1u >= n_rec) { bad = true; break; }
+                const uint32_t len = r & 0xffffu;
+                const uint64_t off = lane_read(R, 1);
+                for (uint32_t k = 0; k < len; k += 64u) {
+                    int32_t src[SMG_INF_LANES];
+                    const uint32_t m = len - k < 64u ? len - k : 64u;
+                    { SMG_INF_EACH_LANE(lane, slot) { src[slot] = lane < m ? (int32_t)(0x40000000u | bytes[off + k + lane]) : 0; } }
+                    tile(src, m);
+                }
+                r0 += 2u;
+                continue;
+            }
+            const uint32_t T = h < 64u ? lane_read(POS, h) : total;
+            { SMG_INF_EACH_LANE(lane, slot) { X.pos[lane] = lane < h ? POS[slot] : 0xffffffffu; X.rec[lane] = R[slot]; } }
+            const uint32_t base = g0;
+            for (uint32_t t0 = 0; t0 < T; t0 += 64u) {
+                int32_t src[SMG_INF_LANES];
+                const uint32_t m = T - t0 < 64u ? T - t0 : 64u;
+                { SMG_INF_EACH_LANE(lane, slot) {
+                    const uint32_t j = t0 + lane;
+                    uint32_t lo = 0;                                  // the last record whose place is <= j
+                    for (uint32_t step = 32u; step; step >>= 1) if (X.pos[lo + step] <= j) lo += step;
+                    const uint32_t r = X.rec[lo];
+                    int32_t sv;
+                    if (r & REC_LITERAL) sv = (int32_t)(0x40000000u | (r & 0xffu));
+                    else {
+                        const uint32_t len = r & 0x1ffu, dist = (r >> 9) + 1u;
+                        uint32_t k = j - X.pos[lo];
+                        if (dist < len) k %= dist;
+                        const int64_t p = (int64_t)base + X.pos[lo] - (int64_t)dist + k;
+                        sv = (int32_t)(p < -(int64_t)WIN ? -(int32_t)WIN - 1 : p);
+                    }
+                    src[slot] = lane < m ? sv : 0;
+                } }
+                tile(src, m);
+            }
+            r0 += h;
+        }
+        commit();
     }
-    SMG_HD void finish() { if (o) flush(); commit(); }
-    SMG_HD uint64_t total() const { return g0; }
 };
 
 struct RunResult {
     uint64_t end_bit;           // where the run stopped: the next dynamic non-final header, or behind the final block
     uint64_t out_len;
+    uint32_t n_records;
     uint32_t status;            // RUN_OK: stopped in front of a block header; RUN_FINAL: the stream's last block is done; else an error
 };
 
@@ -654,7 +660,7 @@ SMG_HD RunResult decode_run(const uint32_t* words, uint64_t bit, uint64_t end_bi
             if ((len ^ nlen) != 0xffffu) { r.status = RUN_BAD_BLOCK; break; }
             const uint64_t at = br.pos();
             if (at + (uint64_t)len * 8 > br.end) { r.status = RUN_PAST_END; break; }
-            sink.stored(reinterpret_cast<const uint8_t*>(words) + (at >> 3), len);
+            sink.stored(at >> 3, len);
             br.init(words, at + (uint64_t)len * 8, end_bit);
         } else if (type == 3) {
             r.status = RUN_BAD_BLOCK;
@@ -747,9 +753,10 @@ SMG_HD RunResult decode_run(const uint32_t* words, uint64_t bit, uint64_t end_bi
         if (final_block) { r.status = RUN_FINAL; break; }
     }
     sink.finish();
-    if (sink.bad && (r.status == RUN_OK || r.status == RUN_FINAL)) r.status = RUN_BAD_DISTANCE;
+    if (sink.bad && (r.status == RUN_OK || r.status == RUN_FINAL)) r.status = RUN_TOO_LONG;
     r.end_bit = br.pos();
     r.out_len = sink.total();
+    r.n_records = sink.n;
     if (r.out_len > max_out && (r.status == RUN_OK || r.status == RUN_FINAL)) r.status = RUN_TOO_LONG;
     return r;
 }
@@ -815,7 +822,7 @@ inline bool parse_single_member(const uint8_t* p, uint64_t size, Member& m) {
 // a candidate block start after pass 1
 struct Cand {
     uint64_t bit = 0, end_bit = 0, out_len = 0;
-    uint32_t status = 0;
+    uint32_t status = 0, n_records = 0;
 };
 
 // The chain of runs from `first_bit` to the end of the final block.  cands: sorted by bit, holding first_bit itself.

@@ -283,7 +283,7 @@ inline void* gunzip_file_to_device(IngestScratch& scratch, const std::string& pa
     struct stat sb;
     if (fstat(fd, &sb) != 0 || !S_ISREG(sb.st_mode)) return nullptr;
     const uint64_t size = (uint64_t)sb.st_size;
-    constexpr uint64_t MAX_FILE = (uint64_t)4 << 30;                  // (symbols + bytes of the inflated member are resident at once)
+    constexpr uint64_t MAX_FILE = (uint64_t)2 << 30;                  // (resident at once: 32 B of records per input byte, symbols + bytes of the output)
     if (size < 26 || size > MAX_FILE) { if (why) *why = "file size outside the device inflater's range"; return nullptr; }
     uint8_t magic[3] = {0, 0, 0};
     if (::pread(fd, magic, 3, 0) != 3 || magic[0] != 0x1f || magic[1] != 0x8b || magic[2] != 8) return nullptr;
@@ -522,6 +522,144 @@ inline void sketch_file_with(IngestWorker& w, std::vector<KmerMinHash*>& mhs, co
                 path.c_str(), t_loop - t_start, t_wait, t_sync, now() - t_loop);
 }
 
+// Many small files whose bytes are in HBM already (a batch of gzip members inflated together) sketched TOGETHER: the per-file
+// pipeline above reads back counts after every chunk and sorts per sketch -- a dozen stream synchronisations per file, which is
+// all a single genome costs.  Here every file's parse + k-mer launches are queued without a read-back (each file's compacted
+// bytes land in its own region of one block pre-filled with separators, so the k-mer kernel can be given the raw length as an
+// upper bound), the counts of all files come back in ONE copy, the per-sketch sorts are queued, and the sketches come back
+// in one more.  done[i] = true for the files served; the others (too large, bottom-k sketches, an output estimate exceeded)
+// take the per-file path.
+inline void sketch_slices_batched(IngestWorker& w, const std::vector<InflatedSlice>& slices, const std::vector<uint8_t>& first_bytes,
+                                  std::vector<Signature>& sigs, std::vector<uint64_t>& bases_out, std::vector<bool>& done) {
+    const size_t n = slices.size();
+    done.assign(n, false);
+    bases_out.assign(n, 0);
+    constexpr uint64_t MAX_LEN = (uint64_t)32 << 20;
+    hipStream_t st = w.stream;
+    std::vector<size_t> idx;
+    uint64_t max_len = 0;
+    uint32_t kmax = 0;
+    size_t n_sk = 0;
+    for (size_t i = 0; i < n; ++i) {
+        if (!slices[i].p || slices[i].len == 0 || slices[i].len > MAX_LEN) continue;
+        bool ok = !sigs[i].sketches.empty();
+        for (auto& mh : sigs[i].sketches) ok = ok && mh.is_dna() && mh.num == 0 && mh.max_hash != 0 && mh.ksize >= 1 && mh.ksize <= 256;
+        if (!ok) continue;
+        idx.push_back(i);
+        max_len = std::max(max_len, slices[i].len);
+        for (auto& mh : sigs[i].sketches) kmax = std::max(kmax, mh.ksize);
+        n_sk = std::max(n_sk, sigs[i].sketches.size());
+    }
+    if (idx.empty()) return;
+    // (the parser's scratch for the longest file of the batch; the worker's own chunk buffers stay at their 4 MiB)
+    const size_t parse_temp_bytes = fastx_temp_bytes(max_len);
+    AsyncBuf parse_state((size_t)max_len + 64, st), parse_temp(parse_temp_bytes, st);
+    (void)kmax;
+    constexpr size_t HALO = 256;
+    // layout: per file a region of the compacted-bytes block, 32 bytes of scalars, and per sketch an output region + 16 bytes of counts
+    struct Slot { uint64_t comp_off, out_off[8], cap[8]; };
+    if (n_sk > 8) return;
+    std::vector<Slot> slot(idx.size());
+    uint64_t comp_bytes = 0, out_entries = 0;
+    for (size_t j = 0; j < idx.size(); ++j) {
+        const size_t i = idx[j];
+        slot[j].comp_off = comp_bytes + HALO;
+        comp_bytes += HALO + ((slices[i].len + 64 + 255) & ~255ull);
+        for (size_t q = 0; q < sigs[i].sketches.size(); ++q) {
+            const KmerMinHash& mh = sigs[i].sketches[q];
+            const double frac = (double)mh.max_hash / 18446744073709551616.0;
+            const double len = (double)slices[i].len;
+            const uint64_t cap = std::min<uint64_t>(slices[i].len, (uint64_t)(len * frac * 2.0 + 16.0 * std::sqrt(len * frac + 1.0)) + 4096);
+            slot[j].out_off[q] = out_entries;
+            slot[j].cap[q] = cap;
+            out_entries += cap;
+        }
+    }
+    const size_t per_file_scalars = 32 + 16 * 8;                       // carry (4) | n_kept (8 @ 8) | records (8 @ 16); then 8 x {count, unique}
+    AsyncBuf comp(comp_bytes + 256, st), outs(out_entries * 8 + 256, st), small(idx.size() * per_file_scalars + 64, st);
+    hip_check(hipMemsetAsync(comp.p, '\n', comp_bytes + 256, st), "memset");
+    std::vector<uint8_t> h_small(idx.size() * per_file_scalars, 0);
+    std::vector<int> fastq(idx.size());
+    for (size_t j = 0; j < idx.size(); ++j) {
+        fastq[j] = first_bytes[idx[j]] == '@' ? 1 : 0;
+        uint8_t* c = h_small.data() + j * per_file_scalars;
+        c[0] = (uint8_t)(fastq[j] ? 3 : 1); c[1] = 1;
+    }
+    hip_check(hipMemcpyAsync(small.p, h_small.data(), h_small.size(), hipMemcpyHostToDevice, st), "H2D");
+    for (size_t j = 0; j < idx.size(); ++j) {
+        const size_t i = idx[j];
+        uint8_t* sc = small.as<uint8_t>() + j * per_file_scalars;
+        uint8_t* cp = comp.as<uint8_t>() + slot[j].comp_off;
+        hip_check(fastx_compact_launch(static_cast<const uint8_t*>(slices[i].p), slices[i].len, fastq[j], sc, parse_state.as<uint8_t>(), cp,
+                                       reinterpret_cast<unsigned long long*>(sc + 8), reinterpret_cast<unsigned long long*>(sc + 16),
+                                       parse_temp.p, parse_temp_bytes, st), "fastx");
+        for (size_t q = 0; q < sigs[i].sketches.size(); ++q) {
+            const KmerMinHash& mh = sigs[i].sketches[q];
+            const uint32_t k = mh.ksize;
+            hip_check(sketch_dna_launch(cp - (k - 1), (uint64_t)(k - 1) + slices[i].len, k, mh.seed, mh.max_hash, outs.as<uint64_t>() + slot[j].out_off[q],
+                                        reinterpret_cast<unsigned long long*>(sc + 32 + 16 * q), slot[j].cap[q], st), "sketch_dna");
+        }
+    }
+    hip_check(hipMemcpyAsync(h_small.data(), small.p, h_small.size(), hipMemcpyDeviceToHost, st), "D2H");
+    hip_check(hipStreamSynchronize(st), "sync");
+    // sorts: only where the estimate held
+    std::vector<bool> fits(idx.size(), true);
+    uint64_t uniq_entries = 0, max_count = 0;
+    std::vector<uint64_t> uoff(idx.size() * 8, 0);
+    auto scalar = [&](size_t j, size_t off) { uint64_t v; memcpy(&v, h_small.data() + j * per_file_scalars + off, 8); return v; };
+    for (size_t j = 0; j < idx.size(); ++j) {
+        const size_t i = idx[j];
+        for (size_t q = 0; q < sigs[i].sketches.size(); ++q) if (scalar(j, 32 + 16 * q) > slot[j].cap[q]) fits[j] = false;
+        if (!fits[j]) continue;
+        for (size_t q = 0; q < sigs[i].sketches.size(); ++q) {
+            const uint64_t c = scalar(j, 32 + 16 * q);
+            uoff[j * 8 + q] = uniq_entries;
+            uniq_entries += 2 * c;
+            max_count = std::max(max_count, c);
+        }
+    }
+    if (uniq_entries) {
+        const size_t tb = sort_unique_temp_bytes(max_count);
+        AsyncBuf tmp(tb, st), uniq(uniq_entries * 8 + 256, st);
+        for (size_t j = 0; j < idx.size(); ++j) {
+            if (!fits[j]) continue;
+            const size_t i = idx[j];
+            uint8_t* sc = small.as<uint8_t>() + j * per_file_scalars;
+            for (size_t q = 0; q < sigs[i].sketches.size(); ++q) {
+                const uint64_t c = scalar(j, 32 + 16 * q);
+                if (!c) continue;
+                const uint64_t thr = sigs[i].sketches[q].max_hash;
+                int bits = 1;
+                while (bits < 64 && (thr >> bits)) ++bits;
+                uint64_t* d_u = uniq.as<uint64_t>() + uoff[j * 8 + q];
+                hip_check(sort_unique(outs.as<uint64_t>() + slot[j].out_off[q], c, d_u, d_u + c, reinterpret_cast<uint64_t*>(sc + 32 + 16 * q + 8),
+                                      tmp.p, tb, bits, st), "sort_unique");
+            }
+        }
+        std::vector<uint64_t> h_uniq(uniq_entries);
+        hip_check(hipMemcpyAsync(h_small.data(), small.p, h_small.size(), hipMemcpyDeviceToHost, st), "D2H");
+        hip_check(hipMemcpyAsync(h_uniq.data(), uniq.p, uniq_entries * 8, hipMemcpyDeviceToHost, st), "D2H");
+        hip_check(hipStreamSynchronize(st), "sync");
+        for (size_t j = 0; j < idx.size(); ++j) {
+            if (!fits[j]) continue;
+            const size_t i = idx[j];
+            for (size_t q = 0; q < sigs[i].sketches.size(); ++q) {
+                const uint64_t c = scalar(j, 32 + 16 * q);
+                if (!c) continue;
+                const uint64_t nu = scalar(j, 32 + 16 * q + 8);
+                KmerMinHash& mh = sigs[i].sketches[q];
+                const uint64_t* hu = h_uniq.data() + uoff[j * 8 + q];
+                mh.add_sorted_batch(hu, mh.track_abundance ? hu + c : nullptr, (size_t)nu);
+            }
+        }
+    }
+    for (size_t j = 0; j < idx.size(); ++j) {
+        if (!fits[j]) continue;
+        done[idx[j]] = true;
+        bases_out[idx[j]] = scalar(j, 8) - scalar(j, 16);             // one separator byte per record is in the compacted stream
+    }
+}
+
 // single-file entry point: the shared pipeline on the context's stream
 inline void sketch_file_into(std::vector<KmerMinHash*>& mhs, const std::string& path, uint64_t* n_records,
                              uint64_t* n_bases) {
@@ -552,7 +690,10 @@ inline void sketch_files_parallel(const std::vector<std::string>& paths, const C
     (void)hipGetDevice(&device);
     // files are claimed a batch at a time: the gzip members of a batch (single genomes: a few dozen deflate blocks each) are
     // inflated on the device in ONE pass (gunzip.hpp) -- a member by itself would keep a few dozen wavefronts busy
-    const size_t per_batch = std::max<size_t>(1, std::min<size_t>(64, paths.size() / std::max(1u, threads)));
+    // (a batch costs ~20 ms of dependent steps however few files it holds and ~0.3 ms of launches per file: up to 64 files a
+    //  batch, about four batches side by side -- more workers than that only contend for the runtime's locks)
+    const size_t per_batch = threads <= 1 ? std::min<size_t>(64, paths.size())
+                                          : std::max<size_t>(1, std::min<size_t>(64, (paths.size() + 3) / 4));
     constexpr uint64_t BATCH_FILE_MAX = (uint64_t)64 << 20;          // larger files go by themselves (sketch_file_with inflates them)
     static const bool device_gunzip = [] { const char* e = getenv("SMG_GUNZIP_DEVICE"); return !(e && e[0] == '0'); }();
     auto run = [&]() {
@@ -564,10 +705,16 @@ inline void sketch_files_parallel(const std::vector<std::string>& paths, const C
                 const size_t i0 = next.fetch_add(per_batch);
                 if (i0 >= paths.size()) break;
                 const size_t i1 = std::min(paths.size(), i0 + per_batch);
+                static const bool trace = getenv("SMG_INGEST_TRACE") != nullptr;
+                auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+                const double t_begin = now();
+                double t_read = 0, t_inflate = 0, t_sketch = 0;
+                GunzipStats gstats;
                 // ---- the batch's gzip files -> pinned memory -> HBM -> inflated ----
                 std::vector<GunzipMember> ms;
                 std::vector<size_t> owner;                            // ms[k] is paths[owner[k]]
                 std::vector<InflatedSlice> slice(i1 - i0);
+                std::vector<uint8_t> first(i1 - i0, 0);
                 void* d_out = nullptr;
                 struct FreeOut { void*& p; hipStream_t st; ~FreeOut() { if (p) arena_free(p, st); } } free_out{d_out, w.stream};
                 if (device_gunzip && i1 - i0 > 1) {
@@ -604,29 +751,47 @@ inline void sketch_files_parallel(const std::vector<std::string>& paths, const C
                             const uint64_t end = ms[k].file_off + ms[k].file_len;
                             memset(h + end, 0, (size_t)((((end + 7) & ~7ull)) - end));
                         }
+                        t_read = now() - t_begin;
                         if (read_ok) {
                             memset(h + total, 0, GUNZIP_PAD);
                             hip_check(hipMemcpyAsync(w.scratch.gzdev.p, h, (size_t)total + GUNZIP_PAD, hipMemcpyHostToDevice, w.stream), "H2D");
-                            gunzip_device(h, w.scratch.gzdev.as<uint8_t>(), total, ms, &d_out, w.stream);
+                            gunzip_device(h, w.scratch.gzdev.as<uint8_t>(), total, ms, &d_out, w.stream, trace ? &gstats : nullptr);
+                            t_inflate = now() - t_begin - t_read;
                             for (size_t k = 0; k < ms.size(); ++k) {
                                 InflatedSlice& sl = slice[owner[k] - i0];
-                                if (ms[k].ok) { sl.p = (const uint8_t*)d_out + ms[k].out_off; sl.len = ms[k].out_len; gunzip_counters().on_device++; }
+                                if (ms[k].ok) {
+                                    sl.p = (const uint8_t*)d_out + ms[k].out_off; sl.len = ms[k].out_len; first[owner[k] - i0] = ms[k].first_byte;
+                                    gunzip_counters().on_device++;
+                                }
                                 else { sl.refused = true; gunzip_counters().refused++; }
                             }
                         }
                     }
                 }
+                std::vector<Signature> sigs;
+                for (size_t i = i0; i < i1; ++i) sigs.push_back(Signature::from_params(params));
+                std::vector<bool> done(i1 - i0, false);
+                std::vector<uint64_t> file_bases(i1 - i0, 0);
+                const double t_s0 = now();
+                if (d_out) sketch_slices_batched(w, slice, first, sigs, file_bases, done);
+                t_sketch = now() - t_s0;
                 for (size_t i = i0; i < i1; ++i) {
-                    Signature sig = Signature::from_params(params);
-                    std::vector<KmerMinHash*> mhs;
-                    for (auto& mh : sig.sketches) mhs.push_back(&mh);
-                    uint64_t recs = 0, b = 0;
-                    const InflatedSlice& sl = slice[i - i0];
-                    sketch_file_with(w, mhs, paths[i], (size_t)4 << 20, 1, &recs, &b, (sl.p || sl.refused) ? &sl : nullptr);
+                    Signature& sig = sigs[i - i0];
+                    uint64_t recs = 0, b = file_bases[i - i0];
+                    if (!done[i - i0]) {
+                        std::vector<KmerMinHash*> mhs;
+                        for (auto& mh : sig.sketches) mhs.push_back(&mh);
+                        const InflatedSlice& sl = slice[i - i0];
+                        sketch_file_with(w, mhs, paths[i], (size_t)4 << 20, 1, &recs, &b, (sl.p || sl.refused) ? &sl : nullptr);
+                    }
                     sig.filename = paths[i];
                     bases += b;
                     out[i] = std::move(sig);
                 }
+                if (trace)
+                    fprintf(stderr, "[ingest] batch of %zu files: %.1f ms (read %.1f, H2D + inflate %.1f [scan %.1f pass1 %.1f link %.1f pass2 %.1f finish %.1f], "
+                                    "batched sketch %.1f, the rest %.1f)\n", i1 - i0, now() - t_begin, t_read, t_inflate, gstats.scan_ms, gstats.pass1_ms,
+                            gstats.link_ms, gstats.pass2_ms, gstats.finish_ms, t_sketch, now() - t_begin - t_read - t_inflate - t_sketch);
             }
             hip_check(hipStreamSynchronize(w.stream), "sync");
         } catch (const Error& e) {

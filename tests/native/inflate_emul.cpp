@@ -53,10 +53,14 @@ int64_t emul_gunzip(const uint8_t* file, uint64_t size, uint8_t* out, uint64_t c
     for (uint64_t i = 0; i < nc; ++i)
         if (bits[i] != first_bit) { Cand c; c.bit = bits[i]; cands.push_back(c); }
     std::unique_ptr<Scratch> S(new Scratch());
-    for (auto& c : cands) {                                           // pass 1
-        CountSink sink;
+    std::vector<uint32_t> rec(size * 8 + 64);
+    for (size_t i = 0; i < cands.size(); ++i) {                       // pass 1: records at [bit, next candidate's bit)
+        Cand& c = cands[i];
+        RecordSink sink;
+        sink.rec = rec.data() + c.bit;
+        sink.cap = (i + 1 < cands.size() ? cands[i + 1].bit : trailer_bit) - c.bit;
         const RunResult r = decode_run(words.data(), c.bit, trailer_bit, *S, sink, MAX_RUN_BYTES);
-        c.end_bit = r.end_bit; c.out_len = r.out_len; c.status = r.status;
+        c.end_bit = r.end_bit; c.out_len = r.out_len; c.status = r.status; c.n_records = r.n_records;
     }
     std::string why;
     const std::vector<uint32_t> chain = link_chain(cands, first_bit, trailer_bit, why);
@@ -67,14 +71,16 @@ int64_t emul_gunzip(const uint8_t* file, uint64_t size, uint8_t* out, uint64_t c
     if (stats) { stats[0] = cands.size(); stats[1] = chain.size(); stats[2] = 0; }
     if (total > cap) return -5;
     std::vector<uint16_t> sym(total + 64);
-    for (size_t i = 0; i < chain.size(); ++i) {                       // pass 2
+    std::unique_ptr<ExpandScratch> X(new ExpandScratch());
+    for (size_t i = 0; i < chain.size(); ++i) {                       // pass 2: records -> symbols
         const Cand& c = cands[chain[i]];
-        WaveSink sink;
-        sink.out = sym.data() + start[i];
-        sink.cap = c.out_len;
-        sink.no_window = i == 0;
-        const RunResult r = decode_run(words.data(), c.bit, trailer_bit, *S, sink, MAX_RUN_BYTES);
-        if (r.status != c.status || r.out_len != c.out_len || r.end_bit != c.end_bit || sink.g0 != c.out_len) return -3;
+        Expander ex;
+        ex.out = sym.data() + start[i];
+        ex.cap = c.out_len;
+        ex.bytes = (const uint8_t*)words.data();
+        ex.no_window = i == 0;
+        ex.run(rec.data() + c.bit, c.n_records, *X);
+        if (ex.bad || ex.g0 != c.out_len) return -3;
     }
     // tails in stream order, then everything else (here: one loop does both, in order)
     uint64_t markers = 0;

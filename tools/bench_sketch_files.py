@@ -27,8 +27,8 @@ def main():
         paths.append(p)
     bases = 4_641_652 * copies
     out = {"files": copies, "bases": bases, "params": "k=21,k=31,k=51,scaled=1000"}
-    sketch_files(paths[:8], out["params"], threads=threads)                  # warm
-    for t in (1, threads):
+    sketch_files(paths, out["params"], threads=threads)                      # warm: page cache, pinned buffers, code objects
+    for t in (1, 4, threads):
         t0 = time.perf_counter()
         sigs = sketch_files(paths, out["params"], threads=t)
         dt = time.perf_counter() - t0
