@@ -257,6 +257,9 @@ uint64_t smgpu_minhash_add_file(SourmashKmerMinHash *ptr, const char *path, uint
  * cheap header test, [1] candidates decoded, [2] runs on the chains, [3..8] milliseconds: scan, pass 1, link, pass 2, tails +
  * resolve + CRC, everything on the device; [9] H2D copy + file reads.  Returns the bytes written. */
 uint64_t smgpu_gunzip_files(const char *const *paths, uintptr_t n, uint8_t *out, uint64_t capacity, uint64_t *lens, double *stats);
+/* out[0]: signature documents smgpu_sketchset_load has parsed with the device doing inflate and number parsing (csrc/sigload.hpp)
+ * since the library was loaded, out[1]: documents its host parser took (SMG_SIGLOAD_DEVICE=0 sends every document there). */
+void smgpu_sigload_counters(uint64_t *out);
 /* out[0]: gzip files the ingest inflated on the device since the library was loaded, out[1]: files it handed to the host inflater
  * after the device refused them. */
 void smgpu_gunzip_counters(uint64_t *out);

@@ -24,6 +24,7 @@
 #include "hostxfer.hpp"
 #include "pargz.hpp"
 #include "ingest.hpp"
+#include "sigload.hpp"
 #include "murmur3.hpp"
 #include "residues.hpp"
 #include "signature_host.hpp"
@@ -834,6 +835,11 @@ uint64_t smgpu_gunzip_files(const char* const* paths, uintptr_t n, uint8_t* out,
         return at;
     });
 }
+void smgpu_sigload_counters(uint64_t* out) {
+    if (!out) return;
+    out[0] = sigload_counters().on_device.load();
+    out[1] = sigload_counters().on_host.load();
+}
 void smgpu_gunzip_counters(uint64_t* out) {
     if (!out) return;
     out[0] = gunzip_counters().on_device.load();
@@ -1640,8 +1646,38 @@ static SketchSet* upload_collection(LoadedCollection&& col) {
 SmgpuSketchSet* smgpu_sketchset_load(const char* const* paths, uintptr_t n_paths, uint32_t ksize, const char* moltype,
                                      uint64_t scaled, uint32_t n_threads) {
     return landing<SmgpuSketchSet*>([&]() -> SmgpuSketchSet* {
-        (void)DeviceCtx::get();                                     // fail before parsing when there is no GPU
-        return reinterpret_cast<SmgpuSketchSet*>(upload_collection(load_collection(paths, n_paths, ksize, moltype, scaled, n_threads)));
+        DeviceCtx& ctx = DeviceCtx::get();                          // fail before parsing when there is no GPU
+        static const bool host_only = [] { const char* e = getenv("SMG_SIGLOAD_DEVICE"); return e && e[0] == '0'; }();
+        if (host_only)
+            return reinterpret_cast<SmgpuSketchSet*>(upload_collection(load_collection(paths, n_paths, ksize, moltype, scaled, n_threads)));
+        // inflate + number parsing on the device, the CSR never leaves HBM (sigload.hpp); what the device does not take is
+        // parsed by the host path document by document
+        LoadSelect sel;
+        sel.ksize = ksize;
+        sel.hash_function = (moltype && *moltype) ? (int)molecule_from_name(moltype) : -1;
+        sel.scaled = scaled;
+        CollectionLoader loader(sel, n_threads);
+        for (uintptr_t i = 0; i < n_paths; ++i) loader.add_path(paths[i]);
+        std::lock_guard<std::recursive_mutex> g(ctx.mutex());
+        hipStream_t st = ctx.stream();
+        CollectionLoader::DeviceResult res;
+        loader.run_device(st, res);
+        std::unique_ptr<SketchSet> s(new SketchSet());
+        s->hashes.p = res.d_hashes;
+        s->hashes.cap = (size_t)res.total * 8 + 16;
+        s->hashes.st = st;
+        s->n = res.rows.size();
+        s->total = res.total;
+        s->offsets.reserve((s->n + 1) * 8, st);
+        hip_check(hipMemcpyAsync(s->offsets.p, res.offsets.data(), (s->n + 1) * 8, hipMemcpyHostToDevice, st), "H2D");
+        hip_check(hipStreamSynchronize(st), "sync");
+        s->host_offsets = std::move(res.offsets);
+        s->rows = std::move(res.rows);
+        s->ksize = res.ksize; s->hash_function = res.hash_function; s->seed = res.seed;
+        s->max_hash = res.max_hash; s->num = res.num; s->skipped = res.skipped;
+        sigload_counters().on_device += res.on_device;
+        sigload_counters().on_host += res.on_host;
+        return reinterpret_cast<SmgpuSketchSet*>(s.release());
     });
 }
 SmgpuSketchSet* smgpu_sketchset_from_collection(const SmgpuCollection* p) {

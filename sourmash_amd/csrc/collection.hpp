@@ -25,6 +25,7 @@
 #include <mutex>
 #include <memory>
 #include <vector>
+#include <hip/hip_runtime_api.h>
 #include "json.hpp"
 #include "md5.hpp"
 #include "minhash_host.hpp"
@@ -79,6 +80,18 @@ class ZipReader {
     const ZipMember* find(const std::string& name) const {
         auto it = by_name_.find(name);
         return it == by_name_.end() ? nullptr : &members_[it->second];
+    }
+    // thread-safe (pread): the bytes of a STORED member as they lie in the archive, into dst[0, m.comp_size); false for a
+    // compressed member (the device loader takes .sig.gz members stored, as sourmash writes them)
+    bool read_stored_into(const ZipMember& m, uint8_t* dst) const {
+        if (m.method != 0) return false;
+        uint8_t lh[30];
+        pread_exact(m.local_offset, lh, 30);
+        if (le32(lh) != 0x04034b50u) fail("bad local file header");
+        const uint64_t data = m.local_offset + 30 + le16(lh + 26) + le16(lh + 28);
+        if (m.comp_size > file_size_ || data > file_size_ - m.comp_size) fail("member " + m.name + " reaches past the end of the archive");
+        if (m.comp_size) pread_exact(data, dst, m.comp_size);
+        return true;
     }
     // thread-safe (pread): the member's bytes, inflated
     std::string read(const ZipMember& m) const {
@@ -309,8 +322,14 @@ struct LoadSelect {
 
 inline const char* manifest_moltype(uint32_t hf) { return molecule_name(hf); }   // "DNA", "protein", "dayhoff", "hp"
 
+// a `mins` array the device has parsed (sigload.hpp): where its values lie, how many, how many survive the down-sampling
+struct DeviceArray { uint64_t value_off = 0; uint32_t n_values = 0, n_kept = 0; bool is_mins = false, odd = false; };
+struct NeedsHost {};                       // thrown by the scanner in device mode: this document is the host parser's
+
 struct LoadedPiece {
-    std::vector<uint64_t> hashes;          // rows back to back
+    std::vector<uint64_t> hashes;          // rows back to back (host mode)
+    std::vector<uint64_t> dev_off;         // per row: where its values lie in the group's value block (device mode)
+    int group = -1;                        // device mode: which group's value block
     std::vector<uint64_t> lens;            // per row
     std::vector<ManifestRow> rows;         // as stored (before downsampling), one per row
     std::vector<uint64_t> seeds;
@@ -321,6 +340,9 @@ struct LoadedPiece {
 class SigScanner : public json::Parser {
   public:
     SigScanner(const char* p, size_t n) : json::Parser(p, n) {}
+    // device mode: the text's `mins` arrays hold one number each -- the index of the array in `arrays` -- and the values
+    // themselves are in HBM (sigload.hpp)
+    SigScanner(const char* p, size_t n, const DeviceArray* arrays, size_t n_arrays) : json::Parser(p, n), arrays_(arrays), n_arrays_(n_arrays) {}
 
     void scan(const LoadSelect& sel, const std::string& location, LoadedPiece& out) {
         skip_ws();
@@ -481,6 +503,7 @@ class SigScanner : public json::Parser {
                           (sel.hash_function < 0 || (uint32_t)sel.hash_function == hf) &&
                           (sel.scaled == 0 || (stored_scaled != 0 && stored_scaled <= sel.scaled));
         if (!keep) { ++out.skipped; reset(); return; }
+        if (arrays_) { take_device(sel, location, out, hf, stored_scaled); return; }
         if (!std::is_sorted(sk.mins.begin(), sk.mins.end())) std::sort(sk.mins.begin(), sk.mins.end());   // minhash.rs:161-171
         sk.mins.erase(std::unique(sk.mins.begin(), sk.mins.end()), sk.mins.end());
         ManifestRow row;
@@ -503,6 +526,27 @@ class SigScanner : public json::Parser {
         out.rows.push_back(std::move(row));
         reset();
     }
+    void take_device(const LoadSelect& sel, const std::string& location, LoadedPiece& out, uint32_t hf, uint64_t stored_scaled) {
+        Sketch& sk = tmp_;
+        if (sk.mins.size() != 1 || sk.mins[0] >= n_arrays_ || sk.md5.empty()) throw NeedsHost();
+        const DeviceArray& a = arrays_[sk.mins[0]];
+        if (!a.is_mins || a.odd) throw NeedsHost();
+        ManifestRow row;
+        row.internal_location = location;
+        row.ksize = hf == HF_DNA ? sk.ksize : sk.ksize / 3;
+        row.moltype = manifest_moltype(hf);
+        row.num = sk.max_hash ? 0 : sk.num;                          // minhash.rs:150
+        row.scaled = stored_scaled;
+        row.n_hashes = a.n_values;
+        row.with_abundance = sk.has_abund;
+        row.md5 = sk.md5;
+        const uint64_t n = sel.scaled && stored_scaled != sel.scaled ? a.n_kept : a.n_values;   // downsample: keep h <= max_hash(target)
+        out.dev_off.push_back(a.value_off);
+        out.lens.push_back(n);
+        out.seeds.push_back(sk.seed);
+        out.rows.push_back(std::move(row));
+        reset();
+    }
     void reset() {
         tmp_.num = 0; tmp_.seed = 42; tmp_.max_hash = 0; tmp_.ksize = 0;
         tmp_.md5.clear(); tmp_.molecule.clear(); tmp_.mins.clear();
@@ -516,6 +560,8 @@ class SigScanner : public json::Parser {
     }
 
     Sketch tmp_;
+    const DeviceArray* arrays_ = nullptr;
+    size_t n_arrays_ = 0;
 };
 
 // ---- the loader -----------------------------------------------------------------------------------------------------
@@ -659,6 +705,10 @@ class CollectionLoader {
     }
 
     size_t work_items() const { return items_.size(); }
+
+    // sigload.hpp: the same collection with inflate and number parsing on the device, the CSR left in HBM
+    struct DeviceResult;
+    void run_device(hipStream_t stream, DeviceResult& out);
 
   private:
     void add_zip(const std::string& path) {

@@ -39,6 +39,9 @@ hipError_t residue_windows_launch(const uint8_t* d_aa, uint64_t n, uint32_t k, u
 
 // ---- device_sort.hip ------------------------------------------------------------
 size_t sort_unique_temp_bytes(uint64_t n);
+// many small lists sorted as one (device_sort.hip): dst[seg.dst + i] = src[seg.src + i] | (list number << hbits)
+struct TagSegment { uint64_t src, dst, n; };
+hipError_t tag_gather_launch(const uint64_t* d_src, const TagSegment* d_segs, uint32_t n_segs, uint64_t* d_dst, int hbits, hipStream_t stream);
 // keys[0,n) -> sorted unique in out[0,*d_n_out); if d_counts != nullptr also the
 // multiplicity of every unique key.  keys is clobbered.  `bits` = significant key bits.
 hipError_t sort_unique(uint64_t* d_keys, uint64_t n, uint64_t* d_out, uint64_t* d_counts, uint64_t* d_n_out,

@@ -59,4 +59,21 @@ hipError_t sort_unique(uint64_t* d_keys, uint64_t n, uint64_t* d_out, uint64_t* 
     return e;
 }
 
+// Many small hash lists sorted as ONE: list s (src[seg.src, seg.src + seg.n)) is copied to dst[seg.dst, ...) with its number in
+// the bits above `hbits` (hashes <= max_hash need fewer than 64 bits), so that one radix sort + one run-length encode of all of
+// dst orders every list by itself -- the per-list sorts of a batch of genomes were a thousand launches of a few microseconds.
+namespace {
+__global__ __launch_bounds__(256) void tag_gather_kernel(const uint64_t* __restrict__ src, const TagSegment* __restrict__ segs, uint64_t* __restrict__ dst, int hbits) {
+    const TagSegment g = segs[blockIdx.x];
+    const uint64_t tag = (uint64_t)blockIdx.x << hbits;
+    for (uint64_t i = threadIdx.x; i < g.n; i += 256u) dst[g.dst + i] = src[g.src + i] | tag;
+}
+}  // namespace
+
+hipError_t tag_gather_launch(const uint64_t* d_src, const TagSegment* d_segs, uint32_t n_segs, uint64_t* d_dst, int hbits, hipStream_t stream) {
+    if (n_segs == 0) return hipSuccess;
+    hipLaunchKernelGGL(tag_gather_kernel, dim3(n_segs), dim3(256), 0, stream, d_src, d_segs, d_dst, hbits);
+    return hipGetLastError();
+}
+
 }  // namespace smg

@@ -618,7 +618,54 @@ inline void sketch_slices_batched(IngestWorker& w, const std::vector<InflatedSli
             max_count = std::max(max_count, c);
         }
     }
-    if (uniq_entries) {
+    // every list that fits, sorted in ONE radix sort: the list's number rides in the key bits above the hashes
+    int hbits = 1;
+    {
+        uint64_t thr = 0;
+        for (size_t j = 0; j < idx.size(); ++j) for (auto& mh : sigs[idx[j]].sketches) thr = std::max(thr, mh.max_hash);
+        while (hbits < 64 && (thr >> hbits)) ++hbits;
+    }
+    std::vector<TagSegment> segs;
+    std::vector<std::pair<size_t, size_t>> seg_of;                     // (j, q) of every segment
+    uint64_t tagged = 0;
+    for (size_t j = 0; j < idx.size(); ++j) {
+        if (!fits[j]) continue;
+        for (size_t q = 0; q < sigs[idx[j]].sketches.size(); ++q) {
+            const uint64_t c = scalar(j, 32 + 16 * q);
+            segs.push_back(TagSegment{slot[j].out_off[q], tagged, c});
+            seg_of.emplace_back(j, q);
+            tagged += c;
+        }
+    }
+    const bool one_sort = hbits < 64 && segs.size() <= ((uint64_t)1 << (64 - hbits)) && tagged < 0xffffffffull;
+    if (tagged && one_sort) {
+        const size_t tb = sort_unique_temp_bytes(tagged);
+        AsyncBuf tmp(tb, st), keys(tagged * 8 + 256, st), uniq(tagged * 16 + 256, st), d_segs(segs.size() * sizeof(TagSegment), st);
+        hip_check(hipMemcpyAsync(d_segs.p, segs.data(), segs.size() * sizeof(TagSegment), hipMemcpyHostToDevice, st), "H2D");
+        hip_check(tag_gather_launch(outs.as<uint64_t>(), d_segs.as<TagSegment>(), (uint32_t)segs.size(), keys.as<uint64_t>(), hbits, st), "tag_gather");
+        uint64_t* d_u = uniq.as<uint64_t>();
+        unsigned long long* d_nu = reinterpret_cast<unsigned long long*>(small.as<uint8_t>());       // (the first file's carry bytes have done their work)
+        hip_check(sort_unique(keys.as<uint64_t>(), tagged, d_u, d_u + tagged, reinterpret_cast<uint64_t*>(d_nu), tmp.p, tb, 64, st), "sort_unique");
+        unsigned long long nu = 0;
+        hip_check(hipMemcpyAsync(&nu, d_nu, 8, hipMemcpyDeviceToHost, st), "D2H");
+        hip_check(hipStreamSynchronize(st), "sync");
+        std::vector<uint64_t> h_u((size_t)nu), h_c((size_t)nu);
+        if (nu) {
+            hip_check(hipMemcpyAsync(h_u.data(), d_u, (size_t)nu * 8, hipMemcpyDeviceToHost, st), "D2H");
+            hip_check(hipMemcpyAsync(h_c.data(), d_u + tagged, (size_t)nu * 8, hipMemcpyDeviceToHost, st), "D2H");
+            hip_check(hipStreamSynchronize(st), "sync");
+        }
+        const uint64_t mask = ((uint64_t)1 << hbits) - 1;
+        size_t at = 0;
+        while (at < (size_t)nu) {                                      // runs of equal list number, in list order
+            const uint64_t tag = h_u[at] >> hbits;
+            size_t end = at;
+            while (end < (size_t)nu && (h_u[end] >> hbits) == tag) { h_u[end] &= mask; ++end; }
+            KmerMinHash& mh = sigs[idx[seg_of[tag].first]].sketches[seg_of[tag].second];
+            mh.add_sorted_batch(h_u.data() + at, mh.track_abundance ? h_c.data() + at : nullptr, end - at);
+            at = end;
+        }
+    } else if (uniq_entries) {
         const size_t tb = sort_unique_temp_bytes(max_count);
         AsyncBuf tmp(tb, st), uniq(uniq_entries * 8 + 256, st);
         for (size_t j = 0; j < idx.size(); ++j) {
@@ -692,15 +739,32 @@ inline void sketch_files_parallel(const std::vector<std::string>& paths, const C
     // inflated on the device in ONE pass (gunzip.hpp) -- a member by itself would keep a few dozen wavefronts busy
     // (a batch costs ~20 ms of dependent steps however few files it holds and ~0.3 ms of launches per file: up to 64 files a
     //  batch, about four batches side by side -- more workers than that only contend for the runtime's locks)
+    static const size_t SMG_BATCHES = [] { const char* e = getenv("SMG_INGEST_BATCHES"); const long v = e ? atol(e) : 0; return (size_t)(v >= 1 && v <= 64 ? v : 6); }();
     const size_t per_batch = threads <= 1 ? std::min<size_t>(64, paths.size())
-                                          : std::max<size_t>(1, std::min<size_t>(64, (paths.size() + 3) / 4));
+                                          : std::max<size_t>(1, std::min<size_t>(64, (paths.size() + SMG_BATCHES - 1) / SMG_BATCHES));
     constexpr uint64_t BATCH_FILE_MAX = (uint64_t)64 << 20;          // larger files go by themselves (sketch_file_with inflates them)
     static const bool device_gunzip = [] { const char* e = getenv("SMG_GUNZIP_DEVICE"); return !(e && e[0] == '0'); }();
+    // Workers outlive the call (pinning 100 MB of host memory and creating a stream cost tens of milliseconds, and the runtime
+    // serialises them against every other thread's work): a pool, leaked on purpose like the context.
+    struct WorkerPool {
+        std::mutex mu;
+        std::vector<IngestWorker*> idle;
+        IngestWorker* take() {
+            { std::lock_guard<std::mutex> g(mu); if (!idle.empty()) { IngestWorker* w = idle.back(); idle.pop_back(); return w; } }
+            IngestWorker* w = new IngestWorker();
+            w->init_own_stream();
+            return w;
+        }
+        void give(IngestWorker* w) { std::lock_guard<std::mutex> g(mu); idle.push_back(w); }
+    };
+    static WorkerPool& workers = *new WorkerPool();
     auto run = [&]() {
         (void)hipSetDevice(device);
-        IngestWorker w;
+        IngestWorker* wp = nullptr;
+        struct Return { WorkerPool& pool; IngestWorker*& w; ~Return() { if (w) { (void)hipStreamSynchronize(w->stream); pool.give(w); } } } give_back{workers, wp};
         try {
-            w.init_own_stream();
+            wp = workers.take();
+            IngestWorker& w = *wp;
             for (;;) {
                 const size_t i0 = next.fetch_add(per_batch);
                 if (i0 >= paths.size()) break;

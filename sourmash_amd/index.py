@@ -159,6 +159,11 @@ class SketchSet(RustObject):
         return self._manifest
 
     @property
+    def skipped(self):
+        "sketches seen in the inputs that the selection left out (a loaded set)"
+        return self._methodcall(lib.smgpu_sketchset_skipped)
+
+    @property
     def sizes(self):
         out = np.zeros(max(len(self), 1), dtype=np.uint64)
         self._methodcall(lib.smgpu_sketchset_sizes, out.ctypes.data_as(C.c_void_p))

@@ -133,3 +133,32 @@ def test_ingest_suite_on_the_host_inflater():
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_gpu_ingest.py"), "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider"],
                        env=env, cwd=ROOT, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+
+
+def test_many_small_files_batched_give_the_per_file_sketches(sk, tmp_path):
+    "smgpu_sketch_files inflates AND sketches its gzip members per batch (one tagged sort for all lists): every signature must equal the per-file one"
+    rng = np.random.default_rng(41)
+    paths = []
+    for i in range(37):
+        kind = i % 6
+        if kind == 0:
+            blob = gz(fastq(rng, 300 + 7 * i), 6)
+        elif kind == 1:
+            blob = fasta(rng, 20_000 + 1000 * i)                       # not compressed: the per-file path
+        elif kind == 2:
+            blob = gz(fasta(rng, 5_000), 6) + gz(fasta(rng, 3_000), 6)  # two members: the host inflater
+        elif kind == 3 and i == 3:
+            blob = gz(b"", 6)                                          # an empty file
+        else:
+            blob = gz(fasta(rng, 30_000 + 4_000 * i) + fasta(rng, 1_000), 1 + i % 9)
+        paths.append(_write(tmp_path, f"m{i}.{'fq' if kind == 0 else 'fa'}{'' if kind == 1 else '.gz'}", blob))
+    for params in ("k=21,k=31,scaled=100,abund", "k=31,scaled=1", "k=31,num=500", "k=21,k=31,k=51,scaled=1000"):
+        many = sk.sketch_files(paths, params, threads=3)
+        for p, sig in zip(paths, many):
+            one, = sk.sketch_file(p, params)
+            assert [m.md5sum() for m in sig.minhashes()] == [m.md5sum() for m in one.minhashes()], (params, p)
+            if "abund" in params:
+                for a, b in zip(sig.minhashes(), one.minhashes()):
+                    assert a.hashes == b.hashes
+    one_thread = sk.sketch_files(paths, "k=31,scaled=100", threads=1)      # one batch of all the files
+    assert [s.minhash.md5sum() for s in one_thread] == [sk.sketch_file(p, "k=31,scaled=100")[0].minhash.md5sum() for p in paths]
