@@ -326,7 +326,19 @@ __global__ __launch_bounds__(64) void gz_crc_kernel(const uint8_t* __restrict__ 
     if (lane == 0) crcs[blockIdx.x] = part;
 }
 
+__global__ __launch_bounds__(256) void gz_first_bytes_kernel(const uint8_t* __restrict__ out, const GzMemberDesc* __restrict__ members, uint32_t n,
+                                                             uint8_t* __restrict__ first) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < n) first[i] = out[members[i].base];
+}
+
 }  // namespace
+
+hipError_t gz_first_bytes_launch(const uint8_t* d_out, const GzMemberDesc* d_members, uint32_t n, uint8_t* d_first, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(gz_first_bytes_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, d_out, d_members, n, d_first);
+    return hipGetLastError();
+}
 
 hipError_t gz_scan_launch(const uint32_t* words, uint64_t n_bytes, uint64_t* d_surv, uint64_t* d_valid, unsigned long long* d_counts,
                           uint64_t cap, hipStream_t stream) {

@@ -223,10 +223,12 @@ inline void gunzip_device(const uint8_t* h_files, const uint8_t* d_files, uint64
         hip_check(hipMemcpyAsync(res2.data(), d_res2.p, res2.size() * sizeof(GzRunResult), hipMemcpyDeviceToHost, stream), "D2H");
         hip_check(hipMemcpyAsync(err.data(), d_err.p, err.size() * 4, hipMemcpyDeviceToHost, stream), "D2H");
         if (!crc.empty()) hip_check(hipMemcpyAsync(crc.data(), d_crc.p, crc.size() * 4, hipMemcpyDeviceToHost, stream), "D2H");
-        for (size_t j = 0; j < mdesc.size(); ++j)
-            if (members[mindex[j]].out_len)
-                hip_check(hipMemcpyAsync(&members[mindex[j]].first_byte, (const uint8_t*)out + mdesc[j].base, 1, hipMemcpyDeviceToHost, stream), "D2H");
+        AsyncBuf d_first(mdesc.size() + 8, stream);
+        std::vector<uint8_t> first(mdesc.size());
+        hip_check(gz_first_bytes_launch((const uint8_t*)out, d_m.as<GzMemberDesc>(), (uint32_t)mdesc.size(), d_first.as<uint8_t>(), stream), "gz_first_bytes");
+        hip_check(hipMemcpyAsync(first.data(), d_first.p, first.size(), hipMemcpyDeviceToHost, stream), "D2H");
         hip_check(hipStreamSynchronize(stream), "sync");
+        for (size_t j = 0; j < mdesc.size(); ++j) members[mindex[j]].first_byte = members[mindex[j]].out_len ? first[j] : 0;
         // ---- the checks ----
         const uint32_t x64k = crc_xpow8(65536);
         for (size_t j = 0; j < mdesc.size(); ++j) {

@@ -58,6 +58,8 @@ hipError_t gz_pass2_launch(const uint32_t* words, const uint32_t* d_rec, const G
 hipError_t gz_tails_launch(uint16_t* d_sym, uint8_t* d_out, const GzRunDesc* d_runs, const GzGroupDesc* d_groups, uint32_t n_groups,
                            const GzMemberDesc* d_members, uint32_t n_members, uint32_t* d_err, hipStream_t stream);
 hipError_t gz_resolve_launch(const uint16_t* d_sym, uint8_t* d_out, const GzPiece* d_pieces, uint32_t n_pieces, uint32_t* d_err, hipStream_t stream);
+// d_first[i] = the first byte of member i's output (a member of no bytes: whatever lies at its base)
+hipError_t gz_first_bytes_launch(const uint8_t* d_out, const GzMemberDesc* d_members, uint32_t n, uint8_t* d_first, hipStream_t stream);
 // CRC-32 (as in the gzip trailer) of every chunk
 hipError_t gz_crc_launch(const uint8_t* d_out, const GzChunk* d_chunks, uint32_t n_chunks, uint32_t* d_crc, hipStream_t stream);
 

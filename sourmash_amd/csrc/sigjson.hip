@@ -97,58 +97,75 @@ __global__ __launch_bounds__(64) void sj_spans_kernel(const uint8_t* __restrict_
     if (lane == 0) doc_flags[d] = flags | n;
 }
 
+// A wavefront per array.  The text goes through LDS 4 KB at a time (coalesced 16-byte loads; a lane reading its own stretch of
+// the array byte by byte from HBM was one dependent trip to memory per byte: 17 ms for 6,000 arrays): lane l owns bytes
+// [64 l, 64 l + 64) of the chunk, counts its commas, a prefix sum gives every number its index, and the
+// lane parses the numbers that begin behind its commas -- they may run on into the next lane's bytes or the 64 bytes read
+// beyond the chunk.  Order and the down-sampling count are taken from the written values afterwards.
+constexpr uint32_t SJ_CHUNK = 4096, SJ_AHEAD = 64;
+
 __global__ __launch_bounds__(64) void sj_parse_kernel(const uint8_t* __restrict__ base, const SjParse* __restrict__ jobs, uint32_t n_jobs,
                                                       uint64_t* __restrict__ values, SjParsed* __restrict__ results, uint64_t keep_max) {
+    __shared__ uint4 buf4[(SJ_CHUNK + SJ_AHEAD + 16) / 16 + 1];
+    uint8_t* buf = reinterpret_cast<uint8_t*>(buf4);
     const uint32_t j = blockIdx.x;
     if (j >= n_jobs) return;
     const SjParse job = jobs[j];
     const uint8_t* t = base + job.text_off;
     const uint64_t len = job.len;                                     // bytes between '[' and ']'
     const uint32_t lane = threadIdx.x & 63u;
-    const uint64_t a = len * lane / 64, b = len * (lane + 1) / 64;
-    uint32_t my_commas = 0;
-    for (uint64_t i = a; i < b; ++i) my_commas += t[i] == ',';
-    uint32_t incl = my_commas;
-    for (int o = 1; o < 64; o <<= 1) { const uint32_t u = __shfl_up(incl, o); if (lane >= (uint32_t)o) incl += u; }
-    uint64_t idx = incl - my_commas;                                  // commas in front of this lane's piece
     uint64_t* out = values + job.value_off;
-    uint32_t bad = 0, kept = 0, any = 0;
-    uint64_t first = 0, last = 0;
-    auto number = [&](uint64_t from, uint64_t index) {                // the number that begins at `from` (white space allowed around it)
-        uint64_t i = from;
-        while (i < len && is_ws(t[i])) ++i;
-        uint64_t v = 0;
-        uint32_t nd = 0;
-        while (i < len && t[i] >= '0' && t[i] <= '9') {
-            if (nd >= 19 && (v > 1844674407370955161ull || (v == 1844674407370955161ull && t[i] > '5'))) bad = 1;   // beyond 2^64 - 1
-            v = v * 10 + (uint64_t)(t[i] - '0');
-            ++nd;
-            ++i;
-        }
-        while (i < len && is_ws(t[i])) ++i;
-        if (nd == 0 || (i < len && t[i] != ',')) bad = 1;
-        if (index < job.n_values) out[index] = v;
-        if (any && v <= last) bad = 1;                                // ascending, no repeats
-        if (!any) first = v;
-        last = v;
-        any = 1;
+    uint32_t bad = 0;
+    uint64_t index = 0;                                               // numbers in front of the chunk
+    for (uint64_t c0 = 0; c0 < len; c0 += SJ_CHUNK) {
+        // bytes [c0, c0 + SJ_CHUNK + SJ_AHEAD) of the array -> buf[shift ...], from the 16-byte line they begin in
+        const uintptr_t addr = reinterpret_cast<uintptr_t>(t + c0);
+        const uint32_t shift = (uint32_t)(addr & 15u);
+        const uint4* src = reinterpret_cast<const uint4*>(addr - shift);
+        const uint64_t avail = len - c0;                              // bytes of the array from c0 on
+        const uint32_t want = (uint32_t)(avail < SJ_CHUNK + SJ_AHEAD ? avail : SJ_CHUNK + SJ_AHEAD);
+        const uint32_t lines = (shift + want + 15u) / 16u;
+        __syncthreads();
+        for (uint32_t l = lane; l < lines; l += 64u) buf4[l] = src[l];
+        __syncthreads();
+        const uint8_t* b = buf + shift;                               // b[i] = byte c0 + i of the array, i < want
+        const uint32_t in_chunk = (uint32_t)(avail < SJ_CHUNK ? avail : SJ_CHUNK);
+        const uint32_t p0 = lane * 64u, p1 = p0 + 64u < in_chunk ? p0 + 64u : in_chunk;
+        uint32_t commas = 0;
+        for (uint32_t i = p0; i < p1; ++i) commas += b[i] == ',';
+        uint32_t incl = commas;
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t u = __shfl_up(incl, o); if (lane >= (uint32_t)o) incl += u; }
+        const uint32_t chunk_commas = __shfl(incl, 63);
+        uint64_t k = index + (incl - commas);                         // commas in front of this lane's bytes = index of the number open there
+        auto number = [&](uint32_t from, uint64_t idx) {              // the number that begins at b[from] (white space allowed around it)
+            uint32_t i = from;
+            while (i < want && is_ws(b[i])) ++i;
+            uint64_t v = 0;
+            uint32_t nd = 0;
+            while (i < want && b[i] >= '0' && b[i] <= '9') {
+                if (nd >= 19 && (v > 1844674407370955161ull || (v == 1844674407370955161ull && b[i] > '5'))) bad = 1;   // beyond 2^64 - 1
+                v = v * 10 + (uint64_t)(b[i] - '0');
+                ++nd;
+                ++i;
+            }
+            while (i < want && is_ws(b[i])) ++i;
+            if (nd == 0 || nd > 20) bad = 1;
+            if (i < want ? b[i] != ',' : c0 + i < len) bad = 1;       // ends at a comma, or at the end of the array (not at the end of what was read)
+            if (idx < job.n_values) out[idx] = v;
+        };
+        if (c0 == 0 && lane == 0 && job.n_values) number(0, 0);
+        for (uint32_t i = p0; i < p1; ++i)
+            if (b[i] == ',') { ++k; number(i + 1, k); }
+        index += chunk_commas;
+    }
+    // order (ascending, no repeats: minhash.rs:161-171 would sort -- such an array is the host's) and the down-sampling count
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __syncthreads();
+    uint32_t kept = 0;
+    for (uint64_t i = lane; i < job.n_values; i += 64u) {
+        const uint64_t v = out[i];
         kept += v <= keep_max;
-    };
-    if (lane == 0 && job.n_values) number(0, 0);
-    for (uint64_t i = a; i < b; ++i)
-        if (t[i] == ',') { ++idx; number(i + 1, idx); }
-    // order across the pieces: every lane's first value against the last value in front of it
-    uint32_t have_prev = 0;
-    uint64_t prev = 0;
-    for (uint32_t l = 0; l < 64; ++l) {
-        const uint32_t l_any = __shfl(any, l);
-        const uint64_t l_first = ((uint64_t)__shfl((uint32_t)(first >> 32), l) << 32) | __shfl((uint32_t)first, l);
-        const uint64_t l_last = ((uint64_t)__shfl((uint32_t)(last >> 32), l) << 32) | __shfl((uint32_t)last, l);
-        if (l_any) {
-            if (have_prev && l_first <= prev) bad = 1;
-            prev = l_last;
-            have_prev = 1;
-        }
+        if (i + 1 < job.n_values && out[i + 1] <= v) bad = 1;
     }
     for (int o = 32; o; o >>= 1) { kept += __shfl_xor(kept, o); bad |= __shfl_xor(bad, o); }
     if (lane == 0) {

@@ -78,9 +78,16 @@ inline void CollectionLoader::run_device(hipStream_t st, DeviceResult& out) {
     }
     const uint64_t keep_max = sel_.scaled ? max_hash_for_scaled(sel_.scaled) : ~0ull;
     std::vector<std::unique_ptr<AsyncBuf>> value_blocks(groups.size());
-    PinnedBuf host;
+    // (pinning a quarter of a gigabyte costs tens of milliseconds: the staging buffer outlives the call, like the ingest's;
+    //  callers hold the context's mutex)
+    static PinnedBuf& host = *new PinnedBuf();
+    static const bool trace = getenv("SMG_SIGLOAD_TRACE") != nullptr;
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     for (size_t g = 0; g < groups.size(); ++g) {
         const size_t i0 = groups[g].i0, i1 = groups[g].i1, n = i1 - i0;
+        const double t_g0 = now();
+        double t_read = 0, t_inflate = 0, t_spans = 0, t_parse = 0;
+        GunzipStats gstats;
         // the bytes of the group's gzip documents, side by side
         std::vector<GunzipMember> ms(n);
         uint64_t total = 0;
@@ -113,6 +120,7 @@ inline void CollectionLoader::run_device(hipStream_t st, DeviceResult& out) {
             memset(dst + ms[k].file_len, 0, (size_t)(((ms[k].file_len + 7) & ~7ull) - ms[k].file_len));
             have[k] = dst[0] == 0x1f && dst[1] == 0x8b;
         });
+        t_read = now() - t_g0;
         std::vector<size_t> live;                                     // group-relative numbers of the documents on the device path
         std::vector<GunzipMember> gm;
         for (size_t k = 0; k < n; ++k) if (have[k]) { gm.push_back(ms[k]); live.push_back(k); } else by_host[i0 + k] = 1;
@@ -121,7 +129,8 @@ inline void CollectionLoader::run_device(hipStream_t st, DeviceResult& out) {
         AsyncBuf d_files((size_t)total + GUNZIP_PAD + 64, st);
         hip_check(hipMemcpyAsync(d_files.p, host.p, (size_t)total + GUNZIP_PAD, hipMemcpyHostToDevice, st), "H2D");
         void* d_text = nullptr;
-        gunzip_device(host.p, d_files.as<uint8_t>(), total, gm, &d_text, st);
+        gunzip_device(host.p, d_files.as<uint8_t>(), total, gm, &d_text, st, trace ? &gstats : nullptr);
+        t_inflate = now() - t_g0 - t_read;
         struct FreeText { void*& p; hipStream_t st; ~FreeText() { if (p) arena_free(p, st); } } free_text{d_text, st};
         std::vector<SjDoc> docs;
         std::vector<size_t> doc_item;                                 // docs[d] is item i0 + doc_item[d]
@@ -140,6 +149,7 @@ inline void CollectionLoader::run_device(hipStream_t st, DeviceResult& out) {
         hip_check(hipMemcpyAsync(spans.data(), d_spans.p, spans.size() * sizeof(SjSpan), hipMemcpyDeviceToHost, st), "D2H");
         hip_check(hipMemcpyAsync(flags.data(), d_flags.p, flags.size() * 4, hipMemcpyDeviceToHost, st), "D2H");
         hip_check(hipStreamSynchronize(st), "sync");
+        t_spans = now() - t_g0 - t_read - t_inflate;
         // ---- the numbers of every `mins` array; what lies outside the arrays, packed for the host ----
         std::vector<SjParse> jobs;
         std::vector<SjPiece> rest;                                    // pieces of text outside the arrays
@@ -189,6 +199,7 @@ inline void CollectionLoader::run_device(hipStream_t st, DeviceResult& out) {
             if (rest_bytes) hip_check(hipMemcpyAsync(rest_text.data(), d_rest_bytes.p, (size_t)rest_bytes, hipMemcpyDeviceToHost, st), "D2H");
         }
         hip_check(hipStreamSynchronize(st), "sync");
+        t_parse = now() - t_g0 - t_read - t_inflate - t_spans;
         // ---- the metadata, by the host's scanner on the remainder (every array replaced by its index) ----
         parallel(docs.size(), [&](size_t d) {
             const DocPlan& pl = plan[d];
@@ -231,7 +242,12 @@ inline void CollectionLoader::run_device(hipStream_t st, DeviceResult& out) {
             piece.group = (int)g;
             pieces[item] = std::move(piece);
         });
+        if (trace)
+            fprintf(stderr, "[sigload] group of %zu documents (%.0f MB): %.1f ms (read %.1f, H2D + inflate %.1f [scan %.1f pass1 %.1f link %.1f pass2 %.1f finish %.1f], "
+                            "arrays %.1f, numbers + remainder %.1f, metadata %.1f)\n", n, total / 1e6, now() - t_g0, t_read, t_inflate, gstats.scan_ms, gstats.pass1_ms,
+                    gstats.link_ms, gstats.pass2_ms, gstats.finish_ms, t_spans, t_parse, now() - t_g0 - t_read - t_inflate - t_spans - t_parse);
     }
+    const double t_groups = now();
     // ---- the documents the device did not take: the host path of collection.hpp ----
     std::vector<size_t> host_items;
     for (size_t i = 0; i < n_items; ++i) if (by_host[i]) host_items.push_back(i);
@@ -285,6 +301,7 @@ inline void CollectionLoader::run_device(hipStream_t st, DeviceResult& out) {
         for (auto& row : p.rows) out.rows.push_back(std::move(row));
     }
     out.total = out.offsets.back();
+    const double t_rows = now();
     hip_check(arena_alloc(&out.d_hashes, (size_t)out.total * 8 + 16, st), "arena_alloc");
     try {
         for (size_t g = 0; g < groups.size(); ++g) {
@@ -303,6 +320,8 @@ inline void CollectionLoader::run_device(hipStream_t st, DeviceResult& out) {
         out.d_hashes = nullptr;
         throw;
     }
+    if (trace) fprintf(stderr, "[sigload] %zu documents by the host parser and the rows' bookkeeping %.1f ms, hashes into their rows %.1f ms\n",
+                       host_items.size(), t_rows - t_groups, now() - t_rows);
 }
 
 }  // namespace smg
