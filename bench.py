@@ -490,6 +490,8 @@ def extras_summary(extra):
         "translate_k10_G_windows_per_s": r(get("sketch_translate", "translate_protein_k10", "G_windows_per_s")),
         "sketch_Gbase_per_s_by_k": {k[1:]: v.get("Gbase_per_s") for k, v in bk.items() if k.startswith("k") and isinstance(v, dict)},
         "ingest_fasta_Gbase_per_s": r(get("ingest_fasta", "Gbase_per_s")), "ingest_gz_Gbase_per_s": r(get("ingest_gz", "Gbase_per_s")),
+        "ingest_gz_level6_Gbase_per_s": r(get("ingest_gz_level6", "Gbase_per_s")), "ingest_gz_256_files_Gbase_per_s": r(get("ingest_gz_256_files", "Gbase_per_s")),
+        "sigload_10k_signatures_per_s": r(get("sigload_10k", "signatures_per_s"), 0), "sigload_10k_seconds": r(get("sigload_10k", "seconds")),
         "errors": [k for k in extra if k.endswith("error")],
     }
 
@@ -1335,12 +1337,49 @@ def io_extras(extra, torch, np, dev, smd):
         t0 = time.perf_counter()
         sig_gz, = sketch_file(gz, "k=31,scaled=1000")
         dt = time.perf_counter() - t0
+        from sourmash_amd.sketch import gunzip_files, gunzip_counters, sketch_files
+        c0 = gunzip_counters()
+        _, stages = gunzip_files([gz])
         extra["ingest_gz"] = {
             "gz_bytes": os.path.getsize(gz), "inflated_bytes": part_bytes, "bases": part_bases, "seconds": round(dt, 3),
             "Gbase_per_s": round(part_bases / dt / 1e9, 2), "same_sketch_as_the_plain_file": bool(sig_gz.md5sum() == sig_part.md5sum()),
-            "host_threads": os.cpu_count(), "bound": "zlib inflate on the host's cores: one stream does ~0.25 GB/s; csrc/pargz.hpp cuts one "
-                                                     "member into spans inflated on all usable threads",
-            "what": "one gzip member (level 1) of 400 MB of the same FASTA -> sketch, end to end"}
+            "inflater_stages_ms": {k: round(v, 2) for k, v in stages.items()},
+            "bound": "the device inflater (csrc/gunzip.hip): pass 1 -- one wavefront per deflate block, ~40 instructions a symbol, every "
+                     "CU's issue slots full -- then the expansion of its records; PCIe carries the compressed third of the bytes",
+            "what": "one gzip member (zlib level 1) of 400 MB of the same FASTA -> sketch, end to end; the member is inflated in HBM "
+                    "(every block at once, CRC-32 checked), the host inflater is the fallback"}
+        # the same member at zlib's default level (what `gzip` writes: longer matches, fewer symbols per byte)
+        gz6 = os.path.join(tmp, "synth_part6.fa.gz")
+        co = zlib.compressobj(6, zlib.DEFLATED, 31)
+        with open(part, "rb") as fi, open(gz6, "wb") as fo:
+            while True:
+                block = fi.read(16 << 20)
+                if not block:
+                    break
+                fo.write(co.compress(block))
+            fo.write(co.flush())
+        sketch_file(gz6, "k=31,scaled=1000")
+        t0 = time.perf_counter()
+        sig_gz6, = sketch_file(gz6, "k=31,scaled=1000")
+        dt6 = time.perf_counter() - t0
+        extra["ingest_gz_level6"] = {"gz_bytes": os.path.getsize(gz6), "bases": part_bases, "seconds": round(dt6, 3), "Gbase_per_s": round(part_bases / dt6 / 1e9, 2),
+                                     "same_sketch_as_the_plain_file": bool(sig_gz6.md5sum() == sig_part.md5sum())}
+        # 256 genomes: copies of the reference's E. coli K-12 fixture (1.3 MB .fna.gz each), `sketch` over all of them
+        src = os.path.join(ROOT, "tests", "golden", "ecoli", "GCF_000005845.2_ASM584v2_genomic.fna.gz")
+        many = []
+        for i in range(256):
+            many.append(os.path.join(tmp, f"g{i}.fna.gz"))
+            shutil.copyfile(src, many[-1])
+        sketch_files(many, "k=21,k=31,k=51,scaled=1000", threads=16)
+        t0 = time.perf_counter()
+        sigs = sketch_files(many, "k=21,k=31,k=51,scaled=1000", threads=16)
+        dtm = time.perf_counter() - t0
+        c1 = gunzip_counters()
+        extra["ingest_gz_256_files"] = {
+            "files": 256, "bases": 4_641_652 * 256, "seconds": round(dtm, 3), "Gbase_per_s": round(4_641_652 * 256 / dtm / 1e9, 2),
+            "files_per_s": round(256 / dtm, 1), "golden_md5_k31": all(s.minhashes()[1].md5sum() == "0a8632c67e6d88f737ddb510bef90337" for s in sigs),
+            "what": "smgpu_sketch_files: the members of a batch of files inflated in one pass and sketched together (k = 21, 31, 51)"}
+        extra["gunzip_counters"] = {"inflated_on_the_device": c1[0] - c0[0], "handed_to_the_host_inflater": c1[1] - c0[1]}
         # ---- 10,000 signatures of ~5,000 hashes as a sourmash-style zip -> CSR in HBM ----
         zpath = os.path.join(tmp, "coll.zip")
         nsig = 10_000
@@ -1366,9 +1405,11 @@ def io_extras(extra, torch, np, dev, smd):
         dt = time.perf_counter() - t0
         extra["sigload_10k"] = {
             "signatures": len(db), "zip_bytes": zbytes, "seconds": round(dt, 3), "signatures_per_s": round(len(db) / dt, 1),
-            "zip_MB_per_s": round(zbytes / dt / 1e6, 1), "host_threads": os.cpu_count(),
-            "bound": "gzip inflate + JSON number parsing on the host's cores (the H2D copy of the 400 MB CSR is ~7 ms)",
-            "what": "SketchSet.load of a 10,000-member zip (stored .sig.gz members + manifest) -> one CSR in HBM, no per-sketch object"}
+            "zip_MB_per_s": round(zbytes / dt / 1e6, 1),
+            "bound": "the device inflater's pass 1 over 427 MB of gzip members (digits: literals and short matches, many symbols a byte), "
+                     "then the number parser (csrc/sigjson.hip); the host reads only what lies outside the hash arrays",
+            "what": "SketchSet.load of a 10,000-member zip (stored .sig.gz members + manifest) -> one CSR in HBM, no per-sketch object; "
+                    "100,000 members: profiles/r06_sigload.json (tools/bench_sigload.py)"}
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
 

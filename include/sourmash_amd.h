@@ -379,6 +379,10 @@ void smgpu_host_free(void *ptr);
 /* Bytes and nanoseconds the host-pointer entry points spent moving large pageable buffers (csrc/hostxfer.hpp) since the last reset:
  * out5 = {H2D bytes, D2H bytes, H2D ns, D2H ns, calls}.  Diagnostics for bench.py's API-level lines. */
 void smgpu_xfer_stats(uint64_t *out5, bool reset);
+/* The two directions of that path by themselves (tests): the n host pieces (pieces[i], lens[i] bytes, pageable or pinned, empty
+ * ones allowed) are packed into one device buffer through the pinned ring, and that buffer comes back into out[0, out_bytes)
+ * (out_bytes = the sum of lens) through the ring -- or directly when out is pinned (smgpu_host_alloc). */
+void smgpu_xfer_roundtrip(const void *const *pieces, const uint64_t *lens, uintptr_t n, void *out, uint64_t out_bytes);
 /* All pairs of BOTTOM-K (num) sketches in one launch (csrc/compare_ext.hip) -- what src/sourmash/compare.py:36-54 asks
  * kmerminhash_similarity for pair by pair: common_out[i][j] = |A ∩ B ∩ merged|, union_out[i][j] = |merged| with merged = the
  * num smallest hashes of A ∪ B, num taken from the sketch with the lower index (src/core/src/sketch/minhash.rs:593-621: the

@@ -4,7 +4,9 @@
 // (src/core/src/ffi/{utils,mod,minhash,signature,cmd/compute}.rs) on top of the
 // host containers (minhash_host.hpp, signature_host.hpp) and the HIP kernels
 // (DeviceCtx / device_api.hpp).  Part 2 are the smgpu_* batch extensions.
+#if defined(__SSE2__)
 #include <emmintrin.h>
+#endif
 #include <hip/hip_runtime_api.h>
 #include <stdio.h>
 #include <string.h>
@@ -146,6 +148,7 @@ size_t first_invalid_byte(const uint8_t* seq, size_t len) {
         Table() { memset(bad, 1, sizeof(bad)); for (const char* c = "ACGTacgt"; *c; ++c) bad[(uint8_t)*c] = 0; }
     } t;
     size_t i = 0;
+#if defined(__SSE2__)
     // sixteen bytes at a time (SSE2, part of every x86-64): fold the case bit away, then a byte is fine iff it equals one
     // of A C G T (a byte >= 0x80 keeps its top bit and equals none of them)
     const __m128i fold = _mm_set1_epi8((char)0xdf), cA = _mm_set1_epi8('A'), cC = _mm_set1_epi8('C'), cG = _mm_set1_epi8('G'),
@@ -157,6 +160,7 @@ size_t first_invalid_byte(const uint8_t* seq, size_t len) {
         const unsigned m = (unsigned)_mm_movemask_epi8(ok);
         if (m != 0xffffu) return i + (size_t)__builtin_ctz(~m & 0xffffu);
     }
+#endif
     for (; i < len; ++i)
         if (t.bad[seq[i]]) return i;
     return SIZE_MAX;
@@ -1305,6 +1309,20 @@ void* smgpu_host_alloc(uintptr_t bytes) {
 }
 void smgpu_host_free(void* p) { arena_pinned_free(p); }
 
+void smgpu_xfer_roundtrip(const void* const* pieces, const uint64_t* lens, uintptr_t n, void* out, uint64_t out_bytes) {
+    landing_void([&] {
+        DeviceCtx& ctx = DeviceCtx::get();
+        std::lock_guard<std::recursive_mutex> g(ctx.mutex());
+        hipStream_t st = ctx.stream();
+        std::vector<HostPiece> ps(n);
+        size_t total = 0;
+        for (uintptr_t i = 0; i < n; ++i) { ps[i] = HostPiece{pieces[i], total, (size_t)lens[i]}; total += (size_t)lens[i]; }
+        if (total != out_bytes) throw err_internal("smgpu_xfer_roundtrip: the pieces do not add up to out_bytes");
+        AsyncBuf dev(total + 16, st);
+        HostXfer::get().gather_to_device(dev.p, ps, total, st);
+        HostXfer::get().device_to_host(out, dev.p, total, st);
+    });
+}
 void smgpu_xfer_stats(uint64_t* out5, bool reset) {
     const HostXfer::Stats x = HostXfer::get().stats();
     if (out5) { out5[0] = x.h2d_bytes; out5[1] = x.d2h_bytes; out5[2] = x.h2d_ns; out5[3] = x.d2h_ns; out5[4] = x.calls; }

@@ -12,7 +12,9 @@
 // Callers hold the device context's lock (device_ctx.hpp), which serialises the use of the ring.
 #pragma once
 #include <hip/hip_runtime_api.h>
-#include <emmintrin.h>
+#if defined(__SSE2__)
+#include <emmintrin.h>          // streaming stores; every other host (an aarch64 ROCm node) takes the memcpy path below
+#endif
 #include <sched.h>
 #include <sys/mman.h>
 #include <stdint.h>
@@ -137,6 +139,9 @@ class HostXfer {
     static void copy_streaming(char* dst, const char* src, size_t n) {
         static const bool on = [] { const char* e = getenv("SMG_XFER_STREAM"); return !(e && *e == '0'); }();
         if (!on || n < 256) { memcpy(dst, src, n); return; }
+#if !defined(__SSE2__)
+        memcpy(dst, src, n);
+#else
         const size_t head = (16 - ((uintptr_t)dst & 15)) & 15;
         memcpy(dst, src, head);
         dst += head; src += head; n -= head;
@@ -146,6 +151,7 @@ class HostXfer {
             _mm_stream_si128(reinterpret_cast<__m128i*>(dst) + i, v);
         }
         memcpy(dst + blocks * 16, src + blocks * 16, n - blocks * 16);
+#endif
     }
     // bytes [off, off + len) of the packed buffer, gathered from the pieces, by the worker threads (each takes a byte range)
     static void fill(char* dst, const std::vector<HostPiece>& pieces, size_t first, size_t off, size_t len) {
@@ -156,7 +162,9 @@ class HostXfer {
                 const size_t a = std::max(pieces[i].dst_off, off + lo), b = std::min(pieces[i].dst_off + pieces[i].bytes, off + hi);
                 if (b > a) copy_streaming(dst + (a - off), static_cast<const char*>(pieces[i].src) + (a - pieces[i].dst_off), b - a);
             }
+#if defined(__SSE2__)
             _mm_sfence();                                               // the streamed lines are on their way before the copy engine is told
+#endif
         };
         run(len, part);
     }
