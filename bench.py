@@ -1066,8 +1066,8 @@ def compare_ext_extras(extra, torch, np, dev, be, smd, synth_sketches, timed):
     ms = timed(lambda: be.rustcall(lib.smgpu_compare_abund_raw, p(h), p(ab), p(off), n, True, p(common), p(prod), p(sq), st()))
     extra["compare_abund_1000x1000"] = {"pairs": pairs, "ms": round(ms, 3), "pairs_per_s": round(pairs / (ms * 1e-3), 1),
                                         "roofline": merge_roofline(alg, ms),
-                                        "kernel": "compare_ext_kernel<abund32>: the same tiles accumulating abundance products (minhash.rs:635-680), "
-                                                  "tiles with a long sketch cut into hash-range slices; parity: "
+                                        "kernel": "csrc/abund_pairs.hip: per-block hash-sorted lists (ap_slice_kernel: the sorted rows merged slice by slice in LDS, "
+                                                  "no sort) joined tile by tile (ap_join_kernel, minhash.rs:635-680); parity: "
                                                   "tests/test_gpu_compare.py::test_angular_all_pairs_batched_vs_oracle"}
 
 

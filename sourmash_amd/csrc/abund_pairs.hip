@@ -8,7 +8,7 @@
 // 5 x 10^5 pairs x 10^4 steps at config C3's shape, 5.5 ms, a dependent LDS chain per step.  The work that has to be done is the
 // MATCHES: 2.5 x 10^8 products at C3 (10 % of every pair's hashes are shared), a twentieth of the walk's steps.  Here the
 // collection is turned once into per-block lists -- the elements of 64 consecutive sketches sorted by hash, each with its row within
-// the block and its abundance (two stable device radix sorts: by hash, then by block) -- and an output tile (block bi x block bj)
+// the block and its abundance (round 6: the sorted rows merged slice by slice in LDS, below) -- and an output tile (block bi x block bj)
 // is the merge-join of two such lists: equal hashes meet, and every (row of bi, row of bj) pair of a met hash adds one product to
 // the tile's 64 x 64 accumulators in LDS.  A tile's join is cut into Z hash slices when there are few tiles (C3: 136 tiles on
 // 256 CUs), the slices' sums meeting in the zeroed matrices through atomics.
@@ -23,7 +23,6 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
-#include <rocprim/device/device_radix_sort.hpp>
 #include "arena.hpp"
 #include "device_api.hpp"
 
@@ -49,34 +48,172 @@ constexpr int AP_G = 16;                 // lanes that share a longer run
         if (e_ != hipSuccess) return e_;   \
     } while (0)
 
-// pos[p] = p, blk[p] = block of the sketch that element p belongs to
-__global__ __launch_bounds__(256) void ap_rows_kernel(const uint64_t* __restrict__ offsets, uint32_t n, uint32_t* __restrict__ pos,
-                                                      uint32_t* __restrict__ rowid) {
-    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
-    const int lane = threadIdx.x & 63;
-    for (uint64_t r = wave; r < n; r += n_waves)
-        for (uint64_t i = offsets[r] + lane; i < offsets[r + 1]; i += 64) { pos[i] = (uint32_t)i; rowid[i] = (uint32_t)r; }
+// ---- the lists: a block's 64 sorted rows merged, hash slice by hash slice, in LDS (round 6) ---------------------------------
+// Round 5 built the lists with two device radix sorts (by hash, then by block: nine passes over every element, 0.7 ms of the call's
+// 1.9 at C3's shape) although every row arrives sorted.  Now the hash space is cut into `n_slices` equal slices (a shift of the
+// hash: about a thousand entries of a block fall into one), `cuts[row][s]` = where slice s starts in the row (one binary search per
+// row and slice), and one workgroup merges a (block, slice): its place in the block's list is known from the cuts alone (the
+// entries of the block's rows below the slice), the <= SM_CAP entries go to LDS grouped by SM_BUCKETS order-preserving sub-buckets
+// of the slice (count, prefix, place), and an entry's final position is its bucket's start + the number of the bucket's entries with
+// a smaller (hash, row) -- a handful of compares, no sort.  A slice with more entries than the LDS room (hashes far from uniform)
+// is ranked against the rows' parts in memory instead: slow, same result.
+constexpr int SM_CAP = 2048;             // entries of a (block, slice) merged in LDS
+constexpr int SM_BUCKETS = 2048;         // sub-buckets of a slice
+constexpr int SM_BUCKET_BITS = 11;
+constexpr int SM_THREADS = 256;
+constexpr int SM_TARGET = 640;           // entries per (block, slice) aimed at; the shift lands between this and twice this
+
+struct ApPlan { uint32_t shift, n_slices; };
+
+__global__ __launch_bounds__(1024) void ap_plan_kernel(const uint64_t* __restrict__ hashes, const uint64_t* __restrict__ offsets, uint32_t n,
+                                                       uint32_t s_max, ApPlan* __restrict__ plan) {
+    __shared__ unsigned long long s_m[16];
+    unsigned long long m = 0;
+    for (uint32_t r = threadIdx.x; r < n; r += 1024) {
+        const uint64_t o0 = offsets[r], o1 = offsets[r + 1];
+        if (o1 > o0) { const unsigned long long last = hashes[o1 - 1]; m = last > m ? last : m; }      // rows are sorted
+    }
+#pragma unroll
+    for (int d = 32; d; d >>= 1) { const unsigned long long o = __shfl_xor(m, d); m = o > m ? o : m; }
+    if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < 16; ++w) m = s_m[w] > m ? s_m[w] : m;
+        uint32_t shift = 0;
+        while ((m >> shift) >= (unsigned long long)s_max) ++shift;             // s_max >= 2: ends at 63 at the latest
+        plan->shift = shift;
+        plan->n_slices = (uint32_t)(m >> shift) + 1u;                           // <= s_max
+    }
 }
 
-__global__ __launch_bounds__(256) void ap_block_keys_kernel(const uint32_t* __restrict__ pos_sorted, const uint32_t* __restrict__ rowid,
-                                                            uint64_t total, uint32_t* __restrict__ key) {
-    for (uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (uint64_t)gridDim.x * blockDim.x)
-        key[q] = rowid[pos_sorted[q]] / (uint32_t)AP_T;
+// cuts[r][s], s = 0 .. s_max: the first entry of row r that belongs to slice s or a later one (relative to the row's start)
+__global__ __launch_bounds__(256) void ap_cuts_kernel(const uint64_t* __restrict__ hashes, const uint64_t* __restrict__ offsets, uint32_t n,
+                                                      uint32_t s_max, const ApPlan* __restrict__ plan, uint32_t* __restrict__ cuts) {
+    const uint64_t idx = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    const uint32_t r = (uint32_t)(idx / (s_max + 1u)), s = (uint32_t)(idx % (s_max + 1u));
+    if (r >= n) return;
+    const uint32_t shift = plan->shift, ns = plan->n_slices;
+    const uint64_t o0 = offsets[r];
+    const uint32_t len = (uint32_t)(offsets[r + 1] - o0);
+    uint32_t lo = 0, hi = len;
+    if (s >= ns) lo = len;
+    else if (s > 0) {
+        const uint64_t x = (uint64_t)s << shift;                               // <= the largest hash: no overflow
+        const uint64_t* row = hashes + o0;
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (row[mid] < x) lo = mid + 1; else hi = mid;
+        }
+    }
+    cuts[idx] = lo;
 }
 
-// the lists: element q of the block-major, hash-sorted order -> its hash, its row within the block and its abundance
 template <bool NARROW>
-__global__ __launch_bounds__(256) void ap_gather_kernel(const uint32_t* __restrict__ pos_sorted, const uint32_t* __restrict__ rowid,
-                                                        const uint64_t* __restrict__ hashes, const uint64_t* __restrict__ abunds,
-                                                        uint64_t total, uint64_t* __restrict__ l_hash, uint64_t* __restrict__ l_pay,
-                                                        uint8_t* __restrict__ l_row) {
-    for (uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (uint64_t)gridDim.x * blockDim.x) {
-        const uint32_t p = pos_sorted[q];
-        const uint32_t r = rowid[p] % (uint32_t)AP_T;
-        l_hash[q] = hashes[p];
-        if (NARROW) l_pay[q] = ((uint64_t)r << 32) | (uint32_t)abunds[p];     // row and 32-bit abundance in one word
-        else { l_pay[q] = abunds[p]; l_row[q] = (uint8_t)r; }
+__global__ __launch_bounds__(SM_THREADS) void ap_slice_kernel(const uint64_t* __restrict__ hashes, const uint64_t* __restrict__ abunds,
+                                                              const uint64_t* __restrict__ offsets, uint32_t n,
+                                                              const uint32_t* __restrict__ cuts, uint32_t s_max,
+                                                              const ApPlan* __restrict__ plan, uint64_t* __restrict__ l_hash,
+                                                              uint64_t* __restrict__ l_pay, uint8_t* __restrict__ l_row) {
+    __shared__ uint64_t t_h[SM_CAP], t_v[SM_CAP];
+    __shared__ uint32_t s_cnt[SM_BUCKETS], s_start[SM_BUCKETS + 1];
+    __shared__ uint8_t t_r[SM_CAP];
+    __shared__ uint32_t s_c0[AP_T], s_len[AP_T], s_wsum[SM_THREADS / 64];
+    __shared__ uint32_t s_total;
+    __shared__ uint64_t s_out0;
+    const uint32_t ns = plan->n_slices, shift = plan->shift;
+    const uint32_t s = blockIdx.x % s_max, b = blockIdx.x / s_max;
+    if (s >= ns) return;
+    const int tid = threadIdx.x;
+    const uint32_t r0 = b * AP_T, nr = n - r0 < (uint32_t)AP_T ? n - r0 : (uint32_t)AP_T;
+    if (tid < 64) {
+        uint32_t c0 = 0, len = 0;
+        if ((uint32_t)tid < nr) {
+            const uint64_t at = (uint64_t)(r0 + tid) * (s_max + 1u) + s;
+            c0 = cuts[at];
+            len = cuts[at + 1] - c0;
+        }
+        s_c0[tid] = c0;
+        s_len[tid] = len;
+        unsigned long long below = c0;                                       // the block's entries below the slice: where it starts in the list
+        uint32_t tot = len;
+#pragma unroll
+        for (int d = 32; d; d >>= 1) { below += __shfl_xor(below, d); tot += __shfl_xor(tot, d); }
+        if (tid == 0) { s_total = tot; s_out0 = offsets[r0] + below; }
+    }
+    for (int i = tid; i < SM_BUCKETS; i += SM_THREADS) s_cnt[i] = 0;
+    __syncthreads();
+    const uint32_t total = s_total;
+    if (total == 0) return;
+    const uint64_t out0 = s_out0;
+    const uint32_t rr = (uint32_t)tid >> 2, q = (uint32_t)tid & 3u;          // four lanes walk a row's part of the slice
+    const uint32_t my_len = s_len[rr];
+    const uint64_t my_at = rr < nr ? offsets[r0 + rr] + s_c0[rr] : 0;
+    const uint64_t* row = hashes + my_at;
+    const uint64_t* arow = abunds + my_at;
+    const uint64_t base = (uint64_t)s << shift;
+    auto bucket = [&](uint64_t h) { const uint64_t rel = h - base; return (uint32_t)(shift > (uint32_t)SM_BUCKET_BITS ? rel >> (shift - SM_BUCKET_BITS) : rel); };
+    auto put = [&](uint64_t o, uint64_t h, uint64_t a, uint32_t r) {
+        l_hash[o] = h;
+        if (NARROW) l_pay[o] = ((uint64_t)r << 32) | (uint32_t)a;            // row and 32-bit abundance in one word
+        else { l_pay[o] = a; l_row[o] = (uint8_t)r; }
+    };
+    if (total <= (uint32_t)SM_CAP) {
+        for (uint32_t i = q; i < my_len; i += 4) atomicAdd(&s_cnt[bucket(row[i])], 1u);
+        __syncthreads();
+        {                                                                    // exclusive prefix of the bucket counts; the counts become cursors
+            constexpr int PER = SM_BUCKETS / SM_THREADS;
+            uint32_t c[PER], sum = 0;
+#pragma unroll
+            for (int u = 0; u < PER; ++u) { c[u] = s_cnt[tid * PER + u]; sum += c[u]; }
+            uint32_t incl = sum;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const uint32_t o = __shfl_up(incl, d); if ((tid & 63) >= d) incl += o; }
+            if ((tid & 63) == 63) s_wsum[tid >> 6] = incl;
+            __syncthreads();
+            uint32_t run = incl - sum;
+            for (int w = 0; w < (tid >> 6); ++w) run += s_wsum[w];
+#pragma unroll
+            for (int u = 0; u < PER; ++u) { s_start[tid * PER + u] = run; s_cnt[tid * PER + u] = 0; run += c[u]; }
+            if (tid == SM_THREADS - 1) s_start[SM_BUCKETS] = run;
+        }
+        __syncthreads();
+        for (uint32_t i = q; i < my_len; i += 4) {
+            const uint64_t h = row[i];
+            const uint32_t k = bucket(h);
+            const uint32_t p = s_start[k] + atomicAdd(&s_cnt[k], 1u);
+            t_h[p] = h; t_v[p] = arow[i]; t_r[p] = (uint8_t)rr;
+        }
+        __syncthreads();
+        for (uint32_t p = tid; p < total; p += SM_THREADS) {
+            const uint64_t h = t_h[p];
+            const uint32_t r = t_r[p], k = bucket(h);
+            const uint32_t b0 = s_start[k], b1 = s_start[k + 1];
+            uint32_t rank = 0;
+            for (uint32_t j = b0; j < b1; ++j) {
+                const uint64_t hj = t_h[j];
+                rank += (hj < h || (hj == h && (uint32_t)t_r[j] < r)) ? 1u : 0u;
+            }
+            put(out0 + b0 + rank, h, t_v[p], r);
+        }
+    } else {
+        // more entries than the LDS holds: an entry's place = the entries of the other rows' parts in front of it (equal hashes: the
+        // earlier rows') + its own index
+        for (uint32_t i = q; i < my_len; i += 4) {
+            const uint64_t h = row[i];
+            uint64_t rank = i;
+            for (uint32_t o = 0; o < nr; ++o) {
+                if (o == rr) continue;
+                const uint64_t* other = hashes + offsets[r0 + o] + s_c0[o];
+                uint32_t lo = 0, hi = s_len[o];
+                while (lo < hi) {
+                    const uint32_t mid = (lo + hi) >> 1;
+                    const uint64_t v = other[mid];
+                    if (v < h || (v == h && o < rr)) lo = mid + 1; else hi = mid;
+                }
+                rank += lo;
+            }
+            put(out0 + rank, h, arow[i], rr);
+        }
     }
 }
 
@@ -279,11 +416,6 @@ static_assert(AP_CHUNK <= 4096 && AP_T <= 64, "a worklist word holds a 12-bit ru
 static_assert((AP_CHUNK & (AP_CHUNK - 1)) == 0 && AP_T == 64, "the searches halve a power of two");
 static_assert(AP_THREADS == 1024 && AP_G == 16, "the list walk deals 64 groups of 16 lanes, four to a wave");
 
-unsigned ap_grid(uint64_t n_items) {
-    const uint64_t b = (n_items + 255) / 256;
-    return (unsigned)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
-}
-
 }  // namespace
 
 // -> hipErrorNotSupported when this formulation does not apply (2^32 elements or more): the caller keeps the walk kernel
@@ -297,45 +429,28 @@ hipError_t abund_pairs_launch(const uint64_t* d_hashes, const uint64_t* d_abunds
     AP_TRY(hipMemsetAsync(d_common, 0, (size_t)n * n * 4, stream));       // (pairs with nothing in common stay zero; slices add up)
     AP_TRY(hipMemsetAsync(d_prod, 0, (size_t)n * n * 8, stream));
     if (total == 0) return hipSuccess;
-    ArenaBuf pos_b, pos1_b, pos2_b, rowid_b, key_b, key2_b, h1_b, h2_b, lh_b, lp_b, lr_b, tmp_b;
-    AP_TRY(pos_b.get(total * 4 + 64, stream));
-    AP_TRY(pos1_b.get(total * 4 + 64, stream));
-    AP_TRY(pos2_b.get(total * 4 + 64, stream));
-    AP_TRY(rowid_b.get(total * 4 + 64, stream));
-    AP_TRY(key_b.get(total * 4 + 64, stream));
-    AP_TRY(key2_b.get(total * 4 + 64, stream));
-    AP_TRY(h1_b.get(total * 8 + 64, stream));
-    AP_TRY(h2_b.get(total * 8 + 64, stream));
+    // the per-block lists: plan (shift of the slices from the largest hash), cuts, one workgroup per (block, slice)
+    uint64_t per_block = total / nb / (uint64_t)SM_TARGET;
+    const uint32_t s_max = (uint32_t)(per_block < 2 ? 2 : (per_block > 0x100000ull ? 0x100000ull : per_block));
+    const uint64_t n_cuts = (uint64_t)n * (s_max + 1u);
+    if ((uint64_t)s_max * nb > 0x7fffffffull || n_cuts / 256 > 0x7ffffff0ull) return hipErrorNotSupported;
+    ArenaBuf plan_b, cuts_b, lh_b, lp_b, lr_b;
+    AP_TRY(plan_b.get(64, stream));
+    AP_TRY(cuts_b.get(n_cuts * 4 + 64, stream));
     AP_TRY(lh_b.get(total * 8 + 64, stream));
     AP_TRY(lp_b.get(total * 8 + 64, stream));
     if (!narrow) AP_TRY(lr_b.get(total + 64, stream));
-    uint32_t *pos = pos_b.as<uint32_t>(), *pos1 = pos1_b.as<uint32_t>(), *pos2 = pos2_b.as<uint32_t>(), *rowid = rowid_b.as<uint32_t>();
-    uint32_t *key = key_b.as<uint32_t>(), *key2 = key2_b.as<uint32_t>();
-    uint64_t *h1 = h1_b.as<uint64_t>(), *h2 = h2_b.as<uint64_t>();
-    size_t t1 = 0, t2 = 0;
-    unsigned bits = 1;
-    while ((1u << bits) < nb) ++bits;
-    AP_TRY(rocprim::radix_sort_pairs(nullptr, t1, h1, h2, pos, pos1, (size_t)total, 0u, 64u, stream));
-    AP_TRY(rocprim::radix_sort_pairs(nullptr, t2, key, key2, pos1, pos2, (size_t)total, 0u, bits, stream));
-    const size_t tbytes = (t1 > t2 ? t1 : t2) + 256;
-    AP_TRY(tmp_b.get(tbytes, stream));
-    // by hash (stable: equal hashes keep the order of their sketches) ...
-    AP_TRY(hipMemcpyAsync(h1, d_hashes, total * 8, hipMemcpyDeviceToDevice, stream));
-    hipLaunchKernelGGL(ap_rows_kernel, dim3(ap_grid(((uint64_t)n + 3) / 4 * 256)), dim3(256), 0, stream, d_offsets, n, pos, rowid);
-    AP_TRY(hipGetLastError());
-    size_t tb = tbytes;
-    AP_TRY(rocprim::radix_sort_pairs(tmp_b.p, tb, h1, h2, pos, pos1, (size_t)total, 0u, 64u, stream));
-    // ... then by block (stable: inside a block the elements stay sorted by hash, equal hashes by row)
-    hipLaunchKernelGGL(ap_block_keys_kernel, dim3(ap_grid(total)), dim3(256), 0, stream, (const uint32_t*)pos1, (const uint32_t*)rowid, total, key);
-    AP_TRY(hipGetLastError());
-    tb = tbytes;
-    AP_TRY(rocprim::radix_sort_pairs(tmp_b.p, tb, key, key2, pos1, pos2, (size_t)total, 0u, bits, stream));
+    hipLaunchKernelGGL(ap_plan_kernel, dim3(1), dim3(1024), 0, stream, d_hashes, d_offsets, n, s_max, plan_b.as<ApPlan>());
+    hipLaunchKernelGGL(ap_cuts_kernel, dim3((unsigned)((n_cuts + 255) / 256)), dim3(256), 0, stream, d_hashes, d_offsets, n, s_max,
+                       (const ApPlan*)plan_b.as<ApPlan>(), cuts_b.as<uint32_t>());
     if (narrow)
-        hipLaunchKernelGGL((ap_gather_kernel<true>), dim3(ap_grid(total)), dim3(256), 0, stream, (const uint32_t*)pos2, (const uint32_t*)rowid, d_hashes,
-                           d_abunds, total, lh_b.as<uint64_t>(), lp_b.as<uint64_t>(), (uint8_t*)nullptr);
+        hipLaunchKernelGGL((ap_slice_kernel<true>), dim3(s_max * nb), dim3(SM_THREADS), 0, stream, d_hashes, d_abunds, d_offsets, n,
+                           (const uint32_t*)cuts_b.as<uint32_t>(), s_max, (const ApPlan*)plan_b.as<ApPlan>(), lh_b.as<uint64_t>(), lp_b.as<uint64_t>(),
+                           (uint8_t*)nullptr);
     else
-        hipLaunchKernelGGL((ap_gather_kernel<false>), dim3(ap_grid(total)), dim3(256), 0, stream, (const uint32_t*)pos2, (const uint32_t*)rowid, d_hashes,
-                           d_abunds, total, lh_b.as<uint64_t>(), lp_b.as<uint64_t>(), lr_b.as<uint8_t>());
+        hipLaunchKernelGGL((ap_slice_kernel<false>), dim3(s_max * nb), dim3(SM_THREADS), 0, stream, d_hashes, d_abunds, d_offsets, n,
+                           (const uint32_t*)cuts_b.as<uint32_t>(), s_max, (const ApPlan*)plan_b.as<ApPlan>(), lh_b.as<uint64_t>(), lp_b.as<uint64_t>(),
+                           lr_b.as<uint8_t>());
     AP_TRY(hipGetLastError());
     // hash slices per tile: enough work items to fill the chip twice over when the tiles alone do not (SMG_ABUND_SLICES overrides)
     static const uint32_t z_env = [] { const char* e = getenv("SMG_ABUND_SLICES"); return e ? (uint32_t)atoi(e) : 0u; }();

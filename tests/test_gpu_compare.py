@@ -838,12 +838,13 @@ def test_abundance_join_and_walk_agree_on_ragged_collections(sm):
     and with SMG_COMPARE_ABUND=walk, from the per-pair walk (csrc/compare_ext.hip).  Both against the oracle on a collection with
     empty sketches, one-hash sketches, a sketch holding every hash of the pool, duplicates, more sketches than one 64-sketch block
     and not a multiple of it, and on one with a core of hashes held by EVERY sketch (runs of exactly 64 entries per block, cut by
-    the 4,096-entry staging area; 64-bit abundances whose products wrap); every hash-slice count the join can be cut into
-    (SMG_ABUND_SLICES)."""
+    the 4,096-entry staging area; 64-bit abundances whose products wrap), and on one whose hashes crowd into one hash slice of the
+    list build (round 6: more entries than the slice merge holds in LDS -- ranked against the rows in memory); every hash-slice count
+    the join can be cut into (SMG_ABUND_SLICES)."""
     import os, subprocess, sys
     from conftest import ROOT
     code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
-            "import test_gpu_compare as t\nt._abundance_ragged()\nt._abundance_core()\nprint('ok')\n" % (ROOT, os.path.join(ROOT, "tests")))
+            "import test_gpu_compare as t\nt._abundance_ragged()\nt._abundance_core()\nt._abundance_skewed()\nprint('ok')\n" % (ROOT, os.path.join(ROOT, "tests")))
     for extra in ({}, {"SMG_COMPARE_ABUND": "walk"}, {"SMG_ABUND_SLICES": "1"}, {"SMG_ABUND_SLICES": "3"}, {"SMG_ABUND_SLICES": "16"}):
         p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, **extra))
         assert p.returncode == 0 and p.stdout.strip().endswith("ok"), (extra, p.stdout[-1500:], p.stderr[-1500:])
@@ -874,6 +875,33 @@ def _abundance_ragged():
     want = oracle.similarity_matrix(omhs, ignore_abundance=False, nthreads=oracle.usable_cpus())
     got = angular_matrix(mhs)
     assert np.array_equal(got.view(np.uint64), want.view(np.uint64))
+
+
+def _abundance_skewed():
+    import torch  # noqa: F401
+    import sourmash_amd as sm
+    from sourmash_amd.compare import angular_matrix
+    rng = np.random.default_rng(33)
+    pool = np.unique(rng.integers(1, 20_000, size=5000, dtype=np.uint64))          # everything far below the one large hash
+    rows = [np.sort(rng.choice(pool, size=int(rng.integers(100, 200)), replace=False)) for _ in range(70)]
+    rows[3] = np.array([2**63 + 12345], dtype=np.uint64)                           # stretches the hash range: the others share slice 0
+    rows[69] = np.concatenate([rows[69], np.array([2**63 + 12345], dtype=np.uint64)])
+    mhs, omhs = [], []
+    for i, a in enumerate(rows):
+        ab = (a % np.uint64(9)) + np.uint64(1 + i % 4)
+        if i % 5 == 0:
+            ab = ab << np.uint64(31)                                               # the wide form's lists as well
+        mh = sm.MinHash(0, 31, scaled=1, track_abundance=True)
+        mh.set_abundances(dict(zip(a.tolist(), ab.tolist())))
+        mhs.append(mh)
+        omhs.append(_oracle_sketch(a, scaled=1, abunds=ab))
+    want = oracle.similarity_matrix(omhs, ignore_abundance=False, nthreads=oracle.usable_cpus())
+    got = angular_matrix(mhs)
+    assert np.array_equal(got.view(np.uint64), want.view(np.uint64))
+    narrow = angular_matrix(mhs[1:5] + mhs[6:10] + mhs[11:15] + mhs[16:20] + mhs[21:25] + mhs[26:30] + mhs[31:35] + mhs[36:40] + mhs[41:45] +
+                            mhs[46:50] + mhs[51:55] + mhs[56:60] + mhs[61:65] + mhs[66:70])
+    keep = [i for i in range(70) if i % 5]
+    assert np.array_equal(narrow.view(np.uint64), want[np.ix_(keep, keep)].view(np.uint64))
 
 
 def _abundance_core():
