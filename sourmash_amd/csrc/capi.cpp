@@ -988,8 +988,9 @@ struct BitIndex {
 };
 
 // measured rates behind the cost model (1 x MI355X)
-constexpr double RATE_MERGE_STEPS = 3.0e12;   // merge-step equivalents / s of compare_hash_kernel: 4.3e12 at C4 (431e6 pairs/s x 1e4 steps),
-                                              // 3.0e12 at C3 where 1,000 sketches do not fill the chip -- the smaller one decides small problems
+constexpr double RATE_MERGE_STEPS = 6.0e12;   // merge-step equivalents / s of compare_hash_kernel (a pair of sketches = n_i + n_j steps): 5.7e12 at 1,000 x 5,000
+                                              // hashes, 7.0e12 at 2,000, 9.5e12 at C4 (profiles/r06_compare_small.jsonl) -- the smaller one decides small problems
+constexpr double MERGE_ROUND_FLOOR = 6.0e-8;  // seconds per hash of the mean sketch: the latency floor of the general kernel's rounds
 constexpr double RATE_BIT_WORDS = 9.5e12;     // 32-bit AND+popcount / s (bitmatrix_kernel at C4: the VALU roof)
 constexpr double RATE_PAIR_ATOMICS = 4.0e9;   // matrix increments / s (rare_pairs_kernel)
 // the all-pairs callers compute the triangle and mirror it: a pair costs ONE visit of its tile / ONE increment, like the
@@ -1006,7 +1007,9 @@ static BitIndex* bitindex_build(const uint64_t* d_hashes, const uint64_t* d_offs
         hip_check(hipStreamSynchronize(st), "sync");
     }
     if (total == 0 || total > 0xffffffffull) return nullptr;
-    const double t_merge = (double)n * (double)total / RATE_MERGE_STEPS;
+    // (the general kernel walks a tile's sketches in lock-step rounds of <= 64 hashes, ~4 us a round however few tiles there are:
+    //  sixteen 5,000-hash sketches take 0.32 ms, 256 of them 0.43 -- tools/bench_compare_small.py, profiles/r06_compare_small.jsonl)
+    const double t_merge = std::max((double)n * (double)total / RATE_MERGE_STEPS, (double)total / (double)n * MERGE_ROUND_FLOOR);
     // a hash held by m sketches costs m^2 increments as a rare hash, or one bit column (n^2/2 pairs x 1/32 word) as
     // a frequent one: the two meet at m ~ n * sqrt(RATE_PAIR_ATOMICS / (64 * RATE_BIT_WORDS))
     uint32_t threshold = (uint32_t)((double)n * std::sqrt(RATE_PAIR_ATOMICS / (64.0 * RATE_BIT_WORDS)));
@@ -1052,8 +1055,10 @@ static BitIndex* bitindex_build(const uint64_t* d_hashes, const uint64_t* d_offs
             return bi.release();
         }
     }
-    // an index that serves ONE compare must also pay for its own sort (~0.6 ms of fixed cost + total / 5e9 s measured)
-    if (one_shot && !forced_threshold && t_merge < 0.6e-3 + (double)total / 5.0e9) return nullptr;
+    // an index that serves ONE compare must also pay for its own sort: ~0.6 ms of fixed cost + total / 1.4e9 s (round 6: a collection
+    // of mostly private hashes, 1,000 / 2,000 sketches of 5,000: 3.8 / 8.2 ms through this builder against 0.88 / 2.8 ms for the general
+    // kernel -- the earlier total / 5e9 sent such collections here, tools/bench_compare_small.py)
+    if (one_shot && !forced_threshold && t_merge < 0.6e-3 + (double)total / 1.4e9) return nullptr;
     // (hash, row) of the whole collection sorted by hash; runs = distinct hashes with their number of holders.
     // Scratch comes from the stream-ordered pool and the host reads back once: the kernels of a small build take
     // less time than one hipMalloc / hipFree pair or one extra synchronisation.

@@ -10,17 +10,15 @@
 // Layout: CSR -- d_hashes holds every sketch's sorted unique u64 hashes back to
 // back, d_offsets[n+1] the row starts.
 //
-// Kernel: one workgroup owns a 16 x 16 tile of (row sketch, column sketch)
-// pairs, one lane per pair.  The 32 sketches of the tile are streamed through
-// LDS in lock-step "slabs": every round each sketch contributes its next
-// <= SEG (64) hashes (coalesced loads, one wave per sketch segment), the
-// slab's upper bound `hi` is the smallest last-loaded hash among sketches that
-// still have more to come, and every lane two-pointer-merges the parts of its
-// row and column segments that are <= hi.  Sketches then advance by exactly
-// what was consumed.  This is the reference's merge walk, cut at common hash
-// boundaries so that 256 walks share each byte fetched: HBM/L2 sees every
-// hash of a tile once per round instead of 16 times.  Works for any length
-// mix (empty, 1-hash, 50k-hash rows) because the cut points are data driven.
+// Kernel (compare_hash_kernel, below): one workgroup owns a tile of 16 row sketches x 32 column sketches.  The tile's
+// sketches are streamed through LDS in lock-step "slabs": every round each sketch contributes its next <= 64 hashes
+// (coalesced loads, one wave per sketch segment), the slab's upper bound `hi` is the smallest last-loaded hash among
+// sketches that still have more to come, the rows' staged hashes <= hi go into an LDS hash table and the columns' are
+// looked up in it.  Sketches then advance by exactly what was consumed: the reference's merge walk cut at common hash
+// boundaries, so that HBM/L2 sees every hash of a tile once per round.  Works for any length mix (empty, 1-hash,
+// 50k-hash rows) because the cut points are data driven.  (Rounds 1-5 also kept the per-pair two-pointer walk over the
+// same slabs, compare_tile_kernel, behind SMG_COMPARE_KERNEL=walk, and four table geometries behind SMG_COMPARE_VARIANT:
+// no default reached them; removed in round 6 -- profiles/r02_compare_kernels.txt and HISTORY.md keep their numbers.)
 //
 // union = n_i + n_j - common (scaled sketches; equals the walk's union count),
 // so Jaccard needs only the u32 common matrix and the row lengths.
@@ -35,9 +33,6 @@
 namespace smg {
 
 constexpr int CT = 16;            // tile edge (sketches)
-constexpr int SEG_PAD = 2;        // u64 slack per staged segment: the walk may look one block past the end, and the
-                                  // odd dword shift spreads the 16 column segments over distinct LDS banks
-constexpr int CMP_BLOCK = CT * CT;
 constexpr int CMP_ZMAX = 16;      // hash-range slices per tile (grid.z); a tile uses ceil(longest / slice_len) of them
 
 __device__ __forceinline__ uint64_t lower_bound_row(const uint64_t* __restrict__ a, uint64_t lo, uint64_t hi, uint64_t x) {
@@ -59,7 +54,7 @@ __global__ __launch_bounds__(256) void compare_plan_kernel(
     const uint64_t* __restrict__ offsets, uint32_t n, uint32_t row_lo, uint32_t row_hi, int symmetric,
     uint32_t rb_first, uint32_t rb_stride, uint32_t n_row_tiles, uint32_t n_col_tiles, uint32_t slice_len,
     WorkItem* __restrict__ heavy, WorkItem* __restrict__ light, unsigned int* __restrict__ counters, uint32_t ctc) {
-    // ctc: columns per tile (CT for the walk kernel, HC for the hash kernel); rows per tile are CT for both
+    // ctc: columns per tile (HC); rows per tile are CT
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_row_tiles * n_col_tiles) return;
     const uint32_t ty = t / n_col_tiles, cb = t % n_col_tiles;
@@ -80,156 +75,11 @@ __global__ __launch_bounds__(256) void compare_plan_kernel(
     for (uint32_t z = 0; z < zt; ++z) list[base + z] = WorkItem{ty, cb, z, zt};
 }
 
-// Worker: persistent workgroups pull work items (heavy list first) with one atomic per item.
-template <int SEG>
-__global__ __launch_bounds__(CMP_BLOCK) void compare_tile_kernel(
-    const uint64_t* __restrict__ hashes, const uint64_t* __restrict__ offsets, uint32_t n,
-    uint32_t row_lo, uint32_t row_hi, uint32_t* __restrict__ common, int symmetric,
-    uint32_t rb_first, uint32_t rb_stride, const WorkItem* __restrict__ heavy,
-    const WorkItem* __restrict__ light, unsigned int* __restrict__ counters) {
-    // symmetric: 0 = every tile; 1 = all rows local: tiles on/above the diagonal, mirrored on write;
-    // 2 = upper tiles only, no mirror (sharded launch; symmetrize_kernel fills the rest).
-    // counters: [0] heavy items, [1] light items, [2] next heavy, [3] next light.
-    // Output rows: the tiles this launch owns back to back (local row = ty * CT + r); pre-zeroed,
-    // partial counts of the slices of a tile are combined with atomicAdd.
-    constexpr int SEG_STRIDE = SEG + SEG_PAD;
-    constexpr int PER_LANE = SEG / 64;                 // staged hashes per lane and sketch
-    static_assert(SEG % 64 == 0, "a wave stages whole rounds of 64 hashes");
-    __shared__ uint64_t s_seg[2 * CT][SEG_STRIDE];
-    __shared__ uint64_t s_pos[2 * CT], s_end[2 * CT];
-    __shared__ uint32_t s_take[2 * CT];
-    __shared__ unsigned long long s_hi;
-    __shared__ uint32_t s_live[2];   // [0] rows with data left, [1] columns with data left
-    __shared__ uint64_t s_piv[2];
-    __shared__ WorkItem s_item;
-    __shared__ int s_have;
+// Workers: persistent workgroups pull work items (heavy list first) with one atomic per item.
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int r = tid / CT, c = tid % CT;
-
-    for (;;) {
-        // ---- fetch the next work item ----
-        __syncthreads();                                   // previous item fully done (LDS reuse)
-        if (tid == 0) {
-            int have = 0;
-            unsigned int i = atomicAdd(&counters[2], 1u);
-            if (i < counters[0]) { s_item = heavy[i]; have = 1; }
-            else {
-                i = atomicAdd(&counters[3], 1u);
-                if (i < counters[1]) { s_item = light[i]; have = 1; }
-            }
-            s_have = have;
-        }
-        __syncthreads();
-        if (!s_have) return;
-        const WorkItem it = s_item;
-        const uint32_t rb = rb_first + it.ty * rb_stride;
-        const uint32_t row0 = row_lo + rb * CT, col0 = it.cb * CT;
-
-        if (tid < 2 * CT) {
-            const uint32_t s = tid < CT ? row0 + tid : col0 + (tid - CT);
-            const bool ok = tid < CT ? (s < row_hi) : (s < n);
-            s_pos[tid] = ok ? offsets[s] : 0;
-            s_end[tid] = ok ? offsets[s + 1] : 0;
-        }
-        __syncthreads();
-        // ---- hash-range slice: the tile's longest sketch is cut into zt equal pieces (pivot values);
-        //      slice z of EVERY sketch is its part inside [pivot_z, pivot_z+1) ----
-        if (it.zt > 1) {
-            if (tid == 0) {
-                uint64_t best_len = 0, best_pos = 0;
-                for (int i = 0; i < 2 * CT; ++i) {
-                    const uint64_t len = s_end[i] - s_pos[i];
-                    if (len > best_len) { best_len = len; best_pos = s_pos[i]; }
-                }
-                s_piv[0] = it.z == 0 ? 0ull : hashes[best_pos + (uint64_t)it.z * best_len / it.zt];
-                s_piv[1] = it.z + 1 == it.zt ? ~0ull : hashes[best_pos + (uint64_t)(it.z + 1) * best_len / it.zt];
-            }
-            __syncthreads();
-            if (tid < 2 * CT) {
-                const uint64_t lo = s_pos[tid], hi = s_end[tid];
-                const uint64_t a = it.z == 0 ? lo : lower_bound_row(hashes, lo, hi, s_piv[0]);
-                const uint64_t b = it.z + 1 == it.zt ? hi : lower_bound_row(hashes, a, hi, s_piv[1]);
-                s_pos[tid] = a;
-                s_end[tid] = b;
-            }
-            __syncthreads();
-        }
-        uint32_t cnt = 0;
-
-        for (;;) {
-            if (tid == 0) { s_hi = ~0ull; s_live[0] = 0; s_live[1] = 0; }
-            __syncthreads();
-            // ---- stage the next <= SEG hashes of each of the 32 sketches: wave w takes sketches 8w..8w+7,
-            //      lane l the hashes 2l, 2l+1 (one 16-byte load when aligned) ----
-            uint64_t e[8][PER_LANE];
-            uint32_t have[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int s = wave * 8 + i;
-                const uint64_t pos = s_pos[s], end = s_end[s];
-                const uint64_t left = end - pos;
-                const uint32_t len = left < (uint64_t)SEG ? (uint32_t)left : (uint32_t)SEG;
-                have[i] = len;
-#pragma unroll
-                for (int j = 0; j < PER_LANE; ++j) {
-                    const uint32_t idx = (uint32_t)(lane + 64 * j);
-                    const uint64_t v = idx < len ? hashes[pos + idx] : ~0ull;
-                    e[i][j] = v;
-                    s_seg[s][idx] = v;
-                }
-                if (lane == 0) {
-                    if (left > (uint64_t)SEG) atomicMin(&s_hi, (unsigned long long)hashes[pos + SEG - 1]);
-                    if (len) atomicOr(&s_live[s < CT ? 0 : 1], 1u);
-                }
-            }
-            __syncthreads();
-            if (s_live[0] == 0 || s_live[1] == 0) break;   // every row or every column exhausted
-            const uint64_t hi = s_hi;
-            // ---- how many staged hashes of each sketch are <= hi ----
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int s = wave * 8 + i;
-                uint32_t take = 0;
-#pragma unroll
-                for (int j = 0; j < PER_LANE; ++j)
-                    take += (uint32_t)__popcll(__ballot((uint32_t)(lane + 64 * j) < have[i] && e[i][j] <= hi));
-                if (lane == 0) { s_take[s] = take; s_pos[s] += take; }
-            }
-            __syncthreads();
-            // ---- the merge walk of minhash.rs:915-953 on the LDS-resident parts ----
-            {
-                const uint32_t na = s_take[r], nb = s_take[CT + c];
-                const uint64_t* A = s_seg[r];
-                const uint64_t* B = s_seg[CT + c];
-                uint32_t ia = 0, ib = 0;
-                while (ia < na && ib < nb) {
-                    const uint64_t a = A[ia], b = B[ib];
-                    const bool lt = a < b, gt = b < a;         // compiles to three compares feeding three add-with-carry
-                    cnt += !(lt | gt);
-                    ia += !gt;
-                    ib += !lt;
-                }
-            }
-            // next round's staging overwrites s_seg: the barrier at the top of the loop orders it
-        }
-
-        const uint32_t row = row0 + r, col = col0 + c;
-        if (row < row_hi && col < n && cnt) {
-            const uint64_t idx = (uint64_t)(it.ty * CT + r) * n + col;
-            if (!symmetric) {
-                atomicAdd(&common[idx], cnt);
-            } else if (col >= row) {
-                atomicAdd(&common[idx], cnt);
-                if (symmetric == 1 && col != row) atomicAdd(&common[(uint64_t)(col - row_lo) * n + row], cnt);
-            }
-        }
-    }
-}
-
-// ---- hash-table form of the tile (the default) ---------------------------------------------------------------------
-// The walk above spends one step per element of BOTH lists for EVERY pair (256 pairs x (n_i + n_j) steps per tile,
-// 13 VALU instructions a step): at C4 it is bound by instruction issue, not by LDS or memory.  The same slab structure
+// ---- the tile through a hash table ------------------------------------------------------------------------------------
+// A two-pointer walk spends one step per element of BOTH lists for EVERY pair (256 pairs x (n_i + n_j) steps per tile,
+// 13 VALU instructions a step): at C4 it was bound by instruction issue, not by LDS or memory.  The slab structure
 // admits a formulation whose work grows with the ELEMENTS of a tile instead: per round, the <= 64 staged hashes of each
 // of the 16 ROW sketches are inserted into an LDS hash table (key = hash, value = 16-bit mask of the rows holding it),
 // then every staged hash of the 32 COLUMN sketches is looked up once; bit r of the mask it finds says row r shares it.
@@ -341,7 +191,7 @@ __global__ __launch_bounds__(HBLOCK, MINW) void compare_hash_kernel(
             s_end[tid] = ok ? offsets[s + 1] : 0;
         }
         __syncthreads();
-        if (it.zt > 1) {                                   // hash-range slice of a heavy tile, as in the walk kernel
+        if (it.zt > 1) {                                   // hash-range slice of a heavy tile
             if (tid == 0) {
                 uint64_t best_len = 0, best_pos = 0;
                 for (int i = 0; i < HR + HC; ++i) {
@@ -569,21 +419,10 @@ size_t compare_workspace_bytes(uint32_t n_row_tiles, uint32_t n_col_tiles) {
     return 256 + tiles * sizeof(WorkItem) * (CMP_ZMAX + 1);        // heavy (x ZMAX) + light (x 1) lists
 }
 
-static bool use_walk_kernel() {
-    static const bool walk = [] { const char* e = getenv("SMG_COMPARE_KERNEL"); return e && !strcmp(e, "walk"); }();
-    return walk;
-}
-
-static int hash_variant() {       // SMG_COMPARE_VARIANT: tuning variants of the hash-table kernel (profiles/r02_compare_kernels.txt)
-    static const int v = [] { const char* e = getenv("SMG_COMPARE_VARIANT"); return e ? atoi(e) : 0; }();
-    return v;
-}
-
 static hipError_t compare_launch(const uint64_t* d_hashes, const uint64_t* d_offsets, uint32_t n, uint32_t row_lo,
                                  uint32_t row_hi, int symmetric, uint32_t rb_first, uint32_t rb_stride,
                                  uint32_t n_row_tiles, uint32_t* d_common, hipStream_t stream) {
-    const bool walk = use_walk_kernel();
-    const uint32_t ctc = walk ? CT : HC;                              // columns per tile
+    const uint32_t ctc = HC;                                          // columns per tile
     const uint32_t n_col_tiles = (n + ctc - 1) / ctc;
     const size_t tiles = (size_t)n_row_tiles * n_col_tiles;
     // the sharded form owns whole 16-row tiles ([n_row_tiles * 16][n]); the others own exactly rows [row_lo, row_hi)
@@ -602,29 +441,10 @@ static hipError_t compare_launch(const uint64_t* d_hashes, const uint64_t* d_off
         hipLaunchKernelGGL(compare_plan_kernel, dim3((unsigned)((tiles + 255) / 256)), dim3(256), 0, stream, d_offsets, n,
                            row_lo, row_hi, symmetric, rb_first, rb_stride, n_row_tiles, n_col_tiles,
                            pick_slice_len(work_tiles), heavy, light, counters, ctc);
-        const uint64_t cap = 256ull * (walk ? 8 : (hash_variant() == 3 ? 4 : 3));
+        const uint64_t cap = 256ull * 3;                               // 4,096 slots (load factor 1/4), 43 KiB of LDS, 80 VGPRs: 3 workgroups per CU
         const unsigned grid0 = (unsigned)(work_tiles + 1 < cap ? work_tiles + 1 : cap);
-        if (walk)
-            // 64 hashes per sketch and round: 17 KiB of LDS per workgroup, 8 workgroups (= 8 waves per SIMD) per CU.
-            // The walk is a dependent LDS round trip per step; twice the resident waves hide it better than longer
-            // rounds amortise the barriers (measured: +33 % pairs/s over 128 hashes per round at 5,000-hash sketches).
-            hipLaunchKernelGGL((compare_tile_kernel<64>), dim3(grid0 < 1 ? 1 : grid0), dim3(CMP_BLOCK), 0, stream, d_hashes,
-                               d_offsets, n, row_lo, row_hi, d_common, symmetric, rb_first, rb_stride, heavy, light, counters);
-        else {
-            // two register budgets of the same kernel: 96 VGPRs (2 workgroups = 16 waves per CU, nothing spilled; default)
-            // and 80 VGPRs (3 workgroups, 44 bytes per lane spilled); SMG_COMPARE_OCC=6 picks the second
-            const int variant = hash_variant();
-#define SMG_LAUNCH_HASH(MINW, LOGT)                                                                                              \
-    hipLaunchKernelGGL((compare_hash_kernel<MINW, LOGT>), dim3(grid0 < 1 ? 1 : grid0), dim3(HBLOCK), 0, stream, d_hashes, d_offsets, \
-                       n, row_lo, row_hi, d_common, symmetric, rb_first, rb_stride, heavy, light, counters)
-            if (variant == 1) SMG_LAUNCH_HASH(5, 11);           // 2,048 slots, 96 VGPRs, 2 workgroups per CU
-            else if (variant == 2) SMG_LAUNCH_HASH(6, 11);      // 2,048 slots (load factor 1/2), 80 VGPRs, 3 workgroups per CU
-            else if (variant == 3) SMG_LAUNCH_HASH(8, 11);      // 2,048 slots, 64 VGPRs, 4 workgroups per CU
-            else if (variant == 4) SMG_LAUNCH_HASH(5, 12);      // 4,096 slots, 96 VGPRs, 2 workgroups per CU
-            else SMG_LAUNCH_HASH(6, 12);                        // default: 4,096 slots (load factor 1/4: shorter probe chains), 43 KiB
-                                                                // of LDS, 80 VGPRs, 3 workgroups per CU
-#undef SMG_LAUNCH_HASH
-        }
+        hipLaunchKernelGGL((compare_hash_kernel<6, 12>), dim3(grid0 < 1 ? 1 : grid0), dim3(HBLOCK), 0, stream, d_hashes, d_offsets, n, row_lo, row_hi,
+                           d_common, symmetric, rb_first, rb_stride, heavy, light, counters);
         e = hipGetLastError();
     }
     arena_free(ws, stream);

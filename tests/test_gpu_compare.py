@@ -412,13 +412,11 @@ def test_mixed_scaled_and_mixed_abundance_follow_the_per_pair_rule(sm):
     assert np.array_equal(compare_serial(mixed, True), compare_serial(_sigs_from_arrays(sm, sk[:5]), True))
 
 
-def test_compare_extreme_hash_values_and_both_tile_kernels():
+def test_compare_extreme_hash_values():
     """The hash-table tile kernel keeps 2^64 - 1 (possible with scaled = 1) out of its table and counts it out of band;
-    0 is an ordinary key.  Ragged collection with those values planted, more rows than one tile, vs the oracle -- for the
-    default (hash-table) kernel here and for the walk kernel in a subprocess (SMG_COMPARE_KERNEL is read once)."""
-    import json, os, subprocess, sys
+    0 is an ordinary key.  Ragged collection with those values planted, more rows than one tile, vs the oracle (the general
+    all-pairs kernel: whole matrix and row blocks)."""
     import torch
-    from conftest import ROOT
     from sourmash_amd import device as smd
     rng = np.random.default_rng(11)
     top = np.uint64(2**64 - 1)
@@ -445,21 +443,6 @@ def test_compare_extreme_hash_values_and_both_tile_kernels():
         cb, _ = smd.compare_rows(h, off, lo, hi)
         torch.cuda.synchronize()
         assert np.array_equal(cb.cpu().numpy().view(np.uint32), wc[lo:hi])
-    code = ("import sys, json, numpy as np, torch; sys.path.insert(0, %r)\n"
-            "from sourmash_amd import device as smd\n"
-            "sk = [np.array(r, dtype=np.uint64) for r in json.load(open(sys.argv[1]))]\n"
-            "h, off = smd.pack_csr(sk)\n"
-            "c, j = smd.compare_rows(h, off)\n"
-            "torch.cuda.synchronize()\n"
-            "np.save(sys.argv[2], c.cpu().numpy())\n" % ROOT)
-    import tempfile
-    with tempfile.TemporaryDirectory() as tmp:
-        src, dst = os.path.join(tmp, "sk.json"), os.path.join(tmp, "c.npy")
-        json.dump([r.tolist() for r in sk], open(src, "w"))
-        p = subprocess.run([sys.executable, "-c", code, src, dst], env=dict(os.environ, SMG_COMPARE_KERNEL="walk"),
-                           capture_output=True, text=True, timeout=600)
-        assert p.returncode == 0, p.stderr[-2000:]
-        assert np.array_equal(np.load(dst).view(np.uint32), wc)
 
 
 def _slot_of_table_kernel(v, log_slots=12):

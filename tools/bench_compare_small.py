@@ -35,7 +35,7 @@ def main():
             ms_general = wall(lambda: smd.compare_rows(h, off, common=c0, jaccard=j0))
 
             def forced():
-                idx = smd.BitIndex.build(h, off, threshold=None, one_shot=False)
+                idx = smd.BitIndex.build(h, off, threshold=max(1, int(n * 0.00256)), one_shot=False)   # the model's own threshold, forced
                 return None if idx is None else smd.compare_rows(h, off, index=idx)
             f = forced()
             ms_index = wall(forced) if f is not None else None
@@ -45,7 +45,7 @@ def main():
             same = bool((ca[:n] == c0).all().item()) and bool((ja.view(torch.int64) == j0.view(torch.int64)).all().item())
             rows.append({"collection": label, "n": n, "mean_hashes": round(float(off[-1].item()) / n, 1), "pairs": pairs,
                          "general_ms": round(ms_general, 3), "index_ms_incl_build": None if ms_index is None else round(ms_index, 3),
-                         "auto_ms": round(ms_auto, 3), "auto_took": "general kernel" if took is None else "index (builder %d)" % took.builder,
+                         "auto_ms": round(ms_auto, 3), "auto_took": "general kernel" if took is None else "index (builder %s)" % took.builder,
                          "auto_equals_general_bitwise": same,
                          "general_pairs_per_s": round(pairs / ms_general * 1e3, 1)})
             print(json.dumps(rows[-1]), flush=True)
