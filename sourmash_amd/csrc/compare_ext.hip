@@ -324,10 +324,8 @@ hipError_t compare_abund_launch(const uint64_t* d_hashes, const uint64_t* d_abun
     if (e != hipSuccess) return e;
     // slice length: tiles of ordinary sketches are cut as well when the grid is small -- a 1,000-sketch collection is 2,016 tiles
     // on 1,536 resident workgroups (two rounds, the second a third full); three slices per tile fill the rounds (5.83 -> 5.47 ms at C3)
-    static const uint32_t slice_env = [] { const char* e = getenv("SMG_COMPARE_ABUND_SLICE"); return e ? (uint32_t)atoi(e) : 0u; }();
     const uint32_t tiles = nt * (nt + 1) / 2;
     uint32_t slice_len = tiles >= 16384 ? XSLICE : XSLICE_SMALL;
-    if (slice_env) slice_len = slice_env;
     if (narrow)
         hipLaunchKernelGGL((compare_ext_kernel<X_ABUND32>), dim3(nt, nt, XZMAX), dim3(XT * XT), 0, stream, d_hashes, d_abunds, d_offsets,
                            (const uint32_t*)nullptr, n, d_common, d_prod, slice_len);

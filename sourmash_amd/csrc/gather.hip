@@ -96,15 +96,9 @@ __global__ __launch_bounds__(256) void build_fill_kernel(const uint32_t* __restr
 //   bounds   [R + 1][ndb]  first position of row d whose hash is >= Q[r * BR_RANGE]  (row length for r = R)
 //   partial  [B][nq]       pass 1: postings of query hash j contributed by block b; then its exclusive prefix over b
 // so that in pass 2 the slot of an element is post_off[j] + partial[b][j] + (LDS cursor of j in this workgroup).
-#ifndef SMG_BR_RANGE
-#define SMG_BR_RANGE 32768
-#endif
-constexpr int BR_RANGE = SMG_BR_RANGE;      // query positions per range: row slices long enough (~1 KB) to read DRAM efficiently
+constexpr int BR_RANGE = 32768;      // query positions per range: row slices long enough (~1 KB) to read DRAM efficiently
 constexpr int BR_EPW = 16;           // row slices a wave flattens per step (see apply_kernel)
-#ifndef SMG_BR_AHEAD
-#define SMG_BR_AHEAD 4
-#endif
-constexpr int BR_AHEAD = SMG_BR_AHEAD;   // steps of 64 lookups a wave keeps in flight in pass 1 (see build_range_kernel)
+constexpr int BR_AHEAD = 4;   // steps of 64 lookups a wave keeps in flight in pass 1 (see build_range_kernel)
 constexpr int BR_THREADS = 512;      // 64 KB of LDS per workgroup (u16 slots, two per word): 2 workgroups = 16 waves per CU
 // Two-level fill (the default): a 4-byte store per posting straight into its list leaves 32,768 lists x 8 lines open per
 // range -- far more than one L2 -- and partially filled lines were evicted and fetched back (8.1 GB written and 13.6 GB
@@ -1710,7 +1704,7 @@ static hipError_t gather_build_body(GatherDev& g, hipStream_t stream) {
     hipLaunchKernelGGL(qtable_kernel, dim3((g.q_buckets + 256) / 256), dim3(256), 0, stream, g.Q, g.nq, g.q_shift,
                        g.q_buckets, g.q_table);
     SMG_TRY(hipGetLastError());
-    if (g.nq && !getenv("SMG_GATHER_NO_QREC")) {
+    if (g.nq) {
         SMG_TRY(own_alloc(g, &g.q_rec, (uint64_t)g.q_buckets * sizeof(QRec)));
         hipLaunchKernelGGL(qrec_kernel, dim3((g.q_buckets + 255) / 256), dim3(256), 0, stream, g.Q, g.q_table, g.q_buckets, g.q_rec);
         SMG_TRY(hipGetLastError());
@@ -1738,7 +1732,6 @@ static hipError_t gather_build_body(GatherDev& g, hipStream_t stream) {
     // scratch of the range-partitioned builder: B x nq per-block prefixes and (R + 1) x ndb slice bounds, 4 bytes each.
     // B can shrink to what the 16-bit LDS slots allow (< 65536 rows per block); past 8 GB the atomic builder is used.
     uint64_t B = 64;
-    if (const char* e = getenv("SMG_GATHER_BUILD_BLOCKS")) B = strtoull(e, nullptr, 10);
     const uint64_t R64 = (g.nq + BR_RANGE - 1) / BR_RANGE, B_min = (g.ndb + 65534) / 65535;
     while (B > B_min && B > 1 && B * g.nq * 4 > (4ull << 30)) B /= 2;
     if (B < B_min) B = B_min;
@@ -2092,7 +2085,7 @@ hipError_t gather_launch_loop(GatherDev& g, hipStream_t stream, uint32_t n_wg, c
     if (sh && (sh->W == 0 || sh->W > (uint32_t)PL_THREADS || sh->rank >= sh->W || rowcap == 0)) return hipErrorInvalidValue;
     SMG_TRY(gather_loop_reserve(g, stream, n_wg, rowcap));
     a.xchg = g.loop_xchg;
-    static const uint32_t pf = [] { const char* e = getenv("SMG_GATHER_PREFETCH"); return e ? (uint32_t)atoi(e) : 1u; }();   // 0: no touches
+    const uint32_t pf = 1u;            // the waves that do not sweep touch the own best row while the records travel (0: no touches, 13.3 us per round against 11.8)
     a.prefetch = pf;
     static const bool trace = getenv("SMG_GATHER_TRACE") != nullptr;
     a.dbg = trace ? g.loop_xchg + (size_t)2 * n_wg * 4 : nullptr;           // 16 words behind the granules

@@ -53,7 +53,6 @@ class HostXfer {
             unsigned c = std::max(1u, std::thread::hardware_concurrency());
             cpu_set_t set;
             if (sched_getaffinity(0, sizeof(set), &set) == 0) c = std::min<unsigned>(c, (unsigned)CPU_COUNT(&set));
-            if (const char* e = getenv("SMG_XFER_THREADS")) return (unsigned)std::min(64, std::max(1, atoi(e)));
             return std::min(c, 8u);
         }();
         return n;
@@ -135,10 +134,9 @@ class HostXfer {
         return a.type == hipMemoryTypeHost;
     }
     // memcpy whose stores bypass the caches (SSE2 streaming stores, 16-byte aligned middle): the destination is a pinned slot the copy
-    // engine reads next -- nothing on the host reads it again (SMG_XFER_STREAM=0: plain memcpy)
+    // engine reads next -- nothing on the host reads it again
     static void copy_streaming(char* dst, const char* src, size_t n) {
-        static const bool on = [] { const char* e = getenv("SMG_XFER_STREAM"); return !(e && *e == '0'); }();
-        if (!on || n < 256) { memcpy(dst, src, n); return; }
+        if (n < 256) { memcpy(dst, src, n); return; }
 #if !defined(__SSE2__)
         memcpy(dst, src, n);
 #else

@@ -78,8 +78,7 @@ class RawChunkSource {
         } else {
             const uint64_t n_chunks = (size_ + chunk_ - 1) / chunk_;
             end_seq_ = (int64_t)n_chunks;
-            unsigned want = max_readers;            // SMG_INGEST_THREADS overrides (tuning)
-            if (const char* e = getenv("SMG_INGEST_THREADS")) { const long v = atol(e); if (v >= 1 && v <= SLOTS) want = (unsigned)v; }
+            unsigned want = max_readers;
             const unsigned nt = (unsigned)std::min<uint64_t>(want, n_chunks);
             for (unsigned t = 0; t < nt; ++t) threads_.emplace_back([this] { produce_plain(); });
         }
@@ -743,8 +742,7 @@ inline void sketch_files_parallel(const std::vector<std::string>& paths, const C
     //  pipelines run side by side whatever `threads` says, and the files are dealt in two rounds of batches per worker)
     static const unsigned max_workers = [] { const char* e = getenv("SMG_INGEST_WORKERS"); const long v = e ? atol(e) : 0; return (unsigned)(v >= 1 && v <= 64 ? v : 4); }();
     if (threads > max_workers) threads = max_workers;
-    static const size_t SMG_BATCHES = [] { const char* e = getenv("SMG_INGEST_BATCHES"); const long v = e ? atol(e) : 0; return (size_t)(v >= 1 && v <= 64 ? v : 0); }();
-    const size_t n_batches = SMG_BATCHES ? SMG_BATCHES : (size_t)threads * 2;
+    const size_t n_batches = (size_t)threads * 2;
     const size_t per_batch = threads <= 1 ? std::min<size_t>(64, paths.size())
                                           : std::max<size_t>(1, std::min<size_t>(64, (paths.size() + n_batches - 1) / n_batches));
     constexpr uint64_t BATCH_FILE_MAX = (uint64_t)64 << 20;          // larger files go by themselves (sketch_file_with inflates them)

@@ -180,18 +180,13 @@ struct OwGeom {
     static constexpr size_t LDS = (size_t)QCAP_ * 8 + T_BYTES + ((size_t)3 * ROWS + 8) * 4;
     static constexpr int WAVES_PER_EU = WAVES_PER_EU_;
 };
-#ifndef SMG_OW_LEAN_BATCH
-#define SMG_OW_LEAN_BATCH 4
-#endif
-using OwLean = OwGeom<25, 10240, 11264, uint32_t, 4, SMG_OW_LEAN_BATCH>;  // the lean kernel's geometry: ranges cut by query hashes held, not at a power of two of buckets
+using OwLean = OwGeom<25, 10240, 11264, uint32_t, 4, 4>;  // the lean kernel's geometry: ranges cut by query hashes held, not at a power of two of buckets
 
 // Query hashes per range of the streaming kernels.  A visit loads the next 64 hashes of its row and uses the ones below the
 // range's upper bound: a range should hold so many query hashes that a row's part of it is ~48 hashes (more, and one visit in
 // sixteen has to fetch a second block on the spot; fewer, and the visits multiply) -- 48 x nq / (mean row length), at most what
-// the LDS slice holds.  C5: 48 x 1e6 / 5,000 = 9,600.  SMG_OVERLAP_QPR overrides.
+// the LDS slice holds.  C5: 48 x 1e6 / 5,000 = 9,600.
 double lean_hashes_per_range(uint64_t nq, double mean_row) {
-    static const double env = [] { const char* e = getenv("SMG_OVERLAP_QPR"); return e ? atof(e) : 0.0; }();
-    if (env > 0.0) return env;
     double q = 48.0 * (double)nq / (mean_row < 1.0 ? 1.0 : mean_row);
     if (q > 9600.0) q = 9600.0;
     if (q < 512.0) q = 512.0;

@@ -200,7 +200,6 @@ class ParallelGunzip {
         if (fstat(fd_, &st) != 0) { ::close(fd_); throw std::runtime_error("cannot stat " + path); }
         size_ = (uint64_t)st.st_size;
         if (threads == 0) threads = usable_cpus();
-        if (const char* e = getenv("SMG_GUNZIP_THREADS")) { const long v = atol(e); if (v >= 1 && v <= 64) threads = (unsigned)v; }
         n_threads_ = std::max(1u, std::min(threads, 32u));
         parallel_ = false;
         if (getenv("SMG_GUNZIP_SEQUENTIAL") == nullptr && n_threads_ > 1 && size_ >= 4 * span_) {

@@ -245,9 +245,8 @@ hipError_t residue_windows_launch(const uint8_t* d_aa, uint64_t n, uint32_t k, u
     if (k == 0 || k > (uint32_t)MAX_RESIDUES) return hipErrorInvalidValue;
     if (n < k) return hipSuccess;
     // the register-window form: windows of up to 79 residues over an 8-byte aligned buffer (every buffer the library makes is);
-    // SMG_RESIDUE_KERNEL=bytes keeps the byte-wise kernel (tests: both against the oracle)
-    static const bool bytes_only = [] { const char* e = getenv("SMG_RESIDUE_KERNEL"); return e && !strcmp(e, "bytes"); }();
-    if (!bytes_only && k / 16 <= (uint32_t)RW_MAX_NB && ((uintptr_t)d_aa & 7) == 0) {
+    // longer windows and unaligned caller buffers take the byte-wise kernel below
+    if (k / 16 <= (uint32_t)RW_MAX_NB && ((uintptr_t)d_aa & 7) == 0) {
         switch (k / 16) {
         case 0: return window_fast_launch<0>(d_aa, n, k, seed, thr, d_out, d_count, cap, dense, stream);
         case 1: return window_fast_launch<1>(d_aa, n, k, seed, thr, d_out, d_count, cap, dense, stream);

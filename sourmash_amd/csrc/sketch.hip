@@ -98,8 +98,7 @@ static hipError_t sketch_any(const uint8_t* d_seq, uint64_t len, uint32_t k, uin
                              hipStream_t stream) {
     if (len < k || k == 0) return hipSuccess;
     static const bool generic_only = [] { const char* e = getenv("SMG_SKETCH_GENERIC"); return e && *e == '1'; }();
-    // from which k on the run-time-k kernel is taken (it accepts any k >= 16)
-    static const uint32_t words_from = [] { const char* e = getenv("SMG_SKETCH_WORDS_FROM"); const int v = e ? atoi(e) : 0; return v >= 16 ? (uint32_t)v : (uint32_t)FAST_MAX_K + 1u; }();
+    constexpr uint32_t words_from = (uint32_t)FAST_MAX_K + 1u;         // from this k on the run-time-k kernel is taken (it accepts any k >= 16)
     if (k >= words_from && !generic_only) return sketch_dna_words_launch(d_seq, len, k, seed, thr, d_out, d_count, cap, dense, stream);
     if (!dense && k <= (uint32_t)FAST_MAX_K && !generic_only) {
         const sketch_launch_fn f = k <= (uint32_t)FAST_HERE_K ? sparse_launcher_from<0>(k, std::make_integer_sequence<int, FAST_HERE_K>())

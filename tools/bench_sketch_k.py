@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Sketch throughput by ksize on resident synthetic DNA (kernel + sort + unique, scaled = 1000): every k from 1 to 88 runs an
 instantiation of the register-window kernel, longer k-mers the run-time-k kernel of sketch_words.hip; SMG_SKETCH_GENERIC=1 forces
-the byte loop (run in a subprocess, the switch is read once), SMG_SKETCH_WORDS_FROM=<k> moves the line between the two kernels.
+the byte loop (run in a subprocess, the switch is read once).
 python tools/bench_sketch_k.py [long | cross]"""
 import json
 import os
@@ -42,16 +42,6 @@ if __name__ == "__main__":
                                env=dict(os.environ, SMG_SKETCH_GENERIC="1"))
         generic = json.loads(child.stdout.strip().splitlines()[-1]) if child.returncode == 0 else {"error": child.stderr[-500:]}
         print(json.dumps({"bases": n, "words_kernel": words, "byte_wise_kernel_forced": generic}))
-        sys.exit(0)
-    if len(sys.argv) > 1 and sys.argv[1] == "cross":
-        # where the run-time-k kernel overtakes the unrolled register-window instantiations
-        n = 500_000_000
-        ks = [32, 64, 80, 84, 88]
-        window = run(ks, n)
-        child = subprocess.run([sys.executable, __file__, "child", str(n)] + [str(k) for k in ks], capture_output=True, text=True,
-                               env=dict(os.environ, SMG_SKETCH_WORDS_FROM="16"))
-        words = json.loads(child.stdout.strip().splitlines()[-1]) if child.returncode == 0 else {"error": child.stderr[-500:]}
-        print(json.dumps({"bases": n, "register_window_kernel": window, "words_kernel_forced": words}))
         sys.exit(0)
     n = 2_000_000_000
     fast = run([15, 21, 25, 27, 31, 33, 41, 51, 63, 64, 65, 80, 88, 89, 96, 112, 127, 128], n)
