@@ -1400,10 +1400,14 @@ def io_extras(extra, torch, np, dev, smd):
             zf.writestr("SOURMASH-MANIFEST.csv", man.getvalue(), compress_type=zipfile.ZIP_DEFLATED)
         zbytes = os.path.getsize(zpath)
         index.SketchSet.load(zpath, ksize=31, moltype="DNA")   # warm
-        t0 = time.perf_counter()
-        db = index.SketchSet.load(zpath, ksize=31, moltype="DNA")
-        dt = time.perf_counter() - t0
+        dts = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            db = index.SketchSet.load(zpath, ksize=31, moltype="DNA")
+            dts.append(time.perf_counter() - t0)
+        dt = min(dts)
         extra["sigload_10k"] = {
+            "seconds_each_of_3_loads": [round(x, 3) for x in dts],
             "signatures": len(db), "zip_bytes": zbytes, "seconds": round(dt, 3), "signatures_per_s": round(len(db) / dt, 1),
             "zip_MB_per_s": round(zbytes / dt / 1e6, 1),
             "bound": "the device inflater's pass 1 over 427 MB of gzip members (digits: literals and short matches, many symbols a byte), "

@@ -987,11 +987,11 @@ struct BitIndex {
     }
 };
 
-// measured rates behind the cost model (1 x MI355X; DESIGN.md 4.3b/4.3c)
+// measured rates behind the cost model (1 x MI355X; DESIGN.md 4.3)
 constexpr double RATE_MERGE_STEPS = 6.0e12;   // merge-step equivalents / s of compare_hash_kernel (a pair of sketches = n_i + n_j steps): 5.7e12 at 1,000 x 5,000
                                               // hashes, 7.0e12 at 2,000, 9.5e12 at C4 (profiles/r06_compare_small.jsonl) -- the smaller one decides small problems
 constexpr double MERGE_ROUND_FLOOR = 6.0e-8;  // seconds per hash of the mean sketch: the latency floor of the general kernel's rounds
-constexpr double RATE_BIT_WORDS = 9.5e12;     // 32-bit AND+popcount / s (bitmatrix_kernel at C4: the VALU roof, DESIGN.md 4.3b)
+constexpr double RATE_BIT_WORDS = 9.5e12;     // 32-bit AND+popcount / s (bitmatrix_kernel at C4: the VALU roof, DESIGN.md 4.3)
 constexpr double RATE_PAIR_ATOMICS = 4.0e9;   // matrix increments / s (rare_pairs_kernel)
 // the all-pairs callers compute the triangle and mirror it: a pair costs ONE visit of its tile / ONE increment, like the
 // n * total / 2 ... steps the merge rate is calibrated on.  (A bit column costs n^2/2 pairs x 1/32 word, a rare hash held by

@@ -165,7 +165,7 @@ __global__ __launch_bounds__(SL_THREADS) void stream_lookup_kernel(const uint64_
 // most lanes busy.  A workgroup owns a contiguous block of rows and walks every range over them, so every row is counted by
 // exactly one workgroup: plain stores, no atomics.  (Round 3's form of this kernel -- row cursors in LDS, per-lane flags;
 // overlap_wide_kernel and its two-workgroups-per-CU geometry -- was superseded by the lean visits below in round 4 and removed in
-// round 5: DESIGN.md 4.4 keeps its measurements.)
+// round 5: profiles/HISTORY.md 4.4 keeps its measurements.)
 constexpr int OW_THREADS = 1024;
 constexpr int OW_WAVES = OW_THREADS / 64;
 template <int SLOTS_, int BUCKETS_, int QCAP_, typename TT_, int WAVES_PER_EU_, int BATCH_>

@@ -1,4 +1,4 @@
-// Reproducer attempt for DESIGN.md 4.4 "the slice fill": does a scan over a sorted slice in LDS ever run past the two words of
+// Reproducer attempt for profiles/HISTORY.md 4.4 "the slice fill": does a scan over a sorted slice in LDS ever run past the two words of
 // 2^64 - 1 written behind the slice, depending on the FORM of the code that fills the table slice next to it?
 //
 // One 1,024-thread workgroup per CU walks the ranges of a query exactly as overlap_lean_kernel does (table slice + query slice into
