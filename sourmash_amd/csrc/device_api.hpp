@@ -17,6 +17,11 @@ hipError_t sketch_dna_launch(const uint8_t* d_seq, uint64_t len, uint32_t k, uin
 // d_out[i] = hash of the canonical k-mer starting at i for i in [0, n_kmers) (0 for k-mers
 // covering a byte outside ACGTacgt).  d_out must be zeroed by the caller.
 // k-mers longer than the register-window kernel holds (sketch_words.hip): k = 129 .. sketch_dna_max_k(), any k >= 16 accepted
+// several ksizes of one stretch in one pass (sketch_multi.hip): the standard ksize sets only
+struct SketchMultiOut { uint64_t thr; uint64_t* out; unsigned long long* count; uint64_t cap; };
+bool sketch_dna_multi_supported(const uint32_t* ks, int n);
+hipError_t sketch_dna_multi_launch(const uint8_t* d_new, uint64_t n_new, const uint32_t* ks, int n, uint64_t seed, const SketchMultiOut* outs,
+                                   hipStream_t stream);
 hipError_t sketch_dna_words_launch(const uint8_t* d_seq, uint64_t len, uint32_t k, uint64_t seed, uint64_t thr, uint64_t* d_out,
                                    unsigned long long* d_count, uint64_t cap, bool dense, hipStream_t stream);
 uint32_t sketch_dna_max_k();

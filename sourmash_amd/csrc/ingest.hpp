@@ -43,6 +43,9 @@ struct PinnedBuf {
         if (n <= cap) return;
         if (p) (void)hipHostFree(p);
         p = nullptr; cap = 0;
+        // (a quarter more than asked for, in whole 16 MiB: batches differ by a file or two, and pinning 60 MB takes ~100 ms --
+        //  a worker that grew by a megabyte per batch spent more time here than on its files)
+        n = ((n + n / 4) + ((size_t)16 << 20) - 1) & ~(((size_t)16 << 20) - 1);
         hip_check(hipHostMalloc((void**)&p, n, hipHostMallocDefault), "hipHostMalloc");
         cap = n;
     }
@@ -475,6 +478,8 @@ inline void sketch_file_with(IngestWorker& w, std::vector<KmerMinHash*>& mhs, co
         t_sync += now() - t1;
         if (src_host) src_host->release(seq);                 // the copy is complete: the pinned slot can be refilled
         total_kept += n_kept;
+        struct Pending { size_t s; uint32_t k; uint64_t thr; };
+        std::vector<Pending> pending;
         for (size_t s = 0; s < mhs.size(); ++s) {
             KmerMinHash& mh = *mhs[s];
             Acc& a = acc[s];
@@ -500,8 +505,32 @@ inline void sketch_file_with(IngestWorker& w, std::vector<KmerMinHash*>& mhs, co
                 a.out.p = bigger;
                 a.cap = ncap;
             }
-            hip_check(sketch_dna_launch(comp - (k - 1), slen, k, mh.seed, thr, a.out.as<uint64_t>(),
-                                        a.cnt.as<unsigned long long>(), a.cap, st), "sketch_dna");
+            pending.push_back(Pending{s, k, thr});
+        }
+        // the launches of this chunk: the signature's ksizes in one pass where the set has a fused kernel (sketch_multi.hip), else one each
+        {
+            bool fused = false;
+            if (pending.size() == 3 && pending.size() == mhs.size() && n_kept >= 64) {
+                uint32_t ks[3];
+                SketchMultiOut mo[3];
+                bool ok = true;
+                for (size_t q = 0; q < 3; ++q) {
+                    const Pending& pn = pending[q];
+                    ks[q] = pn.k;
+                    mo[q] = SketchMultiOut{pn.thr, acc[pn.s].out.as<uint64_t>(), acc[pn.s].cnt.as<unsigned long long>(), acc[pn.s].cap};
+                    ok = ok && mhs[pn.s]->seed == mhs[pending[0].s]->seed;
+                }
+                if (ok && sketch_dna_multi_supported(ks, 3)) {
+                    hip_check(sketch_dna_multi_launch(comp, (uint64_t)n_kept, ks, 3, mhs[pending[0].s]->seed, mo, st), "sketch_dna_multi");
+                    fused = true;
+                }
+            }
+            for (size_t q = 0; !fused && q < pending.size(); ++q) {
+                const Pending& pn = pending[q];
+                Acc& a = acc[pn.s];
+                hip_check(sketch_dna_launch(comp - (pn.k - 1), (size_t)(pn.k - 1) + (size_t)n_kept, pn.k, mhs[pn.s]->seed, pn.thr, a.out.as<uint64_t>(),
+                                            a.cnt.as<unsigned long long>(), a.cap, st), "sketch_dna");
+            }
         }
         // the next chunk's halo: the last kmax-1 bytes of the stream so far
         hip_check(fastx_halo_launch(comp, d_n, halo, scratch.comp[b ^ 1].as<uint8_t>() + scratch.halo - halo, st), "halo");
@@ -592,7 +621,24 @@ inline void sketch_slices_batched(IngestWorker& w, const std::vector<InflatedSli
         hip_check(fastx_compact_launch(static_cast<const uint8_t*>(slices[i].p), slices[i].len, fastq[j], sc, parse_state.as<uint8_t>(), cp,
                                        reinterpret_cast<unsigned long long*>(sc + 8), reinterpret_cast<unsigned long long*>(sc + 16),
                                        parse_temp.p, parse_temp_bytes, st), "fastx");
-        for (size_t q = 0; q < sigs[i].sketches.size(); ++q) {
+        // the signature's ksizes in one pass where the set has a fused kernel (sketch_multi.hip: 21 / 31 / 51), else a launch each
+        bool fused = false;
+        {
+            const auto& sk = sigs[i].sketches;
+            uint32_t ks[3];
+            SketchMultiOut mo[3];
+            bool same_seed = sk.size() == 3;
+            for (size_t q = 0; same_seed && q < 3; ++q) {
+                ks[q] = sk[q].ksize;
+                mo[q] = SketchMultiOut{sk[q].max_hash, outs.as<uint64_t>() + slot[j].out_off[q], reinterpret_cast<unsigned long long*>(sc + 32 + 16 * q), slot[j].cap[q]};
+                same_seed = sk[q].seed == sk[0].seed;
+            }
+            if (same_seed && sketch_dna_multi_supported(ks, 3)) {
+                hip_check(sketch_dna_multi_launch(cp, slices[i].len, ks, 3, sk[0].seed, mo, st), "sketch_dna_multi");
+                fused = true;
+            }
+        }
+        for (size_t q = 0; !fused && q < sigs[i].sketches.size(); ++q) {
             const KmerMinHash& mh = sigs[i].sketches[q];
             const uint32_t k = mh.ksize;
             hip_check(sketch_dna_launch(cp - (k - 1), (uint64_t)(k - 1) + slices[i].len, k, mh.seed, mh.max_hash, outs.as<uint64_t>() + slot[j].out_off[q],

@@ -107,6 +107,52 @@ for path in ({fq!r}, {fa!r}):
         assert np.array_equal(np.load(path + ".num.npy"), _oracle_sig(recs, 31, num=300).mins)
 
 
+def test_record_parser_over_many_blocks_and_the_fused_ksize_pass(sm, tmp_path):
+    """Round 6: the record structure comes from per-block summaries (csrc/fastx.hip: a block's effect on the line state, its kept
+    bytes as a function of the state that enters it), and k = 21 / 31 / 51 are hashed in one pass (csrc/sketch_multi.hip).  A FASTQ
+    of several hundred 8 KiB blocks whose quality lines start with '@', '>' and '+' (line counting, not first characters, decides),
+    a CRLF FASTA with '>' inside sequence lines and empty lines, whole and in chunks that are not multiples of the block -- with
+    abundances, so a k-mer hashed twice at a chunk border (the shorter ksizes start behind the longest one's halo) would show."""
+    rng = np.random.default_rng(77)
+    recs = []
+    for i in range(1500):
+        L = int(rng.integers(30, 2500))
+        s = bytearray(rng.choice(np.frombuffer(b"ACGTacgt", dtype=np.uint8), size=L).tobytes())
+        if i % 7 == 0:
+            s[L // 2] = ord("N")
+        recs.append((f"read{i}/1 len={L}", s.decode()))
+    fq = str(tmp_path / "big.fastq")
+    with open(fq, "w") as fh:
+        for i, (n, s) in enumerate(recs):
+            q = ("@>+I"[i % 4] + "I" * (len(s) - 1)) if s else ""
+            fh.write(f"@{n}\n{s}\n+{n if i % 3 == 0 else ''}\n{q}\n")
+    fa = str(tmp_path / "big.fa")
+    with open(fa, "wb") as fh:
+        for i, (n, s) in enumerate(recs):
+            body = "\r\n".join(s[j:j + 80] for j in range(0, len(s), 80))
+            fh.write((f">{n} a>b\r\n{body}\r\n" + ("\r\n" if i % 11 == 0 else "")).encode())
+    assert os.path.getsize(fq) > 300 * 8192
+    code = f"""
+import sys, numpy as np
+sys.path.insert(0, {ROOT!r})
+import torch
+from sourmash_amd.sketch import sketch_file
+for path in ({fq!r}, {fa!r}):
+    sig, = sketch_file(path, "k=21,k=31,k=51,scaled=50,abund")
+    for mh in sig.minhashes():
+        np.save(path + f".k{{mh.ksize}}.npy", np.array([list(mh.hashes.keys()), list(mh.hashes.values())], dtype=np.uint64))
+"""
+    wants = {k: _oracle_sig(recs, k, scaled=50, abund=True) for k in (21, 31, 51)}
+    for chunk in (None, "100003", "8192", "70001"):
+        env = dict(os.environ) if chunk is None else dict(os.environ, SMG_INGEST_CHUNK=chunk)
+        subprocess.check_call([sys.executable, "-c", code], env=env)
+        for path in (fq, fa):
+            for k in (21, 31, 51):
+                got = np.load(path + f".k{k}.npy")
+                assert np.array_equal(got[0], wants[k].mins), (chunk, path, k)
+                assert np.array_equal(got[1], wants[k].abunds), (chunk, path, k)
+
+
 def test_long_kmers_across_chunk_boundaries(sm, tmp_path):
     """k = 300 and 1,500 through the streaming ingest with chunks of 1,000 bytes: the halo between chunks is k - 1 bytes -- longer
     than a chunk for the second (rounds 1-4 kept a fixed 256-byte halo and refused k > 256)"""
