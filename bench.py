@@ -1059,11 +1059,12 @@ def compare_ext_extras(extra, torch, np, dev, be, smd, synth_sketches, timed):
     sk = synth_sketches(n, seed=1234)
     h, off = smd.pack_csr(sk, device=dev)
     ab = (h % 7 + 1) * ((h >> 3) % 11 + 1)
+    tot = int(off[-1].item())               # the caller of a raw device entry point knows its array sizes
     prod = torch.zeros((n, n), dtype=torch.int64, device=dev)
     sq = torch.zeros((n,), dtype=torch.int64, device=dev)
     sizes = (off[1:] - off[:-1]).cpu().numpy().astype(np.int64)
     alg = 2 * 8 * int(sizes.sum() * (n - 1))                 # hashes and abundances of both sketches of every pair
-    ms = timed(lambda: be.rustcall(lib.smgpu_compare_abund_raw, p(h), p(ab), p(off), n, True, p(common), p(prod), p(sq), st()))
+    ms = timed(lambda: be.rustcall(lib.smgpu_compare_abund_raw_n, p(h), p(ab), p(off), n, tot, True, p(common), p(prod), p(sq), st()))
     extra["compare_abund_1000x1000"] = {"pairs": pairs, "ms": round(ms, 3), "pairs_per_s": round(pairs / (ms * 1e-3), 1),
                                         "roofline": merge_roofline(alg, ms),
                                         "kernel": "csrc/abund_pairs.hip: per-block hash-sorted lists (ap_slice_kernel: the sorted rows merged slice by slice in LDS, "

@@ -288,7 +288,8 @@ uint64_t smgpu_sort_unique_raw(uint64_t *d_keys, uint64_t n, uint64_t *d_out, ui
                                uint64_t workspace_bytes, void *stream);
 /* The kernels of protein / dayhoff / hp sketches on device-resident input (src/core/src/signature.rs:307-393,
  * src/core/src/encodings.rs:103-368): the residues of a protein sequence -- or, translate = true, the six-frame translation of
- * DNA -- go to d_aa (capacity aa_capacity bytes; translated DNA needs 2 * len + 6), every window of k_aa residues is hashed and
+ * DNA -- go to d_aa (capacity aa_capacity bytes: the residue count rounded up to 8 -- the window kernel reads whole aligned
+ * 8-byte words; translated DNA needs 2 * len + 6 residues), every window of k_aa residues is hashed and
  * the hashes 1 <= h <= max_hash are appended unordered to d_out, their count added to *d_count (device u64, caller zeroes).
  * -> residues written to d_aa.  Fully asynchronous.  hash_function: 2 protein, 3 dayhoff, 4 hp. */
 uint64_t smgpu_sketch_residues_kernels_raw(const uint8_t *d_seq, uint64_t len, uint32_t k_aa, uint32_t hash_function, uint64_t seed,
@@ -404,6 +405,10 @@ void smgpu_compare_num_raw(const uint64_t *d_hashes, const uint64_t *d_offsets, 
                            uint32_t *d_common, uint32_t *d_union, double *d_jaccard, void *stream);
 void smgpu_compare_abund_raw(const uint64_t *d_hashes, const uint64_t *d_abunds, const uint64_t *d_offsets, uint32_t n, bool narrow,
                              uint32_t *d_common, uint64_t *d_prod, uint64_t *d_sumsq, void *stream);
+/* The same with the number of hashes (= d_offsets[n]) given by the caller: only enqueues work.  The form above reads d_offsets[n]
+ * back first and so blocks the caller until `stream` has drained. */
+void smgpu_compare_abund_raw_n(const uint64_t *d_hashes, const uint64_t *d_abunds, const uint64_t *d_offsets, uint32_t n,
+                               uint64_t total_hashes, bool narrow, uint32_t *d_common, uint64_t *d_prod, uint64_t *d_sumsq, void *stream);
 
 /* Device-resident sketch collection + gather counters: the batched form of CounterGather
  * (src/sourmash/index/__init__.py:735-909).  A SketchSet is a CSR of n sorted sketches in HBM;

@@ -200,8 +200,9 @@ void arena_pinned_free(void* p) {
         auto it = a.pinned_live.find(p);
         if (it == a.pinned_live.end()) return;
         // page-locked memory is the host's scarce kind: the cache of released blocks is bounded (SMG_PINNED_CACHE_MAX, default
-        // 4 GiB -- two 10,000 x 10,000 f64 result matrices and the transfer ring); what does not fit goes back to the driver
-        static const size_t cache_max = [] { const char* e = getenv("SMG_PINNED_CACHE_MAX"); return e ? (size_t)strtoull(e, nullptr, 10) : ((size_t)4 << 30); }();
+        // 2 GiB -- two 10,000 x 10,000 f64 result matrices, the common repeated shape, and the transfer ring; 4 GiB until round 6:
+        // ADVICE r05); what does not fit goes back to the driver
+        static const size_t cache_max = [] { const char* e = getenv("SMG_PINNED_CACHE_MAX"); return e ? (size_t)strtoull(e, nullptr, 10) : ((size_t)2 << 30); }();
         size_t cached = 0;
         for (const auto& pb : a.pinned_cached) cached += pb.second;
         if (cached + it->second <= cache_max) a.pinned_cached.emplace_back(p, it->second);

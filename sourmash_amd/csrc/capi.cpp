@@ -202,6 +202,7 @@ void add_sequence_dna(KmerMinHash& mh, const uint8_t* seq, size_t len, bool forc
     if (len < k || k == 0) return;                                  // signature.rs:206-210
     if (mh.num == 0 && mh.max_hash == 0) return;                    // sketch that can never hold anything
     (void)DeviceCtx::get();                                         // no device: fail now, not at the first accessor
+    check_dna_ksize(k);
     size_t use_len = len;
     bool raise = false;
     size_t bad_kmer = 0;
@@ -875,6 +876,7 @@ uint64_t smgpu_sketch_dna_raw(const uint8_t* d_seq, uint64_t len, uint32_t ksize
         void* d_tmp = (char*)d_ws + ((cap * 8 + 255) / 256) * 256;
         const size_t tmp_bytes = (size_t)(ws_bytes - ((cap * 8 + 255) / 256) * 256);
         const uint64_t thr = max_hash ? max_hash : ~0ull;
+        check_dna_ksize(ksize);
         hip_check(hipMemsetAsync(d_result, 0, 16, st), "memset");
         hip_check(sketch_dna_launch(d_seq, len, ksize, seed, thr, d_raw, (unsigned long long*)d_result, cap, st), "sketch_dna");
         unsigned long long kept = 0;
@@ -910,6 +912,7 @@ uint64_t smgpu_sort_unique_raw(uint64_t* d_keys, uint64_t n, uint64_t* d_out, ui
 void smgpu_sketch_dna_kernel_raw(const uint8_t* d_seq, uint64_t len, uint32_t ksize, uint64_t seed, uint64_t max_hash,
                                  uint64_t* d_out, uint64_t cap, uint64_t* d_count, void* stream) {
     landing_void([&] {
+        check_dna_ksize(ksize);
         hip_check(sketch_dna_launch(d_seq, len, ksize, seed, max_hash ? max_hash : ~0ull, d_out,
                                     (unsigned long long*)d_count, cap, (hipStream_t)stream), "sketch_dna");
     });
@@ -924,7 +927,8 @@ uint64_t smgpu_sketch_residues_kernels_raw(const uint8_t* d_seq, uint64_t len, u
     return landing<uint64_t>([&]() -> uint64_t {
         if (hash_function < HF_PROTEIN || hash_function > HF_HP) throw err_internal("hash_function must be protein, dayhoff or hp");
         const uint64_t n_aa = translate ? translated_bytes(len) : len;
-        if (n_aa > aa_capacity) throw err_internal("d_aa is too small: " + std::to_string(n_aa) + " residues");
+        // (the window kernel reads d_aa in aligned 8-byte words: the capacity has to cover the last word it touches)
+        if (((n_aa + 7) & ~7ull) > aa_capacity) throw err_internal("d_aa is too small: " + std::to_string(n_aa) + " residues need " + std::to_string((n_aa + 7) & ~7ull) + " bytes");
         hipStream_t st = (hipStream_t)stream;
         if (translate) hip_check(translate_launch(d_seq, len, hash_function, d_aa, st), "translate");
         else hip_check(residues_launch(d_seq, len, hash_function, d_aa, st), "residues");
@@ -1440,7 +1444,8 @@ void smgpu_compare_angular_all_pairs(const SourmashKmerMinHash* const* mhs, uint
             hip_check(hipMemsetAsync(dc.p, 0, (size_t)n * n * 4, st), "memset");
             hip_check(hipMemsetAsync(dp.p, 0, (size_t)n * n * 8, st), "memset");
             hip_check(compare_abund_launch(dh.as<uint64_t>(), da.as<uint64_t>(), doff.as<uint64_t>(), (uint32_t)n, narrow,
-                                           dc.as<uint32_t>(), dp.as<unsigned long long>(), ds.as<unsigned long long>(), st), "compare (abundance)");
+                                           dc.as<uint32_t>(), dp.as<unsigned long long>(), ds.as<unsigned long long>(), st, offsets.empty() ? 0 : offsets.back()),
+                      "compare (abundance)");
             HostXfer::get().device_to_host(prod.data(), dp.p, (size_t)n * n * 8, st);
             hip_check(hipMemcpyAsync(sq.data(), ds.p, n * 8, hipMemcpyDeviceToHost, st), "D2H");
             hip_check(hipStreamSynchronize(st), "sync");
@@ -1461,6 +1466,14 @@ void smgpu_compare_abund_raw(const uint64_t* d_hashes, const uint64_t* d_abunds,
     landing_void([&] {
         hip_check(compare_abund_launch(d_hashes, d_abunds, d_offsets, n, narrow, d_common, (unsigned long long*)d_prod,
                                        (unsigned long long*)d_sumsq, (hipStream_t)stream), "compare (abundance)");
+    });
+}
+
+void smgpu_compare_abund_raw_n(const uint64_t* d_hashes, const uint64_t* d_abunds, const uint64_t* d_offsets, uint32_t n, uint64_t total_hashes,
+                               bool narrow, uint32_t* d_common, uint64_t* d_prod, uint64_t* d_sumsq, void* stream) {
+    landing_void([&] {
+        hip_check(compare_abund_launch(d_hashes, d_abunds, d_offsets, n, narrow, d_common, (unsigned long long*)d_prod,
+                                       (unsigned long long*)d_sumsq, (hipStream_t)stream, total_hashes), "compare (abundance)");
     });
 }
 

@@ -298,17 +298,21 @@ hipError_t compare_num_launch(const uint64_t* d_hashes, const uint64_t* d_offset
 
 hipError_t compare_abund_launch(const uint64_t* d_hashes, const uint64_t* d_abunds, const uint64_t* d_offsets, uint32_t n,
                                 bool narrow, uint32_t* d_common, unsigned long long* d_prod, unsigned long long* d_sumsq,
-                                hipStream_t stream) {
+                                hipStream_t stream, uint64_t total_known) {
     if (n == 0) return hipSuccess;
     // Round 5: the sums come from joins of per-block lists sorted by hash (abund_pairs.hip: work grows with the MATCHES, not with
     // pairs x lengths).  SMG_COMPARE_ABUND=walk keeps the per-pair walk below (tests run both against the oracle); it also serves
     // collections of 2^32 elements or more.
     static const bool walk_only = [] { const char* e = getenv("SMG_COMPARE_ABUND"); return e && !strcmp(e, "walk"); }();
     if (!walk_only) {
-        uint64_t total = 0;
-        hipError_t et = hipMemcpyAsync(&total, d_offsets + n, 8, hipMemcpyDeviceToHost, stream);
-        if (et == hipSuccess) et = hipStreamSynchronize(stream);
-        if (et != hipSuccess) return et;
+        // the number of elements sizes the lists: callers that packed the collection pass it; the raw entry point without it reads
+        // offsets[n] back, which BLOCKS the caller until the stream has drained (documented in the header)
+        uint64_t total = total_known;
+        if (total == 0) {
+            hipError_t et = hipMemcpyAsync(&total, d_offsets + n, 8, hipMemcpyDeviceToHost, stream);
+            if (et == hipSuccess) et = hipStreamSynchronize(stream);
+            if (et != hipSuccess) return et;
+        }
         const hipError_t ej = abund_pairs_launch(d_hashes, d_abunds, d_offsets, n, total, narrow, d_common, d_prod, stream);
         if (ej == hipSuccess) {
             hipLaunchKernelGGL(ext_rows_kernel, dim3(n < 4096u ? n : 4096u), dim3(256), 0, stream, d_abunds, d_offsets, n, d_common, d_prod, d_sumsq);

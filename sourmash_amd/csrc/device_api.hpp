@@ -81,7 +81,7 @@ hipError_t compare_num_launch(const uint64_t* d_hashes, const uint64_t* d_offset
 // narrow: every abundance fits 32 bits (one v_mad_u64_u32 per common hash instead of a 64 x 64 product).
 hipError_t compare_abund_launch(const uint64_t* d_hashes, const uint64_t* d_abunds, const uint64_t* d_offsets, uint32_t n,
                                 bool narrow, uint32_t* d_common, unsigned long long* d_prod, unsigned long long* d_sumsq,
-                                hipStream_t stream);
+                                hipStream_t stream, uint64_t total = 0);
 
 // abund_pairs.hip: the same two matrices (diagonals excluded: the caller's row kernel writes them) from joins of per-block lists
 // sorted by hash; scratch from the library's arena.  hipErrorNotSupported: 2^32 elements or more -- the caller keeps the walk.

@@ -24,6 +24,15 @@
 
 namespace smg {
 
+// A DNA ksize the device at hand cannot take (sketch_words.hip: the long-k kernel's window lives in LDS) is refused in words, at
+// the entry points, instead of surfacing as a bare "invalid value" from a launch.
+inline void check_dna_ksize(uint32_t k) {
+    const uint32_t max_k = sketch_dna_max_k();
+    if (k > max_k)
+        throw err_internal("ksize " + std::to_string(k) + " is longer than the longest DNA k-mer this device's LDS holds (" + std::to_string(max_k) + ")");
+}
+
+
 inline void hip_check(hipError_t e, const char* what) {
     if (e != hipSuccess)
         throw err_internal(std::string("HIP failure in ") + what + ": " + hipGetErrorString(e));
@@ -143,6 +152,7 @@ class DeviceCtx {
         upload_seq(seq, len);
         out_.reserve(nk * 8, stream_);
         hip_check(hipMemsetAsync(out_.p, 0, nk * 8, stream_), "memset");
+        check_dna_ksize(k);
         hip_check(kmer_hashes_launch(seq_.as<uint8_t>(), len, k, seed, out_.as<uint64_t>(), nk, stream_), "kmer_hashes");
         out.resize(nk);
         hip_check(hipMemcpyAsync(out.data(), out_.p, nk * 8, hipMemcpyDeviceToHost, stream_), "D2H");

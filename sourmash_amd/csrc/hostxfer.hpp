@@ -16,6 +16,7 @@
 #include <emmintrin.h>          // streaming stores; every other host (an aarch64 ROCm node) takes the memcpy path below
 #endif
 #include <sched.h>
+#include <unistd.h>
 #include <sys/mman.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -174,13 +175,17 @@ class HostXfer {
     // worker k; the caller takes share 0 and waits for the others.  (One job at a time: callers hold the device context's lock.)
     class Pool {
       public:
-        explicit Pool(unsigned n) {
+        explicit Pool(unsigned n) : owner_(getpid()) {
             for (unsigned k = 1; k < n; ++k) threads_.emplace_back([this, k] { loop(k); });
         }
         unsigned size() const { return (unsigned)threads_.size() + 1; }
         template <class F>
         void run(F&& share) {                                       // share(k) for k = 0 .. size() - 1
             if (threads_.empty()) { share(0); return; }
+            if (getpid() != owner_) {                               // a forked child: the workers exist in the parent only --
+                for (unsigned k = 0; k < size(); ++k) share(k);     // every share on the caller instead of a wait that never ends
+                return;
+            }
             std::function<void(unsigned)> f = std::forward<F>(share);
             std::lock_guard<std::mutex> one_job(run_m_);
             {
@@ -212,6 +217,7 @@ class HostXfer {
                 if (--pending_ == 0) done_.notify_one();
             }
         }
+        const pid_t owner_;
         std::mutex m_, run_m_;
         std::condition_variable start_, done_;
         std::vector<std::thread> threads_;

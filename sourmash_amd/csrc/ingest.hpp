@@ -339,6 +339,7 @@ inline void sketch_file_with(IngestWorker& w, std::vector<KmerMinHash*>& mhs, co
     uint32_t kmax = 0;
     for (auto* mh : mhs) kmax = std::max(kmax, mh->ksize);
     if (mhs.empty() || kmax == 0) return;
+    check_dna_ksize(kmax);
     hipStream_t st = w.stream;
     IngestScratch& scratch = w.scratch;
     scratch.prepare(CHUNK, kmax, st);

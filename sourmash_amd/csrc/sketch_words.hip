@@ -160,14 +160,14 @@ hipError_t sketch_dna_words_launch(const uint8_t* d_seq, uint64_t len, uint32_t 
     len += skip;
     const uint64_t n_tiles = (len + WORDS_TILE - 1) / WORDS_TILE;
     if (n_tiles == 0) return hipSuccess;
+    if (k > sketch_dna_max_k()) return hipErrorInvalidValue;      // (the host entry points say so in words before they get here)
     const WordsGeom g = words_geometry(k);
-    if (g.lds + sizeof(uint64_t) * SK_OUT_CAP + 64 > 160u * 1024u) return hipErrorInvalidValue;   // (WORDS_MAX_K is chosen so that this holds)
-    if (g.lds > 48 * 1024) {                                     // more dynamic LDS than a kernel gets unasked: allow the most any k may need, once
+    if (g.lds > 48 * 1024) {                                     // more dynamic LDS than a kernel gets unasked: allow what the longest k of THIS device needs, once
         static std::once_flag once;
         static hipError_t allowed = hipSuccess;
         std::call_once(once, [] {
             allowed = hipFuncSetAttribute((const void*)sketch_dna_words_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          (int)words_geometry(WORDS_MAX_K).lds);
+                                          (int)words_geometry(sketch_dna_max_k()).lds);
         });
         if (allowed != hipSuccess) return allowed;
     }
@@ -178,6 +178,26 @@ hipError_t sketch_dna_words_launch(const uint8_t* d_seq, uint64_t len, uint32_t 
     return hipGetLastError();
 }
 
-uint32_t sketch_dna_max_k() { return WORDS_MAX_K; }
+// The longest k-mer the device at hand can take: the kernel's LDS (stretch, reverse complement, masks) + its static 16 KB of kept
+// hashes must fit what the device gives a workgroup (160 KB on MI355X -> WORDS_MAX_K; a 64 KB part ~ 17,000).  Asked once.
+uint32_t sketch_dna_max_k() {
+    static const uint32_t max_k = [] {
+        int dev = 0, lds = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&lds, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess || lds <= 0) {
+            (void)hipGetLastError();
+            lds = 64 * 1024;
+        }
+        const size_t room = (size_t)lds;
+        auto fits = [&](uint32_t k) { return words_geometry(k).lds + sizeof(uint64_t) * SK_OUT_CAP + 64 <= room; };
+        uint32_t lo = 16, hi = WORDS_MAX_K;                          // the largest k in [16, WORDS_MAX_K] that fits (lds grows with k)
+        if (!fits(lo)) return 0u;
+        while (lo < hi) {
+            const uint32_t mid = lo + (hi - lo + 1) / 2;
+            if (fits(mid)) lo = mid; else hi = mid - 1;
+        }
+        return lo;
+    }();
+    return max_k;
+}
 
 }  // namespace smg

@@ -190,9 +190,11 @@ def test_the_longest_kmer_the_lds_holds(sm):
     want = oracle.sketch_dna_bulk(s, 60_000, scaled=2, nthreads=8)
     assert len(want) > 3000 and np.array_equal(mh._mins_array(), want)
     mh = sm.MinHash(0, 60_001, scaled=2)
-    with pytest.raises(Exception):
+    with pytest.raises(Exception, match="longest DNA k-mer this device"):       # said in words at the entry point, per-record call as well
         mh.add_sequence_buffer(s)
         len(mh)                                                  # (buffers may be hashed when the sketch is next looked at)
+    with pytest.raises(Exception, match="longest DNA k-mer this device"):
+        sm.MinHash(0, 60_001, scaled=2).add_sequence(s.decode() if isinstance(s, (bytes, bytearray)) else bytes(s).decode(), True)
 
 
 def test_abundance_and_num(sm):

@@ -48,10 +48,11 @@ def main():
     sk = synth_sketches(n, seed=1234)
     h, off = smd.pack_csr(sk, device=dev)
     ab = (h % 7 + 1) * ((h >> 3) % 11 + 1)
+    tot = int(off[-1].item())               # the caller of a raw device entry point knows its array sizes
     prod = torch.zeros((n, n), dtype=torch.int64, device=dev)
     sq = torch.zeros((n,), dtype=torch.int64, device=dev)
     for narrow in (True, False):
-        ms = timed(lambda: be.rustcall(lib.smgpu_compare_abund_raw, p(h), p(ab), p(off), n, narrow, p(common), p(prod), p(sq), s()))
+        ms = timed(lambda: be.rustcall(lib.smgpu_compare_abund_raw_n, p(h), p(ab), p(off), n, tot, narrow, p(common), p(prod), p(sq), s()))
         out["abund_c3_%s" % ("u32" if narrow else "u64")] = {"sketches": n, "hashes": int(off[-1].item()), "pairs": pairs, "ms": round(ms, 3),
                                                             "pairs_per_s": round(pairs / (ms * 1e-3), 1),
                                                             "prod_checksum": int(prod.sum().item())}
@@ -61,7 +62,8 @@ def main():
     sk = [np.unique(np.concatenate([core, rng.integers(1, 2**54, 3000, dtype=np.int64).astype(np.uint64)])) for _ in range(n)]
     h, off = smd.pack_csr(sk, device=dev)
     ab = (h % 7 + 1) * ((h >> 3) % 11 + 1)
-    ms = timed(lambda: be.rustcall(lib.smgpu_compare_abund_raw, p(h), p(ab), p(off), n, True, p(common), p(prod), p(sq), s()))
+    tot = int(off[-1].item())               # the caller of a raw device entry point knows its array sizes
+    ms = timed(lambda: be.rustcall(lib.smgpu_compare_abund_raw_n, p(h), p(ab), p(off), n, tot, True, p(common), p(prod), p(sq), s()))
     out["abund_core_u32"] = {"sketches": n, "hashes": int(off[-1].item()), "pairs": pairs, "ms": round(ms, 3), "pairs_per_s": round(pairs / (ms * 1e-3), 1),
                              "prod_checksum": int(prod.sum().item()), "min_common": int((common + torch.eye(n, dtype=torch.int32, device=dev) * 10**6).min().item())}
     print(json.dumps(out))
