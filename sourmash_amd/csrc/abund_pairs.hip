@@ -454,8 +454,11 @@ hipError_t abund_pairs_launch(const uint64_t* d_hashes, const uint64_t* d_abunds
     AP_TRY(hipGetLastError());
     // hash slices per tile: enough work items to fill the chip twice over when the tiles alone do not (SMG_ABUND_SLICES overrides)
     static const uint32_t z_env = [] { const char* e = getenv("SMG_ABUND_SLICES"); return e ? (uint32_t)atoi(e) : 0u; }();
-    uint32_t Z = 1;
-    while (Z < (uint32_t)AP_ZMAX && tiles * Z < 1024) Z *= 2;          // (C3, 136 tiles: 3.16 / 2.94 / 2.60 / 2.45 / 2.55 ms at 1 / 2 / 4 / 8 / 16 slices)
+    // ~2.5 workgroups per CU, and an ODD count: C3 (136 tiles, round 6) 1.49 / 1.19 / 1.28 / 1.18 / 1.28 / 1.21 / 1.27 ms for the call at
+    // 2 / 3 / 4 / 5 / 6 / 7 / 8 slices -- with an even count the slices of one tile sit on workgroup ids that differ by less than 8 and
+    // so on different XCDs at the same moment, all adding into the same output tile through eight L2s
+    uint32_t Z = tiles >= 640 ? 1u : (uint32_t)((640 + tiles - 1) / tiles) | 1u;
+    if (Z > (uint32_t)AP_ZMAX - 1u) Z = (uint32_t)AP_ZMAX - 1u;
     if (z_env >= 1 && z_env <= (uint32_t)AP_ZMAX) Z = z_env;
     // (initialised once, whichever host thread comes first: a function-local static's initialiser is serialised by the language)
     static const int attr = [] {
