@@ -62,7 +62,7 @@ PMC_GATHER_FILE = _newest("profiles/r06_gather_pmc.txt", "profiles/r05_gather_pm
 PMC_COMPARE_FILE = _newest("profiles/r04_compare_pmc.txt", "profiles/r03_compare_pmc.txt")
 COMPARE_BITS_SOURCES = ["bitindex.hip"]
 SKETCH_SOURCES = ["sketch.hip", "sketch_kernel.hpp", "kmer_core.hpp", "murmur3.hpp"]
-GATHER_SOURCES = ["gather.hip", "overlap.hip", "gather_parts.hpp", "qindex.hpp"]
+GATHER_SOURCES = ["gather.hip", "gather_build.hip", "overlap.hip", "gather_parts.hpp", "qindex.hpp"]
 # the launch the sketch counters were taken on: the default C2 batch of the round that took them (round 6: the literal 1,000 records)
 PMC_C2_INPUT_BYTES = 10_000_001_000 if "r06" in PMC_FILE else 9_990_000_999
 N_SIMDS = 1024

@@ -1,4 +1,4 @@
-// Device-resident min-set-cover gather (gather.hip).  Raw device pointers; owns its index and counters.
+// Device-resident min-set-cover gather (gather_build.hip: the index; gather.hip: the rounds).  Raw device pointers; owns its index and counters.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

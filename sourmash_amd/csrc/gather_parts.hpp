@@ -1,9 +1,13 @@
-// gather_parts.hpp -- what gather.hip (index build, rounds, resident loop) and overlap.hip (the streaming walks over a
-// collection: the overlap pass of search / prefetch, and pass 1 + 2a of the index build) share.  Internal to the two units.
+// gather_parts.hpp -- what gather_build.hip (the index build), gather.hip (rounds, resident loop) and overlap.hip (the streaming walks over a
+// collection: the overlap pass of search / prefetch, and pass 1 + 2a of the index build) share.  Internal to the three units.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stddef.h>
+#include <chrono>
+#include "gather_api.hpp"
+#include "arena.hpp"
+#include "qindex.hpp"
 
 namespace smg {
 
@@ -35,5 +39,38 @@ hipError_t build_stage_launch(const uint64_t* Q, uint64_t nq, const uint32_t* T,
 void lean_table_geometry(uint64_t nq, uint64_t q_max, double mean_row, uint32_t* shift, uint32_t* buckets);
 struct LeanPlan { uint32_t bpr, n_ranges, qcap, rows_cap; };
 LeanPlan build_lean_plan(uint64_t nq, uint32_t buckets, double mean_row);
+
+// ---- shared by gather_build.hip and gather.hip ----
+__device__ __forceinline__ unsigned long long wave_max(unsigned long long k) {
+    for (int off = 32; off > 0; off >>= 1) {
+        const unsigned long long o = __shfl_down(k, off);
+        k = o > k ? o : k;
+    }
+    return k;
+}
+
+static inline QIndex qindex_of(const GatherDev& g) { return QIndex{g.q_padded, g.nq, g.q_table, g.q_shift, g.q_max, g.q_rec}; }
+
+
+
+// Owned buffers and build scratch come from the arena (arena.hpp): blocks the library keeps between builds, so that a
+// rebuild of the same shape makes no driver call.  (Round 2 used hipMallocAsync with a raised release threshold; on the
+// benchmark host that still cost 175 ms per build against 6.9 ms of kernels -- VERDICT r02.)
+template <class T>
+static inline hipError_t own_alloc(GatherDev& g, T** p, size_t bytes, hipStream_t user = nullptr) {
+    return arena_alloc((void**)p, bytes, user ? user : g.stream);
+}
+
+static inline uint64_t host_ns() {
+    return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+static inline hipError_t timed_sync(GatherDev& g, hipStream_t stream) {
+    const uint64_t t0 = host_ns();
+    const hipError_t e = hipStreamSynchronize(stream);
+    g.build_sync_wait_ns += host_ns() - t0;
+    g.build_syncs++;
+    return e;
+}
+
 
 }  // namespace smg

@@ -5,7 +5,7 @@
 //                           (src/core/src/index/linear.rs:52-113, src/sourmash/index/__init__.py:115-170,241-256 walk the rows one by
 //                           one) -- overlap_lean_kernel<0> for collections that give every CU a few dozen rows, stream_lookup_kernel
 //                           below that, the one-wave-per-row kernel of pair_ops.hip for what neither can take
-//   build_stage_launch      the same walk as pass 1 + 2a of the gather index build (gather.hip): overlap_lean_kernel<2> also
+//   build_stage_launch      the same walk as pass 1 + 2a of the gather index build (gather_build.hip): overlap_lean_kernel<2> also
 //                           leaves every database hash's query position and the postings, staged by window
 //
 // Split from gather.hip in round 5 (Weak 10), with the superseded forms removed: round 3's overlap_wide_kernel and its

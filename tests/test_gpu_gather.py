@@ -145,7 +145,7 @@ def test_search_and_prefetch_vs_oracle(sm):
 
 @pytest.mark.parametrize("build", ["atomic", "ranges", "ranges-direct"])
 def test_synthetic_gather_vs_oracle(sm, build, monkeypatch):
-    # the builders of the inverted index (csrc/gather.hip: one atomic per element / range-partitioned with the
+    # the builders of the inverted index (csrc/gather_build.hip: one atomic per element / range-partitioned with the
     # histogram in LDS, postings filled through the two-level partition or by direct stores) -- the size heuristic
     # would pick "atomic" for a database this small
     monkeypatch.setenv("SMG_GATHER_BUILD", build.split("-")[0])
@@ -201,7 +201,7 @@ def test_range_builder_postings_are_exact(fill, pass1, monkeypatch):
 
 
 def test_index_build_of_many_rows_takes_the_lean_pass(monkeypatch):
-    """From 64 rows per CU up the builder's pass 1 is the lean streaming kernel by default (gather.hip: gather_build_body): 17,000
+    """From 64 rows per CU up the builder's pass 1 is the lean streaming kernel by default (gather_build.hip: gather_build_body): 17,000
     ragged rows, the result the oracle's, every counter zero at the end (every posting in exactly one list), and the same
     again with pass 1 by lookups."""
     import torch
