@@ -296,7 +296,7 @@ size_t fastx_temp_bytes(uint64_t max_chunk) {
 // d_state: unused since round 6 (the per-byte states are never materialised); kept in the signature for the callers' scratch layout
 hipError_t fastx_compact_launch(const uint8_t* d_raw, uint64_t n, int fastq, uint8_t* d_carry, uint8_t* d_state,
                                 uint8_t* d_out, unsigned long long* d_n_out, unsigned long long* d_n_records,
-                                void* d_temp, size_t temp_bytes, hipStream_t stream) {
+                                void* d_temp, size_t temp_bytes, hipStream_t stream, bool last_piece) {
     (void)d_state;
     if (n == 0) return hipMemsetAsync(d_n_out, 0, 8, stream);
     if (temp_bytes < fastx_temp_bytes(n)) return hipErrorInvalidValue;
@@ -312,7 +312,7 @@ hipError_t fastx_compact_launch(const uint8_t* d_raw, uint64_t n, int fastq, uin
     hipLaunchKernelGGL(fx_scatter_kernel, dim3((unsigned)n_blocks), dim3(FX_THREADS), 0, stream, d_raw, n, fastq, d_carry, (const uint8_t*)entry,
                        (const unsigned long long*)block_off, d_out);
     const hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
+    if (e != hipSuccess || last_piece) return e;
     return hipMemcpyAsync(d_carry, d_carry + 2, 2, hipMemcpyDeviceToDevice, stream);
 }
 

@@ -582,7 +582,7 @@ inline void sketch_slices_batched(IngestWorker& w, const std::vector<InflatedSli
     if (idx.empty()) return;
     // (the parser's scratch for the longest file of the batch; the worker's own chunk buffers stay at their 4 MiB)
     const size_t parse_temp_bytes = fastx_temp_bytes(max_len);
-    AsyncBuf parse_state((size_t)max_len + 64, st), parse_temp(parse_temp_bytes, st);
+    AsyncBuf parse_temp(parse_temp_bytes, st);
     (void)kmax;
     constexpr size_t HALO = 256;
     // layout: per file a region of the compacted-bytes block, 32 bytes of scalars, and per sketch an output region + 16 bytes of counts
@@ -619,9 +619,9 @@ inline void sketch_slices_batched(IngestWorker& w, const std::vector<InflatedSli
         const size_t i = idx[j];
         uint8_t* sc = small.as<uint8_t>() + j * per_file_scalars;
         uint8_t* cp = comp.as<uint8_t>() + slot[j].comp_off;
-        hip_check(fastx_compact_launch(static_cast<const uint8_t*>(slices[i].p), slices[i].len, fastq[j], sc, parse_state.as<uint8_t>(), cp,
+        hip_check(fastx_compact_launch(static_cast<const uint8_t*>(slices[i].p), slices[i].len, fastq[j], sc, nullptr, cp,
                                        reinterpret_cast<unsigned long long*>(sc + 8), reinterpret_cast<unsigned long long*>(sc + 16),
-                                       parse_temp.p, parse_temp_bytes, st), "fastx");
+                                       parse_temp.p, parse_temp_bytes, st, true), "fastx");
         // the signature's ksizes in one pass where the set has a fused kernel (sketch_multi.hip: 21 / 31 / 51), else a launch each
         bool fused = false;
         {
