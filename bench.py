@@ -1197,9 +1197,19 @@ def ksize_extras(extra, torch, np, dev, smd, args):
         torch.cuda.synchronize()
         ms = float(np.median([a.elapsed_time(b) for a, b in evs]))
         blocks = k // 16 + (1 if k % 16 else 0)
+        # what binds these kernels is VALU issue, not HBM: instructions per k-mer as counted (profiles/r05_long_k_pmc.txt: k = 88, 128,
+        # 200; profiles/r06_pmc.txt: k = 31) or, for the run-time-k kernel at other k, from its two counted points (41.1 per 16 bytes
+        # of key), priced at the 3.74-cycle instruction mix of profiles/valu_mix_sketch.json over the step's time
+        counted = {88: 264.6, 128: 414.2, 200: 599.2}
+        insts = counted.get(k) if k in counted else (414.2 + 41.1 * (k - 128) / 16.0 if k >= 89 else None)
+        valu = None
+        if insts is not None:
+            valu = {"insts_per_kmer": round(insts, 1), "counted": k in counted,
+                    "issue_busy_frac": round(3.74 * insts * (n / 64.0) / (ms * 1e-3 * 2.4e9 * N_SIMDS), 3),
+                    "from": "profiles/r05_long_k_pmc.txt (SQ_INSTS_VALU per dispatch), over the whole step's time (kernel + sort + unique)"}
         out["k%d" % k] = {"ms": round(ms, 3), "Gbase_per_s": round(n / (ms * 1e-3) / 1e9, 1), "hashes": int(h.numel()),
                           "kernel": "register window (unrolled)" if k <= 88 else "run-time k (sketch_words.hip)",
-                          "cpu_port": cpu_port,
+                          "cpu_port": cpu_port, "valu": valu,
                           "roofline": hbm_roofline(n + 8 * int(h.numel()), ms, "1 B per base + 8 B per kept hash; whole step (kernel + sort + unique); "
                                                    "the kernels are bound by instruction issue: MurmurHash3 is 4 64-bit multiplies per 16-byte "
                                                    "block of the key, %d blocks at this k" % blocks)}
