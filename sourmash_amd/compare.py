@@ -22,7 +22,7 @@ import itertools
 import numpy as np
 
 from ._lowlevel import lib
-from .utils import rustcall
+from .utils import objptr_array, rustcall
 
 __all__ = ["compare_all_pairs", "compare_serial", "compare_parallel", "compare_serial_containment",
            "compare_serial_max_containment", "compare_serial_avg_containment", "common_matrix", "num_matrix", "angular_matrix",
@@ -49,7 +49,7 @@ class _Views:
             self.ptrs = (C.c_void_p * max(n, 1))()
             self.params = np.zeros((max(n, 1), 8), dtype=np.uint64)
             if n:
-                sp = (C.c_void_p * n)(*[s._get_objptr() for s in self.sigs])
+                sp, _alive = objptr_array(self.sigs)
                 rustcall(lib.smgpu_signatures_sketch_views, sp, n, self.ptrs, self.params.ctypes.data_as(C.c_void_p))
             self.params = self.params[:n]
         p = self.params
@@ -84,7 +84,7 @@ class _Handles:
     def __init__(self, mhs):
         self.keep = list(mhs)
         self.n = len(self.keep)
-        self.ptrs = (C.c_void_p * max(self.n, 1))(*[mh._get_objptr() for mh in self.keep])
+        self.ptrs, self._ptrs_alive = objptr_array(self.keep)
 
 
 _PINNED_FROM = 32 << 20         # result arrays from this size up live in page-locked memory (SMG_PINNED_RESULTS=0: never)

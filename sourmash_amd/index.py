@@ -24,7 +24,7 @@ from ._lowlevel import lib
 from .minhash import flatten_and_downsample_num, flatten_and_downsample_scaled, flatten_and_intersect_scaled
 from .search import calc_threshold_from_bp, make_containment_query, make_jaccard_search_query
 from .signature import SourmashSignature, load_signatures_from_json, save_signatures_to_json
-from .utils import RustObject, decode_str, rustcall
+from .utils import RustObject, decode_str, objptr_array, rustcall
 
 __all__ = ["IndexSearchResult", "Collection", "SketchSet", "select_signature", "Index", "LinearIndex", "CounterGather"]
 
@@ -136,7 +136,7 @@ class SketchSet(RustObject):
 
     def __init__(self, minhashes):
         self._keep = list(minhashes)
-        ptrs = (C.c_void_p * max(len(self._keep), 1))(*[mh._get_objptr() for mh in self._keep])
+        ptrs, _alive = objptr_array(self._keep)
         self._objptr = rustcall(lib.smgpu_sketchset_new, ptrs, len(self._keep))
 
     @classmethod

@@ -11,6 +11,7 @@ rm -rf "$ROOT/_refrun"; mkdir -p "$ROOT/_refrun"
 cp -r "$ROOT"/tests/refcompat/shim/* "$ROOT/_refrun/"
 cp -r "$REF/test-data" "$ROOT/_refrun/test-data"
 for m in $MODS; do cp "$REF/$m" "$ROOT/_refrun/"; done
+chmod -R u+w "$ROOT/_refrun"     # (the reference tree is read-only: a test that rewrites a staged fixture would fail on its permissions)
 trap 'rm -rf "$ROOT/_refrun"' EXIT
 if [ -n "$SMG_REFRUN_LOCAL" ]; then      # collection / host-only check in the build container (no GPU: device calls fail)
   cd "$ROOT/_refrun" && PYTHONPATH=$ROOT python -m pytest -q -p no:cacheprovider --tb=short $MODS
