@@ -428,6 +428,18 @@ SMG_HD bool valid_dynamic_header(const uint32_t* words, uint64_t bit, uint64_t e
 // records of a run of the chain.)
 constexpr uint32_t REC_LITERAL = 0x80000000u, REC_STORED = 0x40000000u;
 
+// set bits of m below bit `lane` (on the device: below the calling lane -- v_mbcnt, no lane-mask constant to keep or to spill)
+SMG_HD uint32_t popc_below(uint64_t m, uint32_t lane) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    (void)lane;
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+#else
+    uint32_t n = 0;
+    for (uint64_t b = m & ((1ull << lane) - 1ull); b; b &= b - 1) ++n;
+    return n;
+#endif
+}
+
 SMG_HD uint32_t popc64(uint64_t m) {
 #if defined(__HIP_DEVICE_COMPILE__)
     return (uint32_t)__popcll(m);
@@ -463,7 +475,7 @@ struct RecordSink {
             if ((mask >> lane) & 1u) {
                 const uint32_t x = L[slot];
                 acc[slot] += x & 0x80000000u ? 1u : x;
-                if (rec) rec[n + popc64(mask & ((1ull << lane) - 1ull))] = x & 0x80000000u ? x : (((D[slot] - 1u) << 9) | x);
+                if (rec) rec[n + popc_below(mask, lane)] = x & 0x80000000u ? x : (((D[slot] - 1u) << 9) | x);
             }
         }
         n += k;
