@@ -205,11 +205,11 @@ __global__ __launch_bounds__(1024) void fx_offsets_kernel(const BlockSum* __rest
     const uint32_t before = threadIdx.x ? st[threadIdx.x - 1] : 0u;
     uint32_t e = fastq ? (uint32_t)((carry[0] + before) & 3u) : (before ? before : (uint32_t)carry[0]);
     unsigned long long kept = 0, recs = 0;
-    for (unsigned i = lo; i < hi; ++i) {
-        const BlockSum s = sums[i];
+    for (unsigned i = lo; i < hi; ++i) {                          // (the summary is indexed in memory: a local copy indexed by the phase lands in scratch)
+        const BlockSum* s = sums + i;
         entry[i] = (uint8_t)e;
-        if (fastq) { kept += s.cnt[e & 3u]; recs += s.hdr[e & 3u]; e = (e + s.starts) & 3u; }
-        else { kept += s.cnt[0] + (e == 1u ? s.cnt[1] : 0u); recs += s.hdr[0]; e = s.last_kind ? s.last_kind : e; }
+        if (fastq) { kept += s->cnt[e & 3u]; recs += s->hdr[e & 3u]; e = (e + s->starts) & 3u; }
+        else { const uint32_t lk = s->last_kind; kept += s->cnt[0] + (e == 1u ? s->cnt[1] : 0u); recs += s->hdr[0]; e = lk ? lk : e; }
     }
     if (hi == n_blocks && lo < hi) {                             // the thread that owns the last block: the carry
         carry_out[0] = (uint8_t)e;
@@ -225,10 +225,10 @@ __global__ __launch_bounds__(1024) void fx_offsets_kernel(const BlockSum* __rest
     }
     unsigned long long run = threadIdx.x ? part[threadIdx.x - 1] : 0;
     for (unsigned i = lo; i < hi; ++i) {
-        const BlockSum s = sums[i];
+        const BlockSum* s = sums + i;
         const uint32_t ei = entry[i];
         block_off[i] = run;
-        run += fastq ? s.cnt[ei & 3u] : s.cnt[0] + (ei == 1u ? s.cnt[1] : 0u);
+        run += fastq ? s->cnt[ei & 3u] : s->cnt[0] + (ei == 1u ? s->cnt[1] : 0u);
     }
     if (threadIdx.x == 1023) *total = part[1023];
     // records: a sum over the threads through the same scratch
