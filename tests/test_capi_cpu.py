@@ -169,3 +169,19 @@ def test_gpu_only_operations_fail_loudly_without_a_device(sm):
     with pytest.raises(RuntimeError):
         from sourmash_amd import device as smd
         smd.synth_dna(10)
+
+
+def test_handle_arrays_of_object_lists(sm):
+    "utils.objptr_array: what SketchSet / compare hand to the library for a list of objects -- the handles in order, a closed object refused"
+    from sourmash_amd.utils import objptr_array
+    mhs = [sm.MinHash(0, 21 + i, scaled=1000) for i in range(257)]
+    arr, keep = objptr_array(mhs)
+    assert len(arr) == 257 and all(int(arr[i]) == mhs[i]._objptr for i in range(257))
+    assert keep.dtype == np.uintp and keep.ctypes.data == C.addressof(arr)             # the C array is a view of the numpy block
+    empty, _ = objptr_array([])
+    assert len(empty) == 1 and not empty[0]                                            # (callers pass n = 0 beside it)
+
+    class Closed:
+        _objptr = 0
+    with pytest.raises(RuntimeError, match="closed"):
+        objptr_array(mhs[:3] + [Closed()])
