@@ -68,7 +68,7 @@ inline void CollectionLoader::run_device(hipStream_t st, DeviceResult& out) {
         if (w.zip) { const ZipMember* m = w.zip->find(w.member); item_bytes[i] = m && m->method == 0 ? m->comp_size : 0; }
         else { struct stat sb; item_bytes[i] = stat(w.path.c_str(), &sb) == 0 ? (uint64_t)sb.st_size : 0; }
     }
-    constexpr uint64_t GROUP_BYTES = (uint64_t)256 << 20;
+    constexpr uint64_t GROUP_BYTES = (uint64_t)128 << 20;          // (two groups are under way at a time: see the workers below)
     for (size_t i = 0; i < n_items;) {
         size_t j = i;
         uint64_t bytes = 0;
@@ -80,10 +80,12 @@ inline void CollectionLoader::run_device(hipStream_t st, DeviceResult& out) {
     std::vector<std::unique_ptr<AsyncBuf>> value_blocks(groups.size());
     // (pinning a quarter of a gigabyte costs tens of milliseconds: the staging buffer outlives the call, like the ingest's;
     //  callers hold the context's mutex)
-    static PinnedBuf& host = *new PinnedBuf();
+    static PinnedBuf& host_a = *new PinnedBuf();
+    static PinnedBuf& host_b = *new PinnedBuf();
     static const bool trace = getenv("SMG_SIGLOAD_TRACE") != nullptr;
     auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    for (size_t g = 0; g < groups.size(); ++g) {
+    // one group, start to finish, on the stream and the staging buffer of the worker that took it
+    auto do_group = [&](size_t g, hipStream_t st, PinnedBuf& host) {
         const size_t i0 = groups[g].i0, i1 = groups[g].i1, n = i1 - i0;
         const double t_g0 = now();
         double t_read = 0, t_inflate = 0, t_spans = 0, t_parse = 0;
@@ -124,7 +126,7 @@ inline void CollectionLoader::run_device(hipStream_t st, DeviceResult& out) {
         std::vector<size_t> live;                                     // group-relative numbers of the documents on the device path
         std::vector<GunzipMember> gm;
         for (size_t k = 0; k < n; ++k) if (have[k]) { gm.push_back(ms[k]); live.push_back(k); } else by_host[i0 + k] = 1;
-        if (gm.empty()) continue;
+        if (gm.empty()) return;
         memset(host.p + total, 0, GUNZIP_PAD);
         AsyncBuf d_files((size_t)total + GUNZIP_PAD + 64, st);
         hip_check(hipMemcpyAsync(d_files.p, host.p, (size_t)total + GUNZIP_PAD, hipMemcpyHostToDevice, st), "H2D");
@@ -139,7 +141,7 @@ inline void CollectionLoader::run_device(hipStream_t st, DeviceResult& out) {
             docs.push_back(SjDoc{gm[q].out_off, gm[q].out_len});
             doc_item.push_back(live[q]);
         }
-        if (docs.empty()) continue;
+        if (docs.empty()) return;
         // ---- where the arrays are ----
         AsyncBuf d_docs(docs.size() * sizeof(SjDoc), st), d_spans(docs.size() * SJ_MAX_SPANS * sizeof(SjSpan), st), d_flags(docs.size() * 4, st);
         hip_check(hipMemcpyAsync(d_docs.p, docs.data(), docs.size() * sizeof(SjDoc), hipMemcpyHostToDevice, st), "H2D");
@@ -246,6 +248,44 @@ inline void CollectionLoader::run_device(hipStream_t st, DeviceResult& out) {
             fprintf(stderr, "[sigload] group of %zu documents (%.0f MB): %.1f ms (read %.1f, H2D + inflate %.1f [scan %.1f pass1 %.1f link %.1f pass2 %.1f finish %.1f], "
                             "arrays %.1f, numbers + remainder %.1f, metadata %.1f)\n", n, total / 1e6, now() - t_g0, t_read, t_inflate, gstats.scan_ms, gstats.pass1_ms,
                     gstats.link_ms, gstats.pass2_ms, gstats.finish_ms, t_spans, t_parse, now() - t_g0 - t_read - t_inflate - t_spans - t_parse);
+    };
+    // Two groups under way at a time (round 6): a group is a chain of device passes with host steps between them -- file reads, the
+    // link of the inflater's runs, the plan of the number parser, the metadata scan -- and alone it keeps the device busy about half
+    // of its time.  The second worker has a stream and a staging buffer of its own (leaked like the first); groups are dealt from a
+    // counter; whatever a worker throws is raised here after both have stopped.
+    {
+        static hipStream_t st_b = nullptr;
+        const bool two = groups.size() >= 2;
+        if (two && !st_b) hip_check(hipStreamCreateWithFlags(&st_b, hipStreamNonBlocking), "hipStreamCreate");
+        int device = 0;
+        (void)hipGetDevice(&device);
+        std::atomic<size_t> next_g(0);
+        std::mutex err_mu;
+        std::vector<Error> errs;
+        auto worker = [&](hipStream_t ws, PinnedBuf* wh) {
+            (void)hipSetDevice(device);
+            try {
+                for (;;) {
+                    const size_t g = next_g.fetch_add(1);
+                    if (g >= groups.size()) break;
+                    do_group(g, ws, *wh);
+                }
+                hip_check(hipStreamSynchronize(ws), "sync");
+            } catch (const Error& e) {
+                std::lock_guard<std::mutex> lk(err_mu);
+                errs.push_back(e);
+                next_g.store(groups.size());                          // the other worker finishes its group and stops
+            } catch (const std::exception& e) {
+                std::lock_guard<std::mutex> lk(err_mu);
+                errs.push_back(err_internal(std::string("collection loader: ") + e.what()));
+                next_g.store(groups.size());
+            }
+        };
+        std::thread second;
+        if (two) second = std::thread(worker, st_b, &host_b);
+        worker(st, &host_a);
+        if (second.joinable()) second.join();
+        if (!errs.empty()) throw errs.front();
     }
     const double t_groups = now();
     // ---- the documents the device did not take: the host path of collection.hpp ----
