@@ -68,7 +68,9 @@ inline void CollectionLoader::run_device(hipStream_t st, DeviceResult& out) {
         if (w.zip) { const ZipMember* m = w.zip->find(w.member); item_bytes[i] = m && m->method == 0 ? m->comp_size : 0; }
         else { struct stat sb; item_bytes[i] = stat(w.path.c_str(), &sb) == 0 ? (uint64_t)sb.st_size : 0; }
     }
-    constexpr uint64_t GROUP_BYTES = (uint64_t)128 << 20;          // (two groups are under way at a time: see the workers below)
+    // (two groups are under way at a time: see the workers below.  SMG_SIGLOAD_GROUP_BYTES: tests cut small collections into many groups)
+    static const uint64_t GROUP_BYTES = [] { const char* e = getenv("SMG_SIGLOAD_GROUP_BYTES"); const long long v = e ? atoll(e) : 0;
+                                             return v >= 1024 ? (uint64_t)v : (uint64_t)128 << 20; }();
     for (size_t i = 0; i < n_items;) {
         size_t j = i;
         uint64_t bytes = 0;

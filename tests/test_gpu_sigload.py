@@ -232,3 +232,34 @@ def test_a_larger_collection_and_what_is_done_with_it(sm, tmp_path):
     common, _ = sub.compare(jaccard=False)
     want, _ = oracle.compare_all_pairs(*oracle.make_csr(sk[::10]), nthreads=8)
     assert np.array_equal(common, want)
+
+
+def test_many_groups_through_both_workers(sm, tmp_path):
+    """Round 6: groups of documents are dealt to two workers, each with a stream and a staging buffer of its own (csrc/sigload.hpp).
+    A collection cut into dozens of small groups (SMG_SIGLOAD_GROUP_BYTES, read once: a subprocess), with documents the device hands
+    back to the host scattered through it -- rows, manifest and hashes equal the host loader's, in input order, five times over."""
+    import subprocess, sys
+    from conftest import ROOT
+    rng = np.random.default_rng(41)
+    docs = []
+    for i in range(700):
+        mins = rand_mins(rng, int(rng.integers(1, 1500)))
+        if i % 97 == 5:                                             # unsorted: parsed (and re-sorted) by the host
+            shuffled = mins[::-1]
+            docs.append((sig_doc([sketch_json(shuffled, md5=md5_of(31, mins))], name=f"s{i}"), [(md5_of(31, mins), 31, "DNA", 0, 1000, len(mins), False)]))
+        elif i % 53 == 7:                                           # two sketches in one document
+            other = rand_mins(rng, 300)
+            docs.append((sig_doc([sketch_json(mins), sketch_json(other, ksize=21)], name=f"s{i}"),
+                         [(md5_of(31, mins), 31, "DNA", 0, 1000, len(mins), False), (md5_of(21, other), 21, "DNA", 0, 1000, len(other), False)]))
+        else:
+            docs.append((sig_doc([sketch_json(mins)], name=f"s{i}"), [(md5_of(31, mins), 31, "DNA", 0, 1000, len(mins), False)]))
+    z = str(tmp_path / "groups.zip")
+    write_zip(z, docs)
+    code = ("import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+            "import torch, sourmash_amd, test_gpu_sigload as t\n"
+            "for rep in range(5):\n"
+            "    dev, host = t.same_collection(sourmash_amd, %r, ksize=31, moltype='DNA')\n"
+            "    assert len(dev) == 700\n"
+            "print('ok', t.counters())\n" % (ROOT, os.path.join(ROOT, "tests"), z))
+    p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=900, env=dict(os.environ, SMG_SIGLOAD_GROUP_BYTES="65536"))
+    assert p.returncode == 0 and p.stdout.strip().startswith("ok"), (p.stdout[-1500:], p.stderr[-1500:])
